@@ -1,0 +1,161 @@
+"""Synthetic misaligned-read regions -- build-owned generator.
+
+Counter-based RNG (splitmix64 keyed by (global_seed, region_id, stream)) so that
+this container and the GPU box generate byte-identical inputs without Python's
+`random`.  A region mimics what the reference hands to its hot path for one
+target: a reference window (target interval + 200 bp flanks, utils.py:367 /
+sv_processor.py:431), the cleaned reads (utils.py:203-246), read ids in the
+`@<qname>/<1|2>_<0|1>` convention (utils.py:436-443), discordant-pair evidence
+(sv_processor.py:376-408) and a one-gene-per-window annotation (utils.py:727-773).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_C1 = np.uint64(0xBF58476D1CE4E5B9)
+_C2 = np.uint64(0x94D049BB133111EB)
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+SV_TYPES = ("del", "ins", "inv", "dup", "trl")
+
+
+def _mix(z):
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * _C1
+        z = (z ^ (z >> np.uint64(27))) * _C2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def stream_key(global_seed: int, region_id: int, stream: int) -> np.uint64:
+    with np.errstate(over="ignore"):
+        k = _mix(np.uint64(global_seed) * _GOLD + np.uint64(1))
+        k = _mix(k ^ (np.uint64(region_id) * _GOLD + np.uint64(2)))
+        k = _mix(k ^ (np.uint64(stream) * _GOLD + np.uint64(3)))
+    return np.uint64(k)
+
+
+def rand_u64(key: np.uint64, n: int, offset: int = 0) -> np.ndarray:
+    """n counter-based 64-bit values: splitmix64(key + (offset+i)*GOLD)."""
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(offset, offset + n, dtype=np.uint64) + np.uint64(1)) * _GOLD + np.uint64(key)
+    return _mix(ctr)
+
+
+def rand_bases(key, n):
+    return (rand_u64(key, n) >> np.uint64(62)).astype(np.uint8)          # codes 0..3
+
+
+def rand_below(key, n, bound):
+    # 53-bit multiply-shift; bias is irrelevant here, determinism is what matters
+    return ((rand_u64(key, n) >> np.uint64(11)).astype(np.float64) * (float(bound) / 9007199254740992.0)).astype(np.int64)
+
+
+def revcomp_codes(c):
+    return (3 - c[::-1]).astype(np.uint8)
+
+
+def codes_to_str(c) -> str:
+    return BASES[np.asarray(c, dtype=np.uint8)].tobytes().decode()
+
+
+def str_to_codes(s: str) -> np.ndarray:
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    out = lut[np.frombuffer(s.encode(), dtype=np.uint8)]
+    if (out == 255).any():
+        raise ValueError("non-ACGT base in sequence (unsupported on this path)")
+    return out
+
+
+class Region(object):
+    """One synthetic target region.
+
+    Attributes
+    ----------
+    name, chrom, start, end : target interval (BED-like); window = [start-200, end+200)
+    window    : uint8 codes, reference window (forward)
+    partners  : list of (chrom, start, end, name, codes) extra windows in genome coords
+    donor     : uint8 codes, sample haplotype the reads are drawn from
+    reads     : uint8 [N, L] codes (reference orientation, FASTQ order)
+    read_ids  : list[str]
+    sv_type   : one of SV_TYPES
+    disc_reads: dict as built by sv_processor.py:476-531
+    """
+
+    def __init__(self):
+        self.partners = []
+
+    def read_strs(self):
+        return [codes_to_str(r) for r in self.reads]
+
+    @property
+    def window_str(self):
+        return codes_to_str(self.window)
+
+
+def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int = 150, depth: int = 500,
+                sv_type: str = "del", sv_size: int | None = None, noise: float = 0.0,
+                n_reads: int | None = None) -> Region:
+    """Generate region `region_id` (config 1-3 defaults)."""
+    assert sv_type in SV_TYPES
+    r = Region()
+    r.region_id = region_id
+    r.sv_type = sv_type
+    r.name = "GENE%05d" % region_id
+    r.chrom = "%d" % (1 + region_id % 22)            # BED chrom without "chr" (sv_caller.py:917,1124)
+    flank = 200
+    r.start = 100000 + 20000 * (region_id // 22) + flank
+    r.end = r.start + (W - 2 * flank)
+    win = rand_bases(stream_key(global_seed, region_id, 0), W)
+    r.window = win
+    c = W // 2
+    if sv_size is None:
+        sv_size = 60 if sv_type == "ins" else 200
+    h = sv_size // 2
+    r.sv_size = sv_size
+    if sv_type == "del":
+        donor = np.concatenate([win[:c - h], win[c + h:]])
+    elif sv_type == "ins":
+        ins = rand_bases(stream_key(global_seed, region_id, 1), sv_size)
+        donor = np.concatenate([win[:c], ins, win[c:]])
+    elif sv_type == "inv":
+        donor = np.concatenate([win[:c - h], revcomp_codes(win[c - h:c + h]), win[c + h:]])
+    elif sv_type == "dup":
+        donor = np.concatenate([win[:c + h], win[c - h:c + h], win[c + h:]])
+    else:  # trl: left half of target window joined to right half of a partner window
+        pw = rand_bases(stream_key(global_seed, region_id, 1), W)
+        pchrom = "%d" % (1 + (region_id + 7) % 22)
+        pstart = 50000000 + 20000 * region_id
+        r.partners.append((pchrom, pstart, pstart + W, "PARTNER%05d" % region_id, pw))
+        donor = np.concatenate([win[:c], pw[c:]])
+    r.donor = donor
+    N = n_reads if n_reads is not None else (depth * W) // L
+    starts = rand_below(stream_key(global_seed, region_id, 2), N, len(donor) - L + 1)
+    idx = starts[:, None] + np.arange(L, dtype=np.int64)[None, :]
+    reads = donor[idx]
+    if noise > 0.0:
+        u = rand_u64(stream_key(global_seed, region_id, 3), N * L).reshape(N, L)
+        flip = (u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) < noise
+        delta = ((u & np.uint64(0x3FF)) % np.uint64(3)).astype(np.uint8) + np.uint8(1)  # 1..3 -> always a different base
+        reads = np.where(flip, (reads + delta) & 3, reads).astype(np.uint8)
+    r.reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    r.read_starts = starts
+    r.read_ids = ["@S:1:1:%d:%d/1_0" % (region_id, i) for i in range(N)]
+    # discordant-pair evidence normally derived from the BAM (sv_processor.py:376-408)
+    npairs = -(-depth // 50)
+    gpos = r.start - flank  # genome coordinate of window[0]
+    disc = {"disc": {}, "inv": [], "td": [], "other": []}
+    if sv_type == "inv":
+        b0, b1 = gpos + c - h, gpos + c + h
+        for i in range(npairs):
+            disc["inv"].append((b0 - 50 - i, b0 + 20 + i, 1, 1, "P%d" % i))
+    elif sv_type == "trl":
+        pchrom, pstart = r.partners[0][0], r.partners[0][1]
+        disc["disc"][pchrom] = [(gpos + c - 100 - i, pstart + c + 100 + i) for i in range(npairs)]
+    r.disc_reads = disc
+    return r

@@ -1,0 +1,590 @@
+/* TEST INFRASTRUCTURE ONLY -- see bk_oracle.h.
+ * CPU restatement of BreaKmer's hot path (olc.py, sv_assembly.py, k-mer set algebra of
+ * sv_processor.py:609-645).  Written from the reference's observable semantics; every
+ * function cites the lines it follows.  Canonicalisations P1 (int division), P2 (sorted set
+ * iteration) and P4 (fq_recs in FASTQ order) of SURVEY.md 8c are part of the definition.
+ */
+#define _GNU_SOURCE
+#include "bk_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static uint64_t g_cells = 0, g_calls = 0;
+uint64_t bko_cells(int reset) { uint64_t v = g_cells; if (reset) g_cells = 0; return v; }
+uint64_t bko_nw_calls(int reset) { uint64_t v = g_calls; if (reset) g_calls = 0; return v; }
+
+static void *xmalloc(size_t n) { void *p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "bk_oracle: OOM\n"); abort(); } return p; }
+static void *xcalloc(size_t n, size_t s) { void *p = calloc(n ? n : 1, s ? s : 1); if (!p) { fprintf(stderr, "bk_oracle: OOM\n"); abort(); } return p; }
+static void *xrealloc(void *q, size_t n) { void *p = realloc(q, n ? n : 1); if (!p) { fprintf(stderr, "bk_oracle: OOM\n"); abort(); } return p; }
+
+/* ------------------------------------------------------------------ olc.nw */
+/* olc.py:40-107: overlap DP, rows = seq2 (n), cols = seq1 (m); scores olc.py:18-20. */
+static int *nw_score = NULL; static unsigned char *nw_ptr = NULL; static size_t nw_cap = 0;
+
+void bko_nw(const char *seq1, int m, const char *seq2, int n, int *out7, char *align1, char *align2)
+{
+    size_t need = (size_t)(n + 1) * (size_t)(m + 1);
+    if (need > nw_cap) {
+        nw_cap = need;
+        nw_score = (int *)xrealloc(nw_score, nw_cap * sizeof(int));
+        nw_ptr = (unsigned char *)xrealloc(nw_ptr, nw_cap);
+    }
+    const int W = m + 1;
+    int *S = nw_score; unsigned char *P = nw_ptr;
+    for (int i = 0; i <= n; i++) { S[(size_t)i * W] = 0; P[(size_t)i * W] = 1; }   /* olc.py:48-49,56-57 */
+    for (int j = 0; j <= m; j++) { S[j] = 0; P[j] = 2; }                            /* olc.py:51-52,58-59 */
+    for (int i = 1; i <= n; i++) {                                                  /* olc.py:62-74 */
+        const int *up = S + (size_t)(i - 1) * W; int *cur = S + (size_t)i * W; unsigned char *pc = P + (size_t)i * W;
+        const char b = seq2[i - 1];
+        for (int j = 1; j <= m; j++) {
+            int d = up[j - 1] + (seq1[j - 1] == b ? 1 : -2);     /* match_score olc.py:32-38 */
+            int su = cur[j - 1] - 2;                              /* score_up   (pointer 2) */
+            int sl = up[j] - 2;                                   /* score_left (pointer 1) */
+            int s = sl > su ? sl : su; if (d > s) s = d;
+            cur[j] = s;
+            pc[j] = (s == d) ? 3 : (s == su) ? 2 : 1;             /* olc.py:69-74 */
+        }
+    }
+    g_cells += (uint64_t)n * (uint64_t)m; g_calls++;
+    int max_i = -200, i = 0;                                      /* olc.py:79-83: last row wins (>=) */
+    for (int ii = 0; ii <= n; ii++) if (S[(size_t)ii * W + m] >= max_i) { max_i = S[(size_t)ii * W + m]; i = ii; }
+    int j = m; const int prei = i, prej = j;
+    /* traceback olc.py:88-105, strings built back to front */
+    int cap = m + n + 1, a = cap, b2 = cap;
+    char *t1 = (char *)xmalloc((size_t)cap + 1), *t2 = (char *)xmalloc((size_t)cap + 1);
+    t1[cap] = 0; t2[cap] = 0;
+    for (;;) {
+        unsigned char p = P[(size_t)i * W + j];
+        if (p == 3) { t1[--a] = seq1[j - 1]; t2[--b2] = seq2[i - 1]; i--; j--; }
+        else if (p == 2) { t2[--b2] = '-'; t1[--a] = seq1[j - 1]; j--; }
+        else { t2[--b2] = seq2[i - 1]; t1[--a] = '-'; i--; }
+        if (i == 0 || j == 0) break;
+    }
+    out7[0] = cap - a; out7[1] = cap - b2; out7[2] = prej; out7[3] = j; out7[4] = prei; out7[5] = i; out7[6] = max_i;
+    if (align1) { memcpy(align1, t1 + a, (size_t)(cap - a)); align1[cap - a] = 0; }
+    if (align2) { memcpy(align2, t2 + b2, (size_t)(cap - b2)); align2[cap - b2] = 0; }
+    free(t1); free(t2);
+}
+
+/* ------------------------------------------------------------------ small string-keyed hash map */
+typedef struct { const char **keys; int *klen; int *val; size_t cap, n; } smap;
+static uint64_t fnv(const char *s, int n) { uint64_t h = 1469598103934665603ULL; for (int i = 0; i < n; i++) { h ^= (unsigned char)s[i]; h *= 1099511628211ULL; } return h ^ (h >> 29); }
+static void smap_init(smap *m, size_t expect) { size_t c = 16; while (c < expect * 2 + 2) c <<= 1; m->cap = c; m->n = 0; m->keys = (const char **)xcalloc(c, sizeof(char *)); m->klen = (int *)xcalloc(c, sizeof(int)); m->val = (int *)xcalloc(c, sizeof(int)); }
+static void smap_free(smap *m) { free(m->keys); free(m->klen); free(m->val); }
+static int *smap_find(smap *m, const char *k, int n) { size_t i = fnv(k, n) & (m->cap - 1); while (m->keys[i]) { if (m->klen[i] == n && memcmp(m->keys[i], k, (size_t)n) == 0) return &m->val[i]; i = (i + 1) & (m->cap - 1); } return NULL; }
+static void smap_grow(smap *m);
+static int *smap_put(smap *m, const char *k, int n, int v0) {
+    if ((m->n + 1) * 2 > m->cap) smap_grow(m);
+    size_t i = fnv(k, n) & (m->cap - 1);
+    while (m->keys[i]) { if (m->klen[i] == n && memcmp(m->keys[i], k, (size_t)n) == 0) return &m->val[i]; i = (i + 1) & (m->cap - 1); }
+    m->keys[i] = k; m->klen[i] = n; m->val[i] = v0; m->n++; return &m->val[i];
+}
+static void smap_grow(smap *m) {
+    smap o = *m; m->cap = o.cap * 2; m->n = 0;
+    m->keys = (const char **)xcalloc(m->cap, sizeof(char *)); m->klen = (int *)xcalloc(m->cap, sizeof(int)); m->val = (int *)xcalloc(m->cap, sizeof(int));
+    for (size_t i = 0; i < o.cap; i++) if (o.keys[i]) *smap_put(m, o.keys[i], o.klen[i], 0) = o.val[i];
+    smap_free(&o);
+}
+
+/* ------------------------------------------------------------------ T1 */
+/* utils.py:239-244: fq_recs[seq].append(fr); iteration order = first occurrence (P4). */
+int bko_group_reads(const char *reads, int stride, const int *lens, int n, int *out_rep, int *out_n)
+{
+    smap m; smap_init(&m, (size_t)n);
+    int U = 0;
+    for (int i = 0; i < n; i++) {
+        const char *s = reads + (size_t)i * stride;
+        int *v = smap_find(&m, s, lens[i]);
+        if (v) out_n[*v]++;
+        else { *smap_put(&m, s, lens[i], U) = U; out_rep[U] = i; out_n[U] = 1; U++; }
+    }
+    smap_free(&m);
+    return U;
+}
+
+/* ------------------------------------------------------------------ K1 + K2 */
+static int acgt_only(const char *s, int k) { for (int i = 0; i < k; i++) { char c = s[i]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return 0; } return 1; }
+static void count_kmers(smap *m, const char *s, int len, int k) {                /* jellyfish count, all len-k+1 positions */
+    for (int i = 0; i + k <= len; i++) if (acgt_only(s + i, k)) (*smap_put(m, s + i, k, 0))++;
+}
+static int cmp_merp(const void *a, const void *b, void *kk) { return memcmp(*(const char *const *)a, *(const char *const *)b, (size_t)*(int *)kk); }
+
+int bko_kmer_select(const char *reads, int stride, const int *lens, int n,
+                    const char *sc, int sc_stride, const int *sc_lens, int nsc,
+                    const char *const *refs, const int *ref_lens, int nref,
+                    int k, char *out_mers, int *out_counts, int cap)
+{
+    smap cs, rf, scm; size_t tot = 0;
+    for (int i = 0; i < n; i++) tot += (size_t)(lens[i] >= k ? lens[i] - k + 1 : 0);
+    smap_init(&cs, tot / 4 + 16);
+    for (int i = 0; i < n; i++) count_kmers(&cs, reads + (size_t)i * stride, lens[i], k);     /* sv_processor.py:617-618 */
+    /* reference: forward and reverse-complement window (sv_processor.py:613-615, files :291) */
+    size_t rtot = 0; for (int r = 0; r < nref; r++) rtot += (size_t)ref_lens[r];
+    smap_init(&rf, rtot * 2 + 16);
+    char **rcs = (char **)xcalloc((size_t)nref, sizeof(char *));
+    for (int r = 0; r < nref; r++) {
+        count_kmers(&rf, refs[r], ref_lens[r], k);
+        rcs[r] = (char *)xmalloc((size_t)ref_lens[r] + 1);
+        for (int i = 0; i < ref_lens[r]; i++) { char c = refs[r][ref_lens[r] - 1 - i]; rcs[r][i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+        count_kmers(&rf, rcs[r], ref_lens[r], k);
+    }
+    int have_sc = nsc >= 0;
+    if (have_sc) { size_t st = 0; for (int i = 0; i < nsc; i++) st += (size_t)sc_lens[i]; smap_init(&scm, st + 16); for (int i = 0; i < nsc; i++) count_kmers(&scm, sc + (size_t)i * sc_stride, sc_lens[i], k); }
+    /* sample_only = (keys(case) & keys(case_sc)) - keys(ref); case_only[mer] = case[mer]  (:621-631) */
+    const char **sel = (const char **)xmalloc(cs.n * sizeof(char *)); size_t ns = 0;
+    for (size_t i = 0; i < cs.cap; i++) if (cs.keys[i]) {
+        if (smap_find(&rf, cs.keys[i], k)) continue;
+        if (have_sc && !smap_find(&scm, cs.keys[i], k)) continue;
+        sel[ns++] = cs.keys[i];
+    }
+    qsort_r(sel, ns, sizeof(char *), cmp_merp, &k);
+    for (size_t i = 0; i < ns && (int)i < cap; i++) { memcpy(out_mers + i * (size_t)k, sel[i], (size_t)k); out_counts[i] = *smap_find(&cs, sel[i], k); }
+    free(sel); smap_free(&cs); smap_free(&rf); if (have_sc) smap_free(&scm);
+    for (int r = 0; r < nref; r++) free(rcs[r]);
+    free(rcs);
+    return (int)ns;
+}
+
+/* ------------------------------------------------------------------ assembler */
+enum { ORD_FOR = 0, ORD_REV = 1, ORD_MID = 2 };
+typedef struct { int mer, pos, lt, dist, order; } ktup;           /* sv_assembly.py:130 tuple */
+typedef struct { int u, pos, len, nreads; } rhit;                  /* read_search tuple, sv_assembly.py:106 */
+
+typedef struct {
+    char *seq; int len;
+    int *io, *ot; int clen;                                        /* assembly_counts :160-221 */
+    ktup *kmers; int nk, kcap;
+    int setup, serial, in_fifo;
+    int *reads; int nr;                                            /* self.reads (set) */
+    int *batch; unsigned char *batch_aligned; int nb, bcap;        /* rb.batch_reads */
+    int *alt; int *alt_n; int nalt;                                /* rb.alt */
+    int *del; int ndel;                                            /* rb.delete */
+    int *kmer_locs;
+} contig;
+
+typedef struct { int mer, read, nreads, alive; } pending;
+
+struct bko_asm {
+    /* inputs */
+    const char *useqs; int stride; const int *ulens, *unreads; const uint8_t *uindel; int U;
+    const char *mers; const int *counts; int M, k, rc_thresh, read_len;
+    /* read state */
+    unsigned char *used, *deleted; int *buf_stamp, *reads_stamp, *founder_of;
+    /* mer state */
+    unsigned char *removed, *usedmer; int *checked_stamp, *mset_stamp, *tmp_stamp; int *order;
+    smap mermap; int stamp_ctr;
+    /* FIFO buff.contigs */
+    pending *pend; int phead, ptail, pcap;
+    int serial;
+    /* results */
+    contig **out; int nout, outcap;
+};
+
+#define RSEQ(a, u) ((a)->useqs + (size_t)(u) * (a)->stride)
+#define MER(a, i) ((a)->mers + (size_t)(i) * (a)->k)
+
+static int mer_lookup(bko_asm *a, const char *s) { int *v = smap_find(&a->mermap, s, a->k); return (v && !a->removed[*v]) ? *v : -1; }   /* membership in akmers.smers_set */
+
+static int cmp_ktup_mid(const void *x, const void *y) {           /* :142 sorted by (x[2], x[3]); stable via pos order of gathering */
+    const ktup *p = (const ktup *)x, *q = (const ktup *)y;
+    if (p->lt != q->lt) return p->lt - q->lt;
+    if (p->dist != q->dist) return p->dist - q->dist;
+    return p->pos - q->pos;                                        /* unreachable tie: (lt,dist) determines pos */
+}
+/* get_read_kmers_ordered, sv_assembly.py:126-143 (P1: integer m; Q1: last k-mer omitted) */
+static int read_kmers_ordered(bko_asm *a, const char *seq, int len, int order, ktup **out)
+{
+    int l = a->k, m = len / 2, n = 0, cap = len > l ? len - l : 0;
+    ktup *v = (ktup *)xmalloc((size_t)(cap + 1) * sizeof(ktup));
+    for (int x = 0; x < len - l; x++) {
+        int idx = mer_lookup(a, seq + x);
+        if (idx < 0) continue;
+        v[n].mer = idx; v[n].pos = x; v[n].lt = x < m; v[n].dist = abs(x - m); v[n].order = order; n++;
+    }
+    if (order == ORD_REV) { for (int i = 0; i < n / 2; i++) { ktup t = v[i]; v[i] = v[n - 1 - i]; v[n - 1 - i] = t; } }
+    else if (order == ORD_MID) qsort(v, (size_t)n, sizeof(ktup), cmp_ktup_mid);
+    *out = v; return n;
+}
+
+static int cmp_hit_for(const void *x, const void *y) {            /* :121 key (pos, -len), stable (tie -> fq_recs order = u) */
+    const rhit *p = (const rhit *)x, *q = (const rhit *)y;
+    if (p->pos != q->pos) return p->pos - q->pos;
+    if (p->len != q->len) return q->len - p->len;
+    return p->u - q->u;
+}
+static int cmp_hit_rev(const void *x, const void *y) {            /* :119 key (-pos, -len) */
+    const rhit *p = (const rhit *)x, *q = (const rhit *)y;
+    if (p->pos != q->pos) return q->pos - p->pos;
+    if (p->len != q->len) return q->len - p->len;
+    return p->u - q->u;
+}
+/* find_reads sv_assembly.py:111-122 (+read_search :102-107). filter_serial<0: used_reads = set() */
+static int find_reads(bko_asm *a, int mer, int rev, int filter_serial, rhit **out)
+{
+    int n = 0, cap = 64; rhit *v = (rhit *)xmalloc((size_t)cap * sizeof(rhit));
+    const char *ms = MER(a, mer);
+    for (int u = 0; u < a->U; u++) {
+        if (a->deleted[u]) continue;
+        const char *s = RSEQ(a, u); int len = a->ulens[u];
+        const char *hit = (const char *)memmem(s, (size_t)len, ms, (size_t)a->k);   /* re.search: first occurrence */
+        if (!hit) continue;
+        if (filter_serial >= 0 && a->buf_stamp[u] == filter_serial) continue;       /* :115-116 */
+        if (n == cap) { cap *= 2; v = (rhit *)xrealloc(v, (size_t)cap * sizeof(rhit)); }
+        v[n].u = u; v[n].pos = (int)(hit - s); v[n].len = len; v[n].nreads = a->unreads[u]; n++;
+    }
+    qsort(v, (size_t)n, sizeof(rhit), rev ? cmp_hit_rev : cmp_hit_for);
+    *out = v; return n;
+}
+
+/* ---- assembly_counts (sv_assembly.py:160-221) */
+static void set_counts(contig *c, int start, int end, int nreads, int indel_only)   /* :195-199, python slice clipping */
+{
+    int s = start < c->clen ? start : c->clen, e = end < c->clen ? end : c->clen;
+    int *v = indel_only ? c->io : c->ot;
+    for (int t = s; t < e; t++) v[t] += nreads;
+}
+static void extend_counts(contig *c, int l, int nreads, int indel_only, int post)     /* :201-221 */
+{
+    int nl = c->clen + l;
+    int *io = (int *)xmalloc((size_t)nl * sizeof(int)), *ot = (int *)xmalloc((size_t)nl * sizeof(int));
+    int off = post ? 0 : l, fill = post ? c->clen : 0;
+    memcpy(io + off, c->io, (size_t)c->clen * sizeof(int)); memcpy(ot + off, c->ot, (size_t)c->clen * sizeof(int));
+    for (int t = 0; t < l; t++) { io[fill + t] = indel_only ? nreads : 0; ot[fill + t] = indel_only ? 0 : nreads; }
+    free(c->io); free(c->ot); c->io = io; c->ot = ot; c->clen = nl;
+}
+static void counts_superseq(contig *c, int rlen, int nreads, int indel_only, int start, int end)   /* :181-193 incl. Q8 */
+{
+    int s = start < rlen ? start : rlen, e = end < rlen ? end : rlen; if (e < s) e = s;
+    int seg = e - s, z = seg < c->clen ? seg : c->clen;           /* zip() truncation */
+    int nl = rlen - seg + z;
+    int *io = (int *)xmalloc((size_t)(nl + 1) * sizeof(int)), *ot = (int *)xmalloc((size_t)(nl + 1) * sizeof(int));
+    int bi = indel_only ? nreads : 0, bo = indel_only ? 0 : nreads, w = 0;
+    for (int t = 0; t < s; t++, w++) { io[w] = bi; ot[w] = bo; }
+    for (int t = 0; t < z; t++, w++) { io[w] = bi + c->io[t]; ot[w] = bo + c->ot[t]; }
+    for (int t = e; t < rlen; t++, w++) { io[w] = bi; ot[w] = bo; }
+    free(c->io); free(c->ot); c->io = io; c->ot = ot; c->clen = nl;
+}
+static int total_reads(const contig *c) { int a = 0, b = 0; for (int t = 0; t < c->clen; t++) { if (t == 0 || c->io[t] > a) a = c->io[t]; if (t == 0 || c->ot[t] > b) b = c->ot[t]; } return a + b; }   /* :178-179 */
+
+/* ---- contig (sv_assembly.py:416-649) */
+static contig *contig_new(bko_asm *a, int mer, int u, int nreads)                     /* :417-426 */
+{
+    contig *c = (contig *)xcalloc(1, sizeof(contig));
+    c->len = a->ulens[u]; c->seq = (char *)xmalloc((size_t)c->len + 1); memcpy(c->seq, RSEQ(a, u), (size_t)c->len);
+    c->clen = c->len; c->io = (int *)xcalloc((size_t)c->len, sizeof(int)); c->ot = (int *)xcalloc((size_t)c->len, sizeof(int));
+    set_counts(c, 0, c->len, nreads, a->uindel[u]);                                   /* :165 */
+    c->serial = ++a->serial;
+    a->checked_stamp[mer] = c->serial;                                                /* checked_kmers = [kmer_val] */
+    a->buf_stamp[u] = c->serial;                                                      /* buffer = set([read.id]) */
+    c->bcap = 16; c->batch = (int *)xmalloc(16 * sizeof(int)); c->batch_aligned = (unsigned char *)xmalloc(16);
+    c->batch[0] = u; c->batch_aligned[0] = 1; c->nb = 1;                              /* read_batch :383 */
+    c->reads = (int *)xmalloc((size_t)a->U * sizeof(int));
+    c->alt = (int *)xmalloc((size_t)a->U * sizeof(int)); c->alt_n = (int *)xmalloc((size_t)a->U * sizeof(int));
+    c->del = (int *)xmalloc((size_t)a->U * sizeof(int));
+    return c;
+}
+static void contig_free(contig *c) { if (!c) return; free(c->seq); free(c->io); free(c->ot); free(c->kmers); free(c->reads); free(c->batch); free(c->batch_aligned); free(c->alt); free(c->alt_n); free(c->del); free(c->kmer_locs); free(c); }
+
+static void set_kmers(bko_asm *a, contig *c) { c->setup = 1; free(c->kmers); c->nk = read_kmers_ordered(a, c->seq, c->len, ORD_MID, &c->kmers); c->kcap = c->nk; }   /* :548-550 */
+static void kmers_extend(contig *c, ktup *v, int n) { if (c->nk + n > c->kcap) { c->kcap = (c->nk + n) * 2 + 8; c->kmers = (ktup *)xrealloc(c->kmers, (size_t)c->kcap * sizeof(ktup)); } memcpy(c->kmers + c->nk, v, (size_t)n * sizeof(ktup)); c->nk += n; }
+
+static void aseq_set_superseq(bko_asm *a, contig *c, int u, int nreads, int start, int end)    /* :232-236 */
+{
+    int rl = a->ulens[u];
+    counts_superseq(c, rl, nreads, a->uindel[u], start, end);
+    free(c->seq); c->seq = (char *)xmalloc((size_t)rl + 1); memcpy(c->seq, RSEQ(a, u), (size_t)rl); c->len = rl;
+}
+/* contig_overlap_read :506-528 */
+static void contig_overlap_read(bko_asm *a, contig *c, const int *aln, int u, int nreads, int grow)
+{
+    if (aln[2] == c->len && aln[3] == 0) { aseq_set_superseq(a, c, u, nreads, aln[5], aln[4]); if (grow) set_kmers(a, c); return; }
+    const char *rs = RSEQ(a, u); int rl = a->ulens[u], pl = rl - aln[4]; if (pl < 0) pl = 0;
+    int km1 = a->k - 1, from = c->len - km1; if (from < 0) { from += c->len; if (from < 0) from = 0; }     /* python negative slice start */
+    int nl = (c->len - from) + pl; char *nseq = (char *)xmalloc((size_t)nl + 1);
+    memcpy(nseq, c->seq + from, (size_t)(c->len - from)); memcpy(nseq + (c->len - from), rs + aln[4], (size_t)pl);
+    /* add_postseq :243-250 */
+    int oldlen = c->len; (void)oldlen;
+    c->seq = (char *)xrealloc(c->seq, (size_t)c->len + pl + 1); memcpy(c->seq + c->len, rs + aln[4], (size_t)pl); c->len += pl;
+    set_counts(c, aln[3], aln[2], nreads, a->uindel[u]);
+    extend_counts(c, pl, nreads, a->uindel[u], 1);
+    if (grow) { ktup *v; int n = read_kmers_ordered(a, nseq, nl, ORD_FOR, &v); kmers_extend(c, v, n); free(v); }
+    free(nseq);
+}
+/* read_overlap_contig :530-546 */
+static void read_overlap_contig(bko_asm *a, contig *c, const int *aln, int u, int nreads, int grow)
+{
+    int rl = a->ulens[u];
+    if (aln[2] == rl && aln[3] == 0) { set_counts(c, aln[5], aln[4], nreads, a->uindel[u]); return; }       /* add_subseq :238-240 */
+    const char *rs = RSEQ(a, u); int pl = aln[3], km1 = a->k - 1, take = km1 < c->len ? km1 : c->len;
+    int nl = pl + take; char *nseq = (char *)xmalloc((size_t)nl + 1);
+    memcpy(nseq, rs, (size_t)pl); memcpy(nseq + pl, c->seq, (size_t)take);
+    /* add_preseq :255-262 */
+    char *ns = (char *)xmalloc((size_t)c->len + pl + 1); memcpy(ns, rs, (size_t)pl); memcpy(ns + pl, c->seq, (size_t)c->len);
+    free(c->seq); c->seq = ns; c->len += pl;
+    set_counts(c, aln[5], aln[4], nreads, a->uindel[u]);
+    extend_counts(c, pl, nreads, a->uindel[u], 0);
+    if (grow) { ktup *v; int n = read_kmers_ordered(a, nseq, nl, ORD_REV, &v); kmers_extend(c, v, n); free(v); }
+    free(nseq);
+}
+static int strip_find(const char *al, int n, const char *mer, int k)                  /* x.replace('-','').find(mer) :485-488 */
+{
+    char *t = (char *)xmalloc((size_t)n + 1); int w = 0;
+    for (int i = 0; i < n; i++) if (al[i] != '-') t[w++] = al[i];
+    const char *h = (const char *)memmem(t, (size_t)w, mer, (size_t)k);
+    int r = h ? (int)(h - t) : -1; free(t); return r;
+}
+/* check_align :449-504 */
+static int check_align(bko_asm *a, contig *c, int u, int mer, int nreads, int grow)
+{
+    const char *rs = RSEQ(a, u); int rl = a->ulens[u];
+    int v1[7], v2[7];
+    char *a11 = (char *)xmalloc((size_t)c->len + rl + 2), *a12 = (char *)xmalloc((size_t)c->len + rl + 2);
+    char *a21 = (char *)xmalloc((size_t)c->len + rl + 2), *a22 = (char *)xmalloc((size_t)c->len + rl + 2);
+    bko_nw(c->seq, c->len, rs, rl, v1, a11, a12);                                     /* :451 */
+    bko_nw(rs, rl, c->seq, c->len, v2, a21, a22);                                     /* :452 */
+    int match = 0;
+    int minlen = c->len < rl ? c->len : rl;
+    /* :459-465 in exact integer form: score >= minlen/4.0  <=> 4*score >= minlen;
+       round(score/ov, 2) >= 0.90 <=> 200*score >= 179*ov */
+    int ok1 = (4 * v1[6] >= minlen) && (200 * v1[6] >= 179 * (v1[2] - v1[3]));
+    int ok2 = (4 * v2[6] >= minlen) && (200 * v2[6] >= 179 * (v2[2] - v2[3]));
+    if (!ok1 && !ok2) goto done;
+    if (v1[6] == v2[6] && v1[3] == 0 && v1[5] == 0 && c->len == rl) { match = 1; goto done; }        /* :466-468 (Q9) */
+    if (v1[6] == v2[6]) {
+        match = 1;
+        if (c->len < rl || (v1[2] == c->len && v1[3] == 0)) {                         /* :471-479 */
+            aseq_set_superseq(a, c, u, nreads, v1[5], v1[4]);
+            if (grow) set_kmers(a, c);
+        } else if (rl < c->len || (v2[2] == rl && v2[3] == 0)) {                      /* :480-482 */
+            set_counts(c, v2[5], v2[4], nreads, a->uindel[u]);
+        } else {                                                                      /* :483-496 */
+            match = 0;
+            const char *ms = MER(a, mer);
+            int i11 = strip_find(a11, v1[0], ms, a->k), i12 = strip_find(a12, v1[1], ms, a->k);
+            int i21 = strip_find(a21, v2[0], ms, a->k), i22 = strip_find(a22, v2[1], ms, a->k);
+            if (i11 > -1 && i12 > -1) {
+                if ((i21 == -1 && i22 == -1) || (abs(i21 - i22) > abs(i11 - i12))) { match = 1; contig_overlap_read(a, c, v1, u, nreads, grow); }
+            } else if (i21 > -1 && i22 > -1) {
+                if ((i11 == -1 && i12 == -1) || (abs(i21 - i22) < abs(i11 - i12))) { match = 1; read_overlap_contig(a, c, v2, u, nreads, grow); }
+            }
+        }
+    } else if (v1[6] > v2[6]) { match = 1; contig_overlap_read(a, c, v1, u, nreads, grow); }           /* :497-499 */
+    else { match = 1; read_overlap_contig(a, c, v2, u, nreads, grow); }                                /* :500-503 */
+done:
+    free(a11); free(a12); free(a21); free(a22);
+    return match;
+}
+/* check_read :552-566 (read_batch.check_mer_read :399-411 always appends and returns True, Q7) */
+static int check_read(bko_asm *a, contig *c, int mer, int mer_count, int u, int nreads, int grow)
+{
+    a->buf_stamp[u] = c->serial;
+    if (c->nb == c->bcap) { c->bcap *= 2; c->batch = (int *)xrealloc(c->batch, (size_t)c->bcap * sizeof(int)); c->batch_aligned = (unsigned char *)xrealloc(c->batch_aligned, (size_t)c->bcap); }
+    c->batch[c->nb] = u; c->batch_aligned[c->nb] = 0; c->nb++;
+    int match = check_align(a, c, u, mer, nreads, grow);
+    if (match) { a->used[u] = 1; c->batch_aligned[c->nb - 1] = 1; return 1; }
+    if (mer_count > 2 && !a->used[u]) { c->alt[c->nalt] = u; c->alt_n[c->nalt] = nreads; c->nalt++; }
+    else c->del[c->ndel++] = u;
+    return 0;
+}
+static void fifo_push(bko_asm *a, int mer, int u, int nreads)                         /* buffer.add_contig :337-340 */
+{
+    if (a->founder_of[u] >= 0 || a->used[u]) return;
+    if (a->ptail == a->pcap) { a->pcap = a->pcap * 2 + 16; a->pend = (pending *)xrealloc(a->pend, (size_t)a->pcap * sizeof(pending)); }
+    a->pend[a->ptail].mer = mer; a->pend[a->ptail].read = u; a->pend[a->ptail].nreads = nreads; a->pend[a->ptail].alive = 1;
+    a->founder_of[u] = a->ptail++; a->used[u] = 1;
+}
+static void fifo_remove(bko_asm *a, int u) { int p = a->founder_of[u]; if (p >= 0) { a->pend[p].alive = 0; a->founder_of[u] = -1; } }   /* remove_contig :342-344 */
+
+static int cmp_mer_asc_ctx_k; static const char *cmp_mer_asc_ctx_mers;
+static int cmp_mer_asc(const void *x, const void *y) { return memcmp(cmp_mer_asc_ctx_mers + (size_t)(*(const int *)x) * cmp_mer_asc_ctx_k, cmp_mer_asc_ctx_mers + (size_t)(*(const int *)y) * cmp_mer_asc_ctx_k, (size_t)cmp_mer_asc_ctx_k); }
+
+/* check_alt_reads :568-582.  set(self.kmers) holds 5-tuples, so it never removes a string (Q-note);
+   iteration over x is sorted() (P2). */
+static void check_alt_reads(bko_asm *a, contig *c)
+{
+    int fin = ++a->stamp_ctr;                     /* identifies mer_set of this call */
+    int xcap = a->read_len + 8; int *x = (int *)xmalloc((size_t)xcap * sizeof(int));
+    for (int t = 0; t < c->nalt; t++) {
+        int u = c->alt[t]; const char *s = RSEQ(a, u); int len = a->ulens[u], nx = 0;
+        int tmp = ++a->stamp_ctr;
+        if (len + 8 > xcap) { xcap = len + 8; x = (int *)xrealloc(x, (size_t)xcap * sizeof(int)); }
+        for (int p = 0; p < len - a->k; p++) {                                        /* get_read_kmers :147-155 (Q1) */
+            int idx = mer_lookup(a, s + p);
+            if (idx < 0 || a->usedmer[idx] || a->mset_stamp[idx] == fin || a->tmp_stamp[idx] == tmp) continue;
+            a->tmp_stamp[idx] = tmp; x[nx++] = idx;
+        }
+        if (nx == 0) continue;                                                        /* :574 */
+        cmp_mer_asc_ctx_k = a->k; cmp_mer_asc_ctx_mers = a->mers;
+        qsort(x, (size_t)nx, sizeof(int), cmp_mer_asc);                               /* P2: sorted(x) */
+        for (int q = 0; q < nx; q++) {
+            if (a->counts[x[q]] > 1) {                                                /* :576-581 */
+                int seed = x[q];
+                for (int z = 0; z < nx; z++) a->mset_stamp[x[z]] = fin;               /* mer_set = mer_set | x */
+                /* The reference collects new_contigs and adds them to buff in finalize (:591-592) in alt
+                   order; add_contig depends only on read.used / membership, which later alt iterations do
+                   not touch, so pushing here is equivalent.  mer_pos is stored but never read. */
+                fifo_push(a, seed, u, c->alt_n[t]);
+                break;
+            }
+        }
+    }
+    free(x);
+}
+/* finalize :584-599 */
+static void finalize(bko_asm *a, contig *c, int setup)
+{
+    if (setup) set_kmers(a, c);
+    check_alt_reads(a, c);
+    int last = -1;
+    for (int t = 0; t < c->nb; t++) if (c->batch_aligned[t]) {                        /* keep_reads :595-597 */
+        int u = c->batch[t]; last = u;
+        if (a->reads_stamp[u] != c->serial) { a->reads_stamp[u] = c->serial; c->reads[c->nr++] = u; }
+    }
+    for (int t = 0; t < c->ndel; t++) a->deleted[c->del[t]] = 1;                      /* rb.clean :390 */
+    c->ndel = 0; c->nalt = 0;
+    c->batch[0] = last; c->batch_aligned[0] = 1; c->nb = 1;                           /* :396 */
+}
+static void set_kmer_locs(bko_asm *a, contig *c)                                      /* :434-438 */
+{
+    free(c->kmer_locs); c->kmer_locs = (int *)xcalloc((size_t)c->len + 1, sizeof(int));
+    for (int t = 0; t < c->nk; t++) {
+        const char *h = (const char *)memmem(c->seq, (size_t)c->len, MER(a, c->kmers[t].mer), (size_t)a->k);
+        int p = h ? (int)(h - c->seq) : -1;
+        int s = p, e = p + a->k;
+        if (s < 0) { s += c->len; if (s < 0) s = 0; }                                 /* python slice semantics for find()==-1 */
+        if (e < 0) { e += c->len; if (e < 0) e = 0; }
+        if (s > c->len) s = c->len;
+        if (e > c->len) e = c->len;
+        for (int q = s; q < e; q++) c->kmer_locs[q]++;
+    }
+}
+/* grow :616-649 */
+static void grow(bko_asm *a, contig *c)
+{
+    if (!c->setup) set_kmers(a, c);
+    for (;;) {
+        int n = 0; ktup *nk = (ktup *)xmalloc((size_t)(c->nk + 1) * sizeof(ktup));
+        for (int t = 0; t < c->nk; t++) if (a->checked_stamp[c->kmers[t].mer] != c->serial) nk[n++] = c->kmers[t];    /* refresh_kmers :601-602 */
+        if (n == 0) { free(nk); break; }
+        for (int t = 0; t < n; t++) {
+            ktup kv = nk[t];
+            int rev = 0;                                                              /* get_mer_reads :604-614 */
+            if (kv.order == ORD_MID) { if (kv.lt == 0) rev = 1; } else if (kv.order == ORD_FOR) rev = 1;
+            rhit *hits; int nh = find_reads(a, kv.mer, rev, c->serial, &hits);
+            a->usedmer[kv.mer] = 1;
+            for (int q = 0; q < nh; q++) {
+                if (check_read(a, c, kv.mer, a->counts[kv.mer], hits[q].u, hits[q].nreads, 1)) fifo_remove(a, hits[q].u);
+            }
+            free(hits);
+            finalize(a, c, 0);
+            a->checked_stamp[kv.mer] = c->serial;      /* checked_kmers.append(mer): stamp is per contig */
+        }
+        free(nk);
+    }
+    set_kmer_locs(a, c);
+}
+/* the per-contig checked set must survive other contigs' stamps: stamps are (serial) values, and only one
+   contig is active at a time (FIFO pops one, grows it to completion), so a single stamp array suffices. */
+
+static void keep_or_drop(bko_asm *a, contig *c)                                       /* init_assembly :53-59 */
+{
+    if (total_reads(c) < a->rc_thresh || c->len <= a->read_len) { contig_free(c); return; }
+    if (a->nout == a->outcap) { a->outcap = a->outcap * 2 + 4; a->out = (contig **)xrealloc(a->out, (size_t)a->outcap * sizeof(contig *)); }
+    a->out[a->nout++] = c;
+}
+/* setup_contigs :11-26 */
+static void setup_contigs(bko_asm *a, int mer)
+{
+    rhit *hits; int nh = find_reads(a, mer, 0, -1, &hits);
+    a->usedmer[mer] = 1;
+    contig *ct = NULL;
+    for (int q = 0; q < nh; q++) {
+        int u = hits[q].u;
+        if (!ct) {
+            ct = contig_new(a, mer, u, hits[q].nreads);
+            if (a->founder_of[u] < 0 && !a->used[u]) { ct->in_fifo = 1; a->used[u] = 1; }    /* buff.add_contig :337-340 */
+        } else check_read(a, ct, mer, a->counts[mer], u, hits[q].nreads, 0);
+    }
+    free(hits);
+    if (!ct) return;
+    finalize(a, ct, 1);
+    if (ct->in_fifo) { grow(a, ct); keep_or_drop(a, ct); }                            /* it is the FIFO head (:50-52) */
+    else contig_free(ct);
+}
+
+static const char *cmp_order_mers; static const int *cmp_order_counts; static int cmp_order_k;
+static int cmp_order(const void *x, const void *y)                                    /* kmers.get_all_kmer_values :281, reverse=True */
+{
+    int i = *(const int *)x, j = *(const int *)y;
+    if (cmp_order_counts[i] != cmp_order_counts[j]) return cmp_order_counts[j] - cmp_order_counts[i];
+    return memcmp(cmp_order_mers + (size_t)j * cmp_order_k, cmp_order_mers + (size_t)i * cmp_order_k, (size_t)cmp_order_k);
+}
+
+bko_asm *bko_init_assembly(const char *useqs, int stride, const int *ulens, const int *unreads,
+                           const uint8_t *uindel, int U,
+                           const char *mers, const int *counts, int M,
+                           int k, int rc_thresh, int read_len)
+{
+    bko_asm *a = (bko_asm *)xcalloc(1, sizeof(bko_asm));
+    a->useqs = useqs; a->stride = stride; a->ulens = ulens; a->unreads = unreads; a->uindel = uindel; a->U = U;
+    a->mers = mers; a->counts = counts; a->M = M; a->k = k; a->rc_thresh = rc_thresh; a->read_len = read_len;
+    a->used = (unsigned char *)xcalloc((size_t)U, 1); a->deleted = (unsigned char *)xcalloc((size_t)U, 1);
+    a->buf_stamp = (int *)xcalloc((size_t)U, sizeof(int)); a->reads_stamp = (int *)xcalloc((size_t)U, sizeof(int));
+    a->founder_of = (int *)xmalloc((size_t)(U + 1) * sizeof(int)); for (int u = 0; u < U; u++) a->founder_of[u] = -1;
+    a->removed = (unsigned char *)xcalloc((size_t)M, 1); a->usedmer = (unsigned char *)xcalloc((size_t)M, 1);
+    a->checked_stamp = (int *)xcalloc((size_t)M, sizeof(int)); a->mset_stamp = (int *)xcalloc((size_t)M, sizeof(int)); a->tmp_stamp = (int *)xcalloc((size_t)M, sizeof(int));
+    a->order = (int *)xmalloc((size_t)(M + 1) * sizeof(int));
+    smap_init(&a->mermap, (size_t)M);
+    if (M == 0) return a;                                                             /* :33-34 */
+    int no = 0;
+    for (int i = 0; i < M; i++) {
+        *smap_put(&a->mermap, MER(a, i), k, i) = i;
+        int multi = 0; for (int t = 1; t < k; t++) if (MER(a, i)[t] != MER(a, i)[0]) { multi = 1; break; }
+        if (multi) a->order[no++] = i; else a->removed[i] = 1;                        /* kmers.add_kmer :276-278 */
+    }
+    cmp_order_mers = mers; cmp_order_counts = counts; cmp_order_k = k;
+    qsort(a->order, (size_t)no, sizeof(int), cmp_order);
+    int head = 0;
+    for (;;) {                                                                        /* :43-62 */
+        while (head < no && a->removed[a->order[head]]) head++;
+        if (head == no || counts[a->order[head]] < 2) break;                          /* has_mers :318-322 (sorted desc => head is max) */
+        int mer = a->order[head];
+        setup_contigs(a, mer);
+        while (a->phead < a->ptail) {                                                 /* :50-59 */
+            pending p = a->pend[a->phead++];
+            if (!p.alive) continue;
+            a->founder_of[p.read] = -1;
+            contig *c = contig_new(a, p.mer, p.read, p.nreads);
+            grow(a, c); keep_or_drop(a, c);
+        }
+        for (int i = 0; i < M; i++) if (a->usedmer[i]) { a->removed[i] = 1; a->usedmer[i] = 0; }      /* remove_kmers :358-360 */
+        /* buff.remove_reads is a no-op (ids vs sequence keys, Q7) */
+    }
+    return a;
+}
+int bko_asm_ncontigs(const bko_asm *a) { return a->nout; }
+int bko_asm_contig_len(const bko_asm *a, int c) { return a->out[c]->len; }
+int bko_asm_contig_clen(const bko_asm *a, int c) { return a->out[c]->clen; }
+int bko_asm_contig_nkmers(const bko_asm *a, int c) { return a->out[c]->nk; }
+int bko_asm_contig_nreads(const bko_asm *a, int c) { return a->out[c]->nr; }
+static int cmp_int(const void *x, const void *y) { return *(const int *)x - *(const int *)y; }
+void bko_asm_contig_get(const bko_asm *a, int ci, char *seq, int *indel_only, int *others, int *kmer_locs, int *kmer_idx, int *read_idx)
+{
+    const contig *c = a->out[ci];
+    if (seq) memcpy(seq, c->seq, (size_t)c->len);
+    if (indel_only) memcpy(indel_only, c->io, (size_t)c->clen * sizeof(int));
+    if (others) memcpy(others, c->ot, (size_t)c->clen * sizeof(int));
+    if (kmer_locs) memcpy(kmer_locs, c->kmer_locs, (size_t)c->len * sizeof(int));
+    if (kmer_idx) for (int t = 0; t < c->nk; t++) kmer_idx[t] = c->kmers[t].mer;
+    if (read_idx) { memcpy(read_idx, c->reads, (size_t)c->nr * sizeof(int)); qsort(read_idx, (size_t)c->nr, sizeof(int), cmp_int); }
+}
+void bko_asm_read_flags(const bko_asm *a, uint8_t *flags) { for (int u = 0; u < a->U; u++) flags[u] = (uint8_t)((a->used[u] ? 1 : 0) | (a->deleted[u] ? 2 : 0)); }
+void bko_asm_free(bko_asm *a)
+{
+    if (!a) return;
+    for (int i = 0; i < a->nout; i++) contig_free(a->out[i]);
+    free(a->out); free(a->used); free(a->deleted); free(a->buf_stamp); free(a->reads_stamp); free(a->founder_of);
+    free(a->removed); free(a->usedmer); free(a->checked_stamp); free(a->mset_stamp); free(a->tmp_stamp); free(a->order);
+    smap_free(&a->mermap); free(a->pend); free(a);
+}

@@ -1,0 +1,65 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement (oracle) of BreaKmer's per-region hot path.
+ *
+ * Plain C restatement of the reference algorithm, function by function, citing the
+ * reference file:line each one follows.  Pinned against golden vectors generated
+ * from the real reference (tests/golden/, tools/make_golden.py).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (breakmer_amd/) never does.
+ */
+#ifndef BK_ORACLE_H
+#define BK_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* olc.nw (olc.py:40-107).  seq1/seq2 are ASCII.  out7 = {len(align1), len(align2)=same,
+ * m, j_start, i_end, i_start, score}; align1/align2 (optional, may be NULL) receive the
+ * gapped strings, caller allocates m+n+1 bytes each. */
+void bko_nw(const char *seq1, int m, const char *seq2, int n, int *out7, char *align1, char *align2);
+/* number of DP cells computed by bko_nw since the last reset (SURVEY 8d "C") */
+uint64_t bko_cells(int reset);
+uint64_t bko_nw_calls(int reset);
+
+/* T1: group identical read sequences (utils.py:239-244): out_rep[u] = index of first read with
+ * that sequence (FASTQ order), out_n[u] = number of reads; returns U. reads are n fixed-stride
+ * ASCII rows (stride bytes apart) with lengths lens[i]. */
+int bko_group_reads(const char *reads, int stride, const int *lens, int n, int *out_rep, int *out_n);
+
+/* K1+K2: Jellyfish-style occurrence counts (utils.py:151-178, 287-296; no -C: strand specific)
+ * and sample-only set algebra (sv_processor.py:609-631).
+ *   case  = k-mers of all n reads (every position, duplicates counted)
+ *   sc    = k-mers of the soft-clip sequences; if nsc < 0 then case_sc := case
+ *   ref   = k-mers of each of the nref reference strings, forward and reverse complement
+ * Result: sample-only k-mers sorted ascending by string, out_mers (cap*k bytes, no NUL),
+ * out_counts; returns the number found (may exceed cap: then only cap are written). */
+int bko_kmer_select(const char *reads, int stride, const int *lens, int n,
+                    const char *sc, int sc_stride, const int *sc_lens, int nsc,
+                    const char *const *refs, const int *ref_lens, int nref,
+                    int k, char *out_mers, int *out_counts, int cap);
+
+/* A1..A12: sv_assembly.init_assembly (sv_assembly.py:30-63) on grouped reads.
+ *   useqs/ulens/unreads/uindel: U unique reads in fq_recs iteration order (first occurrence),
+ *   mers/counts: M sample-only k-mers (any order), k, rc_thresh, read_len.
+ * Returns an opaque result; query with the accessors; free with bko_asm_free. */
+typedef struct bko_asm bko_asm;
+bko_asm *bko_init_assembly(const char *useqs, int stride, const int *ulens, const int *unreads,
+                           const uint8_t *uindel, int U,
+                           const char *mers, const int *counts, int M,
+                           int k, int rc_thresh, int read_len);
+int bko_asm_ncontigs(const bko_asm *a);
+int bko_asm_contig_len(const bko_asm *a, int c);
+int bko_asm_contig_clen(const bko_asm *a, int c);          /* len(counts.others) (Q8: may differ) */
+int bko_asm_contig_nkmers(const bko_asm *a, int c);
+int bko_asm_contig_nreads(const bko_asm *a, int c);
+void bko_asm_contig_get(const bko_asm *a, int c, char *seq, int *indel_only, int *others,
+                        int *kmer_locs, int *kmer_idx /* index into input mers */, int *read_idx /* sorted unique-read idx */);
+/* per-read final flags after assembly: bit0 used, bit1 deleted from fq_recs */
+void bko_asm_read_flags(const bko_asm *a, uint8_t *flags);
+void bko_asm_free(bko_asm *a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
