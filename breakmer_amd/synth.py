@@ -91,7 +91,7 @@ class Region(object):
         self.partners = []
 
     def read_strs(self):
-        return [codes_to_str(r) for r in self.reads]
+        return [codes_to_str(r[:n]) for r, n in zip(self.reads, self.read_lens)]
 
     @property
     def window_str(self):
@@ -100,7 +100,7 @@ class Region(object):
 
 def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int = 150, depth: int = 500,
                 sv_type: str = "del", sv_size: int | None = None, noise: float = 0.0,
-                n_reads: int | None = None) -> Region:
+                n_reads: int | None = None, var_len: float = 0.0, indel_only_frac: float = 0.0) -> Region:
     """Generate region `region_id` (config 1-3 defaults)."""
     assert sv_type in SV_TYPES
     r = Region()
@@ -143,7 +143,27 @@ def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int =
         flip = (u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) < noise
         delta = ((u & np.uint64(0x3FF)) % np.uint64(3)).astype(np.uint8) + np.uint8(1)  # 1..3 -> always a different base
         reads = np.where(flip, (reads + delta) & 3, reads).astype(np.uint8)
-    r.reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    lens = np.full(N, L, dtype=np.int32)
+    if var_len > 0.0:
+        # quality/adapter-trimmed reads (utils.py:385-443, cutadapt): a fraction loses up to 40 bases
+        # from its 3' or 5' end; rows stay left-aligned, the tail is padding (code 0, never read)
+        u = rand_u64(stream_key(global_seed, region_id, 4), N)
+        sel = (u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) < var_len
+        cut = ((u & np.uint64(0xFFFF)) % np.uint64(41)).astype(np.int32)
+        five = ((u >> np.uint64(16)) & np.uint64(1)).astype(bool)
+        for i in np.nonzero(sel & (cut > 0))[0]:
+            c_ = int(cut[i])
+            if five[i]:
+                reads[i, :L - c_] = reads[i, c_:].copy()
+            reads[i, L - c_:] = 0
+            lens[i] = L - c_
+    r.reads = reads
+    r.read_lens = lens
+    r.indel_only = np.zeros(N, dtype=np.uint8)
+    if indel_only_frac > 0.0:
+        u = rand_u64(stream_key(global_seed, region_id, 5), N)
+        r.indel_only = ((u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) < indel_only_frac).astype(np.uint8)
     r.read_starts = starts
     r.read_ids = ["@S:1:1:%d:%d/1_0" % (region_id, i) for i in range(N)]
     # discordant-pair evidence normally derived from the BAM (sv_processor.py:376-408)

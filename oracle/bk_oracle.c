@@ -588,3 +588,51 @@ void bko_asm_free(bko_asm *a)
     free(a->removed); free(a->usedmer); free(a->checked_stamp); free(a->mset_stamp); free(a->tmp_stamp); free(a->order);
     smap_free(&a->mermap); free(a->pend); free(a);
 }
+
+/* ------------------------------------------------------------------ G2 test hook
+ * Reproduces tools/make_golden.py g2(): a contig founded on `contig_seq` (nreads = founder_nreads),
+ * sample k-mer set = every k-mer of contig_seq and read_seq, optional earlier read `pre`
+ * (nreads 1), set_kmers() when grow, then ONE check_align(read).  Outputs the state after. */
+int bko_check_align_case(const char *contig_seq, int clen, const char *read_seq, int rlen, const char *pre, int plen,
+                         const char *mer, int k, int grow, int nreads, int indel_only, int founder_nreads,
+                         char *out_seq, int *out_len, int *out_io, int *out_ot, int *out_clen,
+                         char *out_kmers /* nk*k chars */, int *out_kmeta /* nk*4: pos,lt,dist,order */, int *out_nk)
+{
+    int stride = clen; if (rlen > stride) stride = rlen; if (plen > stride) stride = plen;
+    int U = pre ? 3 : 2;
+    char *useqs = (char *)xcalloc((size_t)U * stride + 1, 1);
+    int ulens[3], unreads[3] = { founder_nreads, nreads, 1 }; uint8_t uindel[3] = { 0, (uint8_t)indel_only, 0 };
+    memcpy(useqs, contig_seq, (size_t)clen); ulens[0] = clen;
+    memcpy(useqs + stride, read_seq, (size_t)rlen); ulens[1] = rlen;
+    if (pre) { memcpy(useqs + 2 * (size_t)stride, pre, (size_t)plen); ulens[2] = plen; }
+    /* sample k-mer set */
+    smap m; smap_init(&m, (size_t)(clen + rlen));
+    int M = 0; char *mers = (char *)xmalloc((size_t)(clen + rlen + 2) * k);
+    const char *srcs[2] = { contig_seq, read_seq }; int sl[2] = { clen, rlen };
+    for (int s = 0; s < 2; s++) for (int i = 0; i + k <= sl[s]; i++) if (!smap_find(&m, srcs[s] + i, k)) { memcpy(mers + (size_t)M * k, srcs[s] + i, (size_t)k); *smap_put(&m, mers + (size_t)M * k, k, M) = M; M++; }
+    int *counts = (int *)xmalloc((size_t)(M + 1) * sizeof(int)); for (int i = 0; i < M; i++) counts[i] = 3;
+    smap_free(&m);
+    /* context without running init_assembly's loop */
+    bko_asm *a = (bko_asm *)xcalloc(1, sizeof(bko_asm));
+    a->useqs = useqs; a->stride = stride; a->ulens = ulens; a->unreads = unreads; a->uindel = uindel; a->U = U;
+    a->mers = mers; a->counts = counts; a->M = M; a->k = k; a->rc_thresh = 2; a->read_len = stride;
+    a->used = (unsigned char *)xcalloc((size_t)U, 1); a->deleted = (unsigned char *)xcalloc((size_t)U, 1);
+    a->buf_stamp = (int *)xcalloc((size_t)U, sizeof(int)); a->reads_stamp = (int *)xcalloc((size_t)U, sizeof(int));
+    a->founder_of = (int *)xmalloc((size_t)(U + 1) * sizeof(int)); for (int u = 0; u < U; u++) a->founder_of[u] = -1;
+    a->removed = (unsigned char *)xcalloc((size_t)M + 1, 1); a->usedmer = (unsigned char *)xcalloc((size_t)M + 1, 1);
+    a->checked_stamp = (int *)xcalloc((size_t)M + 1, sizeof(int)); a->mset_stamp = (int *)xcalloc((size_t)M + 1, sizeof(int)); a->tmp_stamp = (int *)xcalloc((size_t)M + 1, sizeof(int));
+    a->order = (int *)xmalloc((size_t)(M + 1) * sizeof(int));
+    smap_init(&a->mermap, (size_t)M);
+    for (int i = 0; i < M; i++) *smap_put(&a->mermap, MER(a, i), k, i) = i;
+    int *mi = smap_find(&a->mermap, mer, k); int meridx = mi ? *mi : 0;
+    contig *c = contig_new(a, meridx, 0, founder_nreads);
+    if (pre) check_align(a, c, 2, meridx, 1, grow);
+    if (grow) set_kmers(a, c);
+    int match = check_align(a, c, 1, meridx, nreads, grow);
+    memcpy(out_seq, c->seq, (size_t)c->len); *out_len = c->len; *out_clen = c->clen;
+    memcpy(out_io, c->io, (size_t)c->clen * sizeof(int)); memcpy(out_ot, c->ot, (size_t)c->clen * sizeof(int));
+    *out_nk = c->nk;
+    for (int t = 0; t < c->nk; t++) { memcpy(out_kmers + (size_t)t * k, MER(a, c->kmers[t].mer), (size_t)k); out_kmeta[4 * t] = c->kmers[t].pos; out_kmeta[4 * t + 1] = c->kmers[t].lt; out_kmeta[4 * t + 2] = c->kmers[t].dist; out_kmeta[4 * t + 3] = c->kmers[t].order; }
+    contig_free(c); bko_asm_free(a); free(useqs); free(mers); free(counts);
+    return match;
+}

@@ -167,3 +167,23 @@ def assemble_region(read_seqs, refs, k, rc_thresh=2, indel_only=None, sc_seqs=No
     for c in contigs:
         c["reads"] = [int(rep[u]) for u in c["reads"]]          # representative read index (FASTQ order)
     return contigs, {"rep": rep, "nreads": cnt, "mers": mers, "counts": counts, "flags": flags}
+
+
+def check_align_case(contig, read, mer, k, mode, nreads, indel_only, founder_nreads, pre=None):
+    """G2 hook: state of a contig after one check_align (sv_assembly.py:449-504)."""
+    L = lib()
+    L.bko_check_align_case.restype = C.c_int
+    cap = len(contig) + len(read) + (len(pre) if pre else 0) + 8
+    seq = C.create_string_buffer(cap)
+    ln, cl, nk = C.c_int(), C.c_int(), C.c_int()
+    io = (C.c_int * cap)()
+    ot = (C.c_int * cap)()
+    km = C.create_string_buffer(cap * 4 * k)
+    meta = (C.c_int * (cap * 16))()
+    pb = pre.encode() if pre else None
+    m = L.bko_check_align_case(contig.encode(), len(contig), read.encode(), len(read), pb, len(pre) if pre else 0,
+                               mer.encode(), k, 1 if mode == "grow" else 0, nreads, 1 if indel_only else 0, founder_nreads,
+                               seq, C.byref(ln), io, ot, C.byref(cl), km, meta, C.byref(nk))
+    order = {0: "for", 1: "rev", 2: "mid"}
+    kmers = [[km.raw[t * k:(t + 1) * k].decode(), meta[4 * t], meta[4 * t + 1], meta[4 * t + 2], order[meta[4 * t + 3]]] for t in range(nk.value)]
+    return {"match": bool(m), "seq": seq.raw[:ln.value].decode(), "io": list(io[:cl.value]), "ot": list(ot[:cl.value]), "kmers": kmers}

@@ -1,0 +1,204 @@
+"""Generate tests/golden/*.json from the REAL reference (imported from /root/reference through
+oracle/ref_loader.py).  Runs only in the build container; the fixtures (data: inputs or
+generator parameters + expected outputs) are committed, the reference never travels.
+
+  PYTHONHASHSEED=0 python tools/make_golden.py [g1 g2 g3 g4 g5]
+"""
+import hashlib
+import json
+import os
+import random
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_harness as rh  # noqa: E402
+from breakmer_amd import synth  # noqa: E402
+from oracle import ref_loader  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+META = {"generator": "tools/make_golden.py", "reference": "ccgd-profile/BreaKmer @ /root/reference",
+        "patches": ref_loader.PATCH_IDS, "python": sys.version.split()[0]}
+
+
+def dump(name, obj):
+    obj = dict(obj)
+    obj["_meta"] = META
+    path = os.path.join(GOLD, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, separators=(",", ":"))
+    print("wrote %s (%d bytes)" % (path, os.path.getsize(path)))
+
+
+def rs(rnd, n, alphabet="ACGT"):
+    return "".join(rnd.choice(alphabet) for _ in range(n))
+
+
+def g1():
+    """G1: olc.nw known-answer tests, all 7 return fields (olc.py:40-107)."""
+    olc = ref_loader.load()["olc"]
+    rnd = random.Random(20260102)
+    cases = []
+
+    def add(a, b, tag):
+        cases.append({"tag": tag, "seq1": a, "seq2": b, "out": list(olc.nw(a, b))})
+    add("AAAAAAAA", "CCCCCCCC", "no_overlap_Q5")
+    add("ACGTACGT", "ACGTACGT", "identical")
+    add("ACGTTGCA", "TGCAGGGG", "dovetail")
+    add("TTTTACGT", "ACGTACGTACGT", "last_column_tie")
+    add("GGGACGTACGTTT", "ACGTACG", "read_inside")
+    add("ACGTACG", "GGGACGTACGTTT", "contig_inside")
+    add("A", "A", "one")
+    add("A", "C", "one_mis")
+    base = rs(rnd, 80)
+    add(base, base[40:] + rs(rnd, 40), "suffix_prefix_40")
+    add(base, base[40:60] + "T" + base[61:] + rs(rnd, 30), "internal_mismatch")
+    add(base, base[40:60] + base[62:] + rs(rnd, 30), "gap_in_read")
+    add(base, base[40:60] + "GG" + base[60:] + rs(rnd, 30), "gap_in_contig")
+    for t in range(160):
+        m, n = rnd.randint(1, 70), rnd.randint(1, 70)
+        a = rs(rnd, m)
+        mode = rnd.random()
+        if mode < 0.55:
+            ov = rnd.randint(1, min(m, 50))
+            b = a[m - ov:] + rs(rnd, max(0, n - ov))
+            b = "".join((c if rnd.random() > 0.06 else rnd.choice("ACGT")) for c in b)
+        elif mode < 0.75:
+            b = rs(rnd, n, "AC")
+            a = rs(rnd, m, "AC")
+        else:
+            b = rs(rnd, n)
+        add(a, b, "rand%d" % t)
+    for t, (m, n) in enumerate([(150, 150), (298, 150), (150, 298), (600, 250), (250, 600), (900, 250), (31, 900)]):
+        a = rs(rnd, m)
+        ov = min(m, n) * 2 // 3
+        b = a[m - ov:] + rs(rnd, n - ov)
+        b = "".join((c if rnd.random() > 0.02 else rnd.choice("ACGT")) for c in b)
+        add(a, b, "long%d" % t)
+        add(b, a, "long%d_swapped" % t)
+    dump("nw_kats.json", {"cases": cases})
+
+
+class _FakeRead(object):
+    def __init__(self, rid, seq, indel_only):
+        self.id, self.seq, self.qual, self.used, self.dup, self.indel_only = rid, seq, "I" * len(seq), False, False, indel_only
+
+
+def g2():
+    """G2: contig.check_align branch coverage (sv_assembly.py:449-546) on hand-built contig/read pairs.
+    State after the call: match, seq, counts, kmers (grow mode)."""
+    sa = ref_loader.load()["sv_assembly"]
+    rnd = random.Random(77)
+    k = 15
+    cases = []
+    base = rs(rnd, 400)
+
+    def run(tag, contig_seq, read_seq, mer, mode, nreads=3, indel_only=False, founder_nreads=2, pre=None):
+        founder = _FakeRead("@f/1_0", contig_seq, False)
+        ct = sa.contig(mer, founder, contig_seq.find(mer), founder_nreads, k)
+        skm = set()
+        for s in (contig_seq, read_seq):
+            for i in range(len(s) - k + 1):
+                skm.add(s[i:i + k])
+        if pre is not None:       # extra earlier read to de-synchronise counts length from seq length (Q8)
+            ct.check_align(_FakeRead("@p/1_0", pre, False), mer, 1, skm, mode)
+        if mode == "grow":
+            ct.set_kmers(skm)
+        rd = _FakeRead("@r/1_0", read_seq, indel_only)
+        m = ct.check_align(rd, mer, nreads, skm, mode)
+        cases.append({"tag": tag, "k": k, "contig": contig_seq, "read": read_seq, "mer": mer, "mode": mode,
+                      "nreads": nreads, "indel_only": indel_only, "founder_nreads": founder_nreads, "pre": pre,
+                      "match": bool(m), "seq": ct.aseq.seq, "io": list(ct.aseq.counts.indel_only),
+                      "ot": list(ct.aseq.counts.others), "kmers": [list(t) for t in ct.kmers]})
+    c = base[100:250]
+    mer = c[60:75]
+    for mode in ("setup", "grow"):
+        run("no_match", c, rs(rnd, 150), mer, mode)
+        run("identical_Q9", c, c, mer, mode)
+        run("read_right_overhang", c, base[130:280], base[135:150], mode)
+        run("read_left_overhang", c, base[70:220], base[135:150], mode)
+        run("read_left_overhang_indel_only", c, base[70:220], base[135:150], mode, indel_only=True)
+        run("contig_inside_longer_read", c, base[80:270], mer, mode)
+        run("read_inside_contig", c, base[120:230], base[135:150], mode)
+        run("read_inside_contig_indel_only", c, base[120:230], base[135:150], mode, indel_only=True)
+        run("same_len_shift_tiebreak", c, base[101:251], mer, mode)
+        mm = list(base[70:220]); mm[100] = "A" if mm[100] != "A" else "C"
+        run("left_overhang_with_mismatch", c, "".join(mm), base[135:150], mode)
+        gp = base[130:200] + base[202:282]
+        run("right_overhang_gap", c, gp, base[135:150], mode)
+        # superseq whose aligned span is longer than the old contig (gap on contig side): Q8 shrink
+        longer = base[80:160] + "GT" + base[160:270]
+        run("superseq_Q8_gap", c, longer, mer, mode)
+        run("superseq_after_pre", c, base[60:300], mer, mode, pre=base[90:240])
+        # low identity overlap (<0.90) but long
+        noisy = "".join((ch if rnd.random() > 0.2 else rnd.choice("ACGT")) for ch in base[130:280])
+        run("low_identity", c, noisy, base[135:150], mode)
+        # periodic sequence: equal scores both ways, k-mer position tie-break (sv_assembly.py:485-496)
+        per = "ACGTTGCAAT" * 15
+        run("periodic_tie", per, per[3:] + "ACG", per[20:35], mode)
+        run("periodic_tie2", per, "TTG" + per[:147], per[20:35], mode)
+    dump("check_align.json", {"cases": cases})
+
+
+def region_case(tag, k=31, rc_thresh=2, **kw):
+    r = synth.make_region(**kw)
+    reads = r.read_strs()
+    t = time.time()
+    mers = rh.ref_kmer_select(reads, [r.window_str], k)
+    contigs, _ = rh.ref_init_assembly(r.read_ids, reads, mers, k, rc_thresh, r.indel_only)
+    dt = time.time() - t
+    h = hashlib.sha256(("\n".join(reads)).encode()).hexdigest()
+    print("  %-28s reads %5d mers %6d contigs %3d  %.1fs" % (tag, len(reads), len(mers), len(contigs), dt))
+    msum = hashlib.sha256(("\n".join("%s %d" % (m, mers[m]) for m in sorted(mers))).encode()).hexdigest()
+    return {"tag": tag, "k": k, "rc_thresh": rc_thresh, "gen": kw, "reads_sha256": h, "n_mers": len(mers),
+            "mers_sha256": msum, "mers": ({m: mers[m] for m in sorted(mers)} if len(mers) <= 200 else None),
+            "contigs": contigs, "ref_seconds": round(dt, 2)}
+
+
+def g3():
+    """G3: init_assembly (sv_assembly.py:30-63) end to end on seeded synthetic regions.  Inputs are
+    regenerated from `gen` (breakmer_amd.synth.make_region) and checked by sha256."""
+    cases = []
+    for i, sv in enumerate(synth.SV_TYPES):
+        if sv == "trl":
+            continue
+        cases.append(region_case("d60_" + sv, region_id=10 + i, sv_type=sv, depth=60, W=1500))
+    cases.append(region_case("d30_trl", region_id=15, sv_type="trl", depth=30, W=900))
+    cases.append(region_case("config1_del_500x", region_id=0, sv_type="del", depth=500, W=3000))
+    cases.append(region_case("L250_k41_ins", k=41, region_id=21, sv_type="ins", depth=40, W=1500, L=250))
+    cases.append(region_case("L250_k41_noise5", k=41, region_id=22, sv_type="del", depth=24, W=1000, L=250, noise=0.05))
+    for j, nz in enumerate((0.01, 0.02, 0.05)):
+        cases.append(region_case("noise%d_del" % int(nz * 100), region_id=30 + j, sv_type="del", depth=30, W=900, noise=nz))
+    cases.append(region_case("noise2_inv_d60", region_id=34, sv_type="inv", depth=60, W=900, noise=0.02))
+    cases.append(region_case("varlen_indelonly_ins", region_id=7, sv_type="ins", depth=60, W=1500, var_len=0.4, indel_only_frac=0.3, noise=0.005))
+    cases.append(region_case("varlen_dup_rc3", rc_thresh=3, region_id=8, sv_type="dup", depth=80, W=1500, var_len=0.5, noise=0.01))
+    cases.append(region_case("no_sv", region_id=9, sv_type="del", sv_size=0, depth=40, W=900))
+    dump("assembly.json", {"cases": cases})
+
+
+def g4():
+    """G4: k-mer set algebra (sv_processor.py:609-631) incl. a separate soft-clip set."""
+    rnd = random.Random(4)
+    cases = []
+    for t in range(6):
+        k = rnd.choice([5, 7, 11])
+        ref = rs(rnd, 120)
+        reads = [ref[s:s + 40] for s in (rnd.randint(0, 80) for _ in range(25))]
+        reads += [rs(rnd, 40) for _ in range(3)] + ["A" * 40] + [reads[0]] * 2
+        sc = None if t % 2 == 0 else [r for r in reads if rnd.random() < 0.5]
+        d = rh.ref_kmer_select(reads, [ref], k, sc)
+        cases.append({"k": k, "ref": ref, "reads": reads, "sc": sc, "mers": {m: d[m] for m in sorted(d)}})
+    dump("kmer_select.json", {"cases": cases})
+
+
+if __name__ == "__main__":
+    assert ref_loader.available(), "reference not present"
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    for w in which:
+        print(w)
+        globals()[w]()
