@@ -1,0 +1,441 @@
+// bk_api.hip -- host side of libbreakmer_hip.so: the C-ABI of include/breakmer_hip.h.
+// gfx950 only; there is no CPU fallback anywhere in this library.
+#include "../../include/breakmer_hip.h"
+#include "bk_common.h"
+#include "bk_kmer.hip.h"
+#include "bk_asm.hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static std::string g_create_err;
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n ? n : 256);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct bk_handle {
+    int dev = 0; hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
+    bk_config cfg{}; std::string err;
+    int n_regions = 0; bool submitted = false, ran = false, fetched = false, synced = false;
+    uint32_t ran_mask = 0;
+    // device
+    DevBuf d_desc, d_work, d_part, d_reads, d_rlen, d_rflag, d_sc, d_sclen, d_win;
+    DevBuf d_ddslot, d_ddrep, d_ddcnt, d_ddu, d_grp, d_urep, d_unr, d_ufl, d_ubuf, d_ureads, d_ufound, d_uminpos;
+    DevBuf d_arena, d_out, d_tops;
+    uint64_t arena_cap = 0, out_cap = 0;
+    uint32_t ref_cap = 0, win_words_cap = 0;
+    // host mirrors
+    std::vector<BkRegionDesc> h_desc; std::vector<BkRegionWork> h_work; std::vector<uint8_t> h_out;
+    std::vector<BkPartnerDesc> h_part;
+    uint64_t total_reads = 0, alg_bytes = 0;
+    float ms[4] = {0, 0, 0, 0};
+    BkParams params{};
+};
+
+#define HIPCHK(h, call)                                                                              \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BK_E_HIP; } } while (0)
+
+static int fail(bk_handle *h, int code, const std::string &msg) { if (h) h->err = msg; else g_create_err = msg; return code; }
+
+extern "C" int bk_abi_version(void) { return BK_ABI_VERSION; }
+extern "C" const char *bk_last_error(const bk_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, BK_E_ARG, "bk_create: null argument");
+    if (cfg->abi_version != BK_ABI_VERSION) return fail(nullptr, BK_E_ARG, "bk_create: ABI version mismatch");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, BK_E_NOGPU, "bk_create: no HIP device visible (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, BK_E_ARG, "bk_create: bad device id");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, BK_E_HIP, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(nullptr, BK_E_NOGPU, std::string("bk_create: device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only");
+    if (cfg->kmer_size < 2 || cfg->kmer_size > 64) return fail(nullptr, BK_E_ARG, "bk_create: kmer_size must be in [2, 64]");
+    bk_handle *h = new bk_handle();
+    h->dev = device_id; h->cfg = *cfg;
+    if (h->cfg.max_contig_len <= 0) h->cfg.max_contig_len = 4096;
+    if (h->cfg.max_read_len <= 0) h->cfg.max_read_len = 1024;
+    if (h->cfg.max_candidates <= 0) h->cfg.max_candidates = 2048;
+    if (h->cfg.sw_min_score <= 0) h->cfg.sw_min_score = 20;
+    if (h->cfg.rc_thresh <= 0) h->cfg.rc_thresh = 2;
+    if (h->cfg.max_read_len > 1024 || h->cfg.max_contig_len > 4095 + 1 || h->cfg.max_contig_len > 2 * h->cfg.max_candidates) {
+        delete h; return fail(nullptr, BK_E_ARG, "bk_create: limits: max_read_len <= 1024, max_contig_len <= 4096 and <= 2*max_candidates");
+    }
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, BK_E_HIP, "stream creation failed"); }
+    for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { delete h; return fail(nullptr, BK_E_HIP, "event creation failed"); }
+    *out = h;
+    return BK_OK;
+}
+
+extern "C" int bk_destroy(bk_handle *h)
+{
+    if (!h) return BK_OK;
+    (void)hipSetDevice(h->dev);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
+                      &h->d_ddu, &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops};
+    for (auto b : bufs) b->release();
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return BK_OK;
+}
+
+// 2 bit/base, first base in the most significant bits (bk_common.h)
+static bool pack_seq(const char *s, int len, uint32_t *w, int nwords)
+{
+    for (int i = 0; i < nwords; i++) w[i] = 0;
+    for (int i = 0; i < len; i++) {
+        uint32_t c;
+        switch (s[i]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: return false; }
+        w[i >> 4] |= c << (30 - 2 * (i & 15));
+    }
+    return true;
+}
+
+template <class T> static hipError_t upload(bk_handle *h, DevBuf &b, const std::vector<T> &v)
+{
+    hipError_t e = b.ensure(std::max<size_t>(v.size() * sizeof(T), 256));
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream);
+}
+
+extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions)
+{
+    if (!h || !regions || n_regions <= 0) return fail(h, BK_E_ARG, "bk_submit_regions: bad argument");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int k = h->cfg.kmer_size;
+    std::vector<uint32_t> reads, sc, win; std::vector<uint16_t> rlen, sclen; std::vector<uint8_t> rflag;
+    h->h_desc.assign(n_regions, BkRegionDesc{}); h->h_part.clear();
+    uint64_t dd_total = 0; uint32_t max_w = 0; h->alg_bytes = 0;
+    size_t tot_reads = 0, tot_words = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;
+    for (int r = 0; r < n_regions; r++) {
+        const bk_region &g = regions[r];
+        if (g.n_reads < 0 || !g.window || g.window_len <= 0 || (g.n_reads > 0 && (!g.reads || !g.read_lens))) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": missing reads/window");
+        if (g.n_reads >= (1 << 22)) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 4M reads in one region");
+        uint32_t maxl = 0; for (int i = 0; i < g.n_reads; i++) maxl = std::max<uint32_t>(maxl, g.read_lens[i]);
+        if ((int)maxl > h->cfg.max_read_len) return fail(h, BK_E_LIMIT, "bk_submit_regions: read longer than max_read_len");
+        tot_reads += g.n_reads; tot_words += (size_t)g.n_reads * ((maxl + 15) / 16 + 1);
+        if (g.n_sc > 0) { uint32_t ms = 0; for (int i = 0; i < g.n_sc; i++) ms = std::max<uint32_t>(ms, g.sc_lens[i]); tot_sc += g.n_sc; tot_scw += (size_t)g.n_sc * ((ms + 15) / 16 + 1); }
+        tot_win += (g.window_len + 15) / 16 + 2; for (int q = 0; q < g.n_partners; q++) tot_win += (g.partner_lens[q] + 15) / 16 + 2;
+    }
+    reads.reserve(tot_words); rlen.reserve(tot_reads); rflag.reserve(tot_reads); sc.reserve(tot_scw); sclen.reserve(tot_sc); win.reserve(tot_win);
+    for (int r = 0; r < n_regions; r++) {
+        const bk_region &g = regions[r]; BkRegionDesc &d = h->h_desc[r];
+        uint32_t maxl = 0; for (int i = 0; i < g.n_reads; i++) maxl = std::max<uint32_t>(maxl, g.read_lens[i]);
+        d.n_reads = g.n_reads; d.read_words = (maxl + 15) / 16 + 1;          // +1: k-mer extraction may touch one word past the end
+        d.max_len = maxl;
+        d.reads_word_off = reads.size(); d.read_meta_off = rlen.size();
+        reads.resize(reads.size() + (size_t)d.n_reads * d.read_words);
+        for (int i = 0; i < g.n_reads; i++) {
+            if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words))
+                return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + " read " + std::to_string(i) + ": non-ACGT base (unsupported)");
+            rlen.push_back(g.read_lens[i]); rflag.push_back(g.indel_only ? g.indel_only[i] : 0);
+        }
+        d.n_sc = g.n_sc < 0 ? -1 : g.n_sc; d.sc_word_off = sc.size(); d.sc_meta_off = sclen.size(); d.sc_words = 1;
+        if (g.n_sc > 0) {
+            uint32_t ms = 0; for (int i = 0; i < g.n_sc; i++) ms = std::max<uint32_t>(ms, g.sc_lens[i]);
+            d.sc_words = (ms + 15) / 16 + 1; sc.resize(sc.size() + (size_t)g.n_sc * d.sc_words);
+            for (int i = 0; i < g.n_sc; i++) {
+                if (!pack_seq(g.sc_seqs + (size_t)i * g.sc_stride, g.sc_lens[i], sc.data() + d.sc_word_off + (size_t)i * d.sc_words, d.sc_words)) return fail(h, BK_E_ARG, "bk_submit_regions: non-ACGT base in soft-clip sequence");
+                sclen.push_back(g.sc_lens[i]);
+            }
+        }
+        d.win_len = g.window_len; d.win_word_off = win.size();
+        { size_t nw = (g.window_len + 15) / 16 + 2; win.resize(win.size() + nw); if (!pack_seq(g.window, g.window_len, win.data() + d.win_word_off, (int)nw)) return fail(h, BK_E_ARG, "bk_submit_regions: non-ACGT base in reference window"); }
+        max_w = std::max<uint32_t>(max_w, g.window_len);
+        d.n_partners = g.n_partners; d.part_desc_off = h->h_part.size();
+        for (int q = 0; q < g.n_partners; q++) {
+            BkPartnerDesc pd; pd.word_off = win.size(); pd.len = g.partner_lens[q]; pd.pad = 0;
+            size_t nw = (pd.len + 15) / 16 + 2; win.resize(win.size() + nw);
+            if (!pack_seq(g.partners[q], pd.len, win.data() + pd.word_off, (int)nw)) return fail(h, BK_E_ARG, "bk_submit_regions: non-ACGT base in partner window");
+            h->h_part.push_back(pd);
+        }
+        uint32_t cap = 64; while (cap < 2u * (uint32_t)std::max(g.n_reads, 1)) cap <<= 1;
+        d.dedup_cap = cap; d.dedup_off = dd_total; dd_total += cap;
+        // algorithmic HBM bytes per region: 2-bit reads + 4 B/read offsets + window fwd+rc + ~2 KB of output
+        uint64_t bases = 0; for (int i = 0; i < g.n_reads; i++) bases += g.read_lens[i];
+        h->alg_bytes += (bases + 3) / 4 + 4ull * g.n_reads + 2ull * ((g.window_len + 3) / 4) + 2048;
+    }
+    h->total_reads = rlen.size(); h->n_regions = n_regions;
+    // reference k-mer table geometry (LDS): load factor <= 0.5
+    const uint32_t wk2 = max_w >= (uint32_t)k ? 2 * (max_w - k + 1) : 0;
+    uint32_t ref_cap = 1024; while (ref_cap < 2 * wk2) ref_cap <<= 1;
+    h->ref_cap = ref_cap; h->win_words_cap = ((max_w + 15) / 16 + 2 + 3) & ~3u;
+    const size_t lds_k = (32 + 2 * (size_t)h->win_words_cap + ref_cap) * 4;
+    if (lds_k > 160 * 1024 || wk2 >= (1u << 18)) return fail(h, BK_E_LIMIT, "bk_submit_regions: reference window too long for the LDS k-mer set (limit ~9.8 kb in this round)");
+    if (rlen.empty()) { rlen.push_back(0); rflag.push_back(0); }
+    if (reads.empty()) reads.push_back(0);
+    if (sc.empty()) sc.push_back(0);
+    if (sclen.empty()) sclen.push_back(0);
+    if (h->h_part.empty()) h->h_part.push_back(BkPartnerDesc{0, 0, 0});
+    HIPCHK(h, upload(h, h->d_desc, h->h_desc)); HIPCHK(h, upload(h, h->d_part, h->h_part));
+    HIPCHK(h, upload(h, h->d_reads, reads)); HIPCHK(h, upload(h, h->d_rlen, rlen)); HIPCHK(h, upload(h, h->d_rflag, rflag));
+    HIPCHK(h, upload(h, h->d_sc, sc)); HIPCHK(h, upload(h, h->d_sclen, sclen)); HIPCHK(h, upload(h, h->d_win, win));
+    const size_t nr = std::max<size_t>(h->total_reads, 1), nd = std::max<uint64_t>(dd_total, 1);
+    HIPCHK(h, h->d_work.ensure(sizeof(BkRegionWork) * n_regions));
+    HIPCHK(h, h->d_ddslot.ensure(nd * 8)); HIPCHK(h, h->d_ddrep.ensure(nd * 4)); HIPCHK(h, h->d_ddcnt.ensure(nd * 4)); HIPCHK(h, h->d_ddu.ensure(nd * 4));
+    HIPCHK(h, h->d_grp.ensure(nr * 4)); HIPCHK(h, h->d_urep.ensure(nr * 4)); HIPCHK(h, h->d_unr.ensure(nr * 4)); HIPCHK(h, h->d_ufl.ensure(nr));
+    HIPCHK(h, h->d_ubuf.ensure(nr * 4)); HIPCHK(h, h->d_ureads.ensure(nr * 4)); HIPCHK(h, h->d_ufound.ensure(nr * 4)); HIPCHK(h, h->d_uminpos.ensure(nr * 4));
+    HIPCHK(h, h->d_tops.ensure(256));
+    if (h->arena_cap == 0) {
+        uint64_t want = h->cfg.arena_bytes > 0 ? (uint64_t)h->cfg.arena_bytes : std::max<uint64_t>(64ull << 20, (uint64_t)n_regions * (1ull << 20) + h->total_reads * 64ull);
+        h->arena_cap = want;
+    }
+    if (h->out_cap == 0) h->out_cap = std::max<uint64_t>(8ull << 20, (uint64_t)n_regions * (64ull << 10));
+    HIPCHK(h, h->d_arena.ensure(h->arena_cap)); HIPCHK(h, h->d_out.ensure(h->out_cap));
+    HIPCHK(h, hipStreamSynchronize(h->stream));          // host staging vectors go out of scope
+    h->submitted = true; h->ran = false; h->fetched = false;
+    return BK_OK;
+}
+
+static void fill_params(bk_handle *h)
+{
+    BkParams &p = h->params;
+    p.desc = (const BkRegionDesc *)h->d_desc.p; p.work = (BkRegionWork *)h->d_work.p; p.partners = (const BkPartnerDesc *)h->d_part.p;
+    p.reads = (const uint32_t *)h->d_reads.p; p.read_len = (const uint16_t *)h->d_rlen.p; p.read_flag = (const uint8_t *)h->d_rflag.p;
+    p.sc = (const uint32_t *)h->d_sc.p; p.sc_len = (const uint16_t *)h->d_sclen.p; p.windows = (const uint32_t *)h->d_win.p;
+    p.dd_slot = (unsigned long long *)h->d_ddslot.p; p.dd_rep = (uint32_t *)h->d_ddrep.p; p.dd_cnt = (uint32_t *)h->d_ddcnt.p; p.dd_u = (uint32_t *)h->d_ddu.p;
+    p.grp_slot = (uint32_t *)h->d_grp.p; p.urep = (uint32_t *)h->d_urep.p; p.unreads = (uint32_t *)h->d_unr.p; p.uflag = (uint8_t *)h->d_ufl.p;
+    p.ubuf = (int32_t *)h->d_ubuf.p; p.ureads = (int32_t *)h->d_ureads.p; p.ufound = (int32_t *)h->d_ufound.p; p.uminpos = (int32_t *)h->d_uminpos.p;
+    p.arena = (uint8_t *)h->d_arena.p; p.arena_top = (unsigned long long *)h->d_tops.p; p.arena_cap = h->arena_cap;
+    p.out = (uint8_t *)h->d_out.p; p.out_top = (unsigned long long *)h->d_tops.p + 1; p.out_cap = h->out_cap;
+    p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->cfg.max_read_len;
+    p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions;
+}
+
+static size_t asm_lds_bytes(const bk_handle *h)
+{
+    size_t o = (sizeof(BkAsmShared) + 15) / 16 * 16;
+    o += (size_t)h->cfg.max_candidates * 8 + (size_t)2 * (h->cfg.max_read_len + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + (size_t)h->cfg.max_read_len + 16;
+    return (o + 15) / 16 * 16;
+}
+
+static int launch(bk_handle *h, uint32_t mask)
+{
+    fill_params(h);
+    const unsigned long long tops[2] = {256, 256};
+    HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    if (mask & BK_STAGE_KMER) {
+        const size_t lds = (32 + 2 * (size_t)h->win_words_cap + h->ref_cap) * 4;
+        HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bk_kmer_kernel, dim3(h->n_regions), dim3(BK_KT), lds, h->stream, h->params, h->ref_cap, h->win_words_cap);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    if (mask & BK_STAGE_ASSEMBLE) {
+        const size_t lds = asm_lds_bytes(h);
+        HIPCHK(h, hipFuncSetAttribute((const void *)bk_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bk_asm_kernel, dim3(h->n_regions), dim3(BK_AT), lds, h->stream, h->params);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    return BK_OK;
+}
+
+extern "C" int bk_run(bk_handle *h, uint32_t stage_mask)
+{
+    if (!h) return BK_E_ARG;
+    if (!h->submitted) return fail(h, BK_E_STATE, "bk_run: no regions submitted");
+    if ((stage_mask & BK_STAGE_ASSEMBLE) && !(stage_mask & BK_STAGE_KMER)) return fail(h, BK_E_ARG, "bk_run: BK_STAGE_ASSEMBLE needs BK_STAGE_KMER in the same run");
+    if (stage_mask & BK_STAGE_REALIGN) return fail(h, BK_E_ARG, "bk_run: BK_STAGE_REALIGN is not built in this round");
+    HIPCHK(h, hipSetDevice(h->dev));
+    h->ran_mask = stage_mask; h->fetched = false; h->synced = false;
+    int rc = launch(h, stage_mask);
+    if (rc == BK_OK) h->ran = true;
+    return rc;
+}
+
+static const char *st_name(int s)
+{
+    switch (s) {
+    case BK_ST_ARENA: return "device scratch arena exhausted"; case BK_ST_WINDOW: return "reference window too long";
+    case BK_ST_CONTIG: return "contig longer than max_contig_len"; case BK_ST_CAND: return "more candidate reads for one k-mer than max_candidates";
+    case BK_ST_KLIST: return "contig k-mer list overflow"; case BK_ST_READLEN: return "read longer than max_read_len";
+    case BK_ST_OUT: return "output arena exhausted"; case BK_ST_HITS: return "too many alignment hits"; default: return "unknown";
+    }
+}
+
+// wait, read back the work records and the result arena; grow arenas and rerun when they overflowed
+extern "C" int bk_sync(bk_handle *h)
+{
+    if (!h) return BK_E_ARG;
+    if (!h->ran) return fail(h, BK_E_STATE, "bk_sync: nothing was run");
+    if (h->synced) return BK_OK;
+    HIPCHK(h, hipSetDevice(h->dev));
+    for (int attempt = 0; attempt < 6; attempt++) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->h_work.resize(h->n_regions);
+        HIPCHK(h, hipMemcpy(h->h_work.data(), h->d_work.p, sizeof(BkRegionWork) * h->n_regions, hipMemcpyDeviceToHost));
+        bool grow_arena = false, grow_out = false; int bad = -1;
+        for (int r = 0; r < h->n_regions; r++) {
+            int s = h->h_work[r].status;
+            if (s == BK_ST_ARENA) grow_arena = true; else if (s == BK_ST_OUT) grow_out = true; else if (s != BK_ST_OK && bad < 0) bad = r;
+        }
+        if (bad >= 0) return fail(h, BK_E_LIMIT, "region " + std::to_string(bad) + ": " + st_name(h->h_work[bad].status));
+        if (!grow_arena && !grow_out) {
+            for (int i = 0; i < 3; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]); h->ms[i + 1] = ms; }
+            (void)hipEventElapsedTime(&h->ms[0], h->ev[0], h->ev[3]);
+            h->synced = true;
+            return BK_OK;
+        }
+        if (grow_arena) { h->arena_cap *= 4; HIPCHK(h, h->d_arena.ensure(h->arena_cap)); }
+        if (grow_out) { h->out_cap *= 4; HIPCHK(h, h->d_out.ensure(h->out_cap)); }
+        int rc = launch(h, h->ran_mask);
+        if (rc != BK_OK) return rc;
+    }
+    return fail(h, BK_E_NOMEM, "bk_sync: arenas still too small after 6 growth steps");
+}
+
+static int fetch(bk_handle *h)
+{
+    int rc = bk_sync(h);
+    if (rc != BK_OK) return rc;
+    if (h->fetched) return BK_OK;
+    unsigned long long tops[2];
+    HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
+    h->h_out.resize(tops[1]);
+    HIPCHK(h, hipMemcpy(h->h_out.data(), h->d_out.p, tops[1], hipMemcpyDeviceToHost));
+    h->fetched = true;
+    return BK_OK;
+}
+
+extern "C" int bk_last_kernel_ms(bk_handle *h, int which, float *ms)
+{
+    if (!h || !ms || which < 0 || which > 3) return BK_E_ARG;
+    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    *ms = h->ms[which]; return BK_OK;
+}
+
+static void key_to_str(uint64_t lo, uint64_t hi, int k, char *out)
+{
+    for (int t = k - 1; t >= 0; t--) { out[t] = "ACGT"[lo & 3u]; lo = (lo >> 2) | (hi << 62); hi >>= 2; }
+}
+
+extern "C" int bk_get_kmer_count(bk_handle *h, int32_t region, int32_t *n_mers, int32_t *n_unique)
+{
+    if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
+    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    if (n_mers) *n_mers = (int32_t)h->h_work[region].M;
+    if (n_unique) *n_unique = (int32_t)h->h_work[region].U;
+    return BK_OK;
+}
+
+extern "C" int bk_get_kmers(bk_handle *h, int32_t region, char *mers, int32_t *counts, int32_t cap)
+{
+    if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
+    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    const BkRegionWork &w = h->h_work[region];
+    const int n = std::min<int>((int)w.M, cap), k = h->cfg.kmer_size;
+    if (n <= 0) return BK_OK;
+    std::vector<uint64_t> lo(n), hi(n); std::vector<uint32_t> c(n);
+    HIPCHK(h, hipMemcpy(lo.data(), (uint8_t *)h->d_arena.p + w.o_key_lo, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(hi.data(), (uint8_t *)h->d_arena.p + w.o_key_hi, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(c.data(), (uint8_t *)h->d_arena.p + w.o_kcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) { if (mers) key_to_str(lo[i], hi[i], k, mers + (size_t)i * k); if (counts) counts[i] = (int32_t)c[i]; }
+    return BK_OK;
+}
+
+static const BkContigRec *find_contig(bk_handle *h, int region, int contig)
+{
+    uint64_t off = h->h_work[region].o_first_contig;
+    for (int i = 0; off && i < contig; i++) off = ((const BkContigRec *)(h->h_out.data() + off))->next;
+    return off ? (const BkContigRec *)(h->h_out.data() + off) : nullptr;
+}
+
+extern "C" int bk_get_contig_count(bk_handle *h, int32_t region, int32_t *n)
+{
+    if (!h || !n || region < 0 || region >= h->n_regions) return BK_E_ARG;
+    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    *n = (int32_t)h->h_work[region].n_contigs; return BK_OK;
+}
+
+extern "C" int bk_get_contig_info(bk_handle *h, int32_t region, int32_t contig, bk_contig_info *info)
+{
+    if (!h || !info || region < 0 || region >= h->n_regions) return BK_E_ARG;
+    int rc = fetch(h); if (rc != BK_OK) return rc;
+    const BkContigRec *c = find_contig(h, region, contig);
+    if (!c) return fail(h, BK_E_ARG, "bk_get_contig_info: no such contig");
+    info->seq_len = c->seq_len; info->counts_len = c->counts_len; info->n_kmers = c->n_kmers; info->n_reads = c->n_reads; info->total_reads = c->total_reads; info->n_hits = c->n_hits;
+    return BK_OK;
+}
+
+extern "C" int bk_get_contig(bk_handle *h, int32_t region, int32_t contig, char *seq, int32_t *indel_only, int32_t *others, int32_t *kmer_locs, char *kmers, int32_t *reads)
+{
+    if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
+    int rc = fetch(h); if (rc != BK_OK) return rc;
+    const BkContigRec *c = find_contig(h, region, contig);
+    if (!c) return fail(h, BK_E_ARG, "bk_get_contig: no such contig");
+    const uint8_t *b = (const uint8_t *)c; const int k = h->cfg.kmer_size;
+    if (seq) memcpy(seq, b + c->o_seq, c->seq_len);
+    if (indel_only) memcpy(indel_only, b + c->o_io, (size_t)c->counts_len * 4);
+    if (others) memcpy(others, b + c->o_ot, (size_t)c->counts_len * 4);
+    if (kmer_locs) memcpy(kmer_locs, b + c->o_klocs, (size_t)c->seq_len * 4);
+    if (kmers) { const uint64_t *kk = (const uint64_t *)(b + c->o_kmers); for (int i = 0; i < c->n_kmers; i++) key_to_str(kk[2 * i], kk[2 * i + 1], k, kmers + (size_t)i * k); }
+    if (reads) { memcpy(reads, b + c->o_reads, (size_t)c->n_reads * 4); std::sort(reads, reads + c->n_reads); }
+    return BK_OK;
+}
+
+extern "C" int bk_get_hits(bk_handle *h, int32_t, int32_t, bk_psl *, int32_t) { return fail(h, BK_E_ARG, "bk_get_hits: BK_STAGE_REALIGN is not built in this round"); }
+
+extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
+{
+    if (!h || !value) return BK_E_ARG;
+    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    uint64_t v = 0;
+    for (int r = 0; r < h->n_regions; r++) {
+        const BkRegionWork &w = h->h_work[r];
+        switch (which) { case 0: v += w.nw_cells; break; case 1: v += w.nw_calls; break; case 2: v += w.sw_cells; break; case 4: v += w.U; break; case 5: v += w.M; break; case 6: v += w.n_contigs; break; default: break; }
+    }
+    if (which == 3) v = h->alg_bytes;
+    *value = v; return BK_OK;
+}
+
+// ---- batched olc.nw (G1 known-answer tests and the DP micro-benchmark) -------------------------------------
+// seqs: ASCII, pairs (off1,len1,off2,len2) into `seqs`; out: 4 ints per pair (j_start, i_end, i_start, score);
+// reps > 1 repeats each DP (timing); *ms receives the kernel time.
+extern "C" int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, const uint32_t *off1, const uint32_t *len1,
+                           const uint32_t *off2, const uint32_t *len2, int32_t n_pairs, int32_t reps, int32_t *out, float *ms)
+{
+    if (!h || !seqs || n_pairs <= 0 || !out) return BK_E_ARG;
+    HIPCHK(h, hipSetDevice(h->dev));
+    std::vector<uint8_t> codes(seq_bytes);
+    for (size_t i = 0; i < seq_bytes; i++) { char ch = seqs[i]; codes[i] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
+    uint32_t maxm = 0, maxn = 0;
+    for (int i = 0; i < n_pairs; i++) { maxm = std::max(maxm, len1[i]); maxn = std::max(maxn, len2[i]); if (len1[i] == 0 || len2[i] == 0) return fail(h, BK_E_ARG, "bk_nw_batch: empty sequence"); }
+    if (maxm > 4095 || maxn > 4095) return fail(h, BK_E_LIMIT, "bk_nw_batch: sequence longer than 4095");
+    DevBuf dc, d1, d2, d3, d4, dout;
+    size_t nb = (size_t)n_pairs * 4;
+    HIPCHK(h, dc.ensure(seq_bytes)); HIPCHK(h, d1.ensure(nb)); HIPCHK(h, d2.ensure(nb)); HIPCHK(h, d3.ensure(nb)); HIPCHK(h, d4.ensure(nb)); HIPCHK(h, dout.ensure(nb * 4));
+    HIPCHK(h, hipMemcpy(dc.p, codes.data(), seq_bytes, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d1.p, off1, nb, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(d2.p, len1, nb, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d3.p, off2, nb, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(d4.p, len2, nb, hipMemcpyHostToDevice));
+    const size_t lds = ((maxm + 15) & ~15u) + ((maxn + 15) & ~15u) + (size_t)2 * (maxn + 2) * 4;
+    HIPCHK(h, hipFuncSetAttribute((const void *)bk_nw_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+    hipLaunchKernelGGL(bk_nw_batch_kernel, dim3(n_pairs), dim3(64), lds, h->stream, (const uint8_t *)dc.p, (const uint32_t *)d1.p, (const uint32_t *)d2.p,
+                       (const uint32_t *)d3.p, (const uint32_t *)d4.p, (int32_t *)dout.p, reps < 1 ? 1 : reps);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ms) (void)hipEventElapsedTime(ms, h->ev[4], h->ev[5]);
+    HIPCHK(h, hipMemcpy(out, dout.p, nb * 4, hipMemcpyDeviceToHost));
+    dc.release(); d1.release(); d2.release(); d3.release(); d4.release(); dout.release();
+    return BK_OK;
+}

@@ -1,0 +1,707 @@
+// bk_asm.hip.h -- stage BK_STAGE_ASSEMBLE: sv_assembly.init_assembly (sv_assembly.py:30-63) as a
+// device-side state machine, one 256-thread workgroup per target region.
+//
+// The reference's greedy assembler is order dependent (every accepted read changes the contig the
+// next read is aligned to), so within a region the chain is serial; parallelism comes from
+//   * many regions in flight (one workgroup each),
+//   * the two overlap DPs of check_align (sv_assembly.py:451-452) on two wavefronts,
+//   * the lanes of each wavefront along the DP (bk_nw.hip.h),
+//   * the data-parallel bookkeeping (k-mer lists, count vectors, candidate sort) over 256 threads.
+// Only ONE contig is live at a time: buff.contigs is a FIFO whose head is grown to completion, and
+// every other entry is a fresh contig fully described by (seed k-mer, founding read).
+//
+// All threads execute the control flow redundantly on state kept in LDS (struct BkAsmShared);
+// thread 0 commits scalar state between barriers.  Canonicalisations P1/P2/P4 of SURVEY.md 8c.
+#pragma once
+#include "bk_common.h"
+#include "bk_nw.hip.h"
+
+#define BK_AT 256
+
+enum { BK_ORD_FOR = 0, BK_ORD_REV = 1, BK_ORD_MID = 2 };
+enum { BK_DEC_NONE = 0, BK_DEC_SAME = 1, BK_DEC_SUPER = 2, BK_DEC_SUB = 3, BK_DEC_POST = 4, BK_DEC_PRE = 5 };
+
+struct BkAsmShared {
+    int status;
+    // live contig
+    int cbase, clen;             // sequence deque in cseq[]
+    int nbase, nlen, cbuf;       // count-vector deque (global), active buffer
+    int serial, setup, founder, founder_added, in_fifo;
+    int nk;                      // len(contig.kmers)
+    int nr;                      // len(contig.reads)
+    int nalt;
+    // current read
+    int ru, rlen, rn, rindel;
+    // FIFO buff.contigs
+    int phead, ptail;
+    // misc
+    int serial_ctr, stamp_ctr, head, nused;
+    int ncand, dec, dstart, dend, tmp0, tmp1, tmp2;
+    int n_contigs;
+    unsigned long long cells, calls;
+    BkNwResult v1, v2;
+    uint32_t scan[24];
+};
+
+// The context lives in LDS (not in registers: ~60 uniform pointers would spill the SGPR file) at the
+// start of the dynamic LDS block, followed by BkAsmShared and the byte/word buffers (offsets below).
+struct BkAsmCtx {
+    int o_cseq, o_rseq;          // LDS: contig deque (2*MAXC bytes), current read
+    int o_bound;                 // LDS: DP tile boundary
+    int o_cand;                  // LDS: candidate sort keys (max_cand); afterwards int scratch[2*max_cand]
+    int o_candu;                 // LDS: sorted candidate reads (unique-read index)
+    // region data
+    BkRegionWork *wk;
+    uint8_t *out; unsigned long long *out_top; uint64_t out_cap;
+    int rc_thresh; uint32_t read_words, max_len;
+    const uint32_t *reads; const uint16_t *rlen;
+    uint32_t *urep, *unr; uint8_t *ufl; int32_t *ubuf, *ureads, *ufound, *uminpos;
+    const uint32_t *tslot, *trank; const uint64_t *klo, *khi; const uint32_t *kcnt; uint8_t *kstate; int32_t *kstamp;
+    const uint32_t *poff, *post;
+    uint32_t U, M, tmask;
+    // per-region scratch (arena)
+    int32_t *cnt;                // 2 buffers x {io, ot} x 2*MAXC
+    uint32_t *klist, *nklist;    // contig.kmers / refresh snapshot (rank | rev << 31)
+    uint32_t *pend;              // FIFO: 2 words per entry (rank, u)
+    uint32_t *altl, *readl, *usedl;
+    int MAXC, MAXR, MAXCAND, KCAP, k;
+};
+
+#define BK_TID ((int)threadIdx.x)
+#define BK_SYNC() __syncthreads()
+
+extern __shared__ __attribute__((aligned(16))) uint8_t bk_lds[];
+#define BK_SH_OFF ((int)((sizeof(BkAsmCtx) + 15) / 16 * 16))
+#define BK_BUF_OFF ((int)(BK_SH_OFF + (sizeof(BkAsmShared) + 15) / 16 * 16))
+#define C_ (*(BkAsmCtx *)bk_lds)
+#define S_ ((BkAsmShared *)(bk_lds + BK_SH_OFF))
+#define L_CSEQ (bk_lds + C_.o_cseq)
+#define L_RSEQ (bk_lds + C_.o_rseq)
+#define L_BOUND ((int *)(bk_lds + C_.o_bound))
+#define L_CAND ((unsigned long long *)(bk_lds + C_.o_cand))
+#define L_CANDU ((uint32_t *)(bk_lds + C_.o_candu))
+
+__device__ inline int32_t *bk_cnt_io(int buf) { return C_.cnt + (size_t)buf * 4 * C_.MAXC; }
+__device__ inline int32_t *bk_cnt_ot(int buf) { return C_.cnt + (size_t)buf * 4 * C_.MAXC + 2 * C_.MAXC; }
+
+__device__ inline void bk_fail(int st) { if (BK_TID == 0 && S_->status == 0) S_->status = st; }
+
+// k-mer key of LDS bytes s[0..k)
+__device__ inline BkKey bk_bytes_kmer(const uint8_t *s, int k) { BkKey key; key.hi = 0; key.lo = 0; for (int i = 0; i < k; i++) key_push(key, s[i], 64); return key; }
+
+// sample k-mer table lookup -> rank or -1 (any state)
+__device__ inline int bk_lookup(const BkKey &key)
+{
+    if (C_.M == 0) return -1;
+    uint32_t s = key_hash(key) & C_.tmask;
+    for (;;) {
+        uint32_t cur = C_.tslot[s];
+        if (cur == BK_EMPTY32) return -1;
+        uint32_t rk = C_.trank[s];
+        if (rk != BK_EMPTY32 && C_.klo[rk] == key.lo && C_.khi[rk] == key.hi) return (int)rk;
+        s = (s + 1) & C_.tmask;
+    }
+}
+
+__device__ inline uint32_t bk_scan256(uint32_t v, uint32_t *scr, uint32_t *total)
+{
+    const int lane = BK_TID & 63, wv = BK_TID >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    BK_SYNC();
+    if (lane == 63) scr[wv] = inc;
+    BK_SYNC();
+    uint32_t base = 0, tot = 0;
+    for (int i = 0; i < BK_AT / 64; i++) { uint32_t t = scr[i]; if (i < wv) base += t; tot += t; }
+    *total = tot;
+    BK_SYNC();
+    return base + inc - v;
+}
+__device__ inline int bk_max256(int v, uint32_t *scr)
+{
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    BK_SYNC();
+    if ((BK_TID & 63) == 0) scr[BK_TID >> 6] = (uint32_t)v;
+    BK_SYNC();
+    int r = (int)scr[0];
+    for (int i = 1; i < BK_AT / 64; i++) r = max(r, (int)scr[i]);
+    BK_SYNC();
+    return r;
+}
+
+// ---- unpack unique read u into rseq (LDS bytes) ----------------------------------------------------
+__device__ inline void bk_load_read(int u)
+{
+    const uint32_t i = C_.urep[u];
+    const int len = C_.rlen[i];
+    const uint32_t *w = C_.reads + (uint64_t)i * C_.read_words;
+    BK_SYNC();
+    for (int t = BK_TID; t < len; t += BK_AT) L_RSEQ[t] = (uint8_t)seq_base(w, t);
+    if (BK_TID == 0) { S_->ru = u; S_->rlen = len; S_->rn = (int)C_.unr[u]; S_->rindel = (C_.ufl[u] & BK_R_INDEL) ? 1 : 0; }
+    BK_SYNC();
+}
+
+// ---- assembly_counts (sv_assembly.py:160-221) --------------------------------------------------------
+__device__ inline void bk_set_counts(int start, int end, int nreads, int indel)   // :195-199 with python slice clipping
+{
+    BkAsmShared *S = S_;
+    const int e = min(end, S->nlen);
+    int32_t *v = (indel ? bk_cnt_io(S->cbuf) : bk_cnt_ot(S->cbuf)) + S->nbase;
+    for (int t = start + BK_TID; t < e; t += BK_AT) v[t] += nreads;
+    BK_SYNC();
+}
+__device__ inline void bk_extend_counts(int l, int nreads, int indel, bool post)   // :201-221
+{
+    BkAsmShared *S = S_;
+    int32_t *io = bk_cnt_io(S->cbuf), *ot = bk_cnt_ot(S->cbuf);
+    const int at = post ? S->nbase + S->nlen : S->nbase - l;
+    if (at < 0 || at + l > 2 * C_.MAXC) { bk_fail(BK_ST_CONTIG); BK_SYNC(); return; }
+    for (int t = BK_TID; t < l; t += BK_AT) { io[at + t] = indel ? nreads : 0; ot[at + t] = indel ? 0 : nreads; }
+    BK_SYNC();
+    if (BK_TID == 0) { if (!post) S->nbase -= l; S->nlen += l; }
+    BK_SYNC();
+}
+// set_superseq :181-193 incl. the zip()-truncating slice assignment (Q8); new vectors go to the other buffer
+__device__ inline void bk_counts_superseq(int rlen, int nreads, int indel, int start, int end)
+{
+    BkAsmShared *S = S_;
+    const int s = min(start, rlen), e = max(min(end, rlen), s);
+    const int seg = e - s, z = min(seg, S->nlen), nl = rlen - seg + z;
+    const int nb = C_.MAXC - nl, ob = S->nbase, obuf = S->cbuf, nbuf = obuf ^ 1;
+    const int32_t *oio = bk_cnt_io(obuf) + ob, *oot = bk_cnt_ot(obuf) + ob;
+    int32_t *nio = bk_cnt_io(nbuf) + nb, *not_ = bk_cnt_ot(nbuf) + nb;
+    const int bi = indel ? nreads : 0, bo = indel ? 0 : nreads;
+    for (int w = BK_TID; w < nl; w += BK_AT) {
+        int a = bi, b = bo;
+        if (w >= s && w < s + z) { a += oio[w - s]; b += oot[w - s]; }
+        nio[w] = a; not_[w] = b;
+    }
+    BK_SYNC();
+    if (BK_TID == 0) { S->cbuf = nbuf; S->nbase = nb; S->nlen = nl; }
+    BK_SYNC();
+}
+__device__ inline int bk_total_reads()                                                   // :178-179
+{
+    BkAsmShared *S = S_;
+    const int32_t *io = bk_cnt_io(S->cbuf) + S->nbase, *ot = bk_cnt_ot(S->cbuf) + S->nbase;
+    int a = -0x7FFFFFFF, b = -0x7FFFFFFF;
+    for (int t = BK_TID; t < S->nlen; t += BK_AT) { a = max(a, io[t]); b = max(b, ot[t]); }
+    a = bk_max256(a, S->scan); b = bk_max256(b, S->scan);
+    return a + b;
+}
+
+// ---- get_read_kmers_ordered (sv_assembly.py:126-143) on cseq[s0 .. s0+L) ---------------------------------
+// order MID replaces contig.kmers (set_kmers :548-550), FOR/REV extend it (:525-527, :543-545).
+// P1: m = L // 2 ; Q1: positions range(0, L-k).
+__device__ inline void bk_kmers_ordered(int s0, int L, int order)
+{
+    BkAsmShared *S = S_;
+    const int k = C_.k, np = L - k;                      // number of positions
+    int *tmp = (int *)L_CAND;                           // rank per position (or -1)
+    const int m = L / 2;
+    if (np > 2 * C_.MAXCAND) { bk_fail(BK_ST_KLIST); BK_SYNC(); return; }
+    for (int x = BK_TID; x < np; x += BK_AT) {
+        BkKey key = bk_bytes_kmer(L_CSEQ + s0 + x, k);
+        int rk = bk_lookup(key);
+        if (rk >= 0 && C_.kstate[rk] == BK_K_REMOVED) rk = -1;          // not in akmers.smers_set
+        tmp[x] = rk;
+    }
+    BK_SYNC();
+    const int chunk = (max(np, 0) + BK_AT - 1) / BK_AT, b = BK_TID * chunk, e = min(np, b + chunk);
+    uint32_t cnt = 0, T;
+    for (int x = b; x < e; x++) cnt += tmp[x] >= 0;
+    uint32_t pre = bk_scan256(cnt, S->scan, &T);
+    // pre_m = number of valid positions < m
+    if (order == BK_ORD_MID) {
+        if (BK_TID == 0) S->tmp0 = (int)T;              // default when m >= np
+        BK_SYNC();
+        if (m >= b && m < e) { uint32_t q = pre; for (int x = b; x < m; x++) q += tmp[x] >= 0; S->tmp0 = (int)q; }
+        BK_SYNC();
+    }
+    const int pre_m = S->tmp0;
+    const int base = (order == BK_ORD_MID) ? 0 : S->nk;
+    if (base + (int)T > C_.KCAP) { bk_fail(BK_ST_KLIST); BK_SYNC(); return; }
+    uint32_t q = pre;
+    for (int x = b; x < e; x++) {
+        int rk = tmp[x];
+        if (rk < 0) continue;
+        int idx; uint32_t rev;
+        if (order == BK_ORD_FOR) { idx = (int)q; rev = 1u; }                            // get_mer_reads :610-611: 'for' -> 'rev'
+        else if (order == BK_ORD_REV) { idx = (int)T - 1 - (int)q; rev = 0u; }
+        else { if (x >= m) { idx = (int)q - pre_m; rev = 1u; } else { idx = (int)T - 1 - (int)q; rev = 0u; } }   // :142 sorted by (x<m, |x-m|); :607-609
+        C_.klist[base + idx] = (uint32_t)rk | (rev << 31);
+        q++;
+    }
+    BK_SYNC();
+    if (BK_TID == 0) { S->nk = base + (int)T; if (order == BK_ORD_MID) S->setup = 1; }
+    BK_SYNC();
+}
+
+// ---- find_reads (sv_assembly.py:111-122) from the posting list of k-mer `rank` -------------------------
+// key (pos, -len) / (-pos, -len); stable sort ties keep fq_recs order = unique index u.
+__device__ inline void bk_find_reads(int rank, bool rev, bool filter)
+{
+    BkAsmShared *S = S_;
+    const uint32_t b = C_.poff[rank], e = C_.poff[rank + 1];
+    if (BK_TID == 0) S->ncand = 0;
+    BK_SYNC();
+    // first occurrence of the k-mer in each read (re.search): min pos per read
+    for (uint32_t i = b + BK_TID; i < e; i += BK_AT) { uint32_t en = C_.post[i]; atomicMin(&C_.uminpos[en >> 10], (int)(en & 1023u)); }
+    BK_SYNC();
+    for (uint32_t i = b + BK_TID; i < e; i += BK_AT) {
+        uint32_t en = C_.post[i], u = en >> 10; int pos = (int)(en & 1023u);
+        if (C_.uminpos[u] != pos) continue;
+        if (C_.ufl[u] & BK_R_DELETED) continue;                                  // deleted from fq_recs (rb.clean :390)
+        if (filter && C_.ubuf[u] == S->serial) continue;                         // ids - self.buffer (:115-116)
+        int idx = atomicAdd(&S->ncand, 1);
+        if (idx < C_.MAXCAND) {
+            unsigned long long len = C_.rlen[C_.urep[u]];
+            unsigned long long pk = rev ? (unsigned long long)(0xFFFF - pos) : (unsigned long long)pos;
+            L_CAND[idx] = (pk << 40) | ((0xFFFFull - len) << 24) | u;
+        }
+    }
+    BK_SYNC();
+    for (uint32_t i = b + BK_TID; i < e; i += BK_AT) C_.uminpos[C_.post[i] >> 10] = 0x7FFFFFFF;
+    const int n = S->ncand;
+    if (n > C_.MAXCAND) { bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); return; }
+    int npad = 1; while (npad < n) npad <<= 1;
+    for (int i = n + BK_TID; i < npad; i += BK_AT) L_CAND[i] = ~0ull;
+    BK_SYNC();
+    for (int sz = 2; sz <= npad; sz <<= 1)
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = BK_TID; i < npad / 2; i += BK_AT) {
+                int lo = (i / st) * (st * 2) + (i % st), hi = lo + st;
+                bool up = ((lo & sz) == 0);
+                unsigned long long a = L_CAND[lo], bb = L_CAND[hi];
+                if ((a > bb) == up) { L_CAND[lo] = bb; L_CAND[hi] = a; }
+            }
+            BK_SYNC();
+        }
+    for (int i = BK_TID; i < n; i += BK_AT) L_CANDU[i] = (uint32_t)(L_CAND[i] & 0xFFFFFFull);
+    BK_SYNC();
+}
+
+// first occurrence of the k-mer bytes `pat` in seq[0..n) (str.find), executed by wave 0; result to *out
+__device__ inline int bk_find_bytes_wave(const uint8_t *seq, int n, const uint8_t *pat, int k)
+{
+    const int lane = BK_TID & 63;
+    for (int b = 0; b + k <= n + 63; b += 64) {
+        int x = b + lane; bool ok = x + k <= n;
+        for (int t = 0; ok && t < k; t++) ok = seq[x + t] == pat[t];
+        unsigned long long m = __ballot(ok);
+        if (m) return b + __ffsll((long long)m) - 1;
+        if (b + 64 + k > n) break;
+    }
+    return -1;
+}
+
+// ---- contig life cycle ------------------------------------------------------------------------------
+__device__ inline void bk_contig_new(int rank, int u, bool in_fifo)                  // contig.__init__ :417-426
+{
+    BkAsmShared *S = S_;
+    bk_load_read(u);
+    const int len = S->rlen, nreads = S->rn, indel = S->rindel;
+    if (len > C_.MAXC) { bk_fail(BK_ST_CONTIG); BK_SYNC(); return; }
+    const int base = C_.MAXC - len;
+    for (int t = BK_TID; t < len; t += BK_AT) L_CSEQ[base + t] = L_RSEQ[t];
+    int32_t *io = bk_cnt_io(0) + base, *ot = bk_cnt_ot(0) + base;
+    for (int t = BK_TID; t < len; t += BK_AT) { io[t] = indel ? nreads : 0; ot[t] = indel ? 0 : nreads; }      // :162-165
+    BK_SYNC();
+    if (BK_TID == 0) {
+        S->cbase = base; S->clen = len; S->nbase = base; S->nlen = len; S->cbuf = 0;
+        S->serial = ++S->serial_ctr; S->setup = 0; S->founder = u; S->founder_added = 0; S->in_fifo = in_fifo ? 1 : 0;
+        S->nk = 0; S->nr = 0; S->nalt = 0;
+        C_.kstamp[3 * rank] = S->serial;                 // checked_kmers = [kmer_val]
+        C_.ubuf[u] = S->serial;                          // buffer = set([read.id])
+    }
+    BK_SYNC();
+}
+__device__ inline void bk_fifo_push(int rank, int u)                                 // buffer.add_contig :337-340 (thread 0)
+{
+    BkAsmShared *S = S_;
+    if (C_.ufound[u] >= 0 || (C_.ufl[u] & BK_R_USED)) return;
+    C_.pend[2 * S->ptail] = (uint32_t)rank; C_.pend[2 * S->ptail + 1] = (uint32_t)u;
+    C_.ufound[u] = S->ptail; S->ptail++; C_.ufl[u] |= BK_R_USED;
+}
+__device__ inline void bk_add_used_mer(int rank)                                     // thread 0
+{
+    if (C_.kstate[rank] == BK_K_LIVE) { C_.kstate[rank] = BK_K_USED; C_.usedl[S_->nused++] = (uint32_t)rank; }
+}
+
+// ---- check_align (sv_assembly.py:449-504) + check_read (:552-566) -------------------------------------
+// `rank` = the k-mer that recruited the read.  Returns (uniform) whether the read matched.
+__device__ inline bool bk_check_read(int rank, int u, bool grow)
+{
+    BkAsmShared *S = S_;
+    const int k = C_.k;
+    bk_load_read(u);
+    if (BK_TID == 0) C_.ubuf[u] = S->serial;                                       // self.buffer.add(read.id)
+    const int clen = S->clen, rl = S->rlen, nreads = S->rn, indel = S->rindel;
+    const uint8_t *cs = L_CSEQ + S->cbase;
+    // the two overlap DPs on wavefronts 0 and 1 (:451-452)
+    const int wv = BK_TID >> 6;
+    if (wv == 0) { BkNwResult r = bk_nw_wave(cs, clen, L_RSEQ, rl, L_BOUND); if ((BK_TID & 63) == 0) S->v1 = r; }
+    else if (wv == 1) { BkNwResult r = bk_nw_wave(L_RSEQ, rl, cs, clen, nullptr); if ((BK_TID & 63) == 0) S->v2 = r; }
+    BK_SYNC();
+    const BkNwResult v1 = S->v1, v2 = S->v2;
+    int dec = BK_DEC_NONE, ds = 0, de = 0;          // uniform: computed identically by every thread
+    bool tie = false;
+    {
+        const int minlen = min(clen, rl);
+        // :459-465 exact integer form: score >= minlen/4.0 ; round(score/overlap, 2) >= 0.90
+        const bool ok1 = (4 * v1.score >= minlen) && (200 * v1.score >= 179 * (clen - v1.j_start));
+        const bool ok2 = (4 * v2.score >= minlen) && (200 * v2.score >= 179 * (rl - v2.j_start));
+        if (!ok1 && !ok2) dec = BK_DEC_NONE;
+        else if (v1.score == v2.score && v1.j_start == 0 && v1.i_start == 0 && clen == rl) dec = BK_DEC_SAME;   // :466-468 (Q9)
+        else if (v1.score == v2.score) {
+            if (clen < rl || v1.j_start == 0) { dec = BK_DEC_SUPER; ds = v1.i_start; de = v1.i_end; }            // :471-479
+            else if (rl < clen || v2.j_start == 0) { dec = BK_DEC_SUB; ds = v2.i_start; de = v2.i_end; }         // :480-482
+            else tie = true;                                                                                  // :483-496
+        } else if (v1.score > v2.score) {                                                                     // :497-499 -> :506-528
+            if (v1.j_start == 0) { dec = BK_DEC_SUPER; ds = v1.i_start; de = v1.i_end; } else dec = BK_DEC_POST;
+        } else {                                                                                              // :500-503 -> :530-546
+            if (v2.j_start == 0) { dec = BK_DEC_SUB; ds = v2.i_start; de = v2.i_end; } else dec = BK_DEC_PRE;
+        }
+    }
+    if (tie) {
+        // k-mer position tie-break: x.replace('-','') of the aligned strings are the plain slices
+        if (wv == 0) {
+            uint8_t pat[64];
+            { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank];
+              for (int t = k - 1; t >= 0; t--) { pat[t] = (uint8_t)(key.lo & 3u); key.lo = (key.lo >> 2) | (key.hi << 62); key.hi >>= 2; } }
+            int i11 = bk_find_bytes_wave(cs + v1.j_start, clen - v1.j_start, pat, k);
+            int i12 = bk_find_bytes_wave(L_RSEQ + v1.i_start, v1.i_end - v1.i_start, pat, k);
+            int i21 = bk_find_bytes_wave(L_RSEQ + v2.j_start, rl - v2.j_start, pat, k);
+            int i22 = bk_find_bytes_wave(cs + v2.i_start, v2.i_end - v2.i_start, pat, k);
+            int d = BK_DEC_NONE;
+            if (i11 > -1 && i12 > -1) { if ((i21 == -1 && i22 == -1) || (abs(i21 - i22) > abs(i11 - i12))) d = BK_DEC_POST; }
+            else if (i21 > -1 && i22 > -1) { if ((i11 == -1 && i12 == -1) || (abs(i21 - i22) < abs(i11 - i12))) d = BK_DEC_PRE; }
+            if (BK_TID == 0) S->dec = d;
+        }
+        BK_SYNC();
+        dec = S->dec;
+        // contig_overlap_read / read_overlap_contig re-test the containment case (:508, :531)
+        if (dec == BK_DEC_POST && v1.j_start == 0) { dec = BK_DEC_SUPER; ds = v1.i_start; de = v1.i_end; }
+        if (dec == BK_DEC_PRE && v2.j_start == 0) { dec = BK_DEC_SUB; ds = v2.i_start; de = v2.i_end; }
+        BK_SYNC();
+    }
+    if (BK_TID == 0) { S->cells += 2ull * (unsigned long long)clen * (unsigned long long)rl; S->calls += 2; }
+    // ---- apply ---------------------------------------------------------------------------------------
+    if (dec == BK_DEC_SUPER) {                                                    // aseq.set_superseq :232-236
+        bk_counts_superseq(rl, nreads, indel, ds, de);
+        const int base = C_.MAXC - rl;
+        for (int t = BK_TID; t < rl; t += BK_AT) L_CSEQ[base + t] = L_RSEQ[t];
+        BK_SYNC();
+        if (BK_TID == 0) { S->cbase = base; S->clen = rl; }
+        BK_SYNC();
+        if (grow) bk_kmers_ordered(S->cbase, S->clen, BK_ORD_MID);              // set_kmers(skmers) :479/:515
+    } else if (dec == BK_DEC_SUB) {                                               // add_subseq :238-240
+        bk_set_counts(ds, de, nreads, indel);
+    } else if (dec == BK_DEC_POST) {                                              // :520-527, add_postseq :243-250
+        const int pl = max(rl - v1.i_end, 0);
+        if (S->cbase + clen + pl > 2 * C_.MAXC || clen + pl > C_.MAXC) { bk_fail(BK_ST_CONTIG); BK_SYNC(); }
+        else {
+            for (int t = BK_TID; t < pl; t += BK_AT) L_CSEQ[S->cbase + clen + t] = L_RSEQ[v1.i_end + t];
+            BK_SYNC();
+            if (BK_TID == 0) S->clen = clen + pl;
+            BK_SYNC();
+            bk_set_counts(v1.j_start, clen, nreads, indel);
+            bk_extend_counts(pl, nreads, indel, true);
+            if (grow) { const int from = max(clen - (k - 1), 0); bk_kmers_ordered(S->cbase + from, (clen - from) + pl, BK_ORD_FOR); }
+        }
+    } else if (dec == BK_DEC_PRE) {                                               // :538-545, add_preseq :255-262
+        const int pl = v2.j_start;
+        if (S->cbase - pl < 0 || clen + pl > C_.MAXC) { bk_fail(BK_ST_CONTIG); BK_SYNC(); }
+        else {
+            for (int t = BK_TID; t < pl; t += BK_AT) L_CSEQ[S->cbase - pl + t] = L_RSEQ[t];
+            BK_SYNC();
+            if (BK_TID == 0) { S->cbase -= pl; S->clen = clen + pl; }
+            BK_SYNC();
+            bk_set_counts(v2.i_start, v2.i_end, nreads, indel);                 // old coordinates first (:261)
+            bk_extend_counts(pl, nreads, indel, false);
+            if (grow) bk_kmers_ordered(S->cbase, pl + min(k - 1, clen), BK_ORD_REV);
+        }
+    }
+    const bool match = dec != BK_DEC_NONE;
+    // check_read bookkeeping (:558-565)
+    if (BK_TID == 0) {
+        if (match) {
+            C_.ufl[u] |= BK_R_USED;
+            if (C_.ureads[u] != S->serial) { C_.ureads[u] = S->serial; C_.readl[S->nr++] = (uint32_t)u; }
+        } else if (C_.kcnt[rank] > 2 && !(C_.ufl[u] & BK_R_USED)) {
+            if (S->nalt < C_.MAXCAND) C_.altl[S->nalt++] = (uint32_t)u; else S->status = BK_ST_CAND;
+        } else C_.ufl[u] |= BK_R_DELETED;                                          // rb.delete -> rb.clean :390
+    }
+    BK_SYNC();
+    return match;
+}
+
+// ---- check_alt_reads (sv_assembly.py:568-582) + the adds of finalize (:590-592) -------------------------
+__device__ inline void bk_check_alt_reads()
+{
+    BkAsmShared *S = S_;
+    const int k = C_.k;
+    const int nalt = S->nalt;
+    if (nalt == 0) return;
+    BK_SYNC();
+    if (BK_TID == 0) S->tmp2 = ++S->stamp_ctr;          // identifies mer_set of this call
+    BK_SYNC();
+    const int fin = S->tmp2;
+    int *tmp = (int *)L_CAND;
+    for (int a = 0; a < nalt; a++) {
+        const int u = (int)C_.altl[a];
+        bk_load_read(u);
+        const int len = S->rlen, np = len - k;
+        // x = get_read_kmers(read) - used_mers - mer_set   (set(self.kmers) holds tuples: removes nothing)
+        BkKey best; best.hi = ~0ull; best.lo = ~0ull; int bestrk = -1; int anyx = 0;
+        for (int x = BK_TID; x < np; x += BK_AT) {
+            BkKey key = bk_bytes_kmer(L_RSEQ + x, k);
+            int rk = bk_lookup(key);
+            if (rk >= 0 && (C_.kstate[rk] != BK_K_LIVE || C_.kstamp[3 * rk + 1] == fin)) rk = -1;
+            tmp[x] = rk;
+            if (rk >= 0) { anyx = 1; if (C_.kcnt[rk] > 1 && key_lt(key, best)) { best = key; bestrk = rk; } }   // sorted(x) (P2): smallest mer with count > 1
+        }
+        // reduce the minimum key over the block
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned long long oh = __shfl_xor(best.hi, o), ol = __shfl_xor(best.lo, o); int ork = __shfl_xor(bestrk, o);
+            BkKey ob; ob.hi = oh; ob.lo = ol;
+            if (ork >= 0 && (bestrk < 0 || key_lt(ob, best))) { best = ob; bestrk = ork; }
+        }
+        unsigned long long *red = (unsigned long long *)(tmp + 2 * C_.MAXCAND - 32);   // tail of the scratch: 4 x (hi, lo, rk)
+        BK_SYNC();
+        if ((BK_TID & 63) == 0) { int w = BK_TID >> 6; red[3 * w] = best.hi; red[3 * w + 1] = best.lo; red[3 * w + 2] = (unsigned long long)(long long)bestrk; }
+        BK_SYNC();
+        { best.hi = red[0]; best.lo = red[1]; bestrk = (int)(long long)red[2];
+          for (int w = 1; w < BK_AT / 64; w++) { BkKey ob; ob.hi = red[3 * w]; ob.lo = red[3 * w + 1]; int ork = (int)(long long)red[3 * w + 2];
+              if (ork >= 0 && (bestrk < 0 || key_lt(ob, best))) { best = ob; bestrk = ork; } } }
+        BK_SYNC();
+        (void)anyx;
+        if (bestrk >= 0) {
+            for (int x = BK_TID; x < np; x += BK_AT) if (tmp[x] >= 0) C_.kstamp[3 * tmp[x] + 1] = fin;       // mer_set = mer_set | x
+            if (BK_TID == 0) bk_fifo_push(bestrk, u);
+        }
+        BK_SYNC();
+    }
+}
+
+// ---- finalize (sv_assembly.py:584-599) ----------------------------------------------------------------
+__device__ inline void bk_finalize(bool setup)
+{
+    BkAsmShared *S = S_;
+    if (setup) bk_kmers_ordered(S->cbase, S->clen, BK_ORD_MID);                 // set_kmers(akmers.smers_set)
+    bk_check_alt_reads();
+    BK_SYNC();
+    if (BK_TID == 0) {
+        if (!S->founder_added) {                                                  // batch_reads[0] = founder, aligned (:383)
+            S->founder_added = 1; int u = S->founder;
+            if (C_.ureads[u] != S->serial) { C_.ureads[u] = S->serial; C_.readl[S->nr++] = (uint32_t)u; }
+        }
+        S->nalt = 0;
+    }
+    BK_SYNC();
+}
+
+// ---- contig.grow (sv_assembly.py:616-649) --------------------------------------------------------------
+__device__ inline void bk_grow()
+{
+    BkAsmShared *S = S_;
+    if (!S->setup) bk_kmers_ordered(S->cbase, S->clen, BK_ORD_MID);
+    for (;;) {
+        if (S->status) return;
+        // refresh_kmers :601-602 -> snapshot list
+        const int nk = S->nk;
+        const int chunk = (nk + BK_AT - 1) / BK_AT, b = BK_TID * chunk, e = min(nk, b + chunk);
+        uint32_t cnt = 0, T;
+        for (int t = b; t < e; t++) cnt += C_.kstamp[3 * (C_.klist[t] & 0x7FFFFFFFu)] != S->serial;
+        uint32_t pre = bk_scan256(cnt, S->scan, &T);
+        for (int t = b; t < e; t++) { uint32_t en = C_.klist[t]; if (C_.kstamp[3 * (en & 0x7FFFFFFFu)] != S->serial) C_.nklist[pre++] = en; }
+        BK_SYNC();
+        if (T == 0) break;
+        for (uint32_t t = 0; t < T; t++) {
+            if (S->status) return;
+            const uint32_t en = C_.nklist[t]; const int rank = (int)(en & 0x7FFFFFFFu); const bool rev = (en >> 31) != 0;
+            bk_find_reads(rank, rev, true);                                    // get_mer_reads :604-614
+            if (BK_TID == 0) bk_add_used_mer(rank);
+            BK_SYNC();
+            const int n = S->ncand;
+            for (int q = 0; q < n; q++) {
+                if (S->status) return;
+                const int u = (int)L_CANDU[q];          // L_CAND itself is scratch from here on
+                const bool hit = bk_check_read(rank, u, true);
+                if (hit && BK_TID == 0) { int pidx = C_.ufound[u]; if (pidx >= 0) { C_.pend[2 * pidx] = BK_EMPTY32; C_.ufound[u] = -1; } }   // buff.remove_contig :638-639
+                BK_SYNC();
+            }
+            bk_finalize(false);
+            if (BK_TID == 0) C_.kstamp[3 * rank] = S->serial;                       // checked_kmers.append(mer)
+            BK_SYNC();
+        }
+    }
+}
+
+// ---- init_assembly keeps a contig iff support >= rc_thresh and len > read_len (sv_assembly.py:53-59);
+//      set_kmer_locs (:434-438) and the record the host reads back ------------------------------------------
+__device__ inline void bk_emit_contig()
+{
+    BkAsmShared *S = S_;
+    const int total = bk_total_reads();
+    if (total < C_.rc_thresh || S->clen <= (int)C_.max_len) return;
+    const int k = C_.k, len = S->clen, nlen = S->nlen, nk = S->nk, nr = S->nr;
+    const uint32_t o_seq = (uint32_t)sizeof(BkContigRec), o_io = (uint32_t)bk_align_up(o_seq + len, 8), o_ot = o_io + 4u * nlen,
+                   o_kl = o_ot + 4u * nlen, o_km = (uint32_t)bk_align_up(o_kl + 4u * len, 8), o_rd = o_km + 16u * nk, size = (uint32_t)bk_align_up(o_rd + 4u * nr, 8);
+    BK_SYNC();
+    if (BK_TID == 0) {
+        uint64_t need = bk_align_up(size, 256);
+        uint64_t off = atomicAdd(C_.out_top, (unsigned long long)need);
+        if (off + need > C_.out_cap) { off = 0; S->status = BK_ST_OUT; }
+        S->scan[20] = (uint32_t)off; S->scan[21] = (uint32_t)(off >> 32);
+    }
+    BK_SYNC();
+    const uint64_t off = ((uint64_t)S->scan[21] << 32) | S->scan[20];
+    if (off == 0) return;                                 // offset 0 is reserved (out_top starts at 256)
+    uint8_t *rec = C_.out + off;
+    BkContigRec *h = (BkContigRec *)rec;
+    char *oseq = (char *)(rec + o_seq); int32_t *oio = (int32_t *)(rec + o_io), *oot = (int32_t *)(rec + o_ot), *okl = (int32_t *)(rec + o_kl);
+    uint64_t *okm = (uint64_t *)(rec + o_km); uint32_t *ord_ = (uint32_t *)(rec + o_rd);
+    const uint8_t *cs = L_CSEQ + S->cbase;
+    const int32_t *io = bk_cnt_io(S->cbuf) + S->nbase, *ot = bk_cnt_ot(S->cbuf) + S->nbase;
+    for (int t = BK_TID; t < len; t += BK_AT) { oseq[t] = "ACGT"[cs[t]]; okl[t] = 0; }
+    for (int t = BK_TID; t < nlen; t += BK_AT) { oio[t] = io[t]; oot[t] = ot[t]; }
+    for (int t = BK_TID; t < nk; t += BK_AT) { uint32_t rk = C_.klist[t] & 0x7FFFFFFFu; okm[2 * t] = C_.klo[rk]; okm[2 * t + 1] = C_.khi[rk]; }
+    for (int t = BK_TID; t < nr; t += BK_AT) ord_[t] = C_.urep[C_.readl[t]];
+    // first occurrence of every sample k-mer in the contig (str.find over all len-k+1 positions)
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { int rk = bk_lookup(bk_bytes_kmer(cs + x, k)); if (rk >= 0) atomicMin(&C_.kstamp[3 * rk + 2], x); }
+    BK_SYNC();
+    for (int t = BK_TID; t < nk; t += BK_AT) {
+        int pos = C_.kstamp[3 * (C_.klist[t] & 0x7FFFFFFFu) + 2];
+        if (pos == 0x7FFFFFFF) continue;                 // find() == -1: the python slice [-1:k-1] is empty for len >= k
+        for (int q = pos; q < min(pos + k, len); q++) atomicAdd(&okl[q], 1);
+    }
+    BK_SYNC();
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { int rk = bk_lookup(bk_bytes_kmer(cs + x, k)); if (rk >= 0) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
+    if (BK_TID == 0) {
+        h->next = 0; h->seq_len = len; h->counts_len = nlen; h->n_kmers = nk; h->n_reads = nr; h->total_reads = total; h->n_hits = 0;
+        h->o_seq = o_seq; h->o_io = o_io; h->o_ot = o_ot; h->o_klocs = o_kl; h->o_kmers = o_km; h->o_reads = o_rd; h->o_hits = 0; h->size = size;
+        if (C_.wk->o_first_contig == 0) C_.wk->o_first_contig = off; else ((BkContigRec *)(C_.out + C_.wk->o_last_contig))->next = off;
+        C_.wk->o_last_contig = off; S->n_contigs++;
+    }
+    BK_SYNC();
+}
+
+// ---- setup_contigs (sv_assembly.py:11-26) -----------------------------------------------------------------
+__device__ inline void bk_setup_contigs(int rank)
+{
+    BkAsmShared *S = S_;
+    bk_find_reads(rank, false, false);                                         // used_reads = set()
+    if (BK_TID == 0) bk_add_used_mer(rank);
+    BK_SYNC();
+    const int n = S->ncand;
+    if (n == 0 || S->status) return;
+    // the candidate list must survive the check_read calls below: candu is not touched by them
+    const int u0 = (int)L_CANDU[0];
+    const bool in_fifo = C_.ufound[u0] < 0 && !(C_.ufl[u0] & BK_R_USED);            // buff.add_contig :337-340
+    BK_SYNC();
+    bk_contig_new(rank, u0, in_fifo);
+    if (BK_TID == 0 && in_fifo) C_.ufl[u0] |= BK_R_USED;
+    BK_SYNC();
+    for (int q = 1; q < n; q++) { if (S->status) return; bk_check_read(rank, (int)L_CANDU[q], false); }
+    bk_finalize(true);
+    if (in_fifo) { bk_grow(); if (!S->status) bk_emit_contig(); }                // it is the FIFO head (:50-52)
+}
+
+extern "C" __global__ void __launch_bounds__(BK_AT) bk_asm_kernel(BkParams p)
+{
+    const int r = blockIdx.x;
+    BkAsmShared *S = S_;
+    BkRegionWork *wk = &p.work[r];
+    if (wk->status != BK_ST_OK) return;                                            // k-mer stage failed for this region
+    if (BK_TID == 0) {
+        const BkRegionDesc d = p.desc[r];
+        BkAsmCtx &c = C_;
+        c.wk = wk; c.out = p.out; c.out_top = p.out_top; c.out_cap = p.out_cap; c.rc_thresh = p.rc_thresh;
+        c.read_words = d.read_words; c.max_len = d.max_len;
+        c.MAXC = p.max_contig; c.MAXR = p.max_read; c.MAXCAND = p.max_cand; c.KCAP = 2 * p.max_contig; c.k = p.k;
+        int o = BK_BUF_OFF;
+        c.o_cand = o; o += c.MAXCAND * 8;
+        c.o_bound = o; o += 2 * (c.MAXR + 2) * 4;
+        c.o_candu = o; o += c.MAXCAND * 4;
+        c.o_cseq = o; o += 2 * c.MAXC;
+        c.o_rseq = o; o += c.MAXR + 16;
+        c.reads = p.reads + d.reads_word_off; c.rlen = p.read_len + d.read_meta_off;
+        const uint64_t mo = d.read_meta_off;
+        c.urep = p.urep + mo; c.unr = p.unreads + mo; c.ufl = p.uflag + mo; c.ubuf = p.ubuf + mo; c.ureads = p.ureads + mo; c.ufound = p.ufound + mo; c.uminpos = p.uminpos + mo;
+        c.U = wk->U; c.M = wk->M; c.tmask = wk->tcap - 1;
+        c.tslot = (const uint32_t *)(p.arena + wk->o_tslot); c.trank = (const uint32_t *)(p.arena + wk->o_trank);
+        c.klo = (const uint64_t *)(p.arena + wk->o_key_lo); c.khi = (const uint64_t *)(p.arena + wk->o_key_hi);
+        c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
+        c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
+        S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
+        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0;
+        // per-region scratch from the arena
+        const uint64_t b_cnt = (uint64_t)8 * c.MAXC * 4, b_kl = (uint64_t)c.KCAP * 4, b_pend = (uint64_t)2 * (c.U + 1) * 4, b_alt = (uint64_t)c.MAXCAND * 4,
+                       b_rd = (uint64_t)(c.U + 1) * 4, b_used = (uint64_t)(c.M + 1) * 4;
+        uint64_t need = bk_align_up(b_cnt + 2 * b_kl + b_pend + b_alt + b_rd + b_used + 64, 256);
+        uint64_t off = atomicAdd(p.arena_top, (unsigned long long)need);
+        if (off + need > p.arena_cap) S->status = BK_ST_ARENA;
+        else {
+            uint8_t *sp = p.arena + off;
+            c.cnt = (int32_t *)sp; sp += b_cnt; c.klist = (uint32_t *)sp; sp += b_kl; c.nklist = (uint32_t *)sp; sp += b_kl;
+            c.pend = (uint32_t *)sp; sp += b_pend; c.altl = (uint32_t *)sp; sp += b_alt; c.readl = (uint32_t *)sp; sp += b_rd; c.usedl = (uint32_t *)sp;
+        }
+    }
+    BK_SYNC();
+    if (C_.M == 0) { if (BK_TID == 0) wk->n_contigs = 0; return; }                 // init_assembly :33-34
+    if (S->status) { if (BK_TID == 0) wk->status = S->status; return; }
+    // ---- init_assembly main loop (:43-62) --------------------------------------------------------------
+    for (;;) {
+        // first k-mer still in akmers.mers in (count, mer) descending order; has_mers (:318-322) <=> its count > 1
+        int head = S->head, found = -1;
+        while (head < (int)C_.M) {
+            int cand_rk = head + BK_TID;
+            int mine = (cand_rk < (int)C_.M && C_.kstate[cand_rk] != BK_K_REMOVED) ? cand_rk : 0x7FFFFFFF;
+            int mn = -bk_max256(-mine, S->scan);
+            if (mn != 0x7FFFFFFF) { found = mn; break; }
+            head += BK_AT;
+        }
+        if (found < 0 || C_.kcnt[found] < 2) break;
+        BK_SYNC();
+        if (BK_TID == 0) S->head = found;
+        BK_SYNC();
+        bk_setup_contigs(found);
+        while (!S->status && S->phead < S->ptail) {                                // :50-59
+            const int ph = S->phead;
+            const uint32_t prk = C_.pend[2 * ph], pu = C_.pend[2 * ph + 1];
+            BK_SYNC();
+            if (BK_TID == 0) { S->phead = ph + 1; if (prk != BK_EMPTY32) C_.ufound[pu] = -1; }
+            BK_SYNC();
+            if (prk == BK_EMPTY32) continue;
+            bk_contig_new((int)prk, (int)pu, true);
+            bk_grow();
+            if (!S->status) bk_emit_contig();
+        }
+        if (S->status) break;
+        BK_SYNC();
+        const int nu = S->nused;
+        for (int i = BK_TID; i < nu; i += BK_AT) C_.kstate[C_.usedl[i]] = BK_K_REMOVED;   // buff.remove_kmers :358-360
+        BK_SYNC();
+        if (BK_TID == 0) S->nused = 0;
+        BK_SYNC();
+    }
+    BK_SYNC();
+    if (BK_TID == 0) { C_.wk->n_contigs = (uint32_t)S->n_contigs; C_.wk->nw_cells = S->cells; C_.wk->nw_calls = S->calls; if (S->status) C_.wk->status = S->status; }
+}
+
+// ---- stand-alone batched olc.nw (known-answer tests G1, DP micro-benchmark) -----------------------------------
+extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_t *codes, const uint32_t *off1, const uint32_t *len1,
+                                                                     const uint32_t *off2, const uint32_t *len2, int32_t *out, int reps)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t l[];
+    const int b = blockIdx.x, m = (int)len1[b], n = (int)len2[b];
+    uint8_t *s1 = l, *s2 = l + ((m + 15) & ~15);
+    int *bound = (int *)(l + ((m + 15) & ~15) + ((n + 15) & ~15));
+    for (int t = threadIdx.x; t < m; t += 64) s1[t] = codes[off1[b] + t];
+    for (int t = threadIdx.x; t < n; t += 64) s2[t] = codes[off2[b] + t];
+    __syncthreads();
+    BkNwResult r{};
+    for (int i = 0; i < reps; i++) r = bk_nw_wave(s1, m, s2, n, bound);
+    if (threadIdx.x == 0) { out[4 * b] = r.j_start; out[4 * b + 1] = r.i_end; out[4 * b + 2] = r.i_start; out[4 * b + 3] = r.score; }
+}

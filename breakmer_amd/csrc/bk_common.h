@@ -1,0 +1,140 @@
+// bk_common.h -- shared device/host definitions for libbreakmer_hip.so (gfx950 only).
+//
+// Data layout in HBM (DESIGN.md "Data layout"):
+//   * sequences are 2 bit/base, 16 bases per 32-bit word, FIRST base in the MOST significant bits
+//     (so that a k-mer read as an integer compares like the string: A<C<G<T), zero padded;
+//   * every read of a region starts on its own word boundary, fixed stride `read_words`;
+//   * k-mer keys are (hi,lo) 128-bit integers: sum(code[i] << 2*(k-1-i)).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BK_WAVE 64
+#define BK_EMPTY32 0xFFFFFFFFu
+#define BK_EMPTY64 0xFFFFFFFFFFFFFFFFull
+
+// per-region status codes written by the kernels (0 = ok)
+enum {
+    BK_ST_OK = 0,
+    BK_ST_ARENA = 1,          // device arena exhausted (host grows it and reruns)
+    BK_ST_WINDOW = 2,         // reference window too long for the LDS k-mer table
+    BK_ST_CONTIG = 3,         // contig longer than max_contig_len
+    BK_ST_CAND = 4,           // more candidate reads for one k-mer than max_candidates
+    BK_ST_KLIST = 5,          // contig k-mer list overflow
+    BK_ST_READLEN = 6,        // read longer than max_read_len
+    BK_ST_OUT = 7,            // output arena exhausted (host grows it and reruns)
+    BK_ST_HITS = 8            // too many alignment blocks/hits
+};
+
+struct BkKey { uint64_t hi, lo; };
+
+__host__ __device__ inline bool key_eq(const BkKey &a, const BkKey &b) { return a.lo == b.lo && a.hi == b.hi; }
+__host__ __device__ inline bool key_lt(const BkKey &a, const BkKey &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+__host__ __device__ inline uint32_t key_hash(const BkKey &k) { return (uint32_t)(mix64(k.lo ^ (k.hi * 0x9E3779B97F4A7C15ull)) >> 20); }
+// append one base (rolling k-mer), k <= 64
+__host__ __device__ inline void key_push(BkKey &key, uint32_t c, int k) {
+    key.hi = (key.hi << 2) | (key.lo >> 62);
+    key.lo = (key.lo << 2) | c;
+    if (k <= 32) { key.hi = 0; if (k < 32) key.lo &= ((1ull << (2 * k)) - 1ull); }
+    else if (k < 64) key.hi &= ((1ull << (2 * (k - 32))) - 1ull);
+}
+// base i of a packed sequence
+__host__ __device__ inline uint32_t seq_base(const uint32_t *w, int i) { return (w[i >> 4] >> (30 - 2 * (i & 15))) & 3u; }
+// k-mer starting at base `pos` of a packed sequence (words may be read up to (pos+k+15)/16)
+__host__ __device__ inline BkKey seq_kmer(const uint32_t *w, int pos, int k) {
+    BkKey key; key.hi = 0; key.lo = 0;
+    int i = pos, end = pos + k;
+    // head: unaligned bases until a word boundary
+    while (i < end && (i & 15)) { key_push(key, seq_base(w, i), 64); i++; }
+    while (i + 16 <= end) { uint32_t x = w[i >> 4]; key.hi = (key.hi << 32) | (key.lo >> 32); key.lo = (key.lo << 32) | x; i += 16; }
+    while (i < end) { key_push(key, seq_base(w, i), 64); i++; }
+    if (k <= 32) { key.hi = 0; if (k < 32) key.lo &= ((1ull << (2 * k)) - 1ull); }
+    else if (k < 64) key.hi &= ((1ull << (2 * (k - 32))) - 1ull);
+    return key;
+}
+__host__ __device__ inline bool key_homopolymer(const BkKey &key, int k) {       // len(set(mer)) == 1  (sv_assembly.py:277)
+    uint32_t c = (uint32_t)(key.lo & 3u);
+    BkKey h; h.hi = 0; h.lo = 0;
+    const uint64_t rep = 0x5555555555555555ull * c;
+    if (k <= 32) { h.lo = (k < 32) ? (rep & ((1ull << (2 * k)) - 1ull)) : rep; }
+    else { h.lo = rep; h.hi = (k < 64) ? (rep & ((1ull << (2 * (k - 32))) - 1ull)) : rep; }
+    return key_eq(h, key);
+}
+
+// ---- host-filled region descriptor (one per region, device-resident) ----------------------
+struct BkRegionDesc {
+    uint64_t reads_word_off;     // into packed reads
+    uint64_t read_meta_off;      // base index of this region in all per-read arrays
+    uint64_t win_word_off;       // packed forward target window
+    uint64_t sc_word_off, sc_meta_off;
+    uint64_t dedup_off;          // base slot of this region in the read-grouping table
+    uint64_t part_desc_off;      // first partner window descriptor
+    uint32_t n_reads, read_words;
+    uint32_t win_len;
+    int32_t n_sc; uint32_t sc_words;
+    uint32_t dedup_cap;          // power of two >= 2*n_reads
+    uint32_t n_partners;
+    uint32_t max_len;            // read_len = max cleaned read length (utils.py:240)
+};
+struct BkPartnerDesc { uint64_t word_off; uint32_t len, pad; };
+
+// ---- device-written per-region work record (k-mer stage -> assembler -> realign) -----------
+struct BkRegionWork {
+    int32_t status;              // BK_ST_*
+    uint32_t U;                  // unique read sequences (fq_recs keys)
+    uint32_t T;                  // non-reference k-mer occurrences in unique reads
+    uint32_t M;                  // sample-only k-mers (incl. homopolymers, which start REMOVED)
+    uint32_t tcap;               // k-mer table capacity (power of two)
+    uint32_t n_contigs;
+    uint64_t nw_cells, nw_calls; // algorithmic DP work
+    uint64_t sw_cells;
+    // arena offsets (bytes)
+    uint64_t o_trip_ent;         // uint32[T]   (u << 10 | pos)
+    uint64_t o_trip_slot;        // uint32[T]
+    uint64_t o_tslot;            // uint32[tcap] claimant triple index
+    uint64_t o_tcnt;             // uint32[tcap] occurrence count (sum of nreads)
+    uint64_t o_trank;            // uint32[tcap] rank of slot (BK_EMPTY32 = dropped)
+    uint64_t o_key_lo, o_key_hi; // uint64[M] sorted (count desc, mer desc)
+    uint64_t o_kcnt;             // uint32[M]
+    uint64_t o_kstate;           // uint8[M]
+    uint64_t o_kstamp;           // int32[3*M]: checked, mset, firstpos
+    uint64_t o_poff;             // uint32[M+1]
+    uint64_t o_post;             // uint32[T]
+    uint64_t o_first_contig;     // `out` offset of first contig record (linked list), 0 = none
+    uint64_t o_last_contig;
+};
+
+// k-mer states (akmers.mers membership, sv_assembly.py:301-326; buffer.used_mers :333)
+enum { BK_K_LIVE = 0, BK_K_USED = 1, BK_K_REMOVED = 2 };
+// unique-read flags
+enum { BK_R_USED = 1, BK_R_DELETED = 2, BK_R_INDEL = 4 };
+
+// contig record in the `out` arena (o_* relative to the record start, 8-byte aligned; k-mers are
+// stored as (lo, hi) key pairs so the record is self-contained)
+struct BkContigRec {
+    uint64_t next;               // arena offset of the next contig record of the region (0 = end)
+    int32_t seq_len, counts_len, n_kmers, n_reads, total_reads, n_hits;
+    uint32_t o_seq, o_io, o_ot, o_klocs, o_kmers, o_reads, o_hits, size;
+};
+
+struct BkParams {
+    const BkRegionDesc *desc; BkRegionWork *work; const BkPartnerDesc *partners;
+    const uint32_t *reads; const uint16_t *read_len; const uint8_t *read_flag;
+    const uint32_t *sc; const uint16_t *sc_len;
+    const uint32_t *windows;
+    // read grouping (sized by total reads / total dedup slots)
+    unsigned long long *dd_slot; uint32_t *dd_rep, *dd_cnt, *dd_u;
+    uint32_t *grp_slot;
+    // unique-read arrays (indexed read_meta_off + u)
+    uint32_t *urep, *unreads; uint8_t *uflag; int32_t *ubuf, *ureads, *ufound, *uminpos;
+    // arena
+    uint8_t *arena; unsigned long long *arena_top; uint64_t arena_cap;     // scratch: k-mer tables, assembler state
+    uint8_t *out; unsigned long long *out_top; uint64_t out_cap;           // results: contig records, hits (copied to the host)
+    int32_t k, rc_thresh, max_contig, max_read, max_cand, sw_min_score;
+    int32_t n_regions;
+};
+
+__device__ inline uint64_t bk_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }

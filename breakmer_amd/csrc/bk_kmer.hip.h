@@ -1,0 +1,353 @@
+// bk_kmer.hip.h -- stage BK_STAGE_KMER: read grouping (T1) + sample-only k-mer selection (K1/K2)
+// + k-mer -> read posting lists (replaces the regex scan of find_reads, sv_assembly.py:111-122).
+//
+// One 1024-thread workgroup per target region.  Reference behaviour reproduced:
+//   utils.py:239-244      fq_recs = dict seq -> [fq_read...]   (grouping, first-occurrence order)
+//   utils.py:151-178      jellyfish count -m k (no -C: strand specific), dump -c
+//   utils.py:287-296      load_kmers: counts summed over files
+//   sv_processor.py:613-631  sample_only = (keys(case) & keys(case_sc)) - keys(ref fwd+rc)
+//   sv_assembly.py:272-285   drop homopolymers, order by (count, mer) descending
+// Bound: HBM streaming of the packed reads (one pass for grouping, one per k-mer pass over the
+// unique reads; the re-reads hit L2/MALL).  No MFMA: integer/byte work.
+#pragma once
+#include "bk_common.h"
+
+#define BK_KT 1024            // threads per workgroup (16 waves)
+
+struct BkRefTab {             // LDS-resident reference k-mer set: window forward + reverse complement
+    const uint32_t *win_f, *win_r;   // packed, LDS
+    uint32_t *tab;                   // (tag << 18 | idx), LDS
+    uint32_t cap_mask; int wk;       // wk = W-k+1 k-mers per strand
+    int k;
+    __device__ inline BkKey key_at(uint32_t idx) const {
+        return idx < (uint32_t)wk ? seq_kmer(win_f, (int)idx, k) : seq_kmer(win_r, (int)idx - wk, k);
+    }
+    __device__ inline int find(const BkKey &key) const {
+        uint32_t h = key_hash(key), tag = (h >> 18) & 0x3FFFu, i = h & cap_mask;
+        for (;;) {
+            uint32_t e = tab[i];
+            if (e == BK_EMPTY32) return -1;
+            if ((e >> 18) == tag) { uint32_t idx = e & 0x3FFFFu; if (key_eq(key_at(idx), key)) return (int)idx; }
+            i = (i + 1) & cap_mask;
+        }
+    }
+    __device__ inline void insert(uint32_t idx) {
+        BkKey key = key_at(idx);
+        uint32_t h = key_hash(key), tag = (h >> 18) & 0x3FFFu, i = h & cap_mask, mine = (tag << 18) | idx;
+        for (;;) {
+            uint32_t e = atomicCAS(&tab[i], BK_EMPTY32, mine);
+            if (e == BK_EMPTY32) return;
+            if ((e >> 18) == tag && key_eq(key_at(e & 0x3FFFFu), key)) return;   // duplicate k-mer
+            i = (i + 1) & cap_mask;
+        }
+    }
+    // next k-mer on the same diagonal as the previous hit (seed-and-extend: skips the hash probe)
+    __device__ inline int extend(int ridx, uint32_t c) const {
+        if (ridx < 0) return -1;
+        if (ridx < wk) { int cand = ridx + 1; return (cand < wk && seq_base(win_f, cand + k - 1) == c) ? cand : -1; }
+        int cand = ridx - wk + 1; return (cand < wk && seq_base(win_r, cand + k - 1) == c) ? wk + cand : -1;
+    }
+};
+
+// walk one packed sequence, call f(pos, key) for every k-mer that is NOT a reference k-mer
+template <class F>
+__device__ inline void bk_scan_nonref(const uint32_t *w, int len, const BkRefTab &rt, F &&f)
+{
+    const int k = rt.k;
+    BkKey key; key.hi = 0; key.lo = 0; int ridx = -1; uint32_t word = 0;
+    for (int i = 0; i < len; i++) {
+        if ((i & 15) == 0) word = w[i >> 4];
+        uint32_t c = word >> 30; word <<= 2;
+        key_push(key, c, k);
+        if (i >= k - 1) {
+            int nidx = rt.extend(ridx, c);
+            if (nidx < 0) nidx = rt.find(key);
+            ridx = nidx;
+            if (nidx < 0) f(i - k + 1, key);
+        }
+    }
+}
+
+__device__ inline uint32_t bk_block_sum(uint32_t v, uint32_t *scratch /* >= 17 words */)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t s = 0; for (int i = 0; i < nw; i++) s += scratch[i]; scratch[16] = s; }
+    __syncthreads();
+    return scratch[16];
+}
+// exclusive scan of one value per thread across the block; returns (prefix, total via *total)
+__device__ inline uint32_t bk_block_excl_scan(uint32_t v, uint32_t *scratch /* >= 18 words */, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) scratch[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t s = 0; for (int i = 0; i < nw; i++) { uint32_t t = scratch[i]; scratch[i] = s; s += t; } scratch[17] = s; }
+    __syncthreads();
+    *total = scratch[17];
+    return scratch[wv] + inc - v;
+}
+
+__device__ inline uint64_t bk_arena_alloc(const BkParams &p, uint64_t bytes, uint32_t *bcast /* LDS 2 words */)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t need = bk_align_up(bytes, 256);
+        uint64_t off = atomicAdd(p.arena_top, (unsigned long long)need);
+        if (off + need > p.arena_cap) off = ~0ull;
+        bcast[0] = (uint32_t)off; bcast[1] = (uint32_t)(off >> 32);
+    }
+    __syncthreads();
+    return ((uint64_t)bcast[1] << 32) | bcast[0];
+}
+
+// comparator of the akmers order: (count, mer) descending (sv_assembly.py:281)
+__device__ inline bool bk_kmer_before(uint32_t ca, const BkKey &ka, uint32_t cb, const BkKey &kb)
+{
+    if (ca != cb) return ca > cb;
+    return key_lt(kb, ka);
+}
+
+extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, uint32_t ref_cap, uint32_t win_words_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const BkRegionDesc d = p.desc[r];
+    BkRegionWork *wk = &p.work[r];
+    const int k = p.k;
+    uint32_t *scr = lds;                       // 32 words scratch
+    uint32_t *win_f = lds + 32;
+    uint32_t *win_r = win_f + win_words_cap;
+    uint32_t *tab = win_r + win_words_cap;     // ref_cap words; later reused as sort permutation
+
+    if (tid == 0) { wk->status = BK_ST_OK; wk->U = 0; wk->T = 0; wk->M = 0; wk->tcap = 0; wk->n_contigs = 0; wk->nw_cells = 0; wk->nw_calls = 0; wk->sw_cells = 0; wk->o_first_contig = 0; wk->o_last_contig = 0; }
+    const int W = (int)d.win_len, WK = W >= k ? W - k + 1 : 0;
+    if ((uint32_t)(2 * WK) * 2u > ref_cap || (uint32_t)((W + 15) / 16 + 2) > win_words_cap || 2 * WK >= (1 << 18)) {
+        if (tid == 0) wk->status = BK_ST_WINDOW;
+        return;
+    }
+    // ---- P0: reference k-mer set in LDS (sv_processor.py:613-615: forward and reverse file) -------
+    const uint32_t *gw = p.windows + d.win_word_off;
+    const int ww = (W + 15) / 16;
+    for (int i = tid; i < (int)win_words_cap; i += nt) { win_f[i] = i < ww ? gw[i] : 0u; win_r[i] = 0u; }
+    for (uint32_t i = tid; i < ref_cap; i += nt) tab[i] = BK_EMPTY32;
+    __syncthreads();
+    // reverse complement, packed: base j of rc = 3 - base (W-1-j) of forward
+    for (int wi = tid; wi < ww; wi += nt) {
+        uint32_t x = 0;
+        for (int t = 0; t < 16; t++) { int j = wi * 16 + t; uint32_t c = j < W ? 3u - seq_base(win_f, W - 1 - j) : 0u; x = (x << 2) | c; }
+        win_r[wi] = x;
+    }
+    __syncthreads();
+    BkRefTab rt; rt.win_f = win_f; rt.win_r = win_r; rt.tab = tab; rt.cap_mask = ref_cap - 1; rt.wk = WK; rt.k = k;
+    for (int i = tid; i < 2 * WK; i += nt) rt.insert((uint32_t)i);
+    __syncthreads();
+
+    // ---- P1: group identical reads (utils.py:239-244) -------------------------------------------
+    const uint32_t N = d.n_reads, RW = d.read_words;
+    const uint32_t *reads = p.reads + d.reads_word_off;
+    const uint16_t *rlen = p.read_len + d.read_meta_off;
+    unsigned long long *dslot = p.dd_slot + d.dedup_off;
+    uint32_t *drep = p.dd_rep + d.dedup_off, *dcnt = p.dd_cnt + d.dedup_off, *du = p.dd_u + d.dedup_off;
+    uint32_t *gslot = p.grp_slot + d.read_meta_off;
+    for (uint32_t i = tid; i < d.dedup_cap; i += nt) { dslot[i] = BK_EMPTY64; drep[i] = BK_EMPTY32; dcnt[i] = 0; }
+    __syncthreads();
+    const uint32_t dmask = d.dedup_cap - 1;
+    for (uint32_t i = tid; i < N; i += nt) {
+        const uint32_t *w = reads + (uint64_t)i * RW; const uint32_t len = rlen[i], nw = (len + 15) / 16;
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
+        for (uint32_t t = 0; t < nw; t++) h = mix64(h ^ w[t]) + 0x632BE59BD9B4E019ull;
+        h = mix64(h);
+        uint32_t tag = (uint32_t)(h >> 32), s = (uint32_t)h & dmask;
+        for (;;) {
+            unsigned long long mine = ((unsigned long long)tag << 32) | i;
+            unsigned long long cur = atomicCAS(&dslot[s], BK_EMPTY64, mine);
+            if (cur == BK_EMPTY64) break;
+            if ((uint32_t)(cur >> 32) == tag) {
+                uint32_t j = (uint32_t)cur; bool same = rlen[j] == len;
+                const uint32_t *wj = reads + (uint64_t)j * RW;
+                for (uint32_t t = 0; same && t < nw; t++) same = wj[t] == w[t];
+                if (same) break;
+            }
+            s = (s + 1) & dmask;
+        }
+        gslot[i] = s; atomicMin(&drep[s], i); atomicAdd(&dcnt[s], 1u);
+    }
+    __syncthreads();
+    // ---- P2: unique reads in first-occurrence (FASTQ) order = fq_recs iteration order (P4) -------
+    uint32_t *urep = p.urep + d.read_meta_off, *unr = p.unreads + d.read_meta_off;
+    uint8_t *ufl = p.uflag + d.read_meta_off;
+    const uint8_t *rflag = p.read_flag + d.read_meta_off;
+    uint32_t U = 0;
+    {
+        const uint32_t chunk = (N + nt - 1) / nt, b = tid * chunk, e = min(N, b + chunk);
+        uint32_t c = 0;
+        for (uint32_t i = b; i < e; i++) c += drep[gslot[i]] == i;
+        uint32_t pre = bk_block_excl_scan(c, scr, &U);
+        for (uint32_t i = b; i < e; i++) if (drep[gslot[i]] == i) {
+            uint32_t s = gslot[i];
+            urep[pre] = i; unr[pre] = dcnt[s]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[s] = pre;
+            p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
+            pre++;
+        }
+    }
+    __syncthreads();
+    // ---- P3a: count non-reference k-mer occurrences over unique reads ---------------------------
+    uint32_t myc = 0;
+    for (uint32_t u = tid; u < U; u += nt) {
+        uint32_t i = urep[u];
+        bk_scan_nonref(reads + (uint64_t)i * RW, rlen[i], rt, [&](int, const BkKey &) { myc++; });
+    }
+    const uint32_t T = bk_block_sum(myc, scr);
+    uint32_t tcap = 256; while (tcap < 2 * T) tcap <<= 1;
+    // ---- P3b: allocate; record (u,pos) triples; insert into the sample k-mer table --------------
+    const uint64_t b1 = (uint64_t)T * 8 + (uint64_t)tcap * 12 + 1024;
+    uint64_t a0 = bk_arena_alloc(p, b1, scr + 20);
+    if (a0 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
+    const uint64_t o_ent = a0, o_tsl = bk_align_up(o_ent + (uint64_t)T * 4, 256), o_tslot = bk_align_up(o_tsl + (uint64_t)T * 4, 256),
+                   o_tcnt = o_tslot + (uint64_t)tcap * 4, o_trank = o_tcnt + (uint64_t)tcap * 4;
+    uint32_t *t_ent = (uint32_t *)(p.arena + o_ent), *t_sl = (uint32_t *)(p.arena + o_tsl);
+    uint32_t *tslot = (uint32_t *)(p.arena + o_tslot), *tcnt = (uint32_t *)(p.arena + o_tcnt), *trank = (uint32_t *)(p.arena + o_trank);
+    for (uint32_t i = tid; i < tcap; i += nt) { tslot[i] = BK_EMPTY32; tcnt[i] = 0; trank[i] = BK_EMPTY32; }
+    if (tid == 0) scr[24] = 0;
+    __syncthreads();
+    for (uint32_t u = tid; u < U; u += nt) {
+        uint32_t i = urep[u];
+        bk_scan_nonref(reads + (uint64_t)i * RW, rlen[i], rt, [&](int pos, const BkKey &) {
+            uint32_t idx = atomicAdd(&scr[24], 1u);
+            t_ent[idx] = (u << 10) | (uint32_t)pos;
+        });
+    }
+    __syncthreads();
+    const uint32_t tmask = tcap - 1;
+    for (uint32_t idx = tid; idx < T; idx += nt) {
+        uint32_t e = t_ent[idx], u = e >> 10, pos = e & 1023u;
+        BkKey key = seq_kmer(reads + (uint64_t)urep[u] * RW, (int)pos, k);
+        uint32_t s = key_hash(key) & tmask;
+        for (;;) {
+            uint32_t cur = atomicCAS(&tslot[s], BK_EMPTY32, idx);
+            if (cur == BK_EMPTY32) break;
+            uint32_t e2 = t_ent[cur];
+            if (key_eq(seq_kmer(reads + (uint64_t)urep[e2 >> 10] * RW, (int)(e2 & 1023u), k), key)) break;
+            s = (s + 1) & tmask;
+        }
+        t_sl[idx] = s; atomicAdd(&tcnt[s], unr[u]);          // case[mer] counts every read (duplicates included)
+    }
+    __syncthreads();
+    // soft-clip set: keep only k-mers also present in case_sc (sv_processor.py:619-621)
+    if (d.n_sc >= 0) {
+        const uint32_t *sc = p.sc + d.sc_word_off; const uint16_t *sl = p.sc_len + d.sc_meta_off;
+        for (uint32_t i = tid; i < (uint32_t)d.n_sc; i += nt) {
+            bk_scan_nonref(sc + (uint64_t)i * d.sc_words, sl[i], rt, [&](int, const BkKey &key) {
+                uint32_t s = key_hash(key) & tmask;
+                for (;;) {
+                    uint32_t cur = tslot[s];
+                    if (cur == BK_EMPTY32) break;
+                    uint32_t e2 = t_ent[cur];
+                    if (key_eq(seq_kmer(reads + (uint64_t)urep[e2 >> 10] * RW, (int)(e2 & 1023u), k), key)) { trank[s] = 0; break; }
+                    s = (s + 1) & tmask;
+                }
+            });
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < tcap; i += nt) { if (tslot[i] != BK_EMPTY32 && trank[i] == BK_EMPTY32) tslot[i] = BK_EMPTY32 - 1; trank[i] = BK_EMPTY32; }   // tombstone: probe chains stay intact
+        __syncthreads();
+    }
+    // ---- P4: compact -> M sample-only k-mers, order by (count, mer) descending -------------------
+    uint32_t M = 0;
+    {
+        const uint32_t chunk = (tcap + nt - 1) / nt, b = tid * chunk, e = min(tcap, b + chunk);
+        uint32_t c = 0;
+        for (uint32_t i = b; i < e; i++) c += tslot[i] < BK_EMPTY32 - 1;
+        uint32_t pre = bk_block_excl_scan(c, scr, &M);
+        for (uint32_t i = b; i < e; i++) if (tslot[i] < BK_EMPTY32 - 1) trank[i] = pre++;    // provisional rank = compaction index
+    }
+    uint32_t npad = 1; while (npad < M) npad <<= 1;
+    const bool perm_in_lds = npad <= ref_cap;                  // else the permutation is sorted in global memory (slow path)
+    const uint64_t b2 = (uint64_t)M * (8 + 8 + 4 + 1 + 12 + 4 + 4) + (uint64_t)T * 4 + 4096 + (perm_in_lds ? 0 : (uint64_t)npad * 4);
+    uint64_t a1 = bk_arena_alloc(p, b2, scr + 20);
+    if (a1 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
+    const uint64_t o_klo = a1, o_khi = o_klo + (uint64_t)M * 8, o_kcnt = o_khi + (uint64_t)M * 8, o_kstamp = bk_align_up(o_kcnt + (uint64_t)M * 4, 16),
+                   o_poff = o_kstamp + (uint64_t)M * 12, o_tmp = bk_align_up(o_poff + (uint64_t)(M + 1) * 4, 16), o_post = bk_align_up(o_tmp + (uint64_t)M * 4, 16),
+                   o_kstate = o_post + (uint64_t)T * 4, o_perm = bk_align_up(o_kstate + M, 16);
+    uint64_t *klo = (uint64_t *)(p.arena + o_klo), *khi = (uint64_t *)(p.arena + o_khi);
+    uint32_t *kcnt = (uint32_t *)(p.arena + o_kcnt), *poff = (uint32_t *)(p.arena + o_poff), *ptmp = (uint32_t *)(p.arena + o_tmp), *post = (uint32_t *)(p.arena + o_post);
+    int32_t *kstamp = (int32_t *)(p.arena + o_kstamp);
+    uint8_t *kstate = (uint8_t *)(p.arena + o_kstate);
+    // permutation sort: perm in LDS (reusing the reference table) when it fits, else in ptmp/global
+    uint32_t *perm = perm_in_lds ? tab : (uint32_t *)(p.arena + o_perm);
+    // materialise keys at the provisional index first (keys/count by compaction index in klo/khi/kcnt)
+    for (uint32_t i = tid; i < tcap; i += nt) if (tslot[i] < BK_EMPTY32 - 1) {
+        uint32_t e2 = t_ent[tslot[i]]; BkKey key = seq_kmer(reads + (uint64_t)urep[e2 >> 10] * RW, (int)(e2 & 1023u), k);
+        uint32_t j = trank[i]; klo[j] = key.lo; khi[j] = key.hi; kcnt[j] = tcnt[i]; ptmp[j] = i;      // ptmp: slot of compaction index
+    }
+    __syncthreads();
+    {
+        for (uint32_t i = tid; i < npad; i += nt) perm[i] = i < M ? i : BK_EMPTY32;
+        __syncthreads();
+        for (uint32_t sz = 2; sz <= npad; sz <<= 1)
+            for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+                for (uint32_t i = tid; i < npad / 2; i += nt) {
+                    uint32_t lo = (i / st) * (st * 2) + (i % st), hi2 = lo + st;
+                    bool up = ((lo & sz) == 0);
+                    uint32_t a = perm[lo], b = perm[hi2];
+                    bool a_first;   // should a come before b in the final order?
+                    if (a == BK_EMPTY32) a_first = false; else if (b == BK_EMPTY32) a_first = true;
+                    else { BkKey ka{khi[a], klo[a]}, kb{khi[b], klo[b]}; a_first = bk_kmer_before(kcnt[a], ka, kcnt[b], kb); }
+                    if (a_first != up) { perm[lo] = b; perm[hi2] = a; }
+                }
+                __syncthreads();
+            }
+    }
+    // apply the permutation: final arrays indexed by rank.  Move through registers (M/nt per thread).
+    {
+        // two-pass to avoid aliasing: stash (lo,hi,cnt,slot) of perm[rank] in LDS-free way: read all, barrier, write all
+        const uint32_t per = (M + nt - 1) / nt;
+        // bounded register staging: process in rounds of nt elements using a temporary copy in ptmp2 area (poff/post are free now)
+        uint64_t *tlo = (uint64_t *)post;                       // T >= M words? post has T*4 bytes; need M*8 -> use kstamp (M*12) instead
+        (void)tlo; (void)per;
+        uint64_t *slo = (uint64_t *)kstamp;                     // M*8 bytes of the M*12 stamp area
+        uint32_t *scn = poff;                                   // (M+1)*4
+        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = perm[j]; slo[j] = klo[a]; scn[j] = kcnt[a]; }
+        __syncthreads();
+        // hi words and slots need a second staging round
+        for (uint32_t j = tid; j < M; j += nt) { klo[j] = slo[j]; kcnt[j] = scn[j]; }
+        __syncthreads();
+        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = perm[j]; slo[j] = khi[a]; scn[j] = ptmp[a]; }
+        __syncthreads();
+        for (uint32_t j = tid; j < M; j += nt) { khi[j] = slo[j]; uint32_t slot = scn[j]; trank[slot] = j; ptmp[j] = 0; }
+        __syncthreads();
+    }
+    for (uint32_t j = tid; j < M; j += nt) {
+        BkKey key{khi[j], klo[j]};
+        kstate[j] = key_homopolymer(key, k) ? BK_K_REMOVED : BK_K_LIVE;      // kmers.add_kmer (sv_assembly.py:277)
+        kstamp[3 * j] = 0; kstamp[3 * j + 1] = 0; kstamp[3 * j + 2] = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    // ---- P5: posting lists k-mer rank -> (u, pos) -------------------------------------------------
+    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) atomicAdd(&ptmp[rk], 1u); }
+    __syncthreads();
+    {
+        const uint32_t chunk = (M + nt - 1) / nt, b = tid * chunk, e = min(M, b + chunk);
+        uint32_t c = 0, tot;
+        for (uint32_t j = b; j < e; j++) c += ptmp[j];
+        uint32_t pre = bk_block_excl_scan(c, scr, &tot);
+        for (uint32_t j = b; j < e; j++) { uint32_t n = ptmp[j]; poff[j] = pre; ptmp[j] = pre; pre += n; }
+        if (tid == 0) poff[M] = tot;
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) post[atomicAdd(&ptmp[rk], 1u)] = t_ent[idx]; }
+    __syncthreads();
+    if (tid == 0) {
+        wk->U = U; wk->T = T; wk->M = M; wk->tcap = tcap;
+        wk->o_trip_ent = o_ent; wk->o_trip_slot = o_tsl; wk->o_tslot = o_tslot; wk->o_tcnt = o_tcnt; wk->o_trank = o_trank;
+        wk->o_key_lo = o_klo; wk->o_key_hi = o_khi; wk->o_kcnt = o_kcnt; wk->o_kstate = o_kstate; wk->o_kstamp = o_kstamp;
+        wk->o_poff = o_poff; wk->o_post = o_post;
+    }
+}

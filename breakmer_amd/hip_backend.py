@@ -1,0 +1,247 @@
+"""Thin ctypes binding of libbreakmer_hip.so (include/breakmer_hip.h).
+
+There is no CPU fallback: importing is harmless, but creating an engine without the built
+library or without a gfx950 GPU raises.  The library is built in-tree by
+`__graft_entry__.build()` / `breakmer_amd.build.build_hip()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbreakmer_hip.so")
+
+BK_STAGE_KMER, BK_STAGE_ASSEMBLE, BK_STAGE_REALIGN, BK_STAGE_ALL = 1, 2, 4, 7
+BK_MAX_BLOCKS = 16
+
+
+class BkConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("kmer_size", C.c_int32), ("rc_thresh", C.c_int32),
+                ("max_contig_len", C.c_int32), ("max_read_len", C.c_int32), ("max_candidates", C.c_int32),
+                ("arena_bytes", C.c_int64), ("sw_min_score", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class BkRegion(C.Structure):
+    _fields_ = [("reads", C.c_void_p), ("read_lens", C.c_void_p), ("indel_only", C.c_void_p),
+                ("n_reads", C.c_int32), ("read_stride", C.c_int32),
+                ("sc_seqs", C.c_void_p), ("sc_lens", C.c_void_p), ("n_sc", C.c_int32), ("sc_stride", C.c_int32),
+                ("window", C.c_char_p), ("window_len", C.c_int32), ("n_partners", C.c_int32),
+                ("partners", C.POINTER(C.c_char_p)), ("partner_lens", C.c_void_p)]
+
+
+class BkContigInfo(C.Structure):
+    _fields_ = [("seq_len", C.c_int32), ("counts_len", C.c_int32), ("n_kmers", C.c_int32), ("n_reads", C.c_int32),
+                ("total_reads", C.c_int32), ("n_hits", C.c_int32)]
+
+
+class BkPsl(C.Structure):
+    _fields_ = [("matches", C.c_int32), ("mismatches", C.c_int32), ("rep_matches", C.c_int32), ("n_count", C.c_int32),
+                ("q_num_insert", C.c_int32), ("q_base_insert", C.c_int32), ("t_num_insert", C.c_int32), ("t_base_insert", C.c_int32),
+                ("strand", C.c_int32), ("q_size", C.c_int32), ("q_start", C.c_int32), ("q_end", C.c_int32),
+                ("t_index", C.c_int32), ("t_size", C.c_int32), ("t_start", C.c_int32), ("t_end", C.c_int32),
+                ("block_count", C.c_int32), ("block_sizes", C.c_int32 * BK_MAX_BLOCKS), ("q_starts", C.c_int32 * BK_MAX_BLOCKS),
+                ("t_starts", C.c_int32 * BK_MAX_BLOCKS), ("score", C.c_int32)]
+
+
+EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_run", "bk_sync",
+           "bk_last_kernel_ms", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
+           "bk_get_contig", "bk_get_hits", "bk_get_stat"]
+
+_lib = None
+
+
+class BreakmerHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the in-tree library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise BreakmerHipError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.bk_last_error.restype = C.c_char_p
+    L.bk_last_error.argtypes = [C.c_void_p]
+    L.bk_create.argtypes = [C.c_int, C.POINTER(BkConfig), C.POINTER(C.c_void_p)]
+    L.bk_destroy.argtypes = [C.c_void_p]
+    L.bk_submit_regions.argtypes = [C.c_void_p, C.POINTER(BkRegion), C.c_int32]
+    L.bk_run.argtypes = [C.c_void_p, C.c_uint32]
+    L.bk_sync.argtypes = [C.c_void_p]
+    L.bk_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.bk_get_kmer_count.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.bk_get_kmers.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    L.bk_get_contig_count.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.bk_get_contig_info.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BkContigInfo)]
+    L.bk_get_contig.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6
+    L.bk_get_hits.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BkPsl), C.c_int32]
+    L.bk_get_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.bk_nw_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+def _ascii_matrix(seqs):
+    """list[str] | uint8 code matrix (+lens) -> (ASCII uint8 matrix, lens uint16)."""
+    n = len(seqs)
+    stride = max([len(s) for s in seqs] + [1])
+    m = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint16)
+    for i, s in enumerate(seqs):
+        b = np.frombuffer(s.encode(), dtype=np.uint8)
+        m[i, :len(b)] = b
+        lens[i] = len(b)
+    return m, lens
+
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+class RegionInput(object):
+    """Host-side view of one target region, kept alive until submit returns."""
+
+    def __init__(self, reads, window, *, read_lens=None, indel_only=None, sc_seqs=None, partners=()):
+        if isinstance(reads, np.ndarray):                   # uint8 codes 0..3, [N, L]
+            self.reads = _ACGT[reads] if reads.size else np.zeros((0, 1), dtype=np.uint8)
+            self.reads = np.ascontiguousarray(self.reads)
+            self.lens = (np.asarray(read_lens, dtype=np.uint16) if read_lens is not None
+                         else np.full(reads.shape[0], reads.shape[1], dtype=np.uint16))
+        else:
+            self.reads, self.lens = _ascii_matrix(list(reads))
+        self.lens = np.ascontiguousarray(self.lens, dtype=np.uint16)
+        self.indel_only = None if indel_only is None else np.ascontiguousarray(indel_only, dtype=np.uint8)
+        self.window = window.encode() if isinstance(window, str) else bytes(_ACGT[np.asarray(window)])
+        if sc_seqs is None:
+            self.sc, self.sc_lens = None, None
+        else:
+            self.sc, self.sc_lens = _ascii_matrix(list(sc_seqs))
+        self.partners = [pw.encode() if isinstance(pw, str) else bytes(_ACGT[np.asarray(pw)]) for pw in partners]
+
+    def fill(self, g: BkRegion):
+        g.reads = self.reads.ctypes.data
+        g.read_lens = self.lens.ctypes.data
+        g.indel_only = self.indel_only.ctypes.data if self.indel_only is not None else None
+        g.n_reads = self.reads.shape[0]
+        g.read_stride = self.reads.shape[1]
+        if self.sc is None:
+            g.sc_seqs, g.sc_lens, g.n_sc, g.sc_stride = None, None, -1, 0
+        else:
+            g.sc_seqs, g.sc_lens, g.n_sc, g.sc_stride = self.sc.ctypes.data, self.sc_lens.ctypes.data, self.sc.shape[0], self.sc.shape[1]
+        g.window = self.window
+        g.window_len = len(self.window)
+        g.n_partners = len(self.partners)
+        self._parr = (C.c_char_p * max(len(self.partners), 1))(*self.partners)
+        self._plens = np.array([len(x) for x in self.partners] + [0], dtype=np.int32)
+        g.partners = self._parr
+        g.partner_lens = self._plens.ctypes.data
+
+
+class Engine(object):
+    """One handle = one GPU + one stream (bk_create ... bk_destroy)."""
+
+    def __init__(self, kmer_size, rc_thresh=2, device=0, **limits):
+        self.L = load_library()
+        cfg = BkConfig()
+        cfg.abi_version = 1
+        cfg.kmer_size = int(kmer_size)
+        cfg.rc_thresh = int(rc_thresh)
+        cfg.max_contig_len = int(limits.get("max_contig_len", 0))
+        cfg.max_read_len = int(limits.get("max_read_len", 0))
+        cfg.max_candidates = int(limits.get("max_candidates", 0))
+        cfg.arena_bytes = int(limits.get("arena_bytes", 0))
+        cfg.sw_min_score = int(limits.get("sw_min_score", 0))
+        self.k = int(kmer_size)
+        self.h = C.c_void_p()
+        rc = self.L.bk_create(int(device), C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            raise BreakmerHipError("bk_create failed (%d): %s" % (rc, self.L.bk_last_error(None).decode()))
+        self.n_regions = 0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise BreakmerHipError("%s failed (%d): %s" % (what, rc, self.L.bk_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.L.bk_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, regions):
+        arr = (BkRegion * len(regions))()
+        for g, r in zip(arr, regions):
+            r.fill(g)
+        self._chk(self.L.bk_submit_regions(self.h, arr, len(regions)), "bk_submit_regions")
+        self.n_regions = len(regions)
+
+    def run(self, stages=BK_STAGE_KMER | BK_STAGE_ASSEMBLE, sync=True):
+        self._chk(self.L.bk_run(self.h, stages), "bk_run")
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._chk(self.L.bk_sync(self.h), "bk_sync")
+
+    def kernel_ms(self, which=0):
+        ms = C.c_float()
+        self._chk(self.L.bk_last_kernel_ms(self.h, which, C.byref(ms)), "bk_last_kernel_ms")
+        return ms.value
+
+    def stat(self, which):
+        v = C.c_uint64()
+        self._chk(self.L.bk_get_stat(self.h, which, C.byref(v)), "bk_get_stat")
+        return v.value
+
+    def kmers(self, region):
+        n, u = C.c_int32(), C.c_int32()
+        self._chk(self.L.bk_get_kmer_count(self.h, region, C.byref(n), C.byref(u)), "bk_get_kmer_count")
+        mers = np.zeros(max(n.value * self.k, 1), dtype=np.uint8)
+        cnt = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._chk(self.L.bk_get_kmers(self.h, region, mers.ctypes.data, cnt.ctypes.data, n.value), "bk_get_kmers")
+        return [mers[i * self.k:(i + 1) * self.k].tobytes().decode() for i in range(n.value)], cnt[:n.value].copy(), u.value
+
+    def contigs(self, region):
+        n = C.c_int32()
+        self._chk(self.L.bk_get_contig_count(self.h, region, C.byref(n)), "bk_get_contig_count")
+        out = []
+        for ci in range(n.value):
+            info = BkContigInfo()
+            self._chk(self.L.bk_get_contig_info(self.h, region, ci, C.byref(info)), "bk_get_contig_info")
+            seq = np.zeros(max(info.seq_len, 1), dtype=np.uint8)
+            io = np.zeros(max(info.counts_len, 1), dtype=np.int32)
+            ot = np.zeros(max(info.counts_len, 1), dtype=np.int32)
+            kl = np.zeros(max(info.seq_len, 1), dtype=np.int32)
+            km = np.zeros(max(info.n_kmers * self.k, 1), dtype=np.uint8)
+            rd = np.zeros(max(info.n_reads, 1), dtype=np.int32)
+            self._chk(self.L.bk_get_contig(self.h, region, ci, seq.ctypes.data, io.ctypes.data, ot.ctypes.data, kl.ctypes.data,
+                                           km.ctypes.data, rd.ctypes.data), "bk_get_contig")
+            out.append({"seq": seq[:info.seq_len].tobytes().decode(), "indel_only": io[:info.counts_len].tolist(),
+                        "others": ot[:info.counts_len].tolist(), "kmer_locs": kl[:info.seq_len].tolist(),
+                        "kmers": [km[i * self.k:(i + 1) * self.k].tobytes().decode() for i in range(info.n_kmers)],
+                        "reads": rd[:info.n_reads].tolist(), "total_reads": info.total_reads, "n_hits": info.n_hits})
+        return out
+
+    def nw_batch(self, pairs, reps=1):
+        """olc.nw on (seq1, seq2) pairs -> int32 [n,4] (j_start, i_end, i_start, score), kernel ms."""
+        blob = bytearray()
+        o1, l1, o2, l2 = [], [], [], []
+        for a, b in pairs:
+            o1.append(len(blob)); l1.append(len(a)); blob += a.encode()
+            o2.append(len(blob)); l2.append(len(b)); blob += b.encode()
+        o1, l1, o2, l2 = (np.array(x, dtype=np.uint32) for x in (o1, l1, o2, l2))
+        out = np.zeros((len(pairs), 4), dtype=np.int32)
+        ms = C.c_float()
+        self._chk(self.L.bk_nw_batch(self.h, bytes(blob), len(blob), o1.ctypes.data, l1.ctypes.data, o2.ctypes.data, l2.ctypes.data,
+                                     len(pairs), reps, out.ctypes.data, C.byref(ms)), "bk_nw_batch")
+        return out, ms.value

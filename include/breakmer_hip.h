@@ -1,0 +1,150 @@
+/* breakmer_hip.h -- C-ABI of libbreakmer_hip.so: the MI355X (gfx950) implementation of
+ * BreaKmer's per-target-region hot path, batched over regions.
+ *
+ * The reference has no FFI: its seams are Python calls and two text-file contracts.
+ * Each entry point below names the reference interface it replaces (file:line under the reference
+ * tree).  Conventions: plain C types only; every function returns 0 on success or a negative
+ * BK_E_* code (bk_last_error() gives the text); the library never frees caller memory; outputs are
+ * copied into caller-allocated buffers after a size query and stay valid until the next bk_run on
+ * the same handle.  One handle = one HIP device + one stream; handles are independent; calls on
+ * one handle are not re-entrant.
+ */
+#ifndef BREAKMER_HIP_H
+#define BREAKMER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BK_ABI_VERSION 1
+
+enum {
+    BK_OK = 0,
+    BK_E_ARG = -1,          /* bad argument */
+    BK_E_HIP = -2,          /* HIP runtime error (text in bk_last_error) */
+    BK_E_NOGPU = -3,        /* no usable gfx950 device: there is NO CPU fallback */
+    BK_E_LIMIT = -4,        /* a documented device limit was exceeded (contig/read/candidate caps) */
+    BK_E_STATE = -5,        /* call out of order (e.g. bk_run before bk_submit_regions) */
+    BK_E_NOMEM = -6
+};
+
+/* stage mask for bk_run */
+enum {
+    BK_STAGE_KMER = 1,      /* T1 read grouping + K1/K2 sample-only k-mer selection            */
+    BK_STAGE_ASSEMBLE = 2,  /* A1..A12 init_assembly incl. olc.nw                               */
+    BK_STAGE_REALIGN = 4,   /* R2 contig -> reference-window Smith-Waterman (replaces BLAT)     */
+    BK_STAGE_ALL = 7
+};
+
+typedef struct bk_handle bk_handle;
+
+/* Parameters the reference reads from its config/options (breakmer.py:73-86, utils.py:659-674). */
+typedef struct bk_config {
+    int32_t abi_version;        /* = BK_ABI_VERSION */
+    int32_t kmer_size;          /* kmer_region.config:16 `kmer_size`, utils.py:659 (<= 64) */
+    int32_t rc_thresh;          /* params.get_sr_thresh('min'), sv_processor.py:642 */
+    int32_t max_contig_len;     /* device cap on contig length (default 4096)      */
+    int32_t max_read_len;       /* device cap on read length   (default 1024)      */
+    int32_t max_candidates;     /* cap on reads returned by one find_reads (default 2048) */
+    int64_t arena_bytes;        /* device scratch arena; 0 = choose from the batch; grown and retried on overflow */
+    int32_t sw_min_score;       /* BLAT -minScore=20 analogue for the realign stage (sv_processor.py:843) */
+    int32_t reserved[7];
+} bk_config;
+
+/* One target region = what sv_processor.target hands to compare_kmers()/resolve_sv()
+ * (sv_processor.py:609-665): the cleaned reads (self.cleaned_read_recs before grouping,
+ * utils.py:203-246), the soft-clip sequences behind case_sc (sv_processor.py:619-620) and the
+ * forward reference window FASTA (sv_processor.py:291; the reverse file is derived).
+ * Sequences are ASCII A/C/G/T, rows `stride` bytes apart with explicit lengths. */
+typedef struct bk_region {
+    const char *reads;          /* n_reads rows */
+    const uint16_t *read_lens;
+    const uint8_t *indel_only;  /* fq_read.indel_only per read (utils.py:688); may be NULL = all 0 */
+    int32_t n_reads;
+    int32_t read_stride;
+    const char *sc_seqs;        /* soft-clip/unmapped sequences; n_sc < 0 => case_sc := case */
+    const uint16_t *sc_lens;
+    int32_t n_sc;
+    int32_t sc_stride;
+    const char *window;         /* forward target window, [start-200, end+200) (utils.py:367) */
+    int32_t window_len;
+    int32_t n_partners;         /* extra windows for realignment (whole-genome fallback stand-in, sv_processor.py:829-831) */
+    const char *const *partners;
+    const int32_t *partner_lens;
+} bk_region;
+
+/* Lifetime (replaces: process start + params(), sv_processor.py:99-105). Fails with BK_E_NOGPU when
+ * no gfx950 device is visible. */
+int bk_create(int device_id, const bk_config *cfg, bk_handle **out);
+int bk_destroy(bk_handle *h);
+const char *bk_last_error(const bk_handle *h);   /* h may be NULL: last error of bk_create */
+int bk_abi_version(void);
+
+/* Pack the regions' sequences to 2 bit/base and make them resident in HBM
+ * (replaces: writing <name>_sv_reads.fastq / *_refseq.fa for jellyfish and the assembler,
+ * sv_processor.py:584-606, utils.py:355-381). */
+int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions);
+
+/* Run the selected stages on everything submitted (replaces, per region:
+ *   BK_STAGE_KMER     run_jellyfish x4 + load_kmers + set algebra, utils.py:151-178,287-296, sv_processor.py:613-631
+ *   BK_STAGE_ASSEMBLE init_assembly(mers, fq_recs, kmer_len, rc_thresh, read_len), sv_assembly.py:30
+ *   BK_STAGE_REALIGN  contig.query_ref -> blat -> PSL, sv_processor.py:823-851).
+ * Asynchronous on the handle's stream; bk_sync() or any bk_get_* waits. */
+int bk_run(bk_handle *h, uint32_t stage_mask);
+int bk_sync(bk_handle *h);
+/* elapsed device time of the kernels of the last bk_run, measured with HIP events on the handle's
+ * stream (ms); which = 0 total, 1 k-mer kernel, 2 assembler kernel, 3 realign kernel */
+int bk_last_kernel_ms(bk_handle *h, int which, float *ms);
+
+/* ---- results, region-major -------------------------------------------------------------- */
+/* K1/K2: sample-only k-mers of region r in the order init_assembly visits them
+ * ((count, mer) descending, sv_assembly.py:281); mers = n*k ASCII bytes. */
+int bk_get_kmer_count(bk_handle *h, int32_t region, int32_t *n_mers, int32_t *n_unique_reads);
+int bk_get_kmers(bk_handle *h, int32_t region, char *mers, int32_t *counts, int32_t cap);
+
+/* contigs of region r, in the order init_assembly returns them (sv_assembly.py:59) */
+typedef struct bk_contig_info {
+    int32_t seq_len;        /* len(contig.aseq.seq)                      */
+    int32_t counts_len;     /* len(contig.aseq.counts.others) (may differ: set_superseq quirk, sv_assembly.py:190-191) */
+    int32_t n_kmers;        /* len(contig.kmers)                         */
+    int32_t n_reads;        /* len(contig.reads)                         */
+    int32_t total_reads;    /* contig.get_total_read_support()           */
+    int32_t n_hits;         /* realign stage: PSL-equivalent records     */
+} bk_contig_info;
+int bk_get_contig_count(bk_handle *h, int32_t region, int32_t *n_contigs);
+int bk_get_contig_info(bk_handle *h, int32_t region, int32_t contig, bk_contig_info *info);
+/* any pointer may be NULL; sizes from bk_contig_info.
+ *   seq        seq_len ASCII bytes            (contig.get_contig_seq(), sv_assembly.py:443)
+ *   indel_only counts_len ints, others ditto  (contig.get_contig_counts(), :446)
+ *   kmer_locs  seq_len ints                   (contig.get_kmer_locs(), :440)
+ *   kmers      n_kmers*k ASCII bytes          (x[0] of contig.kmers, sv_processor.py:760)
+ *   reads      n_reads ints: index (FASTQ order within the region) of each supporting read's representative */
+int bk_get_contig(bk_handle *h, int32_t region, int32_t contig, char *seq, int32_t *indel_only, int32_t *others,
+                  int32_t *kmer_locs, char *kmers, int32_t *reads);
+
+/* realign stage: one PSL-equivalent record per hit (fields consumed by sv_caller.py:911-936) */
+#define BK_MAX_BLOCKS 16
+typedef struct bk_psl {
+    int32_t matches, mismatches, rep_matches, n_count;
+    int32_t q_num_insert, q_base_insert, t_num_insert, t_base_insert;
+    int32_t strand;             /* '+' or '-' */
+    int32_t q_size, q_start, q_end;
+    int32_t t_index;            /* 0 = target window, 1.. = partner windows */
+    int32_t t_size, t_start, t_end;
+    int32_t block_count;
+    int32_t block_sizes[BK_MAX_BLOCKS], q_starts[BK_MAX_BLOCKS], t_starts[BK_MAX_BLOCKS];
+    int32_t score;
+} bk_psl;
+int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl *hits, int32_t cap);
+
+/* bookkeeping for measurement: algorithmic work of the last bk_run
+ *   which = 0: olc.nw DP cells (sum len(seq1)*len(seq2)), 1: olc.nw calls, 2: SW cells,
+ *           3: algorithmic HBM bytes (SURVEY 8d formula), 4: unique reads, 5: sample k-mers, 6: contigs */
+int bk_get_stat(bk_handle *h, int which, uint64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,108 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the oracle and the golden
+fixtures generated from the real reference.  Run with -m gpu on an MI355X."""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+from breakmer_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hb():
+    from breakmer_amd import hip_backend
+    hip_backend.load_library()          # fails loudly if the extension is missing
+    return hip_backend
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def test_g1_nw_kats_gpu(hb, golden_dir):
+    """olc.nw on the wavefront DP == the reference's 7-tuple (fields 2..6; 0,1 are the slices)."""
+    d = _load(golden_dir, "nw_kats.json")
+    eng = hb.Engine(kmer_size=31)
+    pairs = [(c["seq1"], c["seq2"]) for c in d["cases"]]
+    out, _ = eng.nw_batch(pairs)
+    for c, o in zip(d["cases"], out.tolist()):
+        exp = c["out"]
+        assert o == [exp[3], exp[4], exp[5], exp[6]], c["tag"]
+        # the aligned strings stripped of '-' are the plain slices (what check_align consumes)
+        assert exp[0].replace("-", "") == c["seq1"][exp[3]:exp[2]]
+        assert exp[1].replace("-", "") == c["seq2"][exp[5]:exp[4]]
+
+
+def test_nw_random_vs_oracle_gpu(hb):
+    from oracle import bk_oracle as bo
+    rnd = random.Random(11)
+    pairs = []
+    for t in range(400):
+        m, n = rnd.randint(1, 700), rnd.randint(1, 300)
+        a = "".join(rnd.choice("ACGT") for _ in range(m))
+        if rnd.random() < 0.7:
+            ov = rnd.randint(1, min(m, n))
+            b = a[m - ov:] + "".join(rnd.choice("ACGT") for _ in range(n - ov))
+            b = "".join((ch if rnd.random() > 0.03 else rnd.choice("ACGT")) for ch in b)
+        else:
+            b = "".join(rnd.choice("ACGT") for _ in range(n))
+        pairs.append((a, b))
+        pairs.append((b, a))
+    # column tiles: more than 512 columns, and a 4000-column case
+    big = "".join(rnd.choice("ACGT") for _ in range(4000))
+    pairs.append((big, big[3800:] + "ACGTACGT" * 10))
+    pairs.append((big[:1500], big[1300:1500] + "TTTT" * 20))
+    eng = hb.Engine(kmer_size=31)
+    out, _ = eng.nw_batch(pairs)
+    for (a, b), o in zip(pairs, out.tolist()):
+        e = bo.nw(a, b)
+        assert o == [e[3], e[4], e[5], e[6]], (len(a), len(b))
+
+
+def _run_regions(hb, regions, k, rc_thresh=2):
+    eng = hb.Engine(kmer_size=k, rc_thresh=rc_thresh)
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only) for r in regions])
+    eng.run()
+    return eng
+
+
+def _strip(contigs):
+    return [{k: v for k, v in c.items() if k not in ("total_reads", "n_hits")} for c in contigs]
+
+
+def test_g3_assembly_golden_gpu(hb, golden_dir):
+    """k-mer selection + assembly on the GPU == contigs the REAL reference produced (fixtures)."""
+    d = _load(golden_dir, "assembly.json")
+    by_cfg = {}
+    for c in d["cases"]:
+        by_cfg.setdefault((c["k"], c["rc_thresh"]), []).append(c)
+    for (k, rc), cases in by_cfg.items():
+        regions = [synth.make_region(**c["gen"]) for c in cases]
+        for c, r in zip(cases, regions):
+            assert hashlib.sha256(("\n".join(r.read_strs())).encode()).hexdigest() == c["reads_sha256"]
+        eng = _run_regions(hb, regions, k, rc)
+        for i, c in enumerate(cases):
+            mers, counts, U = eng.kmers(i)
+            assert len(mers) == c["n_mers"], c["tag"]
+            got = dict(zip(mers, counts.tolist()))
+            msum = hashlib.sha256(("\n".join("%s %d" % (m, got[m]) for m in sorted(got))).encode()).hexdigest()
+            assert msum == c["mers_sha256"], c["tag"]
+            # visit order of init_assembly: (count, mer) descending
+            assert mers == [m for m, _ in sorted(got.items(), key=lambda x: (x[1], x[0]), reverse=True)], c["tag"]
+            assert _strip(eng.contigs(i)) == c["contigs"], c["tag"]
+
+
+def test_batch_vs_oracle_gpu(hb):
+    """A mixed batch (config-2-like regions at reduced depth) against the C oracle."""
+    from oracle import bk_oracle as bo
+    regions = [synth.make_region(100 + i, sv_type=synth.SV_TYPES[i % 4], depth=100, W=3000) for i in range(16)]
+    eng = _run_regions(hb, regions, 31)
+    for i, r in enumerate(regions):
+        want, info = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
+        assert _strip(eng.contigs(i)) == want, i
+    assert eng.stat(0) > 0 and eng.stat(1) > 0
