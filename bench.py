@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- BreaKmer hot path on MI355X: target regions/s at 500x 150 bp reads, 31-mers.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (the driver launches N>1 through torch.distributed.run).  A "step" is one pass of
+the hot path (read grouping -> k-mer selection -> assembly [-> realign -> call]) over one batch of
+synthetic regions (BASELINE.json configs[1]: 256 regions per GPU, 10,000 x 150 bp reads each, planted
+200 bp deletion, k = 31), inputs already packed and resident in HBM.  Regions are independent, so
+ranks get disjoint region ids (weak scaling) and the only exchange is the all-gather of the per-region
+result records at the end of each step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--regions", type=int, default=256, help="regions per GPU per step (configs[1])")
+    ap.add_argument("--depth", type=int, default=500)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--kmer", type=int, default=31)
+    ap.add_argument("--cpu-sample", type=int, default=24, help="regions timed through the CPU oracle (0 = skip)")
+    return ap.parse_args()
+
+
+def result_records(eng, n_regions):
+    """Per-region result records of this rank as one uint8 blob (what gets collated)."""
+    recs = []
+    for r in range(n_regions):
+        for ci, c in enumerate(eng.contigs(r)):
+            recs.append("%d\t%d\t%s\t%d\t%d" % (r, ci, c["seq"], c["total_reads"], len(c["kmers"])))
+    return np.frombuffer(("\n".join(recs)).encode(), dtype=np.uint8)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from breakmer_amd import hip_backend as hb, synth
+
+    # ---- inputs: disjoint region ids per rank (weak scaling), packed + resident before timing -------
+    ids = range(rank * a.regions, (rank + 1) * a.regions)
+    regions = [synth.make_region(i, depth=a.depth, L=a.read_len, sv_type="del") for i in ids]
+    eng = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local)
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
+    stages = hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE
+
+    def step():
+        eng.run(stages, sync=True)
+        blob = result_records(eng, a.regions)
+        if dist:                                       # collate variable-length records: sizes, then padded all-gather (RCCL)
+            n = torch.tensor([blob.size], device="cuda", dtype=torch.int64)
+            sizes = [torch.zeros_like(n) for _ in range(world)]
+            td.all_gather(sizes, n)
+            mx = int(max(int(s.item()) for s in sizes))
+            buf = torch.zeros(mx, dtype=torch.uint8, device="cuda")
+            buf[:blob.size] = torch.from_numpy(blob.copy()).cuda()
+            out = [torch.empty_like(buf) for _ in range(world)]
+            td.all_gather(out, buf)
+            return sum(int(s.item()) for s in sizes)
+        return blob.size
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    asm_ms = kmer_ms = 0.0
+    for _ in range(a.steps):
+        step()
+        kmer_ms += eng.kernel_ms(1)
+        asm_ms += eng.kernel_ms(2)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    total_regions = a.regions * world * a.steps
+    value = total_regions / dt
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (assembler): algorithmic HBM bytes per launch / kernel time -----
+        alg_bytes = eng.stat(3)                         # 2-bit reads + 4 B/read + window fwd+rc + ~2 KB out, summed over regions
+        asm_s = asm_ms / a.steps / 1e3
+        achieved = alg_bytes / asm_s / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.isfile(tf):
+            try:
+                traffic = json.load(open(tf)).get("bk_asm_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        cells, calls = eng.stat(0), eng.stat(1)
+        out = {
+            "metric": "target regions/sec at 500x 150bp, 31-mers; achieved HBM GB/s vs roofline",
+            "value": round(value, 1), "unit": "regions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d regions/GPU x %d reads x %d bp (%dx), planted 200 bp deletion, k=%d"
+                                   % (a.regions, regions[0].reads.shape[0], a.read_len, a.depth, a.kmer),
+                       "stages": "group reads + k-mer select + assemble (olc.nw) on GPU; results read back and collated",
+                       "parallelism": "regions sharded per GPU, all-gather of result records"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel": "bk_asm_kernel", "kernel_ms": round(asm_ms / a.steps, 3),
+                         "note": "path is integer-DP/latency bound, not HBM bound (SURVEY 8d); see dp_gcups"},
+            "kernels_ms": {"bk_kmer_kernel": round(kmer_ms / a.steps, 3), "bk_asm_kernel": round(asm_ms / a.steps, 3)},
+            "dp_gcups": round(cells / asm_s / 1e9, 1), "dp_cells_per_step": cells, "nw_calls_per_step": calls,
+        }
+        # ---- CPU baseline: the oracle (C port of the reference algorithm), 1 core, bounded sample -------
+        if world == 1 and a.cpu_sample > 0:
+            from oracle import bk_oracle as bo
+            bo.lib()
+            ns = min(a.cpu_sample, a.regions)
+            asc = [synth.BASES[regions[i].reads] for i in range(ns)]
+            wins = [regions[i].window_str for i in range(ns)]
+            t1 = time.perf_counter()
+            wants = [bo.assemble_region(asc[i], [wins[i]], a.kmer, 2)[0] for i in range(ns)]
+            cpu_dt = time.perf_counter() - t1
+            ok = all([{k: v for k, v in c.items() if k not in ("total_reads", "n_hits")} for c in eng.contigs(i)] == wants[i] for i in range(ns))
+            out["cpu_baseline"] = {"value": round(ns / cpu_dt, 3), "unit": "regions/s", "cores": 1, "kind": "port",
+                                   "sample": "%d of the %d regions of the same batch through oracle/bk_oracle.c (T1+K1/K2+init_assembly), 1 thread" % (ns, a.regions),
+                                   "parity_on_sample": bool(ok)}
+        print(json.dumps(out))
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
