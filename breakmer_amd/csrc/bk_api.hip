@@ -4,6 +4,7 @@
 #include "bk_common.h"
 #include "bk_kmer.hip.h"
 #include "bk_asm.hip.h"
+#include "bk_sw.hip.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -40,6 +41,8 @@ struct bk_handle {
     // host mirrors
     std::vector<BkRegionDesc> h_desc; std::vector<BkRegionWork> h_work; std::vector<uint8_t> h_out;
     std::vector<BkPartnerDesc> h_part;
+    std::vector<std::vector<std::string>> h_targets;      // per region: target window + partner windows (ASCII), for PSL assembly
+    uint32_t max_win = 0;
     uint64_t total_reads = 0, alg_bytes = 0;
     float ms[4] = {0, 0, 0, 0};
     BkParams params{};
@@ -120,7 +123,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     HIPCHK(h, hipSetDevice(h->dev));
     const int k = h->cfg.kmer_size;
     std::vector<uint32_t> reads, sc, win; std::vector<uint16_t> rlen, sclen; std::vector<uint8_t> rflag;
-    h->h_desc.assign(n_regions, BkRegionDesc{}); h->h_part.clear();
+    h->h_desc.assign(n_regions, BkRegionDesc{}); h->h_part.clear(); h->h_targets.assign(n_regions, {}); h->max_win = 0;
     uint64_t dd_total = 0; uint32_t max_w = 0; h->alg_bytes = 0;
     size_t tot_reads = 0, tot_words = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;
     for (int r = 0; r < n_regions; r++) {
@@ -158,12 +161,16 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         d.win_len = g.window_len; d.win_word_off = win.size();
         { size_t nw = (g.window_len + 15) / 16 + 2; win.resize(win.size() + nw); if (!pack_seq(g.window, g.window_len, win.data() + d.win_word_off, (int)nw)) return fail(h, BK_E_ARG, "bk_submit_regions: non-ACGT base in reference window"); }
         max_w = std::max<uint32_t>(max_w, g.window_len);
+        h->max_win = std::max<uint32_t>(h->max_win, g.window_len);
+        h->h_targets[r].emplace_back(g.window, g.window_len);
+        if (g.n_partners > 15) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 15 partner windows");
         d.n_partners = g.n_partners; d.part_desc_off = h->h_part.size();
         for (int q = 0; q < g.n_partners; q++) {
             BkPartnerDesc pd; pd.word_off = win.size(); pd.len = g.partner_lens[q]; pd.pad = 0;
             size_t nw = (pd.len + 15) / 16 + 2; win.resize(win.size() + nw);
             if (!pack_seq(g.partners[q], pd.len, win.data() + pd.word_off, (int)nw)) return fail(h, BK_E_ARG, "bk_submit_regions: non-ACGT base in partner window");
             h->h_part.push_back(pd);
+            h->h_targets[r].emplace_back(g.partners[q], pd.len); h->max_win = std::max<uint32_t>(h->max_win, pd.len);
         }
         uint32_t cap = 64; while (cap < 2u * (uint32_t)std::max(g.n_reads, 1)) cap <<= 1;
         d.dedup_cap = cap; d.dedup_off = dd_total; dd_total += cap;
@@ -245,6 +252,13 @@ static int launch(bk_handle *h, uint32_t mask)
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    if (mask & BK_STAGE_REALIGN) {
+        const size_t lds = ((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + h->max_win + 16;
+        if (lds > 160 * 1024) return fail(h, BK_E_LIMIT, "realign: windows too long for LDS staging in this round");
+        HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bk_sw_kernel, dim3(h->n_regions), dim3(BK_ST_T), lds, h->stream, h->params, h->max_win);
+        HIPCHK(h, hipGetLastError());
+    }
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     return BK_OK;
 }
@@ -254,7 +268,7 @@ extern "C" int bk_run(bk_handle *h, uint32_t stage_mask)
     if (!h) return BK_E_ARG;
     if (!h->submitted) return fail(h, BK_E_STATE, "bk_run: no regions submitted");
     if ((stage_mask & BK_STAGE_ASSEMBLE) && !(stage_mask & BK_STAGE_KMER)) return fail(h, BK_E_ARG, "bk_run: BK_STAGE_ASSEMBLE needs BK_STAGE_KMER in the same run");
-    if (stage_mask & BK_STAGE_REALIGN) return fail(h, BK_E_ARG, "bk_run: BK_STAGE_REALIGN is not built in this round");
+    if ((stage_mask & BK_STAGE_REALIGN) && !(stage_mask & BK_STAGE_ASSEMBLE)) return fail(h, BK_E_ARG, "bk_run: BK_STAGE_REALIGN needs BK_STAGE_ASSEMBLE in the same run");
     HIPCHK(h, hipSetDevice(h->dev));
     h->ran_mask = stage_mask; h->fetched = false; h->synced = false;
     int rc = launch(h, stage_mask);
@@ -392,7 +406,65 @@ extern "C" int bk_get_contig(bk_handle *h, int32_t region, int32_t contig, char 
     return BK_OK;
 }
 
-extern "C" int bk_get_hits(bk_handle *h, int32_t, int32_t, bk_psl *, int32_t) { return fail(h, BK_E_ARG, "bk_get_hits: BK_STAGE_REALIGN is not built in this round"); }
+// Chain the raw hits of one contig into PSL-equivalent records (contract: oracle/bk_oracle.h R2 step 3).
+static int chain_hits(const char *contig, int Q, const std::vector<std::string> &targets, std::vector<BkHit> hits, bk_psl *out, int cap)
+{
+    std::string rc(Q, 'N');
+    for (int i = 0; i < Q; i++) { char c = contig[Q - 1 - i]; rc[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+    std::stable_sort(hits.begin(), hits.end(), [](const BkHit &a, const BkHit &b) { return a.fq < b.fq; });
+    const int nh = (int)hits.size();
+    int nrec = 0, i = 0;
+    while (i < nh) {
+        std::vector<BkHit> chain; chain.push_back(hits[i]);           // strand order
+        int j = i + 1;
+        while (j < nh) {
+            BkHit h = hits[j];
+            if (h.tidx != chain.front().tidx || h.strand != chain.front().strand) break;
+            BkHit *first = h.strand == 0 ? &chain.back() : &h, *second = h.strand == 0 ? &h : &chain.front();
+            const int ov = first->te - second->ts;
+            if (ov > 0 && (2 * ov >= first->qe - first->qs || 2 * ov >= second->qe - second->qs)) break;
+            if (second->qs < first->qe) break;
+            if (ov > 0) { second->qs += ov; second->ts += ov; }         // trim micro-homology from the later hit
+            if (h.strand == 0) chain.push_back(h); else chain.insert(chain.begin(), h);
+            j++;
+        }
+        if (nrec < cap) {
+            bk_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
+            const BkHit &f = chain.front(), &l = chain.back();
+            const char *qstr = f.strand == 0 ? contig : rc.c_str(); const std::string &t = targets[f.tidx];
+            r->strand = f.strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = f.tidx; r->t_size = (int32_t)t.size();
+            r->t_start = f.ts; r->t_end = l.te;
+            r->q_start = f.strand == 0 ? f.qs : Q - l.qe; r->q_end = f.strand == 0 ? l.qe : Q - f.qs;
+            int nb = 0, pq = -1, pt = -1;
+            for (const BkHit &c : chain) {
+                r->score += c.score;
+                if (nb >= BK_MAX_BLOCKS) continue;
+                const int bs = c.qe - c.qs;
+                for (int z = 0; z < bs; z++) { if (qstr[c.qs + z] == t[c.ts + z]) r->matches++; else r->mismatches++; }
+                if (pq >= 0) { if (c.qs > pq) { r->q_num_insert++; r->q_base_insert += c.qs - pq; } if (c.ts > pt) { r->t_num_insert++; r->t_base_insert += c.ts - pt; } }
+                r->block_sizes[nb] = bs; r->q_starts[nb] = c.qs; r->t_starts[nb] = c.ts; nb++;
+                pq = c.qe; pt = c.te;
+            }
+            r->block_count = nb;
+        }
+        nrec++;
+        i = j;
+    }
+    return nrec;
+}
+
+extern "C" int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl *hits, int32_t cap)
+{
+    if (!h || region < 0 || region >= h->n_regions || !hits) return BK_E_ARG;
+    int rc = fetch(h); if (rc != BK_OK) return rc;
+    const BkContigRec *c = find_contig(h, region, contig);
+    if (!c) return fail(h, BK_E_ARG, "bk_get_hits: no such contig");
+    std::vector<BkHit> raw;
+    if (c->n_hits > 0 && c->hits_off) { const BkHit *p = (const BkHit *)(h->h_out.data() + c->hits_off); raw.assign(p, p + c->n_hits); }
+    const char *seq = (const char *)c + c->o_seq;
+    std::string s(seq, c->seq_len);
+    return chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, hits, cap);   // returns the number of records (>= 0)
+}
 
 extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
 {

@@ -579,7 +579,7 @@ __device__ inline void bk_emit_contig()
     BK_SYNC();
     for (int x = BK_TID; x + k <= len; x += BK_AT) { int rk = bk_lookup(bk_bytes_kmer(cs + x, k)); if (rk >= 0) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
     if (BK_TID == 0) {
-        h->next = 0; h->seq_len = len; h->counts_len = nlen; h->n_kmers = nk; h->n_reads = nr; h->total_reads = total; h->n_hits = 0;
+        h->next = 0; h->hits_off = 0; h->seq_len = len; h->counts_len = nlen; h->n_kmers = nk; h->n_reads = nr; h->total_reads = total; h->n_hits = 0;
         h->o_seq = o_seq; h->o_io = o_io; h->o_ot = o_ot; h->o_klocs = o_kl; h->o_kmers = o_km; h->o_reads = o_rd; h->o_hits = 0; h->size = size;
         if (C_.wk->o_first_contig == 0) C_.wk->o_first_contig = off; else ((BkContigRec *)(C_.out + C_.wk->o_last_contig))->next = off;
         C_.wk->o_last_contig = off; S->n_contigs++;

@@ -114,8 +114,11 @@ enum { BK_R_USED = 1, BK_R_DELETED = 2, BK_R_INDEL = 4 };
 
 // contig record in the `out` arena (o_* relative to the record start, 8-byte aligned; k-mers are
 // stored as (lo, hi) key pairs so the record is self-contained)
+struct BkHit { int32_t qs, qe, ts, te, strand, tidx, score, fq; };   // qs/qe in strand coordinates, fq = forward query start
+#define BK_MAX_HITS 8
 struct BkContigRec {
-    uint64_t next;               // arena offset of the next contig record of the region (0 = end)
+    uint64_t next;               // `out` offset of the next contig record of the region (0 = end)
+    uint64_t hits_off;           // `out` offset of BkHit[n_hits] (realign stage), 0 = none
     int32_t seq_len, counts_len, n_kmers, n_reads, total_reads, n_hits;
     uint32_t o_seq, o_io, o_ot, o_klocs, o_kmers, o_reads, o_hits, size;
 };

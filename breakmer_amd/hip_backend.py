@@ -232,6 +232,23 @@ class Engine(object):
                         "reads": rd[:info.n_reads].tolist(), "total_reads": info.total_reads, "n_hits": info.n_hits})
         return out
 
+    def hits(self, region, contig):
+        """PSL-equivalent records of one contig (realign stage) as dicts."""
+        arr = (BkPsl * 16)()
+        n = self.L.bk_get_hits(self.h, region, contig, arr, 16)
+        if n < 0:
+            self._chk(n, "bk_get_hits")
+        out = []
+        for r in arr[:min(n, 16)]:
+            nb = r.block_count
+            out.append({"matches": r.matches, "mismatches": r.mismatches, "rep_matches": r.rep_matches, "n_count": r.n_count,
+                        "q_num_insert": r.q_num_insert, "q_base_insert": r.q_base_insert, "t_num_insert": r.t_num_insert,
+                        "t_base_insert": r.t_base_insert, "strand": chr(r.strand), "q_size": r.q_size, "q_start": r.q_start,
+                        "q_end": r.q_end, "t_index": r.t_index, "t_size": r.t_size, "t_start": r.t_start, "t_end": r.t_end,
+                        "block_sizes": list(r.block_sizes[:nb]), "q_starts": list(r.q_starts[:nb]), "t_starts": list(r.t_starts[:nb]),
+                        "score": r.score})
+        return out
+
     def nw_batch(self, pairs, reps=1):
         """olc.nw on (seq1, seq2) pairs -> int32 [n,4] (j_start, i_end, i_start, score), kernel ms."""
         blob = bytearray()

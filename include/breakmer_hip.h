@@ -124,7 +124,9 @@ int bk_get_contig_info(bk_handle *h, int32_t region, int32_t contig, bk_contig_i
 int bk_get_contig(bk_handle *h, int32_t region, int32_t contig, char *seq, int32_t *indel_only, int32_t *others,
                   int32_t *kmer_locs, char *kmers, int32_t *reads);
 
-/* realign stage: one PSL-equivalent record per hit (fields consumed by sv_caller.py:911-936) */
+/* realign stage: PSL-equivalent records of one contig (fields consumed by sv_caller.py:911-936), i.e. the
+ * raw device hits chained on the host.  Returns the number of records (>= 0, may exceed cap) or a
+ * negative BK_E_* code.  q_starts are in strand coordinates as in PSL. */
 #define BK_MAX_BLOCKS 16
 typedef struct bk_psl {
     int32_t matches, mismatches, rep_matches, n_count;

@@ -636,3 +636,119 @@ int bko_check_align_case(const char *contig_seq, int clen, const char *read_seq,
     contig_free(c); bko_asm_free(a); free(useqs); free(mers); free(counts);
     return match;
 }
+
+/* ------------------------------------------------------------------ R2 realign (see bk_oracle.h) */
+static uint64_t g_sw_cells = 0;
+uint64_t bko_sw_cells(int reset) { uint64_t v = g_sw_cells; if (reset) g_sw_cells = 0; return v; }
+#define SW_MAXHITS 8
+typedef struct { int qs, qe, ts, te, strand, tidx, score, nb; int bs[BKO_MAX_BLOCKS], bq[BKO_MAX_BLOCKS], bt[BKO_MAX_BLOCKS]; int fq; } swhit;   /* q coords are strand coords; fq = forward start */
+
+/* Gap-free local Smith-Waterman (maximal scoring segment): H[a][b] = max(0, H[a-1][b-1] + s(q_a, t_b)).
+ * Gaps are NOT opened inside a hit -- like BLAT, hits are ungapped blocks and gaps only appear when
+ * collinear hits are chained (a finite linear gap penalty smears long inserts over coincidental
+ * matches).  Best end = max score, then smallest query end a, then smallest target
+ * end b; the start is where the positive run on that diagonal began. */
+static int sw_local(const char *q, int n, const char *t, int m, int *a0, int *a1, int *b0, int *b1)
+{
+    int *H = (int *)xcalloc((size_t)(m + 1) * 2, sizeof(int)), *R = (int *)xcalloc((size_t)(m + 1) * 2, sizeof(int));
+    int best = 0, ba = 0, bb = 0, br = 0;
+    for (int a = 1; a <= n; a++) {
+        int *hp = H + ((a - 1) & 1) * (m + 1), *hc = H + (a & 1) * (m + 1), *rp = R + ((a - 1) & 1) * (m + 1), *rc_ = R + (a & 1) * (m + 1);
+        hc[0] = 0; rc_[0] = 0;
+        for (int b = 1; b <= m; b++) {
+            int s = hp[b - 1] + (q[a - 1] == t[b - 1] ? 1 : -2), run = rp[b - 1] + 1;
+            if (s <= 0) { s = 0; run = 0; }
+            hc[b] = s; rc_[b] = run;
+            if (s > best) { best = s; ba = a; bb = b; br = run; }    /* strict: smallest a, then smallest b */
+        }
+    }
+    g_sw_cells += (uint64_t)n * (uint64_t)m;
+    *a0 = ba - br; *a1 = ba; *b0 = bb - br; *b1 = bb;
+    free(H); free(R);
+    return best;
+}
+static int sw_blocks(const char *q, const char *t, int a0, int a1, int b0, int b1, int score, int *bs, int *bq, int *bt)
+{
+    (void)q; (void)t; (void)score; (void)b1;
+    bs[0] = a1 - a0; bq[0] = a0; bt[0] = b0;
+    return 1;
+}
+static int cmp_hit_fq(const void *x, const void *y) { return ((const swhit *)x)->fq - ((const swhit *)y)->fq; }
+
+int bko_realign(const char *contig, int Q, const char *const *targets, const int *tlens, int ntargets,
+                int min_score, int min_seg, bko_psl *out, int cap)
+{
+    char *rc = (char *)xmalloc((size_t)Q + 1);
+    for (int i = 0; i < Q; i++) { char c = contig[Q - 1 - i]; rc[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+    swhit hits[SW_MAXHITS]; int nh = 0;
+    int stk[2 * (SW_MAXHITS * 2 + 2)], sp = 0;
+    stk[sp++] = 0; stk[sp++] = Q;
+    while (sp > 0 && nh < SW_MAXHITS) {
+        int qe = stk[--sp], qs = stk[--sp];
+        if (qe - qs < min_seg) continue;
+        swhit best; best.score = 0; int have = 0;
+        for (int ti = 0; ti < ntargets; ti++) for (int st = 0; st < 2; st++) {
+            const char *qq = st == 0 ? contig + qs : rc + (Q - qe);
+            int a0, a1, b0, b1, sc = sw_local(qq, qe - qs, targets[ti], tlens[ti], &a0, &a1, &b0, &b1);
+            if (sc > best.score) {                                   /* strict: earlier (target, strand) wins ties */
+                int off = st == 0 ? qs : Q - qe;
+                best.score = sc; best.qs = off + a0; best.qe = off + a1; best.ts = b0; best.te = b1; best.strand = st; best.tidx = ti; have = 1;
+            }
+        }
+        if (!have || best.score < min_score) continue;
+        const char *qstr = best.strand == 0 ? contig : rc;
+        best.nb = sw_blocks(qstr, targets[best.tidx], best.qs, best.qe, best.ts, best.te, best.score, best.bs, best.bq, best.bt);
+        int fs = best.strand == 0 ? best.qs : Q - best.qe, fe = best.strand == 0 ? best.qe : Q - best.qs;   /* forward query interval */
+        best.fq = fs;
+        hits[nh++] = best;
+        stk[sp++] = fe; stk[sp++] = qe;                              /* right remainder (processed after the left one) */
+        stk[sp++] = qs; stk[sp++] = fs;
+    }
+    qsort(hits, (size_t)nh, sizeof(swhit), cmp_hit_fq);
+    /* chain + emit: hits consecutive in forward query order, same target and strand, collinear on the strand */
+    int nrec = 0, i = 0;
+    while (i < nh) {
+        swhit chain[2 * SW_MAXHITS + 1]; int head = SW_MAXHITS, tail = SW_MAXHITS;     /* deque [head, tail) in strand order */
+        chain[tail++] = hits[i];
+        int j = i + 1;
+        while (j < nh) {
+            swhit h = hits[j];
+            if (h.tidx != chain[head].tidx || h.strand != chain[head].strand) break;
+            /* '+': forward order == strand order; '-': the forward-later hit comes first on the strand */
+            swhit *first = h.strand == 0 ? &chain[tail - 1] : &h, *second = h.strand == 0 ? &h : &chain[head];
+            int ov = first->te - second->ts;
+            if (ov > 0) {                                                 /* small target overlap (micro-homology): trim the later hit */
+                if (2 * ov >= first->qe - first->qs || 2 * ov >= second->qe - second->qs || second->bs[0] <= ov) break;
+            }
+            if (second->qs < first->qe) break;
+            if (ov > 0) { second->bs[0] -= ov; second->bq[0] += ov; second->bt[0] += ov; second->qs += ov; second->ts += ov; }
+            if (h.strand == 0) chain[tail++] = h; else chain[--head] = h;
+            j++;
+        }
+        if (nrec < cap) {
+            bko_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
+            const swhit *f = &chain[head], *l = &chain[tail - 1];
+            const char *qstr = f->strand == 0 ? contig : rc; const char *tstr = targets[f->tidx];
+            r->strand = f->strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = f->tidx; r->t_size = tlens[f->tidx];
+            r->t_start = f->ts; r->t_end = l->te;
+            const int sq = f->qs, eq = l->qe;                            /* strand coordinates */
+            r->q_start = f->strand == 0 ? sq : Q - eq; r->q_end = f->strand == 0 ? eq : Q - sq;
+            int nb = 0, pq = -1, pt = -1;
+            for (int c = head; c < tail; c++) {
+                r->score += chain[c].score;
+                for (int b = 0; b < chain[c].nb && nb < BKO_MAX_BLOCKS; b++) {
+                    int bs = chain[c].bs[b], bq = chain[c].bq[b], bt = chain[c].bt[b];
+                    for (int z = 0; z < bs; z++) { if (qstr[bq + z] == tstr[bt + z]) r->matches++; else r->mismatches++; }
+                    if (pq >= 0) { if (bq > pq) { r->q_num_insert++; r->q_base_insert += bq - pq; } if (bt > pt) { r->t_num_insert++; r->t_base_insert += bt - pt; } }
+                    r->block_sizes[nb] = bs; r->q_starts[nb] = bq; r->t_starts[nb] = bt; nb++;
+                    pq = bq + bs; pt = bt + bs;
+                }
+            }
+            r->block_count = nb;
+        }
+        nrec++;
+        i = j;
+    }
+    free(rc);
+    return nrec;
+}

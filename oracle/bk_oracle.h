@@ -59,6 +59,34 @@ void bko_asm_contig_get(const bko_asm *a, int c, char *seq, int *indel_only, int
 void bko_asm_read_flags(const bko_asm *a, uint8_t *flags);
 void bko_asm_free(bko_asm *a);
 
+/* ------------------------------------------------------------------ R2: contig -> window realignment
+ * Replaces the external BLAT call (sv_processor.py:835-851).  BLAT's source is not in the reference
+ * tree and the binary is absent: PARITY WITH BLAT IS UNPINNED.  This function DEFINES the contract
+ * the HIP realign kernel must reproduce bit for bit (DESIGN.md "Realign contract"):
+ *   1. iterated gap-free local Smith-Waterman (maximal scoring segment; match +1, mismatch -2) of
+ *      the still-unaligned query intervals (>= min_seg bases) against every target on both strands;
+ *      best hit by (score desc, target index asc, '+' first); accepted iff score >= min_score;
+ *      end cell = max score, then smallest query end, then smallest target end;
+ *   2. every hit is one ungapped block (as BLAT's blocks are); gaps arise only from chaining;
+ *   3. hits ordered by query position are chained into one PSL record when they are on the same
+ *      target and strand and collinear (a target overlap smaller than half of either hit is trimmed
+ *      from the later hit).
+ * Output: PSL-equivalent records (fields consumed by sv_caller.py:911-936). */
+#define BKO_MAX_BLOCKS 16
+typedef struct bko_psl {
+    int32_t matches, mismatches, rep_matches, n_count;
+    int32_t q_num_insert, q_base_insert, t_num_insert, t_base_insert;
+    int32_t strand;
+    int32_t q_size, q_start, q_end;
+    int32_t t_index, t_size, t_start, t_end;
+    int32_t block_count;
+    int32_t block_sizes[BKO_MAX_BLOCKS], q_starts[BKO_MAX_BLOCKS], t_starts[BKO_MAX_BLOCKS];
+    int32_t score;
+} bko_psl;
+int bko_realign(const char *contig, int qlen, const char *const *targets, const int *tlens, int ntargets,
+                int min_score, int min_seg, bko_psl *out, int cap);
+uint64_t bko_sw_cells(int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,3 +187,34 @@ def check_align_case(contig, read, mer, k, mode, nreads, indel_only, founder_nre
     order = {0: "for", 1: "rev", 2: "mid"}
     kmers = [[km.raw[t * k:(t + 1) * k].decode(), meta[4 * t], meta[4 * t + 1], meta[4 * t + 2], order[meta[4 * t + 3]]] for t in range(nk.value)]
     return {"match": bool(m), "seq": seq.raw[:ln.value].decode(), "io": list(io[:cl.value]), "ot": list(ot[:cl.value]), "kmers": kmers}
+
+
+class OPsl(C.Structure):
+    _fields_ = [("matches", C.c_int32), ("mismatches", C.c_int32), ("rep_matches", C.c_int32), ("n_count", C.c_int32),
+                ("q_num_insert", C.c_int32), ("q_base_insert", C.c_int32), ("t_num_insert", C.c_int32), ("t_base_insert", C.c_int32),
+                ("strand", C.c_int32), ("q_size", C.c_int32), ("q_start", C.c_int32), ("q_end", C.c_int32),
+                ("t_index", C.c_int32), ("t_size", C.c_int32), ("t_start", C.c_int32), ("t_end", C.c_int32),
+                ("block_count", C.c_int32), ("block_sizes", C.c_int32 * 16), ("q_starts", C.c_int32 * 16),
+                ("t_starts", C.c_int32 * 16), ("score", C.c_int32)]
+
+
+def psl_to_dict(r):
+    n = r.block_count
+    return {"matches": r.matches, "mismatches": r.mismatches, "rep_matches": r.rep_matches, "n_count": r.n_count,
+            "q_num_insert": r.q_num_insert, "q_base_insert": r.q_base_insert, "t_num_insert": r.t_num_insert,
+            "t_base_insert": r.t_base_insert, "strand": chr(r.strand), "q_size": r.q_size, "q_start": r.q_start,
+            "q_end": r.q_end, "t_index": r.t_index, "t_size": r.t_size, "t_start": r.t_start, "t_end": r.t_end,
+            "block_sizes": list(r.block_sizes[:n]), "q_starts": list(r.q_starts[:n]), "t_starts": list(r.t_starts[:n]),
+            "score": r.score}
+
+
+def realign(contig, targets, min_score=20, min_seg=20):
+    """R2 contract (bk_oracle.h): contig vs [target window, partner windows...] -> PSL-equivalent dicts."""
+    L = lib()
+    L.bko_realign.restype = C.c_int
+    tb = [t.encode() for t in targets]
+    arr = (C.c_char_p * len(tb))(*tb)
+    tl = (C.c_int * len(tb))(*[len(t) for t in tb])
+    out = (OPsl * 16)()
+    n = L.bko_realign(contig.encode(), len(contig), arr, tl, len(tb), min_score, min_seg, out, 16)
+    return [psl_to_dict(out[i]) for i in range(min(n, 16))]

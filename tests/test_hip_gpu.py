@@ -64,10 +64,11 @@ def test_nw_random_vs_oracle_gpu(hb):
         assert o == [e[3], e[4], e[5], e[6]], (len(a), len(b))
 
 
-def _run_regions(hb, regions, k, rc_thresh=2):
+def _run_regions(hb, regions, k, rc_thresh=2, stages=3):
     eng = hb.Engine(kmer_size=k, rc_thresh=rc_thresh)
-    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only) for r in regions])
-    eng.run()
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only,
+                               partners=[p[4] for p in r.partners]) for r in regions])
+    eng.run(stages)
     return eng
 
 
@@ -106,3 +107,19 @@ def test_batch_vs_oracle_gpu(hb):
         want, info = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
         assert _strip(eng.contigs(i)) == want, i
     assert eng.stat(0) > 0 and eng.stat(1) > 0
+
+
+def test_realign_vs_oracle_gpu(hb):
+    """R2: the realign kernel + host chaining == the oracle's contract (BLAT parity itself is unpinned)."""
+    from oracle import bk_oracle as bo
+    regions = [synth.make_region(200 + i, sv_type=synth.SV_TYPES[i % 5], depth=60, W=1500, noise=(0.02 if i >= 10 else 0.0)) for i in range(14)]
+    eng = _run_regions(hb, regions, 31, stages=7)
+    nrec = 0
+    for i, r in enumerate(regions):
+        targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        for ci, c in enumerate(eng.contigs(i)):
+            want = bo.realign(c["seq"], targets)
+            got = eng.hits(i, ci)
+            assert got == want, (i, ci, r.sv_type)
+            nrec += len(got)
+    assert nrec > 14 and eng.stat(2) > 0
