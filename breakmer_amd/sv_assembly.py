@@ -1,0 +1,70 @@
+"""Host-side objects of the assembly seam (S2 of SURVEY.md 8b): what `init_assembly` returns to its
+caller in the reference (sv_assembly.py:30-63, consumers sv_processor.py:737-741, 760-761, 864 and
+sv_caller.py:159, 242, 271-277, 634), rebuilt from the records the HIP assembler writes.
+The algorithm itself lives in csrc/bk_asm.hip.h; nothing here computes an assembly."""
+from __future__ import annotations
+
+
+class assembly_counts(object):
+    """Per-base supporting-read counts of a contig (sv_assembly.py:160-221), read-only view."""
+
+    def __init__(self, indel_only, others):
+        self.indel_only = list(indel_only)
+        self.others = list(others)
+
+    def get_counts(self, p1, p2, sv_type):                          # sv_assembly.py:167-176
+        if sv_type in ('indel', 'rearr'):
+            if p1 == p2:
+                return self.indel_only[p1] + self.others[p1]
+            return [a + b for a, b in zip(self.indel_only[p1:p2], self.others[p1:p2])]
+        if p1 == p2:
+            return self.others[p1]
+        return self.others[p1:p2]
+
+    def get_total_reads(self):                                      # :178-179
+        return max(self.indel_only) + max(self.others)
+
+
+class fq_read(object):
+    """utils.py:681-688 -- the fields downstream code reads."""
+
+    def __init__(self, header, seq, qual, indel_only):
+        self.id = header
+        self.seq = str(seq)
+        self.qual = str(qual)
+        self.used = False
+        self.dup = False
+        self.indel_only = indel_only
+
+
+class _Aseq(object):
+    def __init__(self, seq, counts):
+        self.seq = seq
+        self.counts = counts
+
+
+class contig(object):
+    """What sv_processor.contig copies from an assembled contig (sv_processor.py:737-741)."""
+
+    def __init__(self, seq, indel_only, others, kmer_locs, kmers, reads, kmer_len):
+        self.aseq = _Aseq(seq, assembly_counts(indel_only, others))
+        self.kmer_locs = list(kmer_locs)
+        self.kmers = [(m,) for m in kmers]          # only x[0] and len() are read downstream (sv_processor.py:760-761, 864)
+        self.reads = set(reads)
+        self.kmer_len = kmer_len
+
+    def get_total_read_support(self): return self.aseq.counts.get_total_reads()
+    def get_contig_len(self): return len(self.aseq.seq)
+    def get_kmer_locs(self): return self.kmer_locs
+    def get_contig_seq(self): return self.aseq.seq
+    def get_contig_counts(self): return self.aseq.counts
+
+
+def contigs_from_engine(engine, region, reads, kmer_len):
+    """Rebuild contig objects of one region from the HIP engine's records.
+    `reads`: list of fq_read in FASTQ order (the representative of each supporting sequence is
+    indexed by its position)."""
+    out = []
+    for c in engine.contigs(region):
+        out.append(contig(c["seq"], c["indel_only"], c["others"], c["kmer_locs"], c["kmers"], [reads[i] for i in c["reads"]], kmer_len))
+    return out

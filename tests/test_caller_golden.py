@@ -1,0 +1,68 @@
+"""breakmer_amd.sv_caller (host-side call logic) against rows the REAL reference produced (G5)."""
+import json
+import os
+
+from breakmer_amd import sv_assembly, sv_caller
+
+
+class _Anno(object):
+    def __init__(self, genes):
+        self.genes = genes
+
+
+class _Params(object):
+    def __init__(self, opts, genes, repeat_mask):
+        self.opts = dict(opts)
+        self.gene_annotations = _Anno(genes)
+        self.repeat_mask = repeat_mask
+
+    def get_min_segment_length(self, kind):
+        return int(self.opts[kind + '_minseg_len'])
+
+    def get_sr_thresh(self, kind):
+        if kind == 'min':
+            return min(self.get_sr_thresh(x) for x in ('trl', 'rearrangement', 'indel'))
+        return int(self.opts[{'trl': 'trl_sr_thresh', 'rearrangement': 'rearr_sr_thresh', 'indel': 'indel_sr_thresh'}[kind]])
+
+
+def _tuplify(mask):
+    if mask is None:
+        return None
+    if isinstance(mask, dict):
+        return {k: [tuple(x) for x in v] for k, v in mask.items()}
+    return [tuple(x) for x in mask]
+
+
+def run_case(c):
+    qr = c["query_region"]
+    query_region = (qr[0], qr[1], qr[2], qr[3], [tuple(x) for x in qr[4]])
+    cd = c["contig"]
+    reads = [sv_assembly.fq_read(i, "", "", False) for i in c["read_ids"]]
+    ct = sv_assembly.contig(cd["seq"], cd["indel_only"], cd["others"], cd["kmer_locs"], cd["kmers"], reads, 31)
+    d = c["disc_reads"]
+    disc = {"disc": {k: [tuple(x) for x in v] for k, v in d["disc"].items()}, "inv": [tuple(x) for x in d["inv"]],
+            "td": [tuple(x) for x in d["td"]], "other": [tuple(x) for x in d["other"]]}
+    meta = {'params': _Params(c["opts"], c["genes"], _tuplify(c["all_repeat_mask"])), 'repeat_mask': _tuplify(c["target_repeat_mask"]),
+            'query_region': query_region, 'psl_records': c["psl_rows"], 'disc_reads': disc,
+            'contig_vals': (ct.get_contig_seq(), ct.get_contig_counts(), c["contig_id"], ct.reads, len(ct.kmers), ct.get_kmer_locs()),
+            'sbam': None}
+    if c["offset"] is not None:
+        meta['offset'] = c["offset"]
+    if c["tname"] is not None:
+        meta['tname'] = c["tname"]
+    am = sv_caller.align_manager(meta)
+    hit = bool(am.bm.target_hit()) if am.bm.has_blat_results else None
+    return am.get_result(), hit
+
+
+def test_g5_caller_rows(golden_dir):
+    with open(os.path.join(golden_dir, "caller.json")) as f:
+        d = json.load(f)
+    assert len(d["cases"]) >= 30
+    called = 0
+    for c in d["cases"]:
+        got, hit = run_case(c)
+        assert got == c["expected"], c["tag"]
+        assert hit == c["target_hit"], c["tag"]
+        called += got is not None
+    assert called >= 15

@@ -195,10 +195,100 @@ def g4():
     dump("kmer_select.json", {"cases": cases})
 
 
+def g5():
+    """G5: sv_caller.align_manager(meta_dict).get_result() (sv_caller.py:785-833) on explicit PSL rows.
+    Contigs come from the reference's own init_assembly; PSL rows are the build's realign records
+    (oracle contract) and hand-edited variants; the expected 13-field rows come from the reference."""
+    from oracle import bk_oracle as bo
+    from breakmer_amd import sv_caller as my
+    cases = []
+
+    def add(tag, r, sv_rows_fn=None, opts=None, genes_extra=None, drop_partner_gene=False, disc=None, trm=None, arm=None,
+            features='exon', indel_mode=None, noise_seed=None):
+        reads = r.read_strs()
+        mers = rh.ref_kmer_select(reads, [r.window_str], 31)
+        cdicts, cobjs = rh.ref_init_assembly(r.read_ids, reads, mers, 31, 2, r.indel_only)
+        targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        tinfo = [(r.chrom, r.start - 200)] + [(p[0], p[1]) for p in r.partners]
+        qr = (r.chrom, r.start, r.end, r.name, [(r.chrom, r.start, r.end, r.name, features)])
+        genes = {r.name: ['chr' + r.chrom, r.start, r.end]}
+        if not drop_partner_gene:
+            for p_ in r.partners:
+                genes[p_[3]] = ['chr' + p_[0], p_[1], p_[2]]
+        if genes_extra:
+            genes.update(genes_extra)
+        o = dict(rh.DEFAULT_OPTS)
+        if opts:
+            o.update(opts)
+        d = r.disc_reads if disc is None else disc
+        for ci, (cd, co) in enumerate(list(zip(cdicts, cobjs))[:5]):
+            recs = bo.realign(cd['seq'], targets)
+            if indel_mode:       # the offset-shifted '.mod' path of check_target_blat (sv_processor.py:855-859): window coordinates + offset/tname override
+                rows = [my.psl_fields(x, 'contig1', r.name, 0) for x in recs if x['t_index'] == 0]
+                offset, tname = r.start - 200, r.chrom
+            else:                # whole-genome style rows: genome coordinates and chr names (Q14)
+                rows = [my.psl_fields(x, 'contig1', 'chr' + tinfo[x['t_index']][0], tinfo[x['t_index']][1]) for x in recs]
+                offset, tname = None, None
+            if sv_rows_fn:
+                rows = sv_rows_fn(rows)
+            res, am = rh.ref_call(rows, co, 'contig%d' % (ci + 1), qr, o, genes, d, trm, arm, offset, tname)
+            hit = bool(am.bm.target_hit()) if am.bm.has_blat_results else None
+            cases.append({"tag": "%s_c%d" % (tag, ci), "psl_rows": rows, "contig": cd, "read_ids": sorted(x.id for x in co.reads),
+                          "contig_id": 'contig%d' % (ci + 1), "query_region": [qr[0], qr[1], qr[2], qr[3], [list(x) for x in qr[4]]],
+                          "opts": o, "genes": genes, "disc_reads": {"disc": {k: [list(x) for x in v] for k, v in d["disc"].items()},
+                                                                    "inv": [list(x) for x in d["inv"]], "td": [list(x) for x in d["td"]],
+                                                                    "other": [list(x) for x in d["other"]]},
+                          "target_repeat_mask": trm, "all_repeat_mask": arm, "offset": offset, "tname": tname,
+                          "target_hit": hit, "expected": res})
+            print("  %-34s rows %d -> %s" % (cases[-1]["tag"], len(rows), (res[:2] + [res[6]]) if res else None))
+
+    mk = lambda i, sv, **kw: synth.make_region(i, sv_type=sv, depth=60, W=1500, **kw)
+    add("del", mk(3, "del"))
+    add("del_indelmode", mk(3, "del"), indel_mode=True)
+    add("ins", mk(3, "ins"))
+    add("ins_indelmode", mk(5, "ins"), indel_mode=True)
+    add("inv_disc", mk(3, "inv"))
+    add("inv_nodisc", mk(3, "inv"), disc={"disc": {}, "inv": [], "td": [], "other": []})
+    add("dup", mk(3, "dup"))
+    add("trl", mk(3, "trl"))
+    add("trl_intergenic_partner", mk(3, "trl"), drop_partner_gene=True)
+    add("trl_nodisc", mk(3, "trl"), disc={"disc": {}, "inv": [], "td": [], "other": []})
+    add("del_small_indel_size", mk(6, "del", sv_size=10))
+    add("del_size_thresh0", mk(6, "del", sv_size=10), opts={"indel_size": 0})
+    add("del_intron", mk(3, "del"), features='intron')
+    add("del_intron_keep", mk(3, "del"), features='intron', opts={"keep_intron_vars": True})
+    add("del_var_filter_trl_only", mk(3, "del"), opts={"var_filter": ["trl"]})
+    add("inv_var_filter_indel_only", mk(3, "inv"), opts={"var_filter": ["indel"]})
+    add("del_noise2", mk(9, "del", noise=0.02))
+    add("ins_noise1", mk(9, "ins", noise=0.01))
+    r = mk(3, "del")
+    g0 = r.start - 200
+    simple = [(r.chrom, g0 + 640, g0 + 660, "(CA)n")]
+    alu = [(r.chrom, g0 + 300, g0 + 620, "AluY")]
+    add("del_simple_repeat_at_brkpt", r, trm=simple, arm={r.chrom: simple})
+    add("del_alu_far", r, trm=alu, arm={r.chrom: alu})
+    r = mk(3, "trl")
+    p0 = r.partners[0]
+    prep = [(p0[0], p0[1] + 700, p0[1] + 1500, "GA_rich")]
+    add("trl_partner_simple_repeat", r, trm=[(r.chrom, g0 + 10, g0 + 30, "L1")], arm={r.chrom: [(r.chrom, g0 + 10, g0 + 30, "L1")], p0[0]: prep})
+    # '-' strand indel: reverse-complement the contig rows by feeding a window that is the rc (hand edit: flip strand of a del row)
+    def flip(rows):
+        out = []
+        for row in rows:
+            row = list(row)
+            row[8] = '-' if row[8] == '+' else '+'
+            out.append(row)
+        return out
+    add("del_minus_strand_rows", mk(3, "del"), sv_rows_fn=flip)
+    add("no_rows", mk(3, "del"), sv_rows_fn=lambda rows: [])
+    add("single_partial_hit", mk(3, "del"), sv_rows_fn=lambda rows: [[str(x) for x in ["120", "0", "0", "0", "0", "0", "0", "0", "+", "contig1", "297", "0", "120", "chr4", "1500", "100502", "100622", "1", "120,", "0,", "100502,"]]])
+    dump("caller.json", {"cases": cases})
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
     for w in which:
         print(w)
         globals()[w]()

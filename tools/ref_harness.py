@@ -58,3 +58,61 @@ def ref_init_assembly(read_ids, read_strs, mers, k, rc_thresh, indel_only=None):
                     "kmers": [t[0] for t in c.kmers],
                     "reads": sorted(idx[r.id] for r in c.reads)})
     return out, contigs
+
+
+# ---------------------------------------------------------------------------------------------
+# reference caller (sv_caller.align_manager) on explicit PSL columns
+class StubAnno(object):
+    def __init__(self, genes):
+        self.genes = genes
+
+
+class StubParams(object):
+    """What sv_caller reads from utils.params (utils.py:535-674)."""
+
+    def __init__(self, opts, genes, repeat_mask=None):
+        self.opts = dict(opts)
+        self.gene_annotations = StubAnno(genes)
+        self.repeat_mask = repeat_mask
+
+    def get_min_segment_length(self, kind):
+        return int(self.opts[kind + '_minseg_len'])
+
+    def get_sr_thresh(self, kind):
+        if kind == 'min':
+            return min(self.get_sr_thresh('trl'), self.get_sr_thresh('rearrangement'), self.get_sr_thresh('indel'))
+        return int(self.opts[{'trl': 'trl_sr_thresh', 'rearrangement': 'rearr_sr_thresh', 'indel': 'indel_sr_thresh'}[kind]])
+
+
+DEFAULT_OPTS = {'indel_size': 15, 'trl_sr_thresh': 2, 'indel_sr_thresh': 5, 'rearr_sr_thresh': 3, 'rearr_minseg_len': 30,
+                'trl_minseg_len': 25, 'keep_intron_vars': False, 'var_filter': ['indel', 'rearrangement', 'trl'],
+                'keep_repeat_regions': False, 'sample_bam_file': None}
+
+
+def ref_call(psl_rows, ref_contig, contig_id, query_region, opts, genes, disc_reads, target_repeat_mask=None, all_repeat_mask=None,
+             offset=None, tname=None):
+    """sv_caller.align_manager(meta_dict).get_result() of the REAL reference on explicit PSL rows
+    (21 columns each) for an assembled reference contig object; returns the 13-field row or None."""
+    import tempfile
+    mods = ref_loader.load()
+    sc = mods["sv_caller"]
+    params = StubParams(opts, genes, all_repeat_mask)
+    with tempfile.NamedTemporaryFile("w", suffix=".psl", delete=False) as f:
+        for row in psl_rows:
+            f.write("\t".join(str(x) for x in row) + "\n")
+        fn = f.name
+    meta = {'params': params, 'repeat_mask': target_repeat_mask, 'query_region': query_region, 'query_res_fn': fn,
+            'disc_reads': disc_reads,
+            'contig_vals': (ref_contig.aseq.seq, ref_contig.aseq.counts, contig_id, ref_contig.reads, len(ref_contig.kmers), ref_contig.kmer_locs),
+            'sbam': None}
+    if offset is not None:
+        meta['offset'] = offset
+    if tname is not None:
+        meta['tname'] = tname
+    try:
+        am = sc.align_manager(meta)
+        res = am.get_result()
+        # state useful for debugging / target_hit
+        return res, am
+    finally:
+        os.unlink(fn)
