@@ -1,0 +1,40 @@
+"""Collation of per-region SV rows across ranks: regions are independent, so the only
+exchange of the whole path is one all-gather of variable-length records at the end --
+sizes first, then a padded all-gather (RCCL has no gatherv).  Works on any torch.distributed
+backend: `nccl` (= RCCL over xGMI) on the GPU box, `gloo` in the CPU tests."""
+from __future__ import annotations
+
+import json
+
+
+def all_gather_bytes(payload: bytes, device=None):
+    """-> list of bytes objects, one per rank (rank order)."""
+    import torch
+    import torch.distributed as td
+    world = td.get_world_size()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    td.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    td.all_gather(out, buf)
+    return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(out, sizes)]
+
+
+def collate_results(results, summary, device=None):
+    """runner hook: merge (results, summary) of all ranks; ranks own consecutive blocks of the sorted
+    target names, so concatenation in rank order keeps the reference's output order
+    (sv_processor.py:175-176, 212-224)."""
+    parts = all_gather_bytes(json.dumps({"r": results, "s": summary}).encode(), device)
+    all_results, all_summary = [], {}
+    for p in parts:
+        d = json.loads(p.decode())
+        all_results.extend(d["r"])
+        all_summary.update(d["s"])
+    return all_results, all_summary

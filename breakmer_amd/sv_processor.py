@@ -1,0 +1,471 @@
+"""Run orchestration and the per-region plugin surface, re-stated for the batched GPU path.
+
+Keeps the reference's surface (sv_processor.py:98-235 `runner`, :244-722 `target`, :730-866 `contig`;
+utils.py:535-674 `params`, :727-773 `anno`): the same config keys, the same method sequence
+`set_ref_data -> extract_bam_reads -> clean_reads -> compare_kmers -> resolve_sv -> get_summary ->
+write_results`, the same state handed between them (`cleaned_read_recs`, `read_len`,
+`kmers['clusters']`, `results`, `disc_reads`, `repeat_mask`) and the same output files.
+
+What differs, by design: the reference runs jellyfish / the Python assembler / BLAT once per region;
+here `runner.run` gathers every region first and makes ONE batched call into libbreakmer_hip.so
+(grouping + k-mer selection + assembly + realignment on the GPU), after which `compare_kmers()` and
+`resolve_sv()` of each target only pick up their region's records.  BAM extraction (pysam) and
+adapter trimming (cutadapt) are out of scope: reads enter as the files the
+reference itself writes at that point (`<name>_sv_reads.fastq`, `<name>_sv_sc_seqs.fa`,
+`<name>_forward_refseq.fa`) or as in-memory `RegionData`.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import shutil
+from collections import OrderedDict
+
+from . import sv_assembly, sv_caller
+
+HEADER_FIELDS = ['genes', 'target_breakpoints', 'align_cigar', 'mismatches', 'strands', 'rep_overlap_segment_len', 'sv_type',
+                 'split_read_count', 'nkmers', 'disc_read_count', 'breakpoint_coverages', 'contig_id', 'contig_seq']
+
+
+# ------------------------------------------------------------------------------------------------ inputs
+class RegionData(object):
+    """Everything the hot path needs for one target, as the reference has it after clean_reads():
+    reads (FASTQ order: id, seq, qual, indel_only), soft-clip sequences (None => case_sc := case),
+    the forward window, extra windows with genome coordinates, discordant-pair evidence."""
+
+    def __init__(self, read_ids, read_seqs, indel_only=None, sc_seqs=None, window="", partners=(), disc_reads=None, quals=None):
+        self.read_ids = list(read_ids)
+        self.read_seqs = list(read_seqs)
+        self.indel_only = list(indel_only) if indel_only is not None else [False] * len(self.read_ids)
+        self.quals = list(quals) if quals is not None else None
+        self.sc_seqs = sc_seqs
+        self.window = window
+        self.partners = list(partners)          # (chrom, start, end, name, seq)
+        self.disc_reads = disc_reads or {"disc": {}, "inv": [], "td": [], "other": []}
+
+
+def read_fasta_first(fn):
+    seq = []
+    with open(fn) as f:
+        for ln in f:
+            if not ln.startswith(">"):
+                seq.append(ln.strip())
+    return "".join(seq)
+
+
+def read_fastq(fn):
+    """FastqFile (utils.py:693-720): 4-line records; the trailing _<0|1> of the id is the indel_only flag
+    (utils.py:211-213)."""
+    ids, seqs, quals, io = [], [], [], []
+    with open(fn) as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            s, _p, q = f.readline(), f.readline(), f.readline()
+            h = h.strip()
+            ids.append(h)
+            seqs.append(s.strip())
+            quals.append(q.strip())
+            io.append(h.lstrip("@").split("_")[-1] == "1")
+    return ids, seqs, quals, io
+
+
+# ------------------------------------------------------------------------------------------------ params / anno
+class anno(object):                                                 # utils.py:727-773
+    def __init__(self):
+        self.genes = OrderedDict()
+
+    def add_genes(self, gene_fn):
+        with open(gene_fn) as f:
+            lines = f.readlines()
+        for ln in lines[1:]:
+            p = ln.strip().split()
+            chrom, start, end, gid = p[2], int(p[4]), int(p[5]), p[12]
+            if gid in self.genes:
+                if start <= self.genes[gid][1] and end >= self.genes[gid][2]:
+                    self.genes[gid] = [chrom, start, end]
+            else:
+                self.genes[gid] = [chrom, start, end]
+
+    def add_regions(self, bed_fn):
+        with open(bed_fn) as f:
+            for ln in f:
+                if not ln.strip():
+                    continue
+                chrom, start, end, name = ln.split()[:4]
+                if name not in self.genes:
+                    self.genes[name] = [chrom, int(start), int(end)]
+
+
+class params(object):                                               # utils.py:535-674
+    DEFAULTS = {'indel_size': 15, 'trl_sr_thresh': 2, 'indel_sr_thresh': 5, 'rearr_sr_thresh': 3, 'rearr_minseg_len': 30,
+                'trl_minseg_len': 25, 'keep_intron_vars': False, 'keep_repeat_regions': False, 'var_filter': 'all',
+                'no_output_header': False, 'gene_list': None, 'preset_ref_data': False, 'sample_bam_file': None}
+
+    def __init__(self, config_d):
+        self.opts = dict(self.DEFAULTS)
+        self.opts.update(config_d)
+        self.gene_annotations = anno()
+        self.targets = {}
+        self.paths = {}
+        self.logger = logging.getLogger('root')
+        self.repeat_mask = None
+        self.set_params()
+
+    def set_params(self):                                            # utils.py:574-618
+        vf = self.opts['var_filter']
+        if vf == 'all':
+            self.opts['var_filter'] = ['indel', 'rearrangement', 'trl']
+        elif isinstance(vf, str):
+            vf = vf.split(",")
+            self.opts['var_filter'] = vf if any(x in vf for x in ('indel', 'rearrangement', 'trl')) else ['indel', 'rearrangement', 'trl']
+        if self.opts.get('targets_bed_file'):
+            self.set_targets(self.opts.get('gene_list'))
+        if self.opts.get('gene_annotation_file'):
+            self.gene_annotations.add_genes(self.opts['gene_annotation_file'])
+        if self.opts.get('other_regions_file'):
+            self.gene_annotations.add_regions(self.opts['other_regions_file'])
+        if self.opts.get('analysis_dir'):
+            self.paths['analysis'] = os.path.abspath(os.path.normpath(self.opts['analysis_dir']))
+            self.paths['output'] = os.path.join(self.paths['analysis'], 'output')
+            self.paths['targets'] = (os.path.abspath(os.path.normpath(self.opts['targets_dir'])) if 'targets_dir' in self.opts
+                                     else os.path.join(self.paths['analysis'], 'targets'))
+            if self.opts.get('reference_data_dir'):
+                self.paths['ref_data'] = os.path.abspath(os.path.normpath(self.opts['reference_data_dir']))
+            for p in self.paths.values():
+                os.makedirs(p, exist_ok=True)
+        if not self.opts['keep_repeat_regions'] and self.opts.get('repeat_mask_file'):
+            self.repeat_mask = setup_rmask_all(self.opts['repeat_mask_file'])
+
+    def set_targets(self, gene_list):                                # utils.py:545-572
+        wanted = None
+        if gene_list:
+            with open(gene_list) as f:
+                wanted = [ln.strip().upper() for ln in f]
+        with open(self.opts['targets_bed_file']) as f:
+            for ln in f:
+                p = ln.strip().split()
+                if len(p) < 4:
+                    continue
+                chrm, bp1, bp2, name = p[:4]
+                if wanted and name.upper() not in wanted:
+                    continue
+                self.targets.setdefault(name.upper(), []).append((chrm, int(bp1), int(bp2), name, p[4] if len(p) > 4 else None))
+
+    def get_kmer_size(self): return int(self.opts['kmer_size'])
+    def get_min_segment_length(self, kind): return int(self.opts[kind + '_minseg_len'])
+
+    def get_sr_thresh(self, kind):                                   # utils.py:665-674
+        if kind == 'min':
+            return min(self.get_sr_thresh('trl'), self.get_sr_thresh('rearrangement'), self.get_sr_thresh('indel'))
+        return int(self.opts[{'trl': 'trl_sr_thresh', 'rearrangement': 'rearr_sr_thresh', 'indel': 'indel_sr_thresh'}[kind]])
+
+
+def setup_rmask_all(fn):                                            # utils.py:302-316
+    mask = {}
+    with open(fn) as f:
+        for ln in f:
+            p = ln.strip().split("\t")
+            if len(p) < 4:
+                continue
+            c = p[0].replace('chr', '')
+            mask.setdefault(c, []).append((c, int(p[1]), int(p[2]), p[3]))
+    return mask
+
+
+# ------------------------------------------------------------------------------------------------ contig
+class contig(object):
+    """sv_processor.py:730-866: one assembled contig of a target: realign, call, write."""
+
+    def __init__(self, parent_target, contig_id, assembly, hits):
+        self.params = parent_target.params
+        self.id = contig_id
+        self.query_region = parent_target.get_values()
+        self.target = parent_target
+        self.reads = assembly.reads
+        self.kmers = assembly.kmers
+        self.contig_seq = assembly.get_contig_seq()
+        self.contig_rcounts = assembly.get_contig_counts()
+        self.contig_kmer_locs = assembly.get_kmer_locs()
+        self.hits = hits                        # realign records of this contig (engine.hits)
+        self.result = None
+        self.psl_rows = None
+        self.path = os.path.join(parent_target.paths['contigs'], contig_id) if 'contigs' in parent_target.paths else None
+        if self.path:
+            self.setup()
+
+    def setup(self):                                                 # :747-782 cluster file, read fastq, contig fasta
+        os.makedirs(self.path, exist_ok=True)
+        t = self.target
+        if t.files.get('kmer_clusters'):
+            with open(t.files['kmer_clusters'], 'w') as f:
+                f.write(self.id + " " + str(len(self.kmers)) + "\n")
+                f.write(",".join(x[0] for x in self.kmers) + "\n")
+                f.write(",".join(x.id for x in self.reads) + "\n\n")
+        with open(os.path.join(self.path, self.id + ".fq"), 'w') as f:
+            for r in self.reads:
+                f.write(r.id + "\n" + r.seq + "\n+\n" + r.qual + "\n")
+        with open(os.path.join(self.path, self.id + ".fa"), 'w') as f:
+            f.write(">contig1" + "\n" + self.contig_seq)
+
+    def has_result(self): return bool(self.result)
+
+    def query_ref(self):
+        """contig.query_ref + check_target_blat (:823-859): records against the target window are tried
+        first in window coordinates with the (offset, tname) override; if they do not explain the
+        query (`target_hit`), all windows in genome coordinates with chr names are used (Q14)."""
+        t = self.target
+        qr = self.query_region
+        own = [h for h in self.hits if h["t_index"] == 0]
+        if own:
+            rows = [sv_caller.psl_fields(h, 'contig1', t.name, 0) for h in own]
+            meta = {'offset': qr[1] - 200, 'tname': qr[0].replace('chr', ''), 'psl_records': rows, 'sbam': self.params.opts.get('sample_bam_file')}
+            am = sv_caller.align_manager(meta)
+            if am.bm.target_hit():
+                self.psl_rows = [r[3].blat_values for r in am.bm.blat_results]      # the '.mod' rows (:802)
+                return
+        tinfo = [(qr[0], qr[1] - 200)] + [(p[0], p[1]) for p in t.partner_windows]
+        self.psl_rows = [sv_caller.psl_fields(h, 'contig1', 'chr' + str(tinfo[h["t_index"]][0]).replace('chr', ''), tinfo[h["t_index"]][1]) for h in self.hits]
+
+    def make_calls(self, disc_reads, rep_mask):                      # :863-866
+        meta = {'params': self.params, 'repeat_mask': rep_mask, 'query_region': self.query_region, 'psl_records': self.psl_rows,
+                'disc_reads': disc_reads, 'sbam': self.params.opts.get('sample_bam_file'), 'coverage_fn': self.target.coverage_fn,
+                'contig_vals': (self.contig_seq, self.contig_rcounts, self.id, self.reads, len(self.kmers), self.contig_kmer_locs)}
+        self.result = sv_caller.align_manager(meta).get_result()
+
+    def write_result(self, output_path):                             # :791-799
+        if self.result and self.path:
+            fn = os.path.join(self.path, self.id + "_svs.out")
+            with open(fn, 'w') as f:
+                f.write("\t".join(str(x) for x in self.result))
+            shutil.copyfile(fn, os.path.join(output_path, self.id + "_svs.out"))
+
+
+# ------------------------------------------------------------------------------------------------ target
+class target(object):                                               # sv_processor.py:244-722
+    def __init__(self, intervals, prm, data=None, write_files=True):
+        self.params = prm
+        self.name = self.chrom = self.start = self.end = None
+        self.paths, self.files = {}, {}
+        self.disc_reads = None
+        self.cleaned_read_recs = None
+        self.read_len = 0
+        self.kmers = {}
+        self.results = []
+        self.svs = {'trl': [0, '-'], 'indel': [0, ''], 'rearrangement': [0, '']}
+        self.logger = logging.getLogger('root')
+        self.target_intervals = intervals
+        self.repeat_mask = None
+        self.data = data
+        self.partner_windows = []
+        self.coverage_fn = None
+        self.write_files = write_files and 'targets' in prm.paths
+        self.region_index = None                # slot in the batched GPU call
+        self.engine = None
+        self.reads = []
+        self.setup()
+
+    def setup(self):                                                 # :267-294
+        for v in self.target_intervals:
+            if not self.name: self.name = v[3]
+            if not self.chrom: self.chrom = v[0]
+            if not self.start: self.start = int(v[1])
+            if not self.end: self.end = int(v[2])
+            self.start = min(self.start, int(v[1]))
+            self.end = max(self.end, int(v[2]))
+        if self.write_files:
+            base = os.path.join(self.params.paths['targets'], self.name)
+            for key, p in (('base', base), ('data', os.path.join(base, 'data')), ('contigs', os.path.join(base, 'contigs')),
+                           ('kmers', os.path.join(base, 'kmers')), ('output', os.path.join(self.params.paths['output'], self.name))):
+                self.paths[key] = p
+                os.makedirs(p, exist_ok=True)
+            if 'ref_data' in self.params.paths:
+                self.paths['ref_data'] = os.path.join(self.params.paths['ref_data'], self.name)
+                self.files['target_ref_fn'] = [os.path.join(self.paths['ref_data'], self.name + '_forward_refseq.fa'),
+                                               os.path.join(self.paths['ref_data'], self.name + '_reverse_refseq.fa')]
+            self.files['kmer_clusters'] = os.path.join(self.paths['kmers'], self.name + "_sample_kmers_merged.out")
+            self.files['sample_kmers'] = os.path.join(self.paths['kmers'], self.name + "_sample_kmers.out")
+
+    def get_values(self): return (self.chrom, self.start, self.end, self.name, self.target_intervals)
+    def has_results(self): return len(self.results) > 0
+
+    def rm_output_dir(self):
+        if 'output' in self.paths and os.path.isdir(self.paths['output']):
+            shutil.rmtree(self.paths['output'])
+
+    # ---- steps before the hot path (file formats of the reference; BAM extraction itself is out of scope)
+    def set_ref_data(self):                                          # :351-364
+        if self.data is None and self.files.get('target_ref_fn') and os.path.isfile(self.files['target_ref_fn'][0]):
+            self._window = read_fasta_first(self.files['target_ref_fn'][0])
+        elif self.data is not None:
+            self._window = self.data.window
+        else:
+            raise RuntimeError("target %s: no reference window (expected %s)" % (self.name, self.files.get('target_ref_fn')))
+        if self.params.repeat_mask is not None:
+            c = str(self.chrom).replace('chr', '')
+            self.repeat_mask = [m for m in self.params.repeat_mask.get(c, []) if m[1] >= self.start and m[2] <= self.end]      # utils.py:334-339
+
+    def extract_bam_reads(self):                                     # :422-540 (reads arrive extracted)
+        if self.data is None:
+            d = self.paths.get('data', '')
+            fq = os.path.join(d, self.name + "_sv_reads.fastq")
+            if not os.path.isfile(fq):
+                self.data = RegionData([], [], window=self._window)
+                return
+            ids, seqs, quals, io = read_fastq(fq)
+            sc = None
+            scfn = os.path.join(d, self.name + "_sv_sc_seqs.fa")
+            if os.path.isfile(scfn):
+                sc = [ln.strip() for ln in open(scfn) if ln.strip() and not ln.startswith(">")]
+            self.data = RegionData(ids, seqs, io, sc, self._window, quals=quals)
+        self.disc_reads = self.data.disc_reads
+        self.partner_windows = self.data.partners
+
+    def clean_reads(self):                                           # :584-606 (cutadapt out of scope) -> bool
+        d = self.data
+        q = d.quals
+        self.reads = [sv_assembly.fq_read(i, s, (q[n] if q else "I" * len(s)), bool(io)) for n, (i, s, io) in enumerate(zip(d.read_ids, d.read_seqs, d.indel_only))]
+        recs = OrderedDict()
+        for r in self.reads:                                         # utils.py:239-244
+            recs.setdefault(r.seq, []).append(r)
+            self.read_len = max(self.read_len, len(r.seq))
+        self.cleaned_read_recs = recs
+        return len(recs) > 0
+
+    # ---- the hot path: results of the batched GPU call
+    def compare_kmers(self):                                         # :609-645
+        eng, ri = self.engine, self.region_index
+        mers, counts, _u = eng.kmers(ri)
+        self.kmers['case_only'] = dict(zip(mers, counts.tolist()))
+        if self.files.get('sample_kmers'):
+            with open(self.files['sample_kmers'], 'w') as f:
+                for m, c in self.kmers['case_only'].items():
+                    f.write("\t".join([m, str(c)]) + "\n")
+        self.kmers['clusters'] = sv_assembly.contigs_from_engine(eng, ri, self.reads, self.params.get_kmer_size())
+        self.cleaned_read_recs = None
+        self.kmers['case_only'] = {}
+
+    def resolve_sv(self):                                            # :648-665
+        for n, kc in enumerate(self.kmers['clusters'], 1):
+            ctig = contig(self, 'contig' + str(n), kc, self.engine.hits(self.region_index, n - 1))
+            ctig.query_ref()
+            ctig.make_calls(self.disc_reads, self.repeat_mask)
+            if ctig.has_result():
+                if 'output' in self.paths:
+                    ctig.write_result(self.paths['output'])
+                self.results.append(ctig.result)
+
+    def write_results(self):                                         # :668-683
+        files = {}
+        for res in self.results:
+            tag = 'rearrangement' if res[6].find('rearrangement') > -1 else res[6]
+            if tag not in files:
+                files[tag] = open(os.path.join(self.paths['output'], self.name + "_" + tag + "_svs.out"), 'w')
+                if not self.params.opts['no_output_header']:
+                    files[tag].write("\t".join(HEADER_FIELDS) + "\n")
+            files[tag].write("\t".join(str(x) for x in res) + "\n")
+        for f in files.values():
+            f.close()
+
+    def get_sv_counts(self):                                         # :686-705 incl. the 'rearrangment' misspelling (Q11)
+        total = 0
+        for res in self.results:
+            tag = 'rearrangement' if res[6].find('rearrangement') > -1 else res[6]
+            self.svs[tag][0] += 1
+            total += 1
+        return total
+
+    def get_summary(self):                                           # :708-721
+        total = self.get_sv_counts()
+        keys = sorted(self.svs.keys())
+        header = ['Target', 'N_contigs', 'Total_variants'] + ['N_' + str(x) for x in keys] + ['Rearrangements']
+        out = self.name + '\t' + str(len(self.kmers['clusters'])) + '\t' + str(total) + '\t'
+        for t in keys:
+            out += str(self.svs[t][0]) + '\t'
+        out += '-'
+        return "\t".join(header), out
+
+
+# ------------------------------------------------------------------------------------------------ runner
+class runner(object):                                               # sv_processor.py:98-235
+    def __init__(self, config_d, region_data=None, engine_factory=None, rank=0, world=1, collate=None):
+        self.params = params(config_d)
+        self.results = []
+        self.targets = {}
+        self.summary = {}
+        self.summary_header = ''
+        self.logger = logging.getLogger('root')
+        self.region_data = region_data or {}
+        self.engine_factory = engine_factory
+        self.rank, self.world, self.collate = rank, world, collate
+        self.engine = None
+
+    def create_targets(self):                                        # :165-170
+        names = sorted(self.params.targets.keys())
+        for n in names:
+            self.targets[n] = target(self.params.targets[n], self.params, self.region_data.get(n))
+        return names
+
+    def _make_engine(self):
+        if self.engine_factory:
+            return self.engine_factory(self.params)
+        from . import hip_backend
+        return hip_backend.Engine(kmer_size=self.params.get_kmer_size(), rc_thresh=self.params.get_sr_thresh('min'))
+
+    def run(self, start_time=None):                                  # :174-209
+        names = self.create_targets()
+        mine = [n for i, n in enumerate(names) if (i * self.world) // max(len(names), 1) == self.rank]      # block partition
+        live = []
+        for n in mine:
+            t = self.targets[n]
+            t.set_ref_data()
+            t.extract_bam_reads()
+            if not t.clean_reads():
+                t.rm_output_dir()
+                continue
+            live.append(t)
+        if live:
+            # batching front-end: every region first, then ONE call into the HIP library
+            from . import hip_backend
+            self.engine = self._make_engine()
+            ins = []
+            for i, t in enumerate(live):
+                t.region_index, t.engine = i, self.engine
+                d = t.data
+                ins.append(hip_backend.RegionInput(d.read_seqs, d.window, indel_only=[1 if x else 0 for x in d.indel_only], sc_seqs=d.sc_seqs,
+                                                   partners=[p[4] for p in d.partners]))
+            self.engine.submit(ins)
+            self.engine.run(hip_backend.BK_STAGE_ALL)
+        for t in live:
+            t.compare_kmers()
+            t.resolve_sv()
+            self.summary_header, self.summary[t.name] = t.get_summary()
+            if t.has_results():
+                if 'output' in t.paths:
+                    t.write_results()
+                self.results.extend(t.results)
+            else:
+                t.rm_output_dir()
+        if self.collate is not None and self.world > 1:               # collate per-region rows over ranks (RCCL all-gather)
+            self.results, self.summary = self.collate(self.results, self.summary)
+        if self.rank == 0 and 'output' in self.params.paths:
+            self.write_output()
+        return self.results
+
+    def write_output(self):                                          # :212-234
+        files = {}
+        out = self.params.paths['output']
+        for res in self.results:
+            tag = res[6]
+            if tag not in files:
+                files[tag] = open(os.path.join(out, self.params.opts['analysis_name'] + "_" + tag + "_svs.out"), 'w')
+                if not self.params.opts['no_output_header']:
+                    files[tag].write("\t".join(HEADER_FIELDS) + "\n")
+            files[tag].write("\t".join(str(x) for x in res) + "\n")
+        for f in files.values():
+            f.close()
+        with open(os.path.join(out, self.params.opts['analysis_name'] + "_summary.out"), 'w') as f:
+            f.write(self.summary_header + "\n")
+            for gene in sorted(self.summary.keys()):
+                f.write(self.summary[gene] + "\n")

@@ -1,0 +1,38 @@
+"""TEST INFRASTRUCTURE: a stand-in for hip_backend.Engine built on the CPU oracle, so the host logic
+(sv_processor.runner/target/contig, collate) can be exercised without a GPU.  Never shipped: the
+product's runner creates hip_backend.Engine, which fails loudly without the HIP library/GPU."""
+import numpy as np
+
+from oracle import bk_oracle as bo
+
+
+class FakeEngine(object):
+    def __init__(self, kmer_size, rc_thresh=2):
+        self.k, self.rc = kmer_size, rc_thresh
+        self.regions = []
+        self.out = []
+
+    def submit(self, ins):
+        self.regions = []
+        for g in ins:
+            reads = [bytes(g.reads[i, :g.lens[i]]).decode() for i in range(g.reads.shape[0])]
+            io = g.indel_only if g.indel_only is not None else np.zeros(len(reads), dtype=np.uint8)
+            sc = None if g.sc is None else [bytes(g.sc[i, :g.sc_lens[i]]).decode() for i in range(g.sc.shape[0])]
+            self.regions.append((reads, io, sc, g.window.decode(), [p.decode() for p in g.partners]))
+
+    def run(self, stages=7, sync=True):
+        self.out = []
+        for reads, io, sc, window, partners in self.regions:
+            contigs, info = bo.assemble_region(reads, [window], self.k, self.rc, indel_only=io, sc_seqs=sc)
+            order = sorted(range(len(info["mers"])), key=lambda i: (int(info["counts"][i]), info["mers"][i]), reverse=True)
+            hits = [bo.realign(c["seq"], [window] + partners) for c in contigs]
+            self.out.append((contigs, [info["mers"][i] for i in order], np.array([info["counts"][i] for i in order]), len(info["rep"]), hits))
+
+    def kmers(self, r):
+        return self.out[r][1], self.out[r][2], self.out[r][3]
+
+    def contigs(self, r):
+        return self.out[r][0]
+
+    def hits(self, r, ci):
+        return self.out[r][4][ci]

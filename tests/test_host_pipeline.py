@@ -1,0 +1,105 @@
+"""Host logic (runner/target/contig mirror, config parsing, output files, multi-rank collation) on
+CPU with the oracle-backed FakeEngine.  The expected rows are pinned independently: they must equal
+what the REAL reference's caller produced for the same contigs in tests/golden/caller.json."""
+import json
+import os
+import sys
+
+import pytest
+
+from breakmer_amd import sv_processor as sp, synth
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fake_engine import FakeEngine  # noqa: E402
+
+
+def make_inputs(tmp_path, ids_types, write_header=True):
+    bed, genes, data = [], ["header"], {}
+    for rid, sv in ids_types:
+        r = synth.make_region(rid, sv_type=sv, depth=60, W=1500)
+        bed.append("\t".join([r.chrom, str(r.start), str(r.end), r.name, "exon"]))
+        genes.append("\t".join(["0", r.name, "chr" + r.chrom, "+", str(r.start), str(r.end)] + ["x"] * 6 + [r.name]))
+        for p in r.partners:
+            genes.append("\t".join(["0", p[3], "chr" + p[0], "+", str(p[1]), str(p[2])] + ["x"] * 6 + [p[3]]))
+        data[r.name.upper()] = sp.RegionData(r.read_ids, r.read_strs(), r.indel_only.tolist(), None, r.window_str,
+                                             [(p[0], p[1], p[2], p[3], synth.codes_to_str(p[4])) for p in r.partners], r.disc_reads)
+    (tmp_path / "targets.bed").write_text("\n".join(bed) + "\n")
+    (tmp_path / "genes.txt").write_text("\n".join(genes) + "\n")
+    cfg = {"analysis_name": "synth", "targets_bed_file": str(tmp_path / "targets.bed"), "analysis_dir": str(tmp_path / "analysis"),
+           "reference_data_dir": str(tmp_path / "ref"), "gene_annotation_file": str(tmp_path / "genes.txt"), "kmer_size": "31",
+           "keep_repeat_regions": True}
+    return cfg, data
+
+
+CASES = [(3, "del"), (3, "ins"), (3, "inv"), (3, "dup"), (3, "trl")]
+
+
+def test_runner_matches_reference_rows(tmp_path, golden_dir):
+    gold = {c["tag"]: c["expected"] for c in json.load(open(os.path.join(golden_dir, "caller.json")))["cases"]}
+    for rid, sv in CASES:
+        d = tmp_path / sv
+        d.mkdir()
+        cfg, data = make_inputs(d, [(rid, sv)])
+        r = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+        rows = r.run()
+        tag = {"del": "del_indelmode", "ins": "ins", "inv": "inv_disc", "dup": "dup", "trl": "trl"}[sv]
+        want = [gold[k] for k in sorted(gold) if k.startswith(tag + "_c") and gold[k] is not None]
+        assert rows == want, sv
+        out = d / "analysis" / "output"
+        assert (out / "synth_summary.out").is_file()
+        if rows:
+            kind = rows[0][6]
+            lines = (out / ("synth_%s_svs.out" % kind)).read_text().splitlines()
+            assert lines[0].split("\t") == sp.HEADER_FIELDS and lines[1].split("\t") == rows[0]
+
+
+def test_config_and_cli_parsing(tmp_path):
+    from breakmer_amd import breakmer
+    (tmp_path / "c.cfg").write_text("analysis_name=x\nkmer_size=31\n")
+    args = breakmer.build_parser().parse_args(["-s", "7", "-k", str(tmp_path / "c.cfg")])
+    cfgfn = args.config
+    del args.config
+    d = breakmer.parse_config_f(cfgfn, args)
+    assert d["kmer_size"] == "31" and d["indel_size"] == 7 and d["keep_intron_vars"] is True and d["trl_sr_thresh"] == 2
+    (tmp_path / "bad.cfg").write_text("no_equals_sign\n")
+    with pytest.raises(SystemExit):
+        breakmer.parse_config_f(str(tmp_path / "bad.cfg"), args)
+
+
+def _rank_main(rank, world, port, base, q):
+    import torch.distributed as td
+    from breakmer_amd.collate import collate_results
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    import pathlib
+    d = pathlib.Path(base) / ("rank%d" % rank)
+    d.mkdir()
+    cfg, data = make_inputs(d, [(3, "del"), (5, "ins"), (7, "inv"), (9, "del")])
+    r = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')),
+                  rank=rank, world=world, collate=collate_results)
+    rows = r.run()
+    q.put((rank, rows, sorted(r.summary)))
+    td.destroy_process_group()
+
+
+def test_two_rank_collation_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): regions sharded by rank, rows all-gathered == single-process run."""
+    import torch.multiprocessing as mp
+    single = tmp_path / "single"
+    single.mkdir()
+    cfg, data = make_inputs(single, [(3, "del"), (5, "ins"), (7, "inv"), (9, "del")])
+    want = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min'))).run()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rank_main, args=(rk, 2, port, str(tmp_path), q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, rows, names in got:
+        assert rows == want, rank
+        assert len(names) == 4
+    assert len(want) >= 3
