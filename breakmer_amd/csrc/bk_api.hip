@@ -5,6 +5,7 @@
 #include "bk_kmer.hip.h"
 #include "bk_asm.hip.h"
 #include "bk_sw.hip.h"
+#include "bk_call.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -46,6 +47,7 @@ struct bk_handle {
     uint64_t total_reads = 0, alg_bytes = 0;
     float ms[4] = {0, 0, 0, 0};
     BkParams params{};
+    bkcall::Context call_ctx; bool have_ctx = false; std::string calls_blob;
 };
 
 #define HIPCHK(h, call)                                                                              \
@@ -509,5 +511,86 @@ extern "C" int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, con
     if (ms) (void)hipEventElapsedTime(ms, h->ev[4], h->ev[5]);
     HIPCHK(h, hipMemcpy(out, dout.p, nb * 4, hipMemcpyDeviceToHost));
     dc.release(); d1.release(); d2.release(); d3.release(); d4.release(); dout.release();
+    return BK_OK;
+}
+
+// ---- native SV-call tail (C1-C3; same semantics as breakmer_amd/sv_caller.py, pinned by tests/golden/caller.json) ----
+// bk_call_text: CPU-only entry used by the G5 parity test: one contig described entirely by `text`
+// (format: bk_call.h parse_context).  Writes the tab-joined 13-field row (or "") and the target_hit flag.
+extern "C" int bk_call_text(const char *text, char *out, size_t cap, int *target_hit)
+{
+    bkcall::Context cx; std::string err;
+    if (!text || !out || !bkcall::parse_context(text, cx, err) || cx.regions.empty()) { g_create_err = "bk_call_text: " + err; return BK_E_ARG; }
+    bkcall::Contig ct; ct.seq = cx.c_seq; ct.id = cx.c_id; ct.io = cx.c_io.data(); ct.ot = cx.c_ot.data(); ct.clen = (int)cx.c_ot.size(); ct.klocs = cx.c_kl.data(); ct.nkmers = cx.c_nkmers; ct.same_read_tag = cx.c_same != 0;
+    std::vector<bkcall::Psl> rows = cx.rows;
+    for (auto &p : rows) {
+        if (cx.has_tname) p.tname = cx.tname;
+        if (cx.has_offset) { p.tstart += cx.offset; p.tend += cx.offset; for (auto &v : p.ts) v += cx.offset; }
+    }
+    if (target_hit) *target_hit = rows.empty() ? -1 : (bkcall::target_hit(cx.opts, cx.regions[0], cx.tables, ct, rows) ? 1 : 0);
+    std::vector<std::string> row; std::string s;
+    if (bkcall::get_result(cx.opts, cx.regions[0], cx.tables, ct, rows, row)) s = bkcall::join_row(row);
+    if (s.size() + 1 > cap) return BK_E_LIMIT;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return BK_OK;
+}
+
+// batch: annotation/query_region context for the submitted regions (text, bk_call.h), then calls for every contig
+extern "C" int bk_set_call_context(bk_handle *h, const char *text)
+{
+    if (!h || !text) return BK_E_ARG;
+    h->call_ctx = bkcall::Context(); std::string err;
+    if (!bkcall::parse_context(text, h->call_ctx, err)) return fail(h, BK_E_ARG, "bk_set_call_context: " + err);
+    if ((int)h->call_ctx.regions.size() != h->n_regions) return fail(h, BK_E_ARG, "bk_set_call_context: region count differs from the submitted batch");
+    h->have_ctx = true;
+    return BK_OK;
+}
+
+// replaces, per contig: contig.query_ref + check_target_blat + make_calls (sv_processor.py:823-866).  Result: text,
+// one line per called contig: "<region>\t<contig index>\t<13 tab-separated fields>".
+extern "C" int bk_call(bk_handle *h)
+{
+    if (!h) return BK_E_ARG;
+    if (!h->have_ctx) return fail(h, BK_E_STATE, "bk_call: bk_set_call_context first");
+    int rc = fetch(h); if (rc != BK_OK) return rc;
+    h->calls_blob.clear();
+    const bkcall::Context &cx = h->call_ctx;
+    for (int r = 0; r < h->n_regions; r++) {
+        const bkcall::Region &rg = cx.regions[r];
+        uint64_t off = h->h_work[r].o_first_contig; int ci = 0;
+        for (; off; ci++) {
+            const BkContigRec *c = (const BkContigRec *)(h->h_out.data() + off); off = c->next;
+            const uint8_t *b = (const uint8_t *)c;
+            bkcall::Contig ct; ct.seq.assign((const char *)b + c->o_seq, c->seq_len); ct.id = "contig" + std::to_string(ci + 1);
+            ct.io = (const int *)(b + c->o_io); ct.ot = (const int *)(b + c->o_ot); ct.clen = c->counts_len; ct.klocs = (const int *)(b + c->o_klocs); ct.nkmers = c->n_kmers;
+            { const uint32_t *rd = (const uint32_t *)(b + c->o_reads); const std::string &tg = cx.rtags[r]; bool same = true; char first = 0;
+              for (int i = 0; i < c->n_reads; i++) { char t = rd[i] < tg.size() ? tg[rd[i]] : '0'; if (i == 0) first = t; else if (t != first) same = false; } ct.same_read_tag = same && c->n_reads > 0; }
+            std::vector<BkHit> raw; if (c->n_hits > 0 && c->hits_off) { const BkHit *p = (const BkHit *)(h->h_out.data() + c->hits_off); raw.assign(p, p + c->n_hits); }
+            bk_psl recs[16]; int n = chain_hits(ct.seq.c_str(), c->seq_len, h->h_targets[r], raw, recs, 16); if (n > 16) n = 16;
+            auto to_psl = [&](const bk_psl &x, const std::string &tname, int offset) {
+                bkcall::Psl p; p.matches = x.matches; p.mis = x.mismatches; p.rep = x.rep_matches; p.qni = x.q_num_insert; p.qbi = x.q_base_insert; p.tni = x.t_num_insert; p.tbi = x.t_base_insert;
+                p.strand = (char)x.strand; p.qsize = x.q_size; p.qstart = x.q_start; p.qend = x.q_end; p.tname = bkcall::strip_chr(tname); p.tsize = x.t_size; p.tstart = x.t_start + offset; p.tend = x.t_end + offset;
+                for (int i = 0; i < x.block_count; i++) { p.bs.push_back(x.block_sizes[i]); p.qs.push_back(x.q_starts[i]); p.ts.push_back(x.t_starts[i] + offset); }
+                return p; };
+            std::vector<bkcall::Psl> own, rows;
+            for (int i = 0; i < n; i++) if (recs[i].t_index == 0) own.push_back(to_psl(recs[i], rg.chrom, rg.start - 200));
+            if (!own.empty() && bkcall::target_hit(cx.opts, rg, cx.tables, ct, own)) rows = own;          // the '.mod' rows (Q14)
+            else for (int i = 0; i < n; i++) {
+                const int ti = recs[i].t_index;
+                if (ti == 0) rows.push_back(to_psl(recs[i], rg.chrom, rg.start - 200));
+                else if (ti - 1 < (int)cx.partners[r].size()) rows.push_back(to_psl(recs[i], cx.partners[r][ti - 1].first, cx.partners[r][ti - 1].second));
+            }
+            std::vector<std::string> row;
+            if (bkcall::get_result(cx.opts, rg, cx.tables, ct, rows, row)) { h->calls_blob += std::to_string(r) + "\t" + std::to_string(ci) + "\t" + bkcall::join_row(row) + "\n"; }
+        }
+    }
+    return BK_OK;
+}
+
+extern "C" int bk_get_calls(bk_handle *h, char *buf, size_t cap, size_t *needed)
+{
+    if (!h) return BK_E_ARG;
+    if (needed) *needed = h->calls_blob.size() + 1;
+    if (buf && cap >= h->calls_blob.size() + 1) memcpy(buf, h->calls_blob.c_str(), h->calls_blob.size() + 1);
     return BK_OK;
 }

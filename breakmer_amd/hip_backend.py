@@ -46,9 +46,22 @@ class BkPsl(C.Structure):
                 ("t_starts", C.c_int32 * BK_MAX_BLOCKS), ("score", C.c_int32)]
 
 
+def call_text(text):
+    """Native call tail on ONE fully described contig (CPU only; used by the G5 parity test)."""
+    L = load_library()
+    out = C.create_string_buffer(1 << 16)
+    hit = C.c_int(-1)
+    rc = L.bk_call_text(text.encode(), out, len(out), C.byref(hit))
+    if rc != 0:
+        raise BreakmerHipError("bk_call_text failed (%d): %s" % (rc, L.bk_last_error(None).decode()))
+    row = out.value.decode()
+    return (row.split("\t") if row else None), (None if hit.value < 0 else bool(hit.value))
+
+
 EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_run", "bk_sync",
            "bk_last_kernel_ms", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
-           "bk_get_contig", "bk_get_hits", "bk_get_stat"]
+           "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_get_calls",
+           "bk_nw_batch"]
 
 _lib = None
 
@@ -81,6 +94,10 @@ def load_library():
     L.bk_get_contig.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6
     L.bk_get_hits.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BkPsl), C.c_int32]
     L.bk_get_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.bk_call_text.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    L.bk_set_call_context.argtypes = [C.c_void_p, C.c_char_p]
+    L.bk_call.argtypes = [C.c_void_p]
+    L.bk_get_calls.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.bk_nw_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
     _lib = L
@@ -230,6 +247,23 @@ class Engine(object):
                         "others": ot[:info.counts_len].tolist(), "kmer_locs": kl[:info.seq_len].tolist(),
                         "kmers": [km[i * self.k:(i + 1) * self.k].tobytes().decode() for i in range(info.n_kmers)],
                         "reads": rd[:info.n_reads].tolist(), "total_reads": info.total_reads, "n_hits": info.n_hits})
+        return out
+
+    def set_call_context(self, text):
+        self._chk(self.L.bk_set_call_context(self.h, text.encode()), "bk_set_call_context")
+
+    def call(self):
+        """Native SV-call tail over every contig of the batch -> {region: [13-field rows]} (contig order)."""
+        self._chk(self.L.bk_call(self.h), "bk_call")
+        need = C.c_size_t()
+        self.L.bk_get_calls(self.h, None, 0, C.byref(need))
+        buf = C.create_string_buffer(need.value)
+        self._chk(self.L.bk_get_calls(self.h, buf, need.value, C.byref(need)), "bk_get_calls")
+        out = {}
+        for ln in buf.value.decode().split("\n"):
+            if ln:
+                f = ln.split("\t")
+                out.setdefault(int(f[0]), []).append(f[2:])
         return out
 
     def hits(self, region, contig):

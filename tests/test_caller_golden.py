@@ -66,3 +66,26 @@ def test_g5_caller_rows(golden_dir):
         assert hit == c["target_hit"], c["tag"]
         called += got is not None
     assert called >= 15
+
+
+def test_g5_native_call_tail(golden_dir):
+    """The C++ port of the call logic (csrc/bk_call.h, host code of libbreakmer_hip.so; no GPU needed) against
+    the same reference rows."""
+    from breakmer_amd import call_context as cc, hip_backend as hb
+    with open(os.path.join(golden_dir, "caller.json")) as f:
+        d = json.load(f)
+    called = 0
+    for c in d["cases"]:
+        qr = c["query_region"]
+        query_region = (qr[0], qr[1], qr[2], qr[3], [tuple(x) for x in qr[4]])
+        cd = c["contig"]
+        tags = set(i.split("/")[1] for i in c["read_ids"])
+        lines = [cc.opts_line(c["opts"])] + cc.tables_lines(c["genes"], _tuplify(c["all_repeat_mask"]))
+        lines += cc.region_lines(0, query_region, _tuplify(c["target_repeat_mask"]), c["disc_reads"])
+        lines += cc.contig_lines(c["contig_id"], cd["seq"], cd["indel_only"], cd["others"], cd["kmer_locs"], len(cd["kmers"]), len(tags) == 1,
+                                 c["psl_rows"], c["offset"], c["tname"])
+        got, hit = hb.call_text("\n".join(lines) + "\n")
+        assert got == c["expected"], c["tag"]
+        assert hit == c["target_hit"], c["tag"]
+        called += got is not None
+    assert called >= 15

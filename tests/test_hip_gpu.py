@@ -137,11 +137,17 @@ def test_runner_end_to_end_gpu(hb, golden_dir, tmp_path):
     cfg, data = make_inputs(tmp_path, [(3, "del")])
     rows = sp.runner(cfg, region_data=data).run()
     assert rows == [gold["del_indelmode_c0"]]
+    (tmp_path / "py").mkdir()
+    cfg2, data2 = make_inputs(tmp_path / "py", [(3, "del")])
+    assert sp.runner(cfg2, region_data=data2, native_calls=False).run() == rows          # Python tail == native tail
     for sv, tag in (("ins", "ins"), ("inv", "inv_disc"), ("dup", "dup"), ("trl", "trl")):
         d = tmp_path / sv
         d.mkdir()
         cfg, data = make_inputs(d, [(3, sv)])
         rows = sp.runner(cfg, region_data=data).run()
         assert rows == [gold[k] for k in sorted(gold) if k.startswith(tag + "_c") and gold[k] is not None], sv
+        (d / "py").mkdir()
+        cfg2, data2 = make_inputs(d / "py", [(3, sv)])
+        assert sp.runner(cfg2, region_data=data2, native_calls=False).run() == rows, sv
     out = tmp_path / "analysis" / "output"
     assert (out / "synth_indel_svs.out").is_file() and (out / "synth_summary.out").is_file()
