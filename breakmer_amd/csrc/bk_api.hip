@@ -229,8 +229,8 @@ static void fill_params(bk_handle *h)
 
 static size_t asm_lds_bytes(const bk_handle *h)
 {
-    size_t o = (sizeof(BkAsmShared) + 15) / 16 * 16;
-    o += (size_t)h->cfg.max_candidates * 8 + (size_t)2 * (h->cfg.max_read_len + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + (size_t)h->cfg.max_read_len + 16;
+    size_t o = (sizeof(BkAsmCtx) + 15) / 16 * 16 + (sizeof(BkAsmShared) + 15) / 16 * 16;
+    o += (size_t)h->cfg.max_candidates * 8 + (size_t)4 * (h->cfg.max_read_len + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + (size_t)h->cfg.max_read_len + 16;
     return (o + 15) / 16 * 16;
 }
 
@@ -485,7 +485,7 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
 // seqs: ASCII, pairs (off1,len1,off2,len2) into `seqs`; out: 4 ints per pair (j_start, i_end, i_start, score);
 // reps > 1 repeats each DP (timing); *ms receives the kernel time.
 extern "C" int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, const uint32_t *off1, const uint32_t *len1,
-                           const uint32_t *off2, const uint32_t *len2, int32_t n_pairs, int32_t reps, int32_t *out, float *ms)
+                           const uint32_t *off2, const uint32_t *len2, int32_t n_pairs, int32_t reps, int32_t transposed, int32_t *out, float *ms)
 {
     if (!h || !seqs || n_pairs <= 0 || !out) return BK_E_ARG;
     HIPCHK(h, hipSetDevice(h->dev));
@@ -500,11 +500,11 @@ extern "C" int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, con
     HIPCHK(h, hipMemcpy(dc.p, codes.data(), seq_bytes, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d1.p, off1, nb, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(d2.p, len1, nb, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d3.p, off2, nb, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(d4.p, len2, nb, hipMemcpyHostToDevice));
-    const size_t lds = ((maxm + 15) & ~15u) + ((maxn + 15) & ~15u) + (size_t)2 * (maxn + 2) * 4;
+    const size_t lds = ((maxm + 15) & ~15u) + ((maxn + 15) & ~15u) + (size_t)2 * (std::max(maxm, maxn) + 2) * 4;
     HIPCHK(h, hipFuncSetAttribute((const void *)bk_nw_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
     hipLaunchKernelGGL(bk_nw_batch_kernel, dim3(n_pairs), dim3(64), lds, h->stream, (const uint8_t *)dc.p, (const uint32_t *)d1.p, (const uint32_t *)d2.p,
-                       (const uint32_t *)d3.p, (const uint32_t *)d4.p, (int32_t *)dout.p, reps < 1 ? 1 : reps);
+                       (const uint32_t *)d3.p, (const uint32_t *)d4.p, (int32_t *)dout.p, reps < 1 ? 1 : reps, transposed);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

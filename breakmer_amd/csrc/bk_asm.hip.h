@@ -340,8 +340,9 @@ __device__ inline bool bk_check_read(int rank, int u, bool grow)
     const uint8_t *cs = L_CSEQ + S->cbase;
     // the two overlap DPs on wavefronts 0 and 1 (:451-452)
     const int wv = BK_TID >> 6;
-    if (wv == 0) { BkNwResult r = bk_nw_wave(cs, clen, L_RSEQ, rl, L_BOUND); if ((BK_TID & 63) == 0) S->v1 = r; }
-    else if (wv == 1) { BkNwResult r = bk_nw_wave(L_RSEQ, rl, cs, clen, nullptr); if ((BK_TID & 63) == 0) S->v2 = r; }
+    // both with the contig on the tile columns: v1 = nw(contig, read) direct, v2 = nw(read, contig) transposed
+    if (wv == 0) { BkNwResult r = bk_nw_wave<false>(cs, clen, L_RSEQ, rl, L_BOUND); if ((BK_TID & 63) == 0) S->v1 = r; }
+    else if (wv == 1) { BkNwResult r = bk_nw_wave<true>(cs, clen, L_RSEQ, rl, L_BOUND + 2 * (C_.MAXR + 2)); if ((BK_TID & 63) == 0) S->v2 = r; }
     BK_SYNC();
     const BkNwResult v1 = S->v1, v2 = S->v2;
     int dec = BK_DEC_NONE, ds = 0, de = 0;          // uniform: computed identically by every thread
@@ -622,7 +623,7 @@ extern "C" __global__ void __launch_bounds__(BK_AT) bk_asm_kernel(BkParams p)
         c.MAXC = p.max_contig; c.MAXR = p.max_read; c.MAXCAND = p.max_cand; c.KCAP = 2 * p.max_contig; c.k = p.k;
         int o = BK_BUF_OFF;
         c.o_cand = o; o += c.MAXCAND * 8;
-        c.o_bound = o; o += 2 * (c.MAXR + 2) * 4;
+        c.o_bound = o; o += 4 * (c.MAXR + 2) * 4;
         c.o_candu = o; o += c.MAXCAND * 4;
         c.o_cseq = o; o += 2 * c.MAXC;
         c.o_rseq = o; o += c.MAXR + 16;
@@ -692,16 +693,16 @@ extern "C" __global__ void __launch_bounds__(BK_AT) bk_asm_kernel(BkParams p)
 
 // ---- stand-alone batched olc.nw (known-answer tests G1, DP micro-benchmark) -----------------------------------
 extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_t *codes, const uint32_t *off1, const uint32_t *len1,
-                                                                     const uint32_t *off2, const uint32_t *len2, int32_t *out, int reps)
+                                                                     const uint32_t *off2, const uint32_t *len2, int32_t *out, int reps, int transposed)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t l[];
     const int b = blockIdx.x, m = (int)len1[b], n = (int)len2[b];
     uint8_t *s1 = l, *s2 = l + ((m + 15) & ~15);
-    int *bound = (int *)(l + ((m + 15) & ~15) + ((n + 15) & ~15));
+    int *bound = (int *)(l + ((m + 15) & ~15) + ((n + 15) & ~15));   // 2*(max(m,n)+2) ints
     for (int t = threadIdx.x; t < m; t += 64) s1[t] = codes[off1[b] + t];
     for (int t = threadIdx.x; t < n; t += 64) s2[t] = codes[off2[b] + t];
     __syncthreads();
     BkNwResult r{};
-    for (int i = 0; i < reps; i++) r = bk_nw_wave(s1, m, s2, n, bound);
+    for (int i = 0; i < reps; i++) r = transposed ? bk_nw_wave<true>(s2, n, s1, m, bound) : bk_nw_wave<false>(s1, m, s2, n, bound);
     if (threadIdx.x == 0) { out[4 * b] = r.j_start; out[4 * b + 1] = r.i_end; out[4 * b + 2] = r.i_start; out[4 * b + 3] = r.score; }
 }

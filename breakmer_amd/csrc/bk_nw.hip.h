@@ -7,118 +7,159 @@
 // instead of storing pointers each cell carries the border cell its traceback would end in:
 //
 //     cell word = [ score : 14 signed | priority : 2 | origin : 16 ]
-//     origin    = j            for the top border    (0, j)
-//               = 0x8000 | i   for the left border   (i, 0)
+//     origin    = j            for the border row    (0, j)   of the reference matrix
+//               = 0x8000 | i   for the border column (i, 0)
 //
-// One signed max3 over (diag + s, left + gap, up + gap) picks the predecessor with the reference's
-// tie-break (diagonal 3 > S[i][j-1] 2 > S[i-1][j] 1, olc.py:69-74) because the 2-bit priority sits
-// directly below the score; the origin rides along in the low bits and never influences the
-// comparison (priorities are distinct).
+// One signed max3 over (diag + s, S[i][j-1] + gap, S[i-1][j] + gap) picks the predecessor with the
+// reference's tie-break (diagonal 3 > S[i][j-1] 2 > S[i-1][j] 1, olc.py:69-74) because the 2-bit
+// priority sits directly below the score; the origin rides along in the low bits and never
+// influences the comparison (priorities are distinct).
 //
-// Mapping: lane l owns C consecutive columns (C = ceil(cols/64) <= 8, registers); the wave sweeps
-// the rows as a skewed pipeline (lane l works on row t-l at step t) and hands the right edge of
-// its block to lane l+1 with one DPP wave_shr:1 per step.  Wider matrices are processed in column
-// tiles of 64*8 with the tile edge column staged in LDS.  Integer VALU + DPP only (no MFMA: a
-// max-plus recurrence is not a dense contraction).
+// Mapping: lane l owns C consecutive "tile columns" (C = ceil(cols/64) <= 8, registers); the wave
+// sweeps the "tile rows" as a skewed pipeline (lane l works on row t-l at step t) and hands the right
+// edge of its block to lane l+1 with one DPP wave_shr:1 per step; the row symbol travels the same
+// way (lane 0 picks it with a v_readlane from a register block, so there is no LDS access in the
+// loop).  Both DPs of check_align put the CONTIG on the tile columns and the read on the tile rows:
+//   TR = false : nw(contig, read) -- tile columns = reference columns (seq1);
+//   TR = true  : nw(read, contig) -- the reference matrix transposed (tile columns = reference rows,
+//                seq2): the two gap priorities swap places, the "last column" becomes the last tile
+//                row, read out of the registers after the sweep.
+// Wider contigs are processed in column tiles of 64*8 with the tile edge column staged in LDS.
+// Integer VALU + DPP only (no MFMA: a max-plus recurrence is not a dense contraction).
 #pragma once
 #include "bk_common.h"
 
 #define BK_NW_PRIO_MASK 0x00030000
 #define BK_NW_MATCH ((1 << 18) + (2 << 16))
 #define BK_NW_MISM ((int)(((unsigned)-2) << 18) + (2 << 16))
-#define BK_NW_CU ((int)(((unsigned)-2) << 18) + (1 << 16))     // S[i][j-1] + gap, pointer 2
-#define BK_NW_CL ((int)(((unsigned)-2) << 18))                 // S[i-1][j] + gap, pointer 1
+#define BK_NW_G2 ((int)(((unsigned)-2) << 18) + (1 << 16))     // S[i][j-1] + gap, pointer 2
+#define BK_NW_G1 ((int)(((unsigned)-2) << 18))                 // S[i-1][j] + gap, pointer 1
 #define BK_NW_TILE_C 8
 #define BK_NW_TILE_COLS (64 * BK_NW_TILE_C)
 
 struct BkNwResult { int j_start, i_end, i_start, score; };
 
-__device__ inline int bk_dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // lane l <- lane l-1
+__device__ inline int bk_dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }   // lane l <- lane l-1 (lane 0 keeps its own value)
 
-// One column tile.  cols/rows: LDS byte arrays of base codes (0..3).  Columns j0+1 .. j0+mt.
-// bound_in[i]  (i=1..n): word of cell (i, j0) from the previous tile (ignored when j0 == 0)
-// bound_out[i] (i=1..n): word of cell (i, j0+mt), written when !last
-// best_*: running end-cell selection on the last tile.
-// Kept out of line: one function per C keeps the register budget of every caller at the C=8 size
-// (inlining all eight variants into one kernel made the allocator spill: 232+ VGPRs).
-template <int C>
-__device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt,
-                                        const int *bound_in, int *bound_out, bool last, int best_word, int best_i)
+// One column tile.  cols/rows: LDS byte arrays of base codes (0..3).  Tile columns j0+1 .. j0+mt, tile rows 1..n.
+// bound_in[i]  (i=1..n): word of tile cell (i, j0) from the previous tile (ignored when j0 == 0)
+// bound_out[i] (i=1..n): word of tile cell (i, j0+mt), written when !last
+// best (x = word, y = index): running end-cell selection.
+// Kept out of line: one function per (C, TR) keeps the register budget of every caller at the C=8 size
+// (inlining all variants into one kernel made the allocator spill: 232+ VGPRs).
+template <int C, bool TR>
+__device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows, int n_, int j0_, int mt_,
+                                        const int *bound_in, int *bound_out, bool last_, int best_word, int best_i)
 {
+    // the arguments of an out-of-line function arrive in VGPRs: tell the compiler they are wave-uniform so that
+    // the loop control and the lane predicates stay on the scalar unit
+    const int n = __builtin_amdgcn_readfirstlane(n_), j0 = __builtin_amdgcn_readfirstlane(j0_), mt = __builtin_amdgcn_readfirstlane(mt_);
+    const bool last = __builtin_amdgcn_readfirstlane((int)last_) != 0;
     const int lane = threadIdx.x & 63;
     const int lm = (mt - 1) / C, xm = (mt - 1) % C;
+    // which reference neighbour is "horizontal" (previous tile column) / "vertical" (previous tile row)
+    constexpr int GH = TR ? BK_NW_G1 : BK_NW_G2, GV = TR ? BK_NW_G2 : BK_NW_G1;
+    constexpr int TOPB = TR ? 0x8000 : 0, LEFTB = TR ? 0 : 0x8000;   // origin tag of the tile's top / left border
     int H[C]; int cb[C];
 #pragma unroll
     for (int x = 0; x < C; x++) {
-        int jj = lane * C + x;                          // 0-based column inside the tile
-        H[x] = j0 + jj + 1;                             // row 0: score 0, origin = top border (0, j)
+        const int jj = lane * C + x;                    // 0-based tile column
+        H[x] = TOPB | (j0 + jj + 1);                    // tile row 0: score 0, origin = that border cell
         cb[x] = jj < mt ? (int)cols[j0 + jj] : 4;       // 4 never matches
     }
-    int dprev = j0 + lane * C;                          // cell (0, j0 + l*C): score 0, origin (0, j)
-    int out_prev = 0;
+    int dprev = (j0 + lane * C) ? (TOPB | (j0 + lane * C)) : 0;      // tile cell (0, j0 + l*C); the corner (0,0) is origin 0
+    int out_prev = 0, rb_prev = 0;
+    int rblk = (lane < n) ? (int)rows[lane] : 0;        // row symbols t = 0..63
     const int steps = n + lm;                           // lanes 0..lm
     for (int t = 0; t < steps; t++) {
+        const int tl = t & 63;
+        if (tl == 0 && t) rblk = (t + lane < n) ? (int)rows[t + lane] : 0;
+        const int rb0 = __builtin_amdgcn_readlane(rblk, tl);       // rows[t]: the symbol of tile row t+1, enters at lane 0
         const int recv = bk_dpp_shr1(out_prev);
-        const int i = t - lane + 1;                     // row handled by this lane at this step
-        const bool active = (lane <= lm) && (i >= 1) && (i <= n);
+        int rb = bk_dpp_shr1(rb_prev);
+        const int i = t - lane + 1;                     // tile row handled by this lane at this step
+        if (lane == 0) rb = rb0;
+        rb_prev = rb;
+        const bool active = (lane <= lm) && ((unsigned)(i - 1) < (unsigned)n);
         if (active) {
             int left_in;
-            if (lane == 0) left_in = (j0 == 0) ? (0x8000 | i) : bound_in[i];
+            if (lane == 0) left_in = (j0 == 0) ? (LEFTB | i) : bound_in[i];
             else left_in = recv;
-            const int rb = (int)rows[i - 1];
-            int diag = dprev, u_in = left_in;
+            // candidates that only need the previous tile row first (off the dependency chain), then the
+            // serial chain along the row writes H[x] in place (no register shuffling at the loop end)
+            int cd[C], cv[C];
 #pragma unroll
             for (int x = 0; x < C; x++) {
-                int cd = diag + (cb[x] == rb ? BK_NW_MATCH : BK_NW_MISM);
-                int cu = u_in + BK_NW_CU;
-                int cl = H[x] + BK_NW_CL;
-                int nv = max(max(cd, cu), cl) & ~BK_NW_PRIO_MASK;
-                diag = H[x]; H[x] = nv; u_in = nv;
+                cd[x] = (x ? H[x - 1] : dprev) + (cb[x] == rb ? BK_NW_MATCH : BK_NW_MISM);
+                cv[x] = H[x] + GV;
+            }
+            int u_in = left_in;
+#pragma unroll
+            for (int x = 0; x < C; x++) {
+                const int nv = max(max(cd[x], u_in + GH), cv[x]) & ~BK_NW_PRIO_MASK;
+                H[x] = nv; u_in = nv;
             }
             dprev = left_in;
             out_prev = H[C - 1];
-            if (lane == lm) {
+            if (lane == lm && (!TR || !last)) {         // last tile column of this tile row
                 int v = H[0];
 #pragma unroll
                 for (int x = 1; x < C; x++) if (x == xm) v = H[x];
-                if (last) { if ((v >> 18) >= (best_word >> 18)) { best_word = v; best_i = i; } }   // olc.py:81 '>=': last row wins
+                if (!TR && last) { if ((v >> 18) >= (best_word >> 18)) { best_word = v; best_i = i; } }   // olc.py:81 '>=': last row wins
                 else bound_out[i] = v;
             }
         }
     }
-    // hand the end-cell state to every lane
-    if (last) { best_word = __shfl(best_word, lm); best_i = __shfl(best_i, lm); }
+    if (!TR) {
+        if (last) { best_word = __shfl(best_word, lm); best_i = __shfl(best_i, lm); }
+    } else {
+        // reference last column = last tile row: scan tile columns in ascending order, '>=' keeps the largest index
+#pragma unroll
+        for (int x = 0; x < C; x++) {
+            const int jj = lane * C + x;
+            if (jj < mt && lane <= lm && (H[x] >> 18) >= (best_word >> 18)) { best_word = H[x]; best_i = j0 + jj + 1; }
+        }
+        // wave reduction: max score, then largest index (indices are unique, lanes own ascending ranges)
+        for (int o = 1; o < 64; o <<= 1) {
+            const int ow = __shfl_xor(best_word, o), oi = __shfl_xor(best_i, o);
+            const int s = best_word >> 18, os = ow >> 18;
+            if (os > s || (os == s && oi > best_i)) { best_word = ow; best_i = oi; }
+        }
+    }
     return make_int2(best_word, best_i);
 }
 
-template <int C>
+template <int C, bool TR>
 __device__ inline int2 bk_nw_tile_call(int c, const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt,
                                        const int *bi, int *bo, bool last, int bw, int bidx)
 {
-    if (c == C) return bk_nw_tile<C>(cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
-    if constexpr (C < BK_NW_TILE_C) return bk_nw_tile_call<C + 1>(c, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if (c == C) return bk_nw_tile<C, TR>(cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if constexpr (C < BK_NW_TILE_C) return bk_nw_tile_call<C + 1, TR>(c, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
     return make_int2(bw, bidx);
 }
 
-// nw(seq1 = cols (m), seq2 = rows (n)) executed by the calling wave (all 64 lanes must call).
-// bound: LDS scratch of 2*(n+1) ints, needed only when m > BK_NW_TILE_COLS.
-__device__ inline BkNwResult bk_nw_wave(const uint8_t *cols, int m, const uint8_t *rows, int n, int *bound)
+// Executed by the calling wave (all 64 lanes).  `tcols` (length m) goes on the tile columns, `trows` (length n) on
+// the tile rows.  TR = false computes olc.nw(seq1 = tcols, seq2 = trows); TR = true computes
+// olc.nw(seq1 = trows, seq2 = tcols).  bound: LDS scratch of 2*(n+1) ints, needed only when m > BK_NW_TILE_COLS.
+template <bool TR>
+__device__ inline BkNwResult bk_nw_wave(const uint8_t *tcols, int m, const uint8_t *trows, int n, int *bound)
 {
-    int best_word = 0, best_i = 0;                      // row 0 of the last column: score 0 (olc.py:79-83)
+    int best_word = 0, best_i = 0;                      // border cell of the last reference column: score 0 (olc.py:79-83)
     int *bi = bound, *bo = bound ? bound + (n + 1) : nullptr;
     for (int j0 = 0; j0 < m; j0 += BK_NW_TILE_COLS) {
         const int mt = min(m - j0, BK_NW_TILE_COLS);
         const bool last = j0 + mt >= m;
         const int c = (mt + 63) / 64;
-        const int2 b = bk_nw_tile_call<1>(c, cols, rows, n, j0, mt, bi, bo, last, best_word, best_i);
+        const int2 b = bk_nw_tile_call<1, TR>(c, tcols, trows, n, j0, mt, bi, bo, last, best_word, best_i);
         best_word = b.x; best_i = b.y;
         int *tswap = bi; bi = bo; bo = tswap;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    const int m_ref = TR ? n : m;                       // len(seq1) of the reference call
     BkNwResult r;
     if (best_i == 0) {                                  // Q5: one forced traceback step from (0, m): pointer[0][m] = 2
-        r.j_start = m - 1; r.i_end = 0; r.i_start = 0; r.score = 0;
+        r.j_start = m_ref - 1; r.i_end = 0; r.i_start = 0; r.score = 0;
     } else {
         const int org = best_word & 0xFFFF;
         r.score = best_word >> 18; r.i_end = best_i;

@@ -99,7 +99,7 @@ def load_library():
     L.bk_call.argtypes = [C.c_void_p]
     L.bk_get_calls.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.bk_nw_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                              C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
+                              C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -283,7 +283,7 @@ class Engine(object):
                         "score": r.score})
         return out
 
-    def nw_batch(self, pairs, reps=1):
+    def nw_batch(self, pairs, reps=1, transposed=False):
         """olc.nw on (seq1, seq2) pairs -> int32 [n,4] (j_start, i_end, i_start, score), kernel ms."""
         blob = bytearray()
         o1, l1, o2, l2 = [], [], [], []
@@ -294,5 +294,5 @@ class Engine(object):
         out = np.zeros((len(pairs), 4), dtype=np.int32)
         ms = C.c_float()
         self._chk(self.L.bk_nw_batch(self.h, bytes(blob), len(blob), o1.ctypes.data, l1.ctypes.data, o2.ctypes.data, l2.ctypes.data,
-                                     len(pairs), reps, out.ctypes.data, C.byref(ms)), "bk_nw_batch")
+                                     len(pairs), reps, 1 if transposed else 0, out.ctypes.data, C.byref(ms)), "bk_nw_batch")
         return out, ms.value

@@ -30,6 +30,8 @@ def test_g1_nw_kats_gpu(hb, golden_dir):
     eng = hb.Engine(kmer_size=31)
     pairs = [(c["seq1"], c["seq2"]) for c in d["cases"]]
     out, _ = eng.nw_batch(pairs)
+    out_t, _ = eng.nw_batch(pairs, transposed=True)          # the transposed sweep used for nw(read, contig)
+    assert out.tolist() == out_t.tolist()
     for c, o in zip(d["cases"], out.tolist()):
         exp = c["out"]
         assert o == [exp[3], exp[4], exp[5], exp[6]], c["tag"]
@@ -59,9 +61,11 @@ def test_nw_random_vs_oracle_gpu(hb):
     pairs.append((big[:1500], big[1300:1500] + "TTTT" * 20))
     eng = hb.Engine(kmer_size=31)
     out, _ = eng.nw_batch(pairs)
-    for (a, b), o in zip(pairs, out.tolist()):
+    out_t, _ = eng.nw_batch(pairs, transposed=True)
+    for (a, b), o, ot in zip(pairs, out.tolist(), out_t.tolist()):
         e = bo.nw(a, b)
         assert o == [e[3], e[4], e[5], e[6]], (len(a), len(b))
+        assert ot == o, (len(a), len(b), "transposed")
 
 
 def _run_regions(hb, regions, k, rc_thresh=2, stages=3):
