@@ -155,3 +155,72 @@ def test_runner_end_to_end_gpu(hb, golden_dir, tmp_path):
         assert sp.runner(cfg2, region_data=data2, native_calls=False).run() == rows, sv
     out = tmp_path / "analysis" / "output"
     assert (out / "synth_indel_svs.out").is_file() and (out / "synth_summary.out").is_file()
+
+
+def test_g4_kmer_select_gpu(hb, golden_dir):
+    """K1/K2 incl. a separate soft-clip set (case_sc) on the GPU == the reference's set algebra (G4)."""
+    d = _load(golden_dir, "kmer_select.json")
+    by_k = {}
+    for c in d["cases"]:
+        by_k.setdefault(c["k"], []).append(c)
+    for k, cases in by_k.items():
+        eng = hb.Engine(kmer_size=k)
+        eng.submit([hb.RegionInput(c["reads"], c["ref"], sc_seqs=c["sc"]) for c in cases])
+        eng.run(hb.BK_STAGE_KMER)
+        for i, c in enumerate(cases):
+            mers, counts, U = eng.kmers(i)
+            assert dict(zip(mers, counts.tolist())) == c["mers"], (k, i)
+            assert U == len(set(c["reads"]))
+
+
+def test_edge_cases_gpu(hb):
+    """Empty region, region without SV (no sample k-mers), ragged reads shorter than k, one-read region,
+    all in one batch next to a normal region; and loud failures for the documented limits."""
+    from oracle import bk_oracle as bo
+    normal = synth.make_region(3, sv_type="del", depth=60, W=1500)
+    nosv = synth.make_region(9, sv_type="del", sv_size=0, depth=40, W=900)
+    w = normal.window_str
+    ins = [hb.RegionInput(normal.reads, normal.window, read_lens=normal.read_lens),
+           hb.RegionInput([], w),
+           hb.RegionInput(nosv.reads, nosv.window, read_lens=nosv.read_lens),
+           hb.RegionInput([w[100:120], w[300:450], "ACGT" * 10 + w[500:600], w[300:450]], w),
+           hb.RegionInput([w[10:160]], w)]
+    eng = hb.Engine(kmer_size=31)
+    eng.submit(ins)
+    eng.run(hb.BK_STAGE_ALL)
+    want, _ = bo.assemble_region(normal.read_strs(), [w], 31, 2)
+    assert _strip(eng.contigs(0)) == want and len(want) == 1
+    for r in (1, 2, 4):
+        assert eng.contigs(r) == []
+    assert eng.kmers(1)[0] == [] and eng.kmers(2)[0] == []
+    reads3 = [w[100:120], w[300:450], "ACGT" * 10 + w[500:600], w[300:450]]
+    want3, info3 = bo.assemble_region(reads3, [w], 31, 2)
+    mers3, counts3, U3 = eng.kmers(3)
+    assert dict(zip(mers3, counts3.tolist())) == dict(zip(info3["mers"], info3["counts"].tolist())) and U3 == 3
+    assert _strip(eng.contigs(3)) == want3
+    # limits fail loudly
+    with pytest.raises(hb.BreakmerHipError):
+        hb.Engine(kmer_size=31).submit([hb.RegionInput(["ACGTN" * 10], w)])           # non-ACGT base
+    with pytest.raises(hb.BreakmerHipError):
+        hb.Engine(kmer_size=31).submit([hb.RegionInput(["A" * 2000], w)])             # read longer than max_read_len
+    with pytest.raises(hb.BreakmerHipError):
+        hb.Engine(kmer_size=31).submit([hb.RegionInput([w[:150]], "ACGT" * 5000)])    # window too long for the LDS k-mer set
+    with pytest.raises(hb.BreakmerHipError):
+        hb.Engine(kmer_size=99)
+
+
+def test_config4_config5_shapes_gpu(hb):
+    """configs[3]/[4] of BASELINE.json at reduced size: mixed SV set at 1,000x (multi-contig regions, long trl
+    contigs) and 250 bp reads / k=41 / 5 % noise (two-word k-mers, thousands of sample k-mers) vs the oracle."""
+    from oracle import bk_oracle as bo
+    regs = [synth.make_region(300 + i, sv_type=synth.SV_TYPES[i % 5], depth=1000, W=600, L=150) for i in range(5)]
+    eng = _run_regions(hb, regs, 31, stages=7)
+    for i, r in enumerate(regs):
+        want, _ = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
+        assert _strip(eng.contigs(i)) == want, ("cfg4", i)
+    regs = [synth.make_region(400 + i, sv_type="del", depth=100, W=700, L=250, noise=0.05) for i in range(3)]
+    eng = _run_regions(hb, regs, 41, stages=7)
+    for i, r in enumerate(regs):
+        want, info = bo.assemble_region(r.read_strs(), [r.window_str], 41, 2)
+        assert eng.kmers(i)[0] == [m for m, _ in sorted(zip(info["mers"], info["counts"].tolist()), key=lambda x: (x[1], x[0]), reverse=True)]
+        assert _strip(eng.contigs(i)) == want, ("cfg5", i)
