@@ -44,6 +44,7 @@ struct bk_handle {
     std::vector<BkPartnerDesc> h_part;
     std::vector<std::vector<std::string>> h_targets;      // per region: target window + partner windows (ASCII), for PSL assembly
     uint32_t max_win = 0;
+    int eff_max_read = 64;          // batch maximum read length rounded up to 64: sizes the assembler's LDS buffers (occupancy)
     uint64_t total_reads = 0, alg_bytes = 0;
     float ms[4] = {0, 0, 0, 0};
     BkParams params{};
@@ -181,6 +182,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         h->alg_bytes += (bases + 3) / 4 + 4ull * g.n_reads + 2ull * ((g.window_len + 3) / 4) + 2048;
     }
     h->total_reads = rlen.size(); h->n_regions = n_regions;
+    { uint32_t mx = 0; for (auto &d : h->h_desc) mx = std::max(mx, d.max_len); h->eff_max_read = (int)std::min<uint32_t>((uint32_t)h->cfg.max_read_len, std::max<uint32_t>(64, (mx + 63) / 64 * 64)); }
     // reference k-mer table geometry (LDS): load factor <= 0.5
     const uint32_t wk2 = max_w >= (uint32_t)k ? 2 * (max_w - k + 1) : 0;
     uint32_t ref_cap = 1024; while (ref_cap < 2 * wk2) ref_cap <<= 1;
@@ -223,14 +225,14 @@ static void fill_params(bk_handle *h)
     p.ubuf = (int32_t *)h->d_ubuf.p; p.ureads = (int32_t *)h->d_ureads.p; p.ufound = (int32_t *)h->d_ufound.p; p.uminpos = (int32_t *)h->d_uminpos.p;
     p.arena = (uint8_t *)h->d_arena.p; p.arena_top = (unsigned long long *)h->d_tops.p; p.arena_cap = h->arena_cap;
     p.out = (uint8_t *)h->d_out.p; p.out_top = (unsigned long long *)h->d_tops.p + 1; p.out_cap = h->out_cap;
-    p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->cfg.max_read_len;
+    p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->eff_max_read;
     p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions;
 }
 
 static size_t asm_lds_bytes(const bk_handle *h)
 {
     size_t o = (sizeof(BkAsmCtx) + 15) / 16 * 16 + (sizeof(BkAsmShared) + 15) / 16 * 16;
-    o += (size_t)h->cfg.max_candidates * 8 + (size_t)4 * (h->cfg.max_read_len + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + (size_t)h->cfg.max_read_len + 16;
+    o += (size_t)h->cfg.max_candidates * 8 + (size_t)4 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + (size_t)h->eff_max_read + 16;
     return (o + 15) / 16 * 16;
 }
 
@@ -478,6 +480,7 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
         switch (which) { case 0: v += w.nw_cells; break; case 1: v += w.nw_calls; break; case 2: v += w.sw_cells; break; case 4: v += w.U; break; case 5: v += w.M; break; case 6: v += w.n_contigs; break; default: break; }
     }
     if (which == 3) v = h->alg_bytes;
+    if (which >= 100 && which < 112) v = h->h_work[0].stamps[which - 100];      // diagnostic builds (-DBK_PHASE_STAMPS): region 0
     *value = v; return BK_OK;
 }
 

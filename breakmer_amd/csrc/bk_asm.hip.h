@@ -609,7 +609,7 @@ __device__ inline void bk_setup_contigs(int rank)
     if (in_fifo) { bk_grow(); if (!S->status) bk_emit_contig(); }                // it is the FIFO head (:50-52)
 }
 
-extern "C" __global__ void __launch_bounds__(BK_AT) bk_asm_kernel(BkParams p)
+extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
 {
     const int r = blockIdx.x;
     BkAsmShared *S = S_;

@@ -1,7 +1,7 @@
 // bk_kmer.hip.h -- stage BK_STAGE_KMER: read grouping (T1) + sample-only k-mer selection (K1/K2)
 // + k-mer -> read posting lists (replaces the regex scan of find_reads, sv_assembly.py:111-122).
 //
-// One 1024-thread workgroup per target region.  Reference behaviour reproduced:
+// One 512-thread workgroup per target region.  Reference behaviour reproduced:
 //   utils.py:239-244      fq_recs = dict seq -> [fq_read...]   (grouping, first-occurrence order)
 //   utils.py:151-178      jellyfish count -m k (no -C: strand specific), dump -c
 //   utils.py:287-296      load_kmers: counts summed over files
@@ -12,7 +12,7 @@
 #pragma once
 #include "bk_common.h"
 
-#define BK_KT 1024            // threads per workgroup (16 waves)
+#define BK_KT 512             // threads per workgroup (8 waves): small enough to co-reside with assembler workgroups of other batches
 
 struct BkRefTab {             // LDS-resident reference k-mer set: window forward + reverse complement
     const uint32_t *win_f, *win_r;   // packed, LDS
@@ -114,6 +114,12 @@ __device__ inline bool bk_kmer_before(uint32_t ca, const BkKey &ka, uint32_t cb,
     return key_lt(kb, ka);
 }
 
+#ifdef BK_PHASE_STAMPS
+#define BK_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) wk->stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BK_STAMP(i) do { } while (0)
+#endif
+
 extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, uint32_t ref_cap, uint32_t win_words_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -132,6 +138,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
         if (tid == 0) wk->status = BK_ST_WINDOW;
         return;
     }
+    BK_STAMP(0);
     // ---- P0: reference k-mer set in LDS (sv_processor.py:613-615: forward and reverse file) -------
     const uint32_t *gw = p.windows + d.win_word_off;
     const int ww = (W + 15) / 16;
@@ -149,6 +156,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
     for (int i = tid; i < 2 * WK; i += nt) rt.insert((uint32_t)i);
     __syncthreads();
 
+    BK_STAMP(1);
     // ---- P1: group identical reads (utils.py:239-244) -------------------------------------------
     const uint32_t N = d.n_reads, RW = d.read_words;
     const uint32_t *reads = p.reads + d.reads_word_off;
@@ -180,6 +188,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
         gslot[i] = s; atomicMin(&drep[s], i); atomicAdd(&dcnt[s], 1u);
     }
     __syncthreads();
+    BK_STAMP(2);
     // ---- P2: unique reads in first-occurrence (FASTQ) order = fq_recs iteration order (P4) -------
     uint32_t *urep = p.urep + d.read_meta_off, *unr = p.unreads + d.read_meta_off;
     uint8_t *ufl = p.uflag + d.read_meta_off;
@@ -198,6 +207,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
         }
     }
     __syncthreads();
+    BK_STAMP(3);
     // ---- P3a: count non-reference k-mer occurrences over unique reads ---------------------------
     uint32_t myc = 0;
     for (uint32_t u = tid; u < U; u += nt) {
@@ -206,6 +216,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
     }
     const uint32_t T = bk_block_sum(myc, scr);
     uint32_t tcap = 256; while (tcap < 2 * T) tcap <<= 1;
+    BK_STAMP(4);
     // ---- P3b: allocate; record (u,pos) triples; insert into the sample k-mer table --------------
     const uint64_t b1 = (uint64_t)T * 8 + (uint64_t)tcap * 12 + 1024;
     uint64_t a0 = bk_arena_alloc(p, b1, scr + 20);
@@ -259,6 +270,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
         for (uint32_t i = tid; i < tcap; i += nt) { if (tslot[i] != BK_EMPTY32 && trank[i] == BK_EMPTY32) tslot[i] = BK_EMPTY32 - 1; trank[i] = BK_EMPTY32; }   // tombstone: probe chains stay intact
         __syncthreads();
     }
+    BK_STAMP(5);
     // ---- P4: compact -> M sample-only k-mers, order by (count, mer) descending -------------------
     uint32_t M = 0;
     {
@@ -305,23 +317,18 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
                 __syncthreads();
             }
     }
-    // apply the permutation: final arrays indexed by rank.  Move through registers (M/nt per thread).
+    // apply the permutation: arrays indexed by compaction index -> arrays indexed by rank, staged through the
+    // (still unused) stamp and posting-offset areas so that no element is overwritten before it is read
     {
-        // two-pass to avoid aliasing: stash (lo,hi,cnt,slot) of perm[rank] in LDS-free way: read all, barrier, write all
-        const uint32_t per = (M + nt - 1) / nt;
-        // bounded register staging: process in rounds of nt elements using a temporary copy in ptmp2 area (poff/post are free now)
-        uint64_t *tlo = (uint64_t *)post;                       // T >= M words? post has T*4 bytes; need M*8 -> use kstamp (M*12) instead
-        (void)tlo; (void)per;
-        uint64_t *slo = (uint64_t *)kstamp;                     // M*8 bytes of the M*12 stamp area
-        uint32_t *scn = poff;                                   // (M+1)*4
-        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = perm[j]; slo[j] = klo[a]; scn[j] = kcnt[a]; }
+        uint64_t *s64 = (uint64_t *)kstamp;                     // M*8 of the M*12 stamp bytes
+        uint32_t *s32 = poff;                                   // (M+1)*4
+        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = perm[j]; s64[j] = klo[a]; s32[j] = kcnt[a]; }
         __syncthreads();
-        // hi words and slots need a second staging round
-        for (uint32_t j = tid; j < M; j += nt) { klo[j] = slo[j]; kcnt[j] = scn[j]; }
+        for (uint32_t j = tid; j < M; j += nt) { klo[j] = s64[j]; kcnt[j] = s32[j]; }
         __syncthreads();
-        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = perm[j]; slo[j] = khi[a]; scn[j] = ptmp[a]; }
+        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = perm[j]; s64[j] = khi[a]; s32[j] = ptmp[a]; }
         __syncthreads();
-        for (uint32_t j = tid; j < M; j += nt) { khi[j] = slo[j]; uint32_t slot = scn[j]; trank[slot] = j; ptmp[j] = 0; }
+        for (uint32_t j = tid; j < M; j += nt) { khi[j] = s64[j]; trank[s32[j]] = j; ptmp[j] = 0; }
         __syncthreads();
     }
     for (uint32_t j = tid; j < M; j += nt) {
@@ -330,6 +337,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
         kstamp[3 * j] = 0; kstamp[3 * j + 1] = 0; kstamp[3 * j + 2] = 0x7FFFFFFF;
     }
     __syncthreads();
+    BK_STAMP(6);
     // ---- P5: posting lists k-mer rank -> (u, pos) -------------------------------------------------
     for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) atomicAdd(&ptmp[rk], 1u); }
     __syncthreads();
@@ -344,6 +352,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
     __syncthreads();
     for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) post[atomicAdd(&ptmp[rk], 1u)] = t_ent[idx]; }
     __syncthreads();
+    BK_STAMP(7);
     if (tid == 0) {
         wk->U = U; wk->T = T; wk->M = M; wk->tcap = tcap;
         wk->o_trip_ent = o_ent; wk->o_trip_slot = o_tsl; wk->o_tslot = o_tslot; wk->o_tcnt = o_tcnt; wk->o_trank = o_trank;

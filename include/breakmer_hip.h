@@ -141,6 +141,22 @@ typedef struct bk_psl {
 } bk_psl;
 int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl *hits, int32_t cap);
 
+/* ---- SV-call tail (C1-C3): contig + PSL-equivalent records -> the 13-field result row -------------------
+ * Replaces, per contig, contig.query_ref/check_target_blat/make_calls -> align_manager(meta_dict).get_result()
+ * (sv_processor.py:823-866, sv_caller.py:785-833).  Host code; same semantics as breakmer_amd/sv_caller.py.
+ * The context is a line-based text (breakmer_amd/call_context.py): options (breakmer.py:73-86), gene table
+ * (utils.py:727-773), repeat masks (utils.py:302-353) and per region query_region / discordant pairs
+ * (sv_processor.py:376-408) / placement of the partner windows / read-id classes. */
+int bk_set_call_context(bk_handle *h, const char *text);
+int bk_call(bk_handle *h);                                      /* after bk_run: calls for every contig of the batch */
+int bk_get_calls(bk_handle *h, char *buf, size_t cap, size_t *needed);   /* "<region>\t<contig>\t<13 fields>\n" ... */
+int bk_call_text(const char *text, char *out, size_t cap, int *target_hit);   /* one fully described contig; no GPU needed */
+
+/* batched olc.nw on explicit pairs (known-answer tests, DP micro-benchmark): out = 4 ints per pair
+ * (j_start, i_end, i_start, score); transposed != 0 uses the sweep the assembler uses for nw(read, contig) */
+int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, const uint32_t *off1, const uint32_t *len1,
+                const uint32_t *off2, const uint32_t *len2, int32_t n_pairs, int32_t reps, int32_t transposed, int32_t *out, float *ms);
+
 /* bookkeeping for measurement: algorithmic work of the last bk_run
  *   which = 0: olc.nw DP cells (sum len(seq1)*len(seq2)), 1: olc.nw calls, 2: SW cells,
  *           3: algorithmic HBM bytes (SURVEY 8d formula), 4: unique reads, 5: sample k-mers, 6: contigs */

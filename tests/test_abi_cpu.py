@@ -1,0 +1,50 @@
+"""CPU-only checks of the drop-in boundary: the built library loads, exports every symbol that
+include/breakmer_hip.h declares, and refuses to run without a gfx950 GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from breakmer_amd import build, hip_backend
+    build.build_hip()                       # hipcc cross-compiles for gfx950 without a GPU
+    return hip_backend.load_library()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "breakmer_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bk_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 15 and "bk_run" in names and "bk_get_hits" in names
+    for n in names:
+        assert getattr(lib, n) is not None, n
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from breakmer_amd import hip_backend as hb
+    with pytest.raises(hb.BreakmerHipError) as e:
+        hb.Engine(kmer_size=31)
+    assert "no HIP device" in str(e.value) or "gfx950" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """breakmer_amd/ must not reference oracle/ (the oracle is test infrastructure)."""
+    pkg = os.path.join(ROOT, "breakmer_amd")
+    for dp, _dn, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), fn
+                assert "bk_oracle" not in txt.replace("oracle/bk_oracle", ""), fn
