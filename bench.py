@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--cpu-sample", type=int, default=24, help="regions timed through the CPU oracle (0 = skip)")
-    ap.add_argument("--inflight", type=int, default=1, help="steps in flight (independent batches on separate HIP streams)")
+    ap.add_argument("--inflight", type=int, default=3, help="steps in flight (independent batches on separate HIP streams)")
     return ap.parse_args()
 
 
@@ -146,6 +146,24 @@ def main():
         dt = float(t.item())
     total_regions = a.regions * world * a.steps
     value = total_regions / dt
+    # the same steps strictly one after the other (one handle, nothing in flight) for reference
+    serial = None
+    if len(engs) > 1:
+        ks = max(2, min(a.steps, 8))
+        only = engs[:1]
+        saved, engs[:] = list(engs), only
+        barrier()
+        ts = time.perf_counter()
+        s_k, s_a, s_w = run_steps(ks)
+        barrier()
+        sdt = time.perf_counter() - ts
+        engs[:] = saved
+        if dist:
+            t = torch.tensor([sdt], device="cuda", dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            sdt = float(t.item())
+        serial = {"value": round(a.regions * world * ks / sdt, 1), "ms_per_step": round(sdt / ks * 1e3, 3), "steps": ks,
+                  "kernels_ms": {"bk_kmer_kernel": round(s_k / ks, 3), "bk_asm_kernel": round(s_a / ks, 3), "bk_sw_kernel": round(s_w / ks, 3)}}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (assembler): algorithmic HBM bytes per launch / kernel time -----
@@ -178,6 +196,7 @@ def main():
             "kernels_ms": {"bk_kmer_kernel": round(kmer_ms / a.steps, 3), "bk_asm_kernel": round(asm_ms / a.steps, 3),
                            "bk_sw_kernel": round(sw_ms / a.steps, 3)},
             "dp_gcups": round(cells / asm_s / 1e9, 1), "dp_cells_per_step": cells, "nw_calls_per_step": calls,
+            "one_step_at_a_time": serial,
         }
         # ---- CPU baseline: the oracle (C port of the reference algorithm), 1 core, bounded sample -------
         if world == 1 and a.cpu_sample > 0:

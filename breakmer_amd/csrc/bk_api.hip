@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 static std::string g_create_err;
@@ -28,6 +29,13 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+struct HostVec {            // pinned host mirror of the result arena (faster D2H than pageable memory)
+    uint8_t *p = nullptr; size_t cap = 0, n = 0;
+    hipError_t resize(size_t m) { if (m > cap) { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; hipError_t e = hipHostMalloc((void **)&p, m + (m >> 2) + 4096, hipHostMallocDefault); if (e != hipSuccess) return e; cap = m + (m >> 2) + 4096; } n = m; return hipSuccess; }
+    uint8_t *data() { return p; } const uint8_t *data() const { return p; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; }
+};
+
 struct bk_handle {
     int dev = 0; hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
     bk_config cfg{}; std::string err;
@@ -40,7 +48,7 @@ struct bk_handle {
     uint64_t arena_cap = 0, out_cap = 0;
     uint32_t ref_cap = 0, win_words_cap = 0;
     // host mirrors
-    std::vector<BkRegionDesc> h_desc; std::vector<BkRegionWork> h_work; std::vector<uint8_t> h_out;
+    std::vector<BkRegionDesc> h_desc; std::vector<BkRegionWork> h_work; HostVec h_out;
     std::vector<BkPartnerDesc> h_part;
     std::vector<std::vector<std::string>> h_targets;      // per region: target window + partner windows (ASCII), for PSL assembly
     uint32_t max_win = 0;
@@ -95,6 +103,7 @@ extern "C" int bk_destroy(bk_handle *h)
     DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
                       &h->d_ddu, &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops};
     for (auto b : bufs) b->release();
+    h->h_out.release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -328,8 +337,9 @@ static int fetch(bk_handle *h)
     if (h->fetched) return BK_OK;
     unsigned long long tops[2];
     HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
-    h->h_out.resize(tops[1]);
-    HIPCHK(h, hipMemcpy(h->h_out.data(), h->d_out.p, tops[1], hipMemcpyDeviceToHost));
+    HIPCHK(h, h->h_out.resize(tops[1]));
+    HIPCHK(h, hipMemcpyAsync(h->h_out.data(), h->d_out.p, tops[1], hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     h->fetched = true;
     return BK_OK;
 }
@@ -558,35 +568,44 @@ extern "C" int bk_call(bk_handle *h)
     int rc = fetch(h); if (rc != BK_OK) return rc;
     h->calls_blob.clear();
     const bkcall::Context &cx = h->call_ctx;
-    for (int r = 0; r < h->n_regions; r++) {
-        const bkcall::Region &rg = cx.regions[r];
-        uint64_t off = h->h_work[r].o_first_contig; int ci = 0;
-        for (; off; ci++) {
-            const BkContigRec *c = (const BkContigRec *)(h->h_out.data() + off); off = c->next;
-            const uint8_t *b = (const uint8_t *)c;
-            bkcall::Contig ct; ct.seq.assign((const char *)b + c->o_seq, c->seq_len); ct.id = "contig" + std::to_string(ci + 1);
-            ct.io = (const int *)(b + c->o_io); ct.ot = (const int *)(b + c->o_ot); ct.clen = c->counts_len; ct.klocs = (const int *)(b + c->o_klocs); ct.nkmers = c->n_kmers;
-            { const uint32_t *rd = (const uint32_t *)(b + c->o_reads); const std::string &tg = cx.rtags[r]; bool same = true; char first = 0;
-              for (int i = 0; i < c->n_reads; i++) { char t = rd[i] < tg.size() ? tg[rd[i]] : '0'; if (i == 0) first = t; else if (t != first) same = false; } ct.same_read_tag = same && c->n_reads > 0; }
-            std::vector<BkHit> raw; if (c->n_hits > 0 && c->hits_off) { const BkHit *p = (const BkHit *)(h->h_out.data() + c->hits_off); raw.assign(p, p + c->n_hits); }
-            bk_psl recs[16]; int n = chain_hits(ct.seq.c_str(), c->seq_len, h->h_targets[r], raw, recs, 16); if (n > 16) n = 16;
-            auto to_psl = [&](const bk_psl &x, const std::string &tname, int offset) {
-                bkcall::Psl p; p.matches = x.matches; p.mis = x.mismatches; p.rep = x.rep_matches; p.qni = x.q_num_insert; p.qbi = x.q_base_insert; p.tni = x.t_num_insert; p.tbi = x.t_base_insert;
-                p.strand = (char)x.strand; p.qsize = x.q_size; p.qstart = x.q_start; p.qend = x.q_end; p.tname = bkcall::strip_chr(tname); p.tsize = x.t_size; p.tstart = x.t_start + offset; p.tend = x.t_end + offset;
-                for (int i = 0; i < x.block_count; i++) { p.bs.push_back(x.block_sizes[i]); p.qs.push_back(x.q_starts[i]); p.ts.push_back(x.t_starts[i] + offset); }
-                return p; };
-            std::vector<bkcall::Psl> own, rows;
-            for (int i = 0; i < n; i++) if (recs[i].t_index == 0) own.push_back(to_psl(recs[i], rg.chrom, rg.start - 200));
-            if (!own.empty() && bkcall::target_hit(cx.opts, rg, cx.tables, ct, own)) rows = own;          // the '.mod' rows (Q14)
-            else for (int i = 0; i < n; i++) {
-                const int ti = recs[i].t_index;
-                if (ti == 0) rows.push_back(to_psl(recs[i], rg.chrom, rg.start - 200));
-                else if (ti - 1 < (int)cx.partners[r].size()) rows.push_back(to_psl(recs[i], cx.partners[r][ti - 1].first, cx.partners[r][ti - 1].second));
+    // regions are independent: a few host threads, results concatenated in region order
+    const int nthreads = std::max(1, std::min<int>({8, (int)std::thread::hardware_concurrency(), (h->n_regions + 31) / 32}));
+    std::vector<std::string> parts(h->n_regions);
+    auto work = [&](int t) {
+        for (int r = t; r < h->n_regions; r += nthreads) {
+            const bkcall::Region &rg = cx.regions[r];
+            std::string &blob = parts[r];
+            uint64_t off = h->h_work[r].o_first_contig; int ci = 0;
+            for (; off; ci++) {
+                const BkContigRec *c = (const BkContigRec *)(h->h_out.data() + off); off = c->next;
+                const uint8_t *b = (const uint8_t *)c;
+                bkcall::Contig ct; ct.seq.assign((const char *)b + c->o_seq, c->seq_len); ct.id = "contig" + std::to_string(ci + 1);
+                ct.io = (const int *)(b + c->o_io); ct.ot = (const int *)(b + c->o_ot); ct.clen = c->counts_len; ct.klocs = (const int *)(b + c->o_klocs); ct.nkmers = c->n_kmers;
+                { const uint32_t *rd = (const uint32_t *)(b + c->o_reads); const std::string &tg = cx.rtags[r]; bool same = true; char first = 0;
+                  for (int i = 0; i < c->n_reads; i++) { char tch = rd[i] < tg.size() ? tg[rd[i]] : '0'; if (i == 0) first = tch; else if (tch != first) same = false; } ct.same_read_tag = same && c->n_reads > 0; }
+                std::vector<BkHit> raw; if (c->n_hits > 0 && c->hits_off) { const BkHit *p = (const BkHit *)(h->h_out.data() + c->hits_off); raw.assign(p, p + c->n_hits); }
+                bk_psl recs[16]; int n = chain_hits(ct.seq.c_str(), c->seq_len, h->h_targets[r], raw, recs, 16); if (n > 16) n = 16;
+                auto to_psl = [&](const bk_psl &x, const std::string &tname, int offset) {
+                    bkcall::Psl p; p.matches = x.matches; p.mis = x.mismatches; p.rep = x.rep_matches; p.qni = x.q_num_insert; p.qbi = x.q_base_insert; p.tni = x.t_num_insert; p.tbi = x.t_base_insert;
+                    p.strand = (char)x.strand; p.qsize = x.q_size; p.qstart = x.q_start; p.qend = x.q_end; p.tname = bkcall::strip_chr(tname); p.tsize = x.t_size; p.tstart = x.t_start + offset; p.tend = x.t_end + offset;
+                    for (int i = 0; i < x.block_count; i++) { p.bs.push_back(x.block_sizes[i]); p.qs.push_back(x.q_starts[i]); p.ts.push_back(x.t_starts[i] + offset); }
+                    return p; };
+                std::vector<bkcall::Psl> own, rows;
+                for (int i = 0; i < n; i++) if (recs[i].t_index == 0) own.push_back(to_psl(recs[i], rg.chrom, rg.start - 200));
+                if (!own.empty() && bkcall::target_hit(cx.opts, rg, cx.tables, ct, own)) rows = own;          // the '.mod' rows (Q14)
+                else for (int i = 0; i < n; i++) {
+                    const int ti = recs[i].t_index;
+                    if (ti == 0) rows.push_back(to_psl(recs[i], rg.chrom, rg.start - 200));
+                    else if (ti - 1 < (int)cx.partners[r].size()) rows.push_back(to_psl(recs[i], cx.partners[r][ti - 1].first, cx.partners[r][ti - 1].second));
+                }
+                std::vector<std::string> row;
+                if (bkcall::get_result(cx.opts, rg, cx.tables, ct, rows, row)) { blob += std::to_string(r) + "\t" + std::to_string(ci) + "\t" + bkcall::join_row(row) + "\n"; }
             }
-            std::vector<std::string> row;
-            if (bkcall::get_result(cx.opts, rg, cx.tables, ct, rows, row)) { h->calls_blob += std::to_string(r) + "\t" + std::to_string(ci) + "\t" + bkcall::join_row(row) + "\n"; }
         }
-    }
+    };
+    if (nthreads == 1) work(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
+    for (auto &s2 : parts) h->calls_blob += s2;
     return BK_OK;
 }
 

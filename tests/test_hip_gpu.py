@@ -224,3 +224,20 @@ def test_config4_config5_shapes_gpu(hb):
         want, info = bo.assemble_region(r.read_strs(), [r.window_str], 41, 2)
         assert eng.kmers(i)[0] == [m for m, _ in sorted(zip(info["mers"], info["counts"].tolist()), key=lambda x: (x[1], x[0]), reverse=True)]
         assert _strip(eng.contigs(i)) == want, ("cfg5", i)
+
+
+def test_arena_growth_and_rerun_gpu(hb):
+    """A deliberately tiny scratch arena: the library must notice the overflow, grow the arena and rerun --
+    results identical to a run with the default arena; repeated bk_run on one handle is idempotent."""
+    regions = [synth.make_region(500 + i, sv_type=synth.SV_TYPES[i % 4], depth=80, W=1500, noise=(0.02 if i % 2 else 0.0)) for i in range(6)]
+    ins = [hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions]
+    big = hb.Engine(kmer_size=31)
+    big.submit(ins)
+    big.run(hb.BK_STAGE_ALL)
+    small = hb.Engine(kmer_size=31, arena_bytes=1 << 16)
+    small.submit(ins)
+    small.run(hb.BK_STAGE_ALL)
+    small.run(hb.BK_STAGE_ALL)
+    for i in range(len(regions)):
+        assert small.contigs(i) == big.contigs(i), i
+        assert [small.hits(i, c) for c in range(len(small.contigs(i)))] == [big.hits(i, c) for c in range(len(big.contigs(i)))]
