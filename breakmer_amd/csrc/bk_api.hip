@@ -241,7 +241,7 @@ static void fill_params(bk_handle *h)
 static size_t asm_lds_bytes(const bk_handle *h)
 {
     size_t o = (sizeof(BkAsmCtx) + 15) / 16 * 16 + (sizeof(BkAsmShared) + 15) / 16 * 16;
-    o += (size_t)h->cfg.max_candidates * 8 + (size_t)4 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + (size_t)h->eff_max_read + 16;
+    o += (size_t)h->cfg.max_candidates * 8 + (size_t)(BK_AT / 64) * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + (size_t)BK_SPEC * (h->eff_max_read + 16);
     return (o + 15) / 16 * 16;
 }
 

@@ -16,7 +16,8 @@
 #include "bk_common.h"
 #include "bk_nw.hip.h"
 
-#define BK_AT 256
+#define BK_AT 512            // 8 wavefronts: 4 speculative look-ahead slots x 2 overlap DPs
+#define BK_SPEC 4
 
 enum { BK_ORD_FOR = 0, BK_ORD_REV = 1, BK_ORD_MID = 2 };
 enum { BK_DEC_NONE = 0, BK_DEC_SAME = 1, BK_DEC_SUPER = 2, BK_DEC_SUB = 3, BK_DEC_POST = 4, BK_DEC_PRE = 5 };
@@ -40,7 +41,13 @@ struct BkAsmShared {
     int n_contigs;
     unsigned long long cells, calls;
     BkNwResult v1, v2;
+    // look-ahead slots (see bk_run_candidates): read q+s aligned against the PREDICTED contig after reads q..q+s-1
+    struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt; BkNwResult v1, v2; } slot[BK_SPEC];
+    int nb, pc, last_dec;
     uint32_t scan[24];
+#ifdef BK_PHASE_STAMPS
+    unsigned long long acc[8], last;
+#endif
 };
 
 // The context lives in LDS (not in registers: ~60 uniform pointers would spill the SGPR file) at the
@@ -69,6 +76,11 @@ struct BkAsmCtx {
 
 #define BK_TID ((int)threadIdx.x)
 #define BK_SYNC() __syncthreads()
+#ifdef BK_PHASE_STAMPS      // diagnostic build only: where does a region's time go (s_memrealtime, 100 MHz)
+#define BK_ACC(i) do { if (BK_TID == 0) { unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); S_->acc[i] += now_ - S_->last; S_->last = now_; } } while (0)
+#else
+#define BK_ACC(i) do { } while (0)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) uint8_t bk_lds[];
 #define BK_SH_OFF ((int)((sizeof(BkAsmCtx) + 15) / 16 * 16))
@@ -76,8 +88,10 @@ extern __shared__ __attribute__((aligned(16))) uint8_t bk_lds[];
 #define C_ (*(BkAsmCtx *)bk_lds)
 #define S_ ((BkAsmShared *)(bk_lds + BK_SH_OFF))
 #define L_CSEQ (bk_lds + C_.o_cseq)
-#define L_RSEQ (bk_lds + C_.o_rseq)
+#define L_RSEQ (bk_lds + C_.o_rseq)                                   // read buffer of slot 0 (also the generic read buffer)
+#define L_RSEQ_S(s) (bk_lds + C_.o_rseq + (s) * (C_.MAXR + 16))
 #define L_BOUND ((int *)(bk_lds + C_.o_bound))
+#define L_BOUND_W(w) ((int *)(bk_lds + C_.o_bound) + (w) * 2 * (C_.MAXR + 2))
 #define L_CAND ((unsigned long long *)(bk_lds + C_.o_cand))
 #define L_CANDU ((uint32_t *)(bk_lds + C_.o_candu))
 
@@ -277,7 +291,10 @@ __device__ inline void bk_find_reads(int rank, bool rev, bool filter)
             }
             BK_SYNC();
         }
-    for (int i = BK_TID; i < n; i += BK_AT) L_CANDU[i] = (uint32_t)(L_CAND[i] & 0xFFFFFFull);
+    for (int i = BK_TID; i < n; i += BK_AT) {             // u | (k-mer position in the read << 22)
+        const unsigned long long key = L_CAND[i]; const uint32_t pk = (uint32_t)(key >> 40) & 0xFFFFu;
+        L_CANDU[i] = (uint32_t)(key & 0x3FFFFFull) | ((rev ? 0xFFFFu - pk : pk) << 22);
+    }
     BK_SYNC();
 }
 
@@ -329,22 +346,19 @@ __device__ inline void bk_add_used_mer(int rank)                                
 }
 
 // ---- check_align (sv_assembly.py:449-504) + check_read (:552-566) -------------------------------------
-// `rank` = the k-mer that recruited the read.  Returns (uniform) whether the read matched.
-__device__ inline bool bk_check_read(int rank, int u, bool grow)
+// Decision and state update for the read in look-ahead slot `sl`, whose two overlap DPs (v1 = nw(contig, read),
+// v2 = nw(read, contig)) were computed against the CURRENT contig.  `rank` = the k-mer that recruited the read.
+// Returns (uniform) whether the read matched.
+__device__ inline bool bk_retire(int rank, int sl, bool grow)
 {
     BkAsmShared *S = S_;
     const int k = C_.k;
-    bk_load_read(u);
-    if (BK_TID == 0) C_.ubuf[u] = S->serial;                                       // self.buffer.add(read.id)
-    const int clen = S->clen, rl = S->rlen, nreads = S->rn, indel = S->rindel;
+    const int u = S->slot[sl].u, rl = S->slot[sl].rl, nreads = S->slot[sl].rn, indel = S->slot[sl].rindel;
+    const uint8_t *rseq = L_RSEQ_S(sl);
+    const int clen = S->clen;
     const uint8_t *cs = L_CSEQ + S->cbase;
-    // the two overlap DPs on wavefronts 0 and 1 (:451-452)
     const int wv = BK_TID >> 6;
-    // both with the contig on the tile columns: v1 = nw(contig, read) direct, v2 = nw(read, contig) transposed
-    if (wv == 0) { BkNwResult r = bk_nw_wave<false>(cs, clen, L_RSEQ, rl, L_BOUND); if ((BK_TID & 63) == 0) S->v1 = r; }
-    else if (wv == 1) { BkNwResult r = bk_nw_wave<true>(cs, clen, L_RSEQ, rl, L_BOUND + 2 * (C_.MAXR + 2)); if ((BK_TID & 63) == 0) S->v2 = r; }
-    BK_SYNC();
-    const BkNwResult v1 = S->v1, v2 = S->v2;
+    const BkNwResult v1 = S->slot[sl].v1, v2 = S->slot[sl].v2;
     int dec = BK_DEC_NONE, ds = 0, de = 0;          // uniform: computed identically by every thread
     bool tie = false;
     {
@@ -371,8 +385,8 @@ __device__ inline bool bk_check_read(int rank, int u, bool grow)
             { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank];
               for (int t = k - 1; t >= 0; t--) { pat[t] = (uint8_t)(key.lo & 3u); key.lo = (key.lo >> 2) | (key.hi << 62); key.hi >>= 2; } }
             int i11 = bk_find_bytes_wave(cs + v1.j_start, clen - v1.j_start, pat, k);
-            int i12 = bk_find_bytes_wave(L_RSEQ + v1.i_start, v1.i_end - v1.i_start, pat, k);
-            int i21 = bk_find_bytes_wave(L_RSEQ + v2.j_start, rl - v2.j_start, pat, k);
+            int i12 = bk_find_bytes_wave(rseq + v1.i_start, v1.i_end - v1.i_start, pat, k);
+            int i21 = bk_find_bytes_wave(rseq + v2.j_start, rl - v2.j_start, pat, k);
             int i22 = bk_find_bytes_wave(cs + v2.i_start, v2.i_end - v2.i_start, pat, k);
             int d = BK_DEC_NONE;
             if (i11 > -1 && i12 > -1) { if ((i21 == -1 && i22 == -1) || (abs(i21 - i22) > abs(i11 - i12))) d = BK_DEC_POST; }
@@ -386,46 +400,47 @@ __device__ inline bool bk_check_read(int rank, int u, bool grow)
         if (dec == BK_DEC_PRE && v2.j_start == 0) { dec = BK_DEC_SUB; ds = v2.i_start; de = v2.i_end; }
         BK_SYNC();
     }
-    if (BK_TID == 0) { S->cells += 2ull * (unsigned long long)clen * (unsigned long long)rl; S->calls += 2; }
-    // ---- apply ---------------------------------------------------------------------------------------
-    if (dec == BK_DEC_SUPER) {                                                    // aseq.set_superseq :232-236
+    // ---- apply: one fused phase (disjoint index ranges, scalar state committed by thread 0, one barrier) -------
+    const bool match = dec != BK_DEC_NONE;
+    bool ext = false;                                   // contig was extended (POST / PRE): new k-mers in grow mode
+    if (dec == BK_DEC_SUPER) {                                                    // aseq.set_superseq :232-236 (rare: separate phases)
         bk_counts_superseq(rl, nreads, indel, ds, de);
         const int base = C_.MAXC - rl;
-        for (int t = BK_TID; t < rl; t += BK_AT) L_CSEQ[base + t] = L_RSEQ[t];
+        for (int t = BK_TID; t < rl; t += BK_AT) L_CSEQ[base + t] = rseq[t];
         BK_SYNC();
-        if (BK_TID == 0) { S->cbase = base; S->clen = rl; }
+        if (BK_TID == 0) { S->cbase = base; S->clen = rl; S->pc = S->slot[sl].pos; }
         BK_SYNC();
         if (grow) bk_kmers_ordered(S->cbase, S->clen, BK_ORD_MID);              // set_kmers(skmers) :479/:515
-    } else if (dec == BK_DEC_SUB) {                                               // add_subseq :238-240
-        bk_set_counts(ds, de, nreads, indel);
-    } else if (dec == BK_DEC_POST) {                                              // :520-527, add_postseq :243-250
-        const int pl = max(rl - v1.i_end, 0);
-        if (S->cbase + clen + pl > 2 * C_.MAXC || clen + pl > C_.MAXC) { bk_fail(BK_ST_CONTIG); BK_SYNC(); }
-        else {
-            for (int t = BK_TID; t < pl; t += BK_AT) L_CSEQ[S->cbase + clen + t] = L_RSEQ[v1.i_end + t];
-            BK_SYNC();
-            if (BK_TID == 0) S->clen = clen + pl;
-            BK_SYNC();
-            bk_set_counts(v1.j_start, clen, nreads, indel);
-            bk_extend_counts(pl, nreads, indel, true);
-            if (grow) { const int from = max(clen - (k - 1), 0); bk_kmers_ordered(S->cbase + from, (clen - from) + pl, BK_ORD_FOR); }
+    } else if (dec != BK_DEC_NONE && dec != BK_DEC_SAME) {
+        const int cbase = S->cbase, nbase = S->nbase, nlen = S->nlen;
+        int32_t *io = bk_cnt_io(S->cbuf), *ot = bk_cnt_ot(S->cbuf);
+        int32_t *cv = (indel ? io : ot) + nbase;
+        int s0 = ds, s1 = de, pl = 0, at = 0; bool fail = false;
+        if (dec == BK_DEC_POST) {                                                 // :520-527, add_postseq :243-250
+            pl = max(rl - v1.i_end, 0); s0 = v1.j_start; s1 = clen; at = nbase + nlen;
+            fail = cbase + clen + pl > 2 * C_.MAXC || clen + pl > C_.MAXC || at + pl > 2 * C_.MAXC;
+            if (!fail) for (int t = BK_TID; t < pl; t += BK_AT) L_CSEQ[cbase + clen + t] = rseq[v1.i_end + t];
+        } else if (dec == BK_DEC_PRE) {                                           // :538-545, add_preseq :255-262
+            pl = v2.j_start; s0 = v2.i_start; s1 = v2.i_end; at = nbase - pl;
+            fail = cbase - pl < 0 || clen + pl > C_.MAXC || at < 0;
+            if (!fail) for (int t = BK_TID; t < pl; t += BK_AT) L_CSEQ[cbase - pl + t] = rseq[t];
         }
-    } else if (dec == BK_DEC_PRE) {                                               // :538-545, add_preseq :255-262
-        const int pl = v2.j_start;
-        if (S->cbase - pl < 0 || clen + pl > C_.MAXC) { bk_fail(BK_ST_CONTIG); BK_SYNC(); }
+        if (fail) bk_fail(BK_ST_CONTIG);
         else {
-            for (int t = BK_TID; t < pl; t += BK_AT) L_CSEQ[S->cbase - pl + t] = L_RSEQ[t];
-            BK_SYNC();
-            if (BK_TID == 0) { S->cbase -= pl; S->clen = clen + pl; }
-            BK_SYNC();
-            bk_set_counts(v2.i_start, v2.i_end, nreads, indel);                 // old coordinates first (:261)
-            bk_extend_counts(pl, nreads, indel, false);
-            if (grow) bk_kmers_ordered(S->cbase, pl + min(k - 1, clen), BK_ORD_REV);
+            for (int t = s0 + BK_TID; t < min(s1, nlen); t += BK_AT) cv[t] += nreads;          // set_counts :195-199 (old coordinates)
+            for (int t = BK_TID; t < pl; t += BK_AT) { io[at + t] = indel ? nreads : 0; ot[at + t] = indel ? 0 : nreads; }   // extend_counts :201-221
+            if (BK_TID == 0 && dec != BK_DEC_SUB) {
+                if (dec == BK_DEC_PRE) { S->cbase = cbase - pl; S->nbase = nbase - pl; S->pc += pl; }
+                S->clen = clen + pl; S->nlen = nlen + pl;
+            }
+            ext = dec != BK_DEC_SUB;
         }
     }
-    const bool match = dec != BK_DEC_NONE;
-    // check_read bookkeeping (:558-565)
+    // check_read bookkeeping (:552-565)
     if (BK_TID == 0) {
+        S->last_dec = dec;
+        C_.ubuf[u] = S->serial;                                                    // self.buffer.add(read.id)
+        S->cells += 2ull * (unsigned long long)clen * (unsigned long long)rl; S->calls += 2;
         if (match) {
             C_.ufl[u] |= BK_R_USED;
             if (C_.ureads[u] != S->serial) { C_.ureads[u] = S->serial; C_.readl[S->nr++] = (uint32_t)u; }
@@ -434,7 +449,93 @@ __device__ inline bool bk_check_read(int rank, int u, bool grow)
         } else C_.ufl[u] |= BK_R_DELETED;                                          // rb.delete -> rb.clean :390
     }
     BK_SYNC();
+    BK_ACC(3);
+    if (ext && grow && !S->status) {
+        const int k1 = k - 1;
+        if (dec == BK_DEC_POST) { const int from = max(clen - k1, 0); bk_kmers_ordered(S->cbase + from, (clen - from) + (S->clen - clen), BK_ORD_FOR); }
+        else bk_kmers_ordered(S->cbase, (S->clen - clen) + min(k1, clen), BK_ORD_REV);
+    }
     return match;
+}
+
+// ---- the read loop of setup_contigs (:16-23) / grow (:634-639) with speculative look-ahead --------------------
+// The reference checks the candidate reads strictly one after the other: each accepted read changes the contig
+// the next one is aligned to.  The alignment of read q+1 only depends on the contig SEQUENCE after read q, and
+// that is predictable from where the recruiting k-mer sits in the read and in the contig (the read sticks out
+// `pos - pc` bases to the left, or its tail beyond the contig end).  So each round aligns up to BK_SPEC reads
+// at once -- slot s against the contig predicted after slots 0..s-1, two wavefronts per slot -- and then retires
+// them in order, for as long as the contig really became what was predicted (same kind of change, same
+// geometry => same bytes); the first misprediction discards the later slots, which are redone next round.
+// Results are therefore bit-identical to the serial loop; only the DP latency chain gets shorter.
+enum { BK_PK_SAME = 0, BK_PK_PRE = 1, BK_PK_POST = 2, BK_PK_STOP = 3 };
+__device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
+{
+    BkAsmShared *S = S_;
+    const int wv = BK_TID >> 6;
+    int q = first;
+    while (q < n) {
+        if (S->status) return;
+        BK_ACC(0);
+        const int nbmax = min(BK_SPEC, n - q);
+        // 1. stage the reads of this round, plan the predictions (thread 0)
+        BK_SYNC();
+        if (BK_TID == 0) {
+            int pb = S->cbase, plen = S->clen, ppc = S->pc, nb = 0;
+            for (int sl = 0; sl < nbmax; sl++) {
+                const uint32_t cu = L_CANDU[q + sl]; const int u = (int)(cu & 0x3FFFFFu), pos = (int)(cu >> 22);
+                const uint32_t ri = C_.urep[u]; const int rl = C_.rlen[ri];
+                BkAsmShared::Slot &t = S->slot[sl];
+                t.u = u; t.rl = rl; t.rn = (int)C_.unr[u]; t.rindel = (C_.ufl[u] & BK_R_INDEL) ? 1 : 0; t.pos = pos; t.pb = pb; t.plen = plen;
+                nb = sl + 1;
+                const int left = pos - ppc, right = (rl - pos) - (plen - ppc);
+                if (ppc < 0 || (left > 0 && right > 0)) { t.kind = BK_PK_STOP; t.amt = 0; break; }
+                if (left > 0) { t.kind = BK_PK_PRE; t.amt = left; if (pb - left < 0 || plen + left > C_.MAXC) { t.kind = BK_PK_STOP; break; } pb -= left; plen += left; ppc += left; }
+                else if (right > 0) { t.kind = BK_PK_POST; t.amt = right; if (pb + plen + right > 2 * C_.MAXC || plen + right > C_.MAXC) { t.kind = BK_PK_STOP; break; } plen += right; }
+                else { t.kind = BK_PK_SAME; t.amt = 0; }
+            }
+            S->nb = nb;
+        }
+        BK_SYNC();
+        const int nb = S->nb;
+        for (int sl = 0; sl < nb; sl++) {                 // unpack the reads; pre-write the bytes slot sl is predicted to add
+            const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
+            const uint32_t *w = C_.reads + (uint64_t)C_.urep[S->slot[sl].u] * C_.read_words;
+            for (int t = BK_TID; t < rl; t += BK_AT) rs[t] = (uint8_t)seq_base(w, t);
+            if (sl + 1 < nb) {
+                const int amt = S->slot[sl].amt, pb = S->slot[sl].pb, plen = S->slot[sl].plen;
+                if (S->slot[sl].kind == BK_PK_PRE) for (int t = BK_TID; t < amt; t += BK_AT) L_CSEQ[pb - amt + t] = (uint8_t)seq_base(w, t);
+                else if (S->slot[sl].kind == BK_PK_POST) for (int t = BK_TID; t < amt; t += BK_AT) L_CSEQ[pb + plen + t] = (uint8_t)seq_base(w, rl - amt + t);
+            }
+        }
+        BK_SYNC();
+        BK_ACC(1);
+        // 2. the overlap DPs (:451-452), two wavefronts per slot, both with the contig on the tile columns
+        {
+            const int sl = wv >> 1;
+            if (sl < nb) {
+                const uint8_t *cs = L_CSEQ + S->slot[sl].pb; const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
+                if ((wv & 1) == 0) { BkNwResult r = bk_nw_wave<false>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
+                else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
+            }
+        }
+        BK_SYNC();
+        BK_ACC(2);
+        // 3. retire in order while the predictions hold
+        for (int sl = 0; sl < nb; sl++) {
+            if (S->status) return;
+            if (sl > 0) {
+                const int pk = S->slot[sl - 1].kind, ld = S->last_dec;
+                const bool kind_ok = (pk == BK_PK_PRE && ld == BK_DEC_PRE) || (pk == BK_PK_POST && ld == BK_DEC_POST) ||
+                                     (pk == BK_PK_SAME && (ld == BK_DEC_NONE || ld == BK_DEC_SAME || ld == BK_DEC_SUB));
+                if (!kind_ok || S->cbase != S->slot[sl].pb || S->clen != S->slot[sl].plen) break;
+            }
+            const int u = S->slot[sl].u;
+            const bool hit = bk_retire(rank, sl, grow);
+            if (grow && hit && BK_TID == 0) { int pidx = C_.ufound[u]; if (pidx >= 0) { C_.pend[2 * pidx] = BK_EMPTY32; C_.ufound[u] = -1; } }   // buff.remove_contig :638-639
+            q++;
+            BK_SYNC();
+        }
+    }
 }
 
 // ---- check_alt_reads (sv_assembly.py:568-582) + the adds of finalize (:590-592) -------------------------
@@ -524,14 +625,16 @@ __device__ inline void bk_grow()
             bk_find_reads(rank, rev, true);                                    // get_mer_reads :604-614
             if (BK_TID == 0) bk_add_used_mer(rank);
             BK_SYNC();
-            const int n = S->ncand;
-            for (int q = 0; q < n; q++) {
-                if (S->status) return;
-                const int u = (int)L_CANDU[q];          // L_CAND itself is scratch from here on
-                const bool hit = bk_check_read(rank, u, true);
-                if (hit && BK_TID == 0) { int pidx = C_.ufound[u]; if (pidx >= 0) { C_.pend[2 * pidx] = BK_EMPTY32; C_.ufound[u] = -1; } }   // buff.remove_contig :638-639
-                BK_SYNC();
+            // position of this k-mer in the contig (prediction seed); -1 disables the look-ahead
+            if ((BK_TID >> 6) == 0) {
+                uint8_t pat[64];
+                { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank];
+                  for (int z = C_.k - 1; z >= 0; z--) { pat[z] = (uint8_t)(key.lo & 3u); key.lo = (key.lo >> 2) | (key.hi << 62); key.hi >>= 2; } }
+                const int pc = bk_find_bytes_wave(L_CSEQ + S->cbase, S->clen, pat, C_.k);
+                if (BK_TID == 0) S->pc = pc;
             }
+            BK_SYNC();
+            bk_run_candidates(rank, 0, S->ncand, true);
             bk_finalize(false);
             if (BK_TID == 0) C_.kstamp[3 * rank] = S->serial;                       // checked_kmers.append(mer)
             BK_SYNC();
@@ -598,13 +701,15 @@ __device__ inline void bk_setup_contigs(int rank)
     const int n = S->ncand;
     if (n == 0 || S->status) return;
     // the candidate list must survive the check_read calls below: candu is not touched by them
-    const int u0 = (int)L_CANDU[0];
+    const int u0 = (int)(L_CANDU[0] & 0x3FFFFFu);
     const bool in_fifo = C_.ufound[u0] < 0 && !(C_.ufl[u0] & BK_R_USED);            // buff.add_contig :337-340
     BK_SYNC();
     bk_contig_new(rank, u0, in_fifo);
     if (BK_TID == 0 && in_fifo) C_.ufl[u0] |= BK_R_USED;
     BK_SYNC();
-    for (int q = 1; q < n; q++) { if (S->status) return; bk_check_read(rank, (int)L_CANDU[q], false); }
+    if (BK_TID == 0) S->pc = (int)(L_CANDU[0] >> 22);      // the contig IS the first read: the k-mer sits where it sits in that read
+    BK_SYNC();
+    bk_run_candidates(rank, 1, n, false);
     bk_finalize(true);
     if (in_fifo) { bk_grow(); if (!S->status) bk_emit_contig(); }                // it is the FIFO head (:50-52)
 }
@@ -623,10 +728,10 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
         c.MAXC = p.max_contig; c.MAXR = p.max_read; c.MAXCAND = p.max_cand; c.KCAP = 2 * p.max_contig; c.k = p.k;
         int o = BK_BUF_OFF;
         c.o_cand = o; o += c.MAXCAND * 8;
-        c.o_bound = o; o += 4 * (c.MAXR + 2) * 4;
+        c.o_bound = o; o += (BK_AT / 64) * 2 * (c.MAXR + 2) * 4;
         c.o_candu = o; o += c.MAXCAND * 4;
         c.o_cseq = o; o += 2 * c.MAXC;
-        c.o_rseq = o; o += c.MAXR + 16;
+        c.o_rseq = o; o += BK_SPEC * (c.MAXR + 16);
         c.reads = p.reads + d.reads_word_off; c.rlen = p.read_len + d.read_meta_off;
         const uint64_t mo = d.read_meta_off;
         c.urep = p.urep + mo; c.unr = p.unreads + mo; c.ufl = p.uflag + mo; c.ubuf = p.ubuf + mo; c.ureads = p.ureads + mo; c.ufound = p.ufound + mo; c.uminpos = p.uminpos + mo;
@@ -637,6 +742,10 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
         c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
         S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0;
+#ifdef BK_PHASE_STAMPS
+        for (int i = 0; i < 8; i++) S->acc[i] = 0;
+        S->last = __builtin_amdgcn_s_memrealtime();
+#endif
         // per-region scratch from the arena
         const uint64_t b_cnt = (uint64_t)8 * c.MAXC * 4, b_kl = (uint64_t)c.KCAP * 4, b_pend = (uint64_t)2 * (c.U + 1) * 4, b_alt = (uint64_t)c.MAXCAND * 4,
                        b_rd = (uint64_t)(c.U + 1) * 4, b_used = (uint64_t)(c.M + 1) * 4;
@@ -688,7 +797,11 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
         BK_SYNC();
     }
     BK_SYNC();
+    BK_ACC(0);
     if (BK_TID == 0) { C_.wk->n_contigs = (uint32_t)S->n_contigs; C_.wk->nw_cells = S->cells; C_.wk->nw_calls = S->calls; if (S->status) C_.wk->status = S->status; }
+#ifdef BK_PHASE_STAMPS
+    if (BK_TID == 0) for (int i = 0; i < 8; i++) C_.wk->stamps[i] = S->acc[i];
+#endif
 }
 
 // ---- stand-alone batched olc.nw (known-answer tests G1, DP micro-benchmark) -----------------------------------

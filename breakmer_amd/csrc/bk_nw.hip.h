@@ -45,9 +45,11 @@ __device__ inline int bk_dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(v,
 // bound_in[i]  (i=1..n): word of tile cell (i, j0) from the previous tile (ignored when j0 == 0)
 // bound_out[i] (i=1..n): word of tile cell (i, j0+mt), written when !last
 // best (x = word, y = index): running end-cell selection.
-// Kept out of line: one function per (C, TR) keeps the register budget of every caller at the C=8 size
-// (inlining all variants into one kernel made the allocator spill: 232+ VGPRs).
-template <int C, bool TR>
+// Kept out of line: one function per (C, TR, XM) keeps the register budget of every caller at the C=8 size
+// (inlining all variants into one kernel made the allocator spill: 232+ VGPRs).  XM = register that holds the
+// last tile column in lane lm; a template parameter because a run-time select costs C-1 instructions per step
+// (direct sweep only; the transposed sweep reads the end cells after the loop and uses XM = 0).
+template <int C, bool TR, int XM>
 __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows, int n_, int j0_, int mt_,
                                         const int *bound_in, int *bound_out, bool last_, int best_word, int best_i)
 {
@@ -56,7 +58,7 @@ __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows
     const int n = __builtin_amdgcn_readfirstlane(n_), j0 = __builtin_amdgcn_readfirstlane(j0_), mt = __builtin_amdgcn_readfirstlane(mt_);
     const bool last = __builtin_amdgcn_readfirstlane((int)last_) != 0;
     const int lane = threadIdx.x & 63;
-    const int lm = (mt - 1) / C, xm = (mt - 1) % C;
+    const int lm = (mt - 1) / C;
     // which reference neighbour is "horizontal" (previous tile column) / "vertical" (previous tile row)
     constexpr int GH = TR ? BK_NW_G1 : BK_NW_G2, GV = TR ? BK_NW_G2 : BK_NW_G1;
     constexpr int TOPB = TR ? 0x8000 : 0, LEFTB = TR ? 0 : 0x8000;   // origin tag of the tile's top / left border
@@ -102,9 +104,12 @@ __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows
             dprev = left_in;
             out_prev = H[C - 1];
             if (lane == lm && (!TR || !last)) {         // last tile column of this tile row
-                int v = H[0];
+                int v = H[XM];
+                if constexpr (TR) {                     // transposed sweep, not the last tile (contig > 512): rare, run-time select
+                    const int xm = (mt - 1) % C;
 #pragma unroll
-                for (int x = 1; x < C; x++) if (x == xm) v = H[x];
+                    for (int x = 1; x < C; x++) if (x == xm) v = H[x];
+                }
                 if (!TR && last) { if ((v >> 18) >= (best_word >> 18)) { best_word = v; best_i = i; } }   // olc.py:81 '>=': last row wins
                 else bound_out[i] = v;
             }
@@ -129,11 +134,19 @@ __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows
     return make_int2(best_word, best_i);
 }
 
+template <int C, bool TR, int XM>
+__device__ inline int2 bk_nw_tile_xm(int xm, const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt,
+                                     const int *bi, int *bo, bool last, int bw, int bidx)
+{
+    if (TR || xm == XM) return bk_nw_tile<C, TR, TR ? 0 : XM>(cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if constexpr (!TR && XM + 1 < C) return bk_nw_tile_xm<C, TR, XM + 1>(xm, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    return make_int2(bw, bidx);
+}
 template <int C, bool TR>
 __device__ inline int2 bk_nw_tile_call(int c, const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt,
                                        const int *bi, int *bo, bool last, int bw, int bidx)
 {
-    if (c == C) return bk_nw_tile<C, TR>(cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if (c == C) return bk_nw_tile_xm<C, TR, 0>((mt - 1) % C, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
     if constexpr (C < BK_NW_TILE_C) return bk_nw_tile_call<C + 1, TR>(c, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
     return make_int2(bw, bidx);
 }

@@ -13,3 +13,9 @@ print("kmer kernel ms", eng.kernel_ms(1))
 names = ["P0 ref table", "P1 group reads", "P2 compact", "P3a count", "P3b insert", "P4 sort", "P5 postings"]
 for i in range(7):
     print("%-16s %8.1f us" % (names[i], (st[i + 1] - st[i]) / 100.0))
+
+eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)
+eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)
+print("asm kernel ms", eng.kernel_ms(2))
+acc = [eng.stat(100 + i) / 100.0 for i in range(4)]
+print("asm region 0: outside check_read %.1f us | load_read %.1f | DP %.1f | decide+apply+bookkeeping %.1f" % tuple(acc))
