@@ -184,7 +184,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
             h->h_part.push_back(pd);
             h->h_targets[r].emplace_back(g.partners[q], pd.len); h->max_win = std::max<uint32_t>(h->max_win, pd.len);
         }
-        uint32_t cap = 64; while (cap < 2u * (uint32_t)std::max(g.n_reads, 1)) cap <<= 1;
+        uint32_t cap = 64; while ((uint64_t)cap * 7 < (uint64_t)std::max(g.n_reads, 1) * 10) cap <<= 1;      // load factor <= 0.7 even if every read is unique
         d.dedup_cap = cap; d.dedup_off = dd_total; dd_total += cap;
         // algorithmic HBM bytes per region: 2-bit reads + 4 B/read offsets + window fwd+rc + ~2 KB of output
         uint64_t bases = 0; for (int i = 0; i < g.n_reads; i++) bases += g.read_lens[i];
@@ -196,7 +196,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     const uint32_t wk2 = max_w >= (uint32_t)k ? 2 * (max_w - k + 1) : 0;
     uint32_t ref_cap = 1024; while (ref_cap < 2 * wk2) ref_cap <<= 1;
     h->ref_cap = ref_cap; h->win_words_cap = ((max_w + 15) / 16 + 2 + 3) & ~3u;
-    const size_t lds_k = (32 + 2 * (size_t)h->win_words_cap + ref_cap) * 4;
+    const size_t lds_k = (32 + 256 + 2 * (size_t)h->win_words_cap + ref_cap) * 4;
     if (lds_k > 160 * 1024 || wk2 >= (1u << 18)) return fail(h, BK_E_LIMIT, "bk_submit_regions: reference window too long for the LDS k-mer set (limit ~9.8 kb in this round)");
     if (rlen.empty()) { rlen.push_back(0); rflag.push_back(0); }
     if (reads.empty()) reads.push_back(0);
@@ -252,7 +252,7 @@ static int launch(bk_handle *h, uint32_t mask)
     HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if (mask & BK_STAGE_KMER) {
-        const size_t lds = (32 + 2 * (size_t)h->win_words_cap + h->ref_cap) * 4;
+        const size_t lds = (32 + 256 + 2 * (size_t)h->win_words_cap + h->ref_cap) * 4;
         HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bk_kmer_kernel, dim3(h->n_regions), dim3(BK_KT), lds, h->stream, h->params, h->ref_cap, h->win_words_cap);
         HIPCHK(h, hipGetLastError());

@@ -16,7 +16,7 @@
 #include "bk_common.h"
 #include "bk_nw.hip.h"
 
-#define BK_AT 512            // 8 wavefronts: 4 speculative look-ahead slots x 2 overlap DPs
+#define BK_AT 512            // 8 wavefronts: 4 speculative look-ahead slots x 2 overlap DPs (8 slots / 16 waves: 8 % faster alone, slower with batches in flight)
 #define BK_SPEC 4
 
 enum { BK_ORD_FOR = 0, BK_ORD_REV = 1, BK_ORD_MID = 2 };
@@ -497,6 +497,9 @@ __device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
         }
         BK_SYNC();
         const int nb = S->nb;
+#ifdef BK_PHASE_STAMPS
+        if (BK_TID == 0) { S->acc[4] += nb; S->acc[6] += 1; }
+#endif
         for (int sl = 0; sl < nb; sl++) {                 // unpack the reads; pre-write the bytes slot sl is predicted to add
             const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
             const uint32_t *w = C_.reads + (uint64_t)C_.urep[S->slot[sl].u] * C_.read_words;
@@ -531,6 +534,9 @@ __device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
             }
             const int u = S->slot[sl].u;
             const bool hit = bk_retire(rank, sl, grow);
+#ifdef BK_PHASE_STAMPS
+            if (BK_TID == 0) S->acc[5] += 1;
+#endif
             if (grow && hit && BK_TID == 0) { int pidx = C_.ufound[u]; if (pidx >= 0) { C_.pend[2 * pidx] = BK_EMPTY32; C_.ufound[u] = -1; } }   // buff.remove_contig :638-639
             q++;
             BK_SYNC();

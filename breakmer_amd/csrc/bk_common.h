@@ -55,6 +55,23 @@ __host__ __device__ inline BkKey seq_kmer(const uint32_t *w, int pos, int k) {
     else if (k < 64) key.hi &= ((1ull << (2 * (k - 32))) - 1ull);
     return key;
 }
+// same k-mer, extracted with two funnel shifts instead of a per-base loop; words at index >= nw read as 0
+__host__ __device__ inline BkKey seq_kmer_fast(const uint32_t *w, int nw, int pos, int k) {
+    const int wi = pos >> 4, sh = 2 * (pos & 15);
+    const uint64_t w0 = wi < nw ? w[wi] : 0u, w1 = wi + 1 < nw ? w[wi + 1] : 0u, w2 = wi + 2 < nw ? w[wi + 2] : 0u, w3 = wi + 3 < nw ? w[wi + 3] : 0u;
+    const uint64_t a = (w0 << 32) | w1, b = (w2 << 32) | w3;
+    const uint64_t X0 = sh ? (a << sh) | (b >> (64 - sh)) : a;           // bases pos .. pos+31
+    BkKey key;
+    if (k <= 32) { key.hi = 0; key.lo = X0 >> (64 - 2 * k); }
+    else {
+        const uint64_t c = (wi + 4 < nw ? (uint64_t)w[wi + 4] : 0ull) << 32;
+        const uint64_t X1 = sh ? (b << sh) | (c >> (64 - sh)) : b;       // bases pos+32 .. pos+63
+        const int r = 2 * (k - 32);
+        key.hi = r == 64 ? X0 : X0 >> (64 - r);
+        key.lo = r == 64 ? X1 : (X0 << r) | (X1 >> (64 - r));
+    }
+    return key;
+}
 __host__ __device__ inline bool key_homopolymer(const BkKey &key, int k) {       // len(set(mer)) == 1  (sv_assembly.py:277)
     uint32_t c = (uint32_t)(key.lo & 3u);
     BkKey h; h.hi = 0; h.lo = 0;
@@ -75,7 +92,7 @@ struct BkRegionDesc {
     uint32_t n_reads, read_words;
     uint32_t win_len;
     int32_t n_sc; uint32_t sc_words;
-    uint32_t dedup_cap;          // power of two >= 2*n_reads
+    uint32_t dedup_cap;          // power of two >= n_reads / 0.7
     uint32_t n_partners;
     uint32_t max_len;            // read_len = max cleaned read length (utils.py:240)
 };

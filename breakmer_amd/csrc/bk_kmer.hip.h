@@ -18,9 +18,9 @@ struct BkRefTab {             // LDS-resident reference k-mer set: window forwar
     const uint32_t *win_f, *win_r;   // packed, LDS
     uint32_t *tab;                   // (tag << 18 | idx), LDS
     uint32_t cap_mask; int wk;       // wk = W-k+1 k-mers per strand
-    int k;
+    int k, nww;                      // nww = words of each packed window copy
     __device__ inline BkKey key_at(uint32_t idx) const {
-        return idx < (uint32_t)wk ? seq_kmer(win_f, (int)idx, k) : seq_kmer(win_r, (int)idx - wk, k);
+        return idx < (uint32_t)wk ? seq_kmer_fast(win_f, nww, (int)idx, k) : seq_kmer_fast(win_r, nww, (int)idx - wk, k);
     }
     __device__ inline int find(const BkKey &key) const {
         uint32_t h = key_hash(key), tag = (h >> 18) & 0x3FFFu, i = h & cap_mask;
@@ -66,6 +66,98 @@ __device__ inline void bk_scan_nonref(const uint32_t *w, int len, const BkRefTab
             if (nidx < 0) f(i - k + 1, key);
         }
     }
+}
+
+// Reads up to 256 bp: all packed words are fetched up front with independent loads (a thread that walks its read
+// word by word pays one dependent global-load latency per 16 bases), then the k-mers are rolled out of registers.
+#define BK_RW_MAX 16
+__device__ inline void bk_load_words(const uint32_t *gw, uint32_t nw, uint32_t (&wb)[BK_RW_MAX])
+{
+#pragma unroll
+    for (int t = 0; t < BK_RW_MAX; t++) wb[t] = (uint32_t)t < nw ? gw[t] : 0u;
+}
+// Word-level seed-and-extend: a read that keeps matching the reference on the diagonal of its previous k-mer hit is
+// advanced 16 bases at a time (one funnel-shifted compare against the packed window in LDS); only the stretches
+// that leave the diagonal (sequencing errors, the SV junction) are walked base by base with hash probes.
+template <class F>
+__device__ inline void bk_scan_nonref_regs(const uint32_t (&wb)[BK_RW_MAX], int len, const BkRefTab &rt, F &&f)
+{
+    const int k = rt.k;
+    BkKey key; key.hi = 0; key.lo = 0; int ridx = -1;
+#pragma unroll
+    for (int wi = 0; wi < BK_RW_MAX; wi++) {
+        if (wi * 16 < len) {
+            uint32_t word = wb[wi];
+            const int e = min(16, len - wi * 16);
+            bool fast = false;
+            if (e == 16 && ridx >= 0 && wi * 16 >= k) {
+                const bool fw = ridx < rt.wk; const int loc = fw ? ridx : ridx - rt.wk;
+                if (loc + 16 < rt.wk) {                                    // the 16 next k-mers exist on this strand
+                    const uint32_t *W = fw ? rt.win_f : rt.win_r;
+                    const int off = loc + k, wq = off >> 4, sh = 2 * (off & 15);
+                    const uint32_t v = sh ? (W[wq] << sh) | (W[wq + 1] >> (32 - sh)) : W[wq];
+                    fast = v == word;
+                }
+            }
+            if (fast) {
+                key.hi = (key.hi << 32) | (key.lo >> 32); key.lo = (key.lo << 32) | word;
+                if (k <= 32) { key.hi = 0; if (k < 32) key.lo &= ((1ull << (2 * k)) - 1ull); }
+                else if (k < 64) key.hi &= ((1ull << (2 * (k - 32))) - 1ull);
+                ridx += 16;
+            } else {
+                for (int b = 0; b < e; b++) {
+                    const int i = wi * 16 + b;
+                    uint32_t c = word >> 30; word <<= 2;
+                    key_push(key, c, k);
+                    if (i >= k - 1) {
+                        int nidx = rt.extend(ridx, c);
+                        if (nidx < 0) nidx = rt.find(key);
+                        ridx = nidx;
+                        if (nidx < 0) f(i - k + 1, key);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Phase A of the k-mer passes: is every k-mer of this read a reference k-mer on ONE diagonal?  (true for the
+// bulk of the reads: they simply match the window.)  One hash probe for the first k-mer, then word compares; the
+// first thing that does not fit returns false and the read is left to the full scan above.  Separating the two
+// populations matters on a SIMT machine: in a mixed wavefront every lane pays for the slow path of one lane.
+__device__ inline bool bk_read_is_clean(const uint32_t (&wb)[BK_RW_MAX], int len, const BkRefTab &rt)
+{
+    const int k = rt.k;
+    if (len < k) return true;                               // no k-mers at all
+    BkKey key; key.hi = 0; key.lo = 0; int ridx = -1; bool ok = true;
+#pragma unroll
+    for (int wi = 0; wi < BK_RW_MAX; wi++) {
+        if (ok && wi * 16 < len) {
+            uint32_t word = wb[wi];
+            const int e = min(16, len - wi * 16);
+            bool fast = false;
+            if (e == 16 && ridx >= 0 && wi * 16 >= k) {
+                const bool fw = ridx < rt.wk; const int loc = fw ? ridx : ridx - rt.wk;
+                if (loc + 16 < rt.wk) {
+                    const uint32_t *W = fw ? rt.win_f : rt.win_r;
+                    const int off = loc + k, wq = off >> 4, sh = 2 * (off & 15);
+                    const uint32_t v = sh ? (W[wq] << sh) | (W[wq + 1] >> (32 - sh)) : W[wq];
+                    fast = v == word;
+                }
+            }
+            if (fast) ridx += 16;
+            else {
+                for (int b = 0; b < e && ok; b++) {
+                    const int i = wi * 16 + b;
+                    uint32_t c = word >> 30; word <<= 2;
+                    if (i <= k - 1) key_push(key, c, k);             // the key is only needed for the seed probe
+                    if (i == k - 1) { ridx = rt.find(key); ok = ridx >= 0; }
+                    else if (i > k - 1) { ridx = rt.extend(ridx, c); ok = ridx >= 0; }
+                }
+            }
+        }
+    }
+    return ok;
 }
 
 __device__ inline uint32_t bk_block_sum(uint32_t v, uint32_t *scratch /* >= 17 words */)
@@ -128,7 +220,8 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
     BkRegionWork *wk = &p.work[r];
     const int k = p.k;
     uint32_t *scr = lds;                       // 32 words scratch
-    uint32_t *win_f = lds + 32;
+    uint32_t *stage = lds + 32;                // 16 words per wavefront: the read a wavefront scans cooperatively
+    uint32_t *win_f = lds + 32 + 16 * 16;
     uint32_t *win_r = win_f + win_words_cap;
     uint32_t *tab = win_r + win_words_cap;     // ref_cap words; later reused as sort permutation
 
@@ -152,7 +245,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
         win_r[wi] = x;
     }
     __syncthreads();
-    BkRefTab rt; rt.win_f = win_f; rt.win_r = win_r; rt.tab = tab; rt.cap_mask = ref_cap - 1; rt.wk = WK; rt.k = k;
+    BkRefTab rt; rt.win_f = win_f; rt.win_r = win_r; rt.tab = tab; rt.cap_mask = ref_cap - 1; rt.wk = WK; rt.k = k; rt.nww = (int)win_words_cap;
     for (int i = tid; i < 2 * WK; i += nt) rt.insert((uint32_t)i);
     __syncthreads();
 
@@ -162,30 +255,42 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
     const uint32_t *reads = p.reads + d.reads_word_off;
     const uint16_t *rlen = p.read_len + d.read_meta_off;
     unsigned long long *dslot = p.dd_slot + d.dedup_off;
-    uint32_t *drep = p.dd_rep + d.dedup_off, *dcnt = p.dd_cnt + d.dedup_off, *du = p.dd_u + d.dedup_off;
+    uint32_t *dcnt = p.dd_cnt + d.dedup_off, *du = p.dd_u + d.dedup_off;
     uint32_t *gslot = p.grp_slot + d.read_meta_off;
-    for (uint32_t i = tid; i < d.dedup_cap; i += nt) { dslot[i] = BK_EMPTY64; drep[i] = BK_EMPTY32; dcnt[i] = 0; }
+    for (uint32_t i = tid; i < d.dedup_cap; i += nt) { dslot[i] = BK_EMPTY64; dcnt[i] = 0; }
     __syncthreads();
     const uint32_t dmask = d.dedup_cap - 1;
+    // slot word = (hash tag << 32 | smallest read index seen so far): probing reads it with a plain load, only the
+    // first read of a sequence does a CAS and only a smaller index an atomicMin, so a duplicate costs one atomicAdd
     for (uint32_t i = tid; i < N; i += nt) {
         const uint32_t *w = reads + (uint64_t)i * RW; const uint32_t len = rlen[i], nw = (len + 15) / 16;
+        uint32_t wb[BK_RW_MAX]; bk_load_words(w, min(nw, (uint32_t)BK_RW_MAX), wb);
         uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
-        for (uint32_t t = 0; t < nw; t++) h = mix64(h ^ w[t]) + 0x632BE59BD9B4E019ull;
+        if (nw <= BK_RW_MAX) {
+#pragma unroll
+            for (int t = 0; t < BK_RW_MAX; t++) if ((uint32_t)t < nw) h = mix64(h ^ wb[t]) + 0x632BE59BD9B4E019ull;
+        } else for (uint32_t t = 0; t < nw; t++) h = mix64(h ^ w[t]) + 0x632BE59BD9B4E019ull;
         h = mix64(h);
-        uint32_t tag = (uint32_t)(h >> 32), s = (uint32_t)h & dmask;
+        const uint32_t tag = (uint32_t)(h >> 32); uint32_t s = (uint32_t)h & dmask;
+        const unsigned long long mine = ((unsigned long long)tag << 32) | i;
         for (;;) {
-            unsigned long long mine = ((unsigned long long)tag << 32) | i;
-            unsigned long long cur = atomicCAS(&dslot[s], BK_EMPTY64, mine);
-            if (cur == BK_EMPTY64) break;
+            unsigned long long cur = __atomic_load_n(&dslot[s], __ATOMIC_RELAXED);
+            if (cur == BK_EMPTY64) { cur = atomicCAS(&dslot[s], BK_EMPTY64, mine); if (cur == BK_EMPTY64) break; }
             if ((uint32_t)(cur >> 32) == tag) {
-                uint32_t j = (uint32_t)cur; bool same = rlen[j] == len;
+                const uint32_t j = (uint32_t)cur; bool same = rlen[j] == len;
                 const uint32_t *wj = reads + (uint64_t)j * RW;
-                for (uint32_t t = 0; same && t < nw; t++) same = wj[t] == w[t];
-                if (same) break;
+                if (same) {
+                    if (nw <= BK_RW_MAX) {
+                        uint32_t wo[BK_RW_MAX]; bk_load_words(wj, nw, wo);
+#pragma unroll
+                        for (int t = 0; t < BK_RW_MAX; t++) same = same && wo[t] == wb[t];
+                    } else for (uint32_t t = 0; same && t < nw; t++) same = wj[t] == w[t];
+                }
+                if (same) { if (i < j) atomicMin(&dslot[s], mine); break; }
             }
             s = (s + 1) & dmask;
         }
-        gslot[i] = s; atomicMin(&drep[s], i); atomicAdd(&dcnt[s], 1u);
+        gslot[i] = s; atomicAdd(&dcnt[s], 1u);
     }
     __syncthreads();
     BK_STAMP(2);
@@ -197,23 +302,72 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
     {
         const uint32_t chunk = (N + nt - 1) / nt, b = tid * chunk, e = min(N, b + chunk);
         uint32_t c = 0;
-        for (uint32_t i = b; i < e; i++) c += drep[gslot[i]] == i;
-        uint32_t pre = bk_block_excl_scan(c, scr, &U);
-        for (uint32_t i = b; i < e; i++) if (drep[gslot[i]] == i) {
-            uint32_t s = gslot[i];
-            urep[pre] = i; unr[pre] = dcnt[s]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[s] = pre;
-            p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
-            pre++;
+        if (chunk <= 32) {
+            // all loads of the chunk issued back to back (two dependent rounds instead of 2*chunk)
+            uint32_t g[32]; uint32_t isrep = 0;
+#pragma unroll
+            for (int t = 0; t < 32; t++) g[t] = b + t < e ? gslot[b + t] : 0u;
+#pragma unroll
+            for (int t = 0; t < 32; t++) if (b + t < e && (uint32_t)dslot[g[t]] == b + t) isrep |= 1u << t;
+            c = __popc(isrep);
+            uint32_t pre = bk_block_excl_scan(c, scr, &U);
+#pragma unroll
+            for (int t = 0; t < 32; t++) if (isrep & (1u << t)) {
+                const uint32_t i = b + t, sl = g[t];
+                urep[pre] = i; unr[pre] = dcnt[sl]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[sl] = pre;
+                p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
+                pre++;
+            }
+        } else {
+            for (uint32_t i = b; i < e; i++) c += (uint32_t)dslot[gslot[i]] == i;
+            uint32_t pre = bk_block_excl_scan(c, scr, &U);
+            for (uint32_t i = b; i < e; i++) if ((uint32_t)dslot[gslot[i]] == i) {
+                uint32_t sl = gslot[i];
+                urep[pre] = i; unr[pre] = dcnt[sl]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[sl] = pre;
+                p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
+                pre++;
+            }
         }
     }
     __syncthreads();
     BK_STAMP(3);
     // ---- P3a: count non-reference k-mer occurrences over unique reads ---------------------------
-    uint32_t myc = 0;
+    // phase A: reads that simply match the window are recognised with word compares and dropped; the rest
+    // (sequencing errors, SV junctions) go on a list (grp_slot is free after P2) and get the full scan
+    uint32_t *slow = gslot;
+    if (tid == 0) scr[25] = 0;
+    __syncthreads();
     for (uint32_t u = tid; u < U; u += nt) {
-        uint32_t i = urep[u];
-        bk_scan_nonref(reads + (uint64_t)i * RW, rlen[i], rt, [&](int, const BkKey &) { myc++; });
+        const uint32_t i = urep[u]; const int len = rlen[i];
+        bool clean = false;
+        if (len <= 16 * BK_RW_MAX) { uint32_t wb[BK_RW_MAX]; bk_load_words(reads + (uint64_t)i * RW, (len + 15) / 16, wb); clean = bk_read_is_clean(wb, len, rt); }
+        if (!clean) slow[atomicAdd(&scr[25], 1u)] = u;
     }
+    __syncthreads();
+    const uint32_t nslow = scr[25];
+    BK_STAMP(8);
+    // the remaining reads: one WAVEFRONT per read, one k-mer position per lane (no seed-and-extend, plain probes):
+    // walking them one read per lane serialises the rare expensive events of 64 different reads
+    uint32_t myc = 0;
+    const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
+    uint32_t *wst = stage + wv * 16;
+    for (uint32_t q = wv; q < nslow; q += nwv) {
+        const uint32_t u = slow[q], i = urep[u]; const int len = rlen[i];
+        if (len <= 16 * BK_RW_MAX) {
+            const int nwr = (len + 15) / 16;
+            if (lane < 16) wst[lane] = lane < nwr ? reads[(uint64_t)i * RW + lane] : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            for (int p0 = 0; p0 + k <= len; p0 += 64) {
+                const int pp = p0 + lane;
+                if (pp + k <= len && rt.find(seq_kmer_fast(wst, 16, pp, k)) < 0) myc++;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        } else if (lane == 0) bk_scan_nonref(reads + (uint64_t)i * RW, len, rt, [&](int, const BkKey &) { myc++; });
+    }
+    BK_STAMP(9);
+#ifdef BK_PHASE_STAMPS
+    if (tid == 0) wk->stamps[10] = nslow;
+#endif
     const uint32_t T = bk_block_sum(myc, scr);
     uint32_t tcap = 256; while (tcap < 2 * T) tcap <<= 1;
     BK_STAMP(4);
@@ -228,24 +382,31 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
     for (uint32_t i = tid; i < tcap; i += nt) { tslot[i] = BK_EMPTY32; tcnt[i] = 0; trank[i] = BK_EMPTY32; }
     if (tid == 0) scr[24] = 0;
     __syncthreads();
-    for (uint32_t u = tid; u < U; u += nt) {
-        uint32_t i = urep[u];
-        bk_scan_nonref(reads + (uint64_t)i * RW, rlen[i], rt, [&](int pos, const BkKey &) {
-            uint32_t idx = atomicAdd(&scr[24], 1u);
-            t_ent[idx] = (u << 10) | (uint32_t)pos;
-        });
+    for (uint32_t q = wv; q < nslow; q += nwv) {
+        const uint32_t u = slow[q], i = urep[u]; const int len = rlen[i];
+        auto rec = [&](int pos, const BkKey &) { uint32_t idx = atomicAdd(&scr[24], 1u); t_ent[idx] = (u << 10) | (uint32_t)pos; };
+        if (len <= 16 * BK_RW_MAX) {
+            const int nwr = (len + 15) / 16;
+            if (lane < 16) wst[lane] = lane < nwr ? reads[(uint64_t)i * RW + lane] : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            for (int p0 = 0; p0 + k <= len; p0 += 64) {
+                const int pp = p0 + lane;
+                if (pp + k <= len) { const BkKey key = seq_kmer_fast(wst, 16, pp, k); if (rt.find(key) < 0) rec(pp, key); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        } else if (lane == 0) bk_scan_nonref(reads + (uint64_t)i * RW, len, rt, rec);
     }
     __syncthreads();
     const uint32_t tmask = tcap - 1;
     for (uint32_t idx = tid; idx < T; idx += nt) {
         uint32_t e = t_ent[idx], u = e >> 10, pos = e & 1023u;
-        BkKey key = seq_kmer(reads + (uint64_t)urep[u] * RW, (int)pos, k);
+        BkKey key = seq_kmer_fast(reads + (uint64_t)urep[u] * RW, (int)RW, (int)pos, k);
         uint32_t s = key_hash(key) & tmask;
         for (;;) {
             uint32_t cur = atomicCAS(&tslot[s], BK_EMPTY32, idx);
             if (cur == BK_EMPTY32) break;
             uint32_t e2 = t_ent[cur];
-            if (key_eq(seq_kmer(reads + (uint64_t)urep[e2 >> 10] * RW, (int)(e2 & 1023u), k), key)) break;
+            if (key_eq(seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k), key)) break;
             s = (s + 1) & tmask;
         }
         t_sl[idx] = s; atomicAdd(&tcnt[s], unr[u]);          // case[mer] counts every read (duplicates included)
@@ -261,7 +422,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
                     uint32_t cur = tslot[s];
                     if (cur == BK_EMPTY32) break;
                     uint32_t e2 = t_ent[cur];
-                    if (key_eq(seq_kmer(reads + (uint64_t)urep[e2 >> 10] * RW, (int)(e2 & 1023u), k), key)) { trank[s] = 0; break; }
+                    if (key_eq(seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k), key)) { trank[s] = 0; break; }
                     s = (s + 1) & tmask;
                 }
             });
@@ -296,7 +457,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
     uint32_t *perm = perm_in_lds ? tab : (uint32_t *)(p.arena + o_perm);
     // materialise keys at the provisional index first (keys/count by compaction index in klo/khi/kcnt)
     for (uint32_t i = tid; i < tcap; i += nt) if (tslot[i] < BK_EMPTY32 - 1) {
-        uint32_t e2 = t_ent[tslot[i]]; BkKey key = seq_kmer(reads + (uint64_t)urep[e2 >> 10] * RW, (int)(e2 & 1023u), k);
+        uint32_t e2 = t_ent[tslot[i]]; BkKey key = seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k);
         uint32_t j = trank[i]; klo[j] = key.lo; khi[j] = key.hi; kcnt[j] = tcnt[i]; ptmp[j] = i;      // ptmp: slot of compaction index
     }
     __syncthreads();

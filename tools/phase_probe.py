@@ -17,5 +17,6 @@ for i in range(7):
 eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)
 eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)
 print("asm kernel ms", eng.kernel_ms(2))
+print("rounds %d planned slots %d retired %d" % (eng.stat(106), eng.stat(104), eng.stat(105)))
 acc = [eng.stat(100 + i) / 100.0 for i in range(4)]
 print("asm region 0: outside check_read %.1f us | load_read %.1f | DP %.1f | decide+apply+bookkeeping %.1f" % tuple(acc))
