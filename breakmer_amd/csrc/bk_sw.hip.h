@@ -12,7 +12,7 @@
 #pragma once
 #include "bk_common.h"
 
-#define BK_ST_T 1024
+#define BK_ST_T 512
 #define BK_SW_MIN_SEG 20
 
 struct BkSwShared {
