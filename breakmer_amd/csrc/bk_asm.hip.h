@@ -477,15 +477,21 @@ __device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
         if (S->status) return;
         BK_ACC(0);
         const int nbmax = min(BK_SPEC, n - q);
-        // 1. stage the reads of this round, plan the predictions (thread 0)
+        // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
+        BK_SYNC();
+        if (BK_TID < nbmax) {
+            const uint32_t cu = L_CANDU[q + BK_TID]; const int u = (int)(cu & 0x3FFFFFu);
+            const uint32_t ri = C_.urep[u];
+            BkAsmShared::Slot &t = S->slot[BK_TID];
+            t.u = u; t.pos = (int)(cu >> 22); t.rl = C_.rlen[ri]; t.rn = (int)C_.unr[u]; t.rindel = (C_.ufl[u] & BK_R_INDEL) ? 1 : 0;
+        }
         BK_SYNC();
         if (BK_TID == 0) {
             int pb = S->cbase, plen = S->clen, ppc = S->pc, nb = 0;
             for (int sl = 0; sl < nbmax; sl++) {
-                const uint32_t cu = L_CANDU[q + sl]; const int u = (int)(cu & 0x3FFFFFu), pos = (int)(cu >> 22);
-                const uint32_t ri = C_.urep[u]; const int rl = C_.rlen[ri];
                 BkAsmShared::Slot &t = S->slot[sl];
-                t.u = u; t.rl = rl; t.rn = (int)C_.unr[u]; t.rindel = (C_.ufl[u] & BK_R_INDEL) ? 1 : 0; t.pos = pos; t.pb = pb; t.plen = plen;
+                const int pos = t.pos, rl = t.rl;
+                t.pb = pb; t.plen = plen;
                 nb = sl + 1;
                 const int left = pos - ppc, right = (rl - pos) - (plen - ppc);
                 if (ppc < 0 || (left > 0 && right > 0)) { t.kind = BK_PK_STOP; t.amt = 0; break; }
@@ -517,7 +523,8 @@ __device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
             const int sl = wv >> 1;
             if (sl < nb) {
                 const uint8_t *cs = L_CSEQ + S->slot[sl].pb; const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
-                if ((wv & 1) == 0) { BkNwResult r = bk_nw_wave<false>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
+                // waves w and w+4 land on the same SIMD: give it one direct (heavier) and one transposed sweep
+                if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_wave<false>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
                 else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
             }
         }

@@ -350,6 +350,13 @@ class target(object):                                               # sv_process
     def resolve_sv(self):                                            # :648-665
         if self.native_rows is not None:                             # rows computed by the native tail (csrc/bk_call.h) for the whole batch
             self.results = [list(r) for r in self.native_rows]
+            if self.write_files:                                     # per-contig files (:747-799) are still written
+                by_id = {r[11]: r for r in self.results}
+                for n, kc in enumerate(self.kmers['clusters'], 1):
+                    ctig = contig(self, 'contig' + str(n), kc, [])
+                    ctig.result = by_id.get(self.name + "_contig" + str(n))
+                    if ctig.has_result():
+                        ctig.write_result(self.paths['output'])
             return
         for n, kc in enumerate(self.kmers['clusters'], 1):
             ctig = contig(self, 'contig' + str(n), kc, self.engine.hits(self.region_index, n - 1))

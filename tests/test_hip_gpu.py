@@ -155,6 +155,16 @@ def test_runner_end_to_end_gpu(hb, golden_dir, tmp_path):
         assert sp.runner(cfg2, region_data=data2, native_calls=False).run() == rows, sv
     out = tmp_path / "analysis" / "output"
     assert (out / "synth_indel_svs.out").is_file() and (out / "synth_summary.out").is_file()
+    # N1: per-target and per-contig files of the reference (sv_processor.py:668-683, 747-799), native and Python tail alike
+    for base in (tmp_path, tmp_path / "py"):
+        tdir = base / "analysis" / "targets" / "GENE00003"
+        assert (tdir / "contigs" / "contig1" / "contig1.fa").read_text().startswith(">contig1\n")
+        assert (tdir / "contigs" / "contig1" / "contig1.fq").read_text().count("\n+\n") >= 2
+        assert (tdir / "contigs" / "contig1" / "contig1_svs.out").read_text().split("\t")[6] == "indel"
+        assert (tdir / "kmers" / "GENE00003_sample_kmers_merged.out").read_text().startswith("contig1 ")
+        o = base / "analysis" / "output" / "GENE00003"
+        assert (o / "GENE00003_indel_svs.out").read_text().splitlines()[1].split("\t")[1].endswith("(D200)")
+        assert (o / "contig1_svs.out").is_file()
 
 
 def test_g4_kmer_select_gpu(hb, golden_dir):
