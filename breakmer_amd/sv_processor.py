@@ -9,10 +9,10 @@ write_results`, the same state handed between them (`cleaned_read_recs`, `read_l
 What differs, by design: the reference runs jellyfish / the Python assembler / BLAT once per region;
 here `runner.run` gathers every region first and makes ONE batched call into libbreakmer_hip.so
 (grouping + k-mer selection + assembly + realignment on the GPU), after which `compare_kmers()` and
-`resolve_sv()` of each target only pick up their region's records.  BAM extraction (pysam) and
-adapter trimming (cutadapt) are out of scope: reads enter as the files the
-reference itself writes at that point (`<name>_sv_reads.fastq`, `<name>_sv_sc_seqs.fa`,
-`<name>_forward_refseq.fa`) or as in-memory `RegionData`.
+`resolve_sv()` of each target only pick up their region's records.  Reads enter from `sample_bam_file`
+(read_extraction.py), from the files the reference itself writes at that point (`<name>_sv_reads.fastq`,
+`<name>_sv_sc_seqs.fa`, `<name>_forward_refseq.fa`) or as in-memory `RegionData`; adapter trimming (cutadapt)
+is out of scope.
 """
 from __future__ import annotations
 
@@ -21,7 +21,7 @@ import os
 import shutil
 from collections import OrderedDict
 
-from . import sv_assembly, sv_caller
+from . import read_extraction, samio, sv_assembly, sv_caller
 
 HEADER_FIELDS = ['genes', 'target_breakpoints', 'align_cigar', 'mismatches', 'strands', 'rep_overlap_segment_len', 'sv_type',
                  'split_read_count', 'nkmers', 'disc_read_count', 'breakpoint_coverages', 'contig_id', 'contig_seq']
@@ -111,6 +111,7 @@ class params(object):                                               # utils.py:5
         self.paths = {}
         self.logger = logging.getLogger('root')
         self.repeat_mask = None
+        self._bams = {}
         self.set_params()
 
     def set_params(self):                                            # utils.py:574-618
@@ -152,6 +153,11 @@ class params(object):                                               # utils.py:5
                 if wanted and name.upper() not in wanted:
                     continue
                 self.targets.setdefault(name.upper(), []).append((chrm, int(bp1), int(bp2), name, p[4] if len(p) > 4 else None))
+
+    def open_bam(self, fn):                                          # one parse per alignment file, shared by all targets
+        if fn not in self._bams:
+            self._bams[fn] = samio.Samfile(fn)
+        return self._bams[fn]
 
     def get_kmer_size(self): return int(self.opts['kmer_size'])
     def get_min_segment_length(self, kind): return int(self.opts[kind + '_minseg_len'])
@@ -307,7 +313,23 @@ class target(object):                                               # sv_process
             c = str(self.chrom).replace('chr', '')
             self.repeat_mask = [m for m in self.params.repeat_mask.get(c, []) if m[1] >= self.start and m[2] <= self.end]      # utils.py:334-339
 
-    def extract_bam_reads(self):                                     # :422-540 (reads arrive extracted)
+    def extract_bam_reads(self):                                     # :422-540
+        bam_fn = self.params.opts.get('sample_bam_file')
+        if self.data is None and bam_fn and os.path.isfile(bam_fn):
+            # N2: select the evidence reads from the alignment file itself (read_extraction.py, pinned by G6)
+            bam = self.params.open_bam(bam_fn)
+            self.sv_reads, fq_text, fa_text, disc = read_extraction.extract_reads(bam, self.chrom, self.start, self.end,
+                                                                                  self.params.get_kmer_size())
+            d = self.paths.get('data')
+            if d:
+                self.files['sv_fq'] = os.path.join(d, self.name + "_sv_reads.fastq")
+                self.files['sv_sc_unmapped_fa'] = os.path.join(d, self.name + "_sv_sc_seqs.fa")
+                with open(self.files['sv_fq'], 'w') as f: f.write(fq_text)
+                with open(self.files['sv_sc_unmapped_fa'], 'w') as f: f.write(fa_text)
+            recs, _rl = read_extraction.get_fastq_reads(fq_text, self.sv_reads)      # clean_reads' filter (utils.py:203-246)
+            sc = [ln for ln in fa_text.split("\n") if ln and not ln.startswith(">")]
+            self.data = RegionData([x[0] for x in recs], [x[1] for x in recs], [x[3] for x in recs], sc, self._window,
+                                   disc_reads=disc, quals=[x[2] for x in recs])
         if self.data is None:
             d = self.paths.get('data', '')
             fq = os.path.join(d, self.name + "_sv_reads.fastq")

@@ -179,3 +179,98 @@ def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int =
         disc["disc"][pchrom] = [(gpos + c - 100 - i, pstart + c + 100 + i) for i in range(npairs)]
     r.disc_reads = disc
     return r
+
+
+def make_sam(r: Region, n_pairs: int = 200, L: int = 100, global_seed: int = 1, frag: int = 260) -> str:
+    """SAM text of a toy aligner's view of read pairs drawn from `r.donor` (input of the read-extraction step,
+    sv_processor.py:422-540): reads crossing the junction are soft-clipped on their shorter side, a few pairs
+    overlap, have an unmapped mate, are duplicates / QC failures, carry low-quality tails, or are discordant.
+    Only del / ins regions (collinear donor) are mapped; coordinates are 1-based in the text."""
+    assert r.sv_type in ("del", "ins")
+    W = len(r.window)
+    c, h = W // 2, r.sv_size // 2
+    gpos = r.start - 200
+    chrom = r.chrom                                  # BED / BAM names without "chr" (sv_caller.py:917,1124)
+    other = "%d" % (1 + (int(r.chrom) + 4) % 22)
+    key = stream_key(global_seed, r.region_id, 11)
+    u = rand_u64(key, n_pairs * 4).reshape(n_pairs, 4)
+    D = len(r.donor)
+
+    def to_ref(d):                                   # donor offset -> window offset of the base to its right
+        if r.sv_type == "del":
+            return d if d < c - h else d + 2 * h
+        return d if d < c else (c if d < c + r.sv_size else d - r.sv_size)
+
+    junctions = [c - h] if r.sv_type == "del" else [c, c + r.sv_size]
+
+    def place(d0):
+        """(pos0, cigar text) of donor[d0:d0+L]"""
+        for jn in junctions:
+            b = jn - d0
+            if 0 < b < L:
+                if r.sv_type == "del":
+                    return (gpos + to_ref(d0), "%dM%dS" % (b, L - b)) if b >= L - b else (gpos + to_ref(jn), "%dS%dM" % (b, L - b))
+                if jn == c:                          # read runs from reference into the inserted bases
+                    return gpos + to_ref(d0), "%dM%dS" % (b, L - b)
+                return gpos + c, "%dS%dM" % (b, L - b)
+        if r.sv_type == "ins" and c <= d0 and d0 + L <= c + r.sv_size:
+            return None, "*"
+        return gpos + to_ref(d0), "%dM" % L
+
+    out = ["@HD\tVN:1.0\tSO:unsorted", "@SQ\tSN:%s\tLN:250000000" % chrom, "@SQ\tSN:%s\tLN:250000000" % other]
+    for i in range(n_pairs):
+        kind = int(u[i, 1] % np.uint64(16))
+        fl = frag if kind != 1 else L + 30 + int(u[i, 2] % np.uint64(40))        # kind 1: overlapping pair
+        if kind == 7:
+            fl = L - 10                                                         # read-through (adapter) pair
+        span = max(fl, L)
+        # two thirds of the pairs sit near a junction
+        if int(u[i, 0] % np.uint64(3)) < 2:
+            d1 = junctions[0] - L + 5 + int((u[i, 0] >> np.uint64(8)) % np.uint64(L + span - 10)) - (span - L)
+            d1 = min(max(d1, 0), D - span)
+        else:
+            d1 = int((u[i, 0] >> np.uint64(8)) % np.uint64(D - span + 1))
+        d2 = d1 + span - L
+        s1, s2 = codes_to_str(r.donor[d1:d1 + L]), codes_to_str(r.donor[d2:d2 + L])
+        q1 = q2 = "I" * L
+        if kind == 2:
+            q1 = "I" * (L - 12) + "#" * 12
+        if kind == 3:
+            q2 = "#" * 9 + "I" * (L - 9)
+        if kind == 8:
+            q1 = "#" * L
+        (p1, c1), (p2, c2) = place(d1), place(d2)
+        name = "S:1:1:%d:%d" % (r.region_id, i)
+        f1, f2 = 99, 147
+        if int(u[i, 3] & np.uint64(1)):              # read 1 on the reverse strand: it is the rightmost read
+            f1, f2 = 83, 163
+            (p1, c1, s1, q1), (p2, c2, s2, q2) = (p2, c2, s2, q2), (p1, c1, s1, q1)
+        if p1 is None or p2 is None:
+            continue
+        t = (max(p1, p2) + L) - min(p1, p2)
+        t1 = t if p1 <= p2 and f1 == 99 else -t
+        if kind == 4:
+            f1 |= 0x400; f2 |= 0x400
+        if kind == 5:
+            f2 |= 0x200
+        mq1 = mq2 = 60
+        ch1 = ch2 = chrom
+        if kind == 6:                                # mate unmapped: read 2 is stored at read 1's position
+            f1, f2 = 73, 133
+            out.append("\t".join([name, str(f1), chrom, str(p1 + 1), "60", c1, "=", str(p1 + 1), "0", s1, q1]))
+            out.append("\t".join([name, str(f2), chrom, str(p1 + 1), "0", "*", "=", str(p1 + 1), "0", s2, q2]))
+            continue
+        if kind == 9:                                # mate on another chromosome
+            f1 &= ~2; f2 &= ~2
+            out.append("\t".join([name, str(f1), chrom, str(p1 + 1), "60", c1, other, str(5000 + i), "0", s1, q1]))
+            out.append("\t".join([name, str(f2), other, str(5000 + i), "37", "%dM" % L, chrom, str(p1 + 1), "0", s2, q2]))
+            continue
+        if kind == 10:                               # same-strand pair (inversion evidence)
+            f1, f2 = 65 | 0x0, 129
+        if kind == 11:                               # everted pair (tandem-duplication evidence)
+            f1, f2 = (81, 161) if p1 < p2 else (97, 145)
+        if kind == 12:
+            mq1 = 0
+        out.append("\t".join([name, str(f1), ch1, str(p1 + 1), str(mq1), c1, "=", str(p2 + 1), str(t1), s1, q1]))
+        out.append("\t".join([name, str(f2), ch2, str(p2 + 1), str(mq2), c2, "=", str(p1 + 1), str(-t1), s2, q2]))
+    return "\n".join(out) + "\n"

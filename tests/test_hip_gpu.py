@@ -167,6 +167,21 @@ def test_runner_end_to_end_gpu(hb, golden_dir, tmp_path):
         assert (o / "contig1_svs.out").is_file()
 
 
+def test_runner_from_alignment_file_gpu(hb, tmp_path):
+    """N2 -> hot path -> call on the GPU: reads selected from a SAM file (read_extraction.py, pinned by G6), both k=15
+    (the reference's default config) and both call tails."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_pipeline import check_sam_run, make_sam_inputs
+    from breakmer_amd import sv_processor as sp
+    cfg, r = make_sam_inputs(tmp_path)
+    rows = sp.runner(cfg).run()
+    check_sam_run(rows, r, tmp_path)
+    (tmp_path / "py").mkdir()
+    cfg2, r2 = make_sam_inputs(tmp_path / "py")
+    assert sp.runner(cfg2, native_calls=False).run() == rows
+
+
 def test_g4_kmer_select_gpu(hb, golden_dir):
     """K1/K2 incl. a separate soft-clip set (case_sc) on the GPU == the reference's set algebra (G4)."""
     d = _load(golden_dir, "kmer_select.json")

@@ -103,3 +103,37 @@ def test_two_rank_collation_gloo(tmp_path):
         assert rows == want, rank
         assert len(names) == 4
     assert len(want) >= 3
+
+
+def make_sam_inputs(tmp_path, rid=3, sv="del", size=120, n_pairs=400):
+    """Config whose reads come from an alignment file (N2): SAM text + the reference-window FASTA."""
+    r = synth.make_region(rid, W=1200, L=100, depth=5, sv_type=sv, sv_size=size)
+    (tmp_path / "targets.bed").write_text("\t".join([r.chrom, str(r.start), str(r.end), r.name, "exon"]) + "\n")
+    (tmp_path / "genes.txt").write_text("header\n" + "\t".join(["0", r.name, "chr" + r.chrom, "+", str(r.start), str(r.end)] + ["x"] * 6 + [r.name]) + "\n")
+    (tmp_path / "sample.sam").write_text(synth.make_sam(r, n_pairs))
+    ref = tmp_path / "ref" / r.name
+    ref.mkdir(parents=True)
+    (ref / (r.name + "_forward_refseq.fa")).write_text(">w\n" + r.window_str + "\n")
+    cfg = {"analysis_name": "fromsam", "targets_bed_file": str(tmp_path / "targets.bed"), "analysis_dir": str(tmp_path / "analysis"),
+           "reference_data_dir": str(tmp_path / "ref"), "gene_annotation_file": str(tmp_path / "genes.txt"), "kmer_size": "15",
+           "keep_repeat_regions": True, "sample_bam_file": str(tmp_path / "sample.sam")}
+    return cfg, r
+
+
+def check_sam_run(rows, r, tmp_path):
+    assert len(rows) >= 1
+    c = len(r.window) // 2
+    gpos = r.start - 200
+    bps = rows[0][1]
+    assert rows[0][6] == "indel" and rows[0][0] == r.name
+    lo = gpos + c - r.sv_size // 2
+    assert bps == "chr%s:%d-%d (D%d)" % (r.chrom, lo + 1, lo + 1 + r.sv_size, r.sv_size), bps
+    d = tmp_path / "analysis" / "targets" / r.name / "data"
+    assert (d / (r.name + "_sv_reads.fastq")).stat().st_size > 0 and (d / (r.name + "_sv_sc_seqs.fa")).stat().st_size > 0
+
+
+def test_runner_from_alignment_file(tmp_path):
+    cfg, r = make_sam_inputs(tmp_path)
+    run = sp.runner(cfg, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+    rows = run.run()
+    check_sam_run(rows, r, tmp_path)

@@ -1,0 +1,90 @@
+"""N2: read extraction + get_fastq_reads restatement against fixtures generated from the real
+reference (tools/make_golden.py g6), plus the SAM/BAM reader itself.  CPU only."""
+import gzip
+import hashlib
+import json
+import os
+import struct
+
+import pytest
+
+from breakmer_amd import read_extraction as rx
+from breakmer_amd import samio, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "read_extraction.json")
+CASES = json.load(open(GOLD))["cases"]
+
+
+def _sam_for(case, tmp_path):
+    r = synth.make_region(**{k: v for k, v in case["region"].items()})
+    sam = synth.make_sam(r, case["n_pairs"])
+    assert hashlib.sha1(sam.encode()).hexdigest() == case["sam_sha1"], "generator drifted from the fixture"
+    fn = tmp_path / (case["tag"] + ".sam")
+    fn.write_text(sam)
+    return r, str(fn)
+
+
+def _tuples(x):
+    return json.loads(json.dumps(x))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["tag"] for c in CASES])
+def test_extraction_matches_reference(case, tmp_path):
+    r, fn = _sam_for(case, tmp_path)
+    exp = case["expected"]
+    sv, fq, fa, disc = rx.extract_reads(samio.Samfile(fn), r.chrom, r.start, r.end, case["kmer"])
+    assert list(sv) == exp["sv_order"]
+    assert fq == exp["fastq"]
+    assert fa == exp["sc_fasta"]
+    assert _tuples(disc) == exp["disc_reads"]
+    for q, (rd, sc, cc, io) in sv.items():
+        e = exp["sv_reads"][q]
+        assert hashlib.sha1(rd.seq.encode()).hexdigest()[:10] == e[0] and sc == e[1] and cc == e[2] and io == e[3], q
+    for variant in ("as_extracted", "trimmed"):
+        e = exp[variant]
+        recs, read_len = rx.get_fastq_reads(e["cleaned"] if e["cleaned"] is not None else fq, sv)
+        assert [x[0] for x in recs] == e["kept"], variant
+        assert read_len == e["read_len"]
+        assert [bool(x[3]) for x in recs] == e["indel_only"]
+
+
+def _bam_bytes(refs, reads):
+    out = [b"BAM\x01", struct.pack("<i", 0), struct.pack("<i", len(refs))]
+    for n in refs:
+        out += [struct.pack("<i", len(n) + 1), n.encode() + b"\0", struct.pack("<i", 250000000)]
+    for r in reads:
+        cig = r.cigar or []
+        seq = r.seq
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            packed[i >> 1] |= "=ACMGRSVTWYHKDBN".index(ch) << (4 if i % 2 == 0 else 0)
+        body = struct.pack("<iiBBHHHiiii", r.tid, r.pos, len(r.qname) + 1, r.mapq, 0, len(cig), r.flag, len(seq), r.rnext, r.pnext, r.tlen)
+        body += r.qname.encode() + b"\0" + b"".join(struct.pack("<I", ln << 4 | op) for op, ln in cig) + bytes(packed)
+        body += bytes(ord(c) - 33 for c in r.qual)
+        out += [struct.pack("<i", len(body)), body]
+    return b"".join(out)
+
+
+def test_bam_reader_equals_sam_reader(tmp_path):
+    case = CASES[0]
+    r, fn = _sam_for(case, tmp_path)
+    s = samio.Samfile(fn)
+    raw = _bam_bytes(s.references, s.reads)
+    bfn = tmp_path / "x.bam"
+    half = len(raw) // 2                              # two gzip members, like BGZF blocks
+    with open(bfn, "wb") as f:
+        f.write(gzip.compress(raw[:half]) + gzip.compress(raw[half:]))
+    b = samio.Samfile(str(bfn))
+    assert b.references == s.references and len(b.reads) == len(s.reads)
+    for x, y in zip(b.reads, s.reads):
+        assert (x.qname, x.flag, x.tid, x.pos, x.mapq, x.cigar, x.rnext, x.pnext, x.tlen, x.seq, x.qual) == \
+               (y.qname, y.flag, y.tid, y.pos, y.mapq, y.cigar, y.rnext, y.pnext, y.tlen, y.seq, y.qual)
+    a1 = rx.extract_reads(b, r.chrom, r.start, r.end, case["kmer"])
+    assert a1[1] == case["expected"]["fastq"]
+
+
+def test_trim_helpers():
+    assert rx.trim_coords("###III##", 3) == (3, 6, 3)
+    assert rx.trim_coords("####", 3) == (0, 0, 0)
+    assert samio.parse_cigar("5S90M2D5M") == [(4, 5), (0, 90), (2, 2), (0, 5)]
+    assert samio.parse_cigar("*") is None

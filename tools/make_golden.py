@@ -2,7 +2,7 @@
 oracle/ref_loader.py).  Runs only in the build container; the fixtures (data: inputs or
 generator parameters + expected outputs) are committed, the reference never travels.
 
-  PYTHONHASHSEED=0 python tools/make_golden.py [g1 g2 g3 g4 g5]
+  PYTHONHASHSEED=0 python tools/make_golden.py [g1 g2 g3 g4 g5 g6]
 """
 import hashlib
 import json
@@ -285,10 +285,81 @@ def g5():
     dump("caller.json", {"cases": cases})
 
 
+def toy_cutadapt(fq_text, sv_reads_clips):
+    """Deterministic stand-in for the adapter-trimming step between extraction and get_fastq_reads: every 5th
+    record loses 18 bases at its 3' end, every 7th loses its leading soft-clip exactly (when it has one)."""
+    lines = fq_text.split("\n")
+    out = []
+    for n, i in enumerate(range(0, len(lines) - 3, 4)):
+        h, s, q = lines[i], lines[i + 1], lines[i + 3]
+        clips = sv_reads_clips.get("_".join(h.lstrip("@").split("_")[:-1]))
+        if n % 7 == 3 and clips and clips[0] and s.startswith(clips[0]):
+            s, q = s[len(clips[0]):], q[len(clips[0]):]
+        elif n % 5 == 2:
+            s, q = s[:-18], q[:-18]
+        out += [h, s, "+", q]
+    return "\n".join(out) + "\n"
+
+
+def g6():
+    """N2: read extraction (sv_processor.py:12-93,422-583) and get_fastq_reads (utils.py:203-246) of the real
+    reference, fed by breakmer_amd.samio records through a patched `Samfile`."""
+    import logging
+    import tempfile
+    import types
+    from breakmer_amd import samio
+    mods = ref_loader.load()
+    sp, ut = mods["sv_processor"], mods["utils"]
+    cases = []
+    tmp = tempfile.mkdtemp()
+    for tag, rid, svt, size, npairs, k in [("del120", 3, "del", 120, 180, 15), ("ins60", 5, "ins", 60, 180, 15),
+                                           ("del40_k31", 8, "del", 40, 200, 31)]:
+        r = synth.make_region(rid, W=1200, L=100, depth=5, sv_type=svt, sv_size=size)
+        sam = synth.make_sam(r, npairs)
+        fn = os.path.join(tmp, tag + ".sam")
+        open(fn, "w").write(sam)
+
+        class Writer(object):
+            def write(self, _r): pass
+            def close(self): pass
+        sp.Samfile = lambda path, mode="rb", **kw: samio.Samfile(path) if mode == "rb" else Writer()
+        sp.sort = sp.index = lambda *a, **kw: None
+        T = sp.target
+        me = types.SimpleNamespace()
+        me.params = types.SimpleNamespace(opts={"sample_bam_file": fn}, get_kmer_size=lambda: k)
+        me.paths = {"data": tmp}
+        me.files = {}
+        me.name = tag
+        me.chrom, me.start, me.end = r.chrom, r.start, r.end
+        me.logger = logging.getLogger("g6")
+        for meth in ("setup_read_extraction_files", "check_pair_overlap", "check_overlap"):
+            setattr(me, meth, types.MethodType(getattr(T, meth), me))
+        T.extract_bam_reads(me)
+        fq = open(me.files["sv_fq"]).read()
+        fa = open(me.files["sv_sc_unmapped_fa"]).read()
+        clips = {q: (v[1]["clipped"] if v[1] else None) for q, v in me.sv_reads.items()}
+        sv_meta = {q: [hashlib.sha1(v[0].seq.encode()).hexdigest()[:10], v[1], v[2], bool(v[3])] for q, v in me.sv_reads.items()}
+        exp = {"fastq": fq, "sc_fasta": fa, "disc_reads": me.disc_reads, "sv_reads": sv_meta, "sv_order": list(me.sv_reads)}
+        for variant, text in (("as_extracted", fq), ("trimmed", toy_cutadapt(fq, clips))):
+            cfn = os.path.join(tmp, tag + "_" + variant + ".fastq")
+            open(cfn, "w").write(text)
+            _ffn, fq_recs, read_len = ut.get_fastq_reads(cfn, me.sv_reads)
+            kept = [ln for ln in open(_ffn).read().split("\n")[0::4] if ln]
+            flags = {}
+            for seq, lst in fq_recs.items():
+                for fr in lst:
+                    flags[fr.id] = bool(fr.indel_only)
+            exp[variant] = {"cleaned": text if variant == "trimmed" else None, "kept": kept, "read_len": read_len, "indel_only": [flags[h] for h in kept]}
+        cases.append({"tag": tag, "region": {"region_id": rid, "W": 1200, "L": 100, "depth": 5, "sv_type": svt, "sv_size": size},
+                      "n_pairs": npairs, "kmer": k, "sam_sha1": hashlib.sha1(sam.encode()).hexdigest(), "expected": exp})
+        print(tag, len(me.sv_reads), fq.count("\n") // 4, [len(exp[v]["kept"]) for v in ("as_extracted", "trimmed")])
+    dump("read_extraction.json", {"cases": cases})
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     for w in which:
         print(w)
         globals()[w]()
