@@ -47,6 +47,7 @@ struct bk_handle {
     DevBuf d_arena, d_out, d_tops;
     uint64_t arena_cap = 0, out_cap = 0;
     uint32_t ref_cap = 0, win_words_cap = 0;
+    int n_big = 0; uint64_t big_bytes = 0;      // regions whose window needs the global-memory k-mer set
     // host mirrors
     std::vector<BkRegionDesc> h_desc; std::vector<BkRegionWork> h_work; HostVec h_out;
     std::vector<BkPartnerDesc> h_part;
@@ -192,12 +193,23 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     }
     h->total_reads = rlen.size(); h->n_regions = n_regions;
     { uint32_t mx = 0; for (auto &d : h->h_desc) mx = std::max(mx, d.max_len); h->eff_max_read = (int)std::min<uint32_t>((uint32_t)h->cfg.max_read_len, std::max<uint32_t>(64, (mx + 63) / 64 * 64)); }
-    // reference k-mer table geometry (LDS): load factor <= 0.5
-    const uint32_t wk2 = max_w >= (uint32_t)k ? 2 * (max_w - k + 1) : 0;
-    uint32_t ref_cap = 1024; while (ref_cap < 2 * wk2) ref_cap <<= 1;
-    h->ref_cap = ref_cap; h->win_words_cap = ((max_w + 15) / 16 + 2 + 3) & ~3u;
-    const size_t lds_k = (32 + 256 + 2 * (size_t)h->win_words_cap + ref_cap) * 4;
-    if (lds_k > 160 * 1024 || wk2 >= (1u << 18)) return fail(h, BK_E_LIMIT, "bk_submit_regions: reference window too long for the LDS k-mer set (limit ~9.8 kb in this round)");
+    // reference k-mer table geometry (LDS): load factor <= 0.5.  Windows beyond the LDS budget (whole-gene targets)
+    // are flagged `big` and go through bk_kmer_kernel_g (table in the scratch arena).
+    auto lds_need = [&](uint32_t w, uint32_t &cap, uint32_t &words) {
+        const uint32_t wk2 = w >= (uint32_t)k ? 2 * (w - k + 1) : 0;
+        cap = 1024; while (cap < 2 * wk2) cap <<= 1;
+        words = ((w + 15) / 16 + 2 + 3) & ~3u;
+        return wk2 < (1u << 18) ? (32 + 256 + 2 * (size_t)words + cap) * 4 : (size_t)1 << 30;
+    };
+    uint32_t max_small = 0; h->n_big = 0; uint64_t big_bytes = 0;
+    for (auto &d : h->h_desc) {
+        uint32_t cap, words;
+        d.big = lds_need(d.win_len, cap, words) > 160 * 1024 ? 1u : 0u; d.pad_ = 0;
+        if (d.big) { h->n_big++; uint64_t gc = 1024; while (gc < 4ull * d.win_len) gc <<= 1; big_bytes += gc * 8 + d.win_len / 4 + 4096; if (d.win_len >= (1u << 28)) return fail(h, BK_E_LIMIT, "bk_submit_regions: reference window longer than 256 Mb"); }
+        else max_small = std::max(max_small, d.win_len);
+    }
+    { uint32_t cap, words; lds_need(max_small, cap, words); h->ref_cap = cap; h->win_words_cap = words; }
+    h->big_bytes = big_bytes;
     if (rlen.empty()) { rlen.push_back(0); rflag.push_back(0); }
     if (reads.empty()) reads.push_back(0);
     if (sc.empty()) sc.push_back(0);
@@ -215,6 +227,9 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     if (h->arena_cap == 0) {
         uint64_t want = h->cfg.arena_bytes > 0 ? (uint64_t)h->cfg.arena_bytes : std::max<uint64_t>(64ull << 20, (uint64_t)n_regions * (1ull << 20) + h->total_reads * 64ull);
         h->arena_cap = want;
+    }
+    if (h->arena_cap < h->big_bytes + (64ull << 20) && h->big_bytes) {
+        h->arena_cap = h->big_bytes + std::max<uint64_t>(64ull << 20, (uint64_t)n_regions * (1ull << 20) + h->total_reads * 64ull);
     }
     if (h->out_cap == 0) h->out_cap = std::max<uint64_t>(8ull << 20, (uint64_t)n_regions * (64ull << 10));
     HIPCHK(h, h->d_arena.ensure(h->arena_cap)); HIPCHK(h, h->d_out.ensure(h->out_cap));
@@ -252,10 +267,18 @@ static int launch(bk_handle *h, uint32_t mask)
     HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if (mask & BK_STAGE_KMER) {
-        const size_t lds = (32 + 256 + 2 * (size_t)h->win_words_cap + h->ref_cap) * 4;
-        HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bk_kmer_kernel, dim3(h->n_regions), dim3(BK_KT), lds, h->stream, h->params, h->ref_cap, h->win_words_cap);
-        HIPCHK(h, hipGetLastError());
+        if (h->n_big < h->n_regions) {
+            const size_t lds = (32 + 256 + 2 * (size_t)h->win_words_cap + h->ref_cap) * 4;
+            HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(bk_kmer_kernel, dim3(h->n_regions), dim3(BK_KT), lds, h->stream, h->params, h->ref_cap, h->win_words_cap);
+            HIPCHK(h, hipGetLastError());
+        }
+        if (h->n_big > 0) {
+            const size_t lds = (32 + 256 + (size_t)BK_K_PERM_G) * 4;
+            HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(bk_kmer_kernel_g, dim3(h->n_regions), dim3(BK_KT), lds, h->stream, h->params);
+            HIPCHK(h, hipGetLastError());
+        }
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if (mask & BK_STAGE_ASSEMBLE) {
@@ -266,10 +289,11 @@ static int launch(bk_handle *h, uint32_t mask)
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if (mask & BK_STAGE_REALIGN) {
-        const size_t lds = ((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + h->max_win + 16;
-        if (lds > 160 * 1024) return fail(h, BK_E_LIMIT, "realign: windows too long for LDS staging in this round");
+        // target staging buffer: the whole window when it is short, else chunks of diagonals (>= 2 * max_contig bases)
+        const uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)h->cfg.max_contig_len + 16, std::max<uint32_t>(32768, 4 * (uint32_t)h->cfg.max_contig_len));
+        const size_t lds = ((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + tw_cap + 16;
         HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bk_sw_kernel, dim3(h->n_regions), dim3(BK_ST_T), lds, h->stream, h->params, h->max_win);
+        hipLaunchKernelGGL(bk_sw_kernel, dim3(h->n_regions), dim3(BK_ST_T), lds, h->stream, h->params, tw_cap);
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));

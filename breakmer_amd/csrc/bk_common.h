@@ -95,6 +95,8 @@ struct BkRegionDesc {
     uint32_t dedup_cap;          // power of two >= n_reads / 0.7
     uint32_t n_partners;
     uint32_t max_len;            // read_len = max cleaned read length (utils.py:240)
+    uint32_t big;                // window does not fit the LDS k-mer set: handled by bk_kmer_kernel_g
+    uint32_t pad_;
 };
 struct BkPartnerDesc { uint64_t word_off; uint32_t len, pad; };
 

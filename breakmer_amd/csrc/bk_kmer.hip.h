@@ -10,34 +10,49 @@
 // Bound: HBM streaming of the packed reads (one pass for grouping, one per k-mer pass over the
 // unique reads; the re-reads hit L2/MALL).  No MFMA: integer/byte work.
 #pragma once
+#include <type_traits>
 #include "bk_common.h"
 
 #define BK_KT 512             // threads per workgroup (8 waves): small enough to co-reside with assembler workgroups of other batches
 
-struct BkRefTab {             // LDS-resident reference k-mer set: window forward + reverse complement
-    const uint32_t *win_f, *win_r;   // packed, LDS
-    uint32_t *tab;                   // (tag << 18 | idx), LDS
+// Reference k-mer set: window forward + reverse complement.  GLB = false: packed windows and table in LDS, entries
+// (tag:14 | idx:18); GLB = true (windows that do not fit the LDS, e.g. whole-gene targets): windows and table in
+// global memory (scratch arena), entries (tag:32 | idx:32).
+template <bool GLB>
+struct BkRefTabT {
+    typedef typename std::conditional<GLB, unsigned long long, uint32_t>::type E;
+    const uint32_t *win_f, *win_r;   // packed
+    E *tab;
     uint32_t cap_mask; int wk;       // wk = W-k+1 k-mers per strand
     int k, nww;                      // nww = words of each packed window copy
+    static constexpr E EMPTY = (E)~(E)0;
     __device__ inline BkKey key_at(uint32_t idx) const {
         return idx < (uint32_t)wk ? seq_kmer_fast(win_f, nww, (int)idx, k) : seq_kmer_fast(win_r, nww, (int)idx - wk, k);
     }
+    __device__ static inline void split(const BkKey &key, uint32_t cap_mask, uint32_t &slot, uint32_t &tag) {
+        if constexpr (GLB) { const uint64_t h = mix64(key.lo ^ (key.hi * 0x9E3779B97F4A7C15ull)); slot = (uint32_t)(h >> 20) & cap_mask; tag = (uint32_t)(h >> 32) ^ (uint32_t)h; }
+        else { const uint32_t h = key_hash(key); slot = h & cap_mask; tag = (h >> 18) & 0x3FFFu; }
+    }
+    __device__ static inline E pack(uint32_t tag, uint32_t idx) { if constexpr (GLB) return ((E)tag << 32) | idx; else return (tag << 18) | idx; }
+    __device__ static inline uint32_t e_tag(E e) { if constexpr (GLB) return (uint32_t)(e >> 32); else return e >> 18; }
+    __device__ static inline uint32_t e_idx(E e) { if constexpr (GLB) return (uint32_t)e; else return e & 0x3FFFFu; }
     __device__ inline int find(const BkKey &key) const {
-        uint32_t h = key_hash(key), tag = (h >> 18) & 0x3FFFu, i = h & cap_mask;
+        uint32_t i, tag; split(key, cap_mask, i, tag);
         for (;;) {
-            uint32_t e = tab[i];
-            if (e == BK_EMPTY32) return -1;
-            if ((e >> 18) == tag) { uint32_t idx = e & 0x3FFFFu; if (key_eq(key_at(idx), key)) return (int)idx; }
+            const E e = tab[i];
+            if (e == EMPTY) return -1;
+            if (e_tag(e) == tag) { const uint32_t idx = e_idx(e); if (key_eq(key_at(idx), key)) return (int)idx; }
             i = (i + 1) & cap_mask;
         }
     }
     __device__ inline void insert(uint32_t idx) {
-        BkKey key = key_at(idx);
-        uint32_t h = key_hash(key), tag = (h >> 18) & 0x3FFFu, i = h & cap_mask, mine = (tag << 18) | idx;
+        const BkKey key = key_at(idx);
+        uint32_t i, tag; split(key, cap_mask, i, tag);
+        const E mine = pack(tag, idx);
         for (;;) {
-            uint32_t e = atomicCAS(&tab[i], BK_EMPTY32, mine);
-            if (e == BK_EMPTY32) return;
-            if ((e >> 18) == tag && key_eq(key_at(e & 0x3FFFFu), key)) return;   // duplicate k-mer
+            const E e = atomicCAS(&tab[i], EMPTY, mine);
+            if (e == EMPTY) return;
+            if (e_tag(e) == tag && key_eq(key_at(e_idx(e)), key)) return;   // duplicate k-mer
             i = (i + 1) & cap_mask;
         }
     }
@@ -50,8 +65,8 @@ struct BkRefTab {             // LDS-resident reference k-mer set: window forwar
 };
 
 // walk one packed sequence, call f(pos, key) for every k-mer that is NOT a reference k-mer
-template <class F>
-__device__ inline void bk_scan_nonref(const uint32_t *w, int len, const BkRefTab &rt, F &&f)
+template <class RT, class F>
+__device__ inline void bk_scan_nonref(const uint32_t *w, int len, const RT &rt, F &&f)
 {
     const int k = rt.k;
     BkKey key; key.hi = 0; key.lo = 0; int ridx = -1; uint32_t word = 0;
@@ -79,8 +94,8 @@ __device__ inline void bk_load_words(const uint32_t *gw, uint32_t nw, uint32_t (
 // Word-level seed-and-extend: a read that keeps matching the reference on the diagonal of its previous k-mer hit is
 // advanced 16 bases at a time (one funnel-shifted compare against the packed window in LDS); only the stretches
 // that leave the diagonal (sequencing errors, the SV junction) are walked base by base with hash probes.
-template <class F>
-__device__ inline void bk_scan_nonref_regs(const uint32_t (&wb)[BK_RW_MAX], int len, const BkRefTab &rt, F &&f)
+template <class RT, class F>
+__device__ inline void bk_scan_nonref_regs(const uint32_t (&wb)[BK_RW_MAX], int len, const RT &rt, F &&f)
 {
     const int k = rt.k;
     BkKey key; key.hi = 0; key.lo = 0; int ridx = -1;
@@ -125,7 +140,8 @@ __device__ inline void bk_scan_nonref_regs(const uint32_t (&wb)[BK_RW_MAX], int 
 // bulk of the reads: they simply match the window.)  One hash probe for the first k-mer, then word compares; the
 // first thing that does not fit returns false and the read is left to the full scan above.  Separating the two
 // populations matters on a SIMT machine: in a mixed wavefront every lane pays for the slow path of one lane.
-__device__ inline bool bk_read_is_clean(const uint32_t (&wb)[BK_RW_MAX], int len, const BkRefTab &rt)
+template <class RT>
+__device__ inline bool bk_read_is_clean(const uint32_t (&wb)[BK_RW_MAX], int len, const RT &rt)
 {
     const int k = rt.k;
     if (len < k) return true;                               // no k-mers at all
@@ -212,40 +228,64 @@ __device__ inline bool bk_kmer_before(uint32_t ca, const BkKey &ka, uint32_t cb,
 #define BK_STAMP(i) do { } while (0)
 #endif
 
-extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, uint32_t ref_cap, uint32_t win_words_cap)
+#define BK_K_PERM_G 16384      // words of LDS sort permutation in the global-table variant
+
+// GLB = false: regions whose window fits the LDS (d.big == 0); GLB = true: the others.  Both kernels are launched
+// over all regions and return at once for regions of the other kind.
+template <bool GLB>
+__device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_t win_words_cap, uint32_t *lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const BkRegionDesc d = p.desc[r];
+    if ((d.big != 0) != GLB) return;
     BkRegionWork *wk = &p.work[r];
     const int k = p.k;
     uint32_t *scr = lds;                       // 32 words scratch
     uint32_t *stage = lds + 32;                // 16 words per wavefront: the read a wavefront scans cooperatively
-    uint32_t *win_f = lds + 32 + 16 * 16;
-    uint32_t *win_r = win_f + win_words_cap;
-    uint32_t *tab = win_r + win_words_cap;     // ref_cap words; later reused as sort permutation
 
     if (tid == 0) { wk->status = BK_ST_OK; wk->U = 0; wk->T = 0; wk->M = 0; wk->tcap = 0; wk->n_contigs = 0; wk->nw_cells = 0; wk->nw_calls = 0; wk->sw_cells = 0; wk->o_first_contig = 0; wk->o_last_contig = 0; }
     const int W = (int)d.win_len, WK = W >= k ? W - k + 1 : 0;
-    if ((uint32_t)(2 * WK) * 2u > ref_cap || (uint32_t)((W + 15) / 16 + 2) > win_words_cap || 2 * WK >= (1 << 18)) {
-        if (tid == 0) wk->status = BK_ST_WINDOW;
-        return;
-    }
-    BK_STAMP(0);
-    // ---- P0: reference k-mer set in LDS (sv_processor.py:613-615: forward and reverse file) -------
     const uint32_t *gw = p.windows + d.win_word_off;
     const int ww = (W + 15) / 16;
-    for (int i = tid; i < (int)win_words_cap; i += nt) { win_f[i] = i < ww ? gw[i] : 0u; win_r[i] = 0u; }
-    for (uint32_t i = tid; i < ref_cap; i += nt) tab[i] = BK_EMPTY32;
-    __syncthreads();
-    // reverse complement, packed: base j of rc = 3 - base (W-1-j) of forward
-    for (int wi = tid; wi < ww; wi += nt) {
-        uint32_t x = 0;
-        for (int t = 0; t < 16; t++) { int j = wi * 16 + t; uint32_t c = j < W ? 3u - seq_base(win_f, W - 1 - j) : 0u; x = (x << 2) | c; }
-        win_r[wi] = x;
+    BK_STAMP(0);
+    // ---- P0: reference k-mer set (sv_processor.py:613-615: forward and reverse file) -------------
+    BkRefTabT<GLB> rt; rt.cap_mask = 0; rt.wk = WK; rt.k = k;
+    uint32_t *perm_lds; uint32_t perm_cap;
+    if constexpr (!GLB) {
+        uint32_t *win_f = lds + 32 + 16 * 16;
+        uint32_t *win_r = win_f + win_words_cap;
+        uint32_t *tab = win_r + win_words_cap;     // ref_cap words; later reused as sort permutation
+        if ((uint32_t)(2 * WK) * 2u > ref_cap || (uint32_t)(ww + 2) > win_words_cap || 2 * WK >= (1 << 18)) {
+            if (tid == 0) wk->status = BK_ST_WINDOW;
+            return;
+        }
+        for (int i = tid; i < (int)win_words_cap; i += nt) { win_f[i] = i < ww ? gw[i] : 0u; win_r[i] = 0u; }
+        for (uint32_t i = tid; i < ref_cap; i += nt) tab[i] = BK_EMPTY32;
+        rt.win_f = win_f; rt.win_r = win_r; rt.tab = tab; rt.cap_mask = ref_cap - 1; rt.nww = (int)win_words_cap;
+        perm_lds = tab; perm_cap = ref_cap;
+    } else {
+        uint32_t gcap = 1024; while (gcap < 4u * (uint32_t)WK && gcap < (1u << 30)) gcap <<= 1;     // load factor <= 0.5
+        const uint64_t o_wr = bk_arena_alloc(p, (uint64_t)(ww + 2) * 4 + 256 + (uint64_t)gcap * 8, scr + 20);
+        if (o_wr == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
+        if ((uint64_t)4 * WK > gcap) { if (tid == 0) wk->status = BK_ST_WINDOW; return; }
+        uint32_t *win_r = (uint32_t *)(p.arena + o_wr);
+        unsigned long long *tab = (unsigned long long *)(p.arena + bk_align_up(o_wr + (uint64_t)(ww + 2) * 4, 256));
+        for (uint32_t i = tid; i < gcap; i += nt) tab[i] = ~0ull;
+        if (tid < 2) win_r[ww + tid] = 0u;
+        rt.win_f = gw; rt.win_r = win_r; rt.tab = tab; rt.cap_mask = gcap - 1; rt.nww = ww + 2;     // the host pads every packed window with 2 zero words
+        perm_lds = lds + 32 + 16 * 16; perm_cap = BK_K_PERM_G;
     }
     __syncthreads();
-    BkRefTab rt; rt.win_f = win_f; rt.win_r = win_r; rt.tab = tab; rt.cap_mask = ref_cap - 1; rt.wk = WK; rt.k = k; rt.nww = (int)win_words_cap;
+    // reverse complement, packed: base j of rc = 3 - base (W-1-j) of forward
+    {
+        uint32_t *win_r = const_cast<uint32_t *>(rt.win_r);
+        for (int wi = tid; wi < ww; wi += nt) {
+            uint32_t x = 0;
+            for (int t = 0; t < 16; t++) { int j = wi * 16 + t; uint32_t c = j < W ? 3u - seq_base(rt.win_f, W - 1 - j) : 0u; x = (x << 2) | c; }
+            win_r[wi] = x;
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < 2 * WK; i += nt) rt.insert((uint32_t)i);
     __syncthreads();
 
@@ -442,7 +482,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
         for (uint32_t i = b; i < e; i++) if (tslot[i] < BK_EMPTY32 - 1) trank[i] = pre++;    // provisional rank = compaction index
     }
     uint32_t npad = 1; while (npad < M) npad <<= 1;
-    const bool perm_in_lds = npad <= ref_cap;                  // else the permutation is sorted in global memory (slow path)
+    const bool perm_in_lds = npad <= perm_cap;                 // else the permutation is sorted in global memory (slow path)
     const uint64_t b2 = (uint64_t)M * (8 + 8 + 4 + 1 + 12 + 4 + 4) + (uint64_t)T * 4 + 4096 + (perm_in_lds ? 0 : (uint64_t)npad * 4);
     uint64_t a1 = bk_arena_alloc(p, b2, scr + 20);
     if (a1 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
@@ -454,7 +494,7 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
     int32_t *kstamp = (int32_t *)(p.arena + o_kstamp);
     uint8_t *kstate = (uint8_t *)(p.arena + o_kstate);
     // permutation sort: perm in LDS (reusing the reference table) when it fits, else in ptmp/global
-    uint32_t *perm = perm_in_lds ? tab : (uint32_t *)(p.arena + o_perm);
+    uint32_t *perm = perm_in_lds ? perm_lds : (uint32_t *)(p.arena + o_perm);
     // materialise keys at the provisional index first (keys/count by compaction index in klo/khi/kcnt)
     for (uint32_t i = tid; i < tcap; i += nt) if (tslot[i] < BK_EMPTY32 - 1) {
         uint32_t e2 = t_ent[tslot[i]]; BkKey key = seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k);
@@ -520,4 +560,16 @@ extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, u
         wk->o_key_lo = o_klo; wk->o_key_hi = o_khi; wk->o_kcnt = o_kcnt; wk->o_kstate = o_kstate; wk->o_kstamp = o_kstamp;
         wk->o_poff = o_poff; wk->o_post = o_post;
     }
+}
+
+extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, uint32_t ref_cap, uint32_t win_words_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    bk_kmer_body<false>(p, ref_cap, win_words_cap, lds);
+}
+// regions with a window beyond the LDS budget: reference set in global memory (LDS: scratch + BK_K_PERM_G words)
+extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel_g(BkParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    bk_kmer_body<true>(p, 0, 0, lds);
 }

@@ -25,13 +25,14 @@ struct BkSwShared {
     int status;
 };
 
-__device__ inline unsigned long long bk_sw_key(int score, int tidx, int strand, int a, int b)
+__device__ inline unsigned long long bk_sw_key(int score, int tidx, int strand, int a, long long b)
 {   // larger key wins: score desc, target index asc, '+' first, smallest query end, smallest target end
-    return ((unsigned long long)score << 40) | ((unsigned long long)(15 - tidx) << 36) | ((unsigned long long)(1 - strand) << 35) |
-           ((unsigned long long)(0x1FFF - a) << 20) | (unsigned long long)(0xFFFFF - b);
+    // [score:13 | 15-tidx:4 | 1-strand:1 | 0x1FFF-a:13 | 0x1FFFFFFFF-b:33]
+    return ((unsigned long long)score << 51) | ((unsigned long long)(15 - tidx) << 47) | ((unsigned long long)(1 - strand) << 46) |
+           ((unsigned long long)(0x1FFF - a) << 33) | (unsigned long long)(0x1FFFFFFFFll - b);
 }
 
-extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, uint32_t max_win)
+extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, uint32_t tw_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sl[];
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -63,20 +64,25 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                 const uint32_t *gw; int m;
                 if (ti == 0) { gw = p.windows + d.win_word_off; m = (int)d.win_len; }
                 else { const BkPartnerDesc pd = p.partners[d.part_desc_off + ti - 1]; gw = p.windows + pd.word_off; m = (int)pd.len; }
-                if (m > (int)max_win) { if (tid == 0) S->status = BK_ST_WINDOW; m = 0; }
-                __syncthreads();
-                for (int i = tid; i < m; i += BK_ST_T) tw[i] = (uint8_t)seq_base(gw, i);
-                __syncthreads();
-                const int nd = n + m - 1;                               // diagonals: b - a = dd - (n - 1)
-                for (int D = tid; D < 2 * nd; D += BK_ST_T) {
-                    const int st = D >= nd, dd = st ? D - nd : D, off = dd - (n - 1);
-                    const uint8_t *q = st ? qr + (Q - qe) : qf + qs;
-                    int a = off < 0 ? -off : 0, b = a + off;            // first cell of the diagonal (0-based)
-                    int h = 0, run = 0;
-                    for (; a < n && b < m; a++, b++) {
-                        h += (q[a] == tw[b]) ? 1 : -2; run++;
-                        if (h <= 0) { h = 0; run = 0; }
-                        else { unsigned long long key = bk_sw_key(h, ti, st, a + 1, b + 1); if (key > bkey) { bkey = key; brun = run; } }
+                // diagonals off = b - a in [-(n-1), m-1] are independent: they are processed in chunks whose target
+                // bases [o0, o0 + CH + n - 1) fit the staging buffer (one chunk when the window is short)
+                const int CH = (int)tw_cap - n;
+                for (int o0 = -(n - 1); o0 < m; o0 += CH) {
+                    const int o1 = min(o0 + CH, m), t0 = max(o0, 0), t1 = min(m, o1 - 1 + n);
+                    __syncthreads();
+                    for (int i = t0 + tid; i < t1; i += BK_ST_T) tw[i - t0] = (uint8_t)seq_base(gw, i);
+                    __syncthreads();
+                    const int nd = o1 - o0;
+                    for (int D = tid; D < 2 * nd; D += BK_ST_T) {
+                        const int st = D >= nd, off = o0 + (st ? D - nd : D);
+                        const uint8_t *q = st ? qr + (Q - qe) : qf + qs;
+                        int a = off < 0 ? -off : 0, b = a + off;            // first cell of the diagonal (0-based)
+                        int h = 0, run = 0;
+                        for (; a < n && b < m; a++, b++) {
+                            h += (q[a] == tw[b - t0]) ? 1 : -2; run++;
+                            if (h <= 0) { h = 0; run = 0; }
+                            else { unsigned long long key = bk_sw_key(h, ti, st, a + 1, b + 1); if (key > bkey) { bkey = key; brun = run; } }
+                        }
                     }
                 }
                 if (tid == 0) S->cells += 2ull * (unsigned long long)n * (unsigned long long)m;
@@ -88,9 +94,9 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
             __syncthreads();
             if (tid == 0) {
                 for (int w = 0; w < BK_ST_T / 64; w++) if (S->red[w] > S->best_key) { S->best_key = S->red[w]; S->best_run = S->red_run[w]; }
-                const unsigned long long key = S->best_key; const int score = (int)(key >> 40);
+                const unsigned long long key = S->best_key; const int score = (int)(key >> 51);
                 if (score >= p.sw_min_score) {
-                    const int tidx = 15 - (int)((key >> 36) & 15), st = 1 - (int)((key >> 35) & 1), a1 = 0x1FFF - (int)((key >> 20) & 0x1FFF), b1 = 0xFFFFF - (int)(key & 0xFFFFF), run = S->best_run;
+                    const int tidx = 15 - (int)((key >> 47) & 15), st = 1 - (int)((key >> 46) & 1), a1 = 0x1FFF - (int)((key >> 33) & 0x1FFF), b1 = (int)(0x1FFFFFFFFll - (long long)(key & 0x1FFFFFFFFull)), run = S->best_run;
                     const int offq = st ? Q - qe : qs;
                     BkHit hgt; hgt.qs = offq + a1 - run; hgt.qe = offq + a1; hgt.ts = b1 - run; hgt.te = b1; hgt.strand = st; hgt.tidx = tidx; hgt.score = score;
                     const int fs = st ? Q - hgt.qe : hgt.qs, fe = st ? Q - hgt.qs : hgt.qe;

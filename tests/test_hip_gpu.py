@@ -228,8 +228,11 @@ def test_edge_cases_gpu(hb):
         hb.Engine(kmer_size=31).submit([hb.RegionInput(["ACGTN" * 10], w)])           # non-ACGT base
     with pytest.raises(hb.BreakmerHipError):
         hb.Engine(kmer_size=31).submit([hb.RegionInput(["A" * 2000], w)])             # read longer than max_read_len
-    with pytest.raises(hb.BreakmerHipError):
-        hb.Engine(kmer_size=31).submit([hb.RegionInput([w[:150]], "ACGT" * 5000)])    # window too long for the LDS k-mer set
+    e5 = hb.Engine(kmer_size=31)                                                      # 20 kb window of a 4-mer repeat: global-memory k-mer set
+    e5.submit([hb.RegionInput([w[:150]], "ACGT" * 5000)])
+    e5.run(hb.BK_STAGE_ALL)
+    want5, info5 = bo.assemble_region([w[:150]], ["ACGT" * 5000], 31, 2)
+    assert sorted(e5.kmers(0)[0]) == sorted(info5["mers"]) and _strip(e5.contigs(0)) == want5
     with pytest.raises(hb.BreakmerHipError):
         hb.Engine(kmer_size=99)
 
@@ -249,6 +252,39 @@ def test_config4_config5_shapes_gpu(hb):
         want, info = bo.assemble_region(r.read_strs(), [r.window_str], 41, 2)
         assert eng.kmers(i)[0] == [m for m, _ in sorted(zip(info["mers"], info["counts"].tolist()), key=lambda x: (x[1], x[0]), reverse=True)]
         assert _strip(eng.contigs(i)) == want, ("cfg5", i)
+
+
+def test_large_windows_gpu(hb):
+    """Whole-gene windows: beyond the LDS k-mer set (40 kb, 303 kb -> bk_kmer_kernel_g) and beyond the realigner's
+    staging buffer (chunked diagonals), mixed in one batch with an ordinary region and a 120 kb partner window."""
+    import numpy as np
+    from oracle import bk_oracle as bo
+
+    def widen(r, flank, salt):
+        fl = synth.rand_bases(synth.stream_key(7, r.region_id, salt), 2 * flank)
+        r.window = np.concatenate([fl[:flank], r.window, fl[flank:]]).astype(np.uint8)
+        return r
+    regions = [synth.make_region(600, sv_type="del", depth=60, W=3000),
+               widen(synth.make_region(601, sv_type="ins", depth=60, W=3000), 18500, 0),
+               widen(synth.make_region(602, sv_type="del", depth=60, W=3000, noise=0.01), 150000, 0),
+               widen(synth.make_region(603, sv_type="inv", depth=60, W=3000), 40000, 0)]
+    t = synth.make_region(604, sv_type="trl", depth=60, W=3000)
+    pc, ps, pe, pn, pw = t.partners[0]
+    fl = synth.rand_bases(synth.stream_key(7, 604, 1), 117000)
+    t.partners[0] = (pc, ps, pe, pn, np.concatenate([fl[:60000], pw, fl[60000:]]).astype(np.uint8))
+    regions.append(t)
+    eng = _run_regions(hb, regions, 31, stages=7)
+    nrec = 0
+    for i, r in enumerate(regions):
+        targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        want, info = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
+        assert eng.kmers(i)[0] == [m for m, _ in sorted(zip(info["mers"], info["counts"].tolist()), key=lambda x: (x[1], x[0]), reverse=True)], i
+        assert _strip(eng.contigs(i)) == want, i
+        for ci, c in enumerate(eng.contigs(i)):
+            got = eng.hits(i, ci)
+            assert got == bo.realign(c["seq"], targets), (i, ci)
+            nrec += len(got)
+    assert nrec >= 5
 
 
 def test_arena_growth_and_rerun_gpu(hb):
