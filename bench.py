@@ -18,6 +18,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The steps in flight live on separate HIP streams.  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4); once RCCL has created its own streams the default leaves the library's streams sharing queues and the
+# batches serialise (measured: 86 k -> 61 k regions/s).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -36,6 +40,7 @@ def parse():
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--cpu-sample", type=int, default=24, help="regions timed through the CPU oracle (0 = skip)")
     ap.add_argument("--inflight", type=int, default=3, help="steps in flight (independent batches on separate HIP streams)")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (testing)")
     return ap.parse_args()
 
 
@@ -59,7 +64,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    dist = world > 1 or a.force_dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -98,17 +103,47 @@ def main():
         last_rows.clear()
         last_rows.update(rows)
         blob = np.frombuffer("\n".join("%d\t%s" % (r, "\t".join(x)) for r in sorted(rows) for x in rows[r]).encode(), dtype=np.uint8)
-        if dist:                                       # collate variable-length records: sizes, then padded all-gather (RCCL)
-            n = torch.tensor([blob.size], device="cuda", dtype=torch.int64)
-            sizes = [torch.zeros_like(n) for _ in range(world)]
-            td.all_gather(sizes, n)
-            mx = int(max(int(s.item()) for s in sizes))
-            buf = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-            buf[:blob.size] = torch.from_numpy(blob.copy()).cuda()
-            out = [torch.empty_like(buf) for _ in range(world)]
-            td.all_gather(out, buf)
-            return sum(int(s.item()) for s in sizes)
+        if dist:                                       # collate the variable-length records of all ranks (RCCL all-gather)
+            gather(blob)
         return blob.size
+
+    # Collation buffers: [8-byte length | records] per rank, fixed capacity, two slots so that the all-gather of step s
+    # overlaps the kernels of step s+1 (the records are only consumed after the run).  The general two-phase
+    # (sizes, then padded payload) exchange of the product path is breakmer_amd/collate.py.
+    CAP = 1 << 20
+    slots = []
+    if dist:
+        for _ in range(2):
+            slots.append({"host": torch.zeros(CAP, dtype=torch.uint8).pin_memory(), "dev": torch.zeros(CAP, dtype=torch.uint8, device="cuda"),
+                          "out": torch.zeros(world * CAP, dtype=torch.uint8, device="cuda"), "work": None})
+    gstate = {"n": 0, "collated": 0}
+
+    def gather(blob):
+        sl = slots[gstate["n"] % 2]
+        gstate["n"] += 1
+        if sl["work"] is not None:
+            sl["work"].wait()
+        if blob.size + 8 > CAP:
+            raise RuntimeError("collation record larger than %d bytes" % CAP)
+        hv = sl["host"].numpy()
+        hv[:8] = np.frombuffer(np.int64(blob.size).tobytes(), dtype=np.uint8)
+        hv[8:8 + blob.size] = blob
+        sl["dev"][:8 + blob.size].copy_(sl["host"][:8 + blob.size], non_blocking=True)
+        sl["work"] = td.all_gather_into_tensor(sl["out"], sl["dev"], async_op=True)
+
+    def drain():
+        """wait for the outstanding all-gathers; returns the bytes collated by the last one (all ranks)"""
+        tot = 0
+        for sl in slots:
+            if sl["work"] is not None:
+                sl["work"].wait()
+                sl["work"] = None
+        if slots and gstate["n"]:
+            sl = slots[(gstate["n"] - 1) % 2]
+            heads = sl["out"].view(world, CAP)[:, :8].contiguous().cpu().numpy()
+            tot = int(sum(int(np.frombuffer(heads[r].tobytes(), dtype=np.int64)[0]) for r in range(world)))
+        gstate["collated"] = tot
+        return tot
 
     def barrier():
         torch.cuda.synchronize()
@@ -132,6 +167,7 @@ def main():
             finish()
             for j in range(3):
                 acc[j] += x.kernel_ms(j + 1)
+        drain()
         return acc
 
     run_steps(a.warmup)
@@ -188,6 +224,7 @@ def main():
                        "stages": "group reads + k-mer select + assemble (olc.nw) + realign on the GPU, SV-call tail in host C++, rows collated",
                        "sv_calls_per_step": sum(len(v) for v in last_rows.values()),
                        "steps_in_flight": len(engs),
+                       "collated_bytes_per_step": gstate["collated"] if dist else None,
                        "parallelism": "regions sharded per GPU, all-gather of result records"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
