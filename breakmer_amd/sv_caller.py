@@ -12,7 +12,8 @@ Reference semantics followed (file:line under the reference tree):
 Quirks kept on purpose: Q10 (Python-2 round), Q11, Q13 (tandem-dup support is always 0), Q14.
 Records come either from a PSL text file (`query_res_fn`, 21 tab-separated columns, no header) or
 directly as lists of the same 21 fields (`psl_records`) as produced by `records_from_hits`.
-No BAM is opened: breakpoint coverages are 0 unless `meta_dict['coverage_fn']` is supplied.
+Breakpoint coverages come from `meta_dict['coverage_fn']` (sv_processor supplies one over the alignment file when
+`sample_bam_file` is set; 0 otherwise).
 """
 from __future__ import annotations
 
@@ -291,6 +292,30 @@ class blat_res(object):                                             # sv_caller.
 
 
 # --------------------------------------------------------------------------- event = one or more records
+def brkpt_coverages(tbp, coverage_fn):
+    """sv_event.get_brkpt_coverages (sv_caller.py:99-133): one count per breakpoint position of the
+    `target_breakpoints` field; coverage_fn(chrom_without_chr, start, end) -> reads (None: 0)."""
+    if "(" in tbp:
+        tbp = tbp.split()[0]
+    pts = []
+    for bp in tbp.split(','):
+        chrom, locs = bp.split(':')
+        chrom = chrom.replace('chr', '')
+        ll = locs.split('-')
+        pts.append((chrom, int(ll[0]), int(ll[0]) + 1))
+        if len(ll) > 1:
+            pts.append((chrom, int(ll[1]), int(ll[1]) + 1))
+    return ",".join(str(int(coverage_fn(c, s, e)) if coverage_fn else 0) for c, s, e in pts)
+
+
+def bam_coverage_fn(bam):
+    """The read filter of sv_caller.py:121-126 over `samio.Samfile.fetch`."""
+    def cov(chrom, start, end):
+        return sum(1 for r in bam.fetch(str(chrom), start, end)
+                   if not (r.is_duplicate or r.is_qcfail or r.is_unmapped or r.mapq < 10))
+    return cov
+
+
 class sv_event(object):                                             # sv_caller.py:13-517
     def __init__(self, br, query_region, contig_vals, sample_bam, coverage_fn=None):
         self.blat_res = []
@@ -348,20 +373,8 @@ class sv_event(object):                                             # sv_caller.
             self.result_values['sv_type'] += '_' + self.result_values['sv_subtype']
         return self.get_values()
 
-    def get_brkpt_coverages(self):                                   # :99-133 (BAM read replaced by coverage_fn, default 0)
-        tbp = self.result_values['target_breakpoints']
-        if "(" in tbp:
-            tbp = tbp.split()[0]
-        pts = []
-        for bp in tbp.split(','):
-            chrom, locs = bp.split(':')
-            chrom = chrom.replace('chr', '')
-            ll = locs.split('-')
-            pts.append((chrom, int(ll[0]), int(ll[0]) + 1))
-            if len(ll) > 1:
-                pts.append((chrom, int(ll[1]), int(ll[1]) + 1))
-        covs = [int(self.coverage_fn(c, s, e)) if self.coverage_fn else 0 for c, s, e in pts]
-        return ",".join(str(x) for x in covs)
+    def get_brkpt_coverages(self):                                   # :99-133
+        return brkpt_coverages(self.result_values['target_breakpoints'], self.coverage_fn)
 
     def get_values(self):                                            # :137-146
         row = []

@@ -318,6 +318,7 @@ class target(object):                                               # sv_process
         if self.data is None and bam_fn and os.path.isfile(bam_fn):
             # N2: select the evidence reads from the alignment file itself (read_extraction.py, pinned by G6)
             bam = self.params.open_bam(bam_fn)
+            self.coverage_fn = sv_caller.bam_coverage_fn(bam)       # sv_caller.py:99-133
             self.sv_reads, fq_text, fa_text, disc = read_extraction.extract_reads(bam, self.chrom, self.start, self.end,
                                                                                   self.params.get_kmer_size())
             d = self.paths.get('data')
@@ -372,6 +373,9 @@ class target(object):                                               # sv_process
     def resolve_sv(self):                                            # :648-665
         if self.native_rows is not None:                             # rows computed by the native tail (csrc/bk_call.h) for the whole batch
             self.results = [list(r) for r in self.native_rows]
+            if self.coverage_fn is not None:                         # the native tail has no alignment file: field 10 is filled here
+                for r in self.results:
+                    r[10] = sv_caller.brkpt_coverages(r[1], self.coverage_fn)
             if self.write_files:                                     # per-contig files (:747-799) are still written
                 by_id = {r[11]: r for r in self.results}
                 for n, kc in enumerate(self.kmers['clusters'], 1):

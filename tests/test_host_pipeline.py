@@ -128,6 +128,8 @@ def check_sam_run(rows, r, tmp_path):
     assert rows[0][6] == "indel" and rows[0][0] == r.name
     lo = gpos + c - r.sv_size // 2
     assert bps == "chr%s:%d-%d (D%d)" % (r.chrom, lo + 1, lo + 1 + r.sv_size, r.sv_size), bps
+    cov = [int(x) for x in rows[0][10].split(",")]
+    assert len(cov) == 2 and max(cov) > 0, rows[0][10]                # breakpoint coverages from the alignment file
     d = tmp_path / "analysis" / "targets" / r.name / "data"
     assert (d / (r.name + "_sv_reads.fastq")).stat().st_size > 0 and (d / (r.name + "_sv_sc_seqs.fa")).stat().st_size > 0
 

@@ -40,6 +40,10 @@ def test_extraction_matches_reference(case, tmp_path):
     for q, (rd, sc, cc, io) in sv.items():
         e = exp["sv_reads"][q]
         assert hashlib.sha1(rd.seq.encode()).hexdigest()[:10] == e[0] and sc == e[1] and cc == e[2] and io == e[3], q
+    from breakmer_amd import sv_caller
+    cf = sv_caller.bam_coverage_fn(samio.Samfile(fn))
+    for tbp, want in exp["brkpt_coverages"].items():
+        assert sv_caller.brkpt_coverages(tbp, cf) == want, tbp
     for variant in ("as_extracted", "trimmed"):
         e = exp[variant]
         recs, read_len = rx.get_fastq_reads(e["cleaned"] if e["cleaned"] is not None else fq, sv)

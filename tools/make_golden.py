@@ -350,6 +350,16 @@ def g6():
                 for fr in lst:
                     flags[fr.id] = bool(fr.indel_only)
             exp[variant] = {"cleaned": text if variant == "trimmed" else None, "kept": kept, "read_len": read_len, "indel_only": [flags[h] for h in kept]}
+        # sv_event.get_brkpt_coverages (sv_caller.py:99-133) on the same alignment file
+        sc = mods["sv_caller"]
+        sc.Samfile = sp.Samfile
+        c0 = r.start - 200 + len(r.window) // 2
+        cov = {}
+        for tbp in ["chr%s:%d-%d (D120)" % (r.chrom, c0 - 60, c0 + 60), "chr%s:%d" % (r.chrom, c0), "chr%s:%d,chr%s:%d-%d" % (r.chrom, c0 - 300, r.chrom, c0 + 5, c0 + 400),
+                    "chr%s:%d" % (r.chrom, r.start - 5000), "chr%d:%d" % (1 + (int(r.chrom) + 4) % 22, 5010)]:
+            ev = types.SimpleNamespace(result_values={"target_breakpoints": tbp}, sample_bam=fn)
+            cov[tbp] = sc.sv_event.get_brkpt_coverages(ev)
+        exp["brkpt_coverages"] = cov
         cases.append({"tag": tag, "region": {"region_id": rid, "W": 1200, "L": 100, "depth": 5, "sv_type": svt, "sv_size": size},
                       "n_pairs": npairs, "kmer": k, "sam_sha1": hashlib.sha1(sam.encode()).hexdigest(), "expected": exp})
         print(tag, len(me.sv_reads), fq.count("\n") // 4, [len(exp[v]["kept"]) for v in ("as_extracted", "trimmed")])
