@@ -287,6 +287,42 @@ def test_large_windows_gpu(hb):
     assert nrec >= 5
 
 
+def test_full_size_config2_properties_gpu(hb):
+    """BASELINE.json configs[1] at full size (256 regions x 10,000 x 150 bp, k=31) through size-independent
+    properties: (1) every region yields the planted call -- one contig spanning the junction, chained into one PSL
+    record with a single 200 bp target gap at the planted position; (2) a second run on the same handle is identical;
+    (3) results do not depend on the position of a region in the batch (reversed submission order); (4) a sample
+    equals the oracle."""
+    from oracle import bk_oracle as bo
+    n = 256
+    regions = [synth.make_region(i) for i in range(n)]
+    eng = _run_regions(hb, regions, 31, stages=7)
+    first = []
+    for i, r in enumerate(regions):
+        cs = eng.contigs(i)
+        assert len(cs) == 1, i
+        hs = eng.hits(i, 0)
+        assert len(hs) == 1, i
+        h = hs[0]
+        c = len(r.window) // 2
+        assert h["t_num_insert"] == 1 and h["t_base_insert"] == 200 and h["q_num_insert"] == 0 and h["mismatches"] <= 4, (i, h)
+        assert h["matches"] + h["mismatches"] == len(cs[0]["seq"]) and len(h["block_sizes"]) == 2, (i, h)
+        # the gap may slide over the micro-homology (or a chance near-match) at the junction, never further
+        end0 = h["t_starts"][0] + h["block_sizes"][0]
+        assert abs(end0 - (c - 100)) <= 12 and h["t_starts"][1] - end0 == 200, (i, h)
+        first.append((cs, hs, eng.kmers(i)[0]))
+    eng.run(7)
+    for i in (0, 17, 255):
+        assert (eng.contigs(i), eng.hits(i, 0), eng.kmers(i)[0]) == first[i], i
+    rev = _run_regions(hb, regions[::-1], 31, stages=7)
+    for i in range(n):
+        assert (rev.contigs(n - 1 - i), rev.hits(n - 1 - i, 0), rev.kmers(n - 1 - i)[0]) == first[i], i
+    for i in (3, 200):
+        want, _ = bo.assemble_region(regions[i].read_strs(), [regions[i].window_str], 31, 2)
+        assert _strip(first[i][0]) == want, i
+        assert first[i][1] == bo.realign(want[0]["seq"], [regions[i].window_str]), i
+
+
 def test_arena_growth_and_rerun_gpu(hb):
     """A deliberately tiny scratch arena: the library must notice the overflow, grow the arena and rerun --
     results identical to a run with the default arena; repeated bk_run on one handle is idempotent."""
