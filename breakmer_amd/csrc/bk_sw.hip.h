@@ -4,9 +4,14 @@
 // Iterated gap-free local Smith-Waterman (maximal scoring segment, match +1 / mismatch -2) of the
 // still-unaligned query intervals against every window on both strands.  With no gap transitions
 // every cell depends only on its diagonal predecessor, so the diagonals of the DP matrix are
-// independent: each of the 256 threads of the workgroup walks whole diagonals
-// (H = max(0, H + s)), keeping the best (score, query end, target end) under the contract's
-// tie-break, followed by one 64-bit max-reduction.  Sequences are staged in LDS as bytes.
+// independent: a thread walks a whole diagonal (H = max(0, H + s)) and keeps its best
+// (score, query end, run); one 64-bit max-reduction applies the contract's tie-break.
+// Exact pruning: the best segment of a diagonal cannot score more than the diagonal has matching
+// positions, and that count U costs ~0.5 op/base on the 2-bit packed sequences (xor + popcount).
+// Per staged target chunk: (1) U of every diagonal, (2) the diagonals with the block-wide largest
+// U are walked and raise the lower bound L (an achieved score), (3) every diagonal with U >= L is
+// walked.  A diagonal with U < L cannot hold the maximum, ties (U == L) are walked, so the result
+// equals the brute-force scan.  Sequences are staged in LDS as bytes (walks) and words (counts).
 // One workgroup per region; contigs and query intervals are processed in sequence.
 // Chaining of collinear hits into PSL records is host code (bk_api.hip), restated in the oracle.
 #pragma once
@@ -21,6 +26,7 @@ struct BkSwShared {
     unsigned long long red[BK_ST_T / 64]; int red_run[BK_ST_T / 64];
     unsigned long long best_key; int best_run;
     unsigned long long cells;
+    int L, umax;                 // lower bound on the pass maximum (an achieved score); block maximum of U
     unsigned long long rec_off;
     int status;
 };
@@ -30,6 +36,39 @@ __device__ inline unsigned long long bk_sw_key(int score, int tidx, int strand, 
     // [score:13 | 15-tidx:4 | 1-strand:1 | 0x1FFF-a:13 | 0x1FFFFFFFF-b:33]
     return ((unsigned long long)score << 51) | ((unsigned long long)(15 - tidx) << 47) | ((unsigned long long)(1 - strand) << 46) |
            ((unsigned long long)(0x1FFF - a) << 33) | (unsigned long long)(0x1FFFFFFFFll - b);
+}
+
+// matching positions on diagonal `off` (target b = query a + off) of a packed query interval (n bases, qp) against the
+// staged packed target words tp[0..tpn) = target words tpw0.. (16 bases per word, MSB first)
+__device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off)
+{
+    const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
+    if (a1 <= a0) return 0;
+    int u = 0;
+    for (int wq = a0 >> 4; wq <= (a1 - 1) >> 4; wq++) {
+        const int aw = wq << 4, pb = aw + off;                      // target position of the word's first base (may be < 0)
+        const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
+        const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
+        const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
+        const uint32_t x = qp[wq] ^ tb;
+        const uint32_t eq = ~(x | (x >> 1)) & 0x55555555u;
+        const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
+        uint32_t vm = 0xFFFFFFFFu >> (2 * lo);
+        if (hi < 16) vm &= ~(0xFFFFFFFFu >> (2 * hi));
+        u += __popc(eq & vm);
+    }
+    return u;
+}
+// walk one diagonal: best positive run (strict '>': smallest query end among equal scores)
+__device__ inline void bk_sw_walk(const uint8_t *q, const uint8_t *t, int n, int m, int off, int &bh, int &ba, int &br)
+{
+    int a = off < 0 ? -off : 0, b = a + off, h = 0, run = 0;
+    bh = 0; ba = 0; br = 0;
+    for (; a < n && b < m; a++, b++) {
+        h += (q[a] == t[b]) ? 1 : -2; run++;
+        if (h <= 0) { h = 0; run = 0; }
+        else if (h > bh) { bh = h; ba = a + 1; br = run; }
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, uint32_t tw_cap)
@@ -42,7 +81,10 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
     BkSwShared *S = (BkSwShared *)sl;
     uint8_t *qf = sl + ((sizeof(BkSwShared) + 15) / 16) * 16;          // contig forward (codes)
     uint8_t *qr = qf + p.max_contig;                                   // contig reverse complement
-    uint8_t *tw = qr + p.max_contig;                                   // current target window
+    uint8_t *tw = qr + p.max_contig;                                   // current target chunk, bytes
+    uint32_t *qpk = (uint32_t *)(sl + ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)p.max_contig + tw_cap + 15) / 16) * 16);   // packed query interval, both strands
+    const int qpw = p.max_contig / 16 + 2;
+    uint32_t *tp = qpk + 2 * qpw;                                      // current target chunk, packed words
     if (tid == 0) { S->cells = 0; S->status = 0; S->rec_off = wk->o_first_contig; }
     __syncthreads();
     while (S->rec_off != 0) {
@@ -56,9 +98,17 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
         while (S->nseg > 0 && S->nhits < BK_MAX_HITS) {
             const int qs = S->seg[2 * (S->nseg - 1)], qe = S->seg[2 * (S->nseg - 1) + 1], n = qe - qs;
             __syncthreads();
-            if (tid == 0) { S->nseg--; S->best_key = 0; S->best_run = 0; }
+            if (tid == 0) { S->nseg--; S->best_key = 0; S->best_run = 0; S->L = 0; }
             __syncthreads();
             if (n < BK_SW_MIN_SEG) continue;
+            // packed copies of the query interval (both strands) for the match counts
+            for (int w = tid; w < 2 * ((n + 15) / 16); w += BK_ST_T) {
+                const int st = w >= (n + 15) / 16, wi = st ? w - (n + 15) / 16 : w;
+                const uint8_t *q = st ? qr + (Q - qe) : qf + qs;
+                uint32_t x = 0;
+                for (int t = 0; t < 16; t++) { const int a = wi * 16 + t; x = (x << 2) | (a < n ? (uint32_t)q[a] : 0u); }
+                qpk[st * qpw + wi] = x;
+            }
             unsigned long long bkey = 0; int brun = 0;
             for (int ti = 0; ti <= (int)d.n_partners; ti++) {
                 const uint32_t *gw; int m;
@@ -66,23 +116,42 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                 else { const BkPartnerDesc pd = p.partners[d.part_desc_off + ti - 1]; gw = p.windows + pd.word_off; m = (int)pd.len; }
                 // diagonals off = b - a in [-(n-1), m-1] are independent: they are processed in chunks whose target
                 // bases [o0, o0 + CH + n - 1) fit the staging buffer (one chunk when the window is short)
-                const int CH = (int)tw_cap - n;
+                const int CH = (int)tw_cap - n, mw = (m + 15) / 16;
                 for (int o0 = -(n - 1); o0 < m; o0 += CH) {
                     const int o1 = min(o0 + CH, m), t0 = max(o0, 0), t1 = min(m, o1 - 1 + n);
+                    const int tpw0 = t0 >> 4, tpn = ((t1 + 15) >> 4) - tpw0;
                     __syncthreads();
                     for (int i = t0 + tid; i < t1; i += BK_ST_T) tw[i - t0] = (uint8_t)seq_base(gw, i);
+                    for (int i = tid; i < tpn; i += BK_ST_T) tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u;
+                    if (tid == 0) S->umax = 0;
                     __syncthreads();
                     const int nd = o1 - o0;
+                    // (1) match counts; this thread's best diagonal
+                    int myu = -1, myD = 0;
                     for (int D = tid; D < 2 * nd; D += BK_ST_T) {
                         const int st = D >= nd, off = o0 + (st ? D - nd : D);
-                        const uint8_t *q = st ? qr + (Q - qe) : qf + qs;
-                        int a = off < 0 ? -off : 0, b = a + off;            // first cell of the diagonal (0-based)
-                        int h = 0, run = 0;
-                        for (; a < n && b < m; a++, b++) {
-                            h += (q[a] == tw[b - t0]) ? 1 : -2; run++;
-                            if (h <= 0) { h = 0; run = 0; }
-                            else { unsigned long long key = bk_sw_key(h, ti, st, a + 1, b + 1); if (key > bkey) { bkey = key; brun = run; } }
-                        }
+                        const int u = bk_sw_diag_matches(qpk + st * qpw, tp, tpw0, tpn, n, m, off);
+                        if (u > myu) { myu = u; myD = D; }
+                    }
+                    if (myu > 0) atomicMax(&S->umax, myu);
+                    __syncthreads();
+                    // (2) the diagonals with the largest count raise the lower bound
+                    int walked = -1;
+                    if (myu == S->umax && myu >= S->L && myu > 0) {
+                        const int st = myD >= nd, off = o0 + (st ? myD - nd : myD);
+                        int bh, ba, br; bk_sw_walk(st ? qr + (Q - qe) : qf + qs, tw - t0, n, m, off, bh, ba, br);
+                        if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } atomicMax(&S->L, bh); }
+                        walked = myD;
+                    }
+                    __syncthreads();
+                    // (3) every diagonal that can still hold the maximum
+                    for (int D = tid; D < 2 * nd; D += BK_ST_T) {
+                        const int st = D >= nd, off = o0 + (st ? D - nd : D);
+                        if (D == walked) continue;
+                        const int u = bk_sw_diag_matches(qpk + st * qpw, tp, tpw0, tpn, n, m, off);
+                        if (u < *(volatile int *)&S->L || u == 0) continue;
+                        int bh, ba, br; bk_sw_walk(st ? qr + (Q - qe) : qf + qs, tw - t0, n, m, off, bh, ba, br);
+                        if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } if (bh > *(volatile int *)&S->L) atomicMax(&S->L, bh); }
                     }
                 }
                 if (tid == 0) S->cells += 2ull * (unsigned long long)n * (unsigned long long)m;
