@@ -46,7 +46,7 @@ struct BkAsmShared {
     int nb, pc, last_dec;
     uint32_t scan[24];
 #ifdef BK_PHASE_STAMPS
-    unsigned long long acc[8], last;
+    unsigned long long acc[20], last; int ctx;
 #endif
 };
 
@@ -80,6 +80,11 @@ struct BkAsmCtx {
 #define BK_ACC(i) do { if (BK_TID == 0) { unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); S_->acc[i] += now_ - S_->last; S_->last = now_; } } while (0)
 #else
 #define BK_ACC(i) do { } while (0)
+#endif
+#ifdef BK_PHASE_STAMPS
+#define BK_CTX(v) do { BK_SYNC(); if (BK_TID == 0) S_->ctx = (v); BK_SYNC(); } while (0)
+#else
+#define BK_CTX(v) do { } while (0)
 #endif
 
 extern __shared__ __attribute__((aligned(16))) uint8_t bk_lds[];
@@ -209,6 +214,7 @@ __device__ inline int bk_total_reads()                                          
 // P1: m = L // 2 ; Q1: positions range(0, L-k).
 __device__ inline void bk_kmers_ordered(int s0, int L, int order)
 {
+    BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
     const int k = C_.k, np = L - k;                      // number of positions
     int *tmp = (int *)L_CAND;                           // rank per position (or -1)
@@ -249,12 +255,14 @@ __device__ inline void bk_kmers_ordered(int s0, int L, int order)
     BK_SYNC();
     if (BK_TID == 0) { S->nk = base + (int)T; if (order == BK_ORD_MID) S->setup = 1; }
     BK_SYNC();
+    BK_ACC(5);
 }
 
 // ---- find_reads (sv_assembly.py:111-122) from the posting list of k-mer `rank` -------------------------
 // key (pos, -len) / (-pos, -len); stable sort ties keep fq_recs order = unique index u.
 __device__ inline void bk_find_reads(int rank, bool rev, bool filter)
 {
+    BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
     const uint32_t b = C_.poff[rank], e = C_.poff[rank + 1];
     if (BK_TID == 0) S->ncand = 0;
@@ -296,18 +304,19 @@ __device__ inline void bk_find_reads(int rank, bool rev, bool filter)
         L_CANDU[i] = (uint32_t)(key & 0x3FFFFFull) | ((rev ? 0xFFFFu - pk : pk) << 22);
     }
     BK_SYNC();
+    BK_ACC(4);
 }
 
-// first occurrence of the k-mer bytes `pat` in seq[0..n) (str.find), executed by wave 0; result to *out
-__device__ inline int bk_find_bytes_wave(const uint8_t *seq, int n, const uint8_t *pat, int k)
+// first occurrence of k-mer `key` in seq[0..n) (str.find), executed by one wavefront: every lane rolls the k-mer at its
+// own position out of the LDS bytes and compares keys
+__device__ inline int bk_find_kmer_wave(const uint8_t *seq, int n, const BkKey &key, int k)
 {
     const int lane = BK_TID & 63;
-    for (int b = 0; b + k <= n + 63; b += 64) {
-        int x = b + lane; bool ok = x + k <= n;
-        for (int t = 0; ok && t < k; t++) ok = seq[x + t] == pat[t];
-        unsigned long long m = __ballot(ok);
+    for (int b = 0; b + k <= n; b += 64) {
+        const int x = b + lane; bool ok = x + k <= n;
+        if (ok) { const BkKey c = bk_bytes_kmer(seq + x, k); ok = c.lo == key.lo && c.hi == key.hi; }
+        const unsigned long long m = __ballot(ok);
         if (m) return b + __ffsll((long long)m) - 1;
-        if (b + 64 + k > n) break;
     }
     return -1;
 }
@@ -315,6 +324,7 @@ __device__ inline int bk_find_bytes_wave(const uint8_t *seq, int n, const uint8_
 // ---- contig life cycle ------------------------------------------------------------------------------
 __device__ inline void bk_contig_new(int rank, int u, bool in_fifo)                  // contig.__init__ :417-426
 {
+    BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
     bk_load_read(u);
     const int len = S->rlen, nreads = S->rn, indel = S->rindel;
@@ -332,6 +342,7 @@ __device__ inline void bk_contig_new(int rank, int u, bool in_fifo)             
         C_.ubuf[u] = S->serial;                          // buffer = set([read.id])
     }
     BK_SYNC();
+    BK_ACC(9);
 }
 __device__ inline void bk_fifo_push(int rank, int u)                                 // buffer.add_contig :337-340 (thread 0)
 {
@@ -381,13 +392,11 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
     if (tie) {
         // k-mer position tie-break: x.replace('-','') of the aligned strings are the plain slices
         if (wv == 0) {
-            uint8_t pat[64];
-            { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank];
-              for (int t = k - 1; t >= 0; t--) { pat[t] = (uint8_t)(key.lo & 3u); key.lo = (key.lo >> 2) | (key.hi << 62); key.hi >>= 2; } }
-            int i11 = bk_find_bytes_wave(cs + v1.j_start, clen - v1.j_start, pat, k);
-            int i12 = bk_find_bytes_wave(rseq + v1.i_start, v1.i_end - v1.i_start, pat, k);
-            int i21 = bk_find_bytes_wave(rseq + v2.j_start, rl - v2.j_start, pat, k);
-            int i22 = bk_find_bytes_wave(cs + v2.i_start, v2.i_end - v2.i_start, pat, k);
+            BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank];
+            int i11 = bk_find_kmer_wave(cs + v1.j_start, clen - v1.j_start, key, k);
+            int i12 = bk_find_kmer_wave(rseq + v1.i_start, v1.i_end - v1.i_start, key, k);
+            int i21 = bk_find_kmer_wave(rseq + v2.j_start, rl - v2.j_start, key, k);
+            int i22 = bk_find_kmer_wave(cs + v2.i_start, v2.i_end - v2.i_start, key, k);
             int d = BK_DEC_NONE;
             if (i11 > -1 && i12 > -1) { if ((i21 == -1 && i22 == -1) || (abs(i21 - i22) > abs(i11 - i12))) d = BK_DEC_POST; }
             else if (i21 > -1 && i22 > -1) { if ((i11 == -1 && i12 == -1) || (abs(i21 - i22) < abs(i11 - i12))) d = BK_DEC_PRE; }
@@ -475,7 +484,7 @@ __device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
     int q = first;
     while (q < n) {
         if (S->status) return;
-        BK_ACC(0);
+        BK_ACC(S_->ctx);
         const int nbmax = min(BK_SPEC, n - q);
         // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
         BK_SYNC();
@@ -504,7 +513,7 @@ __device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
         BK_SYNC();
         const int nb = S->nb;
 #ifdef BK_PHASE_STAMPS
-        if (BK_TID == 0) { S->acc[4] += nb; S->acc[6] += 1; }
+        if (BK_TID == 0) { S->acc[16] += nb; S->acc[18] += 1; }
 #endif
         for (int sl = 0; sl < nb; sl++) {                 // unpack the reads; pre-write the bytes slot sl is predicted to add
             const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
@@ -542,7 +551,7 @@ __device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
             const int u = S->slot[sl].u;
             const bool hit = bk_retire(rank, sl, grow);
 #ifdef BK_PHASE_STAMPS
-            if (BK_TID == 0) S->acc[5] += 1;
+            if (BK_TID == 0) S->acc[17] += 1;
 #endif
             if (grow && hit && BK_TID == 0) { int pidx = C_.ufound[u]; if (pidx >= 0) { C_.pend[2 * pidx] = BK_EMPTY32; C_.ufound[u] = -1; } }   // buff.remove_contig :638-639
             q++;
@@ -554,6 +563,7 @@ __device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
 // ---- check_alt_reads (sv_assembly.py:568-582) + the adds of finalize (:590-592) -------------------------
 __device__ inline void bk_check_alt_reads()
 {
+    BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
     const int k = C_.k;
     const int nalt = S->nalt;
@@ -597,11 +607,13 @@ __device__ inline void bk_check_alt_reads()
         }
         BK_SYNC();
     }
+    BK_ACC(6);
 }
 
 // ---- finalize (sv_assembly.py:584-599) ----------------------------------------------------------------
 __device__ inline void bk_finalize(bool setup)
 {
+    BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
     if (setup) bk_kmers_ordered(S->cbase, S->clen, BK_ORD_MID);                 // set_kmers(akmers.smers_set)
     bk_check_alt_reads();
@@ -614,11 +626,13 @@ __device__ inline void bk_finalize(bool setup)
         S->nalt = 0;
     }
     BK_SYNC();
+    BK_ACC(10);
 }
 
 // ---- contig.grow (sv_assembly.py:616-649) --------------------------------------------------------------
 __device__ inline void bk_grow()
 {
+    BK_ACC(S_->ctx); BK_CTX(15);
     BkAsmShared *S = S_;
     if (!S->setup) bk_kmers_ordered(S->cbase, S->clen, BK_ORD_MID);
     for (;;) {
@@ -631,6 +645,7 @@ __device__ inline void bk_grow()
         uint32_t pre = bk_scan256(cnt, S->scan, &T);
         for (int t = b; t < e; t++) { uint32_t en = C_.klist[t]; if (C_.kstamp[3 * (en & 0x7FFFFFFFu)] != S->serial) C_.nklist[pre++] = en; }
         BK_SYNC();
+        BK_ACC(13);
         if (T == 0) break;
         for (uint32_t t = 0; t < T; t++) {
             if (S->status) return;
@@ -638,27 +653,28 @@ __device__ inline void bk_grow()
             bk_find_reads(rank, rev, true);                                    // get_mer_reads :604-614
             if (BK_TID == 0) bk_add_used_mer(rank);
             BK_SYNC();
-            // position of this k-mer in the contig (prediction seed); -1 disables the look-ahead
+            // position of this k-mer in the contig (prediction seed); -1 disables the look-ahead, which needs >= 2 candidates
             if ((BK_TID >> 6) == 0) {
-                uint8_t pat[64];
-                { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank];
-                  for (int z = C_.k - 1; z >= 0; z--) { pat[z] = (uint8_t)(key.lo & 3u); key.lo = (key.lo >> 2) | (key.hi << 62); key.hi >>= 2; } }
-                const int pc = bk_find_bytes_wave(L_CSEQ + S->cbase, S->clen, pat, C_.k);
+                int pc = -1;
+                if (S->ncand >= 2) { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank]; pc = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, key, C_.k); }
                 if (BK_TID == 0) S->pc = pc;
             }
             BK_SYNC();
+            BK_ACC(14);
             bk_run_candidates(rank, 0, S->ncand, true);
             bk_finalize(false);
             if (BK_TID == 0) C_.kstamp[3 * rank] = S->serial;                       // checked_kmers.append(mer)
             BK_SYNC();
         }
     }
+    BK_ACC(15); BK_CTX(0);
 }
 
 // ---- init_assembly keeps a contig iff support >= rc_thresh and len > read_len (sv_assembly.py:53-59);
 //      set_kmer_locs (:434-438) and the record the host reads back ------------------------------------------
 __device__ inline void bk_emit_contig()
 {
+    BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
     const int total = bk_total_reads();
     if (total < C_.rc_thresh || S->clen <= (int)C_.max_len) return;
@@ -702,11 +718,13 @@ __device__ inline void bk_emit_contig()
         C_.wk->o_last_contig = off; S->n_contigs++;
     }
     BK_SYNC();
+    BK_ACC(7);
 }
 
 // ---- setup_contigs (sv_assembly.py:11-26) -----------------------------------------------------------------
 __device__ inline void bk_setup_contigs(int rank)
 {
+    BK_ACC(S_->ctx); BK_CTX(8);
     BkAsmShared *S = S_;
     bk_find_reads(rank, false, false);                                         // used_reads = set()
     if (BK_TID == 0) bk_add_used_mer(rank);
@@ -725,6 +743,7 @@ __device__ inline void bk_setup_contigs(int rank)
     bk_run_candidates(rank, 1, n, false);
     bk_finalize(true);
     if (in_fifo) { bk_grow(); if (!S->status) bk_emit_contig(); }                // it is the FIFO head (:50-52)
+    BK_ACC(8); BK_CTX(0);
 }
 
 extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
@@ -756,7 +775,7 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
         S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0;
 #ifdef BK_PHASE_STAMPS
-        for (int i = 0; i < 8; i++) S->acc[i] = 0;
+        for (int i = 0; i < 20; i++) S->acc[i] = 0; S->ctx = 0;
         S->last = __builtin_amdgcn_s_memrealtime();
 #endif
         // per-region scratch from the arena
@@ -789,6 +808,7 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
         BK_SYNC();
         if (BK_TID == 0) S->head = found;
         BK_SYNC();
+        BK_ACC(11);
         bk_setup_contigs(found);
         while (!S->status && S->phead < S->ptail) {                                // :50-59
             const int ph = S->phead;
@@ -806,14 +826,15 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
         const int nu = S->nused;
         for (int i = BK_TID; i < nu; i += BK_AT) C_.kstate[C_.usedl[i]] = BK_K_REMOVED;   // buff.remove_kmers :358-360
         BK_SYNC();
+        BK_ACC(12);
         if (BK_TID == 0) S->nused = 0;
         BK_SYNC();
     }
     BK_SYNC();
-    BK_ACC(0);
+    BK_ACC(S_->ctx);
     if (BK_TID == 0) { C_.wk->n_contigs = (uint32_t)S->n_contigs; C_.wk->nw_cells = S->cells; C_.wk->nw_calls = S->calls; if (S->status) C_.wk->status = S->status; }
 #ifdef BK_PHASE_STAMPS
-    if (BK_TID == 0) for (int i = 0; i < 8; i++) C_.wk->stamps[i] = S->acc[i];
+    if (BK_TID == 0) for (int i = 0; i < 20; i++) C_.wk->stamps[i] = S->acc[i];
 #endif
 }
 

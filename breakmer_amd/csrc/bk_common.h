@@ -124,7 +124,7 @@ struct BkRegionWork {
     uint64_t o_post;             // uint32[T]
     uint64_t o_first_contig;     // `out` offset of first contig record (linked list), 0 = none
     uint64_t o_last_contig;
-    uint64_t stamps[12];         // diagnostic builds only (-DBK_PHASE_STAMPS): s_memrealtime at phase boundaries
+    uint64_t stamps[20];         // diagnostic builds only (-DBK_PHASE_STAMPS): s_memrealtime at phase boundaries
 };
 
 // k-mer states (akmers.mers membership, sv_assembly.py:301-326; buffer.used_mers :333)

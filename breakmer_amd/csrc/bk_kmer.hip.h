@@ -437,6 +437,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         } else if (lane == 0) bk_scan_nonref(reads + (uint64_t)i * RW, len, rt, rec);
     }
     __syncthreads();
+    BK_STAMP(11);
     const uint32_t tmask = tcap - 1;
     for (uint32_t idx = tid; idx < T; idx += nt) {
         uint32_t e = t_ent[idx], u = e >> 10, pos = e & 1023u;

@@ -49,14 +49,16 @@ __device__ inline int bk_dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(v,
 // (inlining all variants into one kernel made the allocator spill: 232+ VGPRs).  XM = register that holds the
 // last tile column in lane lm; a template parameter because a run-time select costs C-1 instructions per step
 // (direct sweep only; the transposed sweep reads the end cells after the loop and uses XM = 0).
-template <int C, bool TR, int XM>
+// ST = the whole matrix is one tile (contig <= 512: every sweep of the benchmark workload): no tile-edge column, no
+// loads/stores and no uniform branches in the loop (the general variant is ~75 instructions per step at C = 4, this one ~50).
+template <int C, bool TR, int XM, bool ST>
 __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows, int n_, int j0_, int mt_,
                                         const int *bound_in, int *bound_out, bool last_, int best_word, int best_i)
 {
     // the arguments of an out-of-line function arrive in VGPRs: tell the compiler they are wave-uniform so that
     // the loop control and the lane predicates stay on the scalar unit
-    const int n = __builtin_amdgcn_readfirstlane(n_), j0 = __builtin_amdgcn_readfirstlane(j0_), mt = __builtin_amdgcn_readfirstlane(mt_);
-    const bool last = __builtin_amdgcn_readfirstlane((int)last_) != 0;
+    const int n = __builtin_amdgcn_readfirstlane(n_), j0 = ST ? 0 : __builtin_amdgcn_readfirstlane(j0_), mt = __builtin_amdgcn_readfirstlane(mt_);
+    const bool last = ST ? true : __builtin_amdgcn_readfirstlane((int)last_) != 0;
     const int lane = threadIdx.x & 63;
     const int lm = (mt - 1) / C;
     // which reference neighbour is "horizontal" (previous tile column) / "vertical" (previous tile row)
@@ -85,8 +87,11 @@ __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows
         const bool active = (lane <= lm) && ((unsigned)(i - 1) < (unsigned)n);
         if (active) {
             int left_in;
-            if (lane == 0) left_in = (j0 == 0) ? (LEFTB | i) : bound_in[i];
-            else left_in = recv;
+            if constexpr (ST) left_in = lane == 0 ? (LEFTB | i) : recv;
+            else {
+                if (lane == 0) left_in = (j0 == 0) ? (LEFTB | i) : bound_in[i];
+                else left_in = recv;
+            }
             // candidates that only need the previous tile row first (off the dependency chain), then the
             // serial chain along the row writes H[x] in place (no register shuffling at the loop end)
             int cd[C], cv[C];
@@ -103,7 +108,13 @@ __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows
             }
             dprev = left_in;
             out_prev = H[C - 1];
-            if (lane == lm && (!TR || !last)) {         // last tile column of this tile row
+            if constexpr (ST) {
+                if constexpr (!TR) {                    // last tile column of this tile row, branch-free (olc.py:81 '>=': last row wins)
+                    const int v = H[XM];
+                    const bool take = (lane == lm) && ((v >> 18) >= (best_word >> 18));
+                    best_word = take ? v : best_word; best_i = take ? i : best_i;
+                }
+            } else if (lane == lm && (!TR || !last)) {  // last tile column of this tile row
                 int v = H[XM];
                 if constexpr (TR) {                     // transposed sweep, not the last tile (contig > 512): rare, run-time select
                     const int xm = (mt - 1) % C;
@@ -134,20 +145,20 @@ __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows
     return make_int2(best_word, best_i);
 }
 
-template <int C, bool TR, int XM>
+template <int C, bool TR, int XM, bool ST>
 __device__ inline int2 bk_nw_tile_xm(int xm, const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt,
                                      const int *bi, int *bo, bool last, int bw, int bidx)
 {
-    if (TR || xm == XM) return bk_nw_tile<C, TR, TR ? 0 : XM>(cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
-    if constexpr (!TR && XM + 1 < C) return bk_nw_tile_xm<C, TR, XM + 1>(xm, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if (TR || xm == XM) return bk_nw_tile<C, TR, TR ? 0 : XM, ST>(cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if constexpr (!TR && XM + 1 < C) return bk_nw_tile_xm<C, TR, XM + 1, ST>(xm, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
     return make_int2(bw, bidx);
 }
-template <int C, bool TR>
+template <int C, bool TR, bool ST>
 __device__ inline int2 bk_nw_tile_call(int c, const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt,
                                        const int *bi, int *bo, bool last, int bw, int bidx)
 {
-    if (c == C) return bk_nw_tile_xm<C, TR, 0>((mt - 1) % C, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
-    if constexpr (C < BK_NW_TILE_C) return bk_nw_tile_call<C + 1, TR>(c, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if (c == C) return bk_nw_tile_xm<C, TR, 0, ST>((mt - 1) % C, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if constexpr (C < BK_NW_TILE_C) return bk_nw_tile_call<C + 1, TR, ST>(c, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
     return make_int2(bw, bidx);
 }
 
@@ -158,16 +169,21 @@ template <bool TR>
 __device__ inline BkNwResult bk_nw_wave(const uint8_t *tcols, int m, const uint8_t *trows, int n, int *bound)
 {
     int best_word = 0, best_i = 0;                      // border cell of the last reference column: score 0 (olc.py:79-83)
-    int *bi = bound, *bo = bound ? bound + (n + 1) : nullptr;
-    for (int j0 = 0; j0 < m; j0 += BK_NW_TILE_COLS) {
-        const int mt = min(m - j0, BK_NW_TILE_COLS);
-        const bool last = j0 + mt >= m;
-        const int c = (mt + 63) / 64;
-        const int2 b = bk_nw_tile_call<1, TR>(c, tcols, trows, n, j0, mt, bi, bo, last, best_word, best_i);
+    if (m <= BK_NW_TILE_COLS) {
+        const int2 b = bk_nw_tile_call<1, TR, true>((m + 63) / 64, tcols, trows, n, 0, m, nullptr, nullptr, true, best_word, best_i);
         best_word = b.x; best_i = b.y;
-        int *tswap = bi; bi = bo; bo = tswap;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    } else {
+        int *bi = bound, *bo = bound ? bound + (n + 1) : nullptr;
+        for (int j0 = 0; j0 < m; j0 += BK_NW_TILE_COLS) {
+            const int mt = min(m - j0, BK_NW_TILE_COLS);
+            const bool last = j0 + mt >= m;
+            const int c = (mt + 63) / 64;
+            const int2 b = bk_nw_tile_call<1, TR, false>(c, tcols, trows, n, j0, mt, bi, bo, last, best_word, best_i);
+            best_word = b.x; best_i = b.y;
+            int *tswap = bi; bi = bo; bo = tswap;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     const int m_ref = TR ? n : m;                       // len(seq1) of the reference call
     BkNwResult r;

@@ -1,0 +1,18 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from breakmer_amd import hip_backend as hb, synth
+hb.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libbk_stamps_probe")
+noise = float(sys.argv[1]) if len(sys.argv) > 1 else 0.005
+regions = [synth.make_region(900, sv_type="del", depth=500, W=3000, L=150, noise=noise)]
+eng = hb.Engine(kmer_size=31)
+eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
+eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)
+eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)
+print("asm kernel ms", eng.kernel_ms(2), "nw calls", eng.stat(1), "cells", eng.stat(0), "contigs", len(eng.contigs(0)), "M", len(eng.kmers(0)[0]))
+names = ["misc", "load_read", "DP", "decide+apply", "find_reads", "kmers_ordered", "check_alt", "emit", "setup_contigs(own)", "contig_new", "finalize(own)",
+         "head scan", "remove_kmers", "grow snapshot", "grow pre-cand (used_mer, find_bytes)", "grow(own)"]
+acc = [eng.stat(100 + i) / 100.0 for i in range(20)]
+tot = sum(acc[:16])
+for n, v in zip(names, acc):
+    print("%-38s %10.1f us  %5.1f %%" % (n, v, 100 * v / tot))
+print("rounds %d slots %d retired %d" % (acc[18] * 100, acc[16] * 100, acc[17] * 100))
