@@ -49,6 +49,95 @@ __device__ inline int bk_dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(v,
 // (inlining all variants into one kernel made the allocator spill: 232+ VGPRs).  XM = register that holds the
 // last tile column in lane lm; a template parameter because a run-time select costs C-1 instructions per step
 // (direct sweep only; the transposed sweep reads the end cells after the loop and uses XM = 0).
+// Single-tile sweep (contig <= 512 columns: every sweep of the benchmark workload).  Same recurrence and the same
+// results as bk_nw_tile below, with everything a one-tile matrix does not need removed from the loop: no tile-edge
+// column, no loads/stores, no uniform branches; the neighbour's
+// edge cell is read straight out of its H register, the row index is a running counter, the end-cell selection of the
+// direct sweep is branch-free.  ~45 instructions per step at C = 4 (general variant: ~75).
+template <int C, bool TR, int XM>
+__device__ __noinline__ int2 bk_nw_tile_st(const uint8_t *cols, const uint8_t *rows, int n_, int mt_)
+{
+    const int n = __builtin_amdgcn_readfirstlane(n_), mt = __builtin_amdgcn_readfirstlane(mt_);
+    const int lane = threadIdx.x & 63;
+    const int lm = (mt - 1) / C;
+    constexpr int GH = TR ? BK_NW_G1 : BK_NW_G2, GV = TR ? BK_NW_G2 : BK_NW_G1;
+    constexpr int TOPB = TR ? 0x8000 : 0, LEFTB = TR ? 0 : 0x8000;
+    int H[C]; int cb[C];
+#pragma unroll
+    for (int x = 0; x < C; x++) {
+        const int jj = lane * C + x;
+        H[x] = TOPB | (jj + 1);
+        cb[x] = jj < mt ? (int)cols[jj] : 4;
+    }
+    int dprev = lane ? (TOPB | (lane * C)) : 0;
+    int rb = 0;
+    int im1 = -lane;                                    // tile row handled at this step, minus 1
+    int best_word = 0, best_im1 = -1;                   // border cell of the last reference column: score 0 (olc.py:79-83)
+    const bool inlanes = lane <= lm;
+    const int steps = n + lm;
+    for (int t0 = 0; t0 < steps; t0 += 64) {
+        const int rblk = (t0 + lane < n) ? (int)rows[t0 + lane] : 0;       // row symbols of this block of 64 steps
+        const int te = min(64, steps - t0);
+        for (int tl = 0; tl < te; tl++) {
+            const int recv = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);       // lane l <- lane l-1: its edge cell of the same tile row
+            rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
+            { const int rb0 = __builtin_amdgcn_readlane(rblk, tl); if (lane == 0) rb = rb0; }       // rows[t] enters at lane 0
+            if (inlanes && (unsigned)im1 < (unsigned)n) {
+                const int left_in = lane == 0 ? (LEFTB + 1) + im1 : recv;
+                int cd[C], cv[C];
+#pragma unroll
+                for (int x = 0; x < C; x++) {
+                    cd[x] = (x ? H[x - 1] : dprev) + (cb[x] == rb ? BK_NW_MATCH : BK_NW_MISM);
+                    cv[x] = H[x] + GV;
+                }
+                int u_in = left_in;
+#pragma unroll
+                for (int x = 0; x < C; x++) {
+                    const int nv = max(max(cd[x], u_in + GH), cv[x]) & ~BK_NW_PRIO_MASK;
+                    H[x] = nv; u_in = nv;
+                }
+                dprev = left_in;
+                if constexpr (!TR) {                    // every lane tracks its own column XM; only lane lm's is read (olc.py:81 '>=': last row wins)
+                    const int v = H[XM];
+                    const bool take = v >= (best_word & ~0x3FFFF);
+                    best_word = take ? v : best_word; best_im1 = take ? im1 : best_im1;
+                }
+            }
+            im1++;
+        }
+    }
+    int best_i = best_im1 + 1;
+    if (!TR) { best_word = __shfl(best_word, lm); best_i = __shfl(best_i, lm); }
+    else {
+        best_word = 0; best_i = 0;
+#pragma unroll
+        for (int x = 0; x < C; x++) {
+            const int jj = lane * C + x;
+            if (jj < mt && lane <= lm && (H[x] >> 18) >= (best_word >> 18)) { best_word = H[x]; best_i = jj + 1; }
+        }
+        for (int o = 1; o < 64; o <<= 1) {
+            const int ow = __shfl_xor(best_word, o), oi = __shfl_xor(best_i, o);
+            const int sc = best_word >> 18, os = ow >> 18;
+            if (os > sc || (os == sc && oi > best_i)) { best_word = ow; best_i = oi; }
+        }
+    }
+    return make_int2(best_word, best_i);
+}
+template <int C, bool TR, int XM>
+__device__ inline int2 bk_nw_st_xm(int xm, const uint8_t *cols, const uint8_t *rows, int n, int mt)
+{
+    if (TR || xm == XM) return bk_nw_tile_st<C, TR, TR ? 0 : XM>(cols, rows, n, mt);
+    if constexpr (!TR && XM + 1 < C) return bk_nw_st_xm<C, TR, XM + 1>(xm, cols, rows, n, mt);
+    return make_int2(0, 0);
+}
+template <int C, bool TR>
+__device__ inline int2 bk_nw_st_call(int c, const uint8_t *cols, const uint8_t *rows, int n, int mt)
+{
+    if (c == C) return bk_nw_st_xm<C, TR, 0>((mt - 1) % C, cols, rows, n, mt);
+    if constexpr (C < BK_NW_TILE_C) return bk_nw_st_call<C + 1, TR>(c, cols, rows, n, mt);
+    return make_int2(0, 0);
+}
+
 // ST = the whole matrix is one tile (contig <= 512: every sweep of the benchmark workload): no tile-edge column, no
 // loads/stores and no uniform branches in the loop (the general variant is ~75 instructions per step at C = 4, this one ~50).
 template <int C, bool TR, int XM, bool ST>
@@ -170,7 +259,7 @@ __device__ inline BkNwResult bk_nw_wave(const uint8_t *tcols, int m, const uint8
 {
     int best_word = 0, best_i = 0;                      // border cell of the last reference column: score 0 (olc.py:79-83)
     if (m <= BK_NW_TILE_COLS) {
-        const int2 b = bk_nw_tile_call<1, TR, true>((m + 63) / 64, tcols, trows, n, 0, m, nullptr, nullptr, true, best_word, best_i);
+        const int2 b = bk_nw_st_call<1, TR>((m + 63) / 64, tcols, trows, n, m);
         best_word = b.x; best_i = b.y;
     } else {
         int *bi = bound, *bo = bound ? bound + (n + 1) : nullptr;
