@@ -231,7 +231,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     if (h->arena_cap < h->big_bytes + (64ull << 20) && h->big_bytes) {
         h->arena_cap = h->big_bytes + std::max<uint64_t>(64ull << 20, (uint64_t)n_regions * (1ull << 20) + h->total_reads * 64ull);
     }
-    if (h->out_cap == 0) h->out_cap = std::max<uint64_t>(8ull << 20, (uint64_t)n_regions * (64ull << 10));
+    if (h->out_cap == 0) h->out_cap = h->cfg.out_kbytes > 0 ? (uint64_t)h->cfg.out_kbytes << 10 : std::max<uint64_t>(8ull << 20, (uint64_t)n_regions * (64ull << 10));
     HIPCHK(h, h->d_arena.ensure(h->arena_cap)); HIPCHK(h, h->d_out.ensure(h->out_cap));
     HIPCHK(h, hipStreamSynchronize(h->stream));          // host staging vectors go out of scope
     h->submitted = true; h->ran = false; h->fetched = false;
@@ -330,7 +330,7 @@ extern "C" int bk_sync(bk_handle *h)
     if (!h->ran) return fail(h, BK_E_STATE, "bk_sync: nothing was run");
     if (h->synced) return BK_OK;
     HIPCHK(h, hipSetDevice(h->dev));
-    for (int attempt = 0; attempt < 6; attempt++) {
+    for (int attempt = 0; attempt < 12; attempt++) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->h_work.resize(h->n_regions);
         HIPCHK(h, hipMemcpy(h->h_work.data(), h->d_work.p, sizeof(BkRegionWork) * h->n_regions, hipMemcpyDeviceToHost));
@@ -346,12 +346,16 @@ extern "C" int bk_sync(bk_handle *h)
             h->synced = true;
             return BK_OK;
         }
-        if (grow_arena) { h->arena_cap *= 4; HIPCHK(h, h->d_arena.ensure(h->arena_cap)); }
-        if (grow_out) { h->out_cap *= 4; HIPCHK(h, h->d_out.ensure(h->out_cap)); }
+        // the bump pointers keep counting past the capacity: what the regions that got that far asked for is a lower
+        // bound of the demand, so grow to that (plus slack) when it is more than the usual factor
+        unsigned long long tops[2] = {0, 0};
+        HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
+        if (grow_arena) { h->arena_cap = std::max<uint64_t>(h->arena_cap * 4, tops[0] + tops[0] / 2); HIPCHK(h, h->d_arena.ensure(h->arena_cap)); }
+        if (grow_out) { h->out_cap = std::max<uint64_t>(h->out_cap * 4, tops[1] + tops[1] / 2); HIPCHK(h, h->d_out.ensure(h->out_cap)); }
         int rc = launch(h, h->ran_mask);
         if (rc != BK_OK) return rc;
     }
-    return fail(h, BK_E_NOMEM, "bk_sync: arenas still too small after 6 growth steps");
+    return fail(h, BK_E_NOMEM, "bk_sync: arenas still too small after 12 growth steps");
 }
 
 static int fetch(bk_handle *h)

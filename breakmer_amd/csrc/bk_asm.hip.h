@@ -63,6 +63,7 @@ struct BkAsmCtx {
     int rc_thresh; uint32_t read_words, max_len;
     const uint32_t *reads; const uint16_t *rlen;
     uint32_t *urep, *unr; uint8_t *ufl; int32_t *ubuf, *ureads, *ufound, *uminpos;
+    const uint32_t *ulen;                      // length of unique read u (k-mer stage)
     const uint32_t *tslot, *trank; const uint64_t *klo, *khi; const uint32_t *kcnt; uint8_t *kstate; int32_t *kstamp;
     const uint32_t *poff, *post;
     uint32_t U, M, tmask;
@@ -265,6 +266,38 @@ __device__ inline void bk_find_reads(int rank, bool rev, bool filter)
     BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
     const uint32_t b = C_.poff[rank], e = C_.poff[rank + 1];
+    if (e - b <= 64u) {
+        // Short posting list (the rule for sequencing-error k-mers): one wavefront does everything in registers --
+        // first occurrence per read, filters, order -- with two global round trips and a single workgroup barrier.
+        if ((BK_TID >> 6) == 0) {
+            const int lane = BK_TID, np = (int)(e - b);
+            const bool have = lane < np;
+            const uint32_t en = have ? C_.post[b + lane] : 0u;
+            const uint32_t u = en >> 10; const int pos = (int)(en & 1023u);
+            uint32_t fl = 0; int bufst = 0; uint32_t len = 0;
+            if (have) { fl = C_.ufl[u]; bufst = C_.ubuf[u]; len = C_.ulen[u]; }
+            bool drop = false;                                                     // a smaller position of the same read exists
+            for (int j = 0; j < np; j++) {
+                const uint32_t oen = (uint32_t)__builtin_amdgcn_readlane((int)en, j);
+                drop = drop || ((oen >> 10) == u && (int)(oen & 1023u) < pos);
+            }
+            const bool valid = have && !drop && !(fl & BK_R_DELETED) && !(filter && bufst == S->serial);
+            const unsigned long long pk = rev ? (unsigned long long)(0xFFFF - pos) : (unsigned long long)pos;
+            const unsigned long long key = valid ? ((pk << 40) | ((0xFFFFull - len) << 24) | u) : ~0ull;
+            int idx = 0;                                                           // rank among the valid keys (unique: u is)
+            for (int j = 0; j < np; j++) {
+                const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+                idx += kj < key;
+            }
+            const unsigned long long vm = __ballot(valid);
+            if (valid) L_CANDU[idx] = u | ((uint32_t)pos << 22);
+            if (lane == 0) S->ncand = __popcll(vm);
+        }
+        BK_SYNC();
+        if (S->ncand > C_.MAXCAND) { bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); }
+        BK_ACC(4);
+        return;
+    }
     if (BK_TID == 0) S->ncand = 0;
     BK_SYNC();
     // first occurrence of the k-mer in each read (re.search): min pos per read
@@ -277,7 +310,7 @@ __device__ inline void bk_find_reads(int rank, bool rev, bool filter)
         if (filter && C_.ubuf[u] == S->serial) continue;                         // ids - self.buffer (:115-116)
         int idx = atomicAdd(&S->ncand, 1);
         if (idx < C_.MAXCAND) {
-            unsigned long long len = C_.rlen[C_.urep[u]];
+            unsigned long long len = C_.ulen[u];
             unsigned long long pk = rev ? (unsigned long long)(0xFFFF - pos) : (unsigned long long)pos;
             L_CAND[idx] = (pk << 40) | ((0xFFFFull - len) << 24) | u;
         }
@@ -647,9 +680,11 @@ __device__ inline void bk_grow()
         BK_SYNC();
         BK_ACC(13);
         if (T == 0) break;
+        uint32_t en_next = C_.nklist[0];
         for (uint32_t t = 0; t < T; t++) {
             if (S->status) return;
-            const uint32_t en = C_.nklist[t]; const int rank = (int)(en & 0x7FFFFFFFu); const bool rev = (en >> 31) != 0;
+            const uint32_t en = en_next; const int rank = (int)(en & 0x7FFFFFFFu); const bool rev = (en >> 31) != 0;
+            if (t + 1 < T) en_next = C_.nklist[t + 1];                           // fetched a whole visit ahead of its use
             bk_find_reads(rank, rev, true);                                    // get_mer_reads :604-614
             if (BK_TID == 0) bk_add_used_mer(rank);
             BK_SYNC();
@@ -663,9 +698,9 @@ __device__ inline void bk_grow()
             BK_ACC(14);
             bk_run_candidates(rank, 0, S->ncand, true);
             bk_finalize(false);
-            if (BK_TID == 0) C_.kstamp[3 * rank] = S->serial;                       // checked_kmers.append(mer)
-            BK_SYNC();
+            if (BK_TID == 0) C_.kstamp[3 * rank] = S->serial;                       // checked_kmers.append(mer): read by the next snapshot only
         }
+        BK_SYNC();                                                                  // the stamps above are visible before the next snapshot reads them
     }
     BK_ACC(15); BK_CTX(0);
 }
@@ -766,7 +801,7 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
         c.o_rseq = o; o += BK_SPEC * (c.MAXR + 16);
         c.reads = p.reads + d.reads_word_off; c.rlen = p.read_len + d.read_meta_off;
         const uint64_t mo = d.read_meta_off;
-        c.urep = p.urep + mo; c.unr = p.unreads + mo; c.ufl = p.uflag + mo; c.ubuf = p.ubuf + mo; c.ureads = p.ureads + mo; c.ufound = p.ufound + mo; c.uminpos = p.uminpos + mo;
+        c.urep = p.urep + mo; c.unr = p.unreads + mo; c.ufl = p.uflag + mo; c.ubuf = p.ubuf + mo; c.ureads = p.ureads + mo; c.ufound = p.ufound + mo; c.uminpos = p.uminpos + mo; c.ulen = p.dd_rep + d.dedup_off;
         c.U = wk->U; c.M = wk->M; c.tmask = wk->tcap - 1;
         c.tslot = (const uint32_t *)(p.arena + wk->o_tslot); c.trank = (const uint32_t *)(p.arena + wk->o_trank);
         c.klo = (const uint64_t *)(p.arena + wk->o_key_lo); c.khi = (const uint64_t *)(p.arena + wk->o_key_hi);

@@ -337,6 +337,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     // ---- P2: unique reads in first-occurrence (FASTQ) order = fq_recs iteration order (P4) -------
     uint32_t *urep = p.urep + d.read_meta_off, *unr = p.unreads + d.read_meta_off;
     uint8_t *ufl = p.uflag + d.read_meta_off;
+    uint32_t *ulen = p.dd_rep + d.dedup_off;                    // length per unique read, for the assembler's find_reads
     const uint8_t *rflag = p.read_flag + d.read_meta_off;
     uint32_t U = 0;
     {
@@ -354,7 +355,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
 #pragma unroll
             for (int t = 0; t < 32; t++) if (isrep & (1u << t)) {
                 const uint32_t i = b + t, sl = g[t];
-                urep[pre] = i; unr[pre] = dcnt[sl]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[sl] = pre;
+                urep[pre] = i; unr[pre] = dcnt[sl]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[sl] = pre; ulen[pre] = rlen[i];
                 p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
                 pre++;
             }
@@ -363,7 +364,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
             uint32_t pre = bk_block_excl_scan(c, scr, &U);
             for (uint32_t i = b; i < e; i++) if ((uint32_t)dslot[gslot[i]] == i) {
                 uint32_t sl = gslot[i];
-                urep[pre] = i; unr[pre] = dcnt[sl]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[sl] = pre;
+                urep[pre] = i; unr[pre] = dcnt[sl]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[sl] = pre; ulen[pre] = rlen[i];
                 p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
                 pre++;
             }

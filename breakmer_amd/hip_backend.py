@@ -21,7 +21,7 @@ BK_MAX_BLOCKS = 16
 class BkConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("kmer_size", C.c_int32), ("rc_thresh", C.c_int32),
                 ("max_contig_len", C.c_int32), ("max_read_len", C.c_int32), ("max_candidates", C.c_int32),
-                ("arena_bytes", C.c_int64), ("sw_min_score", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("arena_bytes", C.c_int64), ("sw_min_score", C.c_int32), ("out_kbytes", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class BkRegion(C.Structure):
@@ -172,6 +172,7 @@ class Engine(object):
         cfg.max_read_len = int(limits.get("max_read_len", 0))
         cfg.max_candidates = int(limits.get("max_candidates", 0))
         cfg.arena_bytes = int(limits.get("arena_bytes", 0))
+        cfg.out_kbytes = int(limits.get("out_kbytes", 0))
         cfg.sw_min_score = int(limits.get("sw_min_score", 0))
         self.k = int(kmer_size)
         self.h = C.c_void_p()

@@ -50,7 +50,8 @@ typedef struct bk_config {
     int32_t max_candidates;     /* cap on reads returned by one find_reads (default 2048) */
     int64_t arena_bytes;        /* device scratch arena; 0 = choose from the batch; grown and retried on overflow */
     int32_t sw_min_score;       /* BLAT -minScore=20 analogue for the realign stage (sv_processor.py:843) */
-    int32_t reserved[7];
+    int32_t out_kbytes;         /* initial result arena in KiB; 0 = choose from the batch; grown and retried on overflow */
+    int32_t reserved[6];
 } bk_config;
 
 /* One target region = what sv_processor.target hands to compare_kmers()/resolve_sv()

@@ -323,6 +323,22 @@ def test_full_size_config2_properties_gpu(hb):
         assert first[i][1] == bo.realign(want[0]["seq"], [regions[i].window_str]), i
 
 
+def test_noisy_regions_and_both_arenas_grow_gpu(hb):
+    """Sequencing noise (1 %, hundreds of recurrent-error contigs per region) against the oracle, started with
+    deliberately tiny scratch AND result arenas: both must grow (several times) and the rerun must be exact."""
+    from oracle import bk_oracle as bo
+    regions = [synth.make_region(901 + i, sv_type="del", depth=300, W=1000, L=150, noise=0.01) for i in range(3)]
+    eng = hb.Engine(kmer_size=31, arena_bytes=1 << 16, out_kbytes=64)
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
+    eng.run(hb.BK_STAGE_ALL)
+    for i in (0, 2):
+        want, info = bo.assemble_region(regions[i].read_strs(), [regions[i].window_str], 31, 2)
+        assert len(want) > 100
+        assert _strip(eng.contigs(i)) == want, i
+        for ci in (0, len(want) // 2, len(want) - 1):
+            assert eng.hits(i, ci) == bo.realign(want[ci]["seq"], [regions[i].window_str]), (i, ci)
+
+
 def test_arena_growth_and_rerun_gpu(hb):
     """A deliberately tiny scratch arena: the library must notice the overflow, grow the arena and rerun --
     results identical to a run with the default arena; repeated bk_run on one handle is idempotent."""
