@@ -510,7 +510,7 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
 // geometry => same bytes); the first misprediction discards the later slots, which are redone next round.
 // Results are therefore bit-identical to the serial loop; only the DP latency chain gets shorter.
 enum { BK_PK_SAME = 0, BK_PK_PRE = 1, BK_PK_POST = 2, BK_PK_STOP = 3 };
-__device__ inline void bk_run_candidates(int rank, int first, int n, bool grow)
+__device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bool grow)
 {
     BkAsmShared *S = S_;
     const int wv = BK_TID >> 6;
@@ -663,7 +663,7 @@ __device__ inline void bk_finalize(bool setup)
 }
 
 // ---- contig.grow (sv_assembly.py:616-649) --------------------------------------------------------------
-__device__ inline void bk_grow()
+__device__ __forceinline__ void bk_grow()
 {
     BK_ACC(S_->ctx); BK_CTX(15);
     BkAsmShared *S = S_;
