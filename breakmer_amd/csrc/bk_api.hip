@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -48,6 +49,7 @@ struct bk_handle {
     uint64_t arena_cap = 0, out_cap = 0;
     uint32_t ref_cap = 0, win_words_cap = 0;
     int n_big = 0; uint64_t big_bytes = 0;      // regions whose window needs the global-memory k-mer set
+    uint32_t group_words = 0;                   // LDS words wanted by the in-LDS read-grouping table (largest region that qualifies)
     // host mirrors
     std::vector<BkRegionDesc> h_desc; std::vector<BkRegionWork> h_work; HostVec h_out;
     std::vector<BkPartnerDesc> h_part;
@@ -209,6 +211,11 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         else max_small = std::max(max_small, d.win_len);
     }
     { uint32_t cap, words; lds_need(max_small, cap, words); h->ref_cap = cap; h->win_words_cap = words; }
+    h->group_words = 0;
+    for (auto &d : h->h_desc) {
+        const uint32_t need = 32 + 256 + d.dedup_cap;
+        if (!d.big && d.n_reads < 16383u && need <= 36864u) h->group_words = std::max(h->group_words, need);
+    }
     h->big_bytes = big_bytes;
     if (rlen.empty()) { rlen.push_back(0); rflag.push_back(0); }
     if (reads.empty()) reads.push_back(0);
@@ -268,9 +275,11 @@ static int launch(bk_handle *h, uint32_t mask)
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if (mask & BK_STAGE_KMER) {
         if (h->n_big < h->n_regions) {
-            const size_t lds = (32 + 256 + 2 * (size_t)h->win_words_cap + h->ref_cap) * 4;
+            // the LDS first holds the read-grouping table (one word per slot, when it fits), then the reference k-mer set
+            const uint32_t lds_words = std::max<uint32_t>(32 + 256 + 2 * h->win_words_cap + h->ref_cap, h->group_words);
+            const size_t lds = (size_t)lds_words * 4;
             HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(bk_kmer_kernel, dim3(h->n_regions), dim3(BK_KT), lds, h->stream, h->params, h->ref_cap, h->win_words_cap);
+            hipLaunchKernelGGL(bk_kmer_kernel, dim3(h->n_regions), dim3(BK_KT), lds, h->stream, h->params, h->ref_cap, h->win_words_cap, lds_words);
             HIPCHK(h, hipGetLastError());
         }
         if (h->n_big > 0) {

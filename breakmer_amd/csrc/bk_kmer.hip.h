@@ -228,12 +228,117 @@ __device__ inline bool bk_kmer_before(uint32_t ca, const BkKey &ka, uint32_t cb,
 #define BK_STAMP(i) do { } while (0)
 #endif
 
+// ---- P1 + P2: group identical reads (utils.py:239-244), unique reads in first-occurrence (FASTQ) order -----------
+// Open-addressing table, slot = (hash tag | smallest read index seen so far): probing reads it with a plain load, only
+// the first read of a sequence does a CAS and only a smaller index an atomicMin, so a duplicate costs one atomicAdd of
+// the count.  LG = true: the table lives in LDS (32-bit slots tag:18|index:14; the copy counts are a second pass that
+// reuses the same words as a histogram once the representatives are known) -- no table initialisation or atomics in
+// global memory; needs n_reads < 16383 and dedup_cap words of LDS, which the reference k-mer set only takes over
+// afterwards.  LG = false: 64-bit slots and 32-bit counts in global memory.
+template <bool LG>
+__device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc &d, uint32_t *scr, uint32_t *lslot)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t N = d.n_reads, RW = d.read_words;
+    const uint32_t *reads = p.reads + d.reads_word_off;
+    const uint16_t *rlen = p.read_len + d.read_meta_off;
+    unsigned long long *dslot = p.dd_slot + d.dedup_off;
+    uint32_t *dcnt = p.dd_cnt + d.dedup_off;
+    uint32_t *gslot = p.grp_slot + d.read_meta_off;
+    if constexpr (LG) { for (uint32_t i = tid; i < d.dedup_cap; i += nt) lslot[i] = BK_EMPTY32; }
+    else for (uint32_t i = tid; i < d.dedup_cap; i += nt) { dslot[i] = BK_EMPTY64; dcnt[i] = 0; }
+    __syncthreads();
+    const uint32_t dmask = d.dedup_cap - 1;
+    for (uint32_t i = tid; i < N; i += nt) {
+        const uint32_t *w = reads + (uint64_t)i * RW; const uint32_t len = rlen[i], nw = (len + 15) / 16;
+        uint32_t wb[BK_RW_MAX]; bk_load_words(w, min(nw, (uint32_t)BK_RW_MAX), wb);
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
+        if (nw <= BK_RW_MAX) {
+#pragma unroll
+            for (int t = 0; t < BK_RW_MAX; t++) if ((uint32_t)t < nw) h = mix64(h ^ wb[t]) + 0x632BE59BD9B4E019ull;
+        } else for (uint32_t t = 0; t < nw; t++) h = mix64(h ^ w[t]) + 0x632BE59BD9B4E019ull;
+        h = mix64(h);
+        const uint32_t tag = LG ? (uint32_t)(h >> 32) & 0x3FFFFu : (uint32_t)(h >> 32); uint32_t s = (uint32_t)h & dmask;
+        const unsigned long long mine = LG ? (unsigned long long)((tag << 14) | i) : (((unsigned long long)tag << 32) | i);
+        for (;;) {
+            unsigned long long cur; bool empty;
+            if constexpr (LG) { uint32_t c32 = *(volatile uint32_t *)&lslot[s]; if (c32 == BK_EMPTY32) c32 = atomicCAS(&lslot[s], BK_EMPTY32, (uint32_t)mine); empty = c32 == BK_EMPTY32; cur = c32; }
+            else { cur = __atomic_load_n(&dslot[s], __ATOMIC_RELAXED); if (cur == BK_EMPTY64) cur = atomicCAS(&dslot[s], BK_EMPTY64, mine); empty = cur == BK_EMPTY64; }
+            if (empty) break;
+            if ((LG ? (uint32_t)cur >> 14 : (uint32_t)(cur >> 32)) == tag) {
+                const uint32_t j = LG ? (uint32_t)cur & 0x3FFFu : (uint32_t)cur; bool same = rlen[j] == len;
+                const uint32_t *wj = reads + (uint64_t)j * RW;
+                if (same) {
+                    if (nw <= BK_RW_MAX) {
+                        uint32_t wo[BK_RW_MAX]; bk_load_words(wj, nw, wo);
+#pragma unroll
+                        for (int t = 0; t < BK_RW_MAX; t++) same = same && wo[t] == wb[t];
+                    } else for (uint32_t t = 0; same && t < nw; t++) same = wj[t] == w[t];
+                }
+                if (same) { if (i < j) { if constexpr (LG) atomicMin(&lslot[s], (uint32_t)mine); else atomicMin(&dslot[s], mine); } break; }
+            }
+            s = (s + 1) & dmask;
+        }
+        gslot[i] = s;
+        if constexpr (!LG) atomicAdd(&dcnt[s], 1u);
+    }
+    __syncthreads();
+#ifdef BK_PHASE_STAMPS
+    if (threadIdx.x == 0) p.work[blockIdx.x].stamps[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    auto rep_of = [&](uint32_t sl) -> uint32_t { if constexpr (LG) return lslot[sl] & 0x3FFFu; else return (uint32_t)dslot[sl]; };
+    auto cnt_of = [&](uint32_t sl) -> uint32_t { if constexpr (LG) return lslot[sl]; else return dcnt[sl]; };
+    uint32_t *urep = p.urep + d.read_meta_off, *unr = p.unreads + d.read_meta_off;
+    uint8_t *ufl = p.uflag + d.read_meta_off;
+    uint32_t *ulen = p.dd_rep + d.dedup_off;                    // length per unique read, for the assembler's find_reads
+    const uint8_t *rflag = p.read_flag + d.read_meta_off;
+    uint32_t U = 0;
+    const uint32_t chunk = (N + nt - 1) / nt, b = tid * chunk, e = min(N, b + chunk);
+    uint32_t c = 0;
+    if (chunk <= 32) {
+        // all loads of the chunk issued back to back (two dependent rounds instead of 2*chunk)
+        uint32_t g[32]; uint32_t isrep = 0;
+#pragma unroll
+        for (int t = 0; t < 32; t++) g[t] = b + t < e ? gslot[b + t] : 0u;
+#pragma unroll
+        for (int t = 0; t < 32; t++) if (b + t < e && rep_of(g[t]) == b + t) isrep |= 1u << t;
+        c = __popc(isrep);
+        if constexpr (LG) {                                     // copy counts: the slot words become a histogram over grp_slot
+            __syncthreads();
+            for (uint32_t i = tid; i < d.dedup_cap; i += nt) lslot[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 32; t++) if (b + t < e) atomicAdd(&lslot[g[t]], 1u);
+            __syncthreads();
+        }
+        uint32_t pre = bk_block_excl_scan(c, scr, &U);
+#pragma unroll
+        for (int t = 0; t < 32; t++) if (isrep & (1u << t)) {
+            const uint32_t i = b + t, sl = g[t];
+            urep[pre] = i; unr[pre] = cnt_of(sl); ufl[pre] = rflag[i] ? BK_R_INDEL : 0; ulen[pre] = rlen[i];
+            p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
+            pre++;
+        }
+    } else {
+        for (uint32_t i = b; i < e; i++) c += rep_of(gslot[i]) == i;
+        uint32_t pre = bk_block_excl_scan(c, scr, &U);
+        for (uint32_t i = b; i < e; i++) if (rep_of(gslot[i]) == i) {
+            uint32_t sl = gslot[i];
+            urep[pre] = i; unr[pre] = cnt_of(sl); ufl[pre] = rflag[i] ? BK_R_INDEL : 0; ulen[pre] = rlen[i];
+            p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
+            pre++;
+        }
+    }
+    __syncthreads();
+    return U;
+}
+
 #define BK_K_PERM_G 16384      // words of LDS sort permutation in the global-table variant
 
 // GLB = false: regions whose window fits the LDS (d.big == 0); GLB = true: the others.  Both kernels are launched
 // over all regions and return at once for regions of the other kind.
 template <bool GLB>
-__device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_t win_words_cap, uint32_t *lds)
+__device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_t win_words_cap, uint32_t lds_words, uint32_t *lds)
 {
     const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const BkRegionDesc d = p.desc[r];
@@ -247,6 +352,15 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     const int W = (int)d.win_len, WK = W >= k ? W - k + 1 : 0;
     const uint32_t *gw = p.windows + d.win_word_off;
     const int ww = (W + 15) / 16;
+    BK_STAMP(1);
+    // ---- P1, P2: read grouping, before the LDS is taken by the reference k-mer set -----------------
+    const uint32_t N = d.n_reads, RW = d.read_words;
+    const uint32_t *reads = p.reads + d.reads_word_off;
+    const uint16_t *rlen = p.read_len + d.read_meta_off;
+    uint32_t *gslot = p.grp_slot + d.read_meta_off;
+    uint32_t *urep = p.urep + d.read_meta_off, *unr = p.unreads + d.read_meta_off;
+    const bool lds_group = N < 16383u && 32u + 16u * 16u + d.dedup_cap <= lds_words;      // N <= 32 per thread: the register-chunk branch of P2
+    const uint32_t U = lds_group ? bk_group_reads<true>(p, d, scr, lds + 32 + 16 * 16) : bk_group_reads<false>(p, d, scr, nullptr);
     BK_STAMP(0);
     // ---- P0: reference k-mer set (sv_processor.py:613-615: forward and reverse file) -------------
     BkRefTabT<GLB> rt; rt.cap_mask = 0; rt.wk = WK; rt.k = k;
@@ -289,88 +403,6 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     for (int i = tid; i < 2 * WK; i += nt) rt.insert((uint32_t)i);
     __syncthreads();
 
-    BK_STAMP(1);
-    // ---- P1: group identical reads (utils.py:239-244) -------------------------------------------
-    const uint32_t N = d.n_reads, RW = d.read_words;
-    const uint32_t *reads = p.reads + d.reads_word_off;
-    const uint16_t *rlen = p.read_len + d.read_meta_off;
-    unsigned long long *dslot = p.dd_slot + d.dedup_off;
-    uint32_t *dcnt = p.dd_cnt + d.dedup_off, *du = p.dd_u + d.dedup_off;
-    uint32_t *gslot = p.grp_slot + d.read_meta_off;
-    for (uint32_t i = tid; i < d.dedup_cap; i += nt) { dslot[i] = BK_EMPTY64; dcnt[i] = 0; }
-    __syncthreads();
-    const uint32_t dmask = d.dedup_cap - 1;
-    // slot word = (hash tag << 32 | smallest read index seen so far): probing reads it with a plain load, only the
-    // first read of a sequence does a CAS and only a smaller index an atomicMin, so a duplicate costs one atomicAdd
-    for (uint32_t i = tid; i < N; i += nt) {
-        const uint32_t *w = reads + (uint64_t)i * RW; const uint32_t len = rlen[i], nw = (len + 15) / 16;
-        uint32_t wb[BK_RW_MAX]; bk_load_words(w, min(nw, (uint32_t)BK_RW_MAX), wb);
-        uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
-        if (nw <= BK_RW_MAX) {
-#pragma unroll
-            for (int t = 0; t < BK_RW_MAX; t++) if ((uint32_t)t < nw) h = mix64(h ^ wb[t]) + 0x632BE59BD9B4E019ull;
-        } else for (uint32_t t = 0; t < nw; t++) h = mix64(h ^ w[t]) + 0x632BE59BD9B4E019ull;
-        h = mix64(h);
-        const uint32_t tag = (uint32_t)(h >> 32); uint32_t s = (uint32_t)h & dmask;
-        const unsigned long long mine = ((unsigned long long)tag << 32) | i;
-        for (;;) {
-            unsigned long long cur = __atomic_load_n(&dslot[s], __ATOMIC_RELAXED);
-            if (cur == BK_EMPTY64) { cur = atomicCAS(&dslot[s], BK_EMPTY64, mine); if (cur == BK_EMPTY64) break; }
-            if ((uint32_t)(cur >> 32) == tag) {
-                const uint32_t j = (uint32_t)cur; bool same = rlen[j] == len;
-                const uint32_t *wj = reads + (uint64_t)j * RW;
-                if (same) {
-                    if (nw <= BK_RW_MAX) {
-                        uint32_t wo[BK_RW_MAX]; bk_load_words(wj, nw, wo);
-#pragma unroll
-                        for (int t = 0; t < BK_RW_MAX; t++) same = same && wo[t] == wb[t];
-                    } else for (uint32_t t = 0; same && t < nw; t++) same = wj[t] == w[t];
-                }
-                if (same) { if (i < j) atomicMin(&dslot[s], mine); break; }
-            }
-            s = (s + 1) & dmask;
-        }
-        gslot[i] = s; atomicAdd(&dcnt[s], 1u);
-    }
-    __syncthreads();
-    BK_STAMP(2);
-    // ---- P2: unique reads in first-occurrence (FASTQ) order = fq_recs iteration order (P4) -------
-    uint32_t *urep = p.urep + d.read_meta_off, *unr = p.unreads + d.read_meta_off;
-    uint8_t *ufl = p.uflag + d.read_meta_off;
-    uint32_t *ulen = p.dd_rep + d.dedup_off;                    // length per unique read, for the assembler's find_reads
-    const uint8_t *rflag = p.read_flag + d.read_meta_off;
-    uint32_t U = 0;
-    {
-        const uint32_t chunk = (N + nt - 1) / nt, b = tid * chunk, e = min(N, b + chunk);
-        uint32_t c = 0;
-        if (chunk <= 32) {
-            // all loads of the chunk issued back to back (two dependent rounds instead of 2*chunk)
-            uint32_t g[32]; uint32_t isrep = 0;
-#pragma unroll
-            for (int t = 0; t < 32; t++) g[t] = b + t < e ? gslot[b + t] : 0u;
-#pragma unroll
-            for (int t = 0; t < 32; t++) if (b + t < e && (uint32_t)dslot[g[t]] == b + t) isrep |= 1u << t;
-            c = __popc(isrep);
-            uint32_t pre = bk_block_excl_scan(c, scr, &U);
-#pragma unroll
-            for (int t = 0; t < 32; t++) if (isrep & (1u << t)) {
-                const uint32_t i = b + t, sl = g[t];
-                urep[pre] = i; unr[pre] = dcnt[sl]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[sl] = pre; ulen[pre] = rlen[i];
-                p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
-                pre++;
-            }
-        } else {
-            for (uint32_t i = b; i < e; i++) c += (uint32_t)dslot[gslot[i]] == i;
-            uint32_t pre = bk_block_excl_scan(c, scr, &U);
-            for (uint32_t i = b; i < e; i++) if ((uint32_t)dslot[gslot[i]] == i) {
-                uint32_t sl = gslot[i];
-                urep[pre] = i; unr[pre] = dcnt[sl]; ufl[pre] = rflag[i] ? BK_R_INDEL : 0; du[sl] = pre; ulen[pre] = rlen[i];
-                p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
-                pre++;
-            }
-        }
-    }
-    __syncthreads();
     BK_STAMP(3);
     // ---- P3a: count non-reference k-mer occurrences over unique reads ---------------------------
     // phase A: reads that simply match the window are recognised with word compares and dropped; the rest
@@ -564,14 +596,14 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     }
 }
 
-extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, uint32_t ref_cap, uint32_t win_words_cap)
+extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel(BkParams p, uint32_t ref_cap, uint32_t win_words_cap, uint32_t lds_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    bk_kmer_body<false>(p, ref_cap, win_words_cap, lds);
+    bk_kmer_body<false>(p, ref_cap, win_words_cap, lds_words, lds);
 }
 // regions with a window beyond the LDS budget: reference set in global memory (LDS: scratch + BK_K_PERM_G words)
 extern "C" __global__ void __launch_bounds__(BK_KT) bk_kmer_kernel_g(BkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    bk_kmer_body<true>(p, 0, 0, lds);
+    bk_kmer_body<true>(p, 0, 0, 32 + 16 * 16 + BK_K_PERM_G, lds);
 }

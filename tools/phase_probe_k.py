@@ -10,6 +10,6 @@ for it in range(3):
     eng.run(hb.BK_STAGE_KMER)
 st = [eng.stat(100 + i) for i in range(12)]
 print("kmer kernel ms", eng.kernel_ms(1), "U", eng.kmers(0)[2], "nslow", st[10])
-seq = [(0, "P0 ref table"), (1, "P1 group"), (2, "P2 compact"), (3, "P3a classify"), (8, "P3a slow count"), (9, "sum"), (4, "P3b alloc+record"), (11, "P3b insert+sc"), (5, "P4 sort"), (6, "P5 postings"), (7, None)]
+seq = [(1, "P1 group"), (2, "P2 compact"), (0, "P0 ref table"), (3, "P3a classify"), (8, "P3a slow count"), (9, "sum"), (4, "P3b alloc+record"), (11, "P3b insert+sc"), (5, "P4 sort"), (6, "P5 postings"), (7, None)]
 for (a, name), (b, _) in zip(seq[:-1], seq[1:]):
     print("%-18s %8.1f us" % (name, (st[b] - st[a]) / 100.0))
