@@ -404,55 +404,37 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     __syncthreads();
 
     BK_STAMP(3);
-    // ---- P3a: count non-reference k-mer occurrences over unique reads ---------------------------
-    // phase A: reads that simply match the window are recognised with word compares and dropped; the rest
-    // (sequencing errors, SV junctions) go on a list (grp_slot is free after P2) and get the full scan
+    // ---- P3a: which unique reads have non-reference k-mers at all -------------------------------------
+    // reads that simply match the window are recognised with word compares and dropped; the rest (sequencing
+    // errors, SV junctions) go on a list (grp_slot is free after P2) and get the full scan
     uint32_t *slow = gslot;
     if (tid == 0) scr[25] = 0;
     __syncthreads();
+    uint32_t myk = 0;                                            // k-mer positions of the listed reads: upper bound of T
     for (uint32_t u = tid; u < U; u += nt) {
         const uint32_t i = urep[u]; const int len = rlen[i];
         bool clean = false;
         if (len <= 16 * BK_RW_MAX) { uint32_t wb[BK_RW_MAX]; bk_load_words(reads + (uint64_t)i * RW, (len + 15) / 16, wb); clean = bk_read_is_clean(wb, len, rt); }
-        if (!clean) slow[atomicAdd(&scr[25], 1u)] = u;
+        if (!clean) { slow[atomicAdd(&scr[25], 1u)] = u; myk += (uint32_t)max(len - k + 1, 0); }
     }
     __syncthreads();
     const uint32_t nslow = scr[25];
     BK_STAMP(8);
-    // the remaining reads: one WAVEFRONT per read, one k-mer position per lane (no seed-and-extend, plain probes):
-    // walking them one read per lane serialises the rare expensive events of 64 different reads
-    uint32_t myc = 0;
     const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
     uint32_t *wst = stage + wv * 16;
-    for (uint32_t q = wv; q < nslow; q += nwv) {
-        const uint32_t u = slow[q], i = urep[u]; const int len = rlen[i];
-        if (len <= 16 * BK_RW_MAX) {
-            const int nwr = (len + 15) / 16;
-            if (lane < 16) wst[lane] = lane < nwr ? reads[(uint64_t)i * RW + lane] : 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            for (int p0 = 0; p0 + k <= len; p0 += 64) {
-                const int pp = p0 + lane;
-                if (pp + k <= len && rt.find(seq_kmer_fast(wst, 16, pp, k)) < 0) myc++;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        } else if (lane == 0) bk_scan_nonref(reads + (uint64_t)i * RW, len, rt, [&](int, const BkKey &) { myc++; });
-    }
     BK_STAMP(9);
 #ifdef BK_PHASE_STAMPS
     if (tid == 0) wk->stamps[10] = nslow;
 #endif
-    const uint32_t T = bk_block_sum(myc, scr);
-    uint32_t tcap = 256; while (tcap < 2 * T) tcap <<= 1;
+    const uint32_t Tmax = bk_block_sum(myk, scr);
     BK_STAMP(4);
-    // ---- P3b: allocate; record (u,pos) triples; insert into the sample k-mer table --------------
-    const uint64_t b1 = (uint64_t)T * 8 + (uint64_t)tcap * 12 + 1024;
-    uint64_t a0 = bk_arena_alloc(p, b1, scr + 20);
+    // ---- P3b: record the (u,pos) occurrences in ONE scan (buffer sized by the upper bound), then size and fill
+    //      the sample k-mer table.  One WAVEFRONT per listed read, one k-mer position per lane (plain probes):
+    //      walking them one read per lane serialises the rare expensive events of 64 different reads.
+    uint64_t a0 = bk_arena_alloc(p, (uint64_t)Tmax * 8 + 1024, scr + 20);
     if (a0 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
-    const uint64_t o_ent = a0, o_tsl = bk_align_up(o_ent + (uint64_t)T * 4, 256), o_tslot = bk_align_up(o_tsl + (uint64_t)T * 4, 256),
-                   o_tcnt = o_tslot + (uint64_t)tcap * 4, o_trank = o_tcnt + (uint64_t)tcap * 4;
+    const uint64_t o_ent = a0, o_tsl = bk_align_up(o_ent + (uint64_t)Tmax * 4, 256);
     uint32_t *t_ent = (uint32_t *)(p.arena + o_ent), *t_sl = (uint32_t *)(p.arena + o_tsl);
-    uint32_t *tslot = (uint32_t *)(p.arena + o_tslot), *tcnt = (uint32_t *)(p.arena + o_tcnt), *trank = (uint32_t *)(p.arena + o_trank);
-    for (uint32_t i = tid; i < tcap; i += nt) { tslot[i] = BK_EMPTY32; tcnt[i] = 0; trank[i] = BK_EMPTY32; }
     if (tid == 0) scr[24] = 0;
     __syncthreads();
     for (uint32_t q = wv; q < nslow; q += nwv) {
@@ -469,6 +451,14 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         } else if (lane == 0) bk_scan_nonref(reads + (uint64_t)i * RW, len, rt, rec);
     }
+    __syncthreads();
+    const uint32_t T = scr[24];
+    uint32_t tcap = 256; while (tcap < 2 * T) tcap <<= 1;
+    uint64_t a0b = bk_arena_alloc(p, (uint64_t)tcap * 12 + 256, scr + 20);
+    if (a0b == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
+    const uint64_t o_tslot = a0b, o_tcnt = o_tslot + (uint64_t)tcap * 4, o_trank = o_tcnt + (uint64_t)tcap * 4;
+    uint32_t *tslot = (uint32_t *)(p.arena + o_tslot), *tcnt = (uint32_t *)(p.arena + o_tcnt), *trank = (uint32_t *)(p.arena + o_trank);
+    for (uint32_t i = tid; i < tcap; i += nt) { tslot[i] = BK_EMPTY32; tcnt[i] = 0; trank[i] = BK_EMPTY32; }
     __syncthreads();
     BK_STAMP(11);
     const uint32_t tmask = tcap - 1;
