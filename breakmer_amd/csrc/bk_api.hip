@@ -369,6 +369,7 @@ extern "C" int bk_sync(bk_handle *h)
 
 static int fetch(bk_handle *h)
 {
+    HIPCHK(h, hipSetDevice(h->dev));                // entry points may be called from any host thread
     int rc = bk_sync(h);
     if (rc != BK_OK) return rc;
     if (h->fetched) return BK_OK;
