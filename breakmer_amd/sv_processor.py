@@ -449,7 +449,8 @@ class runner(object):                                               # sv_process
         if self.engine_factory:
             return self.engine_factory(self.params)
         from . import hip_backend
-        return hip_backend.Engine(kmer_size=self.params.get_kmer_size(), rc_thresh=self.params.get_sr_thresh('min'))
+        dev = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0                # one process per GPU
+        return hip_backend.Engine(kmer_size=self.params.get_kmer_size(), rc_thresh=self.params.get_sr_thresh('min'), device=dev)
 
     def run(self, start_time=None):                                  # :174-209
         names = self.create_targets()

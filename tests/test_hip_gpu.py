@@ -182,6 +182,27 @@ def test_runner_from_alignment_file_gpu(hb, tmp_path):
     assert sp.runner(cfg2, native_calls=False).run() == rows
 
 
+def test_cli_end_to_end_gpu(hb, tmp_path):
+    """`python -m breakmer_amd.breakmer -a <config>` (breakmer.py:50-96): key=value config file on disk, reads from
+    the alignment file, the reference's output files written."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_pipeline import make_sam_inputs
+    from breakmer_amd import breakmer
+    cfg, r = make_sam_inputs(tmp_path)
+    cfg.pop("keep_repeat_regions")
+    (tmp_path / "run.cfg").write_text("".join("%s=%s\n" % kv for kv in cfg.items()))
+    breakmer.main(["-a", "-l", "ERROR", str(tmp_path / "run.cfg")])
+    out = tmp_path / "analysis" / "output"
+    lines = (out / "fromsam_indel_svs.out").read_text().splitlines()
+    assert lines[0].split("\t")[0] == "genes" and len(lines) == 2
+    f = lines[1].split("\t")
+    assert f[0] == r.name and f[1].endswith("(D120)") and f[6] == "indel" and max(int(x) for x in f[10].split(",")) > 0
+    summ = (out / "fromsam_summary.out").read_text().splitlines()
+    assert len(summ) == 2 and summ[1].split("\t")[0] == r.name
+    assert (out / r.name / (r.name + "_indel_svs.out")).is_file()
+
+
 def test_g4_kmer_select_gpu(hb, golden_dir):
     """K1/K2 incl. a separate soft-clip set (case_sc) on the GPU == the reference's set algebra (G4)."""
     d = _load(golden_dir, "kmer_select.json")
