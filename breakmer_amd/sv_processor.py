@@ -348,6 +348,17 @@ class target(object):                                               # sv_process
 
     def clean_reads(self):                                           # :584-606 (cutadapt out of scope) -> bool
         d = self.data
+        # The device path packs A/C/G/T in 2 bits: reads with any other base (N calls of real data) are
+        # left out, with a warning -- a documented deviation from the reference, which keeps them -- instead of failing the run.
+        bad = [n for n, s_ in enumerate(d.read_seqs) if s_.strip("ACGT")]
+        if bad:
+            self.logger.warning('target %s: %d of %d reads contain non-ACGT bases and are skipped' % (self.name, len(bad), len(d.read_seqs)))
+            keep = [n for n in range(len(d.read_seqs)) if n not in set(bad)]
+            d.read_ids = [d.read_ids[n] for n in keep]; d.read_seqs = [d.read_seqs[n] for n in keep]
+            d.indel_only = [d.indel_only[n] for n in keep]
+            if d.quals is not None: d.quals = [d.quals[n] for n in keep]
+        if d.sc_seqs is not None:
+            d.sc_seqs = [x for x in d.sc_seqs if not x.strip("ACGT")]
         q = d.quals
         self.reads = [sv_assembly.fq_read(i, s, (q[n] if q else "I" * len(s)), bool(io)) for n, (i, s, io) in enumerate(zip(d.read_ids, d.read_seqs, d.indel_only))]
         recs = OrderedDict()
