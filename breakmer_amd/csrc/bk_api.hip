@@ -44,7 +44,7 @@ struct bk_handle {
     uint32_t ran_mask = 0;
     // device
     DevBuf d_desc, d_work, d_part, d_reads, d_rlen, d_rflag, d_sc, d_sclen, d_win;
-    DevBuf d_ddslot, d_ddrep, d_ddcnt, d_ddu, d_grp, d_urep, d_unr, d_ufl, d_ubuf, d_ureads, d_ufound, d_uminpos;
+    DevBuf d_ddslot, d_ddrep, d_ddcnt, d_grp, d_urep, d_unr, d_ufl, d_ubuf, d_ureads, d_ufound, d_uminpos;
     DevBuf d_arena, d_out, d_tops;
     uint64_t arena_cap = 0, out_cap = 0;
     uint32_t ref_cap = 0, win_words_cap = 0;
@@ -104,7 +104,7 @@ extern "C" int bk_destroy(bk_handle *h)
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
-                      &h->d_ddu, &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops};
+                      &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops};
     for (auto b : bufs) b->release();
     h->h_out.release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -227,7 +227,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     HIPCHK(h, upload(h, h->d_sc, sc)); HIPCHK(h, upload(h, h->d_sclen, sclen)); HIPCHK(h, upload(h, h->d_win, win));
     const size_t nr = std::max<size_t>(h->total_reads, 1), nd = std::max<uint64_t>(dd_total, 1);
     HIPCHK(h, h->d_work.ensure(sizeof(BkRegionWork) * n_regions));
-    HIPCHK(h, h->d_ddslot.ensure(nd * 8)); HIPCHK(h, h->d_ddrep.ensure(nd * 4)); HIPCHK(h, h->d_ddcnt.ensure(nd * 4)); HIPCHK(h, h->d_ddu.ensure(nd * 4));
+    HIPCHK(h, h->d_ddslot.ensure(nd * 8)); HIPCHK(h, h->d_ddrep.ensure(nd * 4)); HIPCHK(h, h->d_ddcnt.ensure(nd * 4));
     HIPCHK(h, h->d_grp.ensure(nr * 4)); HIPCHK(h, h->d_urep.ensure(nr * 4)); HIPCHK(h, h->d_unr.ensure(nr * 4)); HIPCHK(h, h->d_ufl.ensure(nr));
     HIPCHK(h, h->d_ubuf.ensure(nr * 4)); HIPCHK(h, h->d_ureads.ensure(nr * 4)); HIPCHK(h, h->d_ufound.ensure(nr * 4)); HIPCHK(h, h->d_uminpos.ensure(nr * 4));
     HIPCHK(h, h->d_tops.ensure(256));
@@ -251,7 +251,7 @@ static void fill_params(bk_handle *h)
     p.desc = (const BkRegionDesc *)h->d_desc.p; p.work = (BkRegionWork *)h->d_work.p; p.partners = (const BkPartnerDesc *)h->d_part.p;
     p.reads = (const uint32_t *)h->d_reads.p; p.read_len = (const uint16_t *)h->d_rlen.p; p.read_flag = (const uint8_t *)h->d_rflag.p;
     p.sc = (const uint32_t *)h->d_sc.p; p.sc_len = (const uint16_t *)h->d_sclen.p; p.windows = (const uint32_t *)h->d_win.p;
-    p.dd_slot = (unsigned long long *)h->d_ddslot.p; p.dd_rep = (uint32_t *)h->d_ddrep.p; p.dd_cnt = (uint32_t *)h->d_ddcnt.p; p.dd_u = (uint32_t *)h->d_ddu.p;
+    p.dd_slot = (unsigned long long *)h->d_ddslot.p; p.dd_rep = (uint32_t *)h->d_ddrep.p; p.dd_cnt = (uint32_t *)h->d_ddcnt.p;
     p.grp_slot = (uint32_t *)h->d_grp.p; p.urep = (uint32_t *)h->d_urep.p; p.unreads = (uint32_t *)h->d_unr.p; p.uflag = (uint8_t *)h->d_ufl.p;
     p.ubuf = (int32_t *)h->d_ubuf.p; p.ureads = (int32_t *)h->d_ureads.p; p.ufound = (int32_t *)h->d_ufound.p; p.uminpos = (int32_t *)h->d_uminpos.p;
     p.arena = (uint8_t *)h->d_arena.p; p.arena_top = (unsigned long long *)h->d_tops.p; p.arena_cap = h->arena_cap;

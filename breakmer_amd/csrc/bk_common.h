@@ -149,7 +149,7 @@ struct BkParams {
     const uint32_t *sc; const uint16_t *sc_len;
     const uint32_t *windows;
     // read grouping (sized by total reads / total dedup slots)
-    unsigned long long *dd_slot; uint32_t *dd_rep, *dd_cnt, *dd_u;     // dd_rep doubles as ulen[] (unique-read lengths, indexed from dedup_off)
+    unsigned long long *dd_slot; uint32_t *dd_rep, *dd_cnt;            // dd_rep holds ulen[] (unique-read lengths, indexed from dedup_off)
     uint32_t *grp_slot;
     // unique-read arrays (indexed read_meta_off + u)
     uint32_t *urep, *unreads; uint8_t *uflag; int32_t *ubuf, *ureads, *ufound, *uminpos;
