@@ -267,6 +267,13 @@ def test_config4_config5_shapes_gpu(hb):
     for i, r in enumerate(regs):
         want, _ = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
         assert _strip(eng.contigs(i)) == want, ("cfg4", i)
+    # one region at the FULL configs[3] depth (20,000 reads: beyond the in-LDS read-grouping table -> global-memory table)
+    big = synth.make_region(310, sv_type="del", depth=1000, W=3000, L=150)
+    assert big.reads.shape[0] == 20000
+    eng = _run_regions(hb, [big], 31, stages=7)
+    want, info = bo.assemble_region(big.read_strs(), [big.window_str], 31, 2)
+    assert eng.kmers(0)[0] == [m for m, _ in sorted(zip(info["mers"], info["counts"].tolist()), key=lambda x: (x[1], x[0]), reverse=True)]
+    assert _strip(eng.contigs(0)) == want and eng.hits(0, 0) == bo.realign(want[0]["seq"], [big.window_str])
     regs = [synth.make_region(400 + i, sv_type="del", depth=100, W=700, L=250, noise=0.05) for i in range(3)]
     eng = _run_regions(hb, regs, 41, stages=7)
     for i, r in enumerate(regs):
