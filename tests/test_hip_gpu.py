@@ -367,6 +367,23 @@ def test_noisy_regions_and_both_arenas_grow_gpu(hb):
             assert eng.hits(i, ci) == bo.realign(want[ci]["seq"], [regions[i].window_str]), (i, ci)
 
 
+def test_long_reads_gpu(hb):
+    """Reads beyond 256 bp (the register fast paths of the k-mer kernel end there) up to ~900 bp, incl. noise and
+    trimmed ends: grouping, k-mer selection, assembly (multi-tile DPs) and realignment against the oracle."""
+    from oracle import bk_oracle as bo
+    regs = [synth.make_region(950, sv_type="del", depth=40, W=2400, L=400),
+            synth.make_region(951, sv_type="ins", depth=40, W=2400, L=400, noise=0.01, var_len=0.3),
+            synth.make_region(952, sv_type="del", depth=30, W=4000, L=900, sv_size=300)]
+    eng = _run_regions(hb, regs, 31, stages=7)
+    for i, r in enumerate(regs):
+        want, info = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
+        assert len(want) >= 1, i
+        assert eng.kmers(i)[0] == [m for m, _ in sorted(zip(info["mers"], info["counts"].tolist()), key=lambda x: (x[1], x[0]), reverse=True)], i
+        assert _strip(eng.contigs(i)) == want, i
+        for ci, c in enumerate(want[:4]):
+            assert eng.hits(i, ci) == bo.realign(c["seq"], [r.window_str]), (i, ci)
+
+
 def test_arena_growth_and_rerun_gpu(hb):
     """A deliberately tiny scratch arena: the library must notice the overflow, grow the arena and rerun --
     results identical to a run with the default arena; repeated bk_run on one handle is idempotent."""
