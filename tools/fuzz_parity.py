@@ -16,7 +16,7 @@ bad = 0
 t0 = time.time()
 done = 0
 while done < n:
-    k = int(rng.choice([15, 21, 31, 41]))
+    k = int(rng.choice([int(x) for x in os.environ.get("BK_FUZZ_K", "15,21,31,41").split(",")]))
     rc = int(rng.choice([2, 3]))
     batch = []
     for _ in range(min(16, n - done)):
