@@ -680,11 +680,34 @@ __device__ __forceinline__ void bk_grow()
         BK_SYNC();
         BK_ACC(13);
         if (T == 0) break;
+        // Visits without any candidate read in bulk.  Within one contig the candidate set of a k-mer only shrinks
+        // (reads get buffered or deleted, never the reverse), so a k-mer whose short posting list holds no eligible read
+        // now has none when its turn comes, and such a visit does nothing but mark the k-mer used and checked
+        // (get_mer_reads :604-614 returns [], check_alt_reads has nothing to do).  With sequencing noise that is the
+        // majority of all visits.  The founder read joins the read list first, as the first finalize would do (:383).
+        if (BK_TID == 0 && !S->founder_added) {
+            S->founder_added = 1; const int fu = S->founder;
+            if (C_.ureads[fu] != S->serial) { C_.ureads[fu] = S->serial; C_.readl[S->nr++] = (uint32_t)fu; }
+        }
+        for (uint32_t t = BK_TID; t < T; t += BK_AT) {
+            const int rank = (int)(C_.nklist[t] & 0x7FFFFFFFu);
+            const uint32_t pb = C_.poff[rank], pe = C_.poff[rank + 1];
+            bool has = pe - pb > 16u;                                             // long lists take the ordinary visit
+            for (uint32_t i = pb; !has && i < pe; i++) { const uint32_t u = C_.post[i] >> 10; has = !(C_.ufl[u] & BK_R_DELETED) && C_.ubuf[u] != S->serial; }
+            if (!has) {
+                if (atomicExch(&C_.kstamp[3 * rank], S->serial) != S->serial && C_.kstate[rank] == BK_K_LIVE) {   // once per k-mer (it may be listed twice)
+                    C_.kstate[rank] = BK_K_USED; C_.usedl[atomicAdd(&S->nused, 1)] = (uint32_t)rank;
+                }
+                C_.nklist[t] = BK_EMPTY32;
+            }
+        }
+        BK_SYNC();
         uint32_t en_next = C_.nklist[0];
         for (uint32_t t = 0; t < T; t++) {
             if (S->status) return;
             const uint32_t en = en_next; const int rank = (int)(en & 0x7FFFFFFFu); const bool rev = (en >> 31) != 0;
             if (t + 1 < T) en_next = C_.nklist[t + 1];                           // fetched a whole visit ahead of its use
+            if (en == BK_EMPTY32) continue;                                       // handled in bulk above
             bk_find_reads(rank, rev, true);                                    // get_mer_reads :604-614
             if (BK_TID == 0) bk_add_used_mer(rank);
             BK_SYNC();
