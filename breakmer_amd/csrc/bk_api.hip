@@ -298,9 +298,9 @@ static int launch(bk_handle *h, uint32_t mask)
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if (mask & BK_STAGE_REALIGN) {
-        // target staging buffer: the whole window when it is short, else chunks of diagonals (>= 2 * max_contig bases)
-        const uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)h->cfg.max_contig_len + 16, std::max<uint32_t>(32768, 4 * (uint32_t)h->cfg.max_contig_len));
-        const size_t lds = ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + tw_cap + 15) / 16) * 16 + 4 * (2 * ((size_t)h->cfg.max_contig_len / 16 + 2) + tw_cap / 16 + 8);
+        // target staging buffer (packed, 4 bases per byte): the whole window when it fits, else chunks of diagonals
+        const uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)h->cfg.max_contig_len + 16, std::max<uint32_t>(262144, 4 * (uint32_t)h->cfg.max_contig_len));
+        const size_t lds = ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + 15) / 16) * 16 + 4 * (2 * ((size_t)h->cfg.max_contig_len / 16 + 2) + tw_cap / 16 + 8);
         HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bk_sw_kernel, dim3(h->n_regions), dim3(BK_ST_T), lds, h->stream, h->params, tw_cap);
         HIPCHK(h, hipGetLastError());

@@ -11,7 +11,8 @@
 // Per staged target chunk: (1) U of every diagonal, (2) the diagonals with the block-wide largest
 // U are walked and raise the lower bound L (an achieved score), (3) every diagonal with U >= L is
 // walked.  A diagonal with U < L cannot hold the maximum, ties (U == L) are walked, so the result
-// equals the brute-force scan.  Sequences are staged in LDS as bytes (walks) and words (counts).
+// equals the brute-force scan.  Query interval and target are staged in LDS as packed words; the target stays staged
+// across passes and contigs while it is the same chunk.
 // One workgroup per region; contigs and query intervals are processed in sequence.
 // Chaining of collinear hits into PSL records is host code (bk_api.hip), restated in the oracle.
 #pragma once
@@ -27,6 +28,7 @@ struct BkSwShared {
     unsigned long long best_key; int best_run;
     unsigned long long cells;
     int L, umax;                 // lower bound on the pass maximum (an achieved score); block maximum of U
+    int staged_ti, staged_t0, staged_t1;   // which target bases the packed staging buffer currently holds
     unsigned long long rec_off;
     int status;
 };
@@ -59,15 +61,34 @@ __device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *tp,
     }
     return u;
 }
-// walk one diagonal: best positive run (strict '>': smallest query end among equal scores)
-__device__ inline void bk_sw_walk(const uint8_t *q, const uint8_t *t, int n, int m, int off, int &bh, int &ba, int &br)
+// walk one diagonal on the packed words: best positive run (strict '>': smallest query end among equal scores).  Inside
+// a run of matches the score rises strictly, so only the end of each run can become the new best: the loop advances
+// from mismatch to mismatch (count-leading-zeros on the mismatch mask) instead of base by base.
+__device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int &bh, int &ba, int &br)
 {
-    int a = off < 0 ? -off : 0, b = a + off, h = 0, run = 0;
+    const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
+    int h = 0, run = 0;
     bh = 0; ba = 0; br = 0;
-    for (; a < n && b < m; a++, b++) {
-        h += (q[a] == t[b]) ? 1 : -2; run++;
-        if (h <= 0) { h = 0; run = 0; }
-        else if (h > bh) { bh = h; ba = a + 1; br = run; }
+    if (a1 <= a0) return;
+    for (int wq = a0 >> 4; wq <= (a1 - 1) >> 4; wq++) {
+        const int aw = wq << 4, pb = aw + off;
+        const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
+        const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
+        const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
+        const uint32_t x = qp[wq] ^ tb;
+        const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
+        uint32_t stop = (x | (x >> 1) | (hi < 16 ? 0xFFFFFFFFu >> (2 * hi) : 0u)) & 0x55555555u;   // mismatches and everything from `hi` on
+        int pos = lo;
+        while (pos < hi) {
+            const uint32_t rest = stop & (0xFFFFFFFFu >> (2 * pos));
+            const int ts = rest ? (__clz((int)rest) - 1) >> 1 : 16;           // first non-matching position >= pos
+            const int r = ts - pos;
+            if (r > 0) { h += r; run += r; if (h > bh) { bh = h; ba = aw + ts; br = run; } }
+            if (ts >= hi) break;
+            h -= 2; run++;
+            if (h <= 0) { h = 0; run = 0; }
+            pos = ts + 1;
+        }
     }
 }
 
@@ -81,11 +102,10 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
     BkSwShared *S = (BkSwShared *)sl;
     uint8_t *qf = sl + ((sizeof(BkSwShared) + 15) / 16) * 16;          // contig forward (codes)
     uint8_t *qr = qf + p.max_contig;                                   // contig reverse complement
-    uint8_t *tw = qr + p.max_contig;                                   // current target chunk, bytes
-    uint32_t *qpk = (uint32_t *)(sl + ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)p.max_contig + tw_cap + 15) / 16) * 16);   // packed query interval, both strands
+    uint32_t *qpk = (uint32_t *)(sl + ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)p.max_contig + 15) / 16) * 16);   // packed query interval, both strands
     const int qpw = p.max_contig / 16 + 2;
-    uint32_t *tp = qpk + 2 * qpw;                                      // current target chunk, packed words
-    if (tid == 0) { S->cells = 0; S->status = 0; S->rec_off = wk->o_first_contig; }
+    uint32_t *tp = qpk + 2 * qpw;                                      // staged target chunk, packed words (kept across passes and contigs)
+    if (tid == 0) { S->cells = 0; S->status = 0; S->rec_off = wk->o_first_contig; S->staged_ti = -1; S->staged_t0 = 0; S->staged_t1 = 0; }
     __syncthreads();
     while (S->rec_off != 0) {
         const unsigned long long roff = S->rec_off;
@@ -121,9 +141,10 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     const int o1 = min(o0 + CH, m), t0 = max(o0, 0), t1 = min(m, o1 - 1 + n);
                     const int tpw0 = t0 >> 4, tpn = ((t1 + 15) >> 4) - tpw0;
                     __syncthreads();
-                    for (int i = t0 + tid; i < t1; i += BK_ST_T) tw[i - t0] = (uint8_t)seq_base(gw, i);
-                    for (int i = tid; i < tpn; i += BK_ST_T) tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u;
-                    if (tid == 0) S->umax = 0;
+                    const bool staged = S->staged_ti == ti && S->staged_t0 == t0 && S->staged_t1 == t1;   // e.g. one short window: staged once per region
+                    __syncthreads();
+                    if (!staged) for (int i = tid; i < tpn; i += BK_ST_T) tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u;
+                    if (tid == 0) { S->umax = 0; S->staged_ti = ti; S->staged_t0 = t0; S->staged_t1 = t1; }
                     __syncthreads();
                     const int nd = o1 - o0;
                     // (1) match counts; this thread's best diagonal
@@ -139,7 +160,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     int walked = -1;
                     if (myu == S->umax && myu >= S->L && myu > 0) {
                         const int st = myD >= nd, off = o0 + (st ? myD - nd : myD);
-                        int bh, ba, br; bk_sw_walk(st ? qr + (Q - qe) : qf + qs, tw - t0, n, m, off, bh, ba, br);
+                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, tp, tpw0, tpn, n, m, off, bh, ba, br);
                         if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } atomicMax(&S->L, bh); }
                         walked = myD;
                     }
@@ -150,7 +171,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                         if (D == walked) continue;
                         const int u = bk_sw_diag_matches(qpk + st * qpw, tp, tpw0, tpn, n, m, off);
                         if (u < *(volatile int *)&S->L || u == 0) continue;
-                        int bh, ba, br; bk_sw_walk(st ? qr + (Q - qe) : qf + qs, tw - t0, n, m, off, bh, ba, br);
+                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, tp, tpw0, tpn, n, m, off, bh, ba, br);
                         if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } if (bh > *(volatile int *)&S->L) atomicMax(&S->L, bh); }
                     }
                 }
