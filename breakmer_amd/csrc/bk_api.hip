@@ -408,13 +408,19 @@ extern "C" int bk_get_kmers(bk_handle *h, int32_t region, char *mers, int32_t *c
     if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
     int rc = bk_sync(h); if (rc != BK_OK) return rc;
     const BkRegionWork &w = h->h_work[region];
-    const int n = std::min<int>((int)w.M, cap), k = h->cfg.kmer_size;
+    const int M = (int)w.M, n = std::min<int>(M, cap), k = h->cfg.kmer_size;
     if (n <= 0) return BK_OK;
-    std::vector<uint64_t> lo(n), hi(n); std::vector<uint32_t> c(n);
-    HIPCHK(h, hipMemcpy(lo.data(), (uint8_t *)h->d_arena.p + w.o_key_lo, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(hi.data(), (uint8_t *)h->d_arena.p + w.o_key_hi, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(c.data(), (uint8_t *)h->d_arena.p + w.o_kcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; i++) { if (mers) key_to_str(lo[i], hi[i], k, mers + (size_t)i * k); if (counts) counts[i] = (int32_t)c[i]; }
+    std::vector<uint64_t> lo(M), hi(M); std::vector<uint32_t> c(M);
+    HIPCHK(h, hipMemcpy(lo.data(), (uint8_t *)h->d_arena.p + w.o_key_lo, (size_t)M * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(hi.data(), (uint8_t *)h->d_arena.p + w.o_key_hi, (size_t)M * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(c.data(), (uint8_t *)h->d_arena.p + w.o_kcnt, (size_t)M * 4, hipMemcpyDeviceToHost));
+    // the device orders the k-mers that can seed a contig (count >= 2) by (count, mer) descending and leaves the
+    // count-1 k-mers behind them in table order (nothing on the device depends on their order); the API returns
+    // the whole list in the order init_assembly visits it (sv_assembly.py:281)
+    std::vector<int> ord(M);
+    for (int i = 0; i < M; i++) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { if (c[a] != c[b]) return c[a] > c[b]; if (hi[a] != hi[b]) return hi[a] > hi[b]; return lo[a] > lo[b]; });
+    for (int i = 0; i < n; i++) { const int j = ord[i]; if (mers) key_to_str(lo[j], hi[j], k, mers + (size_t)i * k); if (counts) counts[i] = (int32_t)c[j]; }
     return BK_OK;
 }
 

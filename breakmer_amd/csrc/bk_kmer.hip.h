@@ -496,16 +496,21 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         __syncthreads();
     }
     BK_STAMP(5);
-    // ---- P4: compact -> M sample-only k-mers, order by (count, mer) descending -------------------
-    uint32_t M = 0;
+    // ---- P4: compact -> M sample-only k-mers.  Those that can seed a contig (count >= 2, init_assembly :46) come
+    //      first, ordered by (count, mer) descending; the count-1 k-mers follow in table order: they are looked up and
+    //      recruit reads like the others, but nothing depends on their order, so they are not sorted (with sequencing
+    //      noise they are > 95 % of the set).
+    uint32_t M = 0, M2 = 0;
     {
         const uint32_t chunk = (tcap + nt - 1) / nt, b = tid * chunk, e = min(tcap, b + chunk);
-        uint32_t c = 0;
-        for (uint32_t i = b; i < e; i++) c += tslot[i] < BK_EMPTY32 - 1;
-        uint32_t pre = bk_block_excl_scan(c, scr, &M);
-        for (uint32_t i = b; i < e; i++) if (tslot[i] < BK_EMPTY32 - 1) trank[i] = pre++;    // provisional rank = compaction index
+        uint32_t c2 = 0, c1 = 0, tot1 = 0;
+        for (uint32_t i = b; i < e; i++) if (tslot[i] < BK_EMPTY32 - 1) { if (tcnt[i] >= 2) c2++; else c1++; }
+        uint32_t pre2 = bk_block_excl_scan(c2, scr, &M2);
+        uint32_t pre1 = bk_block_excl_scan(c1, scr, &tot1);
+        M = M2 + tot1;
+        for (uint32_t i = b; i < e; i++) if (tslot[i] < BK_EMPTY32 - 1) trank[i] = tcnt[i] >= 2 ? pre2++ : M2 + pre1++;    // provisional rank = compaction index
     }
-    uint32_t npad = 1; while (npad < M) npad <<= 1;
+    uint32_t npad = 1; while (npad < M2) npad <<= 1;
     const bool perm_in_lds = npad <= perm_cap;                 // else the permutation is sorted in global memory (slow path)
     const uint64_t b2 = (uint64_t)M * (8 + 8 + 4 + 1 + 12 + 4 + 4) + (uint64_t)T * 4 + 4096 + (perm_in_lds ? 0 : (uint64_t)npad * 4);
     uint64_t a1 = bk_arena_alloc(p, b2, scr + 20);
@@ -526,7 +531,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     }
     __syncthreads();
     {
-        for (uint32_t i = tid; i < npad; i += nt) perm[i] = i < M ? i : BK_EMPTY32;
+        for (uint32_t i = tid; i < npad; i += nt) perm[i] = i < M2 ? i : BK_EMPTY32;
         __syncthreads();
         for (uint32_t sz = 2; sz <= npad; sz <<= 1)
             for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
@@ -547,11 +552,11 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     {
         uint64_t *s64 = (uint64_t *)kstamp;                     // M*8 of the M*12 stamp bytes
         uint32_t *s32 = poff;                                   // (M+1)*4
-        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = perm[j]; s64[j] = klo[a]; s32[j] = kcnt[a]; }
+        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = j < M2 ? perm[j] : j; s64[j] = klo[a]; s32[j] = kcnt[a]; }
         __syncthreads();
         for (uint32_t j = tid; j < M; j += nt) { klo[j] = s64[j]; kcnt[j] = s32[j]; }
         __syncthreads();
-        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = perm[j]; s64[j] = khi[a]; s32[j] = ptmp[a]; }
+        for (uint32_t j = tid; j < M; j += nt) { uint32_t a = j < M2 ? perm[j] : j; s64[j] = khi[a]; s32[j] = ptmp[a]; }
         __syncthreads();
         for (uint32_t j = tid; j < M; j += nt) { khi[j] = s64[j]; trank[s32[j]] = j; ptmp[j] = 0; }
         __syncthreads();
