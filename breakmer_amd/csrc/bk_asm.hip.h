@@ -680,34 +680,52 @@ __device__ __forceinline__ void bk_grow()
         BK_SYNC();
         BK_ACC(13);
         if (T == 0) break;
-        // Visits without any candidate read in bulk.  Within one contig the candidate set of a k-mer only shrinks
-        // (reads get buffered or deleted, never the reverse), so a k-mer whose short posting list holds no eligible read
-        // now has none when its turn comes, and such a visit does nothing but mark the k-mer used and checked
-        // (get_mer_reads :604-614 returns [], check_alt_reads has nothing to do).  With sequencing noise that is the
-        // majority of all visits.  The founder read joins the read list first, as the first finalize would do (:383).
+        // Visits without any candidate read.  Within one contig the candidate set of a k-mer only shrinks (reads get
+        // buffered or deleted, never the reverse), so a k-mer whose short posting list holds no eligible read now has
+        // none when its turn comes, and such a visit does nothing but mark the k-mer checked and, AT ITS TURN (the
+        // used set is read by check_alt_reads of the visits before it), used (get_mer_reads :604-614 returns []).
+        // With sequencing noise that is the majority of all visits: they are found here for the whole snapshot at once
+        // (bit 30 of the entry), and the loop below retires whole runs of them with one wavefront.
+        // The founder read joins the read list first, as the first finalize would do (:383).
         if (BK_TID == 0 && !S->founder_added) {
             S->founder_added = 1; const int fu = S->founder;
             if (C_.ureads[fu] != S->serial) { C_.ureads[fu] = S->serial; C_.readl[S->nr++] = (uint32_t)fu; }
         }
         for (uint32_t t = BK_TID; t < T; t += BK_AT) {
-            const int rank = (int)(C_.nklist[t] & 0x7FFFFFFFu);
+            const uint32_t en = C_.nklist[t]; const int rank = (int)(en & 0x3FFFFFFFu);
             const uint32_t pb = C_.poff[rank], pe = C_.poff[rank + 1];
             bool has = pe - pb > 16u;                                             // long lists take the ordinary visit
             for (uint32_t i = pb; !has && i < pe; i++) { const uint32_t u = C_.post[i] >> 10; has = !(C_.ufl[u] & BK_R_DELETED) && C_.ubuf[u] != S->serial; }
-            if (!has) {
-                if (atomicExch(&C_.kstamp[3 * rank], S->serial) != S->serial && C_.kstate[rank] == BK_K_LIVE) {   // once per k-mer (it may be listed twice)
-                    C_.kstate[rank] = BK_K_USED; C_.usedl[atomicAdd(&S->nused, 1)] = (uint32_t)rank;
-                }
-                C_.nklist[t] = BK_EMPTY32;
-            }
+            if (!has) { C_.kstamp[3 * rank] = S->serial; C_.nklist[t] = en | 0x40000000u; }       // checked_kmers is only read by the next snapshot
         }
         BK_SYNC();
-        uint32_t en_next = C_.nklist[0];
-        for (uint32_t t = 0; t < T; t++) {
+        uint32_t t = 0, en_next = C_.nklist[0];
+        while (t < T) {
             if (S->status) return;
-            const uint32_t en = en_next; const int rank = (int)(en & 0x7FFFFFFFu); const bool rev = (en >> 31) != 0;
-            if (t + 1 < T) en_next = C_.nklist[t + 1];                           // fetched a whole visit ahead of its use
-            if (en == BK_EMPTY32) continue;                                       // handled in bulk above
+            const uint32_t en = en_next; const int rank = (int)(en & 0x3FFFFFFFu); const bool rev = (en >> 31) != 0;
+            if (en & 0x40000000u) {
+                // a run of candidate-less visits, in order: used_mers.add(mer) for each k-mer not yet in it
+                if ((BK_TID >> 6) == 0) {
+                    const uint32_t idx = t + BK_TID;
+                    const uint32_t e2 = idx < T ? C_.nklist[idx] : 0u;
+                    const unsigned long long bm = __ballot((e2 & 0x40000000u) != 0);
+                    const int run = ~bm ? __ffsll((long long)~bm) - 1 : 64;                  // entries t .. t+run-1 are candidate-less
+                    const bool in_run = BK_TID < run;
+                    const int rk = (int)(e2 & 0x3FFFFFFFu);
+                    bool ap = in_run && C_.kstate[in_run ? rk : 0] == BK_K_LIVE;
+                    for (int j = 0; j < run; j++) { const int rj = __builtin_amdgcn_readlane(rk, j); if (j < BK_TID && rj == rk) ap = false; }   // listed twice: once
+                    const unsigned long long am = __ballot(ap);
+                    if (ap) { C_.kstate[rk] = BK_K_USED; C_.usedl[S->nused + __popcll(am & ((1ull << BK_TID) - 1ull))] = (uint32_t)rk; }
+                    if (BK_TID == 0) { S->nused += __popcll(am); S->tmp1 = run; }
+                }
+                BK_SYNC();
+                t += (uint32_t)S->tmp1;
+                if (t < T) en_next = C_.nklist[t];
+                BK_SYNC();
+                continue;
+            }
+            t++;
+            if (t < T) en_next = C_.nklist[t];                                     // fetched a whole visit ahead of its use
             bk_find_reads(rank, rev, true);                                    // get_mer_reads :604-614
             if (BK_TID == 0) bk_add_used_mer(rank);
             BK_SYNC();
