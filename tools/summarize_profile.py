@@ -17,7 +17,7 @@ KERNELS = ("bk_kmer_kernel", "bk_kmer_kernel_g", "bk_asm_kernel", "bk_sw_kernel"
 
 def one(pattern):
     fs = glob.glob(os.path.join(src, pattern), recursive=True)
-    return fs[0] if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None        # gpurun merges every call's files: take the latest
 
 
 st = one("stats/**/*_kernel_stats.csv")
