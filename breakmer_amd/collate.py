@@ -28,9 +28,8 @@ def all_gather_bytes(payload: bytes, device=None):
 
 
 def collate_results(results, summary, device=None):
-    """runner hook: merge (results, summary) of all ranks; ranks own consecutive blocks of the sorted
-    target names, so concatenation in rank order keeps the reference's output order
-    (sv_processor.py:175-176, 212-224)."""
+    """runner hook: merge (results, summary) of all ranks (concatenated in rank order; the runner tags every
+    row with its target's position and restores the reference's output order, sv_processor.py:175-176, 212-224)."""
     parts = all_gather_bytes(json.dumps({"r": results, "s": summary}).encode(), device)
     all_results, all_summary = [], {}
     for p in parts:

@@ -465,7 +465,10 @@ class runner(object):                                               # sv_process
 
     def run(self, start_time=None):                                  # :174-209
         names = self.create_targets()
-        mine = [n for i, n in enumerate(names) if (i * self.world) // max(len(names), 1) == self.rank]      # block partition
+        # striped partition over the sorted target names: heavy targets tend to be neighbours (gene families,
+        # translocation partners), stripes spread them; the rows are put back into target order after the collation
+        order = {n: i for i, n in enumerate(names)}
+        mine = [n for i, n in enumerate(names) if i % self.world == self.rank]
         live = []
         for n in mine:
             t = self.targets[n]
@@ -503,11 +506,13 @@ class runner(object):                                               # sv_process
             if t.has_results():
                 if 'output' in t.paths:
                     t.write_results()
-                self.results.extend(t.results)
+                self.results.extend([order[t.name], r] for r in t.results)
             else:
                 t.rm_output_dir()
         if self.collate is not None and self.world > 1:               # collate per-region rows over ranks (RCCL all-gather)
             self.results, self.summary = self.collate(self.results, self.summary)
+        self.results.sort(key=lambda x: x[0])                         # stable: target order (sv_processor.py:175-176), rows of a target as produced
+        self.results = [r for _i, r in self.results]
         if self.rank == 0 and 'output' in self.params.paths:
             self.write_output()
         return self.results
