@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <cstdlib>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -159,11 +160,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         d.max_len = maxl;
         d.reads_word_off = reads.size(); d.read_meta_off = rlen.size();
         reads.resize(reads.size() + (size_t)d.n_reads * d.read_words);
-        for (int i = 0; i < g.n_reads; i++) {
-            if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words))
-                return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + " read " + std::to_string(i) + ": non-ACGT base (unsupported)");
-            rlen.push_back(g.read_lens[i]); rflag.push_back(g.indel_only ? g.indel_only[i] : 0);
-        }
+        for (int i = 0; i < g.n_reads; i++) { rlen.push_back(g.read_lens[i]); rflag.push_back(g.indel_only ? g.indel_only[i] : 0); }   // the reads themselves are packed below, in parallel
         d.n_sc = g.n_sc < 0 ? -1 : g.n_sc; d.sc_word_off = sc.size(); d.sc_meta_off = sclen.size(); d.sc_words = 1;
         if (g.n_sc > 0) {
             uint32_t ms = 0; for (int i = 0; i < g.n_sc; i++) ms = std::max<uint32_t>(ms, g.sc_lens[i]);
@@ -192,6 +189,22 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         // algorithmic HBM bytes per region: 2-bit reads + 4 B/read offsets + window fwd+rc + ~2 KB of output
         uint64_t bases = 0; for (int i = 0; i < g.n_reads; i++) bases += g.read_lens[i];
         h->alg_bytes += (bases + 3) / 4 + 4ull * g.n_reads + 2ull * ((g.window_len + 3) / 4) + 2048;
+    }
+    {   // 2-bit packing of the reads: the bulk of the host work of a submit (0.4 GB of ASCII for 256 regions), regions are independent
+        std::atomic<int> next{0}, bad_region{-1}, bad_read{-1};
+        auto pack = [&]() {
+            for (;;) {
+                const int r = next.fetch_add(1);
+                if (r >= n_regions) break;
+                const bk_region &g = regions[r]; const BkRegionDesc &d = h->h_desc[r];
+                for (int i = 0; i < g.n_reads; i++)
+                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
+            }
+        };
+        const int nth = std::max(1, std::min<int>({8, (int)std::thread::hardware_concurrency(), n_regions}));
+        if (nth == 1) pack();
+        else { std::vector<std::thread> th; for (int t = 0; t < nth; t++) th.emplace_back(pack); for (auto &x : th) x.join(); }
+        if (bad_region >= 0) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_region.load()) + " read " + std::to_string(bad_read.load()) + ": non-ACGT base (unsupported)");
     }
     h->total_reads = rlen.size(); h->n_regions = n_regions;
     { uint32_t mx = 0; for (auto &d : h->h_desc) mx = std::max(mx, d.max_len); h->eff_max_read = (int)std::min<uint32_t>((uint32_t)h->cfg.max_read_len, std::max<uint32_t>(64, (mx + 63) / 64 * 64)); }
