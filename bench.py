@@ -99,10 +99,9 @@ def main():
     def finish():
         e = inflight.pop(0)
         e.sync()
-        rows = e.call()                                # SV-call tail (host C++), 13-field rows per region
-        last_rows.clear()
-        last_rows.update(rows)
-        blob = np.frombuffer("\n".join("%d\t%s" % (r, "\t".join(x)) for r in sorted(rows) for x in rows[r]).encode(), dtype=np.uint8)
+        raw = e.call_blob()                            # SV-call tail (host C++): one tab-separated record per call, region order
+        last_rows["n"] = raw.count(b"\n") + (1 if raw and not raw.endswith(b"\n") else 0)
+        blob = np.frombuffer(raw, dtype=np.uint8)
         if dist:                                       # collate the variable-length records of all ranks (RCCL all-gather)
             gather(blob)
         return blob.size
@@ -222,7 +221,7 @@ def main():
             "config": {"workload": "configs[1]: %d regions/GPU x %d reads x %d bp (%dx), planted 200 bp deletion, k=%d"
                                    % (a.regions, regions[0].reads.shape[0], a.read_len, a.depth, a.kmer),
                        "stages": "group reads + k-mer select + assemble (olc.nw) + realign on the GPU, SV-call tail in host C++, rows collated",
-                       "sv_calls_per_step": sum(len(v) for v in last_rows.values()),
+                       "sv_calls_per_step": last_rows.get("n", 0),
                        "steps_in_flight": len(engs),
                        "collated_bytes_per_step": gstate["collated"] if dist else None,
                        "parallelism": "regions sharded per GPU, all-gather of result records"},

@@ -253,15 +253,20 @@ class Engine(object):
     def set_call_context(self, text):
         self._chk(self.L.bk_set_call_context(self.h, text.encode()), "bk_set_call_context")
 
-    def call(self):
-        """Native SV-call tail over every contig of the batch -> {region: [13-field rows]} (contig order)."""
+    def call_blob(self):
+        """Native SV-call tail over every contig of the batch -> the serialised records (bytes; one line per call:
+        region, contig number, then the 13 result fields, tab separated) as they are collated across ranks."""
         self._chk(self.L.bk_call(self.h), "bk_call")
         need = C.c_size_t()
         self.L.bk_get_calls(self.h, None, 0, C.byref(need))
         buf = C.create_string_buffer(need.value)
         self._chk(self.L.bk_get_calls(self.h, buf, need.value, C.byref(need)), "bk_get_calls")
+        return buf.value
+
+    def call(self):
+        """Native SV-call tail over every contig of the batch -> {region: [13-field rows]} (contig order)."""
         out = {}
-        for ln in buf.value.decode().split("\n"):
+        for ln in self.call_blob().decode().split("\n"):
             if ln:
                 f = ln.split("\t")
                 out.setdefault(int(f[0]), []).append(f[2:])
