@@ -544,7 +544,7 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     uint64_t v = 0;
     for (int r = 0; r < h->n_regions; r++) {
         const BkRegionWork &w = h->h_work[r];
-        switch (which) { case 0: v += w.nw_cells; break; case 1: v += w.nw_calls; break; case 2: v += w.sw_cells; break; case 4: v += w.U; break; case 5: v += w.M; break; case 6: v += w.n_contigs; break; default: break; }
+        switch (which) { case 0: v += w.nw_cells; break; case 1: v += w.nw_calls; break; case 2: v += w.sw_cells; break; case 4: v += w.U; break; case 5: v += w.M; break; case 6: v += w.n_contigs; break; case 7: v += w.T; break; case 8: v += w.tcap; break; default: break; }
     }
     if (which == 3) v = h->alg_bytes;
     if (which >= 100 && which < 120) v = h->h_work[0].stamps[which - 100];      // diagnostic builds (-DBK_PHASE_STAMPS): region 0

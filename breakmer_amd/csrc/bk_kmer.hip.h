@@ -458,7 +458,11 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     if (a0b == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
     const uint64_t o_tslot = a0b, o_tcnt = o_tslot + (uint64_t)tcap * 4, o_trank = o_tcnt + (uint64_t)tcap * 4;
     uint32_t *tslot = (uint32_t *)(p.arena + o_tslot), *tcnt = (uint32_t *)(p.arena + o_tcnt), *trank = (uint32_t *)(p.arena + o_trank);
-    for (uint32_t i = tid; i < tcap; i += nt) { tslot[i] = BK_EMPTY32; tcnt[i] = 0; trank[i] = BK_EMPTY32; }
+    // The table is filled in LDS when it fits and the reference set is no longer needed (no separate soft-clip set to
+    // scan): one CAS and one add per occurrence are device-scope atomics otherwise, each 64 B of write traffic.
+    const bool lds_tab = !GLB && d.n_sc < 0 && 2u * tcap + 32u + 16u * 16u <= lds_words;
+    uint32_t *wslot = lds_tab ? lds + 32 + 16 * 16 : tslot, *wcnt = lds_tab ? lds + 32 + 16 * 16 + tcap : tcnt;
+    for (uint32_t i = tid; i < tcap; i += nt) { wslot[i] = BK_EMPTY32; wcnt[i] = 0; trank[i] = BK_EMPTY32; }
     __syncthreads();
     BK_STAMP(11);
     const uint32_t tmask = tcap - 1;
@@ -467,15 +471,19 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         BkKey key = seq_kmer_fast(reads + (uint64_t)urep[u] * RW, (int)RW, (int)pos, k);
         uint32_t s = key_hash(key) & tmask;
         for (;;) {
-            uint32_t cur = atomicCAS(&tslot[s], BK_EMPTY32, idx);
+            uint32_t cur = atomicCAS(&wslot[s], BK_EMPTY32, idx);
             if (cur == BK_EMPTY32) break;
             uint32_t e2 = t_ent[cur];
             if (key_eq(seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k), key)) break;
             s = (s + 1) & tmask;
         }
-        t_sl[idx] = s; atomicAdd(&tcnt[s], unr[u]);          // case[mer] counts every read (duplicates included)
+        t_sl[idx] = s; atomicAdd(&wcnt[s], unr[u]);          // case[mer] counts every read (duplicates included)
     }
     __syncthreads();
+    if (lds_tab) {                                           // the assembler looks k-mers up in the global copy
+        for (uint32_t i = tid; i < tcap; i += nt) { tslot[i] = wslot[i]; tcnt[i] = wcnt[i]; }
+        __syncthreads();
+    }
     // soft-clip set: keep only k-mers also present in case_sc (sv_processor.py:619-621)
     if (d.n_sc >= 0) {
         const uint32_t *sc = p.sc + d.sc_word_off; const uint16_t *sl = p.sc_len + d.sc_meta_off;
@@ -569,18 +577,21 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     __syncthreads();
     BK_STAMP(6);
     // ---- P5: posting lists k-mer rank -> (u, pos) -------------------------------------------------
-    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) atomicAdd(&ptmp[rk], 1u); }
+    // list lengths and fill cursors in LDS when they fit (the LDS holds nothing that is still needed), else in ptmp
+    uint32_t *pcur = M + 32u + 16u * 16u <= lds_words ? lds + 32 + 16 * 16 : ptmp;
+    if (pcur != ptmp) { for (uint32_t j = tid; j < M; j += nt) pcur[j] = 0; __syncthreads(); }
+    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) atomicAdd(&pcur[rk], 1u); }
     __syncthreads();
     {
         const uint32_t chunk = (M + nt - 1) / nt, b = tid * chunk, e = min(M, b + chunk);
         uint32_t c = 0, tot;
-        for (uint32_t j = b; j < e; j++) c += ptmp[j];
+        for (uint32_t j = b; j < e; j++) c += pcur[j];
         uint32_t pre = bk_block_excl_scan(c, scr, &tot);
-        for (uint32_t j = b; j < e; j++) { uint32_t n = ptmp[j]; poff[j] = pre; ptmp[j] = pre; pre += n; }
+        for (uint32_t j = b; j < e; j++) { uint32_t n = pcur[j]; poff[j] = pre; pcur[j] = pre; pre += n; }
         if (tid == 0) poff[M] = tot;
     }
     __syncthreads();
-    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) post[atomicAdd(&ptmp[rk], 1u)] = t_ent[idx]; }
+    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) post[atomicAdd(&pcur[rk], 1u)] = t_ent[idx]; }
     __syncthreads();
     BK_STAMP(7);
     if (tid == 0) {
