@@ -427,19 +427,42 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     uint32_t *t_ent = (uint32_t *)(p.arena + o_ent), *t_sl = (uint32_t *)(p.arena + o_tsl);
     if (tid == 0) scr[24] = 0;
     __syncthreads();
-    for (uint32_t q = wv; q < nslow; q += nwv) {
-        const uint32_t u = slow[q], i = urep[u]; const int len = rlen[i];
-        auto rec = [&](int pos, const BkKey &) { uint32_t idx = atomicAdd(&scr[24], 1u); t_ent[idx] = (u << 10) | (uint32_t)pos; };
-        if (len <= 16 * BK_RW_MAX) {
-            const int nwr = (len + 15) / 16;
-            if (lane < 16) wst[lane] = lane < nwr ? reads[(uint64_t)i * RW + lane] : 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            for (int p0 = 0; p0 + k <= len; p0 += 64) {
-                const int pp = p0 + lane;
-                if (pp + k <= len) { const BkKey key = seq_kmer_fast(wst, 16, pp, k); if (rt.find(key) < 0) rec(pp, key); }
+    // Each wavefront takes the listed reads wv, wv + 8, ...: the metadata of up to 64 of them is fetched by the 64 lanes
+    // at once and the packed words of read j+1 are requested before read j is scanned, so the scan of a read does not
+    // wait for three dependent global accesses of its own (they were 3 of the 4 us a read took).
+    for (uint32_t q0 = wv; q0 < nslow; q0 += (uint32_t)nwv * 64u) {
+        const uint32_t qm = q0 + (uint32_t)lane * (uint32_t)nwv;
+        uint32_t mu = 0, mi = 0; int mlen = 0;
+        if (qm < nslow) { mu = slow[qm]; mi = urep[mu]; mlen = (int)rlen[mi]; }
+        const int cnt = (int)min(64u, (nslow - q0 + (uint32_t)nwv - 1u) / (uint32_t)nwv);
+        uint32_t wnext = 0;
+        { const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)mi, 0); const int l0 = __builtin_amdgcn_readlane(mlen, 0);
+          if (lane < 16 && l0 <= 16 * BK_RW_MAX) wnext = lane < (l0 + 15) / 16 ? reads[(uint64_t)i0 * RW + lane] : 0u; }
+        for (int j = 0; j < cnt; j++) {
+            const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)mu, j), i = (uint32_t)__builtin_amdgcn_readlane((int)mi, j); const int len = __builtin_amdgcn_readlane(mlen, j);
+            auto rec = [&](int pos, const BkKey &) { uint32_t idx = atomicAdd(&scr[24], 1u); t_ent[idx] = (u << 10) | (uint32_t)pos; };
+            const uint32_t wcur = wnext;
+            if (j + 1 < cnt) {
+                const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane((int)mi, j + 1); const int l2 = __builtin_amdgcn_readlane(mlen, j + 1);
+                if (lane < 16 && l2 <= 16 * BK_RW_MAX) wnext = lane < (l2 + 15) / 16 ? reads[(uint64_t)i2 * RW + lane] : 0u;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        } else if (lane == 0) bk_scan_nonref(reads + (uint64_t)i * RW, len, rt, rec);
+            if (len <= 16 * BK_RW_MAX) {
+                if (lane < 16) wst[lane] = wcur;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                for (int p0 = 0; p0 + k <= len; p0 += 64) {
+                    const int pp = p0 + lane;
+                    const bool nonref = pp + k <= len && rt.find(seq_kmer_fast(wst, 16, pp, k)) < 0;
+                    const unsigned long long nm = __ballot(nonref);                 // one counter update per wavefront, not per lane
+                    if (nm) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&scr[24], (uint32_t)__popcll(nm));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        if (nonref) t_ent[base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = (u << 10) | (uint32_t)pp;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            } else if (lane == 0) bk_scan_nonref(reads + (uint64_t)i * RW, len, rt, rec);
+        }
     }
     __syncthreads();
     const uint32_t T = scr[24];
