@@ -90,21 +90,20 @@ def main():
         engs.append(e)
     eng = engs[0]
     last_rows = {}
-    inflight = []
 
-    def launch(e):
-        e.run(stages, sync=False)                      # group + k-mer select + assemble + realign on the GPU (async)
-        inflight.append(e)
-
-    def finish():
-        e = inflight.pop(0)
-        e.sync()
+    def finish_step(e, relaunch):
+        """consume one step of handle e: wait + copy its records to the host, start the handle's next step at once (its
+        device buffers are free again), then run the SV-call tail on the host copy while those kernels execute"""
+        e.fetch()
+        ms = [e.kernel_ms(j + 1) for j in range(3)]
+        if relaunch:
+            e.run(stages, sync=False)                  # group + k-mer select + assemble + realign on the GPU (async)
         raw = e.call_blob()                            # SV-call tail (host C++): one tab-separated record per call, region order
         last_rows["n"] = raw.count(b"\n") + (1 if raw and not raw.endswith(b"\n") else 0)
         blob = np.frombuffer(raw, dtype=np.uint8)
         if dist:                                       # collate the variable-length records of all ranks (RCCL all-gather)
             gather(blob)
-        return blob.size
+        return ms
 
     # Collation buffers: [8-byte length | records] per rank, fixed capacity, two slots so that the all-gather of step s
     # overlaps the kernels of step s+1 (the records are only consumed after the run).  The general two-phase
@@ -151,21 +150,19 @@ def main():
         torch.cuda.synchronize()
 
     def run_steps(k):
+        """K steps, step s on handle s % inflight; every handle always has its next step queued before the host turns
+        to the call tail of the step it just collected"""
         acc = [0.0, 0.0, 0.0]
+        launched = 0
+        for j in range(min(len(engs), k)):
+            engs[j].run(stages, sync=False)
+            launched += 1
         for s in range(k):
-            e = engs[s % len(engs)]
-            if e in inflight:                          # its previous step must be consumed before the handle is reused
-                while e in inflight:
-                    x = inflight[0]
-                    finish()
-                    for j in range(3):
-                        acc[j] += x.kernel_ms(j + 1)
-            launch(e)
-        while inflight:
-            x = inflight[0]
-            finish()
+            relaunch = launched < k
+            ms = finish_step(engs[s % len(engs)], relaunch)
+            launched += 1 if relaunch else 0
             for j in range(3):
-                acc[j] += x.kernel_ms(j + 1)
+                acc[j] += ms[j]
         drain()
         return acc
 

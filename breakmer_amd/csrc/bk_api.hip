@@ -42,6 +42,7 @@ struct bk_handle {
     int dev = 0; hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
     bk_config cfg{}; std::string err;
     int n_regions = 0; bool submitted = false, ran = false, fetched = false, synced = false;
+    bool hold_snapshot = false;      // bk_fetch() done: bk_call() uses the host copy even if a newer run is in flight
     uint32_t ran_mask = 0;
     // device
     DevBuf d_desc, d_work, d_part, d_reads, d_rlen, d_rflag, d_sc, d_sclen, d_win;
@@ -382,6 +383,7 @@ extern "C" int bk_sync(bk_handle *h)
 
 static int fetch(bk_handle *h)
 {
+    if (h->hold_snapshot) return BK_OK;             // explicit bk_fetch(): keep working on that copy
     HIPCHK(h, hipSetDevice(h->dev));                // entry points may be called from any host thread
     int rc = bk_sync(h);
     if (rc != BK_OK) return rc;
@@ -605,6 +607,16 @@ extern "C" int bk_call_text(const char *text, char *out, size_t cap, int *target
     return BK_OK;
 }
 
+extern "C" int bk_fetch(bk_handle *h)
+{
+    if (!h) return BK_E_ARG;
+    if (!h->ran) return fail(h, BK_E_STATE, "bk_fetch: nothing was run");
+    h->hold_snapshot = false;
+    int rc = fetch(h);
+    if (rc == BK_OK) h->hold_snapshot = true;
+    return rc;
+}
+
 // batch: annotation/query_region context for the submitted regions (text, bk_call.h), then calls for every contig
 extern "C" int bk_set_call_context(bk_handle *h, const char *text)
 {
@@ -663,6 +675,7 @@ extern "C" int bk_call(bk_handle *h)
     if (nthreads == 1) work(0);
     else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
     for (auto &s2 : parts) h->calls_blob += s2;
+    h->hold_snapshot = false;                       // the next getter refers to the newest run again
     return BK_OK;
 }
 

@@ -58,7 +58,7 @@ def call_text(text):
     return (row.split("\t") if row else None), (None if hit.value < 0 else bool(hit.value))
 
 
-EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_run", "bk_sync",
+EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_run", "bk_sync", "bk_fetch",
            "bk_last_kernel_ms", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
            "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_get_calls",
            "bk_nw_batch"]
@@ -86,6 +86,7 @@ def load_library():
     L.bk_submit_regions.argtypes = [C.c_void_p, C.POINTER(BkRegion), C.c_int32]
     L.bk_run.argtypes = [C.c_void_p, C.c_uint32]
     L.bk_sync.argtypes = [C.c_void_p]
+    L.bk_fetch.argtypes = [C.c_void_p]
     L.bk_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.bk_get_kmer_count.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.bk_get_kmers.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
@@ -210,6 +211,10 @@ class Engine(object):
 
     def sync(self):
         self._chk(self.L.bk_sync(self.h), "bk_sync")
+
+    def fetch(self):
+        """Wait for the last run and copy its records to the host; the handle may be run again before call()."""
+        self._chk(self.L.bk_fetch(self.h), "bk_fetch")
 
     def kernel_ms(self, which=0):
         ms = C.c_float()

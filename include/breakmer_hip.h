@@ -95,6 +95,11 @@ int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions)
  * Asynchronous on the handle's stream; bk_sync() or any bk_get_* waits. */
 int bk_run(bk_handle *h, uint32_t stage_mask);
 int bk_sync(bk_handle *h);
+/* Wait for the last bk_run and copy its result records to the host.  The device buffers of the handle are free
+ * for the next bk_run after this call: a following bk_call() works on the host copy even when a new run has been
+ * started in between (the batching analogue of the reference's per-region loop moving on to the next target,
+ * sv_processor.py:185-201, while make_calls of the previous one is still being formatted). */
+int bk_fetch(bk_handle *h);
 /* elapsed device time of the kernels of the last bk_run, measured with HIP events on the handle's
  * stream (ms); which = 0 total, 1 k-mer kernel, 2 assembler kernel, 3 realign kernel */
 int bk_last_kernel_ms(bk_handle *h, int which, float *ms);
