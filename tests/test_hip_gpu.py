@@ -384,6 +384,30 @@ def test_long_reads_gpu(hb):
             assert eng.hits(i, ci) == bo.realign(c["seq"], [r.window_str]), (i, ci)
 
 
+def test_fetch_then_rerun_then_call_gpu(hb):
+    """bk_fetch: the records of a run are on the host, the handle runs again at once, bk_call still reports the run that
+    was fetched (the bench overlaps the call tail of batch i with the kernels of batch i+1 this way)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from breakmer_amd.sv_processor import params as bk_params
+    regions = [synth.make_region(40 + i, depth=80, W=1500, sv_type=synth.SV_TYPES[i % 3]) for i in range(6)]
+    opts = dict(bk_params.DEFAULTS); opts["var_filter"] = ["indel", "rearrangement", "trl"]
+    eng = hb.Engine(kmer_size=31)
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
+    eng.set_call_context(bench.call_context_text(regions, opts))
+    eng.run(hb.BK_STAGE_ALL)
+    want = eng.call()
+    assert sum(len(v) for v in want.values()) >= 4
+    eng.run(hb.BK_STAGE_ALL, sync=False)
+    eng.fetch()
+    eng.run(hb.BK_STAGE_ALL, sync=False)               # in flight while the tail of the fetched run is computed
+    assert eng.call() == want
+    assert eng.call() == want                          # no snapshot held any more: refers to (and waits for) the newest run
+    assert [len(eng.contigs(i)) for i in range(6)] == [len(want.get(i, [])) or len(eng.contigs(i)) for i in range(6)]
+
+
 def test_arena_growth_and_rerun_gpu(hb):
     """A deliberately tiny scratch arena: the library must notice the overflow, grow the arena and rerun --
     results identical to a run with the default arena; repeated bk_run on one handle is idempotent."""
