@@ -352,6 +352,7 @@ extern "C" int bk_sync(bk_handle *h)
     if (!h) return BK_E_ARG;
     if (!h->ran) return fail(h, BK_E_STATE, "bk_sync: nothing was run");
     if (h->synced) return BK_OK;
+    h->hold_snapshot = false;                       // the work records below replace the fetched copy's
     HIPCHK(h, hipSetDevice(h->dev));
     for (int attempt = 0; attempt < 12; attempt++) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
