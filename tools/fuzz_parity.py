@@ -20,7 +20,7 @@ while done < n:
     rc = int(rng.choice([2, 3]))
     batch = []
     for _ in range(min(16, n - done)):
-        L = int(rng.choice([60, 100, 150, 250]))
+        L = int(rng.choice([60, 100, 150, 250, 400]))
         W = int(rng.integers(max(2 * L + 100, 400), 2200))
         kw = dict(W=W, L=L, depth=int(rng.integers(15, 160)), sv_type=str(rng.choice(synth.SV_TYPES)),
                   noise=float(rng.choice([0.0, 0.0, 0.003, 0.01, 0.03])), var_len=float(rng.choice([0.0, 0.0, 0.2])),
@@ -30,6 +30,10 @@ while done < n:
             kw["sv_size"] = 20
         batch.append((int(rng.integers(0, 1 << 30)), kw))
     regs = [synth.make_region(rid, **kw) for rid, kw in batch]
+    for r in regs:                                      # every 5th region gets a whole-gene sized window (global-memory k-mer set, chunked realign)
+        if r.region_id % 5 == 0:
+            fl = synth.rand_bases(synth.stream_key(seed, r.region_id, 9), 2 * 15000)
+            r.window = np.concatenate([fl[:15000], r.window, fl[15000:]]).astype(np.uint8)
     eng = hb.Engine(kmer_size=k, rc_thresh=rc)
     eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only, partners=[p[4] for p in r.partners]) for r in regs])
     eng.run(hb.BK_STAGE_ALL)
