@@ -115,10 +115,9 @@ __device__ inline int bk_lookup(const BkKey &key)
     if (C_.M == 0) return -1;
     uint32_t s = key_hash(key) & C_.tmask;
     for (;;) {
-        uint32_t cur = C_.tslot[s];
-        if (cur == BK_EMPTY32) return -1;
-        uint32_t rk = C_.trank[s];
-        if (rk != BK_EMPTY32 && C_.klo[rk] == key.lo && C_.khi[rk] == key.hi) return (int)rk;
+        const uint32_t rk = C_.tslot[s];                   // rank of the k-mer in this slot (the k-mer stage stores it there)
+        if (rk == BK_EMPTY32) return -1;
+        if (rk != BK_EMPTY32 - 1 && C_.klo[rk] == key.lo && C_.khi[rk] == key.hi) return (int)rk;      // EMPTY-1: tombstone
         s = (s + 1) & C_.tmask;
     }
 }

@@ -113,7 +113,7 @@ struct BkRegionWork {
     // arena offsets (bytes)
     uint64_t o_trip_ent;         // uint32[T]   (u << 10 | pos)
     uint64_t o_trip_slot;        // uint32[T]
-    uint64_t o_tslot;            // uint32[tcap] claimant triple index
+    uint64_t o_tslot;            // uint32[tcap] claimant triple index while the table is built, then the k-mer rank
     uint64_t o_tcnt;             // uint32[tcap] occurrence count (sum of nreads)
     uint64_t o_trank;            // uint32[tcap] rank of slot (BK_EMPTY32 = dropped)
     uint64_t o_key_lo, o_key_hi; // uint64[M] sorted (count desc, mer desc)

@@ -582,6 +582,8 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         for (uint32_t j = tid; j < M; j += nt) { khi[j] = s64[j]; trank[s32[j]] = j; ptmp[j] = 0; }
         __syncthreads();
     }
+    // the assembler's lookups go table slot -> rank -> key: store the rank in the slot itself (one dependent load less)
+    for (uint32_t i = tid; i < tcap; i += nt) if (tslot[i] < BK_EMPTY32 - 1) tslot[i] = trank[i];
     for (uint32_t j = tid; j < M; j += nt) {
         BkKey key{khi[j], klo[j]};
         kstate[j] = key_homopolymer(key, k) ? BK_K_REMOVED : BK_K_LIVE;      // kmers.add_kmer (sv_assembly.py:277)
