@@ -13,6 +13,7 @@
 #include <string>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -60,6 +61,8 @@ struct bk_handle {
     int eff_max_read = 64;          // batch maximum read length rounded up to 64: sizes the assembler's LDS buffers (occupancy)
     uint64_t total_reads = 0, alg_bytes = 0;
     float ms[4] = {0, 0, 0, 0};
+    double submit_pack_ms = 0, submit_h2d_ms = 0;   // host 2-bit packing / host-to-device copies of the last bk_submit_regions
+    int n_failed = 0;                                // regions of the last run that hit a device limit (status per region)
     BkParams params{};
     bkcall::Context call_ctx; bool have_ctx = false; std::string calls_blob;
 };
@@ -95,7 +98,7 @@ extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
         delete h; return fail(nullptr, BK_E_ARG, "bk_create: limits: max_read_len <= 1024, max_contig_len <= 4096 and <= 2*max_candidates");
     }
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, BK_E_HIP, "stream creation failed"); }
-    for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { delete h; return fail(nullptr, BK_E_HIP, "event creation failed"); }
+    for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { (void)bk_destroy(h); return fail(nullptr, BK_E_HIP, "event creation failed"); }
     *out = h;
     return BK_OK;
 }
@@ -139,9 +142,13 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     if (!h || !regions || n_regions <= 0) return fail(h, BK_E_ARG, "bk_submit_regions: bad argument");
     HIPCHK(h, hipSetDevice(h->dev));
     const int k = h->cfg.kmer_size;
+    // a failed submit leaves the handle without a batch (never the old device results paired with new host mirrors):
+    // the new host mirrors are built in locals and swapped in on success only
+    h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->hold_snapshot = false; h->have_ctx = false;
     std::vector<uint32_t> reads, sc, win; std::vector<uint16_t> rlen, sclen; std::vector<uint8_t> rflag;
-    h->h_desc.assign(n_regions, BkRegionDesc{}); h->h_part.clear(); h->h_targets.assign(n_regions, {}); h->max_win = 0;
-    uint64_t dd_total = 0; uint32_t max_w = 0; h->alg_bytes = 0;
+    std::vector<BkRegionDesc> n_desc(n_regions, BkRegionDesc{}); std::vector<BkPartnerDesc> n_part; std::vector<std::vector<std::string>> n_targets(n_regions);
+    uint32_t n_max_win = 0; uint64_t n_alg_bytes = 0;
+    uint64_t dd_total = 0; uint32_t max_w = 0;
     size_t tot_reads = 0, tot_words = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r];
@@ -155,7 +162,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     }
     reads.reserve(tot_words); rlen.reserve(tot_reads); rflag.reserve(tot_reads); sc.reserve(tot_scw); sclen.reserve(tot_sc); win.reserve(tot_win);
     for (int r = 0; r < n_regions; r++) {
-        const bk_region &g = regions[r]; BkRegionDesc &d = h->h_desc[r];
+        const bk_region &g = regions[r]; BkRegionDesc &d = n_desc[r];
         uint32_t maxl = 0; for (int i = 0; i < g.n_reads; i++) maxl = std::max<uint32_t>(maxl, g.read_lens[i]);
         d.n_reads = g.n_reads; d.read_words = (maxl + 15) / 16 + 1;          // +1: k-mer extraction may touch one word past the end
         d.max_len = maxl;
@@ -174,30 +181,31 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         d.win_len = g.window_len; d.win_word_off = win.size();
         { size_t nw = (g.window_len + 15) / 16 + 2; win.resize(win.size() + nw); if (!pack_seq(g.window, g.window_len, win.data() + d.win_word_off, (int)nw)) return fail(h, BK_E_ARG, "bk_submit_regions: non-ACGT base in reference window"); }
         max_w = std::max<uint32_t>(max_w, g.window_len);
-        h->max_win = std::max<uint32_t>(h->max_win, g.window_len);
-        h->h_targets[r].emplace_back(g.window, g.window_len);
+        n_max_win = std::max<uint32_t>(n_max_win, g.window_len);
+        n_targets[r].emplace_back(g.window, g.window_len);
         if (g.n_partners > 15) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 15 partner windows");
-        d.n_partners = g.n_partners; d.part_desc_off = h->h_part.size();
+        d.n_partners = g.n_partners; d.part_desc_off = n_part.size();
         for (int q = 0; q < g.n_partners; q++) {
             BkPartnerDesc pd; pd.word_off = win.size(); pd.len = g.partner_lens[q]; pd.pad = 0;
             size_t nw = (pd.len + 15) / 16 + 2; win.resize(win.size() + nw);
             if (!pack_seq(g.partners[q], pd.len, win.data() + pd.word_off, (int)nw)) return fail(h, BK_E_ARG, "bk_submit_regions: non-ACGT base in partner window");
-            h->h_part.push_back(pd);
-            h->h_targets[r].emplace_back(g.partners[q], pd.len); h->max_win = std::max<uint32_t>(h->max_win, pd.len);
+            n_part.push_back(pd);
+            n_targets[r].emplace_back(g.partners[q], pd.len); n_max_win = std::max<uint32_t>(n_max_win, pd.len);
         }
         uint32_t cap = 64; while ((uint64_t)cap * 7 < (uint64_t)std::max(g.n_reads, 1) * 10) cap <<= 1;      // load factor <= 0.7 even if every read is unique
         d.dedup_cap = cap; d.dedup_off = dd_total; dd_total += cap;
         // algorithmic HBM bytes per region: 2-bit reads + 4 B/read offsets + window fwd+rc + ~2 KB of output
         uint64_t bases = 0; for (int i = 0; i < g.n_reads; i++) bases += g.read_lens[i];
-        h->alg_bytes += (bases + 3) / 4 + 4ull * g.n_reads + 2ull * ((g.window_len + 3) / 4) + 2048;
+        n_alg_bytes += (bases + 3) / 4 + 4ull * g.n_reads + 2ull * ((g.window_len + 3) / 4) + 2048;
     }
+    const auto t_pack0 = std::chrono::steady_clock::now();
     {   // 2-bit packing of the reads: the bulk of the host work of a submit (0.4 GB of ASCII for 256 regions), regions are independent
         std::atomic<int> next{0}, bad_region{-1}, bad_read{-1};
         auto pack = [&]() {
             for (;;) {
                 const int r = next.fetch_add(1);
                 if (r >= n_regions) break;
-                const bk_region &g = regions[r]; const BkRegionDesc &d = h->h_desc[r];
+                const bk_region &g = regions[r]; const BkRegionDesc &d = n_desc[r];
                 for (int i = 0; i < g.n_reads; i++)
                     if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
             }
@@ -208,7 +216,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         if (bad_region >= 0) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_region.load()) + " read " + std::to_string(bad_read.load()) + ": non-ACGT base (unsupported)");
     }
     h->total_reads = rlen.size(); h->n_regions = n_regions;
-    { uint32_t mx = 0; for (auto &d : h->h_desc) mx = std::max(mx, d.max_len); h->eff_max_read = (int)std::min<uint32_t>((uint32_t)h->cfg.max_read_len, std::max<uint32_t>(64, (mx + 63) / 64 * 64)); }
+    { uint32_t mx = 0; for (auto &d : n_desc) mx = std::max(mx, d.max_len); h->eff_max_read = (int)std::min<uint32_t>((uint32_t)h->cfg.max_read_len, std::max<uint32_t>(64, (mx + 63) / 64 * 64)); }
     // reference k-mer table geometry (LDS): load factor <= 0.5.  Windows beyond the LDS budget (whole-gene targets)
     // are flagged `big` and go through bk_kmer_kernel_g (table in the scratch arena).
     auto lds_need = [&](uint32_t w, uint32_t &cap, uint32_t &words) {
@@ -218,7 +226,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         return wk2 < (1u << 18) ? (32 + 256 + 2 * (size_t)words + cap) * 4 : (size_t)1 << 30;
     };
     uint32_t max_small = 0; h->n_big = 0; uint64_t big_bytes = 0;
-    for (auto &d : h->h_desc) {
+    for (auto &d : n_desc) {
         uint32_t cap, words;
         d.big = lds_need(d.win_len, cap, words) > 160 * 1024 ? 1u : 0u; d.pad_ = 0;
         if (d.big) { h->n_big++; uint64_t gc = 1024; while (gc < 4ull * d.win_len) gc <<= 1; big_bytes += gc * 8 + d.win_len / 4 + 4096; if (d.win_len >= (1u << 28)) return fail(h, BK_E_LIMIT, "bk_submit_regions: reference window longer than 256 Mb"); }
@@ -226,7 +234,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     }
     { uint32_t cap, words; lds_need(max_small, cap, words); h->ref_cap = cap; h->win_words_cap = words; }
     h->group_words = 0;
-    for (auto &d : h->h_desc) {
+    for (auto &d : n_desc) {
         const uint32_t need = 32 + 256 + d.dedup_cap;
         if (!d.big && d.n_reads < 16383u && need <= 36864u) h->group_words = std::max(h->group_words, need);
     }
@@ -235,8 +243,9 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     if (reads.empty()) reads.push_back(0);
     if (sc.empty()) sc.push_back(0);
     if (sclen.empty()) sclen.push_back(0);
-    if (h->h_part.empty()) h->h_part.push_back(BkPartnerDesc{0, 0, 0});
-    HIPCHK(h, upload(h, h->d_desc, h->h_desc)); HIPCHK(h, upload(h, h->d_part, h->h_part));
+    if (n_part.empty()) n_part.push_back(BkPartnerDesc{0, 0, 0});
+    const auto t_h2d0 = std::chrono::steady_clock::now();
+    HIPCHK(h, upload(h, h->d_desc, n_desc)); HIPCHK(h, upload(h, h->d_part, n_part));
     HIPCHK(h, upload(h, h->d_reads, reads)); HIPCHK(h, upload(h, h->d_rlen, rlen)); HIPCHK(h, upload(h, h->d_rflag, rflag));
     HIPCHK(h, upload(h, h->d_sc, sc)); HIPCHK(h, upload(h, h->d_sclen, sclen)); HIPCHK(h, upload(h, h->d_win, win));
     const size_t nr = std::max<size_t>(h->total_reads, 1), nd = std::max<uint64_t>(dd_total, 1);
@@ -255,6 +264,9 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     if (h->out_cap == 0) h->out_cap = h->cfg.out_kbytes > 0 ? (uint64_t)h->cfg.out_kbytes << 10 : std::max<uint64_t>(8ull << 20, (uint64_t)n_regions * (64ull << 10));
     HIPCHK(h, h->d_arena.ensure(h->arena_cap)); HIPCHK(h, h->d_out.ensure(h->out_cap));
     HIPCHK(h, hipStreamSynchronize(h->stream));          // host staging vectors go out of scope
+    { const auto t1 = std::chrono::steady_clock::now();
+      h->submit_pack_ms = std::chrono::duration<double, std::milli>(t_h2d0 - t_pack0).count(); h->submit_h2d_ms = std::chrono::duration<double, std::milli>(t1 - t_h2d0).count(); }
+    h->h_desc.swap(n_desc); h->h_part.swap(n_part); h->h_targets.swap(n_targets); h->max_win = n_max_win; h->alg_bytes = n_alg_bytes;
     h->submitted = true; h->ran = false; h->fetched = false;
     return BK_OK;
 }
@@ -358,13 +370,17 @@ extern "C" int bk_sync(bk_handle *h)
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->h_work.resize(h->n_regions);
         HIPCHK(h, hipMemcpy(h->h_work.data(), h->d_work.p, sizeof(BkRegionWork) * h->n_regions, hipMemcpyDeviceToHost));
-        bool grow_arena = false, grow_out = false; int bad = -1;
+        // A region that hit a device cap (candidates per k-mer, contig length, k-mer list) fails ALONE: its status is
+        // kept (bk_get_region_status), it reports no contigs, the other regions of the batch are unaffected.  The
+        // reference has no such caps; the caller logs and skips the target (or raises the cap and resubmits it).
+        bool grow_arena = false, grow_out = false; int bad = 0;
         for (int r = 0; r < h->n_regions; r++) {
             int s = h->h_work[r].status;
-            if (s == BK_ST_ARENA) grow_arena = true; else if (s == BK_ST_OUT) grow_out = true; else if (s != BK_ST_OK && bad < 0) bad = r;
+            if (s == BK_ST_ARENA) grow_arena = true; else if (s == BK_ST_OUT) grow_out = true; else if (s != BK_ST_OK) bad++;
         }
-        if (bad >= 0) return fail(h, BK_E_LIMIT, "region " + std::to_string(bad) + ": " + st_name(h->h_work[bad].status));
+        h->n_failed = bad;
         if (!grow_arena && !grow_out) {
+            for (int r = 0; r < h->n_regions; r++) if (h->h_work[r].status != BK_ST_OK) { h->h_work[r].n_contigs = 0; h->h_work[r].o_first_contig = 0; }
             for (int i = 0; i < 3; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]); h->ms[i + 1] = ms; }
             (void)hipEventElapsedTime(&h->ms[0], h->ev[0], h->ev[3]);
             h->synced = true;
@@ -445,6 +461,16 @@ static const BkContigRec *find_contig(bk_handle *h, int region, int contig)
     uint64_t off = h->h_work[region].o_first_contig;
     for (int i = 0; off && i < contig; i++) off = ((const BkContigRec *)(h->h_out.data() + off))->next;
     return off ? (const BkContigRec *)(h->h_out.data() + off) : nullptr;
+}
+
+extern "C" int bk_get_region_status(bk_handle *h, int32_t region, int32_t *status, const char **text)
+{
+    if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
+    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    const int s = h->h_work[region].status;
+    if (status) *status = s;
+    if (text) *text = s == BK_ST_OK ? "ok" : st_name(s);
+    return BK_OK;
 }
 
 extern "C" int bk_get_contig_count(bk_handle *h, int32_t region, int32_t *n)
@@ -543,6 +569,7 @@ extern "C" int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl 
 extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
 {
     if (!h || !value) return BK_E_ARG;
+    if (which == 20 || which == 21) { *value = (uint64_t)((which == 20 ? h->submit_pack_ms : h->submit_h2d_ms) * 1000.0); return BK_OK; }
     int rc = bk_sync(h); if (rc != BK_OK) return rc;
     uint64_t v = 0;
     for (int r = 0; r < h->n_regions; r++) {
@@ -550,6 +577,9 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
         switch (which) { case 0: v += w.nw_cells; break; case 1: v += w.nw_calls; break; case 2: v += w.sw_cells; break; case 4: v += w.U; break; case 5: v += w.M; break; case 6: v += w.n_contigs; break; case 7: v += w.T; break; case 8: v += w.tcap; break; default: break; }
     }
     if (which == 3) v = h->alg_bytes;
+    if (which == 20) v = (uint64_t)(h->submit_pack_ms * 1000.0);              // microseconds
+    if (which == 21) v = (uint64_t)(h->submit_h2d_ms * 1000.0);
+    if (which == 22) v = (uint64_t)h->n_failed;
     if (which >= 100 && which < 120) v = h->h_work[0].stamps[which - 100];      // diagnostic builds (-DBK_PHASE_STAMPS): region 0
     *value = v; return BK_OK;
 }

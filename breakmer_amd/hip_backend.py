@@ -59,7 +59,7 @@ def call_text(text):
 
 
 EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_run", "bk_sync", "bk_fetch",
-           "bk_last_kernel_ms", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
+           "bk_last_kernel_ms", "bk_get_region_status", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
            "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_get_calls",
            "bk_nw_batch"]
 
@@ -88,6 +88,7 @@ def load_library():
     L.bk_sync.argtypes = [C.c_void_p]
     L.bk_fetch.argtypes = [C.c_void_p]
     L.bk_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.bk_get_region_status.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_char_p)]
     L.bk_get_kmer_count.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.bk_get_kmers.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
     L.bk_get_contig_count.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -225,6 +226,12 @@ class Engine(object):
         v = C.c_uint64()
         self._chk(self.L.bk_get_stat(self.h, which, C.byref(v)), "bk_get_stat")
         return v.value
+
+    def region_status(self, region):
+        """(status, text) of one region of the last run: 0/'ok', or the device cap it hit (it then has no contigs)."""
+        st, tx = C.c_int32(), C.c_char_p()
+        self._chk(self.L.bk_get_region_status(self.h, region, C.byref(st), C.byref(tx)), "bk_get_region_status")
+        return st.value, (tx.value or b"").decode()
 
     def kmers(self, region):
         n, u = C.c_int32(), C.c_int32()

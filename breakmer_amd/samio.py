@@ -3,6 +3,7 @@
 BAM is read through gzip (BGZF is a multi-member gzip stream); no index is used."""
 from __future__ import annotations
 
+import copy
 import gzip
 import struct
 
@@ -150,19 +151,25 @@ class Samfile(object):
     def fetch(self, chrom=None, start=None, end=None):
         """Records of `chrom` overlapping [start, end) in file order (unplaced-but-positioned reads count as 1 bp)."""
         if chrom is None:
-            return list(self.reads)
+            return [copy.copy(r) for r in self.reads]
         self._index()
         tid = self._tid.get(str(chrom), self._tid.get("chr" + str(chrom), -2))
         if tid not in self._by_tid:
             return []
         ids, pos, rend = self._by_tid[tid]
-        return [self.reads[i] for i in ids[(pos < end) & (rend > start)]]
+        # Copies, not the cached records: the reference re-opens the alignment file per target (sv_processor.py:426), so
+        # the in-place quality trimming of fq_line/trim_qual (utils.py:414-443) and the mate_is_unmapped normalisation of
+        # process_reads (:16-17) never leak from one target into the next one whose window overlaps it.
+        return [copy.copy(self.reads[i]) for i in ids[(pos < end) & (rend > start)]]
 
     def mate(self, read):
         self._index()
-        for r in self._mates.get(read.qname, ()):
-            if r is not read and r.is_read1 != read.is_read1:
+        cands = [r for r in self._mates.get(read.qname, ()) if r.is_read1 != read.is_read1]
+        for r in cands:                                    # pysam returns the primary record of the mate
+            if not (r.flag & 0x900):
                 return r
+        if cands:
+            return cands[0]
         raise ValueError("mate not found for " + read.qname)
 
     def write(self, _read): pass

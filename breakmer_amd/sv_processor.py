@@ -271,6 +271,7 @@ class target(object):                                               # sv_process
         self.native_rows = None
         self.engine = None
         self.reads = []
+        self.failed = None                      # text of the device cap this target's region hit (it is skipped then)
         self.setup()
 
     def setup(self):                                                 # :267-294
@@ -490,6 +491,14 @@ class runner(object):                                               # sv_process
                                                    partners=[p[4] for p in d.partners]))
             self.engine.submit(ins)
             self.engine.run(hip_backend.BK_STAGE_ALL)
+            # a region that hit a device cap fails alone (bk_get_region_status): the target is logged and skipped like a
+            # target without reads (sv_processor.py:190-192); the rank still takes part in the collation below
+            if hasattr(self.engine, 'region_status'):
+                for i, t in enumerate(live):
+                    st, text = self.engine.region_status(i)
+                    if st != 0:
+                        self.logger.error('target %s: not assembled on the device: %s' % (t.name, text))
+                        t.failed = text
             if self.native_calls and hasattr(self.engine, 'set_call_context'):
                 from . import call_context as cc
                 lines = [cc.opts_line(self.params.opts)] + cc.tables_lines(self.params.gene_annotations.genes, self.params.repeat_mask)
@@ -500,6 +509,9 @@ class runner(object):                                               # sv_process
                 for i, t in enumerate(live):
                     t.native_rows = rows.get(i, [])
         for t in live:
+            if t.failed:
+                t.rm_output_dir()
+                continue
             t.compare_kmers()
             t.resolve_sv()
             self.summary_header, self.summary[t.name] = t.get_summary()

@@ -104,6 +104,12 @@ int bk_fetch(bk_handle *h);
  * stream (ms); which = 0 total, 1 k-mer kernel, 2 assembler kernel, 3 realign kernel */
 int bk_last_kernel_ms(bk_handle *h, int which, float *ms);
 
+/* Per-region outcome of the last bk_run.  The reference has no size caps; this implementation has a few
+ * (max_candidates reads per k-mer, max_contig_len, the contig k-mer list): a region that hits one fails ALONE --
+ * status != 0, text says which cap, it reports zero contigs -- and bk_run/bk_sync still succeed for the batch
+ * (the per-target analogue of the reference skipping a target, sv_processor.py:190-192).  status 0 = ok. */
+int bk_get_region_status(bk_handle *h, int32_t region, int32_t *status, const char **text);
+
 /* ---- results, region-major -------------------------------------------------------------- */
 /* K1/K2: sample-only k-mers of region r in the order init_assembly visits them
  * ((count, mer) descending, sv_assembly.py:281); mers = n*k ASCII bytes. */
@@ -165,7 +171,9 @@ int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, const uint32_t
 
 /* bookkeeping for measurement: algorithmic work of the last bk_run
  *   which = 0: olc.nw DP cells (sum len(seq1)*len(seq2)), 1: olc.nw calls, 2: SW cells,
- *           3: algorithmic HBM bytes (SURVEY 8d formula), 4: unique reads, 5: sample k-mers, 6: contigs */
+ *           3: algorithmic HBM bytes (SURVEY 8d formula), 4: unique reads, 5: sample k-mers, 6: contigs,
+ *           20/21: host packing / host-to-device copy time of the last bk_submit_regions (microseconds),
+ *           22: regions of the last run that failed on a device cap (bk_get_region_status) */
 int bk_get_stat(bk_handle *h, int which, uint64_t *value);
 
 #ifdef __cplusplus

@@ -16,3 +16,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def _gpu_present():
+    """A device node the HIP runtime can open (no HIP call here: counting devices must not initialise the GPU)."""
+    return os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are skipped, not failed, on a host without a GPU (plain `pytest tests` in the build container);
+    `-m gpu` on the GPU box runs them all -- there the library itself fails loudly if the device is missing."""
+    if _gpu_present():
+        return
+    skip = pytest.mark.skip(reason="no GPU device node (/dev/kfd): run with -m gpu on an MI355X")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)

@@ -28,6 +28,9 @@ class FakeEngine(object):
             hits = [bo.realign(c["seq"], [window] + partners) for c in contigs]
             self.out.append((contigs, [info["mers"][i] for i in order], np.array([info["counts"][i] for i in order]), len(info["rep"]), hits))
 
+    def region_status(self, r):
+        return 0, "ok"
+
     def kmers(self, r):
         return self.out[r][1], self.out[r][2], self.out[r][3]
 

@@ -405,7 +405,14 @@ def test_fetch_then_rerun_then_call_gpu(hb):
     eng.run(hb.BK_STAGE_ALL, sync=False)               # in flight while the tail of the fetched run is computed
     assert eng.call() == want
     assert eng.call() == want                          # no snapshot held any more: refers to (and waits for) the newest run
-    assert [len(eng.contigs(i)) for i in range(6)] == [len(want.get(i, [])) or len(eng.contigs(i)) for i in range(6)]
+    # the getters refer to the newest run again, which equals a fresh handle's run of the same batch; every call row
+    # belongs to a contig of its region
+    fresh = _run_regions(hb, regions, 31, stages=7)
+    for i in range(6):
+        assert eng.contigs(i) == fresh.contigs(i), i
+        assert len(want.get(i, [])) <= len(eng.contigs(i)), i
+        ids = {"%s_contig%d" % (regions[i].name, c + 1) for c in range(len(eng.contigs(i)))}
+        assert all(row[11] in ids for row in want.get(i, [])), i
 
 
 def test_arena_growth_and_rerun_gpu(hb):

@@ -92,3 +92,23 @@ def test_trim_helpers():
     assert rx.trim_coords("####", 3) == (0, 0, 0)
     assert samio.parse_cigar("5S90M2D5M") == [(4, 5), (0, 90), (2, 2), (0, 5)]
     assert samio.parse_cigar("*") is None
+
+
+def test_overlapping_targets_see_pristine_reads(tmp_path):
+    """Two targets whose [start-200, end+200) windows overlap, served by ONE cached Samfile (params.open_bam): the
+    second extraction must equal an extraction from a freshly parsed file, as in the reference, which re-opens the
+    alignment file per target (sv_processor.py:426) -- trim_qual / process_reads mutate the records they are given."""
+    case = CASES[0]
+    r, fn = _sam_for(case, tmp_path)
+    k = case["kmer"]
+    shared = samio.Samfile(fn)
+    first = rx.extract_reads(shared, r.chrom, r.start, r.end, k)
+    assert "#" in "".join(x.qual for x in samio.Samfile(fn).reads), "fixture has no low-quality ends"
+    assert any(len(rd.seq) < len(o.seq) for (rd, _s, _c, _i) in first[0].values()
+               for o in shared.reads if o.qname == rd.qname and o.is_read1 == rd.is_read1), "nothing was trimmed"
+    for shift in (0, 150):                           # the same window again, and one that overlaps it
+        got = rx.extract_reads(shared, r.chrom, r.start + shift, r.end + shift, k)
+        want = rx.extract_reads(samio.Samfile(fn), r.chrom, r.start + shift, r.end + shift, k)
+        assert got[1] == want[1] and got[2] == want[2] and _tuples(got[3]) == _tuples(want[3]), shift
+        assert list(got[0]) == list(want[0])
+    assert rx.extract_reads(shared, r.chrom, r.start, r.end, k)[1] == case["expected"]["fastq"]
