@@ -3,16 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (the driver launches N>1 through torch.distributed.run).  A "step" is one pass of
-the hot path (read grouping -> k-mer selection -> assembly [-> realign -> call]) over one batch of
-synthetic regions (BASELINE.json configs[1]: 256 regions per GPU, 10,000 x 150 bp reads each, planted
-200 bp deletion, k = 31), inputs already packed and resident in HBM.  Regions are independent, so
-ranks get disjoint region ids (weak scaling) and the only exchange is the all-gather of the per-region
-result records at the end of each step.  Rank 0 prints ONE JSON line.
+One process per GPU.  `--gpus N` with N > 1 and no launcher in the environment starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (before anything
+touches the GPU) and exits with its code; under a launcher (RANK set) the process is one rank.
+A "step" is one pass of the hot path (read grouping -> k-mer selection -> assembly -> realign on the GPU,
+SV-call tail in host C++) over one batch of synthetic regions, inputs already packed and resident in HBM:
+  N = 1 : BASELINE.json configs[1], 256 regions x 10,000 x 150 bp reads (500x), planted 200 bp deletion, k = 31;
+  N > 1 : 512 regions per GPU per step (N = 8 is configs[2]: 4,096 regions sharded region-per-GPU).
+Regions are independent, so ranks get disjoint region ids (weak scaling) and the only exchange is the
+all-gather of the per-region result records at the end of each step.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,24 +29,43 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# integer VALU issue peak: 256 CU x 4 SIMD x 32 lanes/clk (a 64-wide wavefront instruction issues over 2 clocks) x 2.4 GHz
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--regions", type=int, default=256, help="regions per GPU per step (configs[1])")
+    ap.add_argument("--regions", type=int, default=0, help="regions per GPU per step (0: 256 = configs[1] at one GPU, 512 at several: configs[2] at 8)")
     ap.add_argument("--depth", type=int, default=500)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--kmer", type=int, default=31)
-    ap.add_argument("--cpu-sample", type=int, default=24, help="regions timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="regions timed through the CPU oracle on ONE core (0 = skip the CPU baseline)")
     ap.add_argument("--inflight", type=int, default=3, help="steps in flight (independent batches on separate HIP streams)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (testing)")
-    return ap.parse_args()
+    ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
+    ap.add_argument("--cfg3-regions", type=int, default=256)
+    ap.add_argument("--cfg4-regions", type=int, default=2)
+    ap.add_argument("--dump-collated", default=None, help="write the bytes collated in the last step to this file (testing)")
+    return ap.parse_args(argv)
+
+
+def self_launch(a):
+    """`bench.py --gpus N` without a launcher: run the ranks as a child process group (never exec: nothing of this
+    process has touched the GPU yet, and it never will)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def call_context_text(regions, opts):
@@ -59,36 +83,119 @@ def call_context_text(regions, opts):
     return "\n".join(lines) + "\n"
 
 
+def default_opts():
+    from breakmer_amd.sv_processor import params as bk_params
+    opts = dict(bk_params.DEFAULTS)
+    opts["var_filter"] = ["indel", "rearrangement", "trl"]
+    return opts
+
+
+def cfg3_region(synth, i, depth=1000):
+    """BASELINE.json configs[3] (SURVEY 8d "Config 4"): SV type = region_id % 4 in {indel (del 200 / ins 60 alternating),
+    inversion 200, tandem-dup 200, translocation with an explicit 3,000 bp partner window}, 1,000x (20,000 reads)."""
+    kind = i % 4
+    sv = ("del" if (i // 4) % 2 == 0 else "ins") if kind == 0 else ("inv", "dup", "trl")[kind - 1]
+    return synth.make_region(30000 + i, sv_type=sv, depth=depth, W=3000, L=150)
+
+
+def cfg4_region(synth, i, depth=2000):
+    """BASELINE.json configs[4] (SURVEY 8d "Config 5"): 250 bp reads at 2,000x (24,000 reads), k = 41, 5 % substitutions."""
+    return synth.make_region(40000 + i, sv_type="del", depth=depth, W=3000, L=250, noise=0.05)
+
+
+def time_other_config(hb, regions, k, opts, reps, device):
+    """whole path (GPU stages + native call tail) over one batch, inputs resident; returns regions/s and details"""
+    eng = hb.Engine(kmer_size=k, rc_thresh=2, device=device)
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, partners=[p[4] for p in r.partners]) for r in regions])
+    eng.set_call_context(call_context_text(regions, opts))
+    eng.run(hb.BK_STAGE_ALL)
+    eng.call_blob()
+    t0 = time.perf_counter()
+    ncalls = 0
+    for _ in range(reps):
+        eng.run(hb.BK_STAGE_ALL, sync=False)
+        eng.fetch()
+        raw = eng.call_blob()
+        ncalls = raw.count(b"\n")
+    dt = (time.perf_counter() - t0) / reps
+    out = {"regions": len(regions), "reads_per_region": int(regions[0].reads.shape[0]), "k": k, "value": round(len(regions) / dt, 1), "unit": "regions/s",
+           "ms_per_batch": round(dt * 1e3, 2), "kernels_ms": {"kmer": round(eng.kernel_ms(1), 2), "asm": round(eng.kernel_ms(2), 2), "sw": round(eng.kernel_ms(3), 2)},
+           "contigs": int(eng.stat(6)), "sv_calls": int(ncalls), "nw_cells": int(eng.stat(0)), "failed_regions": int(eng.stat(22)),
+           "dp_tcups": round(eng.stat(0) / dt / 1e12, 3)}
+    eng.close()
+    return out
+
+
+def _cpu_region(args):
+    """one region through the C oracle (worker of the all-core CPU baseline); returns the number of contigs"""
+    rid, depth, read_len, kmer = args
+    from breakmer_amd import synth
+    from oracle import bk_oracle as bo
+    r = synth.make_region(rid, depth=depth, L=read_len, sv_type="del")
+    t0 = time.perf_counter()
+    want, _ = bo.assemble_region(synth.BASES[r.reads], [r.window_str], kmer, 2)
+    for c in want:
+        bo.realign(c["seq"], [r.window_str])
+    return len(want), time.perf_counter() - t0
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a))
+    # ---- CPU baseline on ALL host cores (process pool over regions through the C oracle).  Runs first, before anything
+    #      initialises the GPU in this process: the workers are spawned (fork + exec) from a GPU-free parent.
+    cpu_all, cpu_cores = None, 1
+    if a.gpus == 1 and not a.force_dist and a.cpu_sample > 0:
+        cpu_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if cpu_cores > 1:
+            import multiprocessing as mp
+            nall = cpu_cores * 32                                # ~13 regions/s/core: a few seconds of wall time per core
+            with mp.get_context("spawn").Pool(cpu_cores) as pool:
+                pool.map(_cpu_region, [(i, 60, a.read_len, a.kmer) for i in range(cpu_cores)])      # start-up (imports, library build/load) outside the clock
+                t2 = time.perf_counter()
+                res = pool.map(_cpu_region, [(i % 256, a.depth, a.read_len, a.kmer) for i in range(nall)], chunksize=1)
+                all_dt = time.perf_counter() - t2
+            cpu_all = {"value": round(nall / all_dt, 3), "regions": nall, "contigs": int(sum(x[0] for x in res))}
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
     dist = world > 1 or a.force_dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     if dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if "RANK" not in os.environ:                       # --force-dist on one GPU without a launcher
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1])); s.close()
+            td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
     from breakmer_amd import hip_backend as hb, synth
+    n_regions = a.regions if a.regions > 0 else (256 if world == 1 else 512)
 
     # ---- inputs: disjoint region ids per rank (weak scaling), packed + resident before timing -------
-    ids = range(rank * a.regions, (rank + 1) * a.regions)
+    ids = range(rank * n_regions, (rank + 1) * n_regions)
     regions = [synth.make_region(i, depth=a.depth, L=a.read_len, sv_type="del") for i in ids]
     stages = hb.BK_STAGE_ALL
-    from breakmer_amd.sv_processor import params as bk_params
-    opts = dict(bk_params.DEFAULTS)
-    opts["var_filter"] = ["indel", "rearrangement", "trl"]
+    opts = default_opts()
     ctx_text = call_context_text(regions, opts)
     ins = [hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions]
     engs = []
+    submit_ms = []
     for _ in range(max(1, a.inflight)):                # one handle (= one HIP stream + its own buffers) per step in flight
         e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local)
+        t0 = time.perf_counter()
         e.submit(ins)
+        submit_ms.append((time.perf_counter() - t0) * 1e3)
         e.set_call_context(ctx_text)
         engs.append(e)
     eng = engs[0]
+    pack_ms, h2d_ms = eng.stat(20) / 1e3, eng.stat(21) / 1e3
     last_rows = {}
 
     def finish_step(e, relaunch):
@@ -100,6 +207,7 @@ def main():
             e.run(stages, sync=False)                  # group + k-mer select + assemble + realign on the GPU (async)
         raw = e.call_blob()                            # SV-call tail (host C++): one tab-separated record per call, region order
         last_rows["n"] = raw.count(b"\n") + (1 if raw and not raw.endswith(b"\n") else 0)
+        last_rows["raw"] = raw
         blob = np.frombuffer(raw, dtype=np.uint8)
         if dist:                                       # collate the variable-length records of all ranks (RCCL all-gather)
             gather(blob)
@@ -114,7 +222,7 @@ def main():
         for _ in range(2):
             slots.append({"host": torch.zeros(CAP, dtype=torch.uint8).pin_memory(), "dev": torch.zeros(CAP, dtype=torch.uint8, device="cuda"),
                           "out": torch.zeros(world * CAP, dtype=torch.uint8, device="cuda"), "work": None})
-    gstate = {"n": 0, "collated": 0}
+    gstate = {"n": 0, "collated": 0, "last": b""}
 
     def gather(blob):
         sl = slots[gstate["n"] % 2]
@@ -130,7 +238,7 @@ def main():
         sl["work"] = td.all_gather_into_tensor(sl["out"], sl["dev"], async_op=True)
 
     def drain():
-        """wait for the outstanding all-gathers; returns the bytes collated by the last one (all ranks)"""
+        """wait for the outstanding all-gathers; returns the bytes collated by the last one (all ranks, rank order)"""
         tot = 0
         for sl in slots:
             if sl["work"] is not None:
@@ -138,8 +246,13 @@ def main():
                 sl["work"] = None
         if slots and gstate["n"]:
             sl = slots[(gstate["n"] - 1) % 2]
-            heads = sl["out"].view(world, CAP)[:, :8].contiguous().cpu().numpy()
-            tot = int(sum(int(np.frombuffer(heads[r].tobytes(), dtype=np.int64)[0]) for r in range(world)))
+            allb = sl["out"].view(world, CAP).cpu().numpy()
+            parts = []
+            for r in range(world):
+                n = int(np.frombuffer(allb[r, :8].tobytes(), dtype=np.int64)[0])
+                parts.append(allb[r, 8:8 + n].tobytes())
+                tot += n
+            gstate["last"] = b"".join(parts)
         gstate["collated"] = tot
         return tot
 
@@ -166,76 +279,113 @@ def main():
         drain()
         return acc
 
+    def allmax(x):
+        if not dist:
+            return x
+        t = torch.tensor([x], device="cuda", dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t.item())
+
     run_steps(a.warmup)
     barrier()
     t0 = time.perf_counter()
     kmer_ms, asm_ms, sw_ms = run_steps(a.steps)
     barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
-    total_regions = a.regions * world * a.steps
+    dt = allmax(time.perf_counter() - t0)
+    total_regions = n_regions * world * a.steps
     value = total_regions / dt
-    # the same steps strictly one after the other (one handle, nothing in flight) for reference
-    serial = None
-    if len(engs) > 1:
-        ks = max(2, min(a.steps, 8))
-        only = engs[:1]
-        saved, engs[:] = list(engs), only
-        barrier()
-        ts = time.perf_counter()
-        s_k, s_a, s_w = run_steps(ks)
-        barrier()
-        sdt = time.perf_counter() - ts
-        engs[:] = saved
-        if dist:
-            t = torch.tensor([sdt], device="cuda", dtype=torch.float64)
-            td.all_reduce(t, op=td.ReduceOp.MAX)
-            sdt = float(t.item())
-        serial = {"value": round(a.regions * world * ks / sdt, 1), "ms_per_step": round(sdt / ks * 1e3, 3), "steps": ks,
-                  "kernels_ms": {"bk_kmer_kernel": round(s_k / ks, 3), "bk_asm_kernel": round(s_a / ks, 3), "bk_sw_kernel": round(s_w / ks, 3)}}
+    collated = gstate["collated"]
+    if a.dump_collated and rank == 0:
+        with open(a.dump_collated, "wb") as f:
+            f.write(gstate["last"])
+        with open(a.dump_collated + ".rank0", "wb") as f:
+            f.write(last_rows.get("raw", b""))
+    # ---- the same steps strictly one after the other (one handle, nothing in flight): the kernel durations of THIS pass
+    #      are exclusive (no co-running batches stretch them) and are what the roofline figures use
+    ks = max(2, min(a.steps, 8))
+    saved, engs[:] = list(engs), engs[:1]
+    barrier()
+    ts = time.perf_counter()
+    s_k, s_a, s_w = run_steps(ks)
+    barrier()
+    sdt = allmax(time.perf_counter() - ts)
+    engs[:] = saved
+    serial = {"value": round(n_regions * world * ks / sdt, 1), "ms_per_step": round(sdt / ks * 1e3, 3), "steps": ks,
+              "kernels_ms": {"bk_kmer_kernel": round(s_k / ks, 3), "bk_asm_kernel": round(s_a / ks, 3), "bk_sw_kernel": round(s_w / ks, 3)}}
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (assembler): algorithmic HBM bytes per launch / kernel time -----
         alg_bytes = eng.stat(3)                         # 2-bit reads + 4 B/read + window fwd+rc + ~2 KB out, summed over regions
-        asm_s = asm_ms / a.steps / 1e3
-        achieved = alg_bytes / asm_s / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.isfile(tf):
-            try:
-                traffic = json.load(open(tf)).get("bk_asm_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
         cells, calls = eng.stat(0), eng.stat(1)
+        asm_excl_s = s_a / ks / 1e3                     # exclusive duration of the dominant kernel (one handle)
+        step_s = dt / a.steps
+        achieved = alg_bytes / asm_excl_s / 1e9
+        prof = {}
+        for name in ("traffic.json", "valu.json"):
+            fn = os.path.join(ROOT, "profiles", name)
+            if os.path.isfile(fn):
+                try:
+                    prof.update(json.load(open(fn)))
+                except Exception:
+                    pass
+        traffic = prof.get("bk_asm_kernel_bytes_per_launch")
+        # integer-VALU roofline of the assembler: lane-ops per DP cell from the SQ_INSTS_VALU pass (profiles/valu.json:
+        # wave instructions x 64 lanes / algorithmic cells); `achieved` = algorithmic cells per second
+        lpc = prof.get("bk_asm_kernel_valu_laneops_per_cell")
+        valu = {"bound": "valu", "unit": "TCUPS", "peak_laneops_per_s": VALU_PEAK_LANEOPS, "laneops_per_cell": lpc,
+                "achieved_kernel": round(cells / asm_excl_s / 1e12, 4), "achieved_path": round(cells / step_s / 1e12, 4)}
+        if lpc:
+            valu["peak"] = round(VALU_PEAK_LANEOPS / lpc / 1e12, 3)
+            valu["frac_kernel"] = round(valu["achieved_kernel"] / valu["peak"], 4)
+            valu["frac"] = round(valu["achieved_path"] / valu["peak"], 4)
         out = {
             "metric": "target regions/sec at 500x 150bp, 31-mers; achieved HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "regions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d regions/GPU x %d reads x %d bp (%dx), planted 200 bp deletion, k=%d"
-                                   % (a.regions, regions[0].reads.shape[0], a.read_len, a.depth, a.kmer),
+            "config": {"workload": "%s: %d regions/GPU x %d reads x %d bp (%dx), planted 200 bp deletion, k=%d"
+                                   % ("configs[1]" if world == 1 else ("configs[2]" if world * n_regions == 4096 else "configs[2]-shaped"),
+                                      n_regions, regions[0].reads.shape[0], a.read_len, a.depth, a.kmer),
                        "stages": "group reads + k-mer select + assemble (olc.nw) + realign on the GPU, SV-call tail in host C++, rows collated",
+                       "regions_total_per_step": n_regions * world,
                        "sv_calls_per_step": last_rows.get("n", 0),
                        "steps_in_flight": len(engs),
-                       "collated_bytes_per_step": gstate["collated"] if dist else None,
+                       "collated_bytes_per_step": collated if dist else None,
                        "parallelism": "regions sharded per GPU, all-gather of result records"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "bk_asm_kernel", "kernel_ms": round(asm_ms / a.steps, 3),
-                         "note": "path is integer-DP/latency bound, not HBM bound (SURVEY 8d); see dp_gcups"},
-            "kernels_ms": {"bk_kmer_kernel": round(kmer_ms / a.steps, 3), "bk_asm_kernel": round(asm_ms / a.steps, 3),
-                           "bk_sw_kernel": round(sw_ms / a.steps, 3)},
-            "dp_gcups": round(cells / asm_s / 1e9, 1), "dp_cells_per_step": cells, "nw_calls_per_step": calls,
+                         "kernel": "bk_asm_kernel", "kernel_ms": round(s_a / ks, 3),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "kernel_ms = exclusive (one handle in flight); the path is integer-VALU/latency bound, not HBM bound (SURVEY 8d): see roofline_valu"},
+            "roofline_valu": valu,
+            "hbm_path": {"achieved": round(alg_bytes / step_s / 1e9, 3), "unit": "GB/s", "frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 6),
+                         "note": "algorithmic bytes of one step / ms_per_step (all kernels, batches in flight)"},
+            "kernels_ms": serial["kernels_ms"],
+            "kernels_ms_inflight": {"bk_kmer_kernel": round(kmer_ms / a.steps, 3), "bk_asm_kernel": round(asm_ms / a.steps, 3), "bk_sw_kernel": round(sw_ms / a.steps, 3)},
+            "dp_gcups": round(cells / step_s / 1e9, 1), "dp_cells_per_step": cells, "nw_calls_per_step": calls,
+            "submit_ms": round(sum(submit_ms) / len(submit_ms), 2), "submit_pack_ms": round(pack_ms, 2), "h2d_ms": round(h2d_ms, 2),
+            "submit_note": "bk_submit_regions of one %d-region batch (host 2-bit packing + H2D), outside the timed region" % n_regions,
             "one_step_at_a_time": serial,
         }
-        # ---- CPU baseline: the oracle (C port of the reference algorithm), 1 core, bounded sample -------
+        # ---- other BASELINE configs on one GPU (not the headline; whole path incl. call tail, inputs resident) -----
+        if world == 1 and a.other_configs:
+            oc = {}
+            try:
+                regs3 = [cfg3_region(synth, i) for i in range(a.cfg3_regions)]
+                oc["configs[3]"] = time_other_config(hb, regs3, 31, opts, 2, local)
+                oc["configs[3]"]["workload"] = "mixed SV set (indel/inv/dup/trl + partner window), 1,000x 150 bp, k=31"
+                del regs3
+                regs4 = [cfg4_region(synth, i) for i in range(a.cfg4_regions)]
+                oc["configs[4]"] = time_other_config(hb, regs4, 41, opts, 1, local)
+                oc["configs[4]"]["workload"] = "250 bp reads at 2,000x, k=41, 5 % substitution noise"
+                del regs4
+            except Exception as ex:                      # never lose the headline line to a side measurement
+                oc["error"] = repr(ex)
+            out["other_configs"] = oc
+        # ---- CPU baseline: the oracle (C port of the reference algorithm) on the host cores, bounded sample -------
         if world == 1 and a.cpu_sample > 0:
             from oracle import bk_oracle as bo
             bo.lib()
-            ns = min(a.cpu_sample, a.regions)
+            ns = min(a.cpu_sample, n_regions)
             asc = [synth.BASES[regions[i].reads] for i in range(ns)]
             wins = [regions[i].window_str for i in range(ns)]
             t1 = time.perf_counter()
@@ -245,9 +395,14 @@ def main():
                     bo.realign(c["seq"], [wins[i]])
             cpu_dt = time.perf_counter() - t1
             ok = all([{k: v for k, v in c.items() if k not in ("total_reads", "n_hits")} for c in eng.contigs(i)] == wants[i] for i in range(ns))
-            out["cpu_baseline"] = {"value": round(ns / cpu_dt, 3), "unit": "regions/s", "cores": 1, "kind": "port",
-                                   "sample": "%d of the %d regions of the same batch through oracle/bk_oracle.c (T1+K1/K2+init_assembly+realign), 1 thread" % (ns, a.regions),
-                                   "parity_on_sample": bool(ok)}
+            one = ns / cpu_dt
+            allc, cores = cpu_all, cpu_cores
+            out["cpu_baseline"] = {"value": allc["value"] if allc else round(one, 3), "unit": "regions/s", "cores": cores if allc else 1, "kind": "port",
+                                   "value_1core": round(one, 3),
+                                   "sample": "oracle/bk_oracle.c (T1+K1/K2+init_assembly+realign): %d regions of the same batch on 1 core; %s"
+                                             % (ns, ("%d regions over %d worker processes (all host cores)" % (allc["regions"], cores)) if allc else "single-core host"),
+                                   "parity_on_sample": bool(ok),
+                                   "context": "the reference's own Python path (lib2to3 translation, build container) runs 0.13-0.2 regions/s on one core"}
         print(json.dumps(out))
     if dist:
         td.destroy_process_group()

@@ -430,3 +430,30 @@ def test_arena_growth_and_rerun_gpu(hb):
     for i in range(len(regions)):
         assert small.contigs(i) == big.contigs(i), i
         assert [small.hits(i, c) for c in range(len(small.contigs(i)))] == [big.hits(i, c) for c in range(len(big.contigs(i)))]
+
+
+def test_bench_dist_path_gathers_call_records_gpu(hb, tmp_path):
+    """bench.py's multi-rank code path (RCCL all_gather_into_tensor of [length | records] buffers, double buffered)
+    on ONE GPU: the collated bytes of the last step equal the rank's own bk_call records, and the JSON line reports
+    them; `--gpus` must equal the real world size."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "collated.bin")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1", "--regions", "12", "--depth", "80",
+           "--cpu-sample", "0", "--other-configs", "0", "--inflight", "2", "--dump-collated", dump]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    got, own = open(dump, "rb").read(), open(dump + ".rank0", "rb").read()
+    assert got == own and len(got) > 0
+    assert line["config"]["collated_bytes_per_step"] == len(got) and line["n_gpus"] == 1
+    assert line["config"]["sv_calls_per_step"] == got.count(b"\n") == 12
+    # a launcher-less `--gpus 2` on a one-GPU box must fail (no silent single-GPU run with n_gpus: 1)
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--cpu-sample", "0"], env=env2,
+                        capture_output=True, text=True, timeout=300)
+    assert p2.returncode != 0 and "--gpus 2" in (p2.stderr + p2.stdout)
