@@ -126,6 +126,26 @@ def time_other_config(hb, regions, k, opts, reps, device):
     return out
 
 
+def usable_cores():
+    """cores this process may really use: the affinity mask, capped by the container's CPU quota (cgroup cpu.max)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for fn in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(fn).read().split()
+            if fn.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def _cpu_region(args):
     """one region through the C oracle (worker of the all-core CPU baseline); returns the number of contigs"""
     rid, depth, read_len, kmer = args
@@ -147,7 +167,7 @@ def main():
     #      initialises the GPU in this process: the workers are spawned (fork + exec) from a GPU-free parent.
     cpu_all, cpu_cores = None, 1
     if a.gpus == 1 and not a.force_dist and a.cpu_sample > 0:
-        cpu_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cpu_cores = usable_cores()
         if cpu_cores > 1:
             import multiprocessing as mp
             nall = cpu_cores * 32                                # ~13 regions/s/core: a few seconds of wall time per core

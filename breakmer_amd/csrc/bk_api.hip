@@ -3,6 +3,7 @@
 #include "../../include/breakmer_hip.h"
 #include "bk_common.h"
 #include "bk_kmer.hip.h"
+#include "bk_sched.hip.h"
 #include "bk_asm.hip.h"
 #include "bk_sw.hip.h"
 #include "bk_call.h"
@@ -48,7 +49,8 @@ struct bk_handle {
     // device
     DevBuf d_desc, d_work, d_part, d_reads, d_rlen, d_rflag, d_sc, d_sclen, d_win;
     DevBuf d_ddslot, d_ddrep, d_ddcnt, d_grp, d_urep, d_unr, d_ufl, d_ubuf, d_ureads, d_ufound, d_uminpos;
-    DevBuf d_arena, d_out, d_tops;
+    DevBuf d_arena, d_out, d_tops, d_order, d_skeys, d_clist;
+    int n_cu = 256, asm_wg_per_cu = 0, sw_wg_per_cu = 0;
     uint64_t arena_cap = 0, out_cap = 0;
     uint32_t ref_cap = 0, win_words_cap = 0;
     int n_big = 0; uint64_t big_bytes = 0;      // regions whose window needs the global-memory k-mer set
@@ -88,7 +90,7 @@ extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
         return fail(nullptr, BK_E_NOGPU, std::string("bk_create: device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only");
     if (cfg->kmer_size < 2 || cfg->kmer_size > 64) return fail(nullptr, BK_E_ARG, "bk_create: kmer_size must be in [2, 64]");
     bk_handle *h = new bk_handle();
-    h->dev = device_id; h->cfg = *cfg;
+    h->dev = device_id; h->cfg = *cfg; h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (h->cfg.max_contig_len <= 0) h->cfg.max_contig_len = 4096;
     if (h->cfg.max_read_len <= 0) h->cfg.max_read_len = 1024;
     if (h->cfg.max_candidates <= 0) h->cfg.max_candidates = 2048;
@@ -109,7 +111,7 @@ extern "C" int bk_destroy(bk_handle *h)
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
-                      &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops};
+                      &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist};
     for (auto b : bufs) b->release();
     h->h_out.release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -282,6 +284,8 @@ static void fill_params(bk_handle *h)
     p.ubuf = (int32_t *)h->d_ubuf.p; p.ureads = (int32_t *)h->d_ureads.p; p.ufound = (int32_t *)h->d_ufound.p; p.uminpos = (int32_t *)h->d_uminpos.p;
     p.arena = (uint8_t *)h->d_arena.p; p.arena_top = (unsigned long long *)h->d_tops.p; p.arena_cap = h->arena_cap;
     p.out = (uint8_t *)h->d_out.p; p.out_top = (unsigned long long *)h->d_tops.p + 1; p.out_cap = h->out_cap;
+    p.n_clist = (unsigned long long *)h->d_tops.p + 2; p.asm_head = (unsigned long long *)h->d_tops.p + 3; p.sw_head = (unsigned long long *)h->d_tops.p + 4;
+    p.order = (uint32_t *)h->d_order.p; p.clist = (unsigned long long *)h->d_clist.p; p.clist_cap = h->d_clist.bytes / 8;
     p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->eff_max_read;
     p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions;
 }
@@ -295,8 +299,12 @@ static size_t asm_lds_bytes(const bk_handle *h)
 
 static int launch(bk_handle *h, uint32_t mask)
 {
+    // every contig record takes >= 256 B of the result arena, so out_cap / 256 list entries can never overflow
+    HIPCHK(h, h->d_clist.ensure(std::max<uint64_t>(h->out_cap / 256, 1024) * 8));
+    uint32_t npad = 1; while ((int)npad < h->n_regions) npad <<= 1;
+    HIPCHK(h, h->d_order.ensure((size_t)h->n_regions * 4)); HIPCHK(h, h->d_skeys.ensure((size_t)npad * 8));
     fill_params(h);
-    const unsigned long long tops[2] = {256, 256};
+    static const unsigned long long tops[5] = {256, 256, 0, 0, 0};      // arena top, out top, contigs listed, region queue head, contig queue head
     HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if (mask & BK_STAGE_KMER) {
@@ -317,9 +325,17 @@ static int launch(bk_handle *h, uint32_t mask)
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if (mask & BK_STAGE_ASSEMBLE) {
+        // regions ordered by estimated cost, heaviest first (part of the assembler's measured time: ev[1]..ev[2])
+        hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad);
+        HIPCHK(h, hipGetLastError());
         const size_t lds = asm_lds_bytes(h);
         HIPCHK(h, hipFuncSetAttribute((const void *)bk_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bk_asm_kernel, dim3(h->n_regions), dim3(BK_AT), lds, h->stream, h->params);
+        // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bk_asm_kernel, BK_AT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        h->asm_wg_per_cu = per_cu;
+        const int grid = std::min<long long>(h->n_regions, (long long)per_cu * h->n_cu);
+        hipLaunchKernelGGL(bk_asm_kernel, dim3(grid), dim3(BK_AT), lds, h->stream, h->params);
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
@@ -328,7 +344,12 @@ static int launch(bk_handle *h, uint32_t mask)
         const uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)h->cfg.max_contig_len + 16, std::max<uint32_t>(262144, 4 * (uint32_t)h->cfg.max_contig_len));
         const size_t lds = ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + 15) / 16) * 16 + 4 * (2 * ((size_t)h->cfg.max_contig_len / 16 + 2) + tw_cap / 16 + 8);
         HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bk_sw_kernel, dim3(h->n_regions), dim3(BK_ST_T), lds, h->stream, h->params, tw_cap);
+        // one workgroup per contig, pulled from the list the assembler appended to; the number of contigs is only known
+        // on the device, so a resident-sized grid of persistent workgroups is launched (idle ones exit at once)
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bk_sw_kernel, BK_ST_T, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        h->sw_wg_per_cu = per_cu;
+        hipLaunchKernelGGL(bk_sw_kernel, dim3(per_cu * h->n_cu), dim3(BK_ST_T), lds, h->stream, h->params, tw_cap);
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));

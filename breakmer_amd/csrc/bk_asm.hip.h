@@ -44,6 +44,7 @@ struct BkAsmShared {
     // look-ahead slots (see bk_run_candidates): read q+s aligned against the PREDICTED contig after reads q..q+s-1
     struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt; BkNwResult v1, v2; } slot[BK_SPEC];
     int nb, pc, last_dec;
+    int qslot;                   // position in the region queue this workgroup is working on
     uint32_t scan[24];
 #ifdef BK_PHASE_STAMPS
     unsigned long long acc[20], last; int ctx;
@@ -60,6 +61,7 @@ struct BkAsmCtx {
     // region data
     BkRegionWork *wk;
     uint8_t *out; unsigned long long *out_top; uint64_t out_cap;
+    unsigned long long *n_clist, *clist; uint64_t clist_cap; int region;
     int rc_thresh; uint32_t read_words, max_len;
     const uint32_t *reads; const uint16_t *rlen;
     uint32_t *urep, *unr; uint8_t *ufl; int32_t *ubuf, *ureads, *ufound, *uminpos;
@@ -565,7 +567,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             if (sl < nb) {
                 const uint8_t *cs = L_CSEQ + S->slot[sl].pb; const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
                 // waves w and w+4 land on the same SIMD: give it one direct (heavier) and one transposed sweep
-                if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_wave<false>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
+                if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
                 else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
             }
         }
@@ -791,6 +793,8 @@ __device__ inline void bk_emit_contig()
         h->o_seq = o_seq; h->o_io = o_io; h->o_ot = o_ot; h->o_klocs = o_kl; h->o_kmers = o_km; h->o_reads = o_rd; h->o_hits = 0; h->size = size;
         if (C_.wk->o_first_contig == 0) C_.wk->o_first_contig = off; else ((BkContigRec *)(C_.out + C_.wk->o_last_contig))->next = off;
         C_.wk->o_last_contig = off; S->n_contigs++;
+        const unsigned long long ci = atomicAdd(C_.n_clist, 1ull);              // work list of the realign stage (one workgroup per contig)
+        if (ci < C_.clist_cap) C_.clist[ci] = off | ((unsigned long long)C_.region << 40);
     }
     BK_SYNC();
     BK_ACC(7);
@@ -821,9 +825,8 @@ __device__ inline void bk_setup_contigs(int rank)
     BK_ACC(8); BK_CTX(0);
 }
 
-extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
+__device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
 {
-    const int r = blockIdx.x;
     BkAsmShared *S = S_;
     BkRegionWork *wk = &p.work[r];
     if (wk->status != BK_ST_OK) return;                                            // k-mer stage failed for this region
@@ -831,6 +834,7 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
         const BkRegionDesc d = p.desc[r];
         BkAsmCtx &c = C_;
         c.wk = wk; c.out = p.out; c.out_top = p.out_top; c.out_cap = p.out_cap; c.rc_thresh = p.rc_thresh;
+        c.n_clist = p.n_clist; c.clist = p.clist; c.clist_cap = p.clist_cap; c.region = r;
         c.read_words = d.read_words; c.max_len = d.max_len;
         c.MAXC = p.max_contig; c.MAXR = p.max_read; c.MAXCAND = p.max_cand; c.KCAP = 2 * p.max_contig; c.k = p.k;
         int o = BK_BUF_OFF;
@@ -913,6 +917,21 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
 #endif
 }
 
+// Persistent workgroups: each pulls the next region of the cost-ordered queue (bk_sched.hip.h) until it is empty, so a
+// batch is not bound by whichever heavy region happened to be launched last, and a batch may hold many more regions
+// than workgroups fit on the chip.
+extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
+{
+    for (;;) {
+        BK_SYNC();                                       // the previous region's LDS state is dead
+        if (BK_TID == 0) S_->qslot = (int)atomicAdd(p.asm_head, 1ull);
+        BK_SYNC();
+        const int q = S_->qslot;
+        if (q >= p.n_regions) break;
+        bk_asm_region(p, (int)p.order[q]);
+    }
+}
+
 // ---- stand-alone batched olc.nw (known-answer tests G1, DP micro-benchmark) -----------------------------------
 extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_t *codes, const uint32_t *off1, const uint32_t *len1,
                                                                      const uint32_t *off2, const uint32_t *len2, int32_t *out, int reps, int transposed)
@@ -925,6 +944,6 @@ extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_
     for (int t = threadIdx.x; t < n; t += 64) s2[t] = codes[off2[b] + t];
     __syncthreads();
     BkNwResult r{};
-    for (int i = 0; i < reps; i++) r = transposed ? bk_nw_wave<true>(s2, n, s1, m, bound) : bk_nw_wave<false>(s1, m, s2, n, bound);
+    for (int i = 0; i < reps; i++) r = transposed == 2 ? bk_nw_suffix(s1, m, s2, n, bound) : transposed ? bk_nw_wave<true>(s2, n, s1, m, bound) : bk_nw_wave<false>(s1, m, s2, n, bound);
     if (threadIdx.x == 0) { out[4 * b] = r.j_start; out[4 * b + 1] = r.i_end; out[4 * b + 2] = r.i_start; out[4 * b + 3] = r.score; }
 }

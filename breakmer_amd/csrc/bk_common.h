@@ -156,6 +156,9 @@ struct BkParams {
     // arena
     uint8_t *arena; unsigned long long *arena_top; uint64_t arena_cap;     // scratch: k-mer tables, assembler state
     uint8_t *out; unsigned long long *out_top; uint64_t out_cap;           // results: contig records, hits (copied to the host)
+    // scheduling (bk_sched.hip.h): regions in descending order of estimated assembler cost, pulled by persistent
+    // workgroups; every emitted contig is appended to `clist` (its `out` offset | region << 40), pulled by the realigner
+    uint32_t *order; unsigned long long *asm_head, *sw_head, *n_clist; unsigned long long *clist; uint64_t clist_cap;
     int32_t k, rc_thresh, max_contig, max_read, max_cand, sw_min_score;
     int32_t n_regions;
 };

@@ -35,6 +35,9 @@
 #define BK_NW_G2 ((int)(((unsigned)-2) << 18) + (1 << 16))     // S[i][j-1] + gap, pointer 2
 #define BK_NW_G1 ((int)(((unsigned)-2) << 18))                 // S[i-1][j] + gap, pointer 1
 #define BK_NW_TILE_C 8
+// "closed" left border: a score no path can recover from (14-bit signed score field; rows <= 1024 cost at most -2048 more)
+#define BK_NW_CLOSED ((int)(((unsigned)-4096) << 18))
+#define LEFTB_OF(TR) ((TR) ? 0 : 0x8000)
 #define BK_NW_TILE_COLS (64 * BK_NW_TILE_C)
 
 struct BkNwResult { int j_start, i_end, i_start, score; };
@@ -55,9 +58,10 @@ __device__ inline int bk_dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(v,
 // edge cell is read straight out of its H register, the row index is a running counter, the end-cell selection of the
 // direct sweep is branch-free.  ~45 instructions per step at C = 4 (general variant: ~75).
 template <int C, bool TR, int XM>
-__device__ __noinline__ int2 bk_nw_tile_st(const uint8_t *cols, const uint8_t *rows, int n_, int mt_)
+__device__ __noinline__ int2 bk_nw_tile_st(const uint8_t *cols, const uint8_t *rows, int n_, int mt_, int lb_)
 {
     const int n = __builtin_amdgcn_readfirstlane(n_), mt = __builtin_amdgcn_readfirstlane(mt_);
+    const int lbase = (LEFTB_OF(TR) + 1) + __builtin_amdgcn_readfirstlane(lb_);      // left border word of row 1 (lb: 0, or BK_NW_CLOSED)
     const int lane = threadIdx.x & 63;
     const int lm = (mt - 1) / C;
     constexpr int GH = TR ? BK_NW_G1 : BK_NW_G2, GV = TR ? BK_NW_G2 : BK_NW_G1;
@@ -83,7 +87,7 @@ __device__ __noinline__ int2 bk_nw_tile_st(const uint8_t *cols, const uint8_t *r
             rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
             { const int rb0 = __builtin_amdgcn_readlane(rblk, tl); if (lane == 0) rb = rb0; }       // rows[t] enters at lane 0
             if (inlanes && (unsigned)im1 < (unsigned)n) {
-                const int left_in = lane == 0 ? (LEFTB + 1) + im1 : recv;
+                const int left_in = lane == 0 ? lbase + im1 : recv;
                 int cd[C], cv[C];
 #pragma unroll
                 for (int x = 0; x < C; x++) {
@@ -124,17 +128,17 @@ __device__ __noinline__ int2 bk_nw_tile_st(const uint8_t *cols, const uint8_t *r
     return make_int2(best_word, best_i);
 }
 template <int C, bool TR, int XM>
-__device__ inline int2 bk_nw_st_xm(int xm, const uint8_t *cols, const uint8_t *rows, int n, int mt)
+__device__ inline int2 bk_nw_st_xm(int xm, const uint8_t *cols, const uint8_t *rows, int n, int mt, int lb)
 {
-    if (TR || xm == XM) return bk_nw_tile_st<C, TR, TR ? 0 : XM>(cols, rows, n, mt);
-    if constexpr (!TR && XM + 1 < C) return bk_nw_st_xm<C, TR, XM + 1>(xm, cols, rows, n, mt);
+    if (TR || xm == XM) return bk_nw_tile_st<C, TR, TR ? 0 : XM>(cols, rows, n, mt, lb);
+    if constexpr (!TR && XM + 1 < C) return bk_nw_st_xm<C, TR, XM + 1>(xm, cols, rows, n, mt, lb);
     return make_int2(0, 0);
 }
 template <int C, bool TR>
-__device__ inline int2 bk_nw_st_call(int c, const uint8_t *cols, const uint8_t *rows, int n, int mt)
+__device__ inline int2 bk_nw_st_call(int c, const uint8_t *cols, const uint8_t *rows, int n, int mt, int lb)
 {
-    if (c == C) return bk_nw_st_xm<C, TR, 0>((mt - 1) % C, cols, rows, n, mt);
-    if constexpr (C < BK_NW_TILE_C) return bk_nw_st_call<C + 1, TR>(c, cols, rows, n, mt);
+    if (c == C) return bk_nw_st_xm<C, TR, 0>((mt - 1) % C, cols, rows, n, mt, lb);
+    if constexpr (C < BK_NW_TILE_C) return bk_nw_st_call<C + 1, TR>(c, cols, rows, n, mt, lb);
     return make_int2(0, 0);
 }
 
@@ -142,8 +146,9 @@ __device__ inline int2 bk_nw_st_call(int c, const uint8_t *cols, const uint8_t *
 // loads/stores and no uniform branches in the loop (the general variant is ~75 instructions per step at C = 4, this one ~50).
 template <int C, bool TR, int XM, bool ST>
 __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows, int n_, int j0_, int mt_,
-                                        const int *bound_in, int *bound_out, bool last_, int best_word, int best_i)
+                                        const int *bound_in, int *bound_out, bool last_, int best_word, int best_i, int lb_)
 {
+    const int lb = __builtin_amdgcn_readfirstlane(lb_);
     // the arguments of an out-of-line function arrive in VGPRs: tell the compiler they are wave-uniform so that
     // the loop control and the lane predicates stay on the scalar unit
     const int n = __builtin_amdgcn_readfirstlane(n_), j0 = ST ? 0 : __builtin_amdgcn_readfirstlane(j0_), mt = __builtin_amdgcn_readfirstlane(mt_);
@@ -178,7 +183,7 @@ __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows
             int left_in;
             if constexpr (ST) left_in = lane == 0 ? (LEFTB | i) : recv;
             else {
-                if (lane == 0) left_in = (j0 == 0) ? (LEFTB | i) : bound_in[i];
+                if (lane == 0) left_in = (j0 == 0) ? (LEFTB | i) + lb : bound_in[i];
                 else left_in = recv;
             }
             // candidates that only need the previous tile row first (off the dependency chain), then the
@@ -236,30 +241,31 @@ __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows
 
 template <int C, bool TR, int XM, bool ST>
 __device__ inline int2 bk_nw_tile_xm(int xm, const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt,
-                                     const int *bi, int *bo, bool last, int bw, int bidx)
+                                     const int *bi, int *bo, bool last, int bw, int bidx, int lb)
 {
-    if (TR || xm == XM) return bk_nw_tile<C, TR, TR ? 0 : XM, ST>(cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
-    if constexpr (!TR && XM + 1 < C) return bk_nw_tile_xm<C, TR, XM + 1, ST>(xm, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if (TR || xm == XM) return bk_nw_tile<C, TR, TR ? 0 : XM, ST>(cols, rows, n, j0, mt, bi, bo, last, bw, bidx, lb);
+    if constexpr (!TR && XM + 1 < C) return bk_nw_tile_xm<C, TR, XM + 1, ST>(xm, cols, rows, n, j0, mt, bi, bo, last, bw, bidx, lb);
     return make_int2(bw, bidx);
 }
 template <int C, bool TR, bool ST>
 __device__ inline int2 bk_nw_tile_call(int c, const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt,
-                                       const int *bi, int *bo, bool last, int bw, int bidx)
+                                       const int *bi, int *bo, bool last, int bw, int bidx, int lb)
 {
-    if (c == C) return bk_nw_tile_xm<C, TR, 0, ST>((mt - 1) % C, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
-    if constexpr (C < BK_NW_TILE_C) return bk_nw_tile_call<C + 1, TR, ST>(c, cols, rows, n, j0, mt, bi, bo, last, bw, bidx);
+    if (c == C) return bk_nw_tile_xm<C, TR, 0, ST>((mt - 1) % C, cols, rows, n, j0, mt, bi, bo, last, bw, bidx, lb);
+    if constexpr (C < BK_NW_TILE_C) return bk_nw_tile_call<C + 1, TR, ST>(c, cols, rows, n, j0, mt, bi, bo, last, bw, bidx, lb);
     return make_int2(bw, bidx);
 }
 
 // Executed by the calling wave (all 64 lanes).  `tcols` (length m) goes on the tile columns, `trows` (length n) on
 // the tile rows.  TR = false computes olc.nw(seq1 = tcols, seq2 = trows); TR = true computes
 // olc.nw(seq1 = trows, seq2 = tcols).  bound: LDS scratch of 2*(n+1) ints, needed only when m > BK_NW_TILE_COLS.
+// lb = BK_NW_CLOSED closes the border column of the reference matrix (direct sweep only): bk_nw_suffix below.
 template <bool TR>
-__device__ inline BkNwResult bk_nw_wave(const uint8_t *tcols, int m, const uint8_t *trows, int n, int *bound)
+__device__ inline BkNwResult bk_nw_wave(const uint8_t *tcols, int m, const uint8_t *trows, int n, int *bound, int lb = 0)
 {
     int best_word = 0, best_i = 0;                      // border cell of the last reference column: score 0 (olc.py:79-83)
     if (m <= BK_NW_TILE_COLS) {
-        const int2 b = bk_nw_st_call<1, TR>((m + 63) / 64, tcols, trows, n, m);
+        const int2 b = bk_nw_st_call<1, TR>((m + 63) / 64, tcols, trows, n, m, lb);
         best_word = b.x; best_i = b.y;
     } else {
         int *bi = bound, *bo = bound ? bound + (n + 1) : nullptr;
@@ -267,7 +273,7 @@ __device__ inline BkNwResult bk_nw_wave(const uint8_t *tcols, int m, const uint8
             const int mt = min(m - j0, BK_NW_TILE_COLS);
             const bool last = j0 + mt >= m;
             const int c = (mt + 63) / 64;
-            const int2 b = bk_nw_tile_call<1, TR, false>(c, tcols, trows, n, j0, mt, bi, bo, last, best_word, best_i);
+            const int2 b = bk_nw_tile_call<1, TR, false>(c, tcols, trows, n, j0, mt, bi, bo, last, best_word, best_i, lb);
             best_word = b.x; best_i = b.y;
             int *tswap = bi; bi = bo; bo = tswap;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -283,5 +289,23 @@ __device__ inline BkNwResult bk_nw_wave(const uint8_t *tcols, int m, const uint8
         r.score = best_word >> 18; r.i_end = best_i;
         if (org & 0x8000) { r.i_start = org & 0x7FFF; r.j_start = 0; } else { r.j_start = org; r.i_start = 0; }
     }
+    return r;
+}
+
+// olc.nw(seq1 = contig, seq2 = read) needs only the last floor(1.5 n) + 2 columns of a long contig.  Proof: the end cell
+// lies in the last column and scores >= 0 (the border cell (0, m) does).  A path that spans L columns over at most n rows
+// has a <= n diagonal steps and >= L - a column gaps, so it scores <= a - 2 (L - a) <= 3 n - 2 L, which is negative for
+// L > 1.5 n: the traceback path of the end cell -- a maximum-score path to it -- starts on the top border at a column
+// >= m - 1.5 n.  Every cell ON that path has the same value in the matrix restricted to the last K columns with the
+// cut column closed (no path may start there), all other cells can only score lower there, so the end-cell rule
+// (largest row among equal maxima) and every pointer decision along the path (priority among equal candidates) come out
+// the same.  Columns before m - K are never computed.
+__device__ inline BkNwResult bk_nw_suffix(const uint8_t *contig, int m, const uint8_t *read, int n, int *bound)
+{
+    const int K = n + (n >> 1) + 2;
+    if (m <= K) return bk_nw_wave<false>(contig, m, read, n, bound, 0);
+    const int off = m - K;
+    BkNwResult r = bk_nw_wave<false>(contig + off, K, read, n, bound, BK_NW_CLOSED);
+    r.j_start += off;                                   // top-border origins (and the forced step of Q5) are column numbers
     return r;
 }

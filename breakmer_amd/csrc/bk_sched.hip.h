@@ -1,0 +1,43 @@
+// bk_sched.hip.h -- work distribution between the stages.
+//
+// The reference loops over its targets one after the other (sv_processor.py:185-201); here a batch of regions is in
+// flight at once and regions differ in cost by three orders of magnitude (a clean 200 bp deletion: 30 sample k-mers,
+// ~10 M DP cells; a translocation whose partner half is all non-reference: 1,500 k-mers, 2 G cells; a noisy region:
+// 10^5 k-mers).  One workgroup per region in launch order leaves a batch waiting for whichever heavy region started
+// last.  So the k-mer stage's own figures (BkRegionWork.T = non-reference k-mer occurrences in unique reads, M = sample
+// k-mers) rank the regions, heaviest first (longest-processing-time-first), and the assembler's workgroups are
+// persistent: each pulls the next region of that order from a device-side queue head until the queue is empty.
+#pragma once
+#include "bk_common.h"
+
+#define BK_SCHED_T 1024
+
+// one workgroup: order[] = region ids by (cost descending, id ascending) -- deterministic
+extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParams p, unsigned long long *keys /* npad words of scratch */, uint32_t npad)
+{
+    const int tid = threadIdx.x, n = p.n_regions;
+    for (uint32_t i = tid; i < npad; i += BK_SCHED_T) {
+        unsigned long long key = ~0ull;                                   // padding sorts last
+        if ((int)i < n) {
+            const BkRegionWork &w = p.work[i];
+            // assembler cost grows with the number of read recruitments (T) and of k-mer visits (M); a failed or empty
+            // region costs nothing
+            unsigned long long cost = w.status == BK_ST_OK ? (unsigned long long)w.T + 4ull * w.M : 0ull;
+            if (cost > 0xFFFFFFFFull) cost = 0xFFFFFFFFull;
+            key = ((0xFFFFFFFFull - cost) << 32) | i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (uint32_t sz = 2; sz <= npad; sz <<= 1)
+        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+            for (uint32_t i = tid; i < npad / 2; i += BK_SCHED_T) {
+                const uint32_t lo = (i / st) * (st * 2) + (i % st), hi = lo + st;
+                const bool up = (lo & sz) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += BK_SCHED_T) p.order[i] = (uint32_t)keys[i];
+}

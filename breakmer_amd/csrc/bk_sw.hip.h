@@ -13,7 +13,8 @@
 // walked.  A diagonal with U < L cannot hold the maximum, ties (U == L) are walked, so the result
 // equals the brute-force scan.  Query interval and target are staged in LDS as packed words; the target stays staged
 // across passes and contigs while it is the same chunk.
-// One workgroup per region; contigs and query intervals are processed in sequence.
+// One workgroup per CONTIG: persistent workgroups pull entries of the contig list the assembler appended to
+// (contigs are independent; a noisy region has thousands of them), query intervals of a contig are processed in sequence.
 // Chaining of collinear hits into PSL records is host code (bk_api.hip), restated in the oracle.
 #pragma once
 #include "bk_common.h"
@@ -28,9 +29,10 @@ struct BkSwShared {
     unsigned long long best_key; int best_run;
     unsigned long long cells;
     int L, umax;                 // lower bound on the pass maximum (an achieved score); block maximum of U
-    int staged_ti, staged_t0, staged_t1;   // which target bases the packed staging buffer currently holds
+    int staged_ti, staged_t0, staged_t1, staged_region;   // which target bases the packed staging buffer currently holds
     unsigned long long rec_off;
     int status;
+    unsigned long long qidx; int skip;
 };
 
 __device__ inline unsigned long long bk_sw_key(int score, int tidx, int strand, int a, long long b)
@@ -95,20 +97,34 @@ __device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *tp, int tp
 extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, uint32_t tw_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sl[];
-    const int r = blockIdx.x, tid = threadIdx.x;
-    BkRegionWork *wk = &p.work[r];
-    if (wk->status != BK_ST_OK) return;
-    const BkRegionDesc d = p.desc[r];
+    const int tid = threadIdx.x;
     BkSwShared *S = (BkSwShared *)sl;
     uint8_t *qf = sl + ((sizeof(BkSwShared) + 15) / 16) * 16;          // contig forward (codes)
     uint8_t *qr = qf + p.max_contig;                                   // contig reverse complement
     uint32_t *qpk = (uint32_t *)(sl + ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)p.max_contig + 15) / 16) * 16);   // packed query interval, both strands
     const int qpw = p.max_contig / 16 + 2;
     uint32_t *tp = qpk + 2 * qpw;                                      // staged target chunk, packed words (kept across passes and contigs)
-    if (tid == 0) { S->cells = 0; S->status = 0; S->rec_off = wk->o_first_contig; S->staged_ti = -1; S->staged_t0 = 0; S->staged_t1 = 0; }
-    __syncthreads();
-    while (S->rec_off != 0) {
-        const unsigned long long roff = S->rec_off;
+    if (tid == 0) { S->staged_ti = -1; S->staged_t0 = 0; S->staged_t1 = 0; S->staged_region = -1; }
+    const unsigned long long n_list = min(*p.n_clist, (unsigned long long)p.clist_cap);
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long qi = atomicAdd(p.sw_head, 1ull);
+            S->qidx = qi; S->cells = 0; S->status = 0; S->skip = 0;
+            if (qi < n_list) {                                          // one reader of the (concurrently written) region status
+                const int rr = (int)(p.clist[qi] >> 40);
+                S->skip = p.work[rr].status != BK_ST_OK;
+                if (S->staged_region != rr) { S->staged_ti = -1; S->staged_region = rr; }
+            }
+        }
+        __syncthreads();
+        if (S->qidx >= n_list) break;
+        if (S->skip) continue;
+        const unsigned long long ent = p.clist[S->qidx];
+        const int r = (int)(ent >> 40);
+        const unsigned long long roff = ent & ((1ull << 40) - 1ull);
+        BkRegionWork *wk = &p.work[r];
+        const BkRegionDesc d = p.desc[r];
         BkContigRec *rec = (BkContigRec *)(p.out + roff);
         const int Q = rec->seq_len;
         const char *seq = (const char *)(p.out + roff + rec->o_seq);
@@ -209,9 +225,8 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                 if (off + need > p.out_cap) { S->status = BK_ST_OUT; rec->n_hits = 0; }
                 else { BkHit *o = (BkHit *)(p.out + off); for (int i = 0; i < nh; i++) o[i] = S->hits[i]; rec->hits_off = off; }
             }
-            S->rec_off = rec->next;
+            atomicAdd((unsigned long long *)&wk->sw_cells, S->cells);
+            if (S->status) wk->status = S->status;
         }
-        __syncthreads();
     }
-    if (tid == 0) { wk->sw_cells = S->cells; if (S->status) wk->status = S->status; }
 }

@@ -302,7 +302,9 @@ class Engine(object):
         return out
 
     def nw_batch(self, pairs, reps=1, transposed=False):
-        """olc.nw on (seq1, seq2) pairs -> int32 [n,4] (j_start, i_end, i_start, score), kernel ms."""
+        """olc.nw on (seq1, seq2) pairs -> int32 [n,4] (j_start, i_end, i_start, score), kernel ms.
+        transposed: False = direct sweep, True = the transposed sweep the assembler uses for nw(read, contig),
+        2 = the direct sweep restricted to the last 1.5 len(seq2) + 2 columns of seq1 (what the assembler runs for nw(contig, read))."""
         blob = bytearray()
         o1, l1, o2, l2 = [], [], [], []
         for a, b in pairs:
@@ -312,5 +314,5 @@ class Engine(object):
         out = np.zeros((len(pairs), 4), dtype=np.int32)
         ms = C.c_float()
         self._chk(self.L.bk_nw_batch(self.h, bytes(blob), len(blob), o1.ctypes.data, l1.ctypes.data, o2.ctypes.data, l2.ctypes.data,
-                                     len(pairs), reps, 1 if transposed else 0, out.ctypes.data, C.byref(ms)), "bk_nw_batch")
+                                     len(pairs), reps, int(transposed), out.ctypes.data, C.byref(ms)), "bk_nw_batch")
         return out, ms.value

@@ -165,7 +165,8 @@ int bk_get_calls(bk_handle *h, char *buf, size_t cap, size_t *needed);   /* "<re
 int bk_call_text(const char *text, char *out, size_t cap, int *target_hit);   /* one fully described contig; no GPU needed */
 
 /* batched olc.nw on explicit pairs (known-answer tests, DP micro-benchmark): out = 4 ints per pair
- * (j_start, i_end, i_start, score); transposed != 0 uses the sweep the assembler uses for nw(read, contig) */
+ * (j_start, i_end, i_start, score); transposed = 1 uses the sweep the assembler uses for nw(read, contig), 2 the
+ * suffix-restricted direct sweep it uses for nw(contig, read) (same results by construction; tests compare all three) */
 int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, const uint32_t *off1, const uint32_t *len1,
                 const uint32_t *off2, const uint32_t *len2, int32_t n_pairs, int32_t reps, int32_t transposed, int32_t *out, float *ms);
 

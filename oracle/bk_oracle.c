@@ -177,6 +177,9 @@ struct bko_asm {
     /* FIFO buff.contigs */
     pending *pend; int phead, ptail, pcap;
     int serial;
+    /* optional index behind find_reads (bko_set_find_index): first occurrence of every sample k-mer in every unique read */
+    int *ix_off, *ix_u, *ix_pos;
+    int *usedlist; int nusedlist;
     /* results */
     contig **out; int nout, outcap;
 };
@@ -219,11 +222,53 @@ static int cmp_hit_rev(const void *x, const void *y) {            /* :119 key (-
     if (p->len != q->len) return q->len - p->len;
     return p->u - q->u;
 }
+/* The reference's find_reads scans EVERY remaining read with a regex for every k-mer visit: O(visits x reads x L), hours
+ * for one region of BASELINE configs[4] (10^5 visits x 24,000 reads).  bko_set_find_index(1) answers the same question
+ * -- which reads contain the k-mer, and where first -- from an index built once per region (k-mer -> (read, first
+ * position), reads in fq_recs order); the dynamic filters (deleted, buffered) and the sort are applied exactly as in
+ * the scan.  Same result by construction, checked against the scan in tests/test_oracle_golden.py; default is the scan. */
+static int g_find_index = 0;
+void bko_set_find_index(int on) { g_find_index = on; }
+static void build_find_index(bko_asm *a)
+{
+    const int M = a->M, k = a->k;
+    int *last = (int *)xmalloc((size_t)(M + 1) * sizeof(int)); for (int i = 0; i < M; i++) last[i] = -1;
+    a->ix_off = (int *)xcalloc((size_t)M + 2, sizeof(int));
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = 0; i < M; i++) last[i] = -1;
+        for (int u = 0; u < a->U; u++) {
+            const char *s = RSEQ(a, u); const int len = a->ulens[u];
+            for (int x = 0; x + k <= len; x++) {
+                const int *v = smap_find(&a->mermap, s + x, k);
+                if (!v || last[*v] == u) continue;                  /* first occurrence only (re.search) */
+                last[*v] = u;
+                if (pass == 0) a->ix_off[*v + 1]++;
+                else { const int at = a->ix_off[*v]++; a->ix_u[at] = u; a->ix_pos[at] = x; }
+            }
+        }
+        if (pass == 0) {
+            for (int i = 0; i < M; i++) a->ix_off[i + 1] += a->ix_off[i];
+            a->ix_u = (int *)xmalloc((size_t)(a->ix_off[M] + 1) * sizeof(int)); a->ix_pos = (int *)xmalloc((size_t)(a->ix_off[M] + 1) * sizeof(int));
+        } else { for (int i = M; i > 0; i--) a->ix_off[i] = a->ix_off[i - 1]; a->ix_off[0] = 0; }
+    }
+    free(last);
+}
 /* find_reads sv_assembly.py:111-122 (+read_search :102-107). filter_serial<0: used_reads = set() */
 static int find_reads(bko_asm *a, int mer, int rev, int filter_serial, rhit **out)
 {
     int n = 0, cap = 64; rhit *v = (rhit *)xmalloc((size_t)cap * sizeof(rhit));
     const char *ms = MER(a, mer);
+    if (a->ix_off) {
+        for (int t = a->ix_off[mer]; t < a->ix_off[mer + 1]; t++) {
+            const int u = a->ix_u[t];
+            if (a->deleted[u]) continue;
+            if (filter_serial >= 0 && a->buf_stamp[u] == filter_serial) continue;
+            if (n == cap) { cap *= 2; v = (rhit *)xrealloc(v, (size_t)cap * sizeof(rhit)); }
+            v[n].u = u; v[n].pos = a->ix_pos[t]; v[n].len = a->ulens[u]; v[n].nreads = a->unreads[u]; n++;
+        }
+        qsort(v, (size_t)n, sizeof(rhit), rev ? cmp_hit_rev : cmp_hit_for);
+        *out = v; return n;
+    }
     for (int u = 0; u < a->U; u++) {
         if (a->deleted[u]) continue;
         const char *s = RSEQ(a, u); int len = a->ulens[u];
@@ -472,7 +517,7 @@ static void grow(bko_asm *a, contig *c)
             int rev = 0;                                                              /* get_mer_reads :604-614 */
             if (kv.order == ORD_MID) { if (kv.lt == 0) rev = 1; } else if (kv.order == ORD_FOR) rev = 1;
             rhit *hits; int nh = find_reads(a, kv.mer, rev, c->serial, &hits);
-            a->usedmer[kv.mer] = 1;
+            if (!a->usedmer[kv.mer]) { a->usedmer[kv.mer] = 1; a->usedlist[a->nusedlist++] = kv.mer; }
             for (int q = 0; q < nh; q++) {
                 if (check_read(a, c, kv.mer, a->counts[kv.mer], hits[q].u, hits[q].nreads, 1)) fifo_remove(a, hits[q].u);
             }
@@ -497,7 +542,7 @@ static void keep_or_drop(bko_asm *a, contig *c)                                 
 static void setup_contigs(bko_asm *a, int mer)
 {
     rhit *hits; int nh = find_reads(a, mer, 0, -1, &hits);
-    a->usedmer[mer] = 1;
+    if (!a->usedmer[mer]) { a->usedmer[mer] = 1; a->usedlist[a->nusedlist++] = mer; }
     contig *ct = NULL;
     for (int q = 0; q < nh; q++) {
         int u = hits[q].u;
@@ -535,6 +580,7 @@ bko_asm *bko_init_assembly(const char *useqs, int stride, const int *ulens, cons
     a->removed = (unsigned char *)xcalloc((size_t)M, 1); a->usedmer = (unsigned char *)xcalloc((size_t)M, 1);
     a->checked_stamp = (int *)xcalloc((size_t)M, sizeof(int)); a->mset_stamp = (int *)xcalloc((size_t)M, sizeof(int)); a->tmp_stamp = (int *)xcalloc((size_t)M, sizeof(int));
     a->order = (int *)xmalloc((size_t)(M + 1) * sizeof(int));
+    a->usedlist = (int *)xmalloc((size_t)(M + 1) * sizeof(int)); a->nusedlist = 0;
     smap_init(&a->mermap, (size_t)M);
     if (M == 0) return a;                                                             /* :33-34 */
     int no = 0;
@@ -545,6 +591,7 @@ bko_asm *bko_init_assembly(const char *useqs, int stride, const int *ulens, cons
     }
     cmp_order_mers = mers; cmp_order_counts = counts; cmp_order_k = k;
     qsort(a->order, (size_t)no, sizeof(int), cmp_order);
+    if (g_find_index) build_find_index(a);
     int head = 0;
     for (;;) {                                                                        /* :43-62 */
         while (head < no && a->removed[a->order[head]]) head++;
@@ -558,7 +605,8 @@ bko_asm *bko_init_assembly(const char *useqs, int stride, const int *ulens, cons
             contig *c = contig_new(a, p.mer, p.read, p.nreads);
             grow(a, c); keep_or_drop(a, c);
         }
-        for (int i = 0; i < M; i++) if (a->usedmer[i]) { a->removed[i] = 1; a->usedmer[i] = 0; }      /* remove_kmers :358-360 */
+        for (int t = 0; t < a->nusedlist; t++) { const int i = a->usedlist[t]; a->removed[i] = 1; a->usedmer[i] = 0; }      /* remove_kmers :358-360 */
+        a->nusedlist = 0;
         /* buff.remove_reads is a no-op (ids vs sequence keys, Q7) */
     }
     return a;
@@ -584,6 +632,7 @@ void bko_asm_free(bko_asm *a)
 {
     if (!a) return;
     for (int i = 0; i < a->nout; i++) contig_free(a->out[i]);
+    free(a->ix_off); free(a->ix_u); free(a->ix_pos); free(a->usedlist);
     free(a->out); free(a->used); free(a->deleted); free(a->buf_stamp); free(a->reads_stamp); free(a->founder_of);
     free(a->removed); free(a->usedmer); free(a->checked_stamp); free(a->mset_stamp); free(a->tmp_stamp); free(a->order);
     smap_free(&a->mermap); free(a->pend); free(a);
@@ -622,6 +671,7 @@ int bko_check_align_case(const char *contig_seq, int clen, const char *read_seq,
     a->removed = (unsigned char *)xcalloc((size_t)M + 1, 1); a->usedmer = (unsigned char *)xcalloc((size_t)M + 1, 1);
     a->checked_stamp = (int *)xcalloc((size_t)M + 1, sizeof(int)); a->mset_stamp = (int *)xcalloc((size_t)M + 1, sizeof(int)); a->tmp_stamp = (int *)xcalloc((size_t)M + 1, sizeof(int));
     a->order = (int *)xmalloc((size_t)(M + 1) * sizeof(int));
+    a->usedlist = (int *)xmalloc((size_t)(M + 1) * sizeof(int)); a->nusedlist = 0;
     smap_init(&a->mermap, (size_t)M);
     for (int i = 0; i < M; i++) *smap_put(&a->mermap, MER(a, i), k, i) = i;
     int *mi = smap_find(&a->mermap, mer, k); int meridx = mi ? *mi : 0;

@@ -48,6 +48,9 @@ bko_asm *bko_init_assembly(const char *useqs, int stride, const int *ulens, cons
                            const uint8_t *uindel, int U,
                            const char *mers, const int *counts, int M,
                            int k, int rc_thresh, int read_len);
+/* 1: find_reads answers from a per-region k-mer -> (read, first position) index instead of scanning every read per visit
+ * (same result, checked in tests; needed for full-size BASELINE configs[4] regions); default 0 = the reference's scan */
+void bko_set_find_index(int on);
 int bko_asm_ncontigs(const bko_asm *a);
 int bko_asm_contig_len(const bko_asm *a, int c);
 int bko_asm_contig_clen(const bko_asm *a, int c);          /* len(counts.others) (Q8: may differ) */

@@ -152,8 +152,10 @@ def init_assembly(useqs, unreads, uindel, mers, counts, k, rc_thresh, read_len):
     return out, flags[:U]
 
 
-def assemble_region(read_seqs, refs, k, rc_thresh=2, indel_only=None, sc_seqs=None):
-    """T1 -> K1/K2 -> init_assembly for one region; returns (contigs, info)."""
+def assemble_region(read_seqs, refs, k, rc_thresh=2, indel_only=None, sc_seqs=None, find_index=False):
+    """T1 -> K1/K2 -> init_assembly for one region; returns (contigs, info).  find_index: answer find_reads from a
+    k-mer -> reads index instead of the reference's scan over all reads (same result; for full-size noisy regions)."""
+    lib().bko_set_find_index(1 if find_index else 0)
     rep, cnt = group_reads(read_seqs)
     if isinstance(read_seqs, np.ndarray):
         useqs = read_seqs[rep]

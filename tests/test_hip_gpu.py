@@ -32,6 +32,7 @@ def test_g1_nw_kats_gpu(hb, golden_dir):
     out, _ = eng.nw_batch(pairs)
     out_t, _ = eng.nw_batch(pairs, transposed=True)          # the transposed sweep used for nw(read, contig)
     assert out.tolist() == out_t.tolist()
+    assert eng.nw_batch(pairs, transposed=2)[0].tolist() == out.tolist()      # suffix-restricted sweep used for nw(contig, read)
     for c, o in zip(d["cases"], out.tolist()):
         exp = c["out"]
         assert o == [exp[3], exp[4], exp[5], exp[6]], c["tag"]
@@ -59,13 +60,31 @@ def test_nw_random_vs_oracle_gpu(hb):
     big = "".join(rnd.choice("ACGT") for _ in range(4000))
     pairs.append((big, big[3800:] + "ACGTACGT" * 10))
     pairs.append((big[:1500], big[1300:1500] + "TTTT" * 20))
+    # long seq1 against short seq2 (the suffix-restricted sweep cuts columns there): planted overlaps at the end, in the
+    # middle (must lose against the end), periodic and low-complexity sequences (ties everywhere), gaps near the cut
+    for t in range(300):
+        m, n = rnd.randint(40, 2500), rnd.randint(1, 160)
+        alpha = "ACGT" if t % 3 else "AC"
+        a = "".join(rnd.choice(alpha) for _ in range(m))
+        if t % 5 == 0:
+            a = ("ACGTTGCA" * 400)[:m]
+        ov = rnd.randint(1, min(m, n))
+        src = a[m - ov:] if t % 4 else a[max(0, m - ov - rnd.randint(0, 300)):][:ov]
+        b = src + "".join(rnd.choice(alpha) for _ in range(n - len(src)))
+        if t % 2:
+            b = "".join((ch if rnd.random() > 0.05 else rnd.choice("ACGT")) for ch in b)
+        if t % 7 == 0 and len(b) > 12:
+            b = b[:5] + b[7:]                                # a gap
+        pairs.append((a, b[:n] if b[:n] else "A"))
     eng = hb.Engine(kmer_size=31)
     out, _ = eng.nw_batch(pairs)
     out_t, _ = eng.nw_batch(pairs, transposed=True)
-    for (a, b), o, ot in zip(pairs, out.tolist(), out_t.tolist()):
+    out_s, _ = eng.nw_batch(pairs, transposed=2)
+    for (a, b), o, ot, os_ in zip(pairs, out.tolist(), out_t.tolist(), out_s.tolist()):
         e = bo.nw(a, b)
         assert o == [e[3], e[4], e[5], e[6]], (len(a), len(b))
         assert ot == o, (len(a), len(b), "transposed")
+        assert os_ == o, (len(a), len(b), "suffix")
 
 
 def _run_regions(hb, regions, k, rc_thresh=2, stages=3):
@@ -457,3 +476,84 @@ def test_bench_dist_path_gathers_call_records_gpu(hb, tmp_path):
     p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--cpu-sample", "0"], env=env2,
                         capture_output=True, text=True, timeout=300)
     assert p2.returncode != 0 and "--gpus 2" in (p2.stderr + p2.stdout)
+
+
+def _bench_mod():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench
+
+
+def test_full_size_config3_regions_gpu(hb):
+    """BASELINE.json configs[3] at FULL size (20,000 x 150 bp reads = 1,000x, W = 3,000): the mixed SV set bench.py
+    times -- deletion, insertion, inversion, tandem duplication, translocation with its partner window -- k-mers,
+    contigs and realign records bit-exact against the C oracle."""
+    from oracle import bk_oracle as bo
+    bench = _bench_mod()
+    regions = [bench.cfg3_region(synth, i) for i in range(8)]
+    assert [r.sv_type for r in regions] == ["del", "inv", "dup", "trl", "ins", "inv", "dup", "trl"]
+    assert all(r.reads.shape == (20000, 150) for r in regions) and len(regions[3].partners) == 1
+    eng = _run_regions(hb, regions, 31, stages=7)
+    nrec = 0
+    for i, r in enumerate(regions):
+        assert eng.region_status(i) == (0, "ok")
+        targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        want, info = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2, find_index=True)
+        assert eng.kmers(i)[0] == [m for m, _ in sorted(zip(info["mers"], info["counts"].tolist()), key=lambda x: (x[1], x[0]), reverse=True)], i
+        got = eng.contigs(i)
+        assert _strip(got) == want and len(want) >= 1, (i, r.sv_type)
+        for ci, c in enumerate(want):
+            assert eng.hits(i, ci) == bo.realign(c["seq"], targets), (i, ci, r.sv_type)
+            nrec += 1
+    assert nrec >= 10
+    assert max(len(c["seq"]) for c in eng.contigs(3)) > 500          # the translocation contig runs far into the partner half
+
+
+def test_full_size_config4_regions_gpu(hb):
+    """BASELINE.json configs[4] at FULL size: 24,000 x 250 bp reads (2,000x), k = 41 (two-word keys), 5 % substitution
+    noise -> millions of sample k-mers and hundreds of recurrent-error contigs per region.  Two regions, everything
+    bit-exact against the C oracle (whose find_reads is answered from its index: the plain scan needs hours here)."""
+    from oracle import bk_oracle as bo
+    bench = _bench_mod()
+    regions = [bench.cfg4_region(synth, i) for i in range(2)]
+    assert all(r.reads.shape == (24000, 250) for r in regions)
+    eng = _run_regions(hb, regions, 41, stages=7)
+    for i, r in enumerate(regions):
+        assert eng.region_status(i) == (0, "ok")
+        want, info = bo.assemble_region(r.read_strs(), [r.window_str], 41, 2, find_index=True)
+        mers, counts, U = eng.kmers(i)
+        assert U == len(info["rep"]) and len(mers) == len(info["mers"]) > 1000000
+        h = hashlib.sha256()
+        for m, c in sorted(zip(mers, counts.tolist()), key=lambda x: (x[1], x[0]), reverse=True):
+            h.update(("%s %d\n" % (m, c)).encode())
+        h2 = hashlib.sha256()
+        for m, c in sorted(zip(info["mers"], info["counts"].tolist()), key=lambda x: (x[1], x[0]), reverse=True):
+            h2.update(("%s %d\n" % (m, c)).encode())
+        assert h.hexdigest() == h2.hexdigest(), i
+        got = eng.contigs(i)
+        assert len(got) == len(want) > 300, (i, len(got), len(want))
+        assert _strip(got) == want, i
+        for ci in (0, 1, len(want) // 2, len(want) - 1):
+            assert eng.hits(i, ci) == bo.realign(want[ci]["seq"], [r.window_str]), (i, ci)
+
+
+def test_more_regions_than_workgroups_gpu(hb):
+    """A batch far larger than the number of resident assembler workgroups (persistent workgroups pulling regions from
+    the cost-ordered queue): every region's result equals what a small batch gives, light and heavy regions mixed."""
+    from oracle import bk_oracle as bo
+    n = 1500
+    regions = [synth.make_region(5000 + i, sv_type=synth.SV_TYPES[i % 5], depth=(200 if i % 97 == 0 else 24), W=700, L=100,
+                                 noise=(0.01 if i % 50 == 7 else 0.0)) for i in range(n)]
+    big = _run_regions(hb, regions, 25, stages=7)
+    assert big.stat(22) == 0
+    picks = list(range(0, n, 97)) + [7, 57, 1, 2, 3, 4, n - 1]
+    small = _run_regions(hb, [regions[i] for i in picks], 25, stages=7)
+    for j, i in enumerate(picks):
+        assert big.contigs(i) == small.contigs(j), i
+        assert [big.hits(i, c) for c in range(len(big.contigs(i)))] == [small.hits(j, c) for c in range(len(small.contigs(j)))], i
+    for i in (0, 7, 97, 1499):
+        r = regions[i]
+        want, _ = bo.assemble_region(r.read_strs(), [r.window_str], 25, 2)
+        assert _strip(big.contigs(i)) == want, i
+    assert sum(len(big.contigs(i)) for i in range(n)) >= n // 2

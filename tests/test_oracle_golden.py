@@ -59,3 +59,21 @@ def test_g3_assembly(golden_dir):
         msum = hashlib.sha256(("\n".join("%s %d" % (m, got[m]) for m in sorted(got))).encode()).hexdigest()
         assert msum == c["mers_sha256"], c["tag"]
         assert contigs == c["contigs"], c["tag"]
+
+
+def test_find_index_equals_scan(golden_dir):
+    """The oracle's optional k-mer -> reads index behind find_reads (needed for full-size noisy regions) gives what the
+    reference's scan over all reads gives: on every G3 fixture (outputs of the real reference) and on noisy regions with
+    hundreds of contigs, short and ragged reads."""
+    d = _load(golden_dir, "assembly.json")
+    for c in d["cases"]:
+        r, reads = _case_inputs(c)
+        contigs, info = bo.assemble_region(reads, [r.window_str], c["k"], c["rc_thresh"], indel_only=r.indel_only, find_index=True)
+        assert contigs == c["contigs"], c["tag"]
+    for rid, kw, k in ((71, dict(depth=300, W=900, noise=0.01), 31), (72, dict(depth=80, W=700, L=250, noise=0.05), 41),
+                       (73, dict(depth=150, W=1200, noise=0.02, var_len=0.4, sv_type="inv"), 21)):
+        r = synth.make_region(rid, **kw)
+        a, ia = bo.assemble_region(r.read_strs(), [r.window_str], k, 2)
+        b, ib = bo.assemble_region(r.read_strs(), [r.window_str], k, 2, find_index=True)
+        assert a == b and len(a) >= 2, rid
+        assert (ia["flags"] == ib["flags"]).all()

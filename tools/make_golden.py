@@ -148,7 +148,9 @@ def region_case(tag, k=31, rc_thresh=2, **kw):
     r = synth.make_region(**kw)
     reads = r.read_strs()
     t = time.time()
-    mers = rh.ref_kmer_select(reads, [r.window_str], k)
+    mers, cap = rh.ref_compare_kmers(r.read_ids, reads, r.window_str, k, None, r.indel_only)       # the reference's own compare_kmers (+ load_kmers)
+    assert cap["kmer_len"] == k and cap["read_len"] == max(len(x) for x in reads)
+    assert mers == rh.ref_kmer_select(reads, [r.window_str], k)                                    # the restated set algebra agrees
     contigs, _ = rh.ref_init_assembly(r.read_ids, reads, mers, k, rc_thresh, r.indel_only)
     dt = time.time() - t
     h = hashlib.sha256(("\n".join(reads)).encode()).hexdigest()
@@ -171,6 +173,8 @@ def g3():
     cases.append(region_case("config1_del_500x", region_id=0, sv_type="del", depth=500, W=3000))
     cases.append(region_case("L250_k41_ins", k=41, region_id=21, sv_type="ins", depth=40, W=1500, L=250))
     cases.append(region_case("L250_k41_noise5", k=41, region_id=22, sv_type="del", depth=24, W=1000, L=250, noise=0.05))
+    cases.append(region_case("L250_k41_noise5_del_d40", k=41, region_id=23, sv_type="del", depth=40, W=700, L=250, noise=0.05))      # >= 1 contig at k=41 / 5 %
+    cases.append(region_case("L250_k41_noise5_ins_d60", k=41, region_id=24, sv_type="ins", depth=60, W=700, L=250, noise=0.05))
     for j, nz in enumerate((0.01, 0.02, 0.05)):
         cases.append(region_case("noise%d_del" % int(nz * 100), region_id=30 + j, sv_type="del", depth=30, W=900, noise=nz))
     cases.append(region_case("noise2_inv_d60", region_id=34, sv_type="inv", depth=60, W=900, noise=0.02))
@@ -181,7 +185,8 @@ def g3():
 
 
 def g4():
-    """G4: k-mer set algebra (sv_processor.py:609-631) incl. a separate soft-clip set."""
+    """G4: k-mer set algebra incl. a separate soft-clip set, produced by the REAL target.compare_kmers + utils.load_kmers
+    (sv_processor.py:609-645, utils.py:287-296); only the absent Jellyfish binary is replaced (rh.jellyfish_standin)."""
     rnd = random.Random(4)
     cases = []
     for t in range(6):
@@ -190,7 +195,9 @@ def g4():
         reads = [ref[s:s + 40] for s in (rnd.randint(0, 80) for _ in range(25))]
         reads += [rs(rnd, 40) for _ in range(3)] + ["A" * 40] + [reads[0]] * 2
         sc = None if t % 2 == 0 else [r for r in reads if rnd.random() < 0.5]
-        d = rh.ref_kmer_select(reads, [ref], k, sc)
+        d, cap = rh.ref_compare_kmers(["@S:1:1:4:%d/1_0" % i for i in range(len(reads))], reads, ref, k, sc)
+        assert cap["rc_thresh"] == 2 and cap["kmer_len"] == k and cap["read_len"] == 40
+        assert d == rh.ref_kmer_select(reads, [ref], k, sc)
         cases.append({"k": k, "ref": ref, "reads": reads, "sc": sc, "mers": {m: d[m] for m in sorted(d)}})
     dump("kmer_select.json", {"cases": cases})
 
@@ -366,10 +373,156 @@ def g6():
     dump("read_extraction.json", {"cases": cases})
 
 
+# ---------------------------------------------------------------------------------------------------------------
+def _read_tree(base):
+    out = {}
+    for dp, _dn, fns in os.walk(base):
+        for fn in fns:
+            full = os.path.join(dp, fn)
+            out[os.path.relpath(full, base)] = open(full).read()
+    return out
+
+
+def g7():
+    """G7 (K2, R1, N1): the REAL reference's per-target surface driven end to end on synthetic regions --
+    target.compare_kmers (sv_processor.py:609-645: run_jellyfish -> load_kmers -> set algebra -> init_assembly),
+    target.resolve_sv (:648-665: contig.__init__/setup/write_* :731-782, query_ref :823-859, make_calls :863-866,
+    write_result :791-799), get_summary (:708-721), write_results (:668-683) and runner.write_output (:212-234).
+    Only what is absent from this image is stood in: the Jellyfish binary (a counter that writes its dump file), the BLAT
+    binary (contig.run_blat writes the PSL text of the build's realign records) and pysam (write_bam is skipped).
+    Expected: the 13-field rows, the summary lines and every output file's bytes (files whose line order comes from
+    CPython set iteration are stored with their records sorted and flagged)."""
+    import logging
+    import shutil
+    import tempfile
+    from collections import OrderedDict
+    from oracle import bk_oracle as bo
+    from breakmer_amd import sv_caller as my
+    mods = ref_loader.load()
+    sp, ut = mods["sv_processor"], mods["utils"]
+    sp.run_jellyfish = rh.jellyfish_standin
+    cur = {}
+
+    def run_blat(self, db, name):                      # sv_processor.py:835-851 with the binary replaced
+        r = cur["r"]
+        targets = [r.window_str] + [synth.codes_to_str(p_[4]) for p_ in r.partners]
+        tinfo = [(r.chrom, r.start - 200)] + [(p_[0], p_[1]) for p_ in r.partners]
+        recs = bo.realign(self.contig_seq, targets)
+        if name == "target":
+            rows = [my.psl_fields(x, 'contig1', r.name, 0) for x in recs if x['t_index'] == 0]
+        else:
+            rows = [my.psl_fields(x, 'contig1', 'chr' + tinfo[x['t_index']][0], tinfo[x['t_index']][1]) for x in recs]
+        self.query_res_fn = os.path.join(self.path, 'blat_res.' + name + '.psl')
+        with open(self.query_res_fn, "w") as f:
+            for row in rows:
+                f.write("\t".join(str(x) for x in row) + "\n")
+        if not rows:
+            self.query_res_fn = self.query_res_fn           # empty file: blat_manager reports no results
+    sp.contig.run_blat = run_blat
+    sp.contig.write_bam = lambda self, bam_in, path: None
+    cases = []
+    specs = [("del_nosc", dict(region_id=3, sv_type="del", depth=60, W=1500), 31, None),
+             ("ins_sc_half", dict(region_id=5, sv_type="ins", depth=60, W=1500), 31, 2),
+             ("inv_disc", dict(region_id=7, sv_type="inv", depth=60, W=1500), 31, None),
+             ("dup", dict(region_id=9, sv_type="dup", depth=60, W=1500), 31, 3),
+             ("trl", dict(region_id=11, sv_type="trl", depth=40, W=1200), 31, None),
+             ("del_k15_noise", dict(region_id=13, sv_type="del", depth=40, W=1000, noise=0.01, var_len=0.3, indel_only_frac=0.2), 15, 2),
+             ("nosv", dict(region_id=15, sv_type="del", sv_size=0, depth=30, W=900), 31, None)]
+    base = tempfile.mkdtemp()
+    opts = dict(rh.DEFAULT_OPTS)
+    opts.update({"keep_repeat_regions": True, "analysis_name": "g7", "no_output_header": False, "jellyfish": "jellyfish", "kmer_size": 31,
+                 "blat": "blat", "gfclient": "gfClient", "blat_port": 0, "reference_fasta": "", "reference_fasta_dir": ""})
+    genes = {}
+    regions = []
+    for tag, kw, k, sc_mod in specs:
+        r = synth.make_region(**kw)
+        regions.append((tag, kw, k, sc_mod, r))
+        genes[r.name] = ['chr' + r.chrom, r.start, r.end]
+        for p_ in r.partners:
+            genes[p_[3]] = ['chr' + p_[0], p_[1], p_[2]]
+    runs = {}                                                                   # one run (analysis) per k-mer size
+    for tag, kw, k, sc_mod, r in sorted(regions, key=lambda x: x[4].name):       # runner.run loops the sorted target names (:175-176)
+        params = rh.StubParams(dict(opts, kmer_size=k), genes, None)
+        params.paths = {"targets": os.path.join(base, "targets"), "ref_data": os.path.join(base, "ref"), "output": os.path.join(base, "output")}
+        params.get_kmer_size = lambda k=k: k
+        for p_ in params.paths.values():
+            os.makedirs(p_, exist_ok=True)
+        t = sp.target([(r.chrom, r.start, r.end, r.name, 'exon')], params)
+        cur["r"] = r
+        reads = r.read_strs()
+        quals = ["".join(chr(33 + 20 + ((i * 7 + j) % 20)) for j in range(len(s_))) for i, s_ in enumerate(reads)]
+        sc = None if sc_mod is None else [s_[:60] for i, s_ in enumerate(reads) if i % sc_mod == 0]
+        os.makedirs(t.paths['ref_data'], exist_ok=True)
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        with open(t.files['target_ref_fn'][0], "w") as f:
+            f.write(">" + r.name + "\n" + r.window_str + "\n")
+        with open(t.files['target_ref_fn'][1], "w") as f:
+            f.write(">" + r.name + "\n" + "".join(comp[c] for c in reversed(r.window_str)) + "\n")
+        t.files['cleaned_fq'] = os.path.join(t.paths['data'], r.name + "_sv_reads_cleaned.fastq")
+        with open(t.files['cleaned_fq'], "w") as f:
+            for rid, s_, q in zip(r.read_ids, reads, quals):
+                f.write(rid + "\n" + s_ + "\n+\n" + q + "\n")
+        t.files['sv_sc_unmapped_fa'] = os.path.join(t.paths['data'], r.name + "_sv_sc_seqs.fa")
+        with open(t.files['sv_sc_unmapped_fa'], "w") as f:
+            for i, s_ in enumerate(sc if sc is not None else reads):            # case_sc := case when no separate set is given (SURVEY 8d)
+                f.write(">s%d\n%s\n" % (i, s_))
+        t.files['sv_bam_sorted'] = None
+        fq = OrderedDict()
+        for i, (rid, s_, q) in enumerate(zip(r.read_ids, reads, quals)):       # utils.get_fastq_reads :239-244 in FASTQ order (P4)
+            fq.setdefault(s_, []).append(ut.fq_read(rid, s_, q, bool(r.indel_only[i])))
+            t.read_len = max(t.read_len, len(s_))
+        t.cleaned_read_recs = fq
+        t.disc_reads = r.disc_reads
+        t.repeat_mask = None
+        t0 = time.time()
+        t.compare_kmers()
+        t.resolve_sv()
+        summary_header, summ = t.get_summary()
+        run = runs.setdefault(k, {"results": [], "summary": {}, "header": ""})
+        run["summary"][t.name] = summ
+        run["header"] = summary_header
+        if t.has_results():
+            t.write_results()
+            run["results"].extend(t.results)
+        files = _read_tree(os.path.join(base, "targets", r.name))
+        files.update({os.path.join("@output", k2): v for k2, v in _read_tree(t.paths['output']).items()})
+        canon = {}
+        for fn, text in files.items():
+            if fn.endswith("_sample_kmers.out"):                                # list(set) order (sv_processor.py:622)
+                canon[fn] = ["sorted_lines", "\n".join(sorted(text.split("\n")))]
+            elif fn.endswith(".fq") and "/contigs/" in "/" + fn:                # `for read in self.reads` over a set (:777)
+                recs = text.split("\n")
+                recs = sorted("\n".join(recs[i:i + 4]) for i in range(0, len(recs) - 3, 4))
+                canon[fn] = ["sorted_records", "\n".join(recs)]
+            elif fn.endswith("_sample_kmers_merged.out"):                       # third line: read ids of a set (:763)
+                ln = text.split("\n")
+                ln[2] = ",".join(sorted(ln[2].split(",")))
+                canon[fn] = ["sorted_read_ids", "\n".join(ln)]
+            elif fn.endswith(".psl") or fn.endswith(".mod") or fn.endswith("_dump") or fn.endswith(".fastq") or fn.endswith("_sc_seqs.fa"):
+                continue                                                       # inputs / stand-in artefacts, not the reference's writers
+            else:
+                canon[fn] = ["bytes", text]
+        cases.append({"tag": tag, "gen": kw, "k": k, "sc_mod": sc_mod, "name": r.name, "rows": t.results, "summary": summ,
+                      "n_clusters": len(t.kmers['clusters']), "files": canon})
+        print("  %-16s k=%d clusters %d rows %d files %d  %.1fs" % (tag, k, len(t.kmers['clusters']), len(t.results), len(canon), time.time() - t0))
+    # run level: runner.write_output (sv_processor.py:212-234) on a runner object that only carries what it reads
+    run_files = {}
+    for k, run in sorted(runs.items()):
+        rn = object.__new__(sp.runner)
+        rn.params = rh.StubParams(dict(opts, analysis_name="g7k%d" % k), genes, None)
+        rn.params.paths = {"output": os.path.join(base, "output")}
+        rn.results, rn.summary, rn.summary_header, rn.logger = run["results"], run["summary"], run["header"], logging.getLogger("g7")
+        rn.write_output()
+        run_files[str(k)] = {fn: text for fn, text in _read_tree(os.path.join(base, "output")).items() if os.sep not in fn and fn.startswith("g7k%d_" % k)}
+    dump("surface.json", {"cases": cases, "run_files": run_files, "opts": {k_: v for k_, v in opts.items()},
+                          "genes": genes, "note": "quals: chr(33+20+((i*7+j)%20)); sc: reads[i][:60] for i % sc_mod == 0; one analysis (g7k<k>) per k-mer size"})
+    shutil.rmtree(base, ignore_errors=True)
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for w in which:
         print(w)
         globals()[w]()
