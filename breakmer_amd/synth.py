@@ -136,11 +136,12 @@ def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int =
     r.donor = donor
     N = n_reads if n_reads is not None else (depth * W) // L
     starts = rand_below(stream_key(global_seed, region_id, 2), N, len(donor) - L + 1)
-    idx = starts[:, None] + np.arange(L, dtype=np.int64)[None, :]
-    reads = donor[idx]
+    reads = np.lib.stride_tricks.sliding_window_view(donor, L)[starts]       # rows donor[s:s+L] (a row gather of a strided view)
     if noise > 0.0:
         u = rand_u64(stream_key(global_seed, region_id, 3), N * L).reshape(N, L)
-        flip = (u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) < noise
+        # (u >> 11) * 2**-53 < noise, evaluated on the integers (x * 2**-53 is exact; for an integer x, x < y <=> x < ceil(y))
+        import math
+        flip = (u >> np.uint64(11)) < np.uint64(math.ceil(noise * 9007199254740992.0))
         delta = ((u & np.uint64(0x3FF)) % np.uint64(3)).astype(np.uint8) + np.uint8(1)  # 1..3 -> always a different base
         reads = np.where(flip, (reads + delta) & 3, reads).astype(np.uint8)
     reads = np.ascontiguousarray(reads, dtype=np.uint8)
