@@ -49,7 +49,7 @@ struct bk_handle {
     // device
     DevBuf d_desc, d_work, d_part, d_reads, d_rlen, d_rflag, d_sc, d_sclen, d_win;
     DevBuf d_ddslot, d_ddrep, d_ddcnt, d_grp, d_urep, d_unr, d_ufl, d_ubuf, d_ureads, d_ufound, d_uminpos;
-    DevBuf d_arena, d_out, d_tops, d_order, d_skeys, d_clist;
+    DevBuf d_arena, d_out, d_tops, d_order, d_skeys, d_clist, d_nlist;
     int n_cu = 256, asm_wg_per_cu = 0, sw_wg_per_cu = 0;
     uint64_t arena_cap = 0, out_cap = 0;
     uint32_t ref_cap = 0, win_words_cap = 0;
@@ -111,7 +111,7 @@ extern "C" int bk_destroy(bk_handle *h)
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
-                      &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist};
+                      &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist, &h->d_nlist};
     for (auto b : bufs) b->release();
     h->h_out.release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -120,13 +120,18 @@ extern "C" int bk_destroy(bk_handle *h)
     return BK_OK;
 }
 
-// 2 bit/base, first base in the most significant bits (bk_common.h)
-static bool pack_seq(const char *s, int len, uint32_t *w, int nwords)
+// 2 bit/base, first base in the most significant bits (bk_common.h).  nlist != nullptr: 'N' is accepted (packed as code 0)
+// and its position appended as (tag << 10 | position); any other character fails.
+static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vector<uint32_t> *nlist = nullptr, uint32_t tag = 0)
 {
     for (int i = 0; i < nwords; i++) w[i] = 0;
     for (int i = 0; i < len; i++) {
         uint32_t c;
-        switch (s[i]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: return false; }
+        switch (s[i]) {
+        case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break;
+        case 'N': if (!nlist) return false; nlist->push_back((tag << 10) | (uint32_t)i); c = 0; break;
+        default: return false;
+        }
         w[i >> 4] |= c << (30 - 2 * (i & 15));
     }
     return true;
@@ -170,7 +175,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         d.max_len = maxl;
         d.reads_word_off = reads.size(); d.read_meta_off = rlen.size();
         reads.resize(reads.size() + (size_t)d.n_reads * d.read_words);
-        for (int i = 0; i < g.n_reads; i++) { rlen.push_back(g.read_lens[i]); rflag.push_back(g.indel_only ? g.indel_only[i] : 0); }   // the reads themselves are packed below, in parallel
+        for (int i = 0; i < g.n_reads; i++) { rlen.push_back(g.read_lens[i]); rflag.push_back(g.indel_only && g.indel_only[i] ? BK_RF_INDEL : 0); }   // the reads themselves are packed below, in parallel
         d.n_sc = g.n_sc < 0 ? -1 : g.n_sc; d.sc_word_off = sc.size(); d.sc_meta_off = sclen.size(); d.sc_words = 1;
         if (g.n_sc > 0) {
             uint32_t ms = 0; for (int i = 0; i < g.n_sc; i++) ms = std::max<uint32_t>(ms, g.sc_lens[i]);
@@ -201,22 +206,33 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
         n_alg_bytes += (bases + 3) / 4 + 4ull * g.n_reads + 2ull * ((g.window_len + 3) / 4) + 2048;
     }
     const auto t_pack0 = std::chrono::steady_clock::now();
+    std::vector<std::vector<uint32_t>> region_nl;
     {   // 2-bit packing of the reads: the bulk of the host work of a submit (0.4 GB of ASCII for 256 regions), regions are independent
         std::atomic<int> next{0}, bad_region{-1}, bad_read{-1};
+        region_nl.assign(n_regions, {});
         auto pack = [&]() {
             for (;;) {
                 const int r = next.fetch_add(1);
                 if (r >= n_regions) break;
                 const bk_region &g = regions[r]; const BkRegionDesc &d = n_desc[r];
                 for (int i = 0; i < g.n_reads; i++)
-                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
+                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
             }
         };
         const int nth = std::max(1, std::min<int>({8, (int)std::thread::hardware_concurrency(), n_regions}));
         if (nth == 1) pack();
         else { std::vector<std::thread> th; for (int t = 0; t < nth; t++) th.emplace_back(pack); for (auto &x : th) x.join(); }
-        if (bad_region >= 0) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_region.load()) + " read " + std::to_string(bad_read.load()) + ": non-ACGT base (unsupported)");
+        if (bad_region >= 0) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_region.load()) + " read " + std::to_string(bad_read.load()) + ": base other than A/C/G/T/N");
     }
+    // N calls: one sorted list per region (reads are packed in order, positions ascending), flag on the reads that have any
+    std::vector<uint32_t> nlist;
+    for (int r = 0; r < n_regions; r++) {
+        BkRegionDesc &d = n_desc[r];
+        d.nlist_off = nlist.size(); d.n_nlist = (uint32_t)region_nl[r].size();
+        for (uint32_t e : region_nl[r]) rflag[d.read_meta_off + (e >> 10)] |= BK_RF_HASN;
+        nlist.insert(nlist.end(), region_nl[r].begin(), region_nl[r].end());
+    }
+    if (nlist.empty()) nlist.push_back(0);
     h->total_reads = rlen.size(); h->n_regions = n_regions;
     { uint32_t mx = 0; for (auto &d : n_desc) mx = std::max(mx, d.max_len); h->eff_max_read = (int)std::min<uint32_t>((uint32_t)h->cfg.max_read_len, std::max<uint32_t>(64, (mx + 63) / 64 * 64)); }
     // reference k-mer table geometry (LDS): load factor <= 0.5.  Windows beyond the LDS budget (whole-gene targets)
@@ -230,7 +246,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     uint32_t max_small = 0; h->n_big = 0; uint64_t big_bytes = 0;
     for (auto &d : n_desc) {
         uint32_t cap, words;
-        d.big = lds_need(d.win_len, cap, words) > 160 * 1024 ? 1u : 0u; d.pad_ = 0;
+        d.big = lds_need(d.win_len, cap, words) > 160 * 1024 ? 1u : 0u;
         if (d.big) { h->n_big++; uint64_t gc = 1024; while (gc < 4ull * d.win_len) gc <<= 1; big_bytes += gc * 8 + d.win_len / 4 + 4096; if (d.win_len >= (1u << 28)) return fail(h, BK_E_LIMIT, "bk_submit_regions: reference window longer than 256 Mb"); }
         else max_small = std::max(max_small, d.win_len);
     }
@@ -250,6 +266,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
     HIPCHK(h, upload(h, h->d_desc, n_desc)); HIPCHK(h, upload(h, h->d_part, n_part));
     HIPCHK(h, upload(h, h->d_reads, reads)); HIPCHK(h, upload(h, h->d_rlen, rlen)); HIPCHK(h, upload(h, h->d_rflag, rflag));
     HIPCHK(h, upload(h, h->d_sc, sc)); HIPCHK(h, upload(h, h->d_sclen, sclen)); HIPCHK(h, upload(h, h->d_win, win));
+    HIPCHK(h, upload(h, h->d_nlist, nlist));
     const size_t nr = std::max<size_t>(h->total_reads, 1), nd = std::max<uint64_t>(dd_total, 1);
     HIPCHK(h, h->d_work.ensure(sizeof(BkRegionWork) * n_regions));
     HIPCHK(h, h->d_ddslot.ensure(nd * 8)); HIPCHK(h, h->d_ddrep.ensure(nd * 4)); HIPCHK(h, h->d_ddcnt.ensure(nd * 4));
@@ -278,6 +295,7 @@ static void fill_params(bk_handle *h)
     BkParams &p = h->params;
     p.desc = (const BkRegionDesc *)h->d_desc.p; p.work = (BkRegionWork *)h->d_work.p; p.partners = (const BkPartnerDesc *)h->d_part.p;
     p.reads = (const uint32_t *)h->d_reads.p; p.read_len = (const uint16_t *)h->d_rlen.p; p.read_flag = (const uint8_t *)h->d_rflag.p;
+    p.nlist = (const uint32_t *)h->d_nlist.p;
     p.sc = (const uint32_t *)h->d_sc.p; p.sc_len = (const uint16_t *)h->d_sclen.p; p.windows = (const uint32_t *)h->d_win.p;
     p.dd_slot = (unsigned long long *)h->d_ddslot.p; p.dd_rep = (uint32_t *)h->d_ddrep.p; p.dd_cnt = (uint32_t *)h->d_ddcnt.p;
     p.grp_slot = (uint32_t *)h->d_grp.p; p.urep = (uint32_t *)h->d_urep.p; p.unreads = (uint32_t *)h->d_unr.p; p.uflag = (uint8_t *)h->d_ufl.p;
@@ -342,7 +360,7 @@ static int launch(bk_handle *h, uint32_t mask)
     if (mask & BK_STAGE_REALIGN) {
         // target staging buffer (packed, 4 bases per byte): the whole window when it fits, else chunks of diagonals
         const uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)h->cfg.max_contig_len + 16, std::max<uint32_t>(262144, 4 * (uint32_t)h->cfg.max_contig_len));
-        const size_t lds = ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + 15) / 16) * 16 + 4 * (2 * ((size_t)h->cfg.max_contig_len / 16 + 2) + tw_cap / 16 + 8);
+        const size_t lds = ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + 15) / 16) * 16 + 4 * (4 * ((size_t)h->cfg.max_contig_len / 16 + 2) + tw_cap / 16 + 8);
         HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // one workgroup per contig, pulled from the list the assembler appended to; the number of contigs is only known
         // on the device, so a resident-sized grid of persistent workgroups is launched (idle ones exit at once)

@@ -42,7 +42,7 @@ struct BkAsmShared {
     unsigned long long cells, calls;
     BkNwResult v1, v2;
     // look-ahead slots (see bk_run_candidates): read q+s aligned against the PREDICTED contig after reads q..q+s-1
-    struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt; BkNwResult v1, v2; } slot[BK_SPEC];
+    struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt, hasn; BkNwResult v1, v2; } slot[BK_SPEC];
     int nb, pc, last_dec;
     int qslot;                   // position in the region queue this workgroup is working on
     uint32_t scan[24];
@@ -64,6 +64,7 @@ struct BkAsmCtx {
     unsigned long long *n_clist, *clist; uint64_t clist_cap; int region;
     int rc_thresh; uint32_t read_words, max_len;
     const uint32_t *reads; const uint16_t *rlen;
+    const uint32_t *nlist; uint32_t n_nlist;   // N calls of the region's reads (read index << 10 | position), sorted
     uint32_t *urep, *unr; uint8_t *ufl; int32_t *ubuf, *ureads, *ufound, *uminpos;
     const uint32_t *ulen;                      // length of unique read u (k-mer stage)
     const uint32_t *tslot, *trank; const uint64_t *klo, *khi; const uint32_t *kcnt; uint8_t *kstate; int32_t *kstamp;
@@ -108,8 +109,19 @@ __device__ inline int32_t *bk_cnt_ot(int buf) { return C_.cnt + (size_t)buf * 4 
 
 __device__ inline void bk_fail(int st) { if (BK_TID == 0 && S_->status == 0) S_->status = st; }
 
-// k-mer key of LDS bytes s[0..k)
-__device__ inline BkKey bk_bytes_kmer(const uint8_t *s, int k) { BkKey key; key.hi = 0; key.lo = 0; for (int i = 0; i < k; i++) key_push(key, s[i], 64); return key; }
+// k-mer key of LDS bytes s[0..k); false when the window holds an N (code 4): no such k-mer exists (Jellyfish skips them)
+__device__ inline bool bk_bytes_kmer(const uint8_t *s, int k, BkKey &key)
+{
+    key.hi = 0; key.lo = 0; uint32_t any = 0;
+    for (int i = 0; i < k; i++) { const uint32_t c = s[i]; any |= c; key_push(key, c & 3u, 64); }
+    return (any & BK_CODE_N) == 0;
+}
+// write code 4 over the N calls of read i (region index) that fall into bases [from, from + count) of the copy at dst
+__device__ inline void bk_patch_n(uint32_t i, uint8_t *dst, int from, int count)
+{
+    uint32_t lo, hi; bk_nlist_range(C_.nlist, C_.n_nlist, i, lo, hi);
+    for (uint32_t e = lo; e < hi; e++) { const int q = (int)(C_.nlist[e] & 1023u) - from; if (q >= 0 && q < count) dst[q] = BK_CODE_N; }
+}
 
 // sample k-mer table lookup -> rank or -1 (any state)
 __device__ inline int bk_lookup(const BkKey &key)
@@ -160,6 +172,7 @@ __device__ inline void bk_load_read(int u)
     for (int t = BK_TID; t < len; t += BK_AT) L_RSEQ[t] = (uint8_t)seq_base(w, t);
     if (BK_TID == 0) { S_->ru = u; S_->rlen = len; S_->rn = (int)C_.unr[u]; S_->rindel = (C_.ufl[u] & BK_R_INDEL) ? 1 : 0; }
     BK_SYNC();
+    if (C_.n_nlist && (C_.ufl[u] & BK_R_HASN)) { if (BK_TID == 0) bk_patch_n(i, L_RSEQ, 0, len); BK_SYNC(); }
 }
 
 // ---- assembly_counts (sv_assembly.py:160-221) --------------------------------------------------------
@@ -223,8 +236,7 @@ __device__ inline void bk_kmers_ordered(int s0, int L, int order)
     const int m = L / 2;
     if (np > 2 * C_.MAXCAND) { bk_fail(BK_ST_KLIST); BK_SYNC(); return; }
     for (int x = BK_TID; x < np; x += BK_AT) {
-        BkKey key = bk_bytes_kmer(L_CSEQ + s0 + x, k);
-        int rk = bk_lookup(key);
+        BkKey key; int rk = bk_bytes_kmer(L_CSEQ + s0 + x, k, key) ? bk_lookup(key) : -1;
         if (rk >= 0 && C_.kstate[rk] == BK_K_REMOVED) rk = -1;          // not in akmers.smers_set
         tmp[x] = rk;
     }
@@ -348,7 +360,7 @@ __device__ inline int bk_find_kmer_wave(const uint8_t *seq, int n, const BkKey &
     const int lane = BK_TID & 63;
     for (int b = 0; b + k <= n; b += 64) {
         const int x = b + lane; bool ok = x + k <= n;
-        if (ok) { const BkKey c = bk_bytes_kmer(seq + x, k); ok = c.lo == key.lo && c.hi == key.hi; }
+        if (ok) { BkKey c; ok = bk_bytes_kmer(seq + x, k, c) && c.lo == key.lo && c.hi == key.hi; }
         const unsigned long long m = __ballot(ok);
         if (m) return b + __ffsll((long long)m) - 1;
     }
@@ -527,6 +539,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             const uint32_t ri = C_.urep[u];
             BkAsmShared::Slot &t = S->slot[BK_TID];
             t.u = u; t.pos = (int)(cu >> 22); t.rl = C_.rlen[ri]; t.rn = (int)C_.unr[u]; t.rindel = (C_.ufl[u] & BK_R_INDEL) ? 1 : 0;
+            t.hasn = (C_.n_nlist && (C_.ufl[u] & BK_R_HASN)) ? 1 : 0;
         }
         BK_SYNC();
         if (BK_TID == 0) {
@@ -560,6 +573,21 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             }
         }
         BK_SYNC();
+        if (C_.n_nlist) {                                 // reads with N calls (rare): code 4 over the unpacked bytes and over the predicted contig bytes
+            bool any = false;
+            for (int sl = 0; sl < nb; sl++) any = any || S->slot[sl].hasn;
+            if (any) {
+                if (BK_TID < nb && S->slot[BK_TID].hasn) {
+                    const BkAsmShared::Slot &t = S->slot[BK_TID]; const uint32_t ri = C_.urep[t.u];
+                    bk_patch_n(ri, L_RSEQ_S(BK_TID), 0, t.rl);
+                    if (BK_TID + 1 < nb) {
+                        if (t.kind == BK_PK_PRE) bk_patch_n(ri, L_CSEQ + t.pb - t.amt, 0, t.amt);
+                        else if (t.kind == BK_PK_POST) bk_patch_n(ri, L_CSEQ + t.pb + t.plen, t.rl - t.amt, t.amt);
+                    }
+                }
+                BK_SYNC();
+            }
+        }
         BK_ACC(1);
         // 2. the overlap DPs (:451-452), two wavefronts per slot, both with the contig on the tile columns
         {
@@ -614,8 +642,7 @@ __device__ inline void bk_check_alt_reads()
         // x = get_read_kmers(read) - used_mers - mer_set   (set(self.kmers) holds tuples: removes nothing)
         BkKey best; best.hi = ~0ull; best.lo = ~0ull; int bestrk = -1; int anyx = 0;
         for (int x = BK_TID; x < np; x += BK_AT) {
-            BkKey key = bk_bytes_kmer(L_RSEQ + x, k);
-            int rk = bk_lookup(key);
+            BkKey key; int rk = bk_bytes_kmer(L_RSEQ + x, k, key) ? bk_lookup(key) : -1;
             if (rk >= 0 && (C_.kstate[rk] != BK_K_LIVE || C_.kstamp[3 * rk + 1] == fin)) rk = -1;
             tmp[x] = rk;
             if (rk >= 0) { anyx = 1; if (C_.kcnt[rk] > 1 && key_lt(key, best)) { best = key; bestrk = rk; } }   // sorted(x) (P2): smallest mer with count > 1
@@ -774,12 +801,12 @@ __device__ inline void bk_emit_contig()
     uint64_t *okm = (uint64_t *)(rec + o_km); uint32_t *ord_ = (uint32_t *)(rec + o_rd);
     const uint8_t *cs = L_CSEQ + S->cbase;
     const int32_t *io = bk_cnt_io(S->cbuf) + S->nbase, *ot = bk_cnt_ot(S->cbuf) + S->nbase;
-    for (int t = BK_TID; t < len; t += BK_AT) { oseq[t] = "ACGT"[cs[t]]; okl[t] = 0; }
+    for (int t = BK_TID; t < len; t += BK_AT) { oseq[t] = "ACGTN"[cs[t]]; okl[t] = 0; }
     for (int t = BK_TID; t < nlen; t += BK_AT) { oio[t] = io[t]; oot[t] = ot[t]; }
     for (int t = BK_TID; t < nk; t += BK_AT) { uint32_t rk = C_.klist[t] & 0x7FFFFFFFu; okm[2 * t] = C_.klo[rk]; okm[2 * t + 1] = C_.khi[rk]; }
     for (int t = BK_TID; t < nr; t += BK_AT) ord_[t] = C_.urep[C_.readl[t]];
     // first occurrence of every sample k-mer in the contig (str.find over all len-k+1 positions)
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { int rk = bk_lookup(bk_bytes_kmer(cs + x, k)); if (rk >= 0) atomicMin(&C_.kstamp[3 * rk + 2], x); }
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0) atomicMin(&C_.kstamp[3 * rk + 2], x); }
     BK_SYNC();
     for (int t = BK_TID; t < nk; t += BK_AT) {
         int pos = C_.kstamp[3 * (C_.klist[t] & 0x7FFFFFFFu) + 2];
@@ -787,7 +814,7 @@ __device__ inline void bk_emit_contig()
         for (int q = pos; q < min(pos + k, len); q++) atomicAdd(&okl[q], 1);
     }
     BK_SYNC();
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { int rk = bk_lookup(bk_bytes_kmer(cs + x, k)); if (rk >= 0) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
     if (BK_TID == 0) {
         h->next = 0; h->hits_off = 0; h->seq_len = len; h->counts_len = nlen; h->n_kmers = nk; h->n_reads = nr; h->total_reads = total; h->n_hits = 0;
         h->o_seq = o_seq; h->o_io = o_io; h->o_ot = o_ot; h->o_klocs = o_kl; h->o_kmers = o_km; h->o_reads = o_rd; h->o_hits = 0; h->size = size;
@@ -844,6 +871,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.o_cseq = o; o += 2 * c.MAXC;
         c.o_rseq = o; o += BK_SPEC * (c.MAXR + 16);
         c.reads = p.reads + d.reads_word_off; c.rlen = p.read_len + d.read_meta_off;
+        c.nlist = p.nlist + d.nlist_off; c.n_nlist = d.n_nlist;
         const uint64_t mo = d.read_meta_off;
         c.urep = p.urep + mo; c.unr = p.unreads + mo; c.ufl = p.uflag + mo; c.ubuf = p.ubuf + mo; c.ureads = p.ureads + mo; c.ufound = p.ufound + mo; c.uminpos = p.uminpos + mo; c.ulen = p.dd_rep + d.dedup_off;
         c.U = wk->U; c.M = wk->M; c.tmask = wk->tcap - 1;

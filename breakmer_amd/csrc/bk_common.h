@@ -4,7 +4,10 @@
 //   * sequences are 2 bit/base, 16 bases per 32-bit word, FIRST base in the MOST significant bits
 //     (so that a k-mer read as an integer compares like the string: A<C<G<T), zero padded;
 //   * every read of a region starts on its own word boundary, fixed stride `read_words`;
-//   * k-mer keys are (hi,lo) 128-bit integers: sum(code[i] << 2*(k-1-i)).
+//   * k-mer keys are (hi,lo) 128-bit integers: sum(code[i] << 2*(k-1-i));
+//   * N calls (the reference keeps reads with N: utils.py:203-246; Jellyfish skips k-mers that contain one; olc.nw
+//     compares characters, so N matches N and nothing else): packed as code 0, and listed per region as sorted
+//     (read index << 10 | position) words; reads that have any carry BK_RF_HASN.  Unpacked byte code of N = 4.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -96,7 +99,8 @@ struct BkRegionDesc {
     uint32_t n_partners;
     uint32_t max_len;            // read_len = max cleaned read length (utils.py:240)
     uint32_t big;                // window does not fit the LDS k-mer set: handled by bk_kmer_kernel_g
-    uint32_t pad_;
+    uint32_t n_nlist;            // N calls in this region's reads
+    uint64_t nlist_off;          // first entry of this region in BkParams.nlist
 };
 struct BkPartnerDesc { uint64_t word_off; uint32_t len, pad; };
 
@@ -130,7 +134,10 @@ struct BkRegionWork {
 // k-mer states (akmers.mers membership, sv_assembly.py:301-326; buffer.used_mers :333)
 enum { BK_K_LIVE = 0, BK_K_USED = 1, BK_K_REMOVED = 2 };
 // unique-read flags
-enum { BK_R_USED = 1, BK_R_DELETED = 2, BK_R_INDEL = 4 };
+enum { BK_R_USED = 1, BK_R_DELETED = 2, BK_R_INDEL = 4, BK_R_HASN = 8 };
+// per-read input flags (read_flag)
+enum { BK_RF_INDEL = 1, BK_RF_HASN = 2 };
+#define BK_CODE_N 4
 
 // contig record in the `out` arena (o_* relative to the record start, 8-byte aligned; k-mers are
 // stored as (lo, hi) key pairs so the record is self-contained)
@@ -146,6 +153,7 @@ struct BkContigRec {
 struct BkParams {
     const BkRegionDesc *desc; BkRegionWork *work; const BkPartnerDesc *partners;
     const uint32_t *reads; const uint16_t *read_len; const uint8_t *read_flag;
+    const uint32_t *nlist;                                             // N calls: (read index in region << 10 | position), sorted per region
     const uint32_t *sc; const uint16_t *sc_len;
     const uint32_t *windows;
     // read grouping (sized by total reads / total dedup slots)
@@ -164,3 +172,13 @@ struct BkParams {
 };
 
 __device__ inline uint64_t bk_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// entries [lo, hi) of a region's N list that belong to read i (binary search; only reads flagged HASN get here)
+__device__ inline void bk_nlist_range(const uint32_t *nl, uint32_t n, uint32_t i, uint32_t &lo, uint32_t &hi)
+{
+    uint32_t a = 0, b = n;
+    while (a < b) { const uint32_t m = (a + b) >> 1; if ((nl[m] >> 10) < i) a = m + 1; else b = m; }
+    lo = a; b = n;
+    while (a < b) { const uint32_t m = (a + b) >> 1; if ((nl[m] >> 10) <= i) a = m + 1; else b = m; }
+    hi = a;
+}

@@ -239,10 +239,15 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
     else for (uint32_t i = tid; i < d.dedup_cap; i += nt) { dslot[i] = BK_EMPTY64; dcnt[i] = 0; }
     __syncthreads();
     const uint32_t dmask = d.dedup_cap - 1;
+    const uint8_t *rfl = p.read_flag + d.read_meta_off;
+    const uint32_t *nl = p.nlist + d.nlist_off; const uint32_t nnl = d.n_nlist;
     for (uint32_t i = tid; i < N; i += nt) {
         const uint32_t *w = reads + (uint64_t)i * RW; const uint32_t len = rlen[i], nw = (len + 15) / 16;
         uint32_t wb[BK_RW_MAX]; bk_load_words(w, min(nw, (uint32_t)BK_RW_MAX), wb);
         uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
+        const bool hasn = nnl && (rfl[i] & BK_RF_HASN);
+        uint32_t nlo = 0, nhi = 0;
+        if (hasn) { bk_nlist_range(nl, nnl, i, nlo, nhi); for (uint32_t e = nlo; e < nhi; e++) h = mix64(h ^ (0x4E00u | (nl[e] & 1023u))); }   // the N calls are part of the string
         if (nw <= BK_RW_MAX) {
 #pragma unroll
             for (int t = 0; t < BK_RW_MAX; t++) if ((uint32_t)t < nw) h = mix64(h ^ wb[t]) + 0x632BE59BD9B4E019ull;
@@ -257,6 +262,15 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
             if (empty) break;
             if ((LG ? (uint32_t)cur >> 14 : (uint32_t)(cur >> 32)) == tag) {
                 const uint32_t j = LG ? (uint32_t)cur & 0x3FFFu : (uint32_t)cur; bool same = rlen[j] == len;
+                if (nnl && same) {                                    // same N calls (packed words hold code 0 under an N)
+                    const bool jn = (rfl[j] & BK_RF_HASN) != 0;
+                    same = jn == hasn;
+                    if (same && hasn) {
+                        uint32_t jlo, jhi; bk_nlist_range(nl, nnl, j, jlo, jhi);
+                        same = jhi - jlo == nhi - nlo;
+                        for (uint32_t e = 0; same && e < nhi - nlo; e++) same = (nl[nlo + e] & 1023u) == (nl[jlo + e] & 1023u);
+                    }
+                }
                 const uint32_t *wj = reads + (uint64_t)j * RW;
                 if (same) {
                     if (nw <= BK_RW_MAX) {
@@ -305,7 +319,7 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
 #pragma unroll
         for (int t = 0; t < 32; t++) if (isrep & (1u << t)) {
             const uint32_t i = b + t, sl = g[t];
-            urep[pre] = i; unr[pre] = cnt_of(sl); ufl[pre] = rflag[i] ? BK_R_INDEL : 0; ulen[pre] = rlen[i];
+            urep[pre] = i; unr[pre] = cnt_of(sl); ufl[pre] = ((rflag[i] & BK_RF_INDEL) ? BK_R_INDEL : 0) | ((rflag[i] & BK_RF_HASN) ? BK_R_HASN : 0); ulen[pre] = rlen[i];
             p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
             pre++;
         }
@@ -314,7 +328,7 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
         uint32_t pre = bk_block_excl_scan(c, scr, &U);
         for (uint32_t i = b; i < e; i++) if (rep_of(gslot[i]) == i) {
             uint32_t sl = gslot[i];
-            urep[pre] = i; unr[pre] = cnt_of(sl); ufl[pre] = rflag[i] ? BK_R_INDEL : 0; ulen[pre] = rlen[i];
+            urep[pre] = i; unr[pre] = cnt_of(sl); ufl[pre] = ((rflag[i] & BK_RF_INDEL) ? BK_R_INDEL : 0) | ((rflag[i] & BK_RF_HASN) ? BK_R_HASN : 0); ulen[pre] = rlen[i];
             p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
             pre++;
         }
@@ -404,7 +418,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     for (uint32_t u = tid; u < U; u += nt) {
         const uint32_t i = urep[u]; const int len = rlen[i];
         bool clean = false;
-        if (len <= 16 * BK_RW_MAX) { uint32_t wb[BK_RW_MAX]; bk_load_words(reads + (uint64_t)i * RW, (len + 15) / 16, wb); clean = bk_read_is_clean(wb, len, rt); }
+        if (len <= 16 * BK_RW_MAX && !(p.uflag[d.read_meta_off + u] & BK_R_HASN)) { uint32_t wb[BK_RW_MAX]; bk_load_words(reads + (uint64_t)i * RW, (len + 15) / 16, wb); clean = bk_read_is_clean(wb, len, rt); }
         if (!clean) { slow[atomicAdd(&scr[25], 1u)] = u; myk += (uint32_t)max(len - k + 1, 0); }
     }
     __syncthreads();
@@ -440,7 +454,11 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
           if (lane < 16 && l0 <= 16 * BK_RW_MAX) wnext = lane < (l0 + 15) / 16 ? reads[(uint64_t)i0 * RW + lane] : 0u; }
         for (int j = 0; j < cnt; j++) {
             const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)mu, j), i = (uint32_t)__builtin_amdgcn_readlane((int)mi, j); const int len = __builtin_amdgcn_readlane(mlen, j);
-            auto rec = [&](int pos, const BkKey &) { uint32_t idx = atomicAdd(&scr[24], 1u); t_ent[idx] = (u << 10) | (uint32_t)pos; };
+            uint32_t nlo = 0, nhi = 0;                                  // N calls of this read (wave-uniform): Jellyfish skips the k-mers that contain one
+            if (d.n_nlist && (p.uflag[d.read_meta_off + u] & BK_R_HASN)) bk_nlist_range(p.nlist + d.nlist_off, d.n_nlist, i, nlo, nhi);
+            const uint32_t *nlp = p.nlist + d.nlist_off;
+            auto has_n = [&](int pos) { bool b = false; for (uint32_t e = nlo; e < nhi; e++) { const int q = (int)(nlp[e] & 1023u); b = b || (q >= pos && q < pos + k); } return b; };
+            auto rec = [&](int pos, const BkKey &) { if (has_n(pos)) return; uint32_t idx = atomicAdd(&scr[24], 1u); t_ent[idx] = (u << 10) | (uint32_t)pos; };
             const uint32_t wcur = wnext;
             if (j + 1 < cnt) {
                 const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane((int)mi, j + 1); const int l2 = __builtin_amdgcn_readlane(mlen, j + 1);
@@ -451,7 +469,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                 for (int p0 = 0; p0 + k <= len; p0 += 64) {
                     const int pp = p0 + lane;
-                    const bool nonref = pp + k <= len && rt.find(seq_kmer_fast(wst, 16, pp, k)) < 0;
+                    const bool nonref = pp + k <= len && !has_n(pp) && rt.find(seq_kmer_fast(wst, 16, pp, k)) < 0;
                     const unsigned long long nm = __ballot(nonref);                 // one counter update per wavefront, not per lane
                     if (nm) {
                         uint32_t base = 0;

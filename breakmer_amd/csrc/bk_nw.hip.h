@@ -71,7 +71,7 @@ __device__ __noinline__ int2 bk_nw_tile_st(const uint8_t *cols, const uint8_t *r
     for (int x = 0; x < C; x++) {
         const int jj = lane * C + x;
         H[x] = TOPB | (jj + 1);
-        cb[x] = jj < mt ? (int)cols[jj] : 4;
+        cb[x] = jj < mt ? (int)cols[jj] : 8;                // 8 never matches (codes: 0..3, N = 4: N matches N, olc.py:32-38)
     }
     int dprev = lane ? (TOPB | (lane * C)) : 0;
     int rb = 0;
@@ -163,7 +163,7 @@ __device__ __noinline__ int2 bk_nw_tile(const uint8_t *cols, const uint8_t *rows
     for (int x = 0; x < C; x++) {
         const int jj = lane * C + x;                    // 0-based tile column
         H[x] = TOPB | (j0 + jj + 1);                    // tile row 0: score 0, origin = that border cell
-        cb[x] = jj < mt ? (int)cols[j0 + jj] : 4;       // 4 never matches
+        cb[x] = jj < mt ? (int)cols[j0 + jj] : 8;       // 8 never matches (N = 4 matches N)
     }
     int dprev = (j0 + lane * C) ? (TOPB | (j0 + lane * C)) : 0;      // tile cell (0, j0 + l*C); the corner (0,0) is origin 0
     int out_prev = 0, rb_prev = 0;

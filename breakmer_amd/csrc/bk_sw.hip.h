@@ -44,7 +44,8 @@ __device__ inline unsigned long long bk_sw_key(int score, int tidx, int strand, 
 
 // matching positions on diagonal `off` (target b = query a + off) of a packed query interval (n bases, qp) against the
 // staged packed target words tp[0..tpn) = target words tpw0.. (16 bases per word, MSB first)
-__device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off)
+// qn: N mask of the packed query (bit 2*(15-t) set where base t of the word is an N: an N matches nothing here)
+__device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off)
 {
     const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
     if (a1 <= a0) return 0;
@@ -55,7 +56,7 @@ __device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *tp,
         const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
         const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
         const uint32_t x = qp[wq] ^ tb;
-        const uint32_t eq = ~(x | (x >> 1)) & 0x55555555u;
+        const uint32_t eq = ~(x | (x >> 1) | qn[wq]) & 0x55555555u;
         const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
         uint32_t vm = 0xFFFFFFFFu >> (2 * lo);
         if (hi < 16) vm &= ~(0xFFFFFFFFu >> (2 * hi));
@@ -66,7 +67,7 @@ __device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *tp,
 // walk one diagonal on the packed words: best positive run (strict '>': smallest query end among equal scores).  Inside
 // a run of matches the score rises strictly, so only the end of each run can become the new best: the loop advances
 // from mismatch to mismatch (count-leading-zeros on the mismatch mask) instead of base by base.
-__device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int &bh, int &ba, int &br)
+__device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int &bh, int &ba, int &br)
 {
     const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
     int h = 0, run = 0;
@@ -79,7 +80,7 @@ __device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *tp, int tp
         const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
         const uint32_t x = qp[wq] ^ tb;
         const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
-        uint32_t stop = (x | (x >> 1) | (hi < 16 ? 0xFFFFFFFFu >> (2 * hi) : 0u)) & 0x55555555u;   // mismatches and everything from `hi` on
+        uint32_t stop = (x | (x >> 1) | qn[wq] | (hi < 16 ? 0xFFFFFFFFu >> (2 * hi) : 0u)) & 0x55555555u;   // mismatches (an N is one) and everything from `hi` on
         int pos = lo;
         while (pos < hi) {
             const uint32_t rest = stop & (0xFFFFFFFFu >> (2 * pos));
@@ -103,7 +104,8 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
     uint8_t *qr = qf + p.max_contig;                                   // contig reverse complement
     uint32_t *qpk = (uint32_t *)(sl + ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)p.max_contig + 15) / 16) * 16);   // packed query interval, both strands
     const int qpw = p.max_contig / 16 + 2;
-    uint32_t *tp = qpk + 2 * qpw;                                      // staged target chunk, packed words (kept across passes and contigs)
+    uint32_t *qnm = qpk + 2 * qpw;                                     // N masks of the packed query interval, both strands
+    uint32_t *tp = qnm + 2 * qpw;                                      // staged target chunk, packed words (kept across passes and contigs)
     if (tid == 0) { S->staged_ti = -1; S->staged_t0 = 0; S->staged_t1 = 0; S->staged_region = -1; }
     const unsigned long long n_list = min(*p.n_clist, (unsigned long long)p.clist_cap);
     for (;;) {
@@ -128,7 +130,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
         BkContigRec *rec = (BkContigRec *)(p.out + roff);
         const int Q = rec->seq_len;
         const char *seq = (const char *)(p.out + roff + rec->o_seq);
-        for (int i = tid; i < Q; i += BK_ST_T) { char ch = seq[i]; uint8_t c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3; qf[i] = c; qr[Q - 1 - i] = (uint8_t)(3 - c); }
+        for (int i = tid; i < Q; i += BK_ST_T) { char ch = seq[i]; uint8_t c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : BK_CODE_N; qf[i] = c; qr[Q - 1 - i] = c == BK_CODE_N ? (uint8_t)BK_CODE_N : (uint8_t)(3 - c); }
         if (tid == 0) { S->nseg = 1; S->seg[0] = 0; S->seg[1] = Q; S->nhits = 0; }
         __syncthreads();
         while (S->nseg > 0 && S->nhits < BK_MAX_HITS) {
@@ -141,9 +143,9 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
             for (int w = tid; w < 2 * ((n + 15) / 16); w += BK_ST_T) {
                 const int st = w >= (n + 15) / 16, wi = st ? w - (n + 15) / 16 : w;
                 const uint8_t *q = st ? qr + (Q - qe) : qf + qs;
-                uint32_t x = 0;
-                for (int t = 0; t < 16; t++) { const int a = wi * 16 + t; x = (x << 2) | (a < n ? (uint32_t)q[a] : 0u); }
-                qpk[st * qpw + wi] = x;
+                uint32_t x = 0, nm = 0;
+                for (int t = 0; t < 16; t++) { const int a = wi * 16 + t; const uint32_t c = a < n ? (uint32_t)q[a] : 0u; x = (x << 2) | (c & 3u); nm = (nm << 2) | (c >> 2); }
+                qpk[st * qpw + wi] = x; qnm[st * qpw + wi] = nm;
             }
             unsigned long long bkey = 0; int brun = 0;
             for (int ti = 0; ti <= (int)d.n_partners; ti++) {
@@ -167,7 +169,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     int myu = -1, myD = 0;
                     for (int D = tid; D < 2 * nd; D += BK_ST_T) {
                         const int st = D >= nd, off = o0 + (st ? D - nd : D);
-                        const int u = bk_sw_diag_matches(qpk + st * qpw, tp, tpw0, tpn, n, m, off);
+                        const int u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off);
                         if (u > myu) { myu = u; myD = D; }
                     }
                     if (myu > 0) atomicMax(&S->umax, myu);
@@ -176,7 +178,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     int walked = -1;
                     if (myu == S->umax && myu >= S->L && myu > 0) {
                         const int st = myD >= nd, off = o0 + (st ? myD - nd : myD);
-                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, tp, tpw0, tpn, n, m, off, bh, ba, br);
+                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, bh, ba, br);
                         if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } atomicMax(&S->L, bh); }
                         walked = myD;
                     }
@@ -185,9 +187,9 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     for (int D = tid; D < 2 * nd; D += BK_ST_T) {
                         const int st = D >= nd, off = o0 + (st ? D - nd : D);
                         if (D == walked) continue;
-                        const int u = bk_sw_diag_matches(qpk + st * qpw, tp, tpw0, tpn, n, m, off);
+                        const int u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off);
                         if (u < *(volatile int *)&S->L || u == 0) continue;
-                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, tp, tpw0, tpn, n, m, off, bh, ba, br);
+                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, bh, ba, br);
                         if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } if (bh > *(volatile int *)&S->L) atomicMax(&S->L, bh); }
                     }
                 }

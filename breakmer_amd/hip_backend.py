@@ -119,7 +119,7 @@ def _ascii_matrix(seqs):
     return m, lens
 
 
-_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_ACGT = np.frombuffer(b"ACGTN", dtype=np.uint8)       # code 4 = N (reads only; windows must be A/C/G/T)
 
 
 class RegionInput(object):

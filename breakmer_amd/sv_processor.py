@@ -349,17 +349,35 @@ class target(object):                                               # sv_process
 
     def clean_reads(self):                                           # :584-606 (cutadapt out of scope) -> bool
         d = self.data
-        # The device path packs A/C/G/T in 2 bits: reads with any other base (N calls of real data) are
-        # left out, with a warning -- a documented deviation from the reference, which keeps them -- instead of failing the run.
-        bad = [n for n, s_ in enumerate(d.read_seqs) if s_.strip("ACGT")]
+        # Reads with N calls are kept, as the reference keeps them (utils.py:203-246): the device path carries the N
+        # positions next to the 2-bit words.  Any other character (IUPAC codes never occur in the alignment files the
+        # reference is run on) cannot be represented: such reads are left out with a warning.
+        bad = [n for n, s_ in enumerate(d.read_seqs) if s_.strip("ACGTN")]
         if bad:
-            self.logger.warning('target %s: %d of %d reads contain non-ACGT bases and are skipped' % (self.name, len(bad), len(d.read_seqs)))
-            keep = [n for n in range(len(d.read_seqs)) if n not in set(bad)]
+            self.logger.warning('target %s: %d of %d reads contain characters other than A/C/G/T/N and are skipped' % (self.name, len(bad), len(d.read_seqs)))
+            drop = set(bad)
+            keep = [n for n in range(len(d.read_seqs)) if n not in drop]
             d.read_ids = [d.read_ids[n] for n in keep]; d.read_seqs = [d.read_seqs[n] for n in keep]
             d.indel_only = [d.indel_only[n] for n in keep]
             if d.quals is not None: d.quals = [d.quals[n] for n in keep]
         if d.sc_seqs is not None:
-            d.sc_seqs = [x for x in d.sc_seqs if not x.strip("ACGT")]
+            # case_sc only contributes the PRESENCE of k-mers (sv_processor.py:621) and Jellyfish skips every k-mer that
+            # holds a non-ACGT character, so a soft-clip sequence split at those characters has the same k-mer set
+            k = self.params.get_kmer_size()
+            pieces = []
+            for x in d.sc_seqs:
+                if not x.strip("ACGT"):
+                    pieces.append(x)
+                else:
+                    cur = []
+                    for ch in x:
+                        if ch in "ACGT":
+                            cur.append(ch)
+                        else:
+                            if len(cur) >= k: pieces.append("".join(cur))
+                            cur = []
+                    if len(cur) >= k: pieces.append("".join(cur))
+            d.sc_seqs = pieces
         q = d.quals
         self.reads = [sv_assembly.fq_read(i, s, (q[n] if q else "I" * len(s)), bool(io)) for n, (i, s, io) in enumerate(zip(d.read_ids, d.read_seqs, d.indel_only))]
         recs = OrderedDict()

@@ -17,7 +17,7 @@ _GOLD = np.uint64(0x9E3779B97F4A7C15)
 _C1 = np.uint64(0xBF58476D1CE4E5B9)
 _C2 = np.uint64(0x94D049BB133111EB)
 
-BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+BASES = np.frombuffer(b"ACGTN", dtype=np.uint8)      # code 4 = N (no-call)
 SV_TYPES = ("del", "ins", "inv", "dup", "trl")
 
 
@@ -72,6 +72,30 @@ def str_to_codes(s: str) -> np.ndarray:
     return out
 
 
+class SynthReadIds(object):
+    """read ids `@S:1:1:<region>:<i>/1_0` (utils.py:436-443 convention), materialised on demand: a region has 10-24
+    thousand of them and the batched paths only need to know that they all carry the same `/1_0` tag"""
+    uniform_tag = "1_0"
+
+    def __init__(self, region_id, n):
+        self.region_id, self.n = region_id, n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self.n))]
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return "@S:1:1:%d:%d/1_0" % (self.region_id, i)
+
+    def __iter__(self):
+        return ("@S:1:1:%d:%d/1_0" % (self.region_id, i) for i in range(self.n))
+
+
 class Region(object):
     """One synthetic target region.
 
@@ -100,7 +124,7 @@ class Region(object):
 
 def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int = 150, depth: int = 500,
                 sv_type: str = "del", sv_size: int | None = None, noise: float = 0.0,
-                n_reads: int | None = None, var_len: float = 0.0, indel_only_frac: float = 0.0) -> Region:
+                n_reads: int | None = None, var_len: float = 0.0, indel_only_frac: float = 0.0, n_frac: float = 0.0) -> Region:
     """Generate region `region_id` (config 1-3 defaults)."""
     assert sv_type in SV_TYPES
     r = Region()
@@ -145,6 +169,15 @@ def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int =
         delta = ((u & np.uint64(0x3FF)) % np.uint64(3)).astype(np.uint8) + np.uint8(1)  # 1..3 -> always a different base
         reads = np.where(flip, (reads + delta) & 3, reads).astype(np.uint8)
     reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    if n_frac > 0.0:
+        # no-calls as real alignment files have them: a fraction of the reads carries one N (code 4), a few of them a second one
+        u = rand_u64(stream_key(global_seed, region_id, 6), N)
+        sel = np.nonzero((u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) < n_frac)[0]
+        p1 = ((u[sel] & np.uint64(0xFFFF)) % np.uint64(L)).astype(np.int64)
+        reads[sel, p1] = 4
+        two = ((u[sel] >> np.uint64(16)) & np.uint64(7)) == np.uint64(0)
+        p2 = (((u[sel] >> np.uint64(20)) & np.uint64(0xFFFF)) % np.uint64(L)).astype(np.int64)
+        reads[sel[two], p2[two]] = 4
     lens = np.full(N, L, dtype=np.int32)
     if var_len > 0.0:
         # quality/adapter-trimmed reads (utils.py:385-443, cutadapt): a fraction loses up to 40 bases
@@ -166,7 +199,7 @@ def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int =
         u = rand_u64(stream_key(global_seed, region_id, 5), N)
         r.indel_only = ((u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) < indel_only_frac).astype(np.uint8)
     r.read_starts = starts
-    r.read_ids = ["@S:1:1:%d:%d/1_0" % (region_id, i) for i in range(N)]
+    r.read_ids = SynthReadIds(region_id, N)
     # discordant-pair evidence normally derived from the BAM (sv_processor.py:376-408)
     npairs = -(-depth // 50)
     gpos = r.start - flank  # genome coordinate of window[0]

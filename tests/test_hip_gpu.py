@@ -265,7 +265,9 @@ def test_edge_cases_gpu(hb):
     assert _strip(eng.contigs(3)) == want3
     # limits fail loudly
     with pytest.raises(hb.BreakmerHipError):
-        hb.Engine(kmer_size=31).submit([hb.RegionInput(["ACGTN" * 10], w)])           # non-ACGT base
+        hb.Engine(kmer_size=31).submit([hb.RegionInput(["ACGTR" * 10], w)])           # a character other than A/C/G/T/N
+    with pytest.raises(hb.BreakmerHipError):
+        hb.Engine(kmer_size=31).submit([hb.RegionInput([w[:100]], w[:500] + "N" + w[501:])])   # windows must be A/C/G/T
     with pytest.raises(hb.BreakmerHipError):
         hb.Engine(kmer_size=31).submit([hb.RegionInput(["A" * 2000], w)])             # read longer than max_read_len
     e5 = hb.Engine(kmer_size=31)                                                      # 20 kb window of a 4-mer repeat: global-memory k-mer set
@@ -557,3 +559,32 @@ def test_more_regions_than_workgroups_gpu(hb):
         want, _ = bo.assemble_region(r.read_strs(), [r.window_str], 25, 2)
         assert _strip(big.contigs(i)) == want, i
     assert sum(len(big.contigs(i)) for i in range(n)) >= n // 2
+
+
+def test_reads_with_n_gpu(hb):
+    """Reads with N calls: grouping (the N is part of the string), k-mer counting (no k-mer spans an N), the overlap DP
+    (N matches N only), contigs that contain N, realignment of such contigs -- against the oracle; the fixtures from the
+    real reference with N reads are part of test_g3_assembly_golden_gpu."""
+    from oracle import bk_oracle as bo
+    regions = [synth.make_region(960, sv_type="del", depth=80, W=1500, n_frac=0.2),
+               synth.make_region(961, sv_type="ins", depth=80, W=1500, n_frac=0.6, noise=0.01, var_len=0.3),
+               synth.make_region(962, sv_type="trl", depth=60, W=1200, n_frac=0.4),
+               synth.make_region(963, sv_type="del", depth=40, W=2400, L=400, n_frac=0.5),      # reads beyond the register fast paths
+               synth.make_region(964, sv_type="inv", depth=300, W=900, n_frac=1.0, noise=0.01)]
+    # duplicates that differ only in an N, and identical reads with the same N: grouped exactly like the strings
+    r0 = regions[0]
+    r0.reads[5] = r0.reads[4]; r0.reads[5, 70] = 4
+    r0.reads[6] = r0.reads[5]
+    eng = _run_regions(hb, regions, 31, stages=7)
+    ncontig_n = 0
+    for i, r in enumerate(regions):
+        targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        want, info = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
+        mers, counts, U = eng.kmers(i)
+        assert U == len(info["rep"]) == len(set(r.read_strs())), i
+        assert dict(zip(mers, counts.tolist())) == dict(zip(info["mers"], info["counts"].tolist())), i
+        assert _strip(eng.contigs(i)) == want and len(want) >= 1, i
+        for ci, c in enumerate(want[:6]):
+            assert eng.hits(i, ci) == bo.realign(c["seq"], targets), (i, ci)
+            ncontig_n += "N" in c["seq"]
+    assert ncontig_n >= 1

@@ -141,18 +141,26 @@ def test_runner_from_alignment_file(tmp_path):
     check_sam_run(rows, r, tmp_path)
 
 
-def test_reads_with_n_are_skipped_not_fatal(tmp_path):
-    """Real alignment files contain N calls; the 2-bit device path cannot hold them: such reads are dropped with a
-    warning (documented deviation), the run still finds the planted call."""
+def test_reads_with_n_are_kept(tmp_path):
+    """Real alignment files contain N calls; the reference keeps such reads (utils.py:203-246) and so does this path:
+    every N read reaches the engine, the run finds the planted call; only characters that are not A/C/G/T/N are dropped."""
     cfg, r = make_sam_inputs(tmp_path)
     sam = (tmp_path / "sample.sam").read_text().splitlines()
     out, n = [], 0
     for ln in sam:
         f = ln.split("\t")
         if not ln.startswith("@") and n < 12 and "S" in f[5]:
-            f[9] = f[9][:40] + "N" + f[9][41:]
+            f[9] = f[9][:40] + ("N" if n < 10 else "R") + f[9][41:]
             n += 1
         out.append("\t".join(f))
     (tmp_path / "sample.sam").write_text("\n".join(out) + "\n")
-    rows = sp.runner(cfg, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min'))).run()
+    seen = {}
+
+    class Spy(FakeEngine):
+        def submit(self, ins):
+            seen["n"] = sum(1 for g in ins for i in range(g.reads.shape[0]) if b"N" in bytes(g.reads[i, :g.lens[i]]))
+            seen["other"] = sum(1 for g in ins for i in range(g.reads.shape[0]) if b"R" in bytes(g.reads[i, :g.lens[i]]))
+            FakeEngine.submit(self, ins)
+    rows = sp.runner(cfg, engine_factory=lambda prm: Spy(prm.get_kmer_size(), prm.get_sr_thresh('min'))).run()
     assert n == 12 and len(rows) >= 1 and rows[0][1].endswith("(D120)")
+    assert seen["n"] >= 8 and seen["other"] == 0

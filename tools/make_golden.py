@@ -181,6 +181,10 @@ def g3():
     cases.append(region_case("varlen_indelonly_ins", region_id=7, sv_type="ins", depth=60, W=1500, var_len=0.4, indel_only_frac=0.3, noise=0.005))
     cases.append(region_case("varlen_dup_rc3", rc_thresh=3, region_id=8, sv_type="dup", depth=80, W=1500, var_len=0.5, noise=0.01))
     cases.append(region_case("no_sv", region_id=9, sv_type="del", sv_size=0, depth=40, W=900))
+    # reads with N calls (kept by the reference, utils.py:203-246; N == N is a match in olc.nw; no k-mer spans an N)
+    cases.append(region_case("nreads_del", region_id=40, sv_type="del", depth=60, W=1500, n_frac=0.15))
+    cases.append(region_case("nreads_ins_noise_varlen", region_id=41, sv_type="ins", depth=60, W=1200, n_frac=0.3, noise=0.01, var_len=0.3))
+    cases.append(region_case("nreads_inv_k21", k=21, region_id=42, sv_type="inv", depth=40, W=1000, n_frac=0.5, noise=0.005))
     dump("assembly.json", {"cases": cases})
 
 
