@@ -50,6 +50,8 @@ def parse(argv=None):
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
     ap.add_argument("--cfg3-regions", type=int, default=4096, help="batch size of the configs[3] side measurement (heavy regions: the chip fills at a few thousand)")
     ap.add_argument("--cfg4-regions", type=int, default=16)
+    ap.add_argument("--flags", type=int, default=0, help="diagnostic library flags (bk_config.reserved[0]); 0 in every reported number")
+    ap.add_argument("--lib", default=None, help="diagnostic: path of an alternative build of the library (A/B runs on one box)")
     ap.add_argument("--dump-collated", default=None, help="write the bytes collated in the last step to this file (testing)")
     return ap.parse_args(argv)
 
@@ -196,6 +198,8 @@ def main():
         else:
             td.init_process_group("nccl", device_id=torch.device("cuda", local))
     from breakmer_amd import hip_backend as hb, synth
+    if a.lib:
+        hb.LIB_PATH = os.path.abspath(a.lib)
     n_regions = a.regions if a.regions > 0 else (256 if world == 1 else 512)
 
     # ---- inputs: disjoint region ids per rank (weak scaling), packed + resident before timing -------
@@ -208,7 +212,7 @@ def main():
     engs = []
     submit_ms = []
     for _ in range(max(1, a.inflight)):                # one handle (= one HIP stream + its own buffers) per step in flight
-        e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local)
+        e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local, flags=a.flags)
         t0 = time.perf_counter()
         e.submit(ins)
         submit_ms.append((time.perf_counter() - t0) * 1e3)
@@ -369,6 +373,7 @@ def main():
                        "regions_total_per_step": n_regions * world,
                        "sv_calls_per_step": last_rows.get("n", 0),
                        "steps_in_flight": len(engs),
+                       "asm_workgroups_per_cu": int(eng.stat(23)),
                        "collated_bytes_per_step": collated if dist else None,
                        "parallelism": "regions sharded per GPU, all-gather of result records"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -305,7 +305,7 @@ static void fill_params(bk_handle *h)
     p.n_clist = (unsigned long long *)h->d_tops.p + 2; p.asm_head = (unsigned long long *)h->d_tops.p + 3; p.sw_head = (unsigned long long *)h->d_tops.p + 4;
     p.order = (uint32_t *)h->d_order.p; p.clist = (unsigned long long *)h->d_clist.p; p.clist_cap = h->d_clist.bytes / 8;
     p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->eff_max_read;
-    p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions;
+    p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions; p.flags = h->cfg.reserved[0];
 }
 
 static size_t asm_lds_bytes(const bk_handle *h)
@@ -619,6 +619,8 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     if (which == 20) v = (uint64_t)(h->submit_pack_ms * 1000.0);              // microseconds
     if (which == 21) v = (uint64_t)(h->submit_h2d_ms * 1000.0);
     if (which == 22) v = (uint64_t)h->n_failed;
+    if (which == 23) v = (uint64_t)h->asm_wg_per_cu;                        // resident assembler / realign workgroups per CU (occupancy query)
+    if (which == 24) v = (uint64_t)h->sw_wg_per_cu;
     if (which >= 100 && which < 120) v = h->h_work[0].stamps[which - 100];      // diagnostic builds (-DBK_PHASE_STAMPS): region 0
     *value = v; return BK_OK;
 }

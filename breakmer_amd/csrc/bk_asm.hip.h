@@ -16,8 +16,11 @@
 #include "bk_common.h"
 #include "bk_nw.hip.h"
 
-#define BK_AT 512            // 8 wavefronts: 4 speculative look-ahead slots x 2 overlap DPs (8 slots / 16 waves: 8 % faster alone, slower with batches in flight)
-#define BK_SPEC 4
+#ifndef BK_AT
+#define BK_AT 512            // 8 wavefronts: 8 speculative look-ahead slots, both overlap DPs of a slot on one wavefront (bk_nw_dual);
+#endif
+#define BK_SPEC (BK_AT / 64)        // contigs beyond BK_NW_DUAL_COLS: half as many slots x 2 wavefronts (one DP each)
+#define BK_SPEC_WIDE (BK_AT / 128)
 
 enum { BK_ORD_FOR = 0, BK_ORD_REV = 1, BK_ORD_MID = 2 };
 enum { BK_DEC_NONE = 0, BK_DEC_SAME = 1, BK_DEC_SUPER = 2, BK_DEC_SUB = 3, BK_DEC_POST = 4, BK_DEC_PRE = 5 };
@@ -43,7 +46,7 @@ struct BkAsmShared {
     BkNwResult v1, v2;
     // look-ahead slots (see bk_run_candidates): read q+s aligned against the PREDICTED contig after reads q..q+s-1
     struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt, hasn; BkNwResult v1, v2; } slot[BK_SPEC];
-    int nb, pc, last_dec;
+    int nb, pc, last_dec, dual;
     int qslot;                   // position in the region queue this workgroup is working on
     uint32_t scan[24];
 #ifdef BK_PHASE_STAMPS
@@ -75,7 +78,7 @@ struct BkAsmCtx {
     uint32_t *klist, *nklist;    // contig.kmers / refresh snapshot (rank | rev << 31)
     uint32_t *pend;              // FIFO: 2 words per entry (rank, u)
     uint32_t *altl, *readl, *usedl;
-    int MAXC, MAXR, MAXCAND, KCAP, k;
+    int MAXC, MAXR, MAXCAND, KCAP, k, flags;
 };
 
 #define BK_TID ((int)threadIdx.x)
@@ -523,6 +526,25 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
 // geometry => same bytes); the first misprediction discards the later slots, which are redone next round.
 // Results are therefore bit-identical to the serial loop; only the DP latency chain gets shorter.
 enum { BK_PK_SAME = 0, BK_PK_PRE = 1, BK_PK_POST = 2, BK_PK_STOP = 3 };
+// The overlap DPs of one look-ahead round.  Everything it needs is in LDS (slots, contig deque, staged reads); it is kept
+// OUT of line so that the dozens of DP variants it dispatches to (one function per column count) have ONE call site
+// whose live state is nothing: inlined into the state machine they made the allocator spill around every variant.
+__device__ __noinline__ void bk_dp_round()
+{
+    BkAsmShared *S = S_;
+    const int wv = BK_TID >> 6, nb = S->nb;
+    if (S->dual) {                                       // both DPs of slot wv on this wavefront
+        if (wv < nb) bk_nw_dual(L_CSEQ + S->slot[wv].pb, S->slot[wv].plen, L_RSEQ_S(wv), S->slot[wv].rl, (int *)&S->slot[wv].v1);
+    } else {                                             // two wavefronts per slot, both with the contig on the tile columns
+        const int sl = wv >> 1;
+        if (sl < nb) {
+            const uint8_t *cs = L_CSEQ + S->slot[sl].pb; const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
+            // waves w and w+4 land on the same SIMD: give it one direct (heavier) and one transposed sweep
+            if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
+            else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
+        }
+    }
+}
 __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bool grow)
 {
     BkAsmShared *S = S_;
@@ -531,7 +553,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
     while (q < n) {
         if (S->status) return;
         BK_ACC(S_->ctx);
-        const int nbmax = min(BK_SPEC, n - q);
+        const int nbmax = min((C_.flags & BK_F_NO_DUAL) ? BK_SPEC_WIDE : BK_SPEC, n - q);
         // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
         BK_SYNC();
         if (BK_TID < nbmax) {
@@ -544,7 +566,9 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         BK_SYNC();
         if (BK_TID == 0) {
             int pb = S->cbase, plen = S->clen, ppc = S->pc, nb = 0;
+            // both DPs of a slot run on one wavefront while the (predicted) contig fits its columns; else two wavefronts per slot
             for (int sl = 0; sl < nbmax; sl++) {
+                if (sl >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) break;
                 BkAsmShared::Slot &t = S->slot[sl];
                 const int pos = t.pos, rl = t.rl;
                 t.pb = pb; t.plen = plen;
@@ -555,6 +579,10 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
                 else if (right > 0) { t.kind = BK_PK_POST; t.amt = right; if (pb + plen + right > 2 * C_.MAXC || plen + right > C_.MAXC) { t.kind = BK_PK_STOP; break; } plen += right; }
                 else { t.kind = BK_PK_SAME; t.amt = 0; }
             }
+            int mx = 0;
+            for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen);
+            S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL);
+            if (!S->dual && nb > BK_SPEC_WIDE) nb = BK_SPEC_WIDE;
             S->nb = nb;
         }
         BK_SYNC();
@@ -589,16 +617,8 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             }
         }
         BK_ACC(1);
-        // 2. the overlap DPs (:451-452), two wavefronts per slot, both with the contig on the tile columns
-        {
-            const int sl = wv >> 1;
-            if (sl < nb) {
-                const uint8_t *cs = L_CSEQ + S->slot[sl].pb; const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
-                // waves w and w+4 land on the same SIMD: give it one direct (heavier) and one transposed sweep
-                if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
-                else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
-            }
-        }
+        // 2. the overlap DPs (:451-452) of every slot of this round
+        bk_dp_round();
         BK_SYNC();
         BK_ACC(2);
         // 3. retire in order while the predictions hold
@@ -653,7 +673,7 @@ __device__ inline void bk_check_alt_reads()
             BkKey ob; ob.hi = oh; ob.lo = ol;
             if (ork >= 0 && (bestrk < 0 || key_lt(ob, best))) { best = ob; bestrk = ork; }
         }
-        unsigned long long *red = (unsigned long long *)(tmp + 2 * C_.MAXCAND - 32);   // tail of the scratch: 4 x (hi, lo, rk)
+        unsigned long long *red = (unsigned long long *)(tmp + 2 * C_.MAXCAND - 64);   // tail of the scratch: (hi, lo, rk) per wavefront (8 x 3 x 8 B <= 256 B)
         BK_SYNC();
         if ((BK_TID & 63) == 0) { int w = BK_TID >> 6; red[3 * w] = best.hi; red[3 * w + 1] = best.lo; red[3 * w + 2] = (unsigned long long)(long long)bestrk; }
         BK_SYNC();
@@ -863,7 +883,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.wk = wk; c.out = p.out; c.out_top = p.out_top; c.out_cap = p.out_cap; c.rc_thresh = p.rc_thresh;
         c.n_clist = p.n_clist; c.clist = p.clist; c.clist_cap = p.clist_cap; c.region = r;
         c.read_words = d.read_words; c.max_len = d.max_len;
-        c.MAXC = p.max_contig; c.MAXR = p.max_read; c.MAXCAND = p.max_cand; c.KCAP = 2 * p.max_contig; c.k = p.k;
+        c.flags = p.flags; c.MAXC = p.max_contig; c.MAXR = p.max_read; c.MAXCAND = p.max_cand; c.KCAP = 2 * p.max_contig; c.k = p.k;
         int o = BK_BUF_OFF;
         c.o_cand = o; o += c.MAXCAND * 8;
         c.o_bound = o; o += (BK_AT / 64) * 2 * (c.MAXR + 2) * 4;
@@ -971,6 +991,15 @@ extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_
     for (int t = threadIdx.x; t < m; t += 64) s1[t] = codes[off1[b] + t];
     for (int t = threadIdx.x; t < n; t += 64) s2[t] = codes[off2[b] + t];
     __syncthreads();
+    if (transposed >= 3) {                             // both DPs of check_align on one wavefront: 3 -> nw(seq1, seq2), 4 -> nw(seq2, seq1)
+        int *res = bound;
+        if (m <= BK_NW_DUAL_COLS) {
+            for (int i = 0; i < reps; i++) bk_nw_dual(s1, m, s2, n, res);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[4 * b + q] = res[(transposed == 4 ? 4 : 0) + q];
+        } else if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[4 * b + q] = -1;
+        return;
+    }
     BkNwResult r{};
     for (int i = 0; i < reps; i++) r = transposed == 2 ? bk_nw_suffix(s1, m, s2, n, bound) : transposed ? bk_nw_wave<true>(s2, n, s1, m, bound) : bk_nw_wave<false>(s1, m, s2, n, bound);
     if (threadIdx.x == 0) { out[4 * b] = r.j_start; out[4 * b + 1] = r.i_end; out[4 * b + 2] = r.i_start; out[4 * b + 3] = r.score; }

@@ -169,7 +169,9 @@ struct BkParams {
     uint32_t *order; unsigned long long *asm_head, *sw_head, *n_clist; unsigned long long *clist; uint64_t clist_cap;
     int32_t k, rc_thresh, max_contig, max_read, max_cand, sw_min_score;
     int32_t n_regions;
+    int32_t flags;               // BK_F_*
 };
+enum { BK_F_NO_DUAL = 1 };      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
 
 __device__ inline uint64_t bk_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 

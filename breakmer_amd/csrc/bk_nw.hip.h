@@ -309,3 +309,109 @@ __device__ inline BkNwResult bk_nw_suffix(const uint8_t *contig, int m, const ui
     r.j_start += off;                                   // top-border origins (and the forced step of Q5) are column numbers
     return r;
 }
+
+// ---- both overlap DPs of check_align (sv_assembly.py:451-452) on ONE wavefront ----------------------------------------
+// Lanes 0..31 run the direct sweep of nw(contig[off1:], read) (closed cut column when off1 > 0, see bk_nw_suffix), lanes
+// 32..63 the transposed sweep of nw(read, contig): the same row symbols (the read) enter both halves at the same step, so
+// the skew is 31 lanes instead of 63 (fill/drain 17 % of the steps instead of 28 %) and a candidate read needs one
+// wavefront instead of two.  Each lane owns C = ceil(contig / 32) <= BK_NW_DUAL_C columns.  The columns are RIGHT-aligned
+// in the lanes of their half: the last column is always register C-1 of the last lane (no run-time register select for
+// the end-cell rule of the direct sweep); the `pad` unused registers at the left of lane 0 hold a symbol that matches
+// nothing and take a horizontal gap constant of 0, so each row's border word simply travels through them.
+#define BK_NW_DUAL_C 10
+#define BK_NW_DUAL_COLS (32 * BK_NW_DUAL_C)
+template <int C>
+__device__ __noinline__ void bk_nw_dual_c(const uint8_t *contig, int clen_, int off1_, const uint8_t *rows, int n_, int *res /* 8 ints in LDS: v1, v2 */)
+{
+    const int clen = __builtin_amdgcn_readfirstlane(clen_), off1 = __builtin_amdgcn_readfirstlane(off1_), n = __builtin_amdgcn_readfirstlane(n_);
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const bool tr = lane >= 32;                                        // half 1: transposed sweep (v2)
+    const int mt = tr ? clen : clen - off1;                            // columns of this half
+    const uint8_t *cols = tr ? contig : contig + off1;
+    const int nl = (mt + C - 1) / C, lm = nl - 1, pad = nl * C - mt;
+    const int lm_max = max((clen - off1 + C - 1) / C, (clen + C - 1) / C) - 1;      // wave-uniform
+    const int GH = tr ? BK_NW_G1 : BK_NW_G2, GV = tr ? BK_NW_G2 : BK_NW_G1;
+    const int TOPB = tr ? 0x8000 : 0, LEFTB = tr ? 0 : 0x8000;
+    const int lbase = (LEFTB + 1) + ((!tr && off1 > 0) ? BK_NW_CLOSED : 0);
+    int H[C], cb[C], gh[C];
+#pragma unroll
+    for (int x = 0; x < C; x++) {
+        const int jj = hl * C + x - pad;                               // 0-based column, < 0: padding
+        const bool real = jj >= 0 && jj < mt && hl <= lm;
+        H[x] = real ? (TOPB | (jj + 1)) : 0;                           // row 0: the border cell (0, jj+1); padding holds the corner
+        cb[x] = real ? (int)cols[jj] : 8;
+        gh[x] = jj >= 0 ? GH : 0;
+    }
+    int dprev = (hl * C - pad) > 0 ? (TOPB | (hl * C - pad)) : 0;
+    int rb = 0, im1 = -hl;
+    int best_word = 0, best_im1 = -1;
+    const bool inl = hl <= lm;
+    const int steps = n + lm_max;
+    for (int t0 = 0; t0 < steps; t0 += 64) {
+        const int rblk = (t0 + lane < n) ? (int)rows[t0 + lane] : 0;
+        const int te = min(64, steps - t0);
+        for (int tl = 0; tl < te; tl++) {
+            const int recv = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);
+            rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
+            { const int rb0 = __builtin_amdgcn_readlane(rblk, tl); if (hl == 0) rb = rb0; }
+            if (inl && (unsigned)im1 < (unsigned)n) {
+                const int left_in = hl == 0 ? lbase + im1 : recv;
+                int cd[C], cv[C];
+#pragma unroll
+                for (int x = 0; x < C; x++) {
+                    cd[x] = (x ? H[x - 1] : dprev) + (cb[x] == rb ? BK_NW_MATCH : BK_NW_MISM);
+                    cv[x] = H[x] + GV;
+                }
+                int u_in = left_in;
+#pragma unroll
+                for (int x = 0; x < C; x++) {
+                    const int nv = max(max(cd[x], u_in + gh[x]), cv[x]) & ~BK_NW_PRIO_MASK;
+                    H[x] = nv; u_in = nv;
+                }
+                dprev = left_in;
+                const int v = H[C - 1];                                // direct half, lane lm: the last column (olc.py:81 '>=': last row wins)
+                const bool take = v >= (best_word & ~0x3FFFF);
+                best_word = take ? v : best_word; best_im1 = take ? im1 : best_im1;
+            }
+            im1++;
+        }
+    }
+    // direct half: lane lm of half 0
+    const int lm1 = (clen - off1 + C - 1) / C - 1;
+    const int w1 = __shfl(best_word, lm1), i1 = __shfl(best_im1, lm1) + 1;
+    // transposed half: the last tile row, scanned in ascending column order ('>=' keeps the largest index), then reduced
+    int w2 = (int)0x80000000, i2 = 0;
+    if (tr) {
+        w2 = 0; i2 = 0;
+#pragma unroll
+        for (int x = 0; x < C; x++) {
+            const int jj = hl * C + x - pad;
+            if (jj >= 0 && jj < mt && hl <= lm && (H[x] >> 18) >= (w2 >> 18)) { w2 = H[x]; i2 = jj + 1; }
+        }
+    }
+    for (int o = 1; o < 32; o <<= 1) {
+        const int ow = __shfl_xor(w2, o), oi = __shfl_xor(i2, o);
+        const int sc = w2 >> 18, os = ow >> 18;
+        if (os > sc || (os == sc && oi > i2)) { w2 = ow; i2 = oi; }
+    }
+    w2 = __shfl(w2, 32); i2 = __shfl(i2, 32);
+    if (lane == 0) {
+        // v1 = nw(contig, read): m_ref = clen; v2 = nw(read, contig): m_ref = n
+        if (i1 == 0) { res[0] = clen - 1; res[1] = 0; res[2] = 0; res[3] = 0; }
+        else { const int org = w1 & 0xFFFF; res[3] = w1 >> 18; res[1] = i1; if (org & 0x8000) { res[2] = org & 0x7FFF; res[0] = 0; } else { res[0] = org + off1; res[2] = 0; } }
+        if (i2 == 0) { res[4] = n - 1; res[5] = 0; res[6] = 0; res[7] = 0; }
+        else { const int org = w2 & 0xFFFF; res[7] = w2 >> 18; res[5] = i2; if (org & 0x8000) { res[6] = org & 0x7FFF; res[4] = 0; } else { res[4] = org; res[6] = 0; } }
+    }
+}
+template <int C>
+__device__ inline void bk_nw_dual_call(int c, const uint8_t *contig, int clen, int off1, const uint8_t *rows, int n, int *res)
+{
+    if (c <= C) { bk_nw_dual_c<C>(contig, clen, off1, rows, n, res); return; }
+    if constexpr (C < BK_NW_DUAL_C) bk_nw_dual_call<C + 1>(c, contig, clen, off1, rows, n, res);
+}
+// contig <= BK_NW_DUAL_COLS.  res: 8 ints (LDS or global), written by lane 0: v1 then v2 as (j_start, i_end, i_start, score)
+__device__ inline void bk_nw_dual(const uint8_t *contig, int clen, const uint8_t *read, int n, int *res)
+{
+    const int K = n + (n >> 1) + 2, off1 = clen > K ? clen - K : 0;
+    bk_nw_dual_call<3>((clen + 31) / 32, contig, clen, off1, read, n, res);
+}

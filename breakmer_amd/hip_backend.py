@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbreakmer_hip.so")
+LIB_PATH = os.environ.get("BREAKMER_HIP_LIB") or os.path.join(_HERE, "libbreakmer_hip.so")     # the override is for A/B builds (tools/)
 
 BK_STAGE_KMER, BK_STAGE_ASSEMBLE, BK_STAGE_REALIGN, BK_STAGE_ALL = 1, 2, 4, 7
 BK_MAX_BLOCKS = 16
@@ -176,6 +176,7 @@ class Engine(object):
         cfg.arena_bytes = int(limits.get("arena_bytes", 0))
         cfg.out_kbytes = int(limits.get("out_kbytes", 0))
         cfg.sw_min_score = int(limits.get("sw_min_score", 0))
+        cfg.reserved[0] = int(limits.get("flags", 0))
         self.k = int(kmer_size)
         self.h = C.c_void_p()
         rc = self.L.bk_create(int(device), C.byref(cfg), C.byref(self.h))

@@ -51,7 +51,7 @@ typedef struct bk_config {
     int64_t arena_bytes;        /* device scratch arena; 0 = choose from the batch; grown and retried on overflow */
     int32_t sw_min_score;       /* BLAT -minScore=20 analogue for the realign stage (sv_processor.py:843) */
     int32_t out_kbytes;         /* initial result arena in KiB; 0 = choose from the batch; grown and retried on overflow */
-    int32_t reserved[6];
+    int32_t reserved[6];        /* [0]: diagnostic flags (0 in production; 1 = one overlap DP per wavefront even for short contigs) */
 } bk_config;
 
 /* One target region = what sv_processor.target hands to compare_kmers()/resolve_sv()

@@ -33,6 +33,9 @@ def test_g1_nw_kats_gpu(hb, golden_dir):
     out_t, _ = eng.nw_batch(pairs, transposed=True)          # the transposed sweep used for nw(read, contig)
     assert out.tolist() == out_t.tolist()
     assert eng.nw_batch(pairs, transposed=2)[0].tolist() == out.tolist()      # suffix-restricted sweep used for nw(contig, read)
+    small = [p for p in pairs if len(p[0]) <= 320]                            # both DPs on one wavefront (contig <= 320 columns)
+    o3, o4 = eng.nw_batch(small, transposed=3)[0].tolist(), eng.nw_batch(small, transposed=4)[0].tolist()
+    assert o3 == eng.nw_batch(small)[0].tolist() and o4 == eng.nw_batch([(b, a) for a, b in small])[0].tolist()
     for c, o in zip(d["cases"], out.tolist()):
         exp = c["out"]
         assert o == [exp[3], exp[4], exp[5], exp[6]], c["tag"]
@@ -85,6 +88,31 @@ def test_nw_random_vs_oracle_gpu(hb):
         assert o == [e[3], e[4], e[5], e[6]], (len(a), len(b))
         assert ot == o, (len(a), len(b), "transposed")
         assert os_ == o, (len(a), len(b), "suffix")
+    # both overlap DPs of check_align on one wavefront: (contig, read) -> nw(contig, read) and nw(read, contig)
+    rnd2 = random.Random(12)
+    dual = [(a, b) for a, b in pairs if len(a) <= 320 and len(b) <= 400]
+    for t in range(300):
+        m, n = rnd2.randint(1, 320), rnd2.randint(1, 260)
+        a = "".join(rnd2.choice("ACGT" if t % 3 else "AC") for _ in range(m))
+        kind = t % 4
+        ov = rnd2.randint(1, min(m, n))
+        if kind == 0:
+            b = a[m - ov:] + "".join(rnd2.choice("ACGT") for _ in range(n - ov))          # read hangs over the contig end
+        elif kind == 1:
+            b = "".join(rnd2.choice("ACGT") for _ in range(n - ov)) + a[:ov]              # ... over its start
+        elif kind == 2:
+            s0 = rnd2.randint(0, m - ov); b = a[s0:s0 + ov]                               # contained
+        else:
+            b = "".join(rnd2.choice("ACGT") for _ in range(n))
+        if t % 2:
+            b = "".join((ch if rnd2.random() > 0.04 else rnd2.choice("ACGTN")) for ch in b)
+        dual.append((a, b if b else "A"))
+    d1, _ = eng.nw_batch(dual, transposed=3)
+    d2, _ = eng.nw_batch(dual, transposed=4)
+    for (a, b), x1, x2 in zip(dual, d1.tolist(), d2.tolist()):
+        e1, e2 = bo.nw(a, b), bo.nw(b, a)
+        assert x1 == [e1[3], e1[4], e1[5], e1[6]], (len(a), len(b), "dual v1")
+        assert x2 == [e2[3], e2[4], e2[5], e2[6]], (len(a), len(b), "dual v2")
 
 
 def _run_regions(hb, regions, k, rc_thresh=2, stages=3):

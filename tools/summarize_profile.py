@@ -57,6 +57,43 @@ if tot:
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of the fetched bytes; calibrated there for wide coalesced "
                   "streams only, our loads are 4 B/lane: upper bound)")
     json.dump(tj, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+# ---- SQ instruction counters (one pass, one handle in flight): VALU issue roofline of the assembler
+cells = None
+bj0 = os.path.join(src, "bench_default.json")
+if os.path.isfile(bj0) and os.path.getsize(bj0):
+    try:
+        line = [ln for ln in open(bj0).read().splitlines() if ln.startswith("{")][-1]
+        cells = json.loads(line).get("dp_cells_per_step")
+    except Exception:
+        cells = None
+for sub, label in (("pmc_sq", "one handle in flight"), ("pmc_sq3", "3 handles in flight")):
+    fn = one(sub + "/**/*_counter_collection.csv")
+    if not fn:
+        continue
+    acc = {}
+    for r in csv.DictReader(open(fn)):
+        if r["Kernel_Name"] in KERNELS:
+            a = acc.setdefault(r["Kernel_Name"], {})
+            c = a.setdefault(r["Counter_Name"], [0.0, set()])
+            c[0] += float(r["Counter_Value"])
+            c[1].add(r["Dispatch_Id"])
+    names = sorted({c for a in acc.values() for c in a})
+    with open(os.path.join(dst, sub + "_summary.csv"), "w") as f:
+        f.write("kernel," + ",".join(n + "_per_launch" for n in names) + "\n")
+        for k, a in sorted(acc.items()):
+            f.write(k + "," + ",".join("%.0f" % (a[n][0] / max(1, len(a[n][1])) if n in a else 0.0) for n in names) + "\n")
+    if sub == "pmc_sq" and "bk_asm_kernel" in acc and "SQ_INSTS_VALU" in acc["bk_asm_kernel"] and cells:
+        a = acc["bk_asm_kernel"]
+        valu = a["SQ_INSTS_VALU"][0] / max(1, len(a["SQ_INSTS_VALU"][1]))
+        vj = {"bk_asm_kernel_valu_insts_per_launch": valu, "dp_cells_per_launch": cells,
+              "bk_asm_kernel_valu_laneops_per_cell": round(valu * 64.0 / cells, 3),
+              "valu_note": "rocprofv3 --pmc SQ_INSTS_VALU ... (bench.py --steps 6 --warmup 2 --inflight 1, 256 regions): wave-level VALU instructions "
+                           "of one bk_asm_kernel launch x 64 lanes / algorithmic DP cells of the launch (sum len(seq1)*len(seq2) over the reference's nw calls)"}
+        for n in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY"):
+            if n in a:
+                vj["bk_asm_kernel_" + n + "_per_launch"] = a[n][0] / max(1, len(a[n][1]))
+        json.dump(vj, open(os.path.join(root, "profiles", "valu.json"), "w"), indent=1)
+        print("valu", vj["bk_asm_kernel_valu_laneops_per_cell"], "lane-ops per algorithmic cell")
 bj = os.path.join(src, "bench_default.json")
 if os.path.isfile(bj) and os.path.getsize(bj):
     open(os.path.join(dst, "bench_default.json"), "w").write(open(bj).read())
