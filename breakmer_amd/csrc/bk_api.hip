@@ -122,18 +122,34 @@ extern "C" int bk_destroy(bk_handle *h)
 
 // 2 bit/base, first base in the most significant bits (bk_common.h).  nlist != nullptr: 'N' is accepted (packed as code 0)
 // and its position appended as (tag << 10 | position); any other character fails.
+// One table look-up per base: code in bits 0-1, bit 2 = N, bit 3 = invalid; 16 bases are folded into a word without a
+// branch and the flag bits of the whole word are tested once.
+struct BkPackLut { uint8_t v[256]; BkPackLut() { for (int i = 0; i < 256; i++) v[i] = 8; v[(int)'A'] = 0; v[(int)'C'] = 1; v[(int)'G'] = 2; v[(int)'T'] = 3; v[(int)'N'] = 4; } };
+static const BkPackLut g_pack_lut;
 static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vector<uint32_t> *nlist = nullptr, uint32_t tag = 0)
 {
-    for (int i = 0; i < nwords; i++) w[i] = 0;
-    for (int i = 0; i < len; i++) {
-        uint32_t c;
-        switch (s[i]) {
-        case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break;
-        case 'N': if (!nlist) return false; nlist->push_back((tag << 10) | (uint32_t)i); c = 0; break;
-        default: return false;
+    const uint8_t *lut = g_pack_lut.v; const unsigned char *u = (const unsigned char *)s;
+    int i = 0, wi = 0;
+    for (; i + 16 <= len; i += 16, wi++) {
+        uint32_t x = 0, fl = 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) { const uint32_t c = lut[u[i + t]]; fl |= c; x = (x << 2) | (c & 3u); }
+        w[wi] = x;
+        if (fl & 12u) {                                  // an N or an invalid character among these 16
+            if ((fl & 8u) || !nlist) return false;
+            for (int t = 0; t < 16; t++) if (lut[u[i + t]] & 4u) nlist->push_back((tag << 10) | (uint32_t)(i + t));
         }
-        w[i >> 4] |= c << (30 - 2 * (i & 15));
     }
+    if (i < len) {
+        uint32_t x = 0;
+        for (int t = 0; t < 16; t++) {
+            uint32_t c = 0;
+            if (i + t < len) { c = lut[u[i + t]]; if ((c & 8u) || ((c & 4u) && !nlist)) return false; if (c & 4u) nlist->push_back((tag << 10) | (uint32_t)(i + t)); }
+            x = (x << 2) | (c & 3u);
+        }
+        w[wi++] = x;
+    }
+    for (; wi < nwords; wi++) w[wi] = 0;
     return true;
 }
 
@@ -219,7 +235,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
                     if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
             }
         };
-        const int nth = std::max(1, std::min<int>({8, (int)std::thread::hardware_concurrency(), n_regions}));
+        const int nth = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), n_regions}));
         if (nth == 1) pack();
         else { std::vector<std::thread> th; for (int t = 0; t < nth; t++) th.emplace_back(pack); for (auto &x : th) x.join(); }
         if (bad_region >= 0) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_region.load()) + " read " + std::to_string(bad_read.load()) + ": base other than A/C/G/T/N");
@@ -545,7 +561,40 @@ extern "C" int bk_get_contig(bk_handle *h, int32_t region, int32_t contig, char 
     return BK_OK;
 }
 
-// Chain the raw hits of one contig into PSL-equivalent records (contract: oracle/bk_oracle.h R2 step 3).
+// ---- realign contract step 4 (oracle/bk_oracle.h): island fill.  Host code like the chaining it refines: the islands are the
+// unaligned rectangles next to chained anchors, a few hundred cells per contig, and they only exist once the chain is known.
+static const int BK_FILL_BAND = 16, BK_FILL_MIN = 8;
+struct BkFillBlk { int qs, qe, ts, te, score; };
+static int fill_best(const char *q, const char *t, int qa, int qb, int ta, int tb, bool use1, int d1, bool use2, int d2, BkFillBlk &out)
+{
+    int best = 0; out.score = 0; out.qe = out.te = 0;
+    int dlo = use1 ? d1 - BK_FILL_BAND : d2 - BK_FILL_BAND, dhi = use1 ? d1 + BK_FILL_BAND : d2 + BK_FILL_BAND;
+    if (use2) { dlo = std::min(dlo, d2 - BK_FILL_BAND); dhi = std::max(dhi, d2 + BK_FILL_BAND); }
+    for (int d = dlo; d <= dhi; d++) {
+        const bool in1 = use1 && d >= d1 - BK_FILL_BAND && d <= d1 + BK_FILL_BAND, in2 = use2 && d >= d2 - BK_FILL_BAND && d <= d2 + BK_FILL_BAND;
+        if (!in1 && !in2) continue;
+        const int a0 = std::max(qa, ta - d), a1 = std::min(qb, tb - d);
+        int h = 0, run = 0;
+        for (int a = a0; a < a1; a++) {
+            h += q[a] == t[a + d] ? 1 : -2; run++;
+            if (h <= 0) { h = 0; run = 0; continue; }
+            const int qe = a + 1, te = a + 1 + d;
+            if (h > best || (h == best && (qe < out.qe || (qe == out.qe && te < out.te)))) { best = h; out.qs = qe - run; out.qe = qe; out.ts = te - run; out.te = te; out.score = h; }
+        }
+    }
+    return best;
+}
+static void fill_gap(const char *q, const char *t, const BkFillBlk *L, const BkFillBlk *R, int qlo, int qhi, int tlo, int thi, std::vector<BkFillBlk> &v, size_t cap)
+{
+    if (qhi - qlo < BK_FILL_MIN || thi - tlo < BK_FILL_MIN || v.size() >= cap) return;
+    BkFillBlk nb;
+    if (fill_best(q, t, qlo, qhi, tlo, thi, L != nullptr, L ? L->te - L->qe : 0, R != nullptr, R ? R->ts - R->qs : 0, nb) < BK_FILL_MIN) return;
+    fill_gap(q, t, L, &nb, qlo, nb.qs, tlo, nb.ts, v, cap);
+    if (v.size() < cap) v.push_back(nb);
+    fill_gap(q, t, &nb, R, nb.qe, qhi, nb.te, thi, v, cap);
+}
+
+// Chain the raw hits of one contig into PSL-equivalent records (contract: oracle/bk_oracle.h R2 steps 3 and 4).
 static int chain_hits(const char *contig, int Q, const std::vector<std::string> &targets, std::vector<BkHit> hits, bk_psl *out, int cap)
 {
     std::string rc(Q, 'N');
@@ -572,12 +621,21 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
             const BkHit &f = chain.front(), &l = chain.back();
             const char *qstr = f.strand == 0 ? contig : rc.c_str(); const std::string &t = targets[f.tidx];
             r->strand = f.strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = f.tidx; r->t_size = (int32_t)t.size();
-            r->t_start = f.ts; r->t_end = l.te;
-            r->q_start = f.strand == 0 ? f.qs : Q - l.qe; r->q_end = f.strand == 0 ? l.qe : Q - f.qs;
+            (void)l;
+            std::vector<BkFillBlk> anch, blocks;
+            for (const BkHit &c : chain) anch.push_back(BkFillBlk{c.qs, c.qe, c.ts, c.te, c.score});
+            const size_t bcap = BK_MAX_BLOCKS; const int T = (int)t.size(), na = (int)anch.size();
+            fill_gap(qstr, t.c_str(), nullptr, &anch[0], 0, anch[0].qs, std::max(0, anch[0].ts - anch[0].qs - BK_FILL_BAND), anch[0].ts, blocks, bcap);
+            for (int c = 0; c < na; c++) {
+                if (blocks.size() < bcap) blocks.push_back(anch[c]);
+                if (c + 1 < na) fill_gap(qstr, t.c_str(), &anch[c], &anch[c + 1], anch[c].qe, anch[c + 1].qs, anch[c].te, anch[c + 1].ts, blocks, bcap);
+            }
+            fill_gap(qstr, t.c_str(), &anch[na - 1], nullptr, anch[na - 1].qe, Q, anch[na - 1].te, std::min(T, anch[na - 1].te + (Q - anch[na - 1].qe) + BK_FILL_BAND), blocks, bcap);
+            r->t_start = blocks.front().ts; r->t_end = blocks.back().te;
+            r->q_start = f.strand == 0 ? blocks.front().qs : Q - blocks.back().qe; r->q_end = f.strand == 0 ? blocks.back().qe : Q - blocks.front().qs;
             int nb = 0, pq = -1, pt = -1;
-            for (const BkHit &c : chain) {
+            for (const BkFillBlk &c : blocks) {
                 r->score += c.score;
-                if (nb >= BK_MAX_BLOCKS) continue;
                 const int bs = c.qe - c.qs;
                 for (int z = 0; z < bs; z++) { if (qstr[c.qs + z] == t[c.ts + z]) r->matches++; else r->mismatches++; }
                 if (pq >= 0) { if (c.qs > pq) { r->q_num_insert++; r->q_base_insert += c.qs - pq; } if (c.ts > pt) { r->t_num_insert++; r->t_base_insert += c.ts - pt; } }
@@ -621,7 +679,7 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     if (which == 22) v = (uint64_t)h->n_failed;
     if (which == 23) v = (uint64_t)h->asm_wg_per_cu;                        // resident assembler / realign workgroups per CU (occupancy query)
     if (which == 24) v = (uint64_t)h->sw_wg_per_cu;
-    if (which >= 100 && which < 120) v = h->h_work[0].stamps[which - 100];      // diagnostic builds (-DBK_PHASE_STAMPS): region 0
+    if (which >= 100 && which < 120) { v = 0; for (int r = 0; r < h->n_regions; r++) v += h->h_work[r].stamps[which - 100]; }      // diagnostic counters, summed over regions
     *value = v; return BK_OK;
 }
 

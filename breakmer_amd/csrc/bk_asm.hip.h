@@ -487,6 +487,10 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
         else {
             for (int t = s0 + BK_TID; t < min(s1, nlen); t += BK_AT) cv[t] += nreads;          // set_counts :195-199 (old coordinates)
             for (int t = BK_TID; t < pl; t += BK_AT) { io[at + t] = indel ? nreads : 0; ot[at + t] = indel ? 0 : nreads; }   // extend_counts :201-221
+            // Every wavefront has read the scalars above (cbase, nbase, clen, nlen) before thread 0 replaces them: without
+            // this barrier a wavefront that is late into this function (starved by co-resident workgroups) reads the
+            // NEW base and updates a range shifted by the prepended length.
+            BK_SYNC();
             if (BK_TID == 0 && dec != BK_DEC_SUB) {
                 if (dec == BK_DEC_PRE) { S->cbase = cbase - pl; S->nbase = nbase - pl; S->pc += pl; }
                 S->clen = clen + pl; S->nlen = nlen + pl;
@@ -534,7 +538,7 @@ __device__ __noinline__ void bk_dp_round()
     BkAsmShared *S = S_;
     const int wv = BK_TID >> 6, nb = S->nb;
     if (S->dual) {                                       // both DPs of slot wv on this wavefront
-        if (wv < nb) bk_nw_dual(L_CSEQ + S->slot[wv].pb, S->slot[wv].plen, L_RSEQ_S(wv), S->slot[wv].rl, (int *)&S->slot[wv].v1);
+        if (wv < nb) bk_nw_dual(C_.o_cseq + S->slot[wv].pb, S->slot[wv].plen, C_.o_rseq + wv * (C_.MAXR + 16), S->slot[wv].rl, (int)((uint8_t *)&S->slot[wv].v1 - bk_lds));
     } else {                                             // two wavefronts per slot, both with the contig on the tile columns
         const int sl = wv >> 1;
         if (sl < nb) {
@@ -553,7 +557,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
     while (q < n) {
         if (S->status) return;
         BK_ACC(S_->ctx);
-        const int nbmax = min((C_.flags & BK_F_NO_DUAL) ? BK_SPEC_WIDE : BK_SPEC, n - q);
+        const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
         // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
         BK_SYNC();
         if (BK_TID < nbmax) {
@@ -994,7 +998,7 @@ extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_
     if (transposed >= 3) {                             // both DPs of check_align on one wavefront: 3 -> nw(seq1, seq2), 4 -> nw(seq2, seq1)
         int *res = bound;
         if (m <= BK_NW_DUAL_COLS) {
-            for (int i = 0; i < reps; i++) bk_nw_dual(s1, m, s2, n, res);
+            for (int i = 0; i < reps; i++) bk_nw_dual((int)(s1 - l), m, (int)(s2 - l), n, (int)((uint8_t *)res - l));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
             if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[4 * b + q] = res[(transposed == 4 ? 4 : 0) + q];
         } else if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[4 * b + q] = -1;

@@ -352,7 +352,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     uint32_t *scr = lds;                       // 32 words scratch
     uint32_t *stage = lds + 32;                // 16 words per wavefront: the read a wavefront scans cooperatively
 
-    if (tid == 0) { wk->status = BK_ST_OK; wk->U = 0; wk->T = 0; wk->M = 0; wk->tcap = 0; wk->n_contigs = 0; wk->nw_cells = 0; wk->nw_calls = 0; wk->sw_cells = 0; wk->o_first_contig = 0; wk->o_last_contig = 0; }
+    if (tid == 0) { wk->status = BK_ST_OK; wk->U = 0; wk->T = 0; wk->M = 0; wk->tcap = 0; wk->n_contigs = 0; wk->nw_cells = 0; wk->nw_calls = 0; wk->sw_cells = 0; wk->o_first_contig = 0; wk->o_last_contig = 0; for (int q = 0; q < 4; q++) wk->stamps[q] = 0; }
     const int W = (int)d.win_len, WK = W >= k ? W - k + 1 : 0;
     const uint32_t *gw = p.windows + d.win_word_off;
     const int ww = (W + 15) / 16;
@@ -485,15 +485,23 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     __syncthreads();
     const uint32_t T = scr[24];
     uint32_t tcap = 256; while (tcap < 2 * T) tcap <<= 1;
-    uint64_t a0b = bk_arena_alloc(p, (uint64_t)tcap * 12 + 256, scr + 20);
-    if (a0b == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
-    const uint64_t o_tslot = a0b, o_tcnt = o_tslot + (uint64_t)tcap * 4, o_trank = o_tcnt + (uint64_t)tcap * 4;
-    uint32_t *tslot = (uint32_t *)(p.arena + o_tslot), *tcnt = (uint32_t *)(p.arena + o_tcnt), *trank = (uint32_t *)(p.arena + o_trank);
     // The table is filled in LDS when it fits and the reference set is no longer needed (no separate soft-clip set to
-    // scan): one CAS and one add per occurrence are device-scope atomics otherwise, each 64 B of write traffic.
+    // scan): one CAS and one add per occurrence are device-scope atomics otherwise, each 64 B of write traffic.  In LDS
+    // it also STAYS there: it is sized by the occurrences (their number is all that is known up front) but holds M
+    // distinct k-mers -- 30 of 16,384 slots for a clean deletion -- so what the assembler gets is a compact copy sized by
+    // M, built at the end; the full-size table never crosses HBM.
     const bool lds_tab = !GLB && d.n_sc < 0 && 2u * tcap + 32u + 16u * 16u <= lds_words;
-    uint32_t *wslot = lds_tab ? lds + 32 + 16 * 16 : tslot, *wcnt = lds_tab ? lds + 32 + 16 * 16 + tcap : tcnt;
-    for (uint32_t i = tid; i < tcap; i += nt) { wslot[i] = BK_EMPTY32; wcnt[i] = 0; trank[i] = BK_EMPTY32; }
+    uint64_t o_tslot = 0, o_tcnt = 0;
+    uint32_t *tslot, *tcnt;                                  // slot -> claimant occurrence, later the k-mer rank; slot -> count
+    if (lds_tab) { tslot = lds + 32 + 16 * 16; tcnt = tslot + tcap; }
+    else {
+        uint64_t a0b = bk_arena_alloc(p, (uint64_t)tcap * 8 + 256, scr + 20);
+        if (a0b == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
+        o_tslot = a0b; o_tcnt = o_tslot + (uint64_t)tcap * 4;
+        tslot = (uint32_t *)(p.arena + o_tslot); tcnt = (uint32_t *)(p.arena + o_tcnt);
+    }
+    uint32_t *wslot = tslot, *wcnt = tcnt;
+    for (uint32_t i = tid; i < tcap; i += nt) { wslot[i] = BK_EMPTY32; wcnt[i] = 0; }
     __syncthreads();
     BK_STAMP(11);
     const uint32_t tmask = tcap - 1;
@@ -511,10 +519,6 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         t_sl[idx] = s; atomicAdd(&wcnt[s], unr[u]);          // case[mer] counts every read (duplicates included)
     }
     __syncthreads();
-    if (lds_tab) {                                           // the assembler looks k-mers up in the global copy
-        for (uint32_t i = tid; i < tcap; i += nt) { tslot[i] = wslot[i]; tcnt[i] = wcnt[i]; }
-        __syncthreads();
-    }
     // soft-clip set: keep only k-mers also present in case_sc (sv_processor.py:619-621)
     if (d.n_sc >= 0) {
         const uint32_t *sc = p.sc + d.sc_word_off; const uint16_t *sl = p.sc_len + d.sc_meta_off;
@@ -525,13 +529,13 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
                     uint32_t cur = tslot[s];
                     if (cur == BK_EMPTY32) break;
                     uint32_t e2 = t_ent[cur];
-                    if (key_eq(seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k), key)) { trank[s] = 0; break; }
+                    if (key_eq(seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k), key)) { atomicOr(&tcnt[s], 0x80000000u); break; }   // seen in case_sc
                     s = (s + 1) & tmask;
                 }
             });
         }
         __syncthreads();
-        for (uint32_t i = tid; i < tcap; i += nt) { if (tslot[i] != BK_EMPTY32 && trank[i] == BK_EMPTY32) tslot[i] = BK_EMPTY32 - 1; trank[i] = BK_EMPTY32; }   // tombstone: probe chains stay intact
+        for (uint32_t i = tid; i < tcap; i += nt) { if (tslot[i] != BK_EMPTY32 && !(tcnt[i] & 0x80000000u)) tslot[i] = BK_EMPTY32 - 1; tcnt[i] &= 0x7FFFFFFFu; }   // tombstone: probe chains stay intact
         __syncthreads();
     }
     BK_STAMP(5);
@@ -540,33 +544,36 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     //      recruit reads like the others, but nothing depends on their order, so they are not sorted (with sequencing
     //      noise they are > 95 % of the set).
     uint32_t M = 0, M2 = 0;
+    const uint32_t chunk4 = (tcap + nt - 1) / nt, b4 = tid * chunk4, e4 = min(tcap, b4 + chunk4);
+    uint32_t pre2, pre1;
     {
-        const uint32_t chunk = (tcap + nt - 1) / nt, b = tid * chunk, e = min(tcap, b + chunk);
         uint32_t c2 = 0, c1 = 0, tot1 = 0;
-        for (uint32_t i = b; i < e; i++) if (tslot[i] < BK_EMPTY32 - 1) { if (tcnt[i] >= 2) c2++; else c1++; }
-        uint32_t pre2 = bk_block_excl_scan(c2, scr, &M2);
-        uint32_t pre1 = bk_block_excl_scan(c1, scr, &tot1);
+        for (uint32_t i = b4; i < e4; i++) if (tslot[i] < BK_EMPTY32 - 1) { if (tcnt[i] >= 2) c2++; else c1++; }
+        pre2 = bk_block_excl_scan(c2, scr, &M2);
+        pre1 = bk_block_excl_scan(c1, scr, &tot1);
         M = M2 + tot1;
-        for (uint32_t i = b; i < e; i++) if (tslot[i] < BK_EMPTY32 - 1) trank[i] = tcnt[i] >= 2 ? pre2++ : M2 + pre1++;    // provisional rank = compaction index
     }
     uint32_t npad = 1; while (npad < M2) npad <<= 1;
+    if (lds_tab) { perm_lds = tcnt; perm_cap = tcap; }         // the count words are free once the counts are materialised (npad <= tcap)
     const bool perm_in_lds = npad <= perm_cap;                 // else the permutation is sorted in global memory (slow path)
-    const uint64_t b2 = (uint64_t)M * (8 + 8 + 4 + 1 + 12 + 4 + 4) + (uint64_t)T * 4 + 4096 + (perm_in_lds ? 0 : (uint64_t)npad * 4);
+    const uint32_t tcap2 = [&] { uint32_t c = 64; while (c < 2 * M) c <<= 1; return c; }();      // compact table for the assembler (lds_tab)
+    const uint64_t b2 = (uint64_t)M * (8 + 8 + 4 + 1 + 12 + 4 + 4) + (uint64_t)T * 4 + 4096 + (perm_in_lds ? 0 : (uint64_t)npad * 4) + (lds_tab ? (uint64_t)tcap2 * 4 + 256 : 0);
     uint64_t a1 = bk_arena_alloc(p, b2, scr + 20);
     if (a1 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
     const uint64_t o_klo = a1, o_khi = o_klo + (uint64_t)M * 8, o_kcnt = o_khi + (uint64_t)M * 8, o_kstamp = bk_align_up(o_kcnt + (uint64_t)M * 4, 16),
                    o_poff = o_kstamp + (uint64_t)M * 12, o_tmp = bk_align_up(o_poff + (uint64_t)(M + 1) * 4, 16), o_post = bk_align_up(o_tmp + (uint64_t)M * 4, 16),
-                   o_kstate = o_post + (uint64_t)T * 4, o_perm = bk_align_up(o_kstate + M, 16);
+                   o_kstate = o_post + (uint64_t)T * 4, o_perm = bk_align_up(o_kstate + M, 16), o_tab2 = bk_align_up(o_perm + (perm_in_lds ? 0 : (uint64_t)npad * 4), 256);
     uint64_t *klo = (uint64_t *)(p.arena + o_klo), *khi = (uint64_t *)(p.arena + o_khi);
     uint32_t *kcnt = (uint32_t *)(p.arena + o_kcnt), *poff = (uint32_t *)(p.arena + o_poff), *ptmp = (uint32_t *)(p.arena + o_tmp), *post = (uint32_t *)(p.arena + o_post);
     int32_t *kstamp = (int32_t *)(p.arena + o_kstamp);
     uint8_t *kstate = (uint8_t *)(p.arena + o_kstate);
-    // permutation sort: perm in LDS (reusing the reference table) when it fits, else in ptmp/global
+    // permutation sort: perm in LDS when it fits, else in global memory
     uint32_t *perm = perm_in_lds ? perm_lds : (uint32_t *)(p.arena + o_perm);
-    // materialise keys at the provisional index first (keys/count by compaction index in klo/khi/kcnt)
-    for (uint32_t i = tid; i < tcap; i += nt) if (tslot[i] < BK_EMPTY32 - 1) {
-        uint32_t e2 = t_ent[tslot[i]]; BkKey key = seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k);
-        uint32_t j = trank[i]; klo[j] = key.lo; khi[j] = key.hi; kcnt[j] = tcnt[i]; ptmp[j] = i;      // ptmp: slot of compaction index
+    // keys and counts at the compaction index (count >= 2 first); ptmp: slot of the compaction index
+    for (uint32_t i = b4; i < e4; i++) if (tslot[i] < BK_EMPTY32 - 1) {
+        const uint32_t e2 = t_ent[tslot[i]]; const BkKey key = seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k);
+        const uint32_t j = tcnt[i] >= 2 ? pre2++ : M2 + pre1++;
+        klo[j] = key.lo; khi[j] = key.hi; kcnt[j] = tcnt[i]; ptmp[j] = i;
     }
     __syncthreads();
     {
@@ -597,11 +604,10 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         __syncthreads();
         for (uint32_t j = tid; j < M; j += nt) { uint32_t a = j < M2 ? perm[j] : j; s64[j] = khi[a]; s32[j] = ptmp[a]; }
         __syncthreads();
-        for (uint32_t j = tid; j < M; j += nt) { khi[j] = s64[j]; trank[s32[j]] = j; ptmp[j] = 0; }
+        // the assembler's lookups go table slot -> rank -> key: the slot itself now holds the rank (the claimant is not needed any more)
+        for (uint32_t j = tid; j < M; j += nt) { khi[j] = s64[j]; tslot[s32[j]] = j; ptmp[j] = 0; }
         __syncthreads();
     }
-    // the assembler's lookups go table slot -> rank -> key: store the rank in the slot itself (one dependent load less)
-    for (uint32_t i = tid; i < tcap; i += nt) if (tslot[i] < BK_EMPTY32 - 1) tslot[i] = trank[i];
     for (uint32_t j = tid; j < M; j += nt) {
         BkKey key{khi[j], klo[j]};
         kstate[j] = key_homopolymer(key, k) ? BK_K_REMOVED : BK_K_LIVE;      // kmers.add_kmer (sv_assembly.py:277)
@@ -611,9 +617,10 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     BK_STAMP(6);
     // ---- P5: posting lists k-mer rank -> (u, pos) -------------------------------------------------
     // list lengths and fill cursors in LDS when they fit (the LDS holds nothing that is still needed), else in ptmp
-    uint32_t *pcur = M + 32u + 16u * 16u <= lds_words ? lds + 32 + 16 * 16 : ptmp;
+    // (LDS table: in the count words, which are free by now; else the start of the LDS, which holds nothing that is still needed)
+    uint32_t *pcur = lds_tab ? tcnt : (M + 32u + 16u * 16u <= lds_words ? lds + 32 + 16 * 16 : ptmp);
     if (pcur != ptmp) { for (uint32_t j = tid; j < M; j += nt) pcur[j] = 0; __syncthreads(); }
-    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) atomicAdd(&pcur[rk], 1u); }
+    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = tslot[t_sl[idx]]; if (rk < BK_EMPTY32 - 1) atomicAdd(&pcur[rk], 1u); }
     __syncthreads();
     {
         const uint32_t chunk = (M + nt - 1) / nt, b = tid * chunk, e = min(M, b + chunk);
@@ -624,12 +631,27 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         if (tid == 0) poff[M] = tot;
     }
     __syncthreads();
-    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = trank[t_sl[idx]]; if (rk != BK_EMPTY32) post[atomicAdd(&pcur[rk], 1u)] = t_ent[idx]; }
+    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = tslot[t_sl[idx]]; if (rk < BK_EMPTY32 - 1) post[atomicAdd(&pcur[rk], 1u)] = t_ent[idx]; }
     __syncthreads();
+    uint32_t out_tcap = tcap;
+    if (lds_tab) {
+        // compact table slot -> rank for the assembler's lookups (bk_lookup): tcap2 >= 2 M slots, built in the count words, copied out once
+        uint32_t *tab2 = tcnt, *gtab2 = (uint32_t *)(p.arena + o_tab2);
+        for (uint32_t i = tid; i < tcap2; i += nt) tab2[i] = BK_EMPTY32;
+        __syncthreads();
+        for (uint32_t j = tid; j < M; j += nt) {
+            const BkKey key{khi[j], klo[j]};
+            uint32_t s2 = key_hash(key) & (tcap2 - 1);
+            while (atomicCAS(&tab2[s2], BK_EMPTY32, j) != BK_EMPTY32) s2 = (s2 + 1) & (tcap2 - 1);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < tcap2; i += nt) gtab2[i] = tab2[i];
+        o_tslot = o_tab2; out_tcap = tcap2;
+    }
     BK_STAMP(7);
     if (tid == 0) {
-        wk->U = U; wk->T = T; wk->M = M; wk->tcap = tcap;
-        wk->o_trip_ent = o_ent; wk->o_trip_slot = o_tsl; wk->o_tslot = o_tslot; wk->o_tcnt = o_tcnt; wk->o_trank = o_trank;
+        wk->U = U; wk->T = T; wk->M = M; wk->tcap = out_tcap;
+        wk->o_trip_ent = o_ent; wk->o_trip_slot = o_tsl; wk->o_tslot = o_tslot; wk->o_tcnt = o_tcnt; wk->o_trank = 0;
         wk->o_key_lo = o_klo; wk->o_key_hi = o_khi; wk->o_kcnt = o_kcnt; wk->o_kstate = o_kstate; wk->o_kstamp = o_kstamp;
         wk->o_poff = o_poff; wk->o_post = o_post;
     }

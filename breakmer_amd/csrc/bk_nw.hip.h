@@ -320,9 +320,14 @@ __device__ inline BkNwResult bk_nw_suffix(const uint8_t *contig, int m, const ui
 // nothing and take a horizontal gap constant of 0, so each row's border word simply travels through them.
 #define BK_NW_DUAL_C 10
 #define BK_NW_DUAL_COLS (32 * BK_NW_DUAL_C)
+extern __shared__ __attribute__((aligned(16))) uint8_t bk_dyn_lds[];      // the dynamic LDS block of the running kernel
 template <int C>
-__device__ __noinline__ void bk_nw_dual_c(const uint8_t *contig, int clen_, int off1_, const uint8_t *rows, int n_, int *res /* 8 ints in LDS: v1, v2 */)
+__device__ __noinline__ void bk_nw_dual_c(int contig_off, int clen_, int off1_, int rows_off, int n_, int res_off /* 8 ints in LDS: v1, v2 */)
 {
+    // sequences and results are addressed as offsets into the dynamic LDS block: plain LDS instructions (a generic pointer
+    // makes every access a FLAT one, whose completion order against s_barrier proved fragile for the result stores)
+    const uint8_t *contig = bk_dyn_lds + contig_off, *rows = bk_dyn_lds + rows_off;
+    int *res = (int *)(bk_dyn_lds + res_off);
     const int clen = __builtin_amdgcn_readfirstlane(clen_), off1 = __builtin_amdgcn_readfirstlane(off1_), n = __builtin_amdgcn_readfirstlane(n_);
     const int lane = threadIdx.x & 63, hl = lane & 31;
     const bool tr = lane >= 32;                                        // half 1: transposed sweep (v2)
@@ -404,13 +409,14 @@ __device__ __noinline__ void bk_nw_dual_c(const uint8_t *contig, int clen_, int 
     }
 }
 template <int C>
-__device__ inline void bk_nw_dual_call(int c, const uint8_t *contig, int clen, int off1, const uint8_t *rows, int n, int *res)
+__device__ inline void bk_nw_dual_call(int c, int contig, int clen, int off1, int rows, int n, int res)
 {
     if (c <= C) { bk_nw_dual_c<C>(contig, clen, off1, rows, n, res); return; }
     if constexpr (C < BK_NW_DUAL_C) bk_nw_dual_call<C + 1>(c, contig, clen, off1, rows, n, res);
 }
-// contig <= BK_NW_DUAL_COLS.  res: 8 ints (LDS or global), written by lane 0: v1 then v2 as (j_start, i_end, i_start, score)
-__device__ inline void bk_nw_dual(const uint8_t *contig, int clen, const uint8_t *read, int n, int *res)
+// contig <= BK_NW_DUAL_COLS.  All three are byte offsets into the dynamic LDS block; res: 8 ints written by lane 0: v1 then
+// v2 as (j_start, i_end, i_start, score)
+__device__ inline void bk_nw_dual(int contig, int clen, int read, int n, int res)
 {
     const int K = n + (n >> 1) + 2, off1 = clen > K ? clen - K : 0;
     bk_nw_dual_call<3>((clen + 31) / 32, contig, clen, off1, read, n, res);

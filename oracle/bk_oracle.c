@@ -725,6 +725,43 @@ static int sw_blocks(const char *q, const char *t, int a0, int a1, int b0, int b
 }
 static int cmp_hit_fq(const void *x, const void *y) { return ((const swhit *)x)->fq - ((const swhit *)y)->fq; }
 
+/* ---- R2 step 4: island fill (bk_oracle.h).  A flank shorter than min_score between two differences cannot anchor a
+ * segment of its own; it is recovered here, next to the anchors it belongs to: inside the unaligned rectangle between two
+ * chained blocks (or beyond the first / last block) the best gap-free segment on a diagonal within FILL_BAND of a
+ * neighbouring block's diagonal becomes a block if it scores >= FILL_MIN; the two rectangles it leaves are filled the
+ * same way.  Ties: higher score, then smaller query end, then smaller target end. */
+#define FILL_BAND 16
+#define FILL_MIN 8
+typedef struct { int qs, qe, ts, te, score; } fblk;
+static int fill_best(const char *q, const char *t, int qa, int qb, int ta, int tb, int use1, int d1, int use2, int d2, fblk *out)
+{
+    int best = 0; out->score = 0;
+    int dlo = use1 ? d1 - FILL_BAND : d2 - FILL_BAND, dhi = use1 ? d1 + FILL_BAND : d2 + FILL_BAND;
+    if (use2) { if (d2 - FILL_BAND < dlo) dlo = d2 - FILL_BAND; if (d2 + FILL_BAND > dhi) dhi = d2 + FILL_BAND; }
+    for (int d = dlo; d <= dhi; d++) {
+        int in1 = use1 && d >= d1 - FILL_BAND && d <= d1 + FILL_BAND, in2 = use2 && d >= d2 - FILL_BAND && d <= d2 + FILL_BAND;
+        if (!in1 && !in2) continue;
+        int a0 = qa > ta - d ? qa : ta - d, a1 = qb < tb - d ? qb : tb - d, h = 0, run = 0;
+        for (int a = a0; a < a1; a++) {
+            h += q[a] == t[a + d] ? 1 : -2; run++;
+            if (h <= 0) { h = 0; run = 0; continue; }
+            int qe = a + 1, te = a + 1 + d;
+            if (h > best || (h == best && (qe < out->qe || (qe == out->qe && te < out->te)))) { best = h; out->qs = qe - run; out->qe = qe; out->ts = te - run; out->te = te; out->score = h; }
+        }
+    }
+    return best;
+}
+static void fill_gap(const char *q, const char *t, const fblk *L, const fblk *R, int qlo, int qhi, int tlo, int thi, fblk *v, int *n, int cap)
+{
+    if (qhi - qlo < FILL_MIN || thi - tlo < FILL_MIN || *n >= cap) return;
+    fblk nb;
+    int sc = fill_best(q, t, qlo, qhi, tlo, thi, L != NULL, L ? L->te - L->qe : 0, R != NULL, R ? R->ts - R->qs : 0, &nb);
+    if (sc < FILL_MIN) return;
+    fill_gap(q, t, L, &nb, qlo, nb.qs, tlo, nb.ts, v, n, cap);
+    if (*n < cap) v[(*n)++] = nb;
+    fill_gap(q, t, &nb, R, nb.qe, qhi, nb.te, thi, v, n, cap);
+}
+
 int bko_realign(const char *contig, int Q, const char *const *targets, const int *tlens, int ntargets,
                 int min_score, int min_seg, bko_psl *out, int cap)
 {
@@ -783,16 +820,28 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
             r->t_start = f->ts; r->t_end = l->te;
             const int sq = f->qs, eq = l->qe;                            /* strand coordinates */
             r->q_start = f->strand == 0 ? sq : Q - eq; r->q_end = f->strand == 0 ? eq : Q - sq;
+            /* anchors in strand order, islands between them and beyond the ends filled (step 4) */
+            fblk blocks[BKO_MAX_BLOCKS * 2]; int nbk = 0; const int bcap = BKO_MAX_BLOCKS;
+            fblk anch[2 * SW_MAXHITS + 1]; int na = 0;
+            for (int c = head; c < tail; c++) { anch[na].qs = chain[c].qs; anch[na].qe = chain[c].qe; anch[na].ts = chain[c].ts; anch[na].te = chain[c].te; anch[na].score = chain[c].score; na++; }
+            { const int gq = anch[0].qs; int tlo = anch[0].ts - gq - FILL_BAND; if (tlo < 0) tlo = 0;
+              fill_gap(qstr, tstr, NULL, &anch[0], 0, anch[0].qs, tlo, anch[0].ts, blocks, &nbk, bcap); }
+            for (int c = 0; c < na; c++) {
+                if (nbk < bcap) blocks[nbk++] = anch[c];
+                if (c + 1 < na) fill_gap(qstr, tstr, &anch[c], &anch[c + 1], anch[c].qe, anch[c + 1].qs, anch[c].te, anch[c + 1].ts, blocks, &nbk, bcap);
+            }
+            { const int gq = Q - anch[na - 1].qe; int thi = anch[na - 1].te + gq + FILL_BAND; if (thi > tlens[f->tidx]) thi = tlens[f->tidx];
+              fill_gap(qstr, tstr, &anch[na - 1], NULL, anch[na - 1].qe, Q, anch[na - 1].te, thi, blocks, &nbk, bcap); }
+            r->t_start = blocks[0].ts; r->t_end = blocks[nbk - 1].te;
+            { const int sq2 = blocks[0].qs, eq2 = blocks[nbk - 1].qe; r->q_start = f->strand == 0 ? sq2 : Q - eq2; r->q_end = f->strand == 0 ? eq2 : Q - sq2; }
             int nb = 0, pq = -1, pt = -1;
-            for (int c = head; c < tail; c++) {
-                r->score += chain[c].score;
-                for (int b = 0; b < chain[c].nb && nb < BKO_MAX_BLOCKS; b++) {
-                    int bs = chain[c].bs[b], bq = chain[c].bq[b], bt = chain[c].bt[b];
-                    for (int z = 0; z < bs; z++) { if (qstr[bq + z] == tstr[bt + z]) r->matches++; else r->mismatches++; }
-                    if (pq >= 0) { if (bq > pq) { r->q_num_insert++; r->q_base_insert += bq - pq; } if (bt > pt) { r->t_num_insert++; r->t_base_insert += bt - pt; } }
-                    r->block_sizes[nb] = bs; r->q_starts[nb] = bq; r->t_starts[nb] = bt; nb++;
-                    pq = bq + bs; pt = bt + bs;
-                }
+            for (int c = 0; c < nbk; c++) {
+                r->score += blocks[c].score;
+                const int bs = blocks[c].qe - blocks[c].qs, bq = blocks[c].qs, bt = blocks[c].ts;
+                for (int z = 0; z < bs; z++) { if (qstr[bq + z] == tstr[bt + z]) r->matches++; else r->mismatches++; }
+                if (pq >= 0) { if (bq > pq) { r->q_num_insert++; r->q_base_insert += bq - pq; } if (bt > pt) { r->t_num_insert++; r->t_base_insert += bt - pt; } }
+                r->block_sizes[nb] = bs; r->q_starts[nb] = bq; r->t_starts[nb] = bt; nb++;
+                pq = bq + bs; pt = bt + bs;
             }
             r->block_count = nb;
         }

@@ -73,7 +73,13 @@ void bko_asm_free(bko_asm *a);
  *   2. every hit is one ungapped block (as BLAT's blocks are); gaps arise only from chaining;
  *   3. hits ordered by query position are chained into one PSL record when they are on the same
  *      target and strand and collinear (a target overlap smaller than half of either hit is trimmed
- *      from the later hit).
+ *      from the later hit);
+ *   4. island fill: the unaligned rectangle between two chained blocks (query AND target bases left over: an indel next
+ *      to another difference, whose short flank cannot anchor a segment of its own) and the rectangles beyond the first
+ *      and the last block are searched for the best gap-free segment on a diagonal within 16 of a neighbouring block's
+ *      diagonal; it becomes a block of the record if it scores >= 8, and the two rectangles it leaves are filled the
+ *      same way (ties: higher score, smaller query end, smaller target end).  tests/golden/realign_evidence.json holds
+ *      what the reference's caller makes of these records next to BLAT-style records built from the known edits.
  * Output: PSL-equivalent records (fields consumed by sv_caller.py:911-936). */
 #define BKO_MAX_BLOCKS 16
 typedef struct bko_psl {

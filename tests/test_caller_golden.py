@@ -89,3 +89,38 @@ def test_g5_native_call_tail(golden_dir):
         assert hit == c["target_hit"], c["tag"]
         called += got is not None
     assert called >= 15
+
+
+def test_g8_realign_contract_evidence(golden_dir):
+    """R2 (BLAT parity unpinned): contigs with small indels / mismatch clusters next to the SV junction.  The fixture holds
+    (A) the records of this build's realign contract and (B) BLAT-style records built from the known edit script, each with
+    the row the REAL reference's caller made of them.  Checked here: the oracle still produces (A); the Python and the
+    native call tail reproduce the reference's rows for both; and (A) gives the same call as (B) in every case but the one
+    whose inserted bases can be placed one position either way (same breakpoints, CIGAR differs)."""
+    from breakmer_amd import call_context as cc, hip_backend as hb
+    from oracle import bk_oracle as bo
+    from breakmer_amd import synth
+    with open(os.path.join(golden_dir, "realign_evidence.json")) as f:
+        d = json.load(f)
+    r = synth.make_region(**d["region"])
+    same = 0
+    for c in d["cases"]:
+        assert bo.realign(c["contig"]["seq"], [r.window_str]) == c["gapfree_chain"]["records"], c["tag"]
+        for label in ("gapfree_chain", "blat_style"):
+            genome = c.get(label + "_genome_rows", False)
+            case = {"query_region": d["query_region"], "contig": c["contig"], "read_ids": c["read_ids"], "disc_reads": d["disc_reads"],
+                    "opts": d["opts"], "genes": d["genes"], "all_repeat_mask": None, "target_repeat_mask": None, "psl_rows": c[label]["psl_rows"],
+                    "contig_id": "contig1", "offset": None if genome else d["offset"], "tname": None if genome else d["tname"]}
+            got, _hit = run_case(case)
+            assert got == c[label]["expected"], (c["tag"], label)
+            qr = d["query_region"]
+            query_region = (qr[0], qr[1], qr[2], qr[3], [tuple(x) for x in qr[4]])
+            cd = c["contig"]
+            lines = [cc.opts_line(d["opts"])] + cc.tables_lines(d["genes"], None) + cc.region_lines(0, query_region, None, d["disc_reads"])
+            lines += cc.contig_lines("contig1", cd["seq"], cd["indel_only"], cd["others"], cd["kmer_locs"], len(cd["kmers"]),
+                                     len(set(i.split("/")[1] for i in c["read_ids"])) == 1, c[label]["psl_rows"], case["offset"], case["tname"])
+            assert hb.call_text("\n".join(lines) + "\n")[0] == c[label]["expected"], (c["tag"], label, "native")
+        a, b = c["gapfree_chain"]["expected"], c["blat_style"]["expected"]
+        assert a is not None and b is not None and a[1] == b[1] and a[6] == b[6] == "indel", c["tag"]       # same breakpoints, same call
+        same += a == b
+    assert same >= len(d["cases"]) - 1

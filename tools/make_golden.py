@@ -523,10 +523,106 @@ def g7():
     shutil.rmtree(base, ignore_errors=True)
 
 
+def g8():
+    """G8 (R2 evidence, SURVEY 8c "BLAT parity unpinned"): what the REAL reference's caller reports when a contig carries
+    small indels / clustered mismatches close to the SV junction, from (A) the records of this build's realign contract
+    (iterated gap-free segments with score >= 20, chained: a flank shorter than 20 bases between two differences cannot
+    anchor and is lost) and from (B) BLAT-style records built from the known edit script (every indel splits a block,
+    mismatches stay inside blocks, the alignment runs to the contig ends).  Both row sets come from the reference's
+    align_manager; the fixture records them side by side with the fields that differ."""
+    import copy
+    from oracle import bk_oracle as bo
+    from breakmer_amd import sv_caller as my
+    r = synth.make_region(3, sv_type="del", depth=60, W=1500)
+    reads = r.read_strs()
+    mers = rh.ref_kmer_select(reads, [r.window_str], 31)
+    cdicts, cobjs = rh.ref_init_assembly(r.read_ids, reads, mers, 31, 2, r.indel_only)
+    base_seq = cdicts[0]["seq"]
+    W = r.window_str
+    J = W.find(base_seq[:60]) + 0                       # window position of contig base 0
+    # contig = W[J : c-100] + W[c+100 : ...]: junction after `jq` contig bases
+    c = len(W) // 2
+    jq = (c - 100) - J
+    assert base_seq == W[J:c - 100] + W[c + 100:c + 100 + len(base_seq) - jq], "unexpected contig layout"
+    qr = (r.chrom, r.start, r.end, r.name, [(r.chrom, r.start, r.end, r.name, 'exon')])
+    genes = {r.name: ['chr' + r.chrom, r.start, r.end]}
+    o = dict(rh.DEFAULT_OPTS)
+    comp = {"A": "C", "C": "G", "G": "T", "T": "A"}
+
+    def variant(tag, edits):
+        """edits: list of (contig position, kind, arg) applied right to left on the contig; kinds: 'sub' (arg = count of
+        consecutive substitutions every 4th base), 'del' (arg = bases removed from the contig = bases present only in the
+        window), 'ins' (arg = string inserted into the contig)."""
+        co = copy.deepcopy(cobjs[0])
+        seq = list(base_seq)
+        io, ot, kl = list(co.aseq.counts.indel_only), list(co.aseq.counts.others), list(co.kmer_locs)
+        # truth alignment as (contig index -> window index) built while editing: start from the plain deletion contig
+        wpos = [J + i if i < jq else (c + 100) + (i - jq) for i in range(len(seq))]
+        for pos, kind, arg in sorted(edits, key=lambda e: -e[0]):
+            if kind == 'sub':
+                for t in range(arg):
+                    q = pos + 4 * t
+                    seq[q] = comp[seq[q]]
+            elif kind == 'del':
+                del seq[pos:pos + arg]; del io[pos:pos + arg]; del ot[pos:pos + arg]; del kl[pos:pos + arg]; del wpos[pos:pos + arg]
+            else:
+                seq[pos:pos] = list(arg); io[pos:pos] = [io[pos]] * len(arg); ot[pos:pos] = [ot[pos]] * len(arg)
+                kl[pos:pos] = [kl[pos]] * len(arg); wpos[pos:pos] = [None] * len(arg)
+        cs = "".join(seq)
+        co.aseq.seq = cs
+        co.aseq.counts.indel_only, co.aseq.counts.others, co.kmer_locs = io, ot, kl
+        # (B) BLAT-style record from the truth: maximal runs of consecutive (contig, window) pairs on one diagonal
+        blocks = []
+        i = 0
+        while i < len(cs):
+            if wpos[i] is None:
+                i += 1
+                continue
+            j = i
+            while j + 1 < len(cs) and wpos[j + 1] is not None and wpos[j + 1] == wpos[j] + 1:
+                j += 1
+            blocks.append((i, wpos[i], j - i + 1))
+            i = j + 1
+        mism = sum(1 for (q0, t0, ln) in blocks for z in range(ln) if cs[q0 + z] != W[t0 + z])
+        match = sum(ln for _q, _t, ln in blocks) - mism
+        qni = sum(1 for a, b in zip(blocks, blocks[1:]) if b[0] > a[0] + a[2]); qbi = sum(b[0] - a[0] - a[2] for a, b in zip(blocks, blocks[1:]))
+        tni = sum(1 for a, b in zip(blocks, blocks[1:]) if b[1] > a[1] + a[2]); tbi = sum(b[1] - a[1] - a[2] for a, b in zip(blocks, blocks[1:]))
+        rec = {"matches": match, "mismatches": mism, "rep_matches": 0, "n_count": 0, "q_num_insert": qni, "q_base_insert": qbi, "t_num_insert": tni,
+               "t_base_insert": tbi, "strand": "+", "q_size": len(cs), "q_start": blocks[0][0], "q_end": blocks[-1][0] + blocks[-1][2], "t_index": 0,
+               "t_size": len(W), "t_start": blocks[0][1], "t_end": blocks[-1][1] + blocks[-1][2], "block_sizes": [b[2] for b in blocks],
+               "q_starts": [b[0] for b in blocks], "t_starts": [b[1] for b in blocks], "score": match - 2 * mism}
+        out = {"tag": tag, "contig": {"seq": cs, "indel_only": io, "others": ot, "kmer_locs": kl, "kmers": cdicts[0]["kmers"], "reads": cdicts[0]["reads"]},
+               "read_ids": sorted(x.id for x in co.reads), "edits": [list(e) for e in edits]}
+        for label, recs in (("gapfree_chain", bo.realign(cs, [W])), ("blat_style", [rec])):
+            rows = [my.psl_fields(x, 'contig1', r.name, 0) for x in recs if x['t_index'] == 0]
+            res, am = rh.ref_call(rows, co, 'contig1', qr, o, genes, r.disc_reads, None, None, r.start - 200, r.chrom)
+            if res is None and not am.bm.target_hit():          # Q14: the reference would go to the whole genome: genome-coordinate rows
+                rows = [my.psl_fields(x, 'contig1', 'chr' + r.chrom, r.start - 200) for x in recs]
+                res, am = rh.ref_call(rows, co, 'contig1', qr, o, genes, r.disc_reads, None, None, None, None)
+                out[label + "_genome_rows"] = True
+            out[label] = {"records": recs, "psl_rows": rows, "expected": res}
+        a, b_ = out["gapfree_chain"]["expected"], out["blat_style"]["expected"]
+        out["same_row"] = a == b_
+        out["differing_fields"] = None if (a is None or b_ is None) else [i for i in range(13) if a[i] != b_[i]]
+        print("  %-30s same=%s diff=%s\n      A %s\n      B %s" % (tag, out["same_row"], out["differing_fields"], a and a[:7], b_ and b_[:7]))
+        return out
+
+    cases = [variant("plain_deletion", []),
+             variant("del2_10bp_left_of_junction", [(jq - 10, 'del', 2)]),
+             variant("ins3_12bp_right_of_junction", [(jq + 12, 'ins', "GAT")]),
+             variant("mismatch_cluster_at_junction", [(jq + 3, 'sub', 3)]),
+             variant("del1_25bp_from_contig_end", [(len(base_seq) - 25, 'del', 1)]),
+             variant("ins5_and_mismatches_both_sides", [(jq - 14, 'ins', "ACGTA"), (jq + 8, 'sub', 2)]),
+             variant("del4_30bp_left_of_junction", [(jq - 30, 'del', 4)])]
+    dump("realign_evidence.json", {"cases": cases, "region": {"region_id": 3, "sv_type": "del", "depth": 60, "W": 1500}, "opts": o, "genes": genes,
+                                   "query_region": [qr[0], qr[1], qr[2], qr[3], [list(x) for x in qr[4]]],
+                                   "disc_reads": {"disc": {}, "inv": [], "td": [], "other": []}, "offset": r.start - 200, "tname": r.chrom})
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         print(w)
         globals()[w]()
