@@ -97,6 +97,20 @@ class anno(object):                                                 # utils.py:7
                 if name not in self.genes:
                     self.genes[name] = [chrom, int(start), int(end)]
 
+    def set_gene(self, chrom, pos):                                  # utils.py:756-773 (table order = insertion order, P4)
+        found = []
+        if str(chrom).find('chr') == -1:
+            chrom = 'chr' + str(chrom)
+        for g, (gchrom, gs, ge) in self.genes.items():
+            if chrom == gchrom:
+                if len(pos) == 1:
+                    if gs <= int(pos[0]) <= ge:
+                        found.append(g)
+                        break
+                elif gs <= int(pos[0]) <= ge or gs <= int(pos[1]) <= ge:
+                    found.append(g)
+        return ",".join(found) if found else 'intergenic'
+
 
 class params(object):                                               # utils.py:535-674
     DEFAULTS = {'indel_size': 15, 'trl_sr_thresh': 2, 'indel_sr_thresh': 5, 'rearr_sr_thresh': 3, 'rearr_minseg_len': 30,
@@ -178,6 +192,31 @@ def setup_rmask_all(fn):                                            # utils.py:3
             c = p[0].replace('chr', '')
             mask.setdefault(c, []).append((c, int(p[1]), int(p[2]), p[3]))
     return mask
+
+
+def setup_rmask(gene_coords, ref_path, all_mask):                   # utils.py:320-353
+    """Repeats of one target: entries of ITS chromosome -- compared as the reference compares, the mask's name with 'chr'
+    stripped against the target's chromosome AS GIVEN (a BED with 'chr1' therefore matches nothing) -- that lie inside
+    [start, end]; written to <ref_path>/<name>_rep_mask.bed the first time, read back from it afterwards (marker file)."""
+    chrom, s, e, name = gene_coords[:4]
+    fn = os.path.join(ref_path, name + '_rep_mask.bed') if ref_path else None
+    marker = os.path.join(ref_path, "." + name + '_rep_mask.bed') if ref_path else None
+    if marker and os.path.isfile(marker):
+        out = []
+        with open(fn) as f:
+            for ln in f:
+                p = ln.strip().split()
+                if len(p) >= 4:
+                    out.append((p[0], int(p[1]), int(p[2]), p[3]))
+        return out
+    out = [m for m in all_mask.get(chrom, []) if m[1] >= int(s) and m[2] <= int(e)]
+    if fn:
+        os.makedirs(ref_path, exist_ok=True)
+        with open(fn, 'w') as f:
+            for m in out:
+                f.write("\t".join(str(x) for x in m) + "\n")
+        open(marker, 'w').close()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ contig
@@ -310,9 +349,8 @@ class target(object):                                               # sv_process
             self._window = self.data.window
         else:
             raise RuntimeError("target %s: no reference window (expected %s)" % (self.name, self.files.get('target_ref_fn')))
-        if self.params.repeat_mask is not None:
-            c = str(self.chrom).replace('chr', '')
-            self.repeat_mask = [m for m in self.params.repeat_mask.get(c, []) if m[1] >= self.start and m[2] <= self.end]      # utils.py:334-339
+        if self.params.repeat_mask is not None:                     # sv_processor.py:353-355 -> utils.setup_rmask
+            self.repeat_mask = setup_rmask(self.get_values(), self.paths.get('ref_data'), self.params.repeat_mask)
 
     def extract_bam_reads(self):                                     # :422-540
         bam_fn = self.params.opts.get('sample_bam_file')

@@ -164,3 +164,29 @@ def test_reads_with_n_are_kept(tmp_path):
     rows = sp.runner(cfg, engine_factory=lambda prm: Spy(prm.get_kmer_size(), prm.get_sr_thresh('min'))).run()
     assert n == 12 and len(rows) >= 1 and rows[0][1].endswith("(D120)")
     assert seen["n"] >= 8 and seen["other"] == 0
+
+
+def test_g9_annotation_and_repeat_mask_loaders(tmp_path, golden_dir):
+    """N3: gene table / extra regions / repeat-mask loaders == what the REAL reference's loaders produced from the same
+    files (tests/golden/loaders.json), incl. the widest-record rule for repeated gene ids, set_gene, the per-target mask
+    with its chromosome-name quirk (a target given as 'chr1' matches no repeat), the bed file it writes and its read-back."""
+    g = json.load(open(os.path.join(golden_dir, "loaders.json")))
+    (tmp_path / "genes.txt").write_text(g["gene_table"])
+    (tmp_path / "other.bed").write_text(g["regions_bed"])
+    (tmp_path / "rmask.bed").write_text(g["repeat_mask_bed"])
+    an = sp.anno()
+    an.add_genes(str(tmp_path / "genes.txt"))
+    assert {k: list(v) for k, v in an.genes.items()} == g["genes_after_add_genes"]
+    an.add_regions(str(tmp_path / "other.bed"))
+    assert {k: list(v) for k, v in an.genes.items()} == g["genes_after_add_regions"] and list(an.genes) == g["gene_order"]
+    for chrom, pos, want in g["set_gene"]:
+        assert an.set_gene(chrom, pos) == want, (chrom, pos)
+    allm = sp.setup_rmask_all(str(tmp_path / "rmask.bed"))
+    assert {k: [list(x) for x in v] for k, v in allm.items()} == g["rmask_all"]
+    for t in g["rmask_targets"]:
+        chrom, s, e, name = t["coords"]
+        ref = tmp_path / ("ref_" + name)
+        first = sp.setup_rmask((chrom, s, e, name, []), str(ref), allm)
+        assert [list(x) for x in first] == t["first"], name
+        assert (ref / (name + "_rep_mask.bed")).read_text() == t["bed"], name
+        assert [list(x) for x in sp.setup_rmask((chrom, s, e, name, []), str(ref), allm)] == t["second"], name

@@ -619,10 +619,60 @@ def g8():
                                    "disc_reads": {"disc": {}, "inv": [], "td": [], "other": []}, "offset": r.start - 200, "tname": r.chrom})
 
 
+def g9():
+    """G9 (N3): the file loaders in front of the caller's filters, executed by the REAL reference on synthetic files --
+    utils.anno.add_genes / add_regions / set_gene (utils.py:727-773), setup_rmask_all (:302-316) and setup_rmask (:320-353,
+    first call: filter + write <name>_rep_mask.bed; second call: read that file back)."""
+    import shutil
+    import tempfile
+    ut = ref_loader.load()["utils"]
+    rnd = random.Random(9)
+    base = tempfile.mkdtemp()
+    # refGene-like table: header line, columns 2 = chrom, 4 = txStart, 5 = txEnd, 12 = name2; repeated gene ids (the widest wins)
+    genes = [("GENEA", "chr1", 1000, 9000), ("GENEA", "chr1", 500, 9500), ("GENEA", "chr1", 2000, 3000), ("GENEB", "chr1", 20000, 30000),
+             ("GENEB", "chr1", 21000, 35000), ("GENEC", "chr2", 100, 900), ("GENED", "chrX", 5000, 6000), ("GENEA2", "chr1", 8000, 12000)]
+    lines = ["#bin\tname\tchrom\tstrand\ttxStart\ttxEnd\tc6\tc7\tc8\tc9\tc10\tc11\tname2"]
+    for n, (g, c, s_, e) in enumerate(genes):
+        lines.append("\t".join(["0", "NM_%d" % n, c, "+" if n % 2 else "-", str(s_), str(e)] + ["x"] * 6 + [g]))
+    gene_fn = os.path.join(base, "genes.txt")
+    open(gene_fn, "w").write("\n".join(lines) + "\n")
+    regions = [("chr3", 100, 2000, "REGION1"), ("chr1", 40000, 41000, "GENEB"), ("chr4", 7, 9, "REGION2")]
+    reg_fn = os.path.join(base, "other.bed")
+    open(reg_fn, "w").write("".join("%s %d %d %s\n" % r_ for r_ in regions))
+    an = ut.anno()
+    an.add_genes(gene_fn)
+    after_genes = {k: list(v) for k, v in an.genes.items()}
+    an.add_regions(reg_fn)
+    queries = [("1", [2500]), ("chr1", [8500]), ("1", [8500, 25000]), ("1", [15000]), ("2", [100]), ("2", [901]), ("X", [5500, 5600]), ("3", [150]), ("7", [5])]
+    set_gene = [[c, pos, an.set_gene(c, pos)] for c, pos in queries]
+    # repeat mask: chrom (with chr), start, end, name, extra columns
+    rm = []
+    for n in range(60):
+        c = rnd.choice(["chr1", "chr1", "chr2", "chrX"])
+        s_ = rnd.randint(0, 40000)
+        rm.append((c, s_, s_ + rnd.randint(5, 400), rnd.choice(["AluY", "(CA)n", "L1PA3", "GA_rich", "MIR"]), rnd.randint(0, 999)))
+    rm_fn = os.path.join(base, "rmask.bed")
+    open(rm_fn, "w").write("".join("%s\t%d\t%d\t%s\t%d\n" % r_ for r_ in rm))
+    all_mask = ut.setup_rmask_all(rm_fn)
+    per_target = []
+    for chrom, s_, e, name in (("1", 1000, 20000, "GENEA"), ("chr1", 1000, 20000, "GENEA_CHR"), ("2", 0, 50000, "GENEC"), ("9", 0, 100, "NONE")):
+        ref_path = os.path.join(base, "ref_" + name)
+        os.makedirs(ref_path)
+        coords = (chrom, s_, e, name, [(chrom, s_, e, name, "exon")])
+        first = ut.setup_rmask(coords, ref_path, rm_fn)
+        bed = open(os.path.join(ref_path, name + "_rep_mask.bed")).read()
+        second = ut.setup_rmask(coords, ref_path, rm_fn)             # marker file present: reads the bed back
+        per_target.append({"coords": [chrom, s_, e, name], "first": [list(x) for x in first], "bed": bed, "second": [list(x) for x in second]})
+    dump("loaders.json", {"gene_table": open(gene_fn).read(), "regions_bed": open(reg_fn).read(), "genes_after_add_genes": after_genes,
+                          "genes_after_add_regions": {k: list(v) for k, v in an.genes.items()}, "gene_order": list(an.genes.keys()), "set_gene": set_gene,
+                          "repeat_mask_bed": open(rm_fn).read(), "rmask_all": {k: [list(x) for x in v] for k, v in all_mask.items()}, "rmask_targets": per_target})
+    shutil.rmtree(base, ignore_errors=True)
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         print(w)
         globals()[w]()
