@@ -148,6 +148,29 @@ def usable_cores():
     return n
 
 
+def time_runner(synth, regions, kmer):
+    """the retained driver surface end to end (breakmer_amd.sv_processor.runner.run: per-target objects, batches on two handles,
+    submit = host 2-bit packing + H2D included, native call tail, rows in target order), code-matrix inputs, no output files"""
+    import tempfile
+    from breakmer_amd import sv_processor as sp
+    d = tempfile.mkdtemp()
+    bed, genes, data = [], ["header"], {}
+    for r in regions:
+        bed.append("\t".join([r.chrom, str(r.start), str(r.end), r.name, "exon"]))
+        genes.append("\t".join(["0", r.name, "chr" + r.chrom, "+", str(r.start), str(r.end)] + ["x"] * 6 + [r.name]))
+        data[r.name.upper()] = sp.RegionData(r.read_ids, None, None, None, r.window_str, [], r.disc_reads, read_codes=r.reads, read_lens=r.read_lens)
+    open(os.path.join(d, "targets.bed"), "w").write("\n".join(bed) + "\n")
+    open(os.path.join(d, "genes.txt"), "w").write("\n".join(genes) + "\n")
+    cfg = {"analysis_name": "bench", "targets_bed_file": os.path.join(d, "targets.bed"), "gene_annotation_file": os.path.join(d, "genes.txt"),
+           "kmer_size": str(kmer), "keep_repeat_regions": True, "batch_regions": 256}
+    t0 = time.perf_counter()
+    rows = sp.runner(cfg, region_data=data).run()
+    dt = time.perf_counter() - t0
+    return {"value": round(len(regions) / dt, 1), "unit": "regions/s", "regions": len(regions), "rows": len(rows), "seconds": round(dt, 3),
+            "note": "runner.run() wall time: host packing + H2D + GPU stages + native call tail + per-target Python objects (no output files); "
+                    "the timed `value` above excludes submit (inputs resident, SURVEY 8d)"}
+
+
 def _cpu_region(args):
     """one region through the C oracle (worker of the all-core CPU baseline); returns the number of contigs"""
     rid, depth, read_len, kmer = args
@@ -391,6 +414,11 @@ def main():
             "submit_note": "bk_submit_regions of one %d-region batch (host 2-bit packing + H2D), outside the timed region" % n_regions,
             "one_step_at_a_time": serial,
         }
+        if world == 1 and a.other_configs:
+            try:
+                out["runner_end_to_end"] = time_runner(synth, regions + [synth.make_region(n_regions + i, depth=a.depth, L=a.read_len, sv_type="del") for i in range(n_regions)], a.kmer)
+            except Exception as ex:
+                out["runner_end_to_end"] = {"error": repr(ex)}
         # ---- other BASELINE configs on one GPU (not the headline; whole path incl. call tail, inputs resident) -----
         if world == 1 and a.other_configs:
             oc = {}

@@ -33,9 +33,13 @@ class RegionData(object):
     reads (FASTQ order: id, seq, qual, indel_only), soft-clip sequences (None => case_sc := case),
     the forward window, extra windows with genome coordinates, discordant-pair evidence."""
 
-    def __init__(self, read_ids, read_seqs, indel_only=None, sc_seqs=None, window="", partners=(), disc_reads=None, quals=None):
-        self.read_ids = list(read_ids)
-        self.read_seqs = list(read_seqs)
+    def __init__(self, read_ids, read_seqs, indel_only=None, sc_seqs=None, window="", partners=(), disc_reads=None, quals=None,
+                 read_codes=None, read_lens=None):
+        # read_codes / read_lens: optional uint8 code matrix [N, L] (0..3 = ACGT, 4 = N) + lengths of the same reads: handed to
+        # the library as is (no per-read Python work); read_seqs may then be a lazy sequence of the strings
+        self.read_codes, self.read_lens = read_codes, read_lens
+        self.read_ids = read_ids if read_codes is not None else list(read_ids)
+        self.read_seqs = read_seqs if read_codes is not None else list(read_seqs)
         self.indel_only = list(indel_only) if indel_only is not None else [False] * len(self.read_ids)
         self.quals = list(quals) if quals is not None else None
         self.sc_seqs = sc_seqs
@@ -69,6 +73,59 @@ def read_fastq(fn):
             quals.append(q.strip())
             io.append(h.lstrip("@").split("_")[-1] == "1")
     return ids, seqs, quals, io
+
+
+class _LazyReads(object):
+    """fq_read objects (utils.py:681-688) of a code-matrix region, made when asked for (a contig names ~150 of 10,000)"""
+
+    def __init__(self, d):
+        self.d, self.cache = d, {}
+
+    def __len__(self):
+        return len(self.d.read_ids)
+
+    def __getitem__(self, i):
+        r = self.cache.get(i)
+        if r is None:
+            d = self.d
+            n = int(d.read_lens[i])
+            seq = bytes(_CODES[d.read_codes[i, :n]]).decode()
+            r = sv_assembly.fq_read(d.read_ids[i], seq, d.quals[i] if d.quals else "I" * n, bool(d.indel_only[i]))
+            self.cache[i] = r
+        return r
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class _LazyRecs(object):
+    """cleaned_read_recs (dict seq -> [fq_read], utils.py:239-244) of a code-matrix region: built when someone iterates it"""
+
+    def __init__(self, reads):
+        self.reads, self._d = reads, None
+
+    def _build(self):
+        if self._d is None:
+            self._d = OrderedDict()
+            for r in self.reads:
+                self._d.setdefault(r.seq, []).append(r)
+        return self._d
+
+    def __len__(self):
+        return len(self._build())
+
+    def __iter__(self):
+        return iter(self._build())
+
+    def __getitem__(self, k):
+        return self._build()[k]
+
+    def items(self):
+        return self._build().items()
+
+
+import numpy as _np  # noqa: E402
+_CODES = _np.frombuffer(b"ACGTN", dtype=_np.uint8)
 
 
 # ------------------------------------------------------------------------------------------------ params / anno
@@ -337,6 +394,12 @@ class target(object):                                               # sv_process
     def get_values(self): return (self.chrom, self.start, self.end, self.name, self.target_intervals)
     def has_results(self): return len(self.results) > 0
 
+    def release(self):
+        """drop the per-target inputs once its rows are out (the reference discards them too, sv_processor.py:643)"""
+        self.data = None
+        self.reads = []
+        self.engine = None
+
     def rm_output_dir(self):
         if 'output' in self.paths and os.path.isdir(self.paths['output']):
             shutil.rmtree(self.paths['output'])
@@ -390,7 +453,7 @@ class target(object):                                               # sv_process
         # Reads with N calls are kept, as the reference keeps them (utils.py:203-246): the device path carries the N
         # positions next to the 2-bit words.  Any other character (IUPAC codes never occur in the alignment files the
         # reference is run on) cannot be represented: such reads are left out with a warning.
-        bad = [n for n, s_ in enumerate(d.read_seqs) if s_.strip("ACGTN")]
+        bad = [] if d.read_codes is not None else [n for n, s_ in enumerate(d.read_seqs) if s_.strip("ACGTN")]
         if bad:
             self.logger.warning('target %s: %d of %d reads contain characters other than A/C/G/T/N and are skipped' % (self.name, len(bad), len(d.read_seqs)))
             drop = set(bad)
@@ -416,6 +479,13 @@ class target(object):                                               # sv_process
                             cur = []
                     if len(cur) >= k: pieces.append("".join(cur))
             d.sc_seqs = pieces
+        if d.read_codes is not None:
+            # code-matrix input (synthetic / pre-packed reads): nothing per read happens on the host; the fq_read objects the
+            # writers and the caller need are made on demand (_LazyReads), cleaned_read_recs only exists as a count
+            self.reads = _LazyReads(d)
+            self.read_len = int(max(d.read_lens)) if len(d.read_lens) else 0
+            self.cleaned_read_recs = _LazyRecs(self.reads)
+            return len(d.read_ids) > 0
         q = d.quals
         self.reads = [sv_assembly.fq_read(i, s, (q[n] if q else "I" * len(s)), bool(io)) for n, (i, s, io) in enumerate(zip(d.read_ids, d.read_seqs, d.indel_only))]
         recs = OrderedDict()
@@ -513,57 +583,44 @@ class runner(object):                                               # sv_process
             self.targets[n] = target(self.params.targets[n], self.params, self.region_data.get(n))
         return names
 
-    def _make_engine(self):
-        if self.engine_factory:
-            return self.engine_factory(self.params)
+    def _start_batch(self, eng, live):
+        """submit one batch of targets and start the GPU stages (asynchronous where the engine supports it)"""
         from . import hip_backend
-        dev = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0                # one process per GPU
-        return hip_backend.Engine(kmer_size=self.params.get_kmer_size(), rc_thresh=self.params.get_sr_thresh('min'), device=dev)
-
-    def run(self, start_time=None):                                  # :174-209
-        names = self.create_targets()
-        # striped partition over the sorted target names (SURVEY 8e): heavy targets tend to be neighbours (gene families,
-        # translocation partners), stripes spread them; the rows are put back into target order after the collation
-        order = {n: i for i, n in enumerate(names)}
-        mine = [n for i, n in enumerate(names) if i % self.world == self.rank]
-        live = []
-        for n in mine:
-            t = self.targets[n]
-            t.set_ref_data()
-            t.extract_bam_reads()
-            if not t.clean_reads():
-                t.rm_output_dir()
-                continue
-            live.append(t)
-        if live:
-            # batching front-end: every region first, then ONE call into the HIP library
-            from . import hip_backend
-            self.engine = self._make_engine()
-            ins = []
+        ins = []
+        for i, t in enumerate(live):
+            t.region_index, t.engine = i, eng
+            d = t.data
+            reads = d.read_codes if d.read_codes is not None else d.read_seqs
+            ins.append(hip_backend.RegionInput(reads, d.window, read_lens=d.read_lens, indel_only=[1 if x else 0 for x in d.indel_only], sc_seqs=d.sc_seqs,
+                                               partners=[p[4] for p in d.partners]))
+        eng.submit(ins)
+        try:
+            eng.run(hip_backend.BK_STAGE_ALL, sync=False)
+        except TypeError:
+            eng.run(hip_backend.BK_STAGE_ALL)
+        if self.native_calls and hasattr(eng, 'set_call_context'):
+            from . import call_context as cc
+            lines = [cc.opts_line(self.params.opts)] + cc.tables_lines(self.params.gene_annotations.genes, self.params.repeat_mask)
             for i, t in enumerate(live):
-                t.region_index, t.engine = i, self.engine
-                d = t.data
-                ins.append(hip_backend.RegionInput(d.read_seqs, d.window, indel_only=[1 if x else 0 for x in d.indel_only], sc_seqs=d.sc_seqs,
-                                                   partners=[p[4] for p in d.partners]))
-            self.engine.submit(ins)
-            self.engine.run(hip_backend.BK_STAGE_ALL)
-            # a region that hit a device cap fails alone (bk_get_region_status): the target is logged and skipped like a
-            # target without reads (sv_processor.py:190-192); the rank still takes part in the collation below
-            if hasattr(self.engine, 'region_status'):
-                for i, t in enumerate(live):
-                    st, text = self.engine.region_status(i)
-                    if st != 0:
-                        self.logger.error('target %s: not assembled on the device: %s' % (t.name, text))
-                        t.failed = text
-            if self.native_calls and hasattr(self.engine, 'set_call_context'):
-                from . import call_context as cc
-                lines = [cc.opts_line(self.params.opts)] + cc.tables_lines(self.params.gene_annotations.genes, self.params.repeat_mask)
-                for i, t in enumerate(live):
-                    lines += cc.region_lines(i, t.get_values(), t.repeat_mask, t.disc_reads, t.partner_windows, t.data.read_ids)
-                self.engine.set_call_context("\n".join(lines) + "\n")
-                rows = self.engine.call()
-                for i, t in enumerate(live):
-                    t.native_rows = rows.get(i, [])
+                lines += cc.region_lines(i, t.get_values(), t.repeat_mask, t.disc_reads, t.partner_windows, t.data.read_ids)
+            eng.set_call_context("\n".join(lines) + "\n")
+
+    def _finish_batch(self, eng, live, order):
+        """wait for a batch, then the reference's per-target sequence compare_kmers -> resolve_sv -> summary -> files"""
+        if hasattr(eng, 'sync'):
+            eng.sync()
+        # a region that hit a device cap fails alone (bk_get_region_status): the target is logged and skipped like a
+        # target without reads (sv_processor.py:190-192); the rank still takes part in the collation
+        if hasattr(eng, 'region_status'):
+            for i, t in enumerate(live):
+                st, text = eng.region_status(i)
+                if st != 0:
+                    self.logger.error('target %s: not assembled on the device: %s' % (t.name, text))
+                    t.failed = text
+        if self.native_calls and hasattr(eng, 'set_call_context'):
+            rows = eng.call()
+            for i, t in enumerate(live):
+                t.native_rows = rows.get(i, [])
         for t in live:
             if t.failed:
                 t.rm_output_dir()
@@ -577,6 +634,53 @@ class runner(object):                                               # sv_process
                 self.results.extend([order[t.name], r] for r in t.results)
             else:
                 t.rm_output_dir()
+            t.release()
+
+    def _make_engine(self):
+        if self.engine_factory:
+            return self.engine_factory(self.params)
+        from . import hip_backend
+        dev = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0                # one process per GPU
+        return hip_backend.Engine(kmer_size=self.params.get_kmer_size(), rc_thresh=self.params.get_sr_thresh('min'), device=dev)
+
+    def run(self, start_time=None):                                  # :174-209
+        names = self.create_targets()
+        # striped partition over the sorted target names (SURVEY 8e): heavy targets tend to be neighbours (gene families,
+        # translocation partners), stripes spread them; the rows are put back into target order after the collation
+        order = {n: i for i, n in enumerate(names)}
+        mine = [n for i, n in enumerate(names) if i % self.world == self.rank]
+        # Batching front-end: the reference handles one target at a time; here bounded batches of targets go through the HIP
+        # library on alternating handles, so that the host work of batch i+1 (read extraction, 2-bit packing, H2D) overlaps
+        # the kernels of batch i and the results of batch i are picked up while batch i+1 runs.
+        bsz = max(1, int(self.params.opts.get('batch_regions', 256)))
+        nh = 1 if len(mine) <= bsz else 2
+        engines = [None] * nh
+        in_flight = [None] * nh                                     # per handle: the targets of the batch it is running
+        for b0 in range(0, len(mine), bsz):
+            slot = (b0 // bsz) % nh
+            if in_flight[slot] is not None:
+                self._finish_batch(engines[slot], in_flight[slot], order)
+                in_flight[slot] = None
+            live = []
+            for n in mine[b0:b0 + bsz]:
+                t = self.targets[n]
+                t.set_ref_data()
+                t.extract_bam_reads()
+                if not t.clean_reads():
+                    t.rm_output_dir()
+                    continue
+                live.append(t)
+            if not live:
+                continue
+            if engines[slot] is None:
+                engines[slot] = self._make_engine()
+            self.engine = engines[slot]
+            self._start_batch(engines[slot], live)
+            in_flight[slot] = live
+        rest = [(b, s_) for s_, b in enumerate(in_flight) if b is not None]
+        rest.sort(key=lambda x: order[x[0][0].name])
+        for live, slot in rest:
+            self._finish_batch(engines[slot], live, order)
         if self.collate is not None and self.world > 1:               # collate per-region rows over ranks (RCCL all-gather)
             self.results, self.summary = self.collate(self.results, self.summary)
         self.results.sort(key=lambda x: x[0])                         # stable: target order (sv_processor.py:175-176), rows of a target as produced

@@ -190,3 +190,34 @@ def test_g9_annotation_and_repeat_mask_loaders(tmp_path, golden_dir):
         assert [list(x) for x in first] == t["first"], name
         assert (ref / (name + "_rep_mask.bed")).read_text() == t["bed"], name
         assert [list(x) for x in sp.setup_rmask((chrom, s, e, name, []), str(ref), allm)] == t["second"], name
+
+
+def test_runner_batches_and_code_matrix_inputs(tmp_path):
+    """runner.run in bounded batches on alternating handles (batch_regions) and with code-matrix inputs (no per-read host
+    work, read objects made on demand) gives the rows and files of the one-batch string path."""
+    ids = [(3, "del"), (5, "ins"), (7, "inv"), (9, "del"), (11, "dup"), (13, "del"), (15, "ins")]
+    one = tmp_path / "one"
+    one.mkdir()
+    cfg, data = make_inputs(one, ids)
+    fac = lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min'))
+    want = sp.runner(cfg, region_data=data, engine_factory=fac).run()
+    assert len(want) >= 4
+    for tag, bsz, codes in (("b2", 2, False), ("b3c", 3, True)):
+        d = tmp_path / tag
+        d.mkdir()
+        cfg2, data2 = make_inputs(d, ids)
+        cfg2["batch_regions"] = bsz
+        if codes:
+            for (rid, sv), key in zip(ids, list(data2)):
+                pass
+            for rid, sv in ids:
+                r = synth.make_region(rid, sv_type=sv, depth=60, W=1500)
+                data2[r.name.upper()] = sp.RegionData(r.read_ids, None, r.indel_only.tolist(), None, r.window_str,
+                                                      [(p[0], p[1], p[2], p[3], synth.codes_to_str(p[4])) for p in r.partners], r.disc_reads,
+                                                      read_codes=r.reads, read_lens=r.read_lens)
+        run = sp.runner(cfg2, region_data=data2, engine_factory=fac)
+        assert run.run() == want, tag
+        a = (one / "analysis" / "output" / "synth_indel_svs.out").read_text()
+        assert (d / "analysis" / "output" / "synth_indel_svs.out").read_text() == a, tag
+        fq1 = sorted((one / "analysis" / "targets" / "GENE00003" / "contigs" / "contig1" / "contig1.fq").read_text().split("\n"))
+        assert sorted((d / "analysis" / "targets" / "GENE00003" / "contigs" / "contig1" / "contig1.fq").read_text().split("\n")) == fq1, tag
