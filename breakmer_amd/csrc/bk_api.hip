@@ -126,9 +126,11 @@ extern "C" int bk_destroy(bk_handle *h)
 // branch and the flag bits of the whole word are tested once.
 struct BkPackLut { uint8_t v[256]; BkPackLut() { for (int i = 0; i < 256; i++) v[i] = 8; v[(int)'A'] = 0; v[(int)'C'] = 1; v[(int)'G'] = 2; v[(int)'T'] = 3; v[(int)'N'] = 4; } };
 static const BkPackLut g_pack_lut;
-static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vector<uint32_t> *nlist = nullptr, uint32_t tag = 0)
+struct BkCodeLut { uint8_t v[256]; BkCodeLut() { for (int i = 0; i < 256; i++) v[i] = 8; for (int i = 0; i < 5; i++) v[i] = (uint8_t)i; } };   // bytes are base codes 0..3, 4 = N
+static const BkCodeLut g_code_lut;
+static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vector<uint32_t> *nlist = nullptr, uint32_t tag = 0, bool codes = false)
 {
-    const uint8_t *lut = g_pack_lut.v; const unsigned char *u = (const unsigned char *)s;
+    const uint8_t *lut = codes ? g_code_lut.v : g_pack_lut.v; const unsigned char *u = (const unsigned char *)s;
     int i = 0, wi = 0;
     for (; i + 16 <= len; i += 16, wi++) {
         uint32_t x = 0, fl = 0;
@@ -160,9 +162,14 @@ template <class T> static hipError_t upload(bk_handle *h, DevBuf &b, const std::
     return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream);
 }
 
-extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions)
+static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags);
+extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions) { return submit_regions(h, regions, n_regions, 0); }
+extern "C" int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags) { return submit_regions(h, regions, n_regions, flags); }
+
+static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags)
 {
     if (!h || !regions || n_regions <= 0) return fail(h, BK_E_ARG, "bk_submit_regions: bad argument");
+    const bool read_codes = (flags & BK_SUBMIT_READ_CODES) != 0;
     HIPCHK(h, hipSetDevice(h->dev));
     const int k = h->cfg.kmer_size;
     // a failed submit leaves the handle without a batch (never the old device results paired with new host mirrors):
@@ -232,7 +239,7 @@ extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t
                 if (r >= n_regions) break;
                 const bk_region &g = regions[r]; const BkRegionDesc &d = n_desc[r];
                 for (int i = 0; i < g.n_reads; i++)
-                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
+                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i, read_codes)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
             }
         };
         const int nth = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), n_regions}));

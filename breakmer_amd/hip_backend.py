@@ -58,7 +58,7 @@ def call_text(text):
     return (row.split("\t") if row else None), (None if hit.value < 0 else bool(hit.value))
 
 
-EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_run", "bk_sync", "bk_fetch",
+EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_submit_regions_ex", "bk_run", "bk_sync", "bk_fetch",
            "bk_last_kernel_ms", "bk_get_region_status", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
            "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_get_calls",
            "bk_nw_batch"]
@@ -84,6 +84,7 @@ def load_library():
     L.bk_create.argtypes = [C.c_int, C.POINTER(BkConfig), C.POINTER(C.c_void_p)]
     L.bk_destroy.argtypes = [C.c_void_p]
     L.bk_submit_regions.argtypes = [C.c_void_p, C.POINTER(BkRegion), C.c_int32]
+    L.bk_submit_regions_ex.argtypes = [C.c_void_p, C.POINTER(BkRegion), C.c_int32, C.c_uint32]
     L.bk_run.argtypes = [C.c_void_p, C.c_uint32]
     L.bk_sync.argtypes = [C.c_void_p]
     L.bk_fetch.argtypes = [C.c_void_p]
@@ -120,15 +121,16 @@ def _ascii_matrix(seqs):
 
 
 _ACGT = np.frombuffer(b"ACGTN", dtype=np.uint8)       # code 4 = N (reads only; windows must be A/C/G/T)
+_CODE2ASCII = bytes(b"ACGTN"[i] if i < 5 else ord("?") for i in range(256))
 
 
 class RegionInput(object):
     """Host-side view of one target region, kept alive until submit returns."""
 
     def __init__(self, reads, window, *, read_lens=None, indel_only=None, sc_seqs=None, partners=()):
-        if isinstance(reads, np.ndarray):                   # uint8 codes 0..3, [N, L]
-            self.reads = _ACGT[reads] if reads.size else np.zeros((0, 1), dtype=np.uint8)
-            self.reads = np.ascontiguousarray(self.reads)
+        self.codes = isinstance(reads, np.ndarray)          # uint8 codes 0..3 (4 = N), [N, L]: handed over as they are (bk_submit_regions_ex)
+        if self.codes:
+            self.reads = np.ascontiguousarray(reads, dtype=np.uint8) if reads.size else np.zeros((0, 1), dtype=np.uint8)
             self.lens = (np.asarray(read_lens, dtype=np.uint16) if read_lens is not None
                          else np.full(reads.shape[0], reads.shape[1], dtype=np.uint16))
         else:
@@ -203,7 +205,16 @@ class Engine(object):
         arr = (BkRegion * len(regions))()
         for g, r in zip(arr, regions):
             r.fill(g)
-        self._chk(self.L.bk_submit_regions(self.h, arr, len(regions)), "bk_submit_regions")
+        kinds = {bool(r.codes) for r in regions if r.reads.shape[0]}
+        if len(kinds) > 1:                                  # mixed batch: the code matrices become ASCII (one C-speed byte translation each)
+            for g, r in zip(arr, regions):
+                if r.codes:
+                    r.reads = np.frombuffer(r.reads.tobytes().translate(_CODE2ASCII), dtype=np.uint8).reshape(r.reads.shape)
+                    r.codes = False
+                    r.fill(g)
+            kinds = {False}
+        flags = 1 if kinds == {True} else 0
+        self._chk(self.L.bk_submit_regions_ex(self.h, arr, len(regions), flags), "bk_submit_regions")
         self.n_regions = len(regions)
 
     def run(self, stages=BK_STAGE_KMER | BK_STAGE_ASSEMBLE, sync=True):

@@ -1,0 +1,133 @@
+"""Reference-genome access for the steps around the hot path (host-side Python, nothing here runs on the GPU):
+
+  * FastaIndex        -- random access to a (multi-)FASTA through a .fai-style index (built by one scan, or read from
+                         <fasta>.fai when present); stands in for Biopython's SeqIO.to_dict (utils.py:363).
+  * extract_refseq_fa -- utils.extract_refseq_fa (utils.py:355-381): the target window [start-200, end+200) of the target's
+                         chromosome as <name>_forward_refseq.fa / <name>_reverse_refseq.fa (+ marker files).
+  * discover_partners -- where the reference hands a contig that its target window does not explain to a whole-genome
+                         gfServer (sv_processor.py:829-831, utils.py:620-657), this path realigns against explicit partner
+                         windows.  They are found here from the evidence the reference itself collects while extracting reads
+                         (read_d['disc'], sv_processor.py:58-66: pairs whose mate maps to another chromosome or > 1 kb away):
+                         the mate positions are clustered and each cluster with enough pairs becomes a window of the genome.
+                         A heuristic stand-in for the genome-wide search -- translocations without discordant pairs are not
+                         found -- NOT pinned against gfServer (absent binary, no genome): DESIGN.md section 8.
+"""
+from __future__ import annotations
+
+import os
+
+_COMP = bytes.maketrans(b"ACGTNacgtn", b"TGCANtgcan")
+
+
+class FastaIndex(object):
+    def __init__(self, path):
+        self.path = path
+        self.index = {}                                  # name -> (length, offset, line_bases, line_bytes)
+        fai = path + ".fai"
+        if os.path.isfile(fai) and os.path.getmtime(fai) >= os.path.getmtime(path):
+            with open(fai) as f:
+                for ln in f:
+                    p = ln.rstrip("\n").split("\t")
+                    if len(p) >= 5:
+                        self.index[p[0]] = (int(p[1]), int(p[2]), int(p[3]), int(p[4]))
+        else:
+            self._scan()
+        self._f = open(path, "rb")
+
+    def _scan(self):
+        name, length, offset, lb, lby = None, 0, 0, 0, 0
+        pos = 0
+        with open(self.path, "rb") as f:
+            for raw in f:
+                if raw.startswith(b">"):
+                    if name is not None:
+                        self.index[name] = (length, offset, lb, lby)
+                    name = raw[1:].split()[0].decode()
+                    length, offset, lb, lby = 0, pos + len(raw), 0, 0
+                else:
+                    n = len(raw.rstrip(b"\r\n"))
+                    if lb == 0 and n:
+                        lb, lby = n, len(raw)
+                    length += n
+                pos += len(raw)
+        if name is not None:
+            self.index[name] = (length, offset, lb, lby)
+
+    def _key(self, chrom):
+        c = str(chrom)
+        for k in (c, "chr" + c, c.replace("chr", "")):
+            if k in self.index:
+                return k
+        raise KeyError("chromosome %s not in %s" % (chrom, self.path))
+
+    def length(self, chrom):
+        return self.index[self._key(chrom)][0]
+
+    def fetch(self, chrom, start, end):
+        """bases [start, end) (0-based, clipped to the sequence), upper case"""
+        length, offset, lb, lby = self.index[self._key(chrom)]
+        start, end = max(0, int(start)), min(length, int(end))
+        if end <= start or lb == 0:
+            return ""
+        b0 = offset + (start // lb) * lby + start % lb
+        b1 = offset + ((end - 1) // lb) * lby + (end - 1) % lb + 1
+        self._f.seek(b0)
+        return self._f.read(b1 - b0).replace(b"\n", b"").replace(b"\r", b"").decode().upper()
+
+    def close(self):
+        self._f.close()
+
+
+def revcomp(seq):
+    return seq.encode().translate(_COMP)[::-1].decode()
+
+
+def extract_refseq_fa(gene_coords, ref_path, fasta, direction):      # utils.py:355-381
+    chrom, s, e, name = gene_coords[:4]
+    fa_fn = os.path.join(ref_path, name + '_' + direction + '_refseq.fa')
+    marker = os.path.join(ref_path, "." + name + '_' + direction + '_refseq.fa')
+    if not os.path.isfile(marker):
+        seq = fasta.fetch(chrom, int(s) - 200, int(e) + 200)
+        if direction == "reverse":
+            seq = revcomp(seq)
+        os.makedirs(ref_path, exist_ok=True)
+        with open(fa_fn, 'w') as f:
+            f.write(">" + name + "\n" + seq + "\n")
+        open(marker, 'w').close()
+    return fa_fn
+
+
+def discover_partners(disc, fasta, annotations, target_chrom, target_start, target_end, min_pairs=2, join=1000, flank=1500, max_windows=8):
+    """disc: {mate chromosome: [(read position, mate position), ...]} of one target (sv_processor.py:60-66).
+    -> [(chrom, start, end, name, sequence)] in genome coordinates, most supported first: one window per cluster of mate
+    positions (neighbours <= `join` apart) with >= `min_pairs` pairs, `flank` bases around it, clipped to the chromosome;
+    clusters inside the target's own window [start-200, end+200) are the target itself and are skipped."""
+    out = []
+    tc = str(target_chrom).replace("chr", "")
+    for chrom, pairs in disc.items():
+        pos = sorted(int(p[1]) for p in pairs)
+        i = 0
+        while i < len(pos):
+            j = i
+            while j + 1 < len(pos) and pos[j + 1] - pos[j] <= join:
+                j += 1
+            n = j - i + 1
+            lo, hi = pos[i], pos[j]
+            i = j + 1
+            if n < min_pairs:
+                continue
+            c = str(chrom).replace("chr", "")
+            if c == tc and hi >= target_start - 200 and lo <= target_end + 200:
+                continue
+            try:
+                clen = fasta.length(c)
+            except KeyError:
+                continue
+            s, e = max(0, lo - flank), min(clen, hi + flank)
+            seq = fasta.fetch(c, s, e)
+            if len(seq) < 64 or seq.strip("ACGT"):
+                continue                                   # windows must be plain A/C/G/T for the device path
+            name = annotations.set_gene(c, [(lo + hi) // 2]) if annotations is not None else "intergenic"
+            out.append((n, (c, s, e, name, seq)))
+    out.sort(key=lambda x: (-x[0], x[1][0], x[1][1]))
+    return [w for _n, w in out[:max_windows]]

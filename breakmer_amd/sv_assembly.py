@@ -50,8 +50,16 @@ class contig(object):
         self.aseq = _Aseq(seq, assembly_counts(indel_only, others))
         self.kmer_locs = list(kmer_locs)
         self.kmers = [(m,) for m in kmers]          # only x[0] and len() are read downstream (sv_processor.py:760-761, 864)
-        self.reads = set(reads)
+        self._reads = None
+        self._read_src = reads                      # (source sequence, indices) or an iterable of fq_read: the set is built when asked for
         self.kmer_len = kmer_len
+
+    @property
+    def reads(self):                                # set of fq_read (sv_assembly.py:423); the writers and the Python call tail read it
+        if self._reads is None:
+            src = self._read_src
+            self._reads = set(src[0][i] for i in src[1]) if isinstance(src, tuple) else set(src)
+        return self._reads
 
     def get_total_read_support(self): return self.aseq.counts.get_total_reads()
     def get_contig_len(self): return len(self.aseq.seq)
@@ -66,5 +74,5 @@ def contigs_from_engine(engine, region, reads, kmer_len):
     indexed by its position)."""
     out = []
     for c in engine.contigs(region):
-        out.append(contig(c["seq"], c["indel_only"], c["others"], c["kmer_locs"], c["kmers"], [reads[i] for i in c["reads"]], kmer_len))
+        out.append(contig(c["seq"], c["indel_only"], c["others"], c["kmer_locs"], c["kmers"], (reads, c["reads"]), kmer_len))
     return out

@@ -21,7 +21,7 @@ import os
 import shutil
 from collections import OrderedDict
 
-from . import read_extraction, samio, sv_assembly, sv_caller
+from . import read_extraction, refseq, samio, sv_assembly, sv_caller
 
 HEADER_FIELDS = ['genes', 'target_breakpoints', 'align_cigar', 'mismatches', 'strands', 'rep_overlap_segment_len', 'sv_type',
                  'split_read_count', 'nkmers', 'disc_read_count', 'breakpoint_coverages', 'contig_id', 'contig_seq']
@@ -40,7 +40,7 @@ class RegionData(object):
         self.read_codes, self.read_lens = read_codes, read_lens
         self.read_ids = read_ids if read_codes is not None else list(read_ids)
         self.read_seqs = read_seqs if read_codes is not None else list(read_seqs)
-        self.indel_only = list(indel_only) if indel_only is not None else [False] * len(self.read_ids)
+        self.indel_only = (indel_only if read_codes is not None else list(indel_only)) if indel_only is not None else ([False] * len(self.read_ids) if read_codes is None else _np.zeros(len(read_ids), dtype=_np.uint8))
         self.quals = list(quals) if quals is not None else None
         self.sc_seqs = sc_seqs
         self.window = window
@@ -183,6 +183,7 @@ class params(object):                                               # utils.py:5
         self.logger = logging.getLogger('root')
         self.repeat_mask = None
         self._bams = {}
+        self._fasta = None
         self.set_params()
 
     def set_params(self):                                            # utils.py:574-618
@@ -224,6 +225,14 @@ class params(object):                                               # utils.py:5
                 if wanted and name.upper() not in wanted:
                     continue
                 self.targets.setdefault(name.upper(), []).append((chrm, int(bp1), int(bp2), name, p[4] if len(p) > 4 else None))
+
+    def open_fasta(self):                                            # the genome reference (`reference_fasta`), indexed once
+        fn = self.opts.get('reference_fasta')
+        if not fn or not os.path.isfile(fn):
+            return None
+        if self._fasta is None:
+            self._fasta = refseq.FastaIndex(fn)
+        return self._fasta
 
     def open_bam(self, fn):                                          # one parse per alignment file, shared by all targets
         if fn not in self._bams:
@@ -406,6 +415,10 @@ class target(object):                                               # sv_process
 
     # ---- steps before the hot path (file formats of the reference; BAM extraction itself is out of scope)
     def set_ref_data(self):                                          # :351-364
+        fa = self.params.open_fasta()
+        if self.data is None and fa is not None and self.files.get('target_ref_fn'):     # utils.extract_refseq_fa, forward + reverse
+            for direction in ("forward", "reverse"):
+                refseq.extract_refseq_fa(self.get_values(), self.paths['ref_data'], fa, direction)
         if self.data is None and self.files.get('target_ref_fn') and os.path.isfile(self.files['target_ref_fn'][0]):
             self._window = read_fasta_first(self.files['target_ref_fn'][0])
         elif self.data is not None:
@@ -446,6 +459,13 @@ class target(object):                                               # sv_process
                 sc = [ln.strip() for ln in open(scfn) if ln.strip() and not ln.startswith(">")]
             self.data = RegionData(ids, seqs, io, sc, self._window, quals=quals)
         self.disc_reads = self.data.disc_reads
+        if not self.data.partners and self.params.open_fasta() is not None and self.disc_reads.get('disc'):
+            # N4: candidate partner windows from the discordant pairs (refseq.discover_partners) stand in for the whole-genome search
+            self.data.partners = refseq.discover_partners(self.disc_reads['disc'], self.params.open_fasta(), self.params.gene_annotations,
+                                                          self.chrom, self.start, self.end, min_pairs=self.params.get_sr_thresh('trl'))
+            if self.data.partners:
+                self.logger.info('target %s: %d partner window(s) from discordant pairs: %s' % (self.name, len(self.data.partners),
+                                 ", ".join("%s:%d-%d" % (p[0], p[1], p[2]) for p in self.data.partners)))
         self.partner_windows = self.data.partners
 
     def clean_reads(self):                                           # :584-606 (cutadapt out of scope) -> bool
@@ -483,7 +503,7 @@ class target(object):                                               # sv_process
             # code-matrix input (synthetic / pre-packed reads): nothing per read happens on the host; the fq_read objects the
             # writers and the caller need are made on demand (_LazyReads), cleaned_read_recs only exists as a count
             self.reads = _LazyReads(d)
-            self.read_len = int(max(d.read_lens)) if len(d.read_lens) else 0
+            self.read_len = int(_np.max(d.read_lens)) if len(d.read_lens) else 0
             self.cleaned_read_recs = _LazyRecs(self.reads)
             return len(d.read_ids) > 0
         q = d.quals
@@ -498,9 +518,9 @@ class target(object):                                               # sv_process
     # ---- the hot path: results of the batched GPU call
     def compare_kmers(self):                                         # :609-645
         eng, ri = self.engine, self.region_index
-        mers, counts, _u = eng.kmers(ri)
-        self.kmers['case_only'] = dict(zip(mers, counts.tolist()))
-        if self.files.get('sample_kmers'):
+        if self.files.get('sample_kmers'):                          # the k-mer set is only materialised for its file (the assembler consumed it on the device)
+            mers, counts, _u = eng.kmers(ri)
+            self.kmers['case_only'] = dict(zip(mers, counts.tolist()))
             with open(self.files['sample_kmers'], 'w') as f:
                 for m, c in self.kmers['case_only'].items():
                     f.write("\t".join([m, str(c)]) + "\n")
@@ -591,7 +611,7 @@ class runner(object):                                               # sv_process
             t.region_index, t.engine = i, eng
             d = t.data
             reads = d.read_codes if d.read_codes is not None else d.read_seqs
-            ins.append(hip_backend.RegionInput(reads, d.window, read_lens=d.read_lens, indel_only=[1 if x else 0 for x in d.indel_only], sc_seqs=d.sc_seqs,
+            ins.append(hip_backend.RegionInput(reads, d.window, read_lens=d.read_lens, indel_only=_np.asarray(d.indel_only, dtype=_np.uint8), sc_seqs=d.sc_seqs,
                                                partners=[p[4] for p in d.partners]))
         eng.submit(ins)
         try:

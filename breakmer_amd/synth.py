@@ -308,3 +308,49 @@ def make_sam(r: Region, n_pairs: int = 200, L: int = 100, global_seed: int = 1, 
         out.append("\t".join([name, str(f1), ch1, str(p1 + 1), str(mq1), c1, "=", str(p2 + 1), str(t1), s1, q1]))
         out.append("\t".join([name, str(f2), ch2, str(p2 + 1), str(mq2), c2, "=", str(p1 + 1), str(-t1), s2, q2]))
     return "\n".join(out) + "\n"
+
+
+def make_sam_trl(r: Region, n_pairs: int = 300, L: int = 100, global_seed: int = 1, frag: int = 260) -> str:
+    """SAM text of a toy aligner's view of read pairs drawn from the donor of a TRANSLOCATION region (left half of the
+    target window joined to the right half of the partner window): reads left of the junction map to the target chromosome,
+    reads right of it to the partner chromosome, reads across it are soft-clipped on their shorter side; a pair with one end
+    on each chromosome is the discordant evidence the reference collects (sv_processor.py:58-66).  Coordinates are 1-based."""
+    assert r.sv_type == "trl" and len(r.partners) == 1
+    W = len(r.window)
+    c = W // 2
+    gpos = r.start - 200
+    pchrom, pstart = r.partners[0][0], r.partners[0][1]
+    u = rand_u64(stream_key(global_seed, r.region_id, 12), n_pairs * 2).reshape(n_pairs, 2)
+    D = len(r.donor)
+
+    def place(d0):
+        b = c - d0                                  # bases of the read left of the junction
+        if b >= L:
+            return r.chrom, gpos + d0, "%dM" % L
+        if b <= 0:
+            return pchrom, pstart + d0, "%dM" % L
+        if b >= L - b:
+            return r.chrom, gpos + d0, "%dM%dS" % (b, L - b)
+        return pchrom, pstart + c, "%dS%dM" % (b, L - b)
+
+    out = ["@HD\tVN:1.0\tSO:unsorted", "@SQ\tSN:%s\tLN:250000000" % r.chrom, "@SQ\tSN:%s\tLN:250000000" % pchrom]
+    for i in range(n_pairs):
+        span = frag
+        if int(u[i, 0] % np.uint64(4)) < 3:          # three quarters of the pairs sit around the junction
+            d1 = c - span + 10 + int((u[i, 0] >> np.uint64(8)) % np.uint64(span + L - 20)) - L // 2
+        else:
+            d1 = int((u[i, 0] >> np.uint64(8)) % np.uint64(D - span + 1))
+        d1 = min(max(d1, 0), D - span)
+        d2 = d1 + span - L
+        s1, s2 = codes_to_str(r.donor[d1:d1 + L]), codes_to_str(r.donor[d2:d2 + L])
+        (c1, p1, g1), (c2, p2, g2) = place(d1), place(d2)
+        name = "T:1:1:%d:%d" % (r.region_id, i)
+        q = "I" * L
+        if c1 == c2:
+            t = (p2 + L) - p1
+            out.append("\t".join([name, "99", c1, str(p1 + 1), "60", g1, "=", str(p2 + 1), str(t), s1, q]))
+            out.append("\t".join([name, "147", c2, str(p2 + 1), "60", g2, "=", str(p1 + 1), str(-t), s2, q]))
+        else:
+            out.append("\t".join([name, "97", c1, str(p1 + 1), "60", g1, c2, str(p2 + 1), "0", s1, q]))
+            out.append("\t".join([name, "145", c2, str(p2 + 1), "60", g2, c1, str(p1 + 1), "0", s2, q]))
+    return "\n".join(out) + "\n"

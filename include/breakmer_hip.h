@@ -87,6 +87,10 @@ int bk_abi_version(void);
  * (replaces: writing <name>_sv_reads.fastq / *_refseq.fa for jellyfish and the assembler,
  * sv_processor.py:584-606, utils.py:355-381). */
 int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions);
+/* Same, for callers that already hold the reads as base codes (one byte per base: 0..3 = A,C,G,T, 4 = N) instead of the
+ * reference's strings: with BK_SUBMIT_READ_CODES the `reads` rows are codes (windows / soft-clip / partner sequences stay ASCII). */
+#define BK_SUBMIT_READ_CODES 1u
+int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags);
 
 /* Run the selected stages on everything submitted (replaces, per region:
  *   BK_STAGE_KMER     run_jellyfish x4 + load_kmers + set algebra, utils.py:151-178,287-296, sv_processor.py:613-631

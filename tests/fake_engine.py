@@ -15,7 +15,8 @@ class FakeEngine(object):
     def submit(self, ins):
         self.regions = []
         for g in ins:
-            reads = [bytes(g.reads[i, :g.lens[i]]).decode() for i in range(g.reads.shape[0])]
+            asc = np.frombuffer(b"ACGTN", dtype=np.uint8)[g.reads] if getattr(g, "codes", False) and g.reads.size else g.reads
+            reads = [bytes(asc[i, :g.lens[i]]).decode() for i in range(g.reads.shape[0])]
             io = g.indel_only if g.indel_only is not None else np.zeros(len(reads), dtype=np.uint8)
             sc = None if g.sc is None else [bytes(g.sc[i, :g.sc_lens[i]]).decode() for i in range(g.sc.shape[0])]
             self.regions.append((reads, io, sc, g.window.decode(), [p.decode() for p in g.partners]))

@@ -622,3 +622,19 @@ def test_reads_with_n_gpu(hb):
             assert eng.hits(i, ci) == bo.realign(c["seq"], targets), (i, ci)
             ncontig_n += "N" in c["seq"]
     assert ncontig_n >= 1
+
+
+def test_translocation_partner_discovery_gpu(hb, tmp_path):
+    """N4 on the GPU: reads from a SAM file, target window cut from the genome FASTA, partner window discovered from the
+    discordant pairs, both call tails."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_pipeline import check_trl_run, make_trl_inputs
+    from breakmer_amd import sv_processor as sp
+    cfg, r = make_trl_inputs(tmp_path)
+    run = sp.runner(cfg)
+    rows = run.run()
+    check_trl_run(run, rows, r, tmp_path)
+    (tmp_path / "py").mkdir()
+    cfg2, r2 = make_trl_inputs(tmp_path / "py")
+    assert sp.runner(cfg2, native_calls=False).run() == rows

@@ -221,3 +221,58 @@ def test_runner_batches_and_code_matrix_inputs(tmp_path):
         assert (d / "analysis" / "output" / "synth_indel_svs.out").read_text() == a, tag
         fq1 = sorted((one / "analysis" / "targets" / "GENE00003" / "contigs" / "contig1" / "contig1.fq").read_text().split("\n"))
         assert sorted((d / "analysis" / "targets" / "GENE00003" / "contigs" / "contig1" / "contig1.fq").read_text().split("\n")) == fq1, tag
+
+
+def make_trl_inputs(tmp_path):
+    """Translocation from files only: alignment file (SAM), genome FASTA with the target and the partner chromosome, BED,
+    gene table -- no reference-window file and no partner window are handed over (N4)."""
+    import numpy as np
+    r = synth.make_region(21, sv_type="trl", W=1200, L=100, depth=5)
+    r.chrom, r.start = "1", 2200
+    r.end = r.start + (len(r.window) - 400)
+    pw = r.partners[0][4]
+    r.partners[0] = ("2", 5000, 5000 + len(pw), "PARTNERX", pw)
+    fl = synth.rand_bases(synth.stream_key(3, 21, 9), 12000)
+    chr1 = np.concatenate([fl[:2000], r.window, fl[2000:4000]])
+    chr2 = np.concatenate([fl[4000:9000], pw, fl[9000:12000]])
+    with open(tmp_path / "genome.fa", "w") as f:
+        for name, seq in (("chr1", chr1), ("chr2", chr2)):
+            s = synth.codes_to_str(seq)
+            f.write(">" + name + " test\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n")
+    (tmp_path / "targets.bed").write_text("\t".join([r.chrom, str(r.start), str(r.end), r.name, "exon"]) + "\n")
+    genes = ["header", "\t".join(["0", r.name, "chr1", "+", str(r.start), str(r.end)] + ["x"] * 6 + [r.name]),
+             "\t".join(["0", "PARTNERX", "chr2", "+", "4000", "7500"] + ["x"] * 6 + ["PARTNERX"])]
+    (tmp_path / "genes.txt").write_text("\n".join(genes) + "\n")
+    (tmp_path / "sample.sam").write_text(synth.make_sam_trl(r, 400))
+    cfg = {"analysis_name": "trlrun", "targets_bed_file": str(tmp_path / "targets.bed"), "analysis_dir": str(tmp_path / "analysis"),
+           "reference_data_dir": str(tmp_path / "ref"), "gene_annotation_file": str(tmp_path / "genes.txt"), "kmer_size": "15",
+           "keep_repeat_regions": True, "sample_bam_file": str(tmp_path / "sample.sam"), "reference_fasta": str(tmp_path / "genome.fa")}
+    return cfg, r
+
+
+def check_trl_run(run, rows, r, tmp_path):
+    from breakmer_amd import refseq
+    t = run.targets[r.name.upper()]
+    ref = tmp_path / "ref" / r.name
+    fwd = (ref / (r.name + "_forward_refseq.fa")).read_text()
+    assert fwd == ">" + r.name + "\n" + r.window_str + "\n"                        # utils.extract_refseq_fa: [start-200, end+200)
+    assert (ref / (r.name + "_reverse_refseq.fa")).read_text() == ">" + r.name + "\n" + refseq.revcomp(r.window_str) + "\n"
+    assert len(t.partner_windows) == 1
+    pc, ps, pe, pn, pseq = t.partner_windows[0]
+    assert pc == "2" and pn == "PARTNERX" and ps < 5000 + 600 < pe and pseq == refseq.FastaIndex(str(tmp_path / "genome.fa")).fetch("2", ps, pe)
+    assert len(rows) >= 1
+    row = rows[0]
+    assert row[6] == "rearrangement" and set(row[0].split(",")) == {r.name, "PARTNERX"}, row[:7]
+    bps = row[1].split(",")
+    assert any(b.startswith("chr1:") and abs(int(b.split(":")[1]) - (r.start - 200 + 600)) <= 12 for b in bps), row[1]
+    assert any(b.startswith("chr2:") and abs(int(b.split(":")[1]) - (5000 + 600)) <= 12 for b in bps), row[1]
+    assert int(row[9]) >= 2                                                         # discordant pairs counted
+
+
+def test_translocation_partner_discovery_from_files(tmp_path):
+    """N4: target window extracted from the genome FASTA (utils.extract_refseq_fa), partner window discovered from the
+    discordant pairs of the alignment file, contig realigned against both, the reference's caller reports the translocation."""
+    cfg, r = make_trl_inputs(tmp_path)
+    run = sp.runner(cfg, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+    rows = run.run()
+    check_trl_run(run, rows, r, tmp_path)
