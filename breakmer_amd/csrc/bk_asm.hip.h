@@ -81,6 +81,13 @@ struct BkAsmCtx {
     int MAXC, MAXR, MAXCAND, KCAP, k, flags;
 };
 
+// Functions off the DP round trip (emit, alt reads, find_reads, contig k-mer lists) are kept out of line: inlined into
+// the state machine they pushed it to 65 spilled VGPRs (176 B of scratch per lane); out of line it has none.
+#ifndef BK_INLINE_COLD
+#define BK_COLD __device__ __noinline__
+#else
+#define BK_COLD __device__ inline
+#endif
 #define BK_TID ((int)threadIdx.x)
 #define BK_SYNC() __syncthreads()
 #ifdef BK_PHASE_STAMPS      // diagnostic build only: where does a region's time go (s_memrealtime, 100 MHz)
@@ -230,7 +237,7 @@ __device__ inline int bk_total_reads()                                          
 // ---- get_read_kmers_ordered (sv_assembly.py:126-143) on cseq[s0 .. s0+L) ---------------------------------
 // order MID replaces contig.kmers (set_kmers :548-550), FOR/REV extend it (:525-527, :543-545).
 // P1: m = L // 2 ; Q1: positions range(0, L-k).
-__device__ inline void bk_kmers_ordered(int s0, int L, int order)
+BK_COLD void bk_kmers_ordered(int s0, int L, int order)
 {
     BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
@@ -277,7 +284,7 @@ __device__ inline void bk_kmers_ordered(int s0, int L, int order)
 
 // ---- find_reads (sv_assembly.py:111-122) from the posting list of k-mer `rank` -------------------------
 // key (pos, -len) / (-pos, -len); stable sort ties keep fq_recs order = unique index u.
-__device__ inline void bk_find_reads(int rank, bool rev, bool filter)
+BK_COLD void bk_find_reads(int rank, bool rev, bool filter)
 {
     BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
@@ -585,7 +592,9 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             }
             int mx = 0;
             for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen);
-            S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL);
+            // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
+            // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
+            S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
             if (!S->dual && nb > BK_SPEC_WIDE) nb = BK_SPEC_WIDE;
             S->nb = nb;
         }
@@ -647,7 +656,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
 }
 
 // ---- check_alt_reads (sv_assembly.py:568-582) + the adds of finalize (:590-592) -------------------------
-__device__ inline void bk_check_alt_reads()
+BK_COLD void bk_check_alt_reads()
 {
     BK_ACC(S_->ctx);
     BkAsmShared *S = S_;
@@ -800,7 +809,7 @@ __device__ __forceinline__ void bk_grow()
 
 // ---- init_assembly keeps a contig iff support >= rc_thresh and len > read_len (sv_assembly.py:53-59);
 //      set_kmer_locs (:434-438) and the record the host reads back ------------------------------------------
-__device__ inline void bk_emit_contig()
+BK_COLD void bk_emit_contig()
 {
     BK_ACC(S_->ctx);
     BkAsmShared *S = S_;

@@ -24,7 +24,7 @@ while done < n:
         W = int(rng.integers(max(2 * L + 100, 400), 2200))
         kw = dict(W=W, L=L, depth=int(rng.integers(15, 160)), sv_type=str(rng.choice(synth.SV_TYPES)),
                   noise=float(rng.choice([0.0, 0.0, 0.003, 0.01, 0.03])), var_len=float(rng.choice([0.0, 0.0, 0.2])),
-                  indel_only_frac=float(rng.choice([0.0, 0.0, 0.3])), global_seed=seed)
+                  indel_only_frac=float(rng.choice([0.0, 0.0, 0.3])), n_frac=float(rng.choice([0.0, 0.0, 0.1, 0.5])), global_seed=seed)
         kw["sv_size"] = int(rng.choice([20, 60, 120, 200])) if kw["sv_type"] in ("del", "ins") else int(rng.choice([100, 200]))
         if kw["sv_size"] >= W // 2 - L:
             kw["sv_size"] = 20
