@@ -38,14 +38,15 @@ VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--regions", type=int, default=0, help="regions per GPU per step (0: 256 = configs[1] at one GPU, 512 at several: configs[2] at 8)")
     ap.add_argument("--depth", type=int, default=500)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--cpu-sample", type=int, default=24, help="regions timed through the CPU oracle on ONE core (0 = skip the CPU baseline)")
-    ap.add_argument("--inflight", type=int, default=4, help="steps in flight (independent batches on separate HIP streams; 3 -> 4: +5 % on one box, 5 and 6 no more)")
+    ap.add_argument("--inflight", type=int, default=6, help="steps in flight (independent batches on separate HIP streams)")
+    ap.add_argument("--wg", type=int, default=256, help="assembler workgroup size of the batches in flight (256: 4 per CU; 512: 2 per CU); the one-step-at-a-time pass always uses 512")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (testing)")
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
     ap.add_argument("--cfg3-regions", type=int, default=4096, help="batch size of the configs[3] side measurement (heavy regions: the chip fills at a few thousand)")
@@ -235,7 +236,7 @@ def main():
     engs = []
     submit_ms = []
     for _ in range(max(1, a.inflight)):                # one handle (= one HIP stream + its own buffers) per step in flight
-        e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local, flags=a.flags)
+        e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local, flags=a.flags, wg_threads=a.wg)
         t0 = time.perf_counter()
         e.submit(ins)
         submit_ms.append((time.perf_counter() - t0) * 1e3)
@@ -350,7 +351,11 @@ def main():
     # ---- the same steps strictly one after the other (one handle, nothing in flight): the kernel durations of THIS pass
     #      are exclusive (no co-running batches stretch them) and are what the roofline figures use
     ks = max(2, min(a.steps, 8))
-    saved, engs[:] = list(engs), engs[:1]
+    lat = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local, flags=a.flags, wg_threads=512)       # the latency-tuned workgroup size
+    lat.submit(ins)
+    lat.set_call_context(ctx_text)
+    saved, engs[:] = list(engs), [lat]
+    run_steps(2)
     barrier()
     ts = time.perf_counter()
     s_k, s_a, s_w = run_steps(ks)
@@ -396,7 +401,8 @@ def main():
                        "regions_total_per_step": n_regions * world,
                        "sv_calls_per_step": last_rows.get("n", 0),
                        "steps_in_flight": len(engs),
-                       "asm_workgroups_per_cu": int(eng.stat(23)),
+                       "asm_workgroup_threads": int(eng.stat(25)), "asm_workgroups_per_cu": int(eng.stat(23)),
+                       "one_step_at_a_time_workgroup_threads": 512,
                        "collated_bytes_per_step": collated if dist else None,
                        "parallelism": "regions sharded per GPU, all-gather of result records"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -4,7 +4,26 @@
 #include "bk_common.h"
 #include "bk_kmer.hip.h"
 #include "bk_sched.hip.h"
+#include "bk_nw.hip.h"
+#define BK_AT 512
+#define BK_ASM_KERNEL bk_asm_kernel
+#define BK_WITH_NW_BATCH
+namespace at512 {
 #include "bk_asm.hip.h"
+static const size_t ctx_shared_bytes = (sizeof(BkAsmCtx) + 15) / 16 * 16 + (sizeof(BkAsmShared) + 15) / 16 * 16;
+}
+#undef BK_AT
+#undef BK_ASM_KERNEL
+#undef BK_WITH_NW_BATCH
+#define BK_AT 256
+#define BK_ASM_KERNEL bk_asm_kernel_w4
+namespace at256 {
+#include "bk_asm.hip.h"
+static const size_t ctx_shared_bytes = (sizeof(BkAsmCtx) + 15) / 16 * 16 + (sizeof(BkAsmShared) + 15) / 16 * 16;
+}
+#undef BK_AT
+#undef BK_ASM_KERNEL
+using at512::bk_nw_batch_kernel;
 #include "bk_sw.hip.h"
 #include "bk_call.h"
 
@@ -50,7 +69,7 @@ struct bk_handle {
     DevBuf d_desc, d_work, d_part, d_reads, d_rlen, d_rflag, d_sc, d_sclen, d_win;
     DevBuf d_ddslot, d_ddrep, d_ddcnt, d_grp, d_urep, d_unr, d_ufl, d_ubuf, d_ureads, d_ufound, d_uminpos;
     DevBuf d_arena, d_out, d_tops, d_order, d_skeys, d_clist, d_nlist;
-    int n_cu = 256, asm_wg_per_cu = 0, sw_wg_per_cu = 0;
+    int n_cu = 256, asm_wg_per_cu = 0, sw_wg_per_cu = 0, asm_threads = 512;
     uint64_t arena_cap = 0, out_cap = 0;
     uint32_t ref_cap = 0, win_words_cap = 0;
     int n_big = 0; uint64_t big_bytes = 0;      // regions whose window needs the global-memory k-mer set
@@ -331,10 +350,11 @@ static void fill_params(bk_handle *h)
     p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions; p.flags = h->cfg.reserved[0];
 }
 
-static size_t asm_lds_bytes(const bk_handle *h)
+static size_t asm_lds_bytes(const bk_handle *h, int threads)
 {
-    size_t o = (sizeof(BkAsmCtx) + 15) / 16 * 16 + (sizeof(BkAsmShared) + 15) / 16 * 16;
-    o += (size_t)h->cfg.max_candidates * 8 + (size_t)(BK_AT / 64) * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + (size_t)BK_SPEC * (h->eff_max_read + 16);
+    const size_t waves = threads / 64;
+    size_t o = threads == 512 ? at512::ctx_shared_bytes : at256::ctx_shared_bytes;
+    o += (size_t)h->cfg.max_candidates * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + waves * (h->eff_max_read + 16);
     return (o + 15) / 16 * 16;
 }
 
@@ -369,14 +389,20 @@ static int launch(bk_handle *h, uint32_t mask)
         // regions ordered by estimated cost, heaviest first (part of the assembler's measured time: ev[1]..ev[2])
         hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad);
         HIPCHK(h, hipGetLastError());
-        const size_t lds = asm_lds_bytes(h);
-        HIPCHK(h, hipFuncSetAttribute((const void *)bk_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // Workgroup size: 512 threads (8 wavefronts, 8 look-ahead slots, 2 per CU) finish ONE batch soonest; 256 threads (4
+        // wavefronts, 4 slots, 4 per CU) give more regions per CU whose serial phases overlap: +14 % regions/s once the
+        // chip is full.  bk_config.reserved[1] = 256 / 512 chooses; 0 = 512 unless the batch alone fills the chip twice.
+        int threads = h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions >= 4 * h->n_cu ? 256 : 512);
+        const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
+        const size_t lds = asm_lds_bytes(h, threads);
+        HIPCHK(h, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bk_asm_kernel, BK_AT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        h->asm_wg_per_cu = per_cu;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        h->asm_wg_per_cu = per_cu; h->asm_threads = threads;
         const int grid = std::min<long long>(h->n_regions, (long long)per_cu * h->n_cu);
-        hipLaunchKernelGGL(bk_asm_kernel, dim3(grid), dim3(BK_AT), lds, h->stream, h->params);
+        if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
+        else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
@@ -686,6 +712,7 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     if (which == 22) v = (uint64_t)h->n_failed;
     if (which == 23) v = (uint64_t)h->asm_wg_per_cu;                        // resident assembler / realign workgroups per CU (occupancy query)
     if (which == 24) v = (uint64_t)h->sw_wg_per_cu;
+    if (which == 25) v = (uint64_t)h->asm_threads;
     if (which >= 100 && which < 120) { v = 0; for (int r = 0; r < h->n_regions; r++) v += h->h_work[r].stamps[which - 100]; }      // diagnostic counters, summed over regions
     *value = v; return BK_OK;
 }

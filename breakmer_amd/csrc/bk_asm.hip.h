@@ -12,15 +12,19 @@
 //
 // All threads execute the control flow redundantly on state kept in LDS (struct BkAsmShared);
 // thread 0 commits scalar state between barriers.  Canonicalisations P1/P2/P4 of SURVEY.md 8c.
-#pragma once
-#include "bk_common.h"
-#include "bk_nw.hip.h"
+// This header is included TWICE by bk_api.hip, each time inside its own namespace, with BK_AT = 512 (8 wavefronts, 8
+// look-ahead slots, 2 workgroups per CU: shortest time for one batch) and BK_AT = 256 (4 wavefronts, 4 slots, 4 workgroups per
+// CU: highest throughput when batches are in flight); BK_ASM_KERNEL names the kernel.  bk_common.h / bk_nw.hip.h are
+// included by bk_api.hip before, outside the namespaces.
 
 #ifndef BK_AT
-#define BK_AT 512            // 8 wavefronts: 8 speculative look-ahead slots, both overlap DPs of a slot on one wavefront (bk_nw_dual);
+#error "define BK_AT (threads per assembler workgroup: 512 or 256) and BK_ASM_KERNEL before including bk_asm.hip.h"
 #endif
-#define BK_SPEC (BK_AT / 64)        // contigs beyond BK_NW_DUAL_COLS: half as many slots x 2 wavefronts (one DP each)
-#define BK_SPEC_WIDE (BK_AT / 128)
+#undef BK_SPEC
+#undef BK_SPEC_WIDE
+#define BK_SPEC (BK_AT / 64)        // look-ahead slots, both overlap DPs of a slot on one wavefront (bk_nw_dual);
+#define BK_SPEC_WIDE (BK_AT / 128)  // contigs beyond BK_NW_DUAL_COLS or few reads in a round: half as many slots x 2 wavefronts (one DP each)
+
 
 enum { BK_ORD_FOR = 0, BK_ORD_REV = 1, BK_ORD_MID = 2 };
 enum { BK_DEC_NONE = 0, BK_DEC_SAME = 1, BK_DEC_SUPER = 2, BK_DEC_SUB = 3, BK_DEC_POST = 4, BK_DEC_PRE = 5 };
@@ -981,7 +985,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
 // Persistent workgroups: each pulls the next region of the cost-ordered queue (bk_sched.hip.h) until it is empty, so a
 // batch is not bound by whichever heavy region happened to be launched last, and a batch may hold many more regions
 // than workgroups fit on the chip.
-extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
+extern "C" __global__ void __launch_bounds__(BK_AT, 4) BK_ASM_KERNEL(BkParams p)
 {
     for (;;) {
         BK_SYNC();                                       // the previous region's LDS state is dead
@@ -993,6 +997,7 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) bk_asm_kernel(BkParams p)
     }
 }
 
+#ifdef BK_WITH_NW_BATCH
 // ---- stand-alone batched olc.nw (known-answer tests G1, DP micro-benchmark) -----------------------------------
 extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_t *codes, const uint32_t *off1, const uint32_t *len1,
                                                                      const uint32_t *off2, const uint32_t *len2, int32_t *out, int reps, int transposed)
@@ -1017,3 +1022,4 @@ extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_
     for (int i = 0; i < reps; i++) r = transposed == 2 ? bk_nw_suffix(s1, m, s2, n, bound) : transposed ? bk_nw_wave<true>(s2, n, s1, m, bound) : bk_nw_wave<false>(s1, m, s2, n, bound);
     if (threadIdx.x == 0) { out[4 * b] = r.j_start; out[4 * b + 1] = r.i_end; out[4 * b + 2] = r.i_start; out[4 * b + 3] = r.score; }
 }
+#endif

@@ -179,6 +179,7 @@ class Engine(object):
         cfg.out_kbytes = int(limits.get("out_kbytes", 0))
         cfg.sw_min_score = int(limits.get("sw_min_score", 0))
         cfg.reserved[0] = int(limits.get("flags", 0))
+        cfg.reserved[1] = int(limits.get("wg_threads", 0))          # assembler workgroup size: 0 = library default, 256 (throughput) or 512 (latency)
         self.k = int(kmer_size)
         self.h = C.c_void_p()
         rc = self.L.bk_create(int(device), C.byref(cfg), C.byref(self.h))

@@ -115,8 +115,8 @@ def test_nw_random_vs_oracle_gpu(hb):
         assert x2 == [e2[3], e2[4], e2[5], e2[6]], (len(a), len(b), "dual v2")
 
 
-def _run_regions(hb, regions, k, rc_thresh=2, stages=3):
-    eng = hb.Engine(kmer_size=k, rc_thresh=rc_thresh)
+def _run_regions(hb, regions, k, rc_thresh=2, stages=3, **limits):
+    eng = hb.Engine(kmer_size=k, rc_thresh=rc_thresh, **limits)
     eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only,
                                partners=[p[4] for p in r.partners]) for r in regions])
     eng.run(stages)
@@ -147,6 +147,24 @@ def test_g3_assembly_golden_gpu(hb, golden_dir):
             # visit order of init_assembly: (count, mer) descending
             assert mers == [m for m, _ in sorted(got.items(), key=lambda x: (x[1], x[0]), reverse=True)], c["tag"]
             assert _strip(eng.contigs(i)) == c["contigs"], c["tag"]
+
+
+def test_both_workgroup_sizes_gpu(hb, golden_dir):
+    """The assembler exists in two workgroup sizes (512 threads / 8 look-ahead slots, 256 threads / 4 slots; bk_config
+    reserved[1]): the reference fixtures, a noisy region and long contigs give the same records through both."""
+    from oracle import bk_oracle as bo
+    d = _load(golden_dir, "assembly.json")
+    cases = [c for c in d["cases"] if c["k"] == 31 and c["rc_thresh"] == 2]
+    regions = [synth.make_region(**c["gen"]) for c in cases]
+    extra = [synth.make_region(970, sv_type="trl", depth=150, W=2400), synth.make_region(971, sv_type="del", depth=300, W=1000, noise=0.01)]
+    for wg in (256, 512):
+        eng = _run_regions(hb, regions + extra, 31, stages=7, wg_threads=wg)
+        assert eng.stat(25) == wg
+        for i, c in enumerate(cases):
+            assert _strip(eng.contigs(i)) == c["contigs"], (wg, c["tag"])
+        for j, r in enumerate(extra):
+            want, _ = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
+            assert _strip(eng.contigs(len(cases) + j)) == want and len(want) >= 1, (wg, j)
 
 
 def test_batch_vs_oracle_gpu(hb):
