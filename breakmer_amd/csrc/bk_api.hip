@@ -368,19 +368,22 @@ static int launch(bk_handle *h, uint32_t mask)
     static const unsigned long long tops[5] = {256, 256, 0, 0, 0};      // arena top, out top, contigs listed, region queue head, contig queue head
     HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    // workgroup sizes: latency mode (one batch at a time) or throughput mode (batches in flight / a batch that fills the chip)
+    const int asm_threads = h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions >= 4 * h->n_cu ? 256 : 512);
+    const int kmer_threads = asm_threads == 512 ? BK_KT_MAX : BK_KT;
     if (mask & BK_STAGE_KMER) {
         if (h->n_big < h->n_regions) {
             // the LDS first holds the read-grouping table (one word per slot, when it fits), then the reference k-mer set
             const uint32_t lds_words = std::max<uint32_t>(32 + 256 + 2 * h->win_words_cap + h->ref_cap, h->group_words);
             const size_t lds = (size_t)lds_words * 4;
             HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(bk_kmer_kernel, dim3(h->n_regions), dim3(BK_KT), lds, h->stream, h->params, h->ref_cap, h->win_words_cap, lds_words);
+            hipLaunchKernelGGL(bk_kmer_kernel, dim3(h->n_regions), dim3(kmer_threads), lds, h->stream, h->params, h->ref_cap, h->win_words_cap, lds_words);
             HIPCHK(h, hipGetLastError());
         }
         if (h->n_big > 0) {
             const size_t lds = (32 + 256 + (size_t)BK_K_PERM_G) * 4;
             HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(bk_kmer_kernel_g, dim3(h->n_regions), dim3(BK_KT), lds, h->stream, h->params);
+            hipLaunchKernelGGL(bk_kmer_kernel_g, dim3(h->n_regions), dim3(kmer_threads), lds, h->stream, h->params);
             HIPCHK(h, hipGetLastError());
         }
     }
@@ -392,7 +395,7 @@ static int launch(bk_handle *h, uint32_t mask)
         // Workgroup size: 512 threads (8 wavefronts, 8 look-ahead slots, 2 per CU) finish ONE batch soonest; 256 threads (4
         // wavefronts, 4 slots, 4 per CU) give more regions per CU whose serial phases overlap: +14 % regions/s once the
         // chip is full.  bk_config.reserved[1] = 256 / 512 chooses; 0 = 512 unless the batch alone fills the chip twice.
-        int threads = h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions >= 4 * h->n_cu ? 256 : 512);
+        const int threads = asm_threads;
         const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
         const size_t lds = asm_lds_bytes(h, threads);
         HIPCHK(h, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -607,14 +607,18 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
 #ifdef BK_PHASE_STAMPS
         if (BK_TID == 0) { S->acc[16] += nb; S->acc[18] += 1; }
 #endif
-        for (int sl = 0; sl < nb; sl++) {                 // unpack the reads; pre-write the bytes slot sl is predicted to add
-            const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
-            const uint32_t *w = C_.reads + (uint64_t)C_.urep[S->slot[sl].u] * C_.read_words;
-            for (int t = BK_TID; t < rl; t += BK_AT) rs[t] = (uint8_t)seq_base(w, t);
-            if (sl + 1 < nb) {
-                const int amt = S->slot[sl].amt, pb = S->slot[sl].pb, plen = S->slot[sl].plen;
-                if (S->slot[sl].kind == BK_PK_PRE) for (int t = BK_TID; t < amt; t += BK_AT) L_CSEQ[pb - amt + t] = (uint8_t)seq_base(w, t);
-                else if (S->slot[sl].kind == BK_PK_POST) for (int t = BK_TID; t < amt; t += BK_AT) L_CSEQ[pb + plen + t] = (uint8_t)seq_base(w, rl - amt + t);
+        {   // unpack the reads; pre-write the bytes slot sl is predicted to add.  One wavefront per slot: the global loads
+            // of all slots are in flight together (slot after slot they were nb dependent round trips per round)
+            const int sl = BK_TID >> 6, ln = BK_TID & 63;
+            if (sl < nb) {
+                const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
+                const uint32_t *w = C_.reads + (uint64_t)C_.urep[S->slot[sl].u] * C_.read_words;
+                for (int t = ln; t < rl; t += 64) rs[t] = (uint8_t)seq_base(w, t);
+                if (sl + 1 < nb) {
+                    const int amt = S->slot[sl].amt, pb = S->slot[sl].pb, plen = S->slot[sl].plen;
+                    if (S->slot[sl].kind == BK_PK_PRE) for (int t = ln; t < amt; t += 64) L_CSEQ[pb - amt + t] = (uint8_t)seq_base(w, t);
+                    else if (S->slot[sl].kind == BK_PK_POST) for (int t = ln; t < amt; t += 64) L_CSEQ[pb + plen + t] = (uint8_t)seq_base(w, rl - amt + t);
+                }
             }
         }
         BK_SYNC();

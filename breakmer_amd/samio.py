@@ -1,6 +1,9 @@
 """Minimal SAM/BAM reader with the attribute names the reference uses from pysam's AlignedRead / Samfile
-(sv_processor.py:12-93, 422-540): no pysam in this image, and only whole-file scans are needed here.
-BAM is read through gzip (BGZF is a multi-member gzip stream); no index is used."""
+(sv_processor.py:12-93, 422-540): no pysam in this image.  BAM is streamed through gzip (BGZF is a multi-member gzip
+stream) record by record; no index is used.  With `regions` (the [start-200, end+200) windows of the run's targets) only the
+records that can matter are kept: those overlapping a window and, found in a second streaming pass, the mates of kept
+records that lie elsewhere (bam.mate() for the discordant-pair evidence) -- a multi-GB panel BAM is then neither held in
+memory nor turned into one Python object per record."""
 from __future__ import annotations
 
 import copy
@@ -63,10 +66,17 @@ def parse_cigar(text):
     return out
 
 
+_NIB = [_SEQ16[b >> 4] + _SEQ16[b & 15] for b in range(256)]           # two bases per packed byte
+_QUAL = bytes((33 + (x if x != 255 else 0)) & 255 for x in range(256))
+
+
 class Samfile(object):
-    def __init__(self, fn, mode="r", **_kw):
+    def __init__(self, fn, mode="r", regions=None, **_kw):
+        """regions: optional [(chrom, start, end), ...] (0-based half-open, chrom with or without 'chr'): keep only the
+        records overlapping one of them, plus the mates of those records wherever they lie."""
         self.references, self._tid, self.reads = [], {}, []
         self._by_tid = self._mates = None
+        self._regions = regions
         if fn is None:
             return
         with open(fn, "rb") as f:
@@ -75,6 +85,27 @@ class Samfile(object):
             self._read_bam(fn)
         else:
             self._read_sam(fn)
+
+    # ---- region filter ------------------------------------------------------------------------------------------
+    def _windows(self):
+        """tid -> sorted [(start, end)] of the requested regions (None: keep everything)"""
+        if self._regions is None:
+            return None
+        w = {}
+        for chrom, s, e in self._regions:
+            c = str(chrom)
+            tid = self._tid.get(c, self._tid.get("chr" + c, self._tid.get(c.replace("chr", ""), -2)))
+            w.setdefault(tid, []).append((int(s), int(e)))
+        for v in w.values():
+            v.sort()
+        return w
+
+    @staticmethod
+    def _hits(wins, tid, pos, end):
+        for s, e in (wins.get(tid) or ()):
+            if pos < e and end > s:
+                return True
+        return False
 
     @classmethod
     def from_records(cls, references, reads):
@@ -100,33 +131,68 @@ class Samfile(object):
                 rnext = tid if p[6] == "=" else self._tid.get(p[6], -1)
                 self.reads.append(AlignedRead(p[0], p[1], tid, int(p[3]) - 1, p[4], parse_cigar(p[5]), rnext, int(p[7]) - 1, p[8],
                                               p[9], p[10]))
+        wins = self._windows()
+        if wins is not None:                             # SAM text is small: filter after the parse, same rule as the BAM stream
+            keep = [r for r in self.reads if self._hits(wins, r.tid, r.pos, r.pos + 1 if r.is_unmapped else r.ref_end())]
+            names = {r.qname for r in keep}
+            kept = set(map(id, keep))
+            self.reads = [r for r in self.reads if id(r) in kept or r.qname in names]
 
     def _read_bam(self, fn):
-        with gzip.open(fn, "rb") as f:
-            data = f.read()
-        assert data[:4] == b"BAM\x01", "not a BAM file"
-        o = 4
-        l_text, = struct.unpack_from("<i", data, o); o += 4 + l_text
-        n_ref, = struct.unpack_from("<i", data, o); o += 4
-        for _ in range(n_ref):
-            l_name, = struct.unpack_from("<i", data, o); o += 4
-            name = data[o:o + l_name - 1].decode(); o += l_name + 4
-            self._tid[name] = len(self.references)
-            self.references.append(name)
-        while o + 4 <= len(data):
-            bs, = struct.unpack_from("<i", data, o); o += 4
-            tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, rnext, pnext, tlen = struct.unpack_from("<iiBBHHHiiii", data, o)
-            q = o + 32
-            qname = data[q:q + l_rn - 1].decode(); q += l_rn
-            cig = []
-            for _i in range(n_cig):
-                v, = struct.unpack_from("<I", data, q); q += 4
-                cig.append((v & 0xF, v >> 4))
-            raw = data[q:q + (l_seq + 1) // 2]; q += (l_seq + 1) // 2
-            seq = "".join(_SEQ16[(raw[i >> 1] >> (4 if i % 2 == 0 else 0)) & 0xF] for i in range(l_seq))
-            qual = "".join(chr(33 + (x if x != 255 else 0)) for x in data[q:q + l_seq])
-            self.reads.append(AlignedRead(qname, flag, tid, pos, mapq, cig or None, rnext, pnext, tlen, seq, qual))
-            o += bs
+        wins = None
+        for want_names in (None, "mates"):                # pass 1: records in the windows; pass 2 (only with a filter): their mates elsewhere
+            if want_names == "mates":
+                if wins is None:
+                    break
+                names = {r.qname for r in self.reads}
+                have = {(r.qname, r.flag & 0xC0, r.tid, r.pos) for r in self.reads}
+                first_pass = self.reads
+                self.reads = []
+            with gzip.open(fn, "rb") as f:
+                assert f.read(4) == b"BAM\x01", "not a BAM file"
+                l_text, = struct.unpack("<i", f.read(4)); f.read(l_text)
+                n_ref, = struct.unpack("<i", f.read(4))
+                refs, tids = [], {}
+                for _ in range(n_ref):
+                    l_name, = struct.unpack("<i", f.read(4))
+                    name = f.read(l_name)[:-1].decode(); f.read(4)
+                    tids[name] = len(refs)
+                    refs.append(name)
+                if want_names is None:
+                    self.references, self._tid = refs, tids
+                    wins = self._windows()
+                while True:
+                    head = f.read(4)
+                    if len(head) < 4:
+                        break
+                    bs, = struct.unpack("<i", head)
+                    rec = f.read(bs)
+                    tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, rnext, pnext, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
+                    q = 32
+                    if wins is not None:
+                        if want_names is None:
+                            end = pos + 1
+                            if not (flag & 0x4) and n_cig:
+                                n = 0
+                                for v in struct.unpack_from("<%dI" % n_cig, rec, q + l_rn):
+                                    if (v & 0xF) in (0, 2, 3, 7, 8):
+                                        n += v >> 4
+                                end = pos + max(n, 1)
+                            if not self._hits(wins, tid, pos, end):
+                                continue
+                        else:
+                            qn = rec[q:q + l_rn - 1].decode()
+                            if qn not in names or (qn, flag & 0xC0, tid, pos) in have:
+                                continue
+                    qname = rec[q:q + l_rn - 1].decode(); q += l_rn
+                    cig = [(v & 0xF, v >> 4) for v in struct.unpack_from("<%dI" % n_cig, rec, q)] if n_cig else []
+                    q += 4 * n_cig
+                    nb = (l_seq + 1) // 2
+                    seq = "".join([_NIB[b_] for b_ in rec[q:q + nb]])[:l_seq]; q += nb
+                    qual = rec[q:q + l_seq].translate(_QUAL).decode("latin-1")
+                    self.reads.append(AlignedRead(qname, flag, tid, pos, mapq, cig or None, rnext, pnext, tlen, seq, qual))
+            if want_names == "mates":
+                self.reads = first_pass + self.reads       # file order within each pass; fetch() orders by position per chromosome
 
     # pysam.Samfile surface used by the reference
     def getrname(self, tid):

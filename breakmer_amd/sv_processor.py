@@ -236,7 +236,11 @@ class params(object):                                               # utils.py:5
 
     def open_bam(self, fn):                                          # one parse per alignment file, shared by all targets
         if fn not in self._bams:
-            self._bams[fn] = samio.Samfile(fn)
+            # only the records the targets can use are kept: their [start-200, end+200) windows (sv_processor.py:431) and the mates
+            regions = []
+            for ivs in self.targets.values():
+                regions.append((ivs[0][0], min(int(v[1]) for v in ivs) - 200, max(int(v[2]) for v in ivs) + 200))
+            self._bams[fn] = samio.Samfile(fn, regions=regions or None)
         return self._bams[fn]
 
     def get_kmer_size(self): return int(self.opts['kmer_size'])

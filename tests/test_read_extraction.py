@@ -112,3 +112,30 @@ def test_overlapping_targets_see_pristine_reads(tmp_path):
         assert got[1] == want[1] and got[2] == want[2] and _tuples(got[3]) == _tuples(want[3]), shift
         assert list(got[0]) == list(want[0])
     assert rx.extract_reads(shared, r.chrom, r.start, r.end, k)[1] == case["expected"]["fastq"]
+
+
+def test_region_filtered_reader_keeps_what_extraction_needs(tmp_path):
+    """Samfile(regions=...) (what params.open_bam passes: the targets' windows) streams the BAM and keeps only the records
+    in the windows plus their mates elsewhere: extraction results equal those of the unfiltered reader, although most of
+    the file (reads far away, on other chromosomes) is never turned into objects."""
+    case = CASES[0]
+    r, fn = _sam_for(case, tmp_path)
+    full = samio.Samfile(fn)
+    far = []
+    for i in range(300):                                  # bulk that no target needs: far away on the same chromosome, and on another one
+        far.append(samio.AlignedRead("far%d" % i, 99 if i % 2 else 147, full._tid[r.chrom] if i % 3 else 1, 5000000 + 37 * i, 60, [(0, 100)],
+                                     full._tid[r.chrom] if i % 3 else 1, 5000200 + 37 * i, 300, "ACGT" * 25, "I" * 100))
+    raw = _bam_bytes(full.references, full.reads + far)
+    bfn = tmp_path / "big.bam"
+    third = len(raw) // 3
+    with open(bfn, "wb") as f:
+        f.write(gzip.compress(raw[:third]) + gzip.compress(raw[third:2 * third]) + gzip.compress(raw[2 * third:]))
+    everything = samio.Samfile(str(bfn))
+    assert len(everything.reads) == len(full.reads) + 300
+    filt = samio.Samfile(str(bfn), regions=[(r.chrom, r.start - 200, r.end + 200)])
+    assert len(filt.reads) < len(everything.reads) - 250 and not any(x.qname.startswith("far") for x in filt.reads)
+    a = rx.extract_reads(everything, r.chrom, r.start, r.end, case["kmer"])
+    b = rx.extract_reads(filt, r.chrom, r.start, r.end, case["kmer"])
+    assert b[1] == a[1] == case["expected"]["fastq"] and b[2] == a[2] and _tuples(b[3]) == _tuples(a[3]) == case["expected"]["disc_reads"]
+    sfilt = samio.Samfile(fn, regions=[(r.chrom, r.start - 200, r.end + 200)])                  # the SAM-text path applies the same rule
+    assert rx.extract_reads(sfilt, r.chrom, r.start, r.end, case["kmer"])[1] == case["expected"]["fastq"]

@@ -11,8 +11,8 @@ mkdir -p "$out"
 python3 bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
 B="--cpu-sample 0 --other-configs 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py $B > "$out/stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 6 --warmup 2 $B --inflight 1 > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 6 --warmup 2 $B --inflight 1 > "$out/pmc_write.log" 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$out/pmc_sq" -- python3 bench.py --steps 6 --warmup 2 $B --inflight 1 > "$out/pmc_sq.log" 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d "$out/pmc_sq3" -- python3 bench.py --steps 8 --warmup 3 $B --inflight 3 > "$out/pmc_sq3.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 6 --warmup 2 $B --inflight 1 --wg 512 > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 6 --warmup 2 $B --inflight 1 --wg 512 > "$out/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$out/pmc_sq" -- python3 bench.py --steps 6 --warmup 2 $B --inflight 1 --wg 512 > "$out/pmc_sq.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d "$out/pmc_sq3" -- python3 bench.py --steps 12 --warmup 6 $B > "$out/pmc_sq3.log" 2>&1
 python3 tools/summarize_profile.py "$out" "$tag"

@@ -12,7 +12,7 @@ src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-KERNELS = ("bk_kmer_kernel", "bk_kmer_kernel_g", "bk_asm_kernel", "bk_sw_kernel")
+KERNELS = ("bk_kmer_kernel", "bk_kmer_kernel_g", "bk_asm_kernel", "bk_asm_kernel_w4", "bk_sw_kernel", "bk_sched_kernel")
 
 
 def one(pattern):
@@ -66,7 +66,7 @@ if os.path.isfile(bj0) and os.path.getsize(bj0):
         cells = json.loads(line).get("dp_cells_per_step")
     except Exception:
         cells = None
-for sub, label in (("pmc_sq", "one handle in flight"), ("pmc_sq3", "3 handles in flight")):
+for sub, label in (("pmc_sq", "one handle in flight, 512-thread workgroups"), ("pmc_sq3", "default: 6 handles in flight, 256-thread workgroups")):
     fn = one(sub + "/**/*_counter_collection.csv")
     if not fn:
         continue
