@@ -77,11 +77,13 @@ class Samfile(object):
         self.references, self._tid, self.reads = [], {}, []
         self._by_tid = self._mates = None
         self._regions = regions
+        self._fn, self._is_bam = fn, False
         if fn is None:
             return
         with open(fn, "rb") as f:
             magic = f.read(2)
         if magic == b"\x1f\x8b":
+            self._is_bam = True
             self._read_bam(fn)
         else:
             self._read_sam(fn)
@@ -227,6 +229,49 @@ class Samfile(object):
         # the in-place quality trimming of fq_line/trim_qual (utils.py:414-443) and the mate_is_unmapped normalisation of
         # process_reads (:16-17) never leak from one target into the next one whose window overlaps it.
         return [copy.copy(self.reads[i]) for i in ids[(pos < end) & (rend > start)]]
+
+    def covered(self, chrom, start, end):
+        """True when [start, end) of `chrom` lies inside a window whose records were all kept (always without a filter)"""
+        if self._regions is None:
+            return True
+        wins = self._windows()
+        c = str(chrom)
+        tid = self._tid.get(c, self._tid.get("chr" + c, self._tid.get(c.replace("chr", ""), -2)))
+        return any(s <= start and end <= e for s, e in (wins.get(tid) or ()))
+
+    def count_region(self, chrom, start, end, pred):
+        """number of records of the FILE overlapping [start, end) that satisfy pred(flag, mapq) -- one streaming pass, for
+        queries outside the kept windows (breakpoint coverage at a translocation partner, sv_caller.py:118-133)"""
+        c = str(chrom)
+        tid = self._tid.get(c, self._tid.get("chr" + c, self._tid.get(c.replace("chr", ""), -2)))
+        n = 0
+        if self._fn is None or not self._is_bam:
+            return sum(1 for r in self.fetch(chrom, start, end) if pred(r.flag, r.mapq))
+        with gzip.open(self._fn, "rb") as f:
+            f.read(4)
+            l_text, = struct.unpack("<i", f.read(4)); f.read(l_text)
+            n_ref, = struct.unpack("<i", f.read(4))
+            for _ in range(n_ref):
+                l_name, = struct.unpack("<i", f.read(4)); f.read(l_name + 4)
+            while True:
+                head = f.read(4)
+                if len(head) < 4:
+                    break
+                bs, = struct.unpack("<i", head)
+                rec = f.read(bs)
+                rtid, pos, l_rn, mapq, _bin, n_cig, flag = struct.unpack_from("<iiBBHHH", rec, 0)
+                if rtid != tid or pos >= end:
+                    continue
+                rend = pos + 1
+                if not (flag & 0x4) and n_cig:
+                    m = 0
+                    for v in struct.unpack_from("<%dI" % n_cig, rec, 32 + l_rn):
+                        if (v & 0xF) in (0, 2, 3, 7, 8):
+                            m += v >> 4
+                    rend = pos + max(m, 1)
+                if rend > start and pred(flag, mapq):
+                    n += 1
+        return n
 
     def mate(self, read):
         self._index()

@@ -311,6 +311,8 @@ def brkpt_coverages(tbp, coverage_fn):
 def bam_coverage_fn(bam):
     """The read filter of sv_caller.py:121-126 over `samio.Samfile.fetch`."""
     def cov(chrom, start, end):
+        if hasattr(bam, "covered") and not bam.covered(chrom, start, end):     # outside the kept windows of a region-filtered reader: count in the file
+            return bam.count_region(chrom, start, end, lambda flag, mapq: not (flag & 0x604) and mapq >= 10)
         return sum(1 for r in bam.fetch(str(chrom), start, end)
                    if not (r.is_duplicate or r.is_qcfail or r.is_unmapped or r.mapq < 10))
     return cov

@@ -139,3 +139,22 @@ def test_region_filtered_reader_keeps_what_extraction_needs(tmp_path):
     assert b[1] == a[1] == case["expected"]["fastq"] and b[2] == a[2] and _tuples(b[3]) == _tuples(a[3]) == case["expected"]["disc_reads"]
     sfilt = samio.Samfile(fn, regions=[(r.chrom, r.start - 200, r.end + 200)])                  # the SAM-text path applies the same rule
     assert rx.extract_reads(sfilt, r.chrom, r.start, r.end, case["kmer"])[1] == case["expected"]["fastq"]
+
+
+def test_coverage_outside_kept_windows_counts_in_the_file(tmp_path):
+    """Breakpoint coverage (sv_caller.py:118-133) at a position outside the windows a region-filtered reader kept (the partner
+    side of a translocation) is counted in the file, not in the kept subset."""
+    from breakmer_amd import sv_caller
+    case = CASES[0]
+    r, fn = _sam_for(case, tmp_path)
+    full = samio.Samfile(fn)
+    far = [samio.AlignedRead("far%d" % i, 99, full._tid[r.chrom], 7000000 + 10 * i, 60 if i % 4 else 5, [(0, 100)], full._tid[r.chrom], 7000300, 300,
+                             "ACGT" * 25, "I" * 100) for i in range(40)]
+    bfn = tmp_path / "c.bam"
+    with open(bfn, "wb") as f:
+        f.write(gzip.compress(_bam_bytes(full.references, full.reads + far)))
+    filt = samio.Samfile(str(bfn), regions=[(r.chrom, r.start - 200, r.end + 200)])
+    everything = samio.Samfile(str(bfn))
+    for tbp in ("chr%s:%d" % (r.chrom, 7000150), "chr%s:%d-%d" % (r.chrom, r.start + 300, 7000200)):
+        want = sv_caller.brkpt_coverages(tbp, sv_caller.bam_coverage_fn(everything))
+        assert sv_caller.brkpt_coverages(tbp, sv_caller.bam_coverage_fn(filt)) == want and any(int(x) > 0 for x in want.split(",")), tbp
