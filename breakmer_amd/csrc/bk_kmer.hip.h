@@ -319,20 +319,20 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
         uint32_t pre = bk_block_excl_scan(c, scr, &U);
 #pragma unroll
         for (int t = 0; t < 32; t++) if (isrep & (1u << t)) {
-            const uint32_t i = b + t, sl = g[t];
-            urep[pre] = i; unr[pre] = cnt_of(sl); ufl[pre] = ((rflag[i] & BK_RF_INDEL) ? BK_R_INDEL : 0) | ((rflag[i] & BK_RF_HASN) ? BK_R_HASN : 0); ulen[pre] = rlen[i];
-            p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
-            pre++;
+            urep[pre++] = b + t;
         }
     } else {
         for (uint32_t i = b; i < e; i++) c += rep_of(gslot[i]) == i;
         uint32_t pre = bk_block_excl_scan(c, scr, &U);
-        for (uint32_t i = b; i < e; i++) if (rep_of(gslot[i]) == i) {
-            uint32_t sl = gslot[i];
-            urep[pre] = i; unr[pre] = cnt_of(sl); ufl[pre] = ((rflag[i] & BK_RF_INDEL) ? BK_R_INDEL : 0) | ((rflag[i] & BK_RF_HASN) ? BK_R_HASN : 0); ulen[pre] = rlen[i];
-            p.ubuf[d.read_meta_off + pre] = 0; p.ureads[d.read_meta_off + pre] = 0; p.ufound[d.read_meta_off + pre] = -1; p.uminpos[d.read_meta_off + pre] = 0x7FFFFFFF;
-            pre++;
-        }
+        for (uint32_t i = b; i < e; i++) if (rep_of(gslot[i]) == i) urep[pre++] = i;
+    }
+    __syncthreads();
+    // only the representative list is written from the per-thread chunks (scattered); the other per-unique-read arrays
+    // are filled by index so that a wave writes whole lines
+    for (uint32_t j = tid; j < U; j += nt) {
+        const uint32_t i = urep[j], sl = gslot[i]; const uint8_t f = rflag[i];
+        unr[j] = cnt_of(sl); ufl[j] = ((f & BK_RF_INDEL) ? BK_R_INDEL : 0) | ((f & BK_RF_HASN) ? BK_R_HASN : 0); ulen[j] = rlen[i];
+        p.ubuf[d.read_meta_off + j] = 0; p.ureads[d.read_meta_off + j] = 0; p.ufound[d.read_meta_off + j] = -1; p.uminpos[d.read_meta_off + j] = 0x7FFFFFFF;
     }
     __syncthreads();
     return U;

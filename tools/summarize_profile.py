@@ -54,8 +54,9 @@ if tot:
             tj[k + "_bytes_per_launch"] = b
             print("pmc", k, "fetch KB %.0f write KB %.0f -> %.1f MB/launch" % (fe, wr, b / 1e6))
     tj["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 6 --warmup 2 --inflight 1, 256 regions); units KB; "
-                  "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of the fetched bytes; calibrated there for wide coalesced "
-                  "streams only, our loads are 4 B/lane: upper bound)")
+                  "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of the fetched bytes); the factor was re-measured for this "
+                  "repo's 4 B/lane and row-strided loads with tools/pmc_calibrate.hip (profiles/r02/pmc_calibration.txt: 0.500-0.502); "
+                  "WRITE_SIZE is exact for coalesced stores/atomics and counts a whole 64-B line per isolated 4-byte store")
     json.dump(tj, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 # ---- SQ instruction counters (one pass, one handle in flight): VALU issue roofline of the assembler
 cells = None
