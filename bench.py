@@ -46,6 +46,7 @@ def parse(argv=None):
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--cpu-sample", type=int, default=24, help="regions timed through the CPU oracle on ONE core (0 = skip the CPU baseline)")
     ap.add_argument("--inflight", type=int, default=6, help="steps in flight (independent batches on separate HIP streams)")
+    ap.add_argument("--max-candidates", type=int, default=0, help="diagnostic: device cap on one k-mer's candidate reads (0 = library default 2048); sizes the assembler's LDS and so its workgroups per CU")
     ap.add_argument("--wg", type=int, default=256, help="assembler workgroup size of the batches in flight (256: 4 per CU; 512: 2 per CU); the one-step-at-a-time pass always uses 512")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (testing)")
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
@@ -149,17 +150,20 @@ def usable_cores():
     return n
 
 
-def time_runner(synth, regions, kmer):
+def time_runner(synth, regions, kmer, cycles=1):
     """the retained driver surface end to end (breakmer_amd.sv_processor.runner.run: per-target objects, batches on two handles,
-    submit = host 2-bit packing + H2D included, native call tail, rows in target order), code-matrix inputs, no output files"""
+    submit = host 2-bit packing + H2D included, native call tail, rows in target order), code-matrix inputs, no output files.
+    cycles > 1: the same regions again under further target names (more batches per run without more host memory)"""
     import tempfile
     from breakmer_amd import sv_processor as sp
     d = tempfile.mkdtemp()
     bed, genes, data = [], ["header"], {}
-    for r in regions:
-        bed.append("\t".join([r.chrom, str(r.start), str(r.end), r.name, "exon"]))
-        genes.append("\t".join(["0", r.name, "chr" + r.chrom, "+", str(r.start), str(r.end)] + ["x"] * 6 + [r.name]))
-        data[r.name.upper()] = sp.RegionData(r.read_ids, None, None, None, r.window_str, [], r.disc_reads, read_codes=r.reads, read_lens=r.read_lens)
+    for c in range(cycles):
+        for r in regions:
+            name = r.name + ("C%d" % c if c else "")
+            bed.append("\t".join([r.chrom, str(r.start), str(r.end), name, "exon"]))
+            genes.append("\t".join(["0", name, "chr" + r.chrom, "+", str(r.start), str(r.end)] + ["x"] * 6 + [name]))
+            data[name.upper()] = sp.RegionData(r.read_ids, None, None, None, r.window_str, [], r.disc_reads, read_codes=r.reads, read_lens=r.read_lens)
     open(os.path.join(d, "targets.bed"), "w").write("\n".join(bed) + "\n")
     open(os.path.join(d, "genes.txt"), "w").write("\n".join(genes) + "\n")
     cfg = {"analysis_name": "bench", "targets_bed_file": os.path.join(d, "targets.bed"), "gene_annotation_file": os.path.join(d, "genes.txt"),
@@ -167,8 +171,10 @@ def time_runner(synth, regions, kmer):
     t0 = time.perf_counter()
     rows = sp.runner(cfg, region_data=data).run()
     dt = time.perf_counter() - t0
-    return {"value": round(len(regions) / dt, 1), "unit": "regions/s", "regions": len(regions), "rows": len(rows), "seconds": round(dt, 3),
-            "note": "runner.run() wall time: host packing + H2D + GPU stages + native call tail + per-target Python objects (no output files); "
+    return {"value": round(len(data) / dt, 1), "unit": "regions/s", "regions": len(data), "rows": len(rows), "seconds": round(dt, 3),
+            "batches": (len(data) + 255) // 256,
+            "note": "runner.run() wall time: host packing + H2D + GPU stages + native call tail + per-target Python objects (no output files), "
+                    "handles created and destroyed inside; 2 x 256 distinct regions cycled under 8 sets of target names; "
                     "the timed `value` above excludes submit (inputs resident, SURVEY 8d)"}
 
 
@@ -236,7 +242,7 @@ def main():
     engs = []
     submit_ms = []
     for _ in range(max(1, a.inflight)):                # one handle (= one HIP stream + its own buffers) per step in flight
-        e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local, flags=a.flags, wg_threads=a.wg)
+        e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local, flags=a.flags, wg_threads=a.wg, max_candidates=a.max_candidates)
         t0 = time.perf_counter()
         e.submit(ins)
         submit_ms.append((time.perf_counter() - t0) * 1e3)
@@ -422,7 +428,7 @@ def main():
         }
         if world == 1 and a.other_configs:
             try:
-                out["runner_end_to_end"] = time_runner(synth, regions + [synth.make_region(n_regions + i, depth=a.depth, L=a.read_len, sv_type="del") for i in range(n_regions)], a.kmer)
+                out["runner_end_to_end"] = time_runner(synth, regions + [synth.make_region(n_regions + i, depth=a.depth, L=a.read_len, sv_type="del") for i in range(n_regions)], a.kmer, cycles=8)
             except Exception as ex:
                 out["runner_end_to_end"] = {"error": repr(ex)}
         # ---- other BASELINE configs on one GPU (not the headline; whole path incl. call tail, inputs resident) -----

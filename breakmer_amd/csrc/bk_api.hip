@@ -34,6 +34,7 @@ using at512::bk_nw_batch_kernel;
 #include <cstdlib>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -76,6 +77,8 @@ struct bk_handle {
     uint32_t group_words = 0;                   // LDS words wanted by the in-LDS read-grouping table (largest region that qualifies)
     // host mirrors
     std::vector<BkRegionDesc> h_desc; std::vector<BkRegionWork> h_work; HostVec h_out;
+    HostVec hs_reads, hs_rlen, hs_rflag;        // pinned staging of a submit (packed reads, lengths, flags): kept and reused, so a
+                                                // submit neither page-faults a fresh 100 MB vector nor copies from pageable memory
     std::vector<BkPartnerDesc> h_part;
     std::vector<std::vector<std::string>> h_targets;      // per region: target window + partner windows (ASCII), for PSL assembly
     uint32_t max_win = 0;
@@ -86,7 +89,17 @@ struct bk_handle {
     int n_failed = 0;                                // regions of the last run that hit a device limit (status per region)
     BkParams params{};
     bkcall::Context call_ctx; bool have_ctx = false; std::string calls_blob;
+    // BK_SUBMIT_ASYNC: the submit runs on this thread; every later call on the handle joins it first (and reports its error)
+    std::thread worker; bool has_worker = false; int worker_rc = 0; std::vector<bk_region> worker_regions;
 };
+
+static int join_pending(bk_handle *h)
+{
+    if (!h || !h->has_worker) return 0;
+    h->worker.join(); h->has_worker = false;
+    return h->worker_rc;
+}
+#define BK_JOIN(h) do { const int jr_ = join_pending(h); if (jr_ != BK_OK) return jr_; } while (0)
 
 #define HIPCHK(h, call)                                                                              \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BK_E_HIP; } } while (0)
@@ -127,12 +140,13 @@ extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
 extern "C" int bk_destroy(bk_handle *h)
 {
     if (!h) return BK_OK;
+    (void)join_pending(h);
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
                       &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist, &h->d_nlist};
     for (auto b : bufs) b->release();
-    h->h_out.release();
+    h->h_out.release(); h->hs_reads.release(); h->hs_rlen.release(); h->hs_rflag.release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -181,9 +195,27 @@ template <class T> static hipError_t upload(bk_handle *h, DevBuf &b, const std::
     return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream);
 }
 
+static hipError_t upload_raw(bk_handle *h, DevBuf &b, const void *src, size_t bytes)
+{
+    hipError_t e = b.ensure(std::max<size_t>(bytes, 256));
+    if (e != hipSuccess || !bytes) return e;
+    return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream);
+}
+
 static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags);
-extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions) { return submit_regions(h, regions, n_regions, 0); }
-extern "C" int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags) { return submit_regions(h, regions, n_regions, flags); }
+extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions) { (void)join_pending(h); return submit_regions(h, regions, n_regions, 0); }
+extern "C" int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags)
+{
+    (void)join_pending(h);                               // an unfinished earlier submit is superseded; its error no longer matters
+    if (!(flags & BK_SUBMIT_ASYNC)) return submit_regions(h, regions, n_regions, flags);
+    if (!h || !regions || n_regions <= 0) return fail(h, BK_E_ARG, "bk_submit_regions: bad argument");
+    // the bk_region array is copied; the sequences it points to stay with the caller until the next call on this handle returns
+    h->worker_regions.assign(regions, regions + n_regions);
+    h->submitted = false; h->ran = false; h->fetched = false; h->synced = false;
+    h->worker_rc = BK_OK; h->has_worker = true;
+    h->worker = std::thread([h, n_regions, flags]() { h->worker_rc = submit_regions(h, h->worker_regions.data(), n_regions, flags & ~(uint32_t)BK_SUBMIT_ASYNC); });
+    return BK_OK;
+}
 
 static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags)
 {
@@ -194,30 +226,57 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     // a failed submit leaves the handle without a batch (never the old device results paired with new host mirrors):
     // the new host mirrors are built in locals and swapped in on success only
     h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->hold_snapshot = false; h->have_ctx = false;
-    std::vector<uint32_t> reads, sc, win; std::vector<uint16_t> rlen, sclen; std::vector<uint8_t> rflag;
+    std::vector<uint32_t> sc, win; std::vector<uint16_t> sclen;
     std::vector<BkRegionDesc> n_desc(n_regions, BkRegionDesc{}); std::vector<BkPartnerDesc> n_part; std::vector<std::vector<std::string>> n_targets(n_regions);
     uint32_t n_max_win = 0; uint64_t n_alg_bytes = 0;
     uint64_t dd_total = 0; uint32_t max_w = 0;
     size_t tot_reads = 0, tot_words = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;
+    const int nth = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), n_regions}));
+    auto run_parallel = [&](const std::function<void()> &fn) {
+        if (nth == 1) { fn(); return; }
+        std::vector<std::thread> th; for (int t = 0; t < nth; t++) th.emplace_back(fn); for (auto &x : th) x.join();
+    };
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r];
         if (g.n_reads < 0 || !g.window || g.window_len <= 0 || (g.n_reads > 0 && (!g.reads || !g.read_lens))) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": missing reads/window");
         if (g.n_reads >= (1 << 22)) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 4M reads in one region");
-        uint32_t maxl = 0; for (int i = 0; i < g.n_reads; i++) maxl = std::max<uint32_t>(maxl, g.read_lens[i]);
-        if ((int)maxl > h->cfg.max_read_len) return fail(h, BK_E_LIMIT, "bk_submit_regions: read longer than max_read_len");
-        tot_reads += g.n_reads; tot_words += (size_t)g.n_reads * ((maxl + 15) / 16 + 1);
+    }
+    // per region: longest read, number of bases (one pass over the lengths, regions in parallel)
+    std::vector<uint32_t> r_maxl(n_regions, 0); std::vector<uint64_t> r_bases(n_regions, 0);
+    {
+        std::atomic<int> next{0};
+        run_parallel([&]() {
+            for (;;) {
+                const int r = next.fetch_add(1);
+                if (r >= n_regions) break;
+                const bk_region &g = regions[r];
+                uint32_t maxl = 0; uint64_t bases = 0;
+                for (int i = 0; i < g.n_reads; i++) { const uint32_t l = g.read_lens[i]; maxl = std::max(maxl, l); bases += l; }
+                r_maxl[r] = maxl; r_bases[r] = bases;
+            }
+        });
+    }
+    for (int r = 0; r < n_regions; r++) {
+        const bk_region &g = regions[r];
+        if ((int)r_maxl[r] > h->cfg.max_read_len) return fail(h, BK_E_LIMIT, "bk_submit_regions: read longer than max_read_len");
+        tot_reads += g.n_reads; tot_words += (size_t)g.n_reads * ((r_maxl[r] + 15) / 16 + 1);
         if (g.n_sc > 0) { uint32_t ms = 0; for (int i = 0; i < g.n_sc; i++) ms = std::max<uint32_t>(ms, g.sc_lens[i]); tot_sc += g.n_sc; tot_scw += (size_t)g.n_sc * ((ms + 15) / 16 + 1); }
         tot_win += (g.window_len + 15) / 16 + 2; for (int q = 0; q < g.n_partners; q++) tot_win += (g.partner_lens[q] + 15) / 16 + 2;
     }
-    reads.reserve(tot_words); rlen.reserve(tot_reads); rflag.reserve(tot_reads); sc.reserve(tot_scw); sclen.reserve(tot_sc); win.reserve(tot_win);
+    HIPCHK(h, hipStreamSynchronize(h->stream));          // the staging buffers may still feed the copies of the previous submit
+    HIPCHK(h, h->hs_reads.resize(std::max<size_t>(tot_words, 1) * 4)); HIPCHK(h, h->hs_rlen.resize(std::max<size_t>(tot_reads, 1) * 2)); HIPCHK(h, h->hs_rflag.resize(std::max<size_t>(tot_reads, 1)));
+    uint32_t *reads = (uint32_t *)h->hs_reads.data(); uint16_t *rlen = (uint16_t *)h->hs_rlen.data(); uint8_t *rflag = h->hs_rflag.data();
+    if (!tot_words) reads[0] = 0;
+    if (!tot_reads) { rlen[0] = 0; rflag[0] = 0; }
+    sc.reserve(tot_scw); sclen.reserve(tot_sc); win.reserve(tot_win);
+    size_t reads_top = 0, meta_top = 0;
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r]; BkRegionDesc &d = n_desc[r];
-        uint32_t maxl = 0; for (int i = 0; i < g.n_reads; i++) maxl = std::max<uint32_t>(maxl, g.read_lens[i]);
+        const uint32_t maxl = r_maxl[r];
         d.n_reads = g.n_reads; d.read_words = (maxl + 15) / 16 + 1;          // +1: k-mer extraction may touch one word past the end
         d.max_len = maxl;
-        d.reads_word_off = reads.size(); d.read_meta_off = rlen.size();
-        reads.resize(reads.size() + (size_t)d.n_reads * d.read_words);
-        for (int i = 0; i < g.n_reads; i++) { rlen.push_back(g.read_lens[i]); rflag.push_back(g.indel_only && g.indel_only[i] ? BK_RF_INDEL : 0); }   // the reads themselves are packed below, in parallel
+        d.reads_word_off = reads_top; d.read_meta_off = meta_top;            // reads, lengths and flags are filled below, regions in parallel
+        reads_top += (size_t)d.n_reads * d.read_words; meta_top += d.n_reads;
         d.n_sc = g.n_sc < 0 ? -1 : g.n_sc; d.sc_word_off = sc.size(); d.sc_meta_off = sclen.size(); d.sc_words = 1;
         if (g.n_sc > 0) {
             uint32_t ms = 0; for (int i = 0; i < g.n_sc; i++) ms = std::max<uint32_t>(ms, g.sc_lens[i]);
@@ -244,26 +303,23 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
         uint32_t cap = 64; while ((uint64_t)cap * 7 < (uint64_t)std::max(g.n_reads, 1) * 10) cap <<= 1;      // load factor <= 0.7 even if every read is unique
         d.dedup_cap = cap; d.dedup_off = dd_total; dd_total += cap;
         // algorithmic HBM bytes per region: 2-bit reads + 4 B/read offsets + window fwd+rc + ~2 KB of output
-        uint64_t bases = 0; for (int i = 0; i < g.n_reads; i++) bases += g.read_lens[i];
-        n_alg_bytes += (bases + 3) / 4 + 4ull * g.n_reads + 2ull * ((g.window_len + 3) / 4) + 2048;
+        n_alg_bytes += (r_bases[r] + 3) / 4 + 4ull * g.n_reads + 2ull * ((g.window_len + 3) / 4) + 2048;
     }
     const auto t_pack0 = std::chrono::steady_clock::now();
     std::vector<std::vector<uint32_t>> region_nl;
     {   // 2-bit packing of the reads: the bulk of the host work of a submit (0.4 GB of ASCII for 256 regions), regions are independent
         std::atomic<int> next{0}, bad_region{-1}, bad_read{-1};
         region_nl.assign(n_regions, {});
-        auto pack = [&]() {
+        run_parallel([&]() {
             for (;;) {
                 const int r = next.fetch_add(1);
                 if (r >= n_regions) break;
                 const bk_region &g = regions[r]; const BkRegionDesc &d = n_desc[r];
+                for (int i = 0; i < g.n_reads; i++) { rlen[d.read_meta_off + i] = g.read_lens[i]; rflag[d.read_meta_off + i] = g.indel_only && g.indel_only[i] ? BK_RF_INDEL : 0; }
                 for (int i = 0; i < g.n_reads; i++)
-                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads.data() + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i, read_codes)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
+                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i, read_codes)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
             }
-        };
-        const int nth = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), n_regions}));
-        if (nth == 1) pack();
-        else { std::vector<std::thread> th; for (int t = 0; t < nth; t++) th.emplace_back(pack); for (auto &x : th) x.join(); }
+        });
         if (bad_region >= 0) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_region.load()) + " read " + std::to_string(bad_read.load()) + ": base other than A/C/G/T/N");
     }
     // N calls: one sorted list per region (reads are packed in order, positions ascending), flag on the reads that have any
@@ -275,7 +331,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
         nlist.insert(nlist.end(), region_nl[r].begin(), region_nl[r].end());
     }
     if (nlist.empty()) nlist.push_back(0);
-    h->total_reads = rlen.size(); h->n_regions = n_regions;
+    h->total_reads = tot_reads; h->n_regions = n_regions;
     { uint32_t mx = 0; for (auto &d : n_desc) mx = std::max(mx, d.max_len); h->eff_max_read = (int)std::min<uint32_t>((uint32_t)h->cfg.max_read_len, std::max<uint32_t>(64, (mx + 63) / 64 * 64)); }
     // reference k-mer table geometry (LDS): load factor <= 0.5.  Windows beyond the LDS budget (whole-gene targets)
     // are flagged `big` and go through bk_kmer_kernel_g (table in the scratch arena).
@@ -299,14 +355,13 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
         if (!d.big && d.n_reads < 16383u && need <= 36864u) h->group_words = std::max(h->group_words, need);
     }
     h->big_bytes = big_bytes;
-    if (rlen.empty()) { rlen.push_back(0); rflag.push_back(0); }
-    if (reads.empty()) reads.push_back(0);
     if (sc.empty()) sc.push_back(0);
     if (sclen.empty()) sclen.push_back(0);
     if (n_part.empty()) n_part.push_back(BkPartnerDesc{0, 0, 0});
     const auto t_h2d0 = std::chrono::steady_clock::now();
     HIPCHK(h, upload(h, h->d_desc, n_desc)); HIPCHK(h, upload(h, h->d_part, n_part));
-    HIPCHK(h, upload(h, h->d_reads, reads)); HIPCHK(h, upload(h, h->d_rlen, rlen)); HIPCHK(h, upload(h, h->d_rflag, rflag));
+    HIPCHK(h, upload_raw(h, h->d_reads, reads, std::max<size_t>(tot_words, 1) * 4)); HIPCHK(h, upload_raw(h, h->d_rlen, rlen, std::max<size_t>(tot_reads, 1) * 2));
+    HIPCHK(h, upload_raw(h, h->d_rflag, rflag, std::max<size_t>(tot_reads, 1)));
     HIPCHK(h, upload(h, h->d_sc, sc)); HIPCHK(h, upload(h, h->d_sclen, sclen)); HIPCHK(h, upload(h, h->d_win, win));
     HIPCHK(h, upload(h, h->d_nlist, nlist));
     const size_t nr = std::max<size_t>(h->total_reads, 1), nd = std::max<uint64_t>(dd_total, 1);
@@ -428,6 +483,7 @@ static int launch(bk_handle *h, uint32_t mask)
 
 extern "C" int bk_run(bk_handle *h, uint32_t stage_mask)
 {
+    BK_JOIN(h);
     if (!h) return BK_E_ARG;
     if (!h->submitted) return fail(h, BK_E_STATE, "bk_run: no regions submitted");
     if ((stage_mask & BK_STAGE_ASSEMBLE) && !(stage_mask & BK_STAGE_KMER)) return fail(h, BK_E_ARG, "bk_run: BK_STAGE_ASSEMBLE needs BK_STAGE_KMER in the same run");
@@ -452,6 +508,7 @@ static const char *st_name(int s)
 // wait, read back the work records and the result arena; grow arenas and rerun when they overflowed
 extern "C" int bk_sync(bk_handle *h)
 {
+    BK_JOIN(h);
     if (!h) return BK_E_ARG;
     if (!h->ran) return fail(h, BK_E_STATE, "bk_sync: nothing was run");
     if (h->synced) return BK_OK;
@@ -507,6 +564,7 @@ static int fetch(bk_handle *h)
 
 extern "C" int bk_last_kernel_ms(bk_handle *h, int which, float *ms)
 {
+    BK_JOIN(h);
     if (!h || !ms || which < 0 || which > 3) return BK_E_ARG;
     int rc = bk_sync(h); if (rc != BK_OK) return rc;
     *ms = h->ms[which]; return BK_OK;
@@ -519,6 +577,7 @@ static void key_to_str(uint64_t lo, uint64_t hi, int k, char *out)
 
 extern "C" int bk_get_kmer_count(bk_handle *h, int32_t region, int32_t *n_mers, int32_t *n_unique)
 {
+    BK_JOIN(h);
     if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
     int rc = bk_sync(h); if (rc != BK_OK) return rc;
     if (n_mers) *n_mers = (int32_t)h->h_work[region].M;
@@ -528,6 +587,7 @@ extern "C" int bk_get_kmer_count(bk_handle *h, int32_t region, int32_t *n_mers, 
 
 extern "C" int bk_get_kmers(bk_handle *h, int32_t region, char *mers, int32_t *counts, int32_t cap)
 {
+    BK_JOIN(h);
     if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
     int rc = bk_sync(h); if (rc != BK_OK) return rc;
     const BkRegionWork &w = h->h_work[region];
@@ -556,6 +616,7 @@ static const BkContigRec *find_contig(bk_handle *h, int region, int contig)
 
 extern "C" int bk_get_region_status(bk_handle *h, int32_t region, int32_t *status, const char **text)
 {
+    BK_JOIN(h);
     if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
     int rc = bk_sync(h); if (rc != BK_OK) return rc;
     const int s = h->h_work[region].status;
@@ -566,6 +627,7 @@ extern "C" int bk_get_region_status(bk_handle *h, int32_t region, int32_t *statu
 
 extern "C" int bk_get_contig_count(bk_handle *h, int32_t region, int32_t *n)
 {
+    BK_JOIN(h);
     if (!h || !n || region < 0 || region >= h->n_regions) return BK_E_ARG;
     int rc = bk_sync(h); if (rc != BK_OK) return rc;
     *n = (int32_t)h->h_work[region].n_contigs; return BK_OK;
@@ -573,6 +635,7 @@ extern "C" int bk_get_contig_count(bk_handle *h, int32_t region, int32_t *n)
 
 extern "C" int bk_get_contig_info(bk_handle *h, int32_t region, int32_t contig, bk_contig_info *info)
 {
+    BK_JOIN(h);
     if (!h || !info || region < 0 || region >= h->n_regions) return BK_E_ARG;
     int rc = fetch(h); if (rc != BK_OK) return rc;
     const BkContigRec *c = find_contig(h, region, contig);
@@ -583,6 +646,7 @@ extern "C" int bk_get_contig_info(bk_handle *h, int32_t region, int32_t contig, 
 
 extern "C" int bk_get_contig(bk_handle *h, int32_t region, int32_t contig, char *seq, int32_t *indel_only, int32_t *others, int32_t *kmer_locs, char *kmers, int32_t *reads)
 {
+    BK_JOIN(h);
     if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
     int rc = fetch(h); if (rc != BK_OK) return rc;
     const BkContigRec *c = find_contig(h, region, contig);
@@ -688,6 +752,7 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
 
 extern "C" int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl *hits, int32_t cap)
 {
+    BK_JOIN(h);
     if (!h || region < 0 || region >= h->n_regions || !hits) return BK_E_ARG;
     int rc = fetch(h); if (rc != BK_OK) return rc;
     const BkContigRec *c = find_contig(h, region, contig);
@@ -701,6 +766,7 @@ extern "C" int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl 
 
 extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
 {
+    BK_JOIN(h);
     if (!h || !value) return BK_E_ARG;
     if (which == 20 || which == 21) { *value = (uint64_t)((which == 20 ? h->submit_pack_ms : h->submit_h2d_ms) * 1000.0); return BK_OK; }
     int rc = bk_sync(h); if (rc != BK_OK) return rc;
@@ -726,6 +792,7 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
 extern "C" int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, const uint32_t *off1, const uint32_t *len1,
                            const uint32_t *off2, const uint32_t *len2, int32_t n_pairs, int32_t reps, int32_t transposed, int32_t *out, float *ms)
 {
+    BK_JOIN(h);
     if (!h || !seqs || n_pairs <= 0 || !out) return BK_E_ARG;
     HIPCHK(h, hipSetDevice(h->dev));
     std::vector<uint8_t> codes(seq_bytes);
@@ -776,6 +843,7 @@ extern "C" int bk_call_text(const char *text, char *out, size_t cap, int *target
 
 extern "C" int bk_fetch(bk_handle *h)
 {
+    BK_JOIN(h);
     if (!h) return BK_E_ARG;
     if (!h->ran) return fail(h, BK_E_STATE, "bk_fetch: nothing was run");
     h->hold_snapshot = false;
@@ -787,6 +855,7 @@ extern "C" int bk_fetch(bk_handle *h)
 // batch: annotation/query_region context for the submitted regions (text, bk_call.h), then calls for every contig
 extern "C" int bk_set_call_context(bk_handle *h, const char *text)
 {
+    BK_JOIN(h);
     if (!h || !text) return BK_E_ARG;
     h->call_ctx = bkcall::Context(); std::string err;
     if (!bkcall::parse_context(text, h->call_ctx, err)) return fail(h, BK_E_ARG, "bk_set_call_context: " + err);
@@ -799,6 +868,7 @@ extern "C" int bk_set_call_context(bk_handle *h, const char *text)
 // one line per called contig: "<region>\t<contig index>\t<13 tab-separated fields>".
 extern "C" int bk_call(bk_handle *h)
 {
+    BK_JOIN(h);
     if (!h) return BK_E_ARG;
     if (!h->have_ctx) return fail(h, BK_E_STATE, "bk_call: bk_set_call_context first");
     int rc = fetch(h); if (rc != BK_OK) return rc;
@@ -848,6 +918,7 @@ extern "C" int bk_call(bk_handle *h)
 
 extern "C" int bk_get_calls(bk_handle *h, char *buf, size_t cap, size_t *needed)
 {
+    BK_JOIN(h);
     if (!h) return BK_E_ARG;
     if (needed) *needed = h->calls_blob.size() + 1;
     if (buf && cap >= h->calls_blob.size() + 1) memcpy(buf, h->calls_blob.c_str(), h->calls_blob.size() + 1);

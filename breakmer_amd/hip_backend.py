@@ -163,6 +163,37 @@ class RegionInput(object):
         g.partner_lens = self._plens.ctypes.data
 
 
+class KmerStrings(object):
+    """The k-mers of one contig as a read-only sequence of str over the bytes the library returned; a string is only made
+    when an element is asked for (the driver's per-target objects rarely look at them)."""
+    __slots__ = ("_b", "_k", "_n")
+
+    def __init__(self, raw, k, n):
+        self._b, self._k, self._n = raw, k, n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return self._b[i * self._k:(i + 1) * self._k].decode()
+
+    def __iter__(self):
+        b, k = self._b, self._k
+        return (b[i * k:(i + 1) * k].decode() for i in range(self._n))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return repr(list(self))
+
+
 class Engine(object):
     """One handle = one GPU + one stream (bk_create ... bk_destroy)."""
 
@@ -195,6 +226,7 @@ class Engine(object):
         if self.h:
             self.L.bk_destroy(self.h)
             self.h = C.c_void_p()
+            self._inputs = None
 
     def __del__(self):
         try:
@@ -202,7 +234,9 @@ class Engine(object):
         except Exception:
             pass
 
-    def submit(self, regions):
+    def submit(self, regions, wait=True):
+        """wait=False: the library packs and copies on its own thread (BK_SUBMIT_ASYNC); the inputs are kept alive here and
+        any error of the submit is raised by the next call on this engine."""
         arr = (BkRegion * len(regions))()
         for g, r in zip(arr, regions):
             r.fill(g)
@@ -214,8 +248,11 @@ class Engine(object):
                     r.codes = False
                     r.fill(g)
             kinds = {False}
-        flags = 1 if kinds == {True} else 0
+        flags = (1 if kinds == {True} else 0) | (0 if wait else 2)
         self._chk(self.L.bk_submit_regions_ex(self.h, arr, len(regions), flags), "bk_submit_regions")
+        # the sequences must outlive the library's packing thread (the previous batch's were still referenced during the call
+        # above, which waits for an unfinished earlier submit)
+        self._inputs = None if wait else (arr, regions)
         self.n_regions = len(regions)
 
     def run(self, stages=BK_STAGE_KMER | BK_STAGE_ASSEMBLE, sync=True):
@@ -254,7 +291,8 @@ class Engine(object):
         self._chk(self.L.bk_get_kmers(self.h, region, mers.ctypes.data, cnt.ctypes.data, n.value), "bk_get_kmers")
         return [mers[i * self.k:(i + 1) * self.k].tobytes().decode() for i in range(n.value)], cnt[:n.value].copy(), u.value
 
-    def contigs(self, region):
+    def contigs(self, region, lazy_kmers=False):
+        """records of the contigs of one region; lazy_kmers: the 'kmers' entry is a KmerStrings view instead of a list"""
         n = C.c_int32()
         self._chk(self.L.bk_get_contig_count(self.h, region, C.byref(n)), "bk_get_contig_count")
         out = []
@@ -271,7 +309,8 @@ class Engine(object):
                                            km.ctypes.data, rd.ctypes.data), "bk_get_contig")
             out.append({"seq": seq[:info.seq_len].tobytes().decode(), "indel_only": io[:info.counts_len].tolist(),
                         "others": ot[:info.counts_len].tolist(), "kmer_locs": kl[:info.seq_len].tolist(),
-                        "kmers": [km[i * self.k:(i + 1) * self.k].tobytes().decode() for i in range(info.n_kmers)],
+                        "kmers": (KmerStrings(km[:info.n_kmers * self.k].tobytes(), self.k, info.n_kmers) if lazy_kmers
+                                  else [km[i * self.k:(i + 1) * self.k].tobytes().decode() for i in range(info.n_kmers)]),
                         "reads": rd[:info.n_reads].tolist(), "total_reads": info.total_reads, "n_hits": info.n_hits})
         return out
 

@@ -9,8 +9,8 @@ class assembly_counts(object):
     """Per-base supporting-read counts of a contig (sv_assembly.py:160-221), read-only view."""
 
     def __init__(self, indel_only, others):
-        self.indel_only = list(indel_only)
-        self.others = list(others)
+        self.indel_only = indel_only if isinstance(indel_only, list) else list(indel_only)     # read-only view: no copy of a list
+        self.others = others if isinstance(others, list) else list(others)
 
     def get_counts(self, p1, p2, sv_type):                          # sv_assembly.py:167-176
         if sv_type in ('indel', 'rearr'):
@@ -43,13 +43,34 @@ class _Aseq(object):
         self.counts = counts
 
 
+class _KmerTuples(object):
+    """contig.kmers of the reference is a list of (kmer, ...) tuples of which only x[0] and len() are read downstream
+    (sv_processor.py:760-761, 864); this is that view over a sequence of k-mer strings, tuples made when asked for."""
+    __slots__ = ("_m",)
+
+    def __init__(self, mers):
+        self._m = mers
+
+    def __len__(self):
+        return len(self._m)
+
+    def __getitem__(self, i):
+        return [(m,) for m in self._m[i]] if isinstance(i, slice) else (self._m[i],)
+
+    def __iter__(self):
+        return ((m,) for m in self._m)
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
 class contig(object):
     """What sv_processor.contig copies from an assembled contig (sv_processor.py:737-741)."""
 
     def __init__(self, seq, indel_only, others, kmer_locs, kmers, reads, kmer_len):
         self.aseq = _Aseq(seq, assembly_counts(indel_only, others))
-        self.kmer_locs = list(kmer_locs)
-        self.kmers = [(m,) for m in kmers]          # only x[0] and len() are read downstream (sv_processor.py:760-761, 864)
+        self.kmer_locs = kmer_locs if isinstance(kmer_locs, list) else list(kmer_locs)
+        self.kmers = _KmerTuples(kmers)
         self._reads = None
         self._read_src = reads                      # (source sequence, indices) or an iterable of fq_read: the set is built when asked for
         self.kmer_len = kmer_len
@@ -73,6 +94,10 @@ def contigs_from_engine(engine, region, reads, kmer_len):
     `reads`: list of fq_read in FASTQ order (the representative of each supporting sequence is
     indexed by its position)."""
     out = []
-    for c in engine.contigs(region):
+    try:
+        recs = engine.contigs(region, lazy_kmers=True)
+    except TypeError:                               # an engine without the lazy view (tests/fake_engine.py)
+        recs = engine.contigs(region)
+    for c in recs:
         out.append(contig(c["seq"], c["indel_only"], c["others"], c["kmer_locs"], c["kmers"], (reads, c["reads"]), kmer_len))
     return out

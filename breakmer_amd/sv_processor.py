@@ -607,8 +607,9 @@ class runner(object):                                               # sv_process
             self.targets[n] = target(self.params.targets[n], self.params, self.region_data.get(n))
         return names
 
-    def _start_batch(self, eng, live):
-        """submit one batch of targets and start the GPU stages (asynchronous where the engine supports it)"""
+    def _submit_batch(self, eng, live):
+        """hand one batch of targets to the library; with a HIP engine the 2-bit packing and the copies run on the library's
+        own thread (BK_SUBMIT_ASYNC) while this thread goes on with the previous batch"""
         from . import hip_backend
         ins = []
         for i, t in enumerate(live):
@@ -617,7 +618,15 @@ class runner(object):                                               # sv_process
             reads = d.read_codes if d.read_codes is not None else d.read_seqs
             ins.append(hip_backend.RegionInput(reads, d.window, read_lens=d.read_lens, indel_only=_np.asarray(d.indel_only, dtype=_np.uint8), sc_seqs=d.sc_seqs,
                                                partners=[p[4] for p in d.partners]))
-        eng.submit(ins)
+        try:
+            eng.submit(ins, wait=False)
+        except TypeError:
+            eng.submit(ins)
+
+    def _launch_batch(self, eng, live):
+        """start the GPU stages of a submitted batch (asynchronous where the engine supports it) and give the library the
+        call context of its regions"""
+        from . import hip_backend
         try:
             eng.run(hip_backend.BK_STAGE_ALL, sync=False)
         except TypeError:
@@ -628,6 +637,10 @@ class runner(object):                                               # sv_process
             for i, t in enumerate(live):
                 lines += cc.region_lines(i, t.get_values(), t.repeat_mask, t.disc_reads, t.partner_windows, t.data.read_ids)
             eng.set_call_context("\n".join(lines) + "\n")
+
+    def _start_batch(self, eng, live):
+        self._submit_batch(eng, live)
+        self._launch_batch(eng, live)
 
     def _finish_batch(self, eng, live, order):
         """wait for a batch, then the reference's per-target sequence compare_kmers -> resolve_sv -> summary -> files"""
@@ -674,17 +687,13 @@ class runner(object):                                               # sv_process
         order = {n: i for i, n in enumerate(names)}
         mine = [n for i, n in enumerate(names) if i % self.world == self.rank]
         # Batching front-end: the reference handles one target at a time; here bounded batches of targets go through the HIP
-        # library on alternating handles, so that the host work of batch i+1 (read extraction, 2-bit packing, H2D) overlaps
-        # the kernels of batch i and the results of batch i are picked up while batch i+1 runs.
+        # library on two alternating handles.  Batch i+1 is handed to the library first (its 2-bit packing and H2D copies
+        # run on a thread of the library), then this thread picks up batch i (call tail, per-target objects, files), then
+        # the kernels of batch i+1 are launched; batches finish in the order they were started.
         bsz = max(1, int(self.params.opts.get('batch_regions', 256)))
-        nh = 1 if len(mine) <= bsz else 2
-        engines = [None] * nh
-        in_flight = [None] * nh                                     # per handle: the targets of the batch it is running
+        engines = [None, None]
+        prev = None                                                 # (handle, targets) of the batch that is running
         for b0 in range(0, len(mine), bsz):
-            slot = (b0 // bsz) % nh
-            if in_flight[slot] is not None:
-                self._finish_batch(engines[slot], in_flight[slot], order)
-                in_flight[slot] = None
             live = []
             for n in mine[b0:b0 + bsz]:
                 t = self.targets[n]
@@ -696,15 +705,17 @@ class runner(object):                                               # sv_process
                 live.append(t)
             if not live:
                 continue
+            slot = 0 if prev is None or prev[0] is engines[1] else 1
             if engines[slot] is None:
                 engines[slot] = self._make_engine()
             self.engine = engines[slot]
-            self._start_batch(engines[slot], live)
-            in_flight[slot] = live
-        rest = [(b, s_) for s_, b in enumerate(in_flight) if b is not None]
-        rest.sort(key=lambda x: order[x[0][0].name])
-        for live, slot in rest:
-            self._finish_batch(engines[slot], live, order)
+            self._submit_batch(engines[slot], live)
+            if prev is not None:
+                self._finish_batch(prev[0], prev[1], order)
+            self._launch_batch(engines[slot], live)
+            prev = (engines[slot], live)
+        if prev is not None:
+            self._finish_batch(prev[0], prev[1], order)
         if self.collate is not None and self.world > 1:               # collate per-region rows over ranks (RCCL all-gather)
             self.results, self.summary = self.collate(self.results, self.summary)
         self.results.sort(key=lambda x: x[0])                         # stable: target order (sv_processor.py:175-176), rows of a target as produced

@@ -92,6 +92,11 @@ int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions)
 /* Same, for callers that already hold the reads as base codes (one byte per base: 0..3 = A,C,G,T, 4 = N) instead of the
  * reference's strings: with BK_SUBMIT_READ_CODES the `reads` rows are codes (windows / soft-clip / partner sequences stay ASCII). */
 #define BK_SUBMIT_READ_CODES 1u
+/* BK_SUBMIT_ASYNC: return at once and pack + copy on a thread of the library, so that a driver can pick up the previous
+ * batch of another handle meanwhile.  The bk_region array is copied; the sequences it points to must stay valid until the
+ * next call on this handle has returned.  Every later call on the handle first waits for the submit and, if it failed,
+ * returns its error code (bk_last_error has the text) instead of doing its own work. */
+#define BK_SUBMIT_ASYNC 2u
 int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags);
 
 /* Run the selected stages on everything submitted (replaces, per region:

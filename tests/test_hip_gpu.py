@@ -656,3 +656,34 @@ def test_translocation_partner_discovery_gpu(hb, tmp_path):
     (tmp_path / "py").mkdir()
     cfg2, r2 = make_trl_inputs(tmp_path / "py")
     assert sp.runner(cfg2, native_calls=False).run() == rows
+
+
+@pytest.mark.gpu
+def test_async_submit_gpu(hb):
+    """BK_SUBMIT_ASYNC (the driver's overlap of packing + H2D with the previous batch): same results as the blocking submit;
+    an input error of the asynchronous submit is raised by the next call on the handle, which then takes a new batch."""
+    regions = [synth.make_region(7100 + i, sv_type=synth.SV_TYPES[i % 5], depth=40, W=700, L=100) for i in range(24)]
+    ref = _run_regions(hb, regions, 25, stages=7)
+
+    def mk(rs):
+        return [hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only, partners=[p[4] for p in r.partners]) for r in rs]
+    eng = hb.Engine(kmer_size=25)
+    for _rep in range(3):                                       # resubmission on the same handle while nothing else is pending
+        eng.submit(mk(regions), wait=False)
+        eng.run(7)
+        for i in range(len(regions)):
+            assert eng.contigs(i) == ref.contigs(i), i
+            assert [eng.hits(i, c) for c in range(len(eng.contigs(i)))] == [ref.hits(i, c) for c in range(len(ref.contigs(i)))], i
+    bad = regions[3].read_strs()
+    bad[5] = bad[5][:10] + "x" + bad[5][11:]
+    ins = mk(regions[:3]) + [hb.RegionInput(bad, regions[3].window_str)]
+    eng.submit(ins, wait=False)
+    with pytest.raises(hb.BreakmerHipError, match="region 3 read 5"):
+        eng.run(7)
+    with pytest.raises(hb.BreakmerHipError):                    # no batch on the handle after a failed submit
+        eng.run(7)
+    eng.submit(mk(regions), wait=False)
+    eng.submit(mk(regions[:5]), wait=False)     # supersedes the unfinished one
+    eng.run(7)
+    assert eng.n_regions == 5 and eng.contigs(4) == ref.contigs(4)
+    eng.close()
