@@ -174,7 +174,7 @@ def time_runner(synth, regions, kmer, cycles=1):
     return {"value": round(len(data) / dt, 1), "unit": "regions/s", "regions": len(data), "rows": len(rows), "seconds": round(dt, 3),
             "batches": (len(data) + 255) // 256,
             "note": "runner.run() wall time: host packing + H2D + GPU stages + native call tail + per-target Python objects (no output files), "
-                    "handles created and destroyed inside; 2 x 256 distinct regions cycled under 8 sets of target names; "
+                    "handles created and destroyed inside; 2 x 256 distinct regions cycled under 16 sets of target names; "
                     "the timed `value` above excludes submit (inputs resident, SURVEY 8d)"}
 
 
@@ -428,7 +428,7 @@ def main():
         }
         if world == 1 and a.other_configs:
             try:
-                out["runner_end_to_end"] = time_runner(synth, regions + [synth.make_region(n_regions + i, depth=a.depth, L=a.read_len, sv_type="del") for i in range(n_regions)], a.kmer, cycles=8)
+                out["runner_end_to_end"] = time_runner(synth, regions + [synth.make_region(n_regions + i, depth=a.depth, L=a.read_len, sv_type="del") for i in range(n_regions)], a.kmer, cycles=16)
             except Exception as ex:
                 out["runner_end_to_end"] = {"error": repr(ex)}
         # ---- other BASELINE configs on one GPU (not the headline; whole path incl. call tail, inputs resident) -----

@@ -161,11 +161,35 @@ struct BkPackLut { uint8_t v[256]; BkPackLut() { for (int i = 0; i < 256; i++) v
 static const BkPackLut g_pack_lut;
 struct BkCodeLut { uint8_t v[256]; BkCodeLut() { for (int i = 0; i < 256; i++) v[i] = 8; for (int i = 0; i < 5; i++) v[i] = (uint8_t)i; } };   // bytes are base codes 0..3, 4 = N
 static const BkCodeLut g_code_lut;
+// 16 bases -> one word with SSSE3 (two multiply-adds fold 16 two-bit codes, one byte shuffle orders them); returns false
+// when the block holds anything but A/C/G/T (codes 0..3): the caller then takes the table path for that block.
+#include <immintrin.h>
+__attribute__((target("ssse3"))) static inline bool pack16_ssse3(const unsigned char *u, bool codes, uint32_t *out)
+{
+    __m128i v = _mm_loadu_si128((const __m128i *)u);
+    if (codes) {
+        const __m128i three = _mm_set1_epi8(3);
+        if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_max_epu8(v, three), three)) != 0xFFFF) return false;
+    } else {
+        const __m128i c = _mm_cmpeq_epi8(v, _mm_set1_epi8('C')), g = _mm_cmpeq_epi8(v, _mm_set1_epi8('G')), t = _mm_cmpeq_epi8(v, _mm_set1_epi8('T'));
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, _mm_set1_epi8('A')), c), _mm_or_si128(g, t));
+        if (_mm_movemask_epi8(ok) != 0xFFFF) return false;
+        v = _mm_or_si128(_mm_and_si128(c, _mm_set1_epi8(1)), _mm_or_si128(_mm_and_si128(g, _mm_set1_epi8(2)), _mm_and_si128(t, _mm_set1_epi8(3))));
+    }
+    const __m128i p = _mm_maddubs_epi16(v, _mm_set1_epi16(0x0104));                 // b[2i]*4 + b[2i+1]
+    const __m128i q = _mm_madd_epi16(p, _mm_set1_epi32(0x00010010));                // p[2j]*16 + p[2j+1]: 4 bases per 32-bit lane, first base on top
+    const __m128i r = _mm_shuffle_epi8(q, _mm_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+    *out = (uint32_t)_mm_cvtsi128_si32(r);
+    return true;
+}
+static const bool g_have_ssse3 = __builtin_cpu_supports("ssse3");
+
 static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vector<uint32_t> *nlist = nullptr, uint32_t tag = 0, bool codes = false)
 {
     const uint8_t *lut = codes ? g_code_lut.v : g_pack_lut.v; const unsigned char *u = (const unsigned char *)s;
     int i = 0, wi = 0;
     for (; i + 16 <= len; i += 16, wi++) {
+        if (g_have_ssse3 && pack16_ssse3(u + i, codes, w + wi)) continue;
         uint32_t x = 0, fl = 0;
 #pragma unroll
         for (int t = 0; t < 16; t++) { const uint32_t c = lut[u[i + t]]; fl |= c; x = (x << 2) | (c & 3u); }

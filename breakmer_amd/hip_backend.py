@@ -213,6 +213,7 @@ class Engine(object):
         cfg.reserved[1] = int(limits.get("wg_threads", 0))          # assembler workgroup size: 0 = library default, 256 (throughput) or 512 (latency)
         self.k = int(kmer_size)
         self.h = C.c_void_p()
+        self.batch_serial = 0
         rc = self.L.bk_create(int(device), C.byref(cfg), C.byref(self.h))
         if rc != 0:
             raise BreakmerHipError("bk_create failed (%d): %s" % (rc, self.L.bk_last_error(None).decode()))
@@ -254,6 +255,7 @@ class Engine(object):
         # above, which waits for an unfinished earlier submit)
         self._inputs = None if wait else (arr, regions)
         self.n_regions = len(regions)
+        self.batch_serial += 1                               # lazily read results (sv_assembly.LazyContigs) belong to one batch
 
     def run(self, stages=BK_STAGE_KMER | BK_STAGE_ASSEMBLE, sync=True):
         self._chk(self.L.bk_run(self.h, stages), "bk_run")
@@ -290,6 +292,11 @@ class Engine(object):
         cnt = np.zeros(max(n.value, 1), dtype=np.int32)
         self._chk(self.L.bk_get_kmers(self.h, region, mers.ctypes.data, cnt.ctypes.data, n.value), "bk_get_kmers")
         return [mers[i * self.k:(i + 1) * self.k].tobytes().decode() for i in range(n.value)], cnt[:n.value].copy(), u.value
+
+    def contig_count(self, region):
+        n = C.c_int32()
+        self._chk(self.L.bk_get_contig_count(self.h, region, C.byref(n)), "bk_get_contig_count")
+        return n.value
 
     def contigs(self, region, lazy_kmers=False):
         """records of the contigs of one region; lazy_kmers: the 'kmers' entry is a KmerStrings view instead of a list"""

@@ -101,3 +101,36 @@ def contigs_from_engine(engine, region, reads, kmer_len):
     for c in recs:
         out.append(contig(c["seq"], c["indel_only"], c["others"], c["kmer_locs"], c["kmers"], (reads, c["reads"]), kmer_len))
     return out
+
+
+class LazyContigs(object):
+    """The contigs of one region as a read-only sequence whose length is known at once and whose objects are only built
+    when one is looked at -- the driver with the native call tail and no per-contig files never does.  The records live in
+    the engine's host copy of the batch, so they must be read before the engine takes its next batch."""
+
+    def __init__(self, engine, region, reads, kmer_len):
+        self._eng, self._region, self._reads, self._k = engine, region, reads, kmer_len
+        self._serial = engine.batch_serial
+        self._n = engine.contig_count(region)
+        self._items = None
+
+    def _get(self):
+        if self._items is None:
+            if self._eng is None or self._eng.batch_serial != self._serial:
+                raise RuntimeError("the contigs of this target were not read before its engine took the next batch")
+            self._items = contigs_from_engine(self._eng, self._region, self._reads, self._k)
+            self._eng = self._reads = None
+        return self._items
+
+    def detach(self):
+        """the engine moves on: keep what was built, forget the rest"""
+        self._eng = self._reads = None
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]

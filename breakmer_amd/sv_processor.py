@@ -412,6 +412,8 @@ class target(object):                                               # sv_process
         self.data = None
         self.reads = []
         self.engine = None
+        if isinstance(self.kmers.get('clusters'), sv_assembly.LazyContigs):
+            self.kmers['clusters'].detach()
 
     def rm_output_dir(self):
         if 'output' in self.paths and os.path.isdir(self.paths['output']):
@@ -528,7 +530,11 @@ class target(object):                                               # sv_process
             with open(self.files['sample_kmers'], 'w') as f:
                 for m, c in self.kmers['case_only'].items():
                     f.write("\t".join([m, str(c)]) + "\n")
-        self.kmers['clusters'] = sv_assembly.contigs_from_engine(eng, ri, self.reads, self.params.get_kmer_size())
+        if self.native_rows is not None and not self.write_files and hasattr(eng, 'contig_count') and hasattr(eng, 'batch_serial'):
+            # rows come from the native tail and no per-contig file is written: only the number of contigs is needed now
+            self.kmers['clusters'] = sv_assembly.LazyContigs(eng, ri, self.reads, self.params.get_kmer_size())
+        else:
+            self.kmers['clusters'] = sv_assembly.contigs_from_engine(eng, ri, self.reads, self.params.get_kmer_size())
         self.cleaned_read_recs = None
         self.kmers['case_only'] = {}
 
@@ -598,6 +604,7 @@ class runner(object):                                               # sv_process
         self.region_data = region_data or {}
         self.engine_factory = engine_factory
         self.rank, self.world, self.collate = rank, world, collate
+        self._ctx_head = None
         self.native_calls = native_calls        # SV-call tail in C++ (bk_call) instead of breakmer_amd/sv_caller.py; same rows
         self.engine = None
 
@@ -633,7 +640,9 @@ class runner(object):                                               # sv_process
             eng.run(hip_backend.BK_STAGE_ALL)
         if self.native_calls and hasattr(eng, 'set_call_context'):
             from . import call_context as cc
-            lines = [cc.opts_line(self.params.opts)] + cc.tables_lines(self.params.gene_annotations.genes, self.params.repeat_mask)
+            if self._ctx_head is None:                               # options + annotation tables: the same text for every batch
+                self._ctx_head = "\n".join([cc.opts_line(self.params.opts)] + cc.tables_lines(self.params.gene_annotations.genes, self.params.repeat_mask))
+            lines = [self._ctx_head]
             for i, t in enumerate(live):
                 lines += cc.region_lines(i, t.get_values(), t.repeat_mask, t.disc_reads, t.partner_windows, t.data.read_ids)
             eng.set_call_context("\n".join(lines) + "\n")
@@ -648,7 +657,7 @@ class runner(object):                                               # sv_process
             eng.sync()
         # a region that hit a device cap fails alone (bk_get_region_status): the target is logged and skipped like a
         # target without reads (sv_processor.py:190-192); the rank still takes part in the collation
-        if hasattr(eng, 'region_status'):
+        if hasattr(eng, 'region_status') and not (hasattr(eng, 'stat') and eng.stat(22) == 0):      # stat 22: regions that failed in the last run
             for i, t in enumerate(live):
                 st, text = eng.region_status(i)
                 if st != 0:
@@ -687,12 +696,21 @@ class runner(object):                                               # sv_process
         order = {n: i for i, n in enumerate(names)}
         mine = [n for i, n in enumerate(names) if i % self.world == self.rank]
         # Batching front-end: the reference handles one target at a time; here bounded batches of targets go through the HIP
-        # library on two alternating handles.  Batch i+1 is handed to the library first (its 2-bit packing and H2D copies
-        # run on a thread of the library), then this thread picks up batch i (call tail, per-target objects, files), then
-        # the kernels of batch i+1 are launched; batches finish in the order they were started.
+        # library on up to three handles.  A batch is handed to the library one iteration before its kernels are launched
+        # (its 2-bit packing and H2D copies run on a thread of the library meanwhile); in between, this thread picks up the
+        # batch that is running (call tail, per-target objects, files).  Batches finish in the order they were started.
         bsz = max(1, int(self.params.opts.get('batch_regions', 256)))
-        engines = [None, None]
-        prev = None                                                 # (handle, targets) of the batch that is running
+        free, pending, running = [], [], []                         # handles; submitted batches; the launched batch
+
+        def advance():
+            eng, live = pending.pop(0)
+            if running:
+                done = running.pop()
+                self._finish_batch(done[0], done[1], order)
+                free.append(done[0])
+            self._launch_batch(eng, live)
+            running.append((eng, live))
+
         for b0 in range(0, len(mine), bsz):
             live = []
             for n in mine[b0:b0 + bsz]:
@@ -705,17 +723,16 @@ class runner(object):                                               # sv_process
                 live.append(t)
             if not live:
                 continue
-            slot = 0 if prev is None or prev[0] is engines[1] else 1
-            if engines[slot] is None:
-                engines[slot] = self._make_engine()
-            self.engine = engines[slot]
-            self._submit_batch(engines[slot], live)
-            if prev is not None:
-                self._finish_batch(prev[0], prev[1], order)
-            self._launch_batch(engines[slot], live)
-            prev = (engines[slot], live)
-        if prev is not None:
-            self._finish_batch(prev[0], prev[1], order)
+            eng = free.pop() if free else self._make_engine()
+            self.engine = eng
+            self._submit_batch(eng, live)
+            pending.append((eng, live))
+            if len(pending) > 1:
+                advance()
+        while pending:
+            advance()
+        if running:
+            self._finish_batch(running[0][0], running[0][1], order)
         if self.collate is not None and self.world > 1:               # collate per-region rows over ranks (RCCL all-gather)
             self.results, self.summary = self.collate(self.results, self.summary)
         self.results.sort(key=lambda x: x[0])                         # stable: target order (sv_processor.py:175-176), rows of a target as produced
