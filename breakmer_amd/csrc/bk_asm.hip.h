@@ -49,8 +49,13 @@ struct BkAsmShared {
     unsigned long long cells, calls;
     BkNwResult v1, v2;
     // look-ahead slots (see bk_run_candidates): read q+s aligned against the PREDICTED contig after reads q..q+s-1
-    struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt, hasn; BkNwResult v1, v2; } slot[BK_SPEC];
+    struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt, hasn, vt, rank; BkNwResult v1, v2; } slot[BK_SPEC];
     int nb, pc, last_dec, dual;
+    // look-ahead across k-mer visits of grow (bk_run_candidates): slots [plan_r, nb) hold reads of LATER visits, already aligned
+    // against the predicted contig; plan_upto = last visit (index into the snapshot) whose candidate list the plan knows
+    int ncur, plan_r, plan_upto, plan_ok, hit;
+    int la_planned, la_adopted;  // slots planned for later visits / retired from there: the look-ahead is paused while most are wasted
+    int la_n[BK_SPEC], la_t[BK_SPEC], la_rank[BK_SPEC], la_pc[BK_SPEC];
     int qslot;                   // position in the region queue this workgroup is working on
     uint32_t scan[24];
 #ifdef BK_PHASE_STAMPS
@@ -111,7 +116,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t bk_lds[];
 #define C_ (*(BkAsmCtx *)bk_lds)
 #define S_ ((BkAsmShared *)(bk_lds + BK_SH_OFF))
 #define L_CSEQ (bk_lds + C_.o_cseq)
-#define L_RSEQ (bk_lds + C_.o_rseq)                                   // read buffer of slot 0 (also the generic read buffer)
+#define L_RSEQ (bk_lds + C_.o_rseq + BK_SPEC * (C_.MAXR + 16))         // the generic read buffer (bk_load_read): not a slot's, slots outlive a visit
 #define L_RSEQ_S(s) (bk_lds + C_.o_rseq + (s) * (C_.MAXR + 16))
 #define L_BOUND ((int *)(bk_lds + C_.o_bound))
 #define L_BOUND_W(w) ((int *)(bk_lds + C_.o_bound) + (w) * 2 * (C_.MAXR + 2))
@@ -511,7 +516,7 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
     }
     // check_read bookkeeping (:552-565)
     if (BK_TID == 0) {
-        S->last_dec = dec;
+        S->last_dec = dec; S->hit = match ? 1 : 0;
         C_.ubuf[u] = S->serial;                                                    // self.buffer.add(read.id)
         S->cells += 2ull * (unsigned long long)clen * (unsigned long long)rl; S->calls += 2;
         if (match) {
@@ -560,15 +565,157 @@ __device__ __noinline__ void bk_dp_round()
         }
     }
 }
-__device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bool grow)
+// Look-ahead across the k-mer visits of grow.  A visit usually recruits only a handful of reads (clean data) or a single
+// one (sequencing noise), far fewer than there are look-ahead slots.  The visits of a snapshot are known in advance
+// (nklist), and so is the candidate list of a LATER visit: every read a visit looks at ends up in the contig's buffer
+// (check_read :552 buffer.add, matched or not), so the list a later visit will see is its eligible reads now minus the
+// reads of the visits in between -- which are exactly the slots planned before it.  A round therefore goes on planning
+// into the following visits until the slots are full; their DPs run in the same round against the predicted contig and
+// their results wait in the slots.  When such a visit comes up, its real candidate list (the ordinary find_reads) is
+// compared with the planned one: equal -> the slots are retired in order under the usual prediction checks, no DP;
+// anything else -> the plan is dropped and the visit runs as before.  State only ever changes in bk_retire / finalize,
+// in the reference's order.
+//
+// One wavefront per following visit: its eligible reads (short posting lists only), ordered as find_reads orders them,
+// with the per-read fields a slot needs, and the position of its k-mer in the current contig.
+#define BK_LA_CH 16                                  // posting lists of up to 64 * BK_LA_CH entries are looked into
+#define BK_LA_CU(w) ((uint32_t *)L_CAND + (w) * 64)
+#define BK_LA_RL(w) ((int *)L_CAND + (BK_AT / 64 + (w)) * 64)
+#define BK_LA_RN(w) ((int *)L_CAND + (2 * (BK_AT / 64) + (w)) * 64)
+#define BK_LA_FL(w) ((int *)L_CAND + (3 * (BK_AT / 64) + (w)) * 64)
+BK_COLD void bk_lookahead_wave(int w, int vt, int T)
+{
+    BkAsmShared *S = S_;
+    const int lane = BK_TID & 63;
+    const int idx = vt + 1 + lane;
+    const uint32_t en = idx < T ? C_.nklist[idx] : 0x40000000u;
+    unsigned long long m = __ballot(!(en & 0x40000000u));                      // visits that may have candidates, in order
+    for (int i = 0; i < w; i++) m &= m - 1;
+    int cnt = -1, tt = -1, rank2 = 0, pc2 = -1;
+    if (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        const uint32_t e2 = (uint32_t)__shfl((int)en, bit);
+        tt = vt + 1 + bit; rank2 = (int)(e2 & 0x3FFFFFFFu);
+        const bool rev = (e2 >> 31) != 0;
+        const uint32_t b = C_.poff[rank2], e = C_.poff[rank2 + 1];
+        if (e - b <= 64u * BK_LA_CH) {
+            // eligible entries of the posting list (a k-mer of a deep region sits in a few hundred reads, nearly all of them
+            // in the buffer already): BK_LA_CH entries per lane, loads issued together, compacted into the list
+            const int np = (int)(e - b);
+            uint32_t pe[BK_LA_CH]; uint32_t fl[BK_LA_CH]; int bs[BK_LA_CH];
+#pragma unroll
+            for (int c = 0; c < BK_LA_CH; c++) pe[c] = lane + 64 * c < np ? C_.post[b + lane + 64 * c] : 0u;
+#pragma unroll
+            for (int c = 0; c < BK_LA_CH; c++) { const bool have = lane + 64 * c < np; fl[c] = have ? C_.ufl[pe[c] >> 10] : 0u; bs[c] = have ? C_.ubuf[pe[c] >> 10] : 0; }
+            int nv = 0;
+#pragma unroll
+            for (int c = 0; c < BK_LA_CH; c++) {
+                const bool okc = lane + 64 * c < np && !(fl[c] & BK_R_DELETED) && bs[c] != S->serial;
+                const unsigned long long vm = __ballot(okc);
+                const int at = nv + __popcll(vm & ((1ull << lane) - 1ull));
+                if (okc && at < 64) { BK_LA_RL(w)[at] = (int)pe[c]; BK_LA_FL(w)[at] = (int)fl[c]; }      // staging: overwritten by the ordered list below
+                nv += __popcll(vm);
+            }
+            if (nv <= 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const bool have = lane < nv;
+                const uint32_t mypost = have ? (uint32_t)BK_LA_RL(w)[lane] : 0u; const uint32_t myfl = have ? (uint32_t)BK_LA_FL(w)[lane] : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const uint32_t u = mypost >> 10; const int pos = (int)(mypost & 1023u);
+                uint32_t len = 0; int rn = 0;
+                if (have) { len = C_.ulen[u]; rn = (int)C_.unr[u]; }
+                bool drop = false;                                                 // the k-mer twice in one read: first occurrence (re.search)
+                for (int j = 0; j < nv; j++) {
+                    const uint32_t oen = (uint32_t)__builtin_amdgcn_readlane((int)mypost, j);
+                    drop = drop || ((oen >> 10) == u && (int)(oen & 1023u) < pos);
+                }
+                const bool valid = have && !drop;
+                const unsigned long long pk = rev ? (unsigned long long)(0xFFFF - pos) : (unsigned long long)pos;
+                const unsigned long long key = valid ? ((pk << 40) | ((0xFFFFull - len) << 24) | u) : ~0ull;
+                int ord = 0;
+                for (int j = 0; j < nv; j++) {
+                    const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+                    ord += kj < key;
+                }
+                if (valid) { BK_LA_CU(w)[ord] = u | ((uint32_t)pos << 22); BK_LA_RL(w)[ord] = (int)len; BK_LA_RN(w)[ord] = rn; BK_LA_FL(w)[ord] = (int)myfl; }
+                cnt = __popcll(__ballot(valid));
+                BkKey kk; kk.hi = C_.khi[rank2]; kk.lo = C_.klo[rank2];
+                pc2 = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, kk, C_.k);
+            }
+        }
+    }
+    if (lane == 0) { S->la_n[w] = cnt; S->la_t[w] = tt; S->la_rank[w] = rank2; S->la_pc[w] = pc2; }
+}
+
+// one step of the prediction chain (thread 0): slot t is aligned against the contig [pb, pb+plen) in which its k-mer sits
+// at ppc; what the read is predicted to do to it.  Returns false when nothing can be predicted past this slot.
+__device__ inline bool bk_predict(BkAsmShared::Slot &t, int &pb, int &plen, int &ppc)
+{
+    const int pos = t.pos, rl = t.rl;
+    t.pb = pb; t.plen = plen;
+    const int left = pos - ppc, right = (rl - pos) - (plen - ppc);
+    if (ppc < 0 || (left > 0 && right > 0)) { t.kind = BK_PK_STOP; t.amt = 0; return false; }
+    if (left > 0) { t.kind = BK_PK_PRE; t.amt = left; if (pb - left < 0 || plen + left > C_.MAXC) { t.kind = BK_PK_STOP; return false; } pb -= left; plen += left; ppc += left; }
+    else if (right > 0) { t.kind = BK_PK_POST; t.amt = right; if (pb + plen + right > 2 * C_.MAXC || plen + right > C_.MAXC) { t.kind = BK_PK_STOP; return false; } plen += right; }
+    else { t.kind = BK_PK_SAME; t.amt = 0; }
+    return true;
+}
+
+// retire slot sl if the contig is what the slot was aligned against; uniform result: 1 retired, 0 prediction failed
+__device__ __forceinline__ int bk_retire_checked(int sl, bool grow)
+{
+    BkAsmShared *S = S_;
+    if (sl > 0) {
+        const int pk = S->slot[sl - 1].kind, ld = S->last_dec;
+        const bool kind_ok = (pk == BK_PK_PRE && ld == BK_DEC_PRE) || (pk == BK_PK_POST && ld == BK_DEC_POST) ||
+                             (pk == BK_PK_SAME && (ld == BK_DEC_NONE || ld == BK_DEC_SAME || ld == BK_DEC_SUB));
+        if (!kind_ok || S->cbase != S->slot[sl].pb || S->clen != S->slot[sl].plen) return 0;
+    }
+    const int u = S->slot[sl].u;
+    const bool hit = bk_retire(S->slot[sl].rank, sl, grow);
+#ifdef BK_PHASE_STAMPS
+    if (BK_TID == 0) S->acc[17] += 1;
+#endif
+    if (grow && hit && BK_TID == 0) { int pidx = C_.ufound[u]; if (pidx >= 0) { C_.pend[2 * pidx] = BK_EMPTY32; C_.ufound[u] = -1; } }   // buff.remove_contig :638-639
+    BK_SYNC();
+    return 1;
+}
+
+// vt / T: index of this visit in the snapshot and the snapshot's length (grow); vt < 0: setup_contigs
+__device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bool grow, int vt, int T)
 {
     BkAsmShared *S = S_;
     const int wv = BK_TID >> 6;
     int q = first;
-    while (q < n) {
+    // 0. a plan of an earlier round covers this visit: adopt its slots if it predicted exactly this candidate list
+    //    (uniform: every thread evaluates the same LDS words)
+    bool adopt = false;
+    int r0 = 0;
+    if (vt >= 0 && S->plan_ok) {
+        r0 = S->plan_r;
+        adopt = vt <= S->plan_upto;
+        int g = 0;
+        if (adopt) { while (r0 + g < S->nb && S->slot[r0 + g].vt == vt) g++; adopt = g == n; }
+        for (int i = 0; adopt && i < n; i++) { const uint32_t cu = L_CANDU[i]; adopt = S->slot[r0 + i].u == (int)(cu & 0x3FFFFFu) && S->slot[r0 + i].pos == (int)(cu >> 22); }
+        if (!adopt || n == 0) {
+            BK_SYNC();
+            if (BK_TID == 0) { if (!adopt) S->plan_ok = 0; else if (r0 >= S->nb && vt >= S->plan_upto) S->plan_ok = 0; }
+            BK_SYNC();
+            adopt = false;
+        }
+    }
+    // one loop for both kinds of pass, so that the decision/apply step (bk_retire) is inlined once: a pass either retires
+    // the adopted slots of this visit or plans, aligns and retires a fresh round
+    while (adopt || q < n) {
+        int s0 = r0, s1 = r0 + n;                   // the adopted slots of this visit ...
+        if (!adopt) {                               // ... or a fresh round:
         if (S->status) return;
         BK_ACC(S_->ctx);
-        const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
+        const int cap = (C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC;
+        const int nbmax = min(cap, n - q);
+        // look into the following visits when this one leaves slots free (needs the scratch for BK_AT/64 lists of 64 reads)
+        const bool la_on = vt >= 0 && n - q < cap && !(C_.flags & BK_F_NO_XVISIT) && 2 * C_.MAXCAND >= 4 * BK_AT;
+        const bool la = la_on && (S->la_planned < 32 || 2 * S->la_adopted >= S->la_planned);
         // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
         BK_SYNC();
         if (BK_TID < nbmax) {
@@ -577,33 +724,75 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             BkAsmShared::Slot &t = S->slot[BK_TID];
             t.u = u; t.pos = (int)(cu >> 22); t.rl = C_.rlen[ri]; t.rn = (int)C_.unr[u]; t.rindel = (C_.ufl[u] & BK_R_INDEL) ? 1 : 0;
             t.hasn = (C_.n_nlist && (C_.ufl[u] & BK_R_HASN)) ? 1 : 0;
+            t.vt = vt; t.rank = rank;
         }
+        if (la) bk_lookahead_wave(wv, vt, T);
         BK_SYNC();
         if (BK_TID == 0) {
             int pb = S->cbase, plen = S->clen, ppc = S->pc, nb = 0;
+            bool go = true;
             // both DPs of a slot run on one wavefront while the (predicted) contig fits its columns; else two wavefronts per slot
-            for (int sl = 0; sl < nbmax; sl++) {
-                if (sl >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) break;
-                BkAsmShared::Slot &t = S->slot[sl];
-                const int pos = t.pos, rl = t.rl;
-                t.pb = pb; t.plen = plen;
+            for (int sl = 0; sl < nbmax && go; sl++) {
+                if (sl >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
                 nb = sl + 1;
-                const int left = pos - ppc, right = (rl - pos) - (plen - ppc);
-                if (ppc < 0 || (left > 0 && right > 0)) { t.kind = BK_PK_STOP; t.amt = 0; break; }
-                if (left > 0) { t.kind = BK_PK_PRE; t.amt = left; if (pb - left < 0 || plen + left > C_.MAXC) { t.kind = BK_PK_STOP; break; } pb -= left; plen += left; ppc += left; }
-                else if (right > 0) { t.kind = BK_PK_POST; t.amt = right; if (pb + plen + right > 2 * C_.MAXC || plen + right > C_.MAXC) { t.kind = BK_PK_STOP; break; } plen += right; }
-                else { t.kind = BK_PK_SAME; t.amt = 0; }
+                go = bk_predict(S->slot[sl], pb, plen, ppc);
+            }
+            const int ncur = nb;
+            int upto = vt;
+#ifdef BK_PHASE_STAMPS
+            if (la_on) S->acc[19] += 1ull;                                               // rounds with free slots
+            if (la_on && !(la && go && q + ncur == n)) S->acc[19] += 1ull << 16;          // ... not looked ahead (paused / STOP / round does not finish the visit)
+            else if (la_on && S->la_n[0] < 0) S->acc[19] += 1ull << 32;                  // ... next visit: none in the window or posting list too long
+            else if (la_on && S->la_n[0] == 0) S->acc[19] += 1ull << 48;                 // ... next visit has no eligible read
+#endif
+            if (la && go && q + ncur == n) {
+                for (int w = 0; w < BK_AT / 64 && go; w++) {
+                    const int cn = S->la_n[w];
+                    if (cn < 0) break;
+                    // the visit's list once the reads planned before it are in the buffer
+                    int keep = 0;
+                    for (int i = 0; i < cn; i++) {
+                        const int u = (int)(BK_LA_CU(w)[i] & 0x3FFFFFu); bool inflight = false;
+                        for (int s2 = 0; s2 < nb; s2++) inflight = inflight || S->slot[s2].u == u;
+                        keep += !inflight;
+                    }
+                    if (nb + keep > cap) break;
+                    const int pc2 = S->la_pc[w];
+                    if (keep > 0 && pc2 < 0) break;
+                    ppc = pc2 + (S->cbase - pb);                    // the predicted contig starts cbase - pb bases before the current one
+                    const int nb0 = nb;
+                    for (int i = 0; i < cn && go; i++) {
+                        const uint32_t cu = BK_LA_CU(w)[i]; const int u = (int)(cu & 0x3FFFFFu); bool inflight = false;
+                        for (int s2 = 0; s2 < nb0; s2++) inflight = inflight || S->slot[s2].u == u;
+                        if (inflight) continue;
+                        if (nb >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
+                        BkAsmShared::Slot &t = S->slot[nb];
+                        const int fl = BK_LA_FL(w)[i];
+                        t.u = u; t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
+                        t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
+                        t.vt = S->la_t[w]; t.rank = S->la_rank[w];
+                        nb++;
+                        go = bk_predict(t, pb, plen, ppc);
+                    }
+                    if (nb - nb0 != keep) { nb = nb0; break; }      // a visit is planned whole or not at all
+                    upto = S->la_t[w];
+                }
             }
             int mx = 0;
             for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen);
             // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
             // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
             S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
-            if (!S->dual && nb > BK_SPEC_WIDE) nb = BK_SPEC_WIDE;
-            S->nb = nb;
+            int nc = ncur;
+            if (!S->dual && nb > BK_SPEC_WIDE) { nc = min(nc, BK_SPEC_WIDE); nb = nc; upto = vt; }      // two wavefronts per slot: this visit's reads only
+            S->nb = nb; S->ncur = nc;
+            S->plan_r = nc; S->plan_upto = upto; S->plan_ok = (nb > nc || upto > vt) ? 1 : 0;
+            S->la_planned += nb - nc;
+            if (la_on && !la) S->la_planned--;                      // paused: retried once the bad stretch has aged out
+            if (S->la_planned >= 256) { S->la_planned >>= 1; S->la_adopted >>= 1; }      // recent history counts
         }
         BK_SYNC();
-        const int nb = S->nb;
+        const int nb = S->nb, ncur = S->ncur;
 #ifdef BK_PHASE_STAMPS
         if (BK_TID == 0) { S->acc[16] += nb; S->acc[18] += 1; }
 #endif
@@ -642,24 +831,25 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         bk_dp_round();
         BK_SYNC();
         BK_ACC(2);
-        // 3. retire in order while the predictions hold
-        for (int sl = 0; sl < nb; sl++) {
-            if (S->status) return;
-            if (sl > 0) {
-                const int pk = S->slot[sl - 1].kind, ld = S->last_dec;
-                const bool kind_ok = (pk == BK_PK_PRE && ld == BK_DEC_PRE) || (pk == BK_PK_POST && ld == BK_DEC_POST) ||
-                                     (pk == BK_PK_SAME && (ld == BK_DEC_NONE || ld == BK_DEC_SAME || ld == BK_DEC_SUB));
-                if (!kind_ok || S->cbase != S->slot[sl].pb || S->clen != S->slot[sl].plen) break;
-            }
-            const int u = S->slot[sl].u;
-            const bool hit = bk_retire(rank, sl, grow);
-#ifdef BK_PHASE_STAMPS
-            if (BK_TID == 0) S->acc[17] += 1;
-#endif
-            if (grow && hit && BK_TID == 0) { int pidx = C_.ufound[u]; if (pidx >= 0) { C_.pend[2 * pidx] = BK_EMPTY32; C_.ufound[u] = -1; } }   // buff.remove_contig :638-639
-            q++;
-            BK_SYNC();
+        s0 = 0; s1 = ncur;
         }
+        // 3. retire this visit's slots in order while the predictions hold; the slots of later visits wait for their turn
+        int sl = s0;
+        for (; sl < s1; sl++) {
+            if (S->status) return;
+            if (!bk_retire_checked(sl, grow)) break;
+            q++;
+        }
+        if (adopt) {
+            BK_SYNC();
+            if (BK_TID == 0) {
+                S->la_adopted += sl - s0;
+                if (sl < s1) S->plan_ok = 0;
+                else { S->plan_r = s1; if (S->plan_r >= S->nb && vt >= S->plan_upto) S->plan_ok = 0; }
+            }
+            BK_SYNC();
+            adopt = false;
+        } else if (sl < s1 && S->plan_ok) { BK_SYNC(); if (BK_TID == 0) S->plan_ok = 0; BK_SYNC(); }      // a prediction failed: what was planned behind it is void
     }
 }
 
@@ -768,6 +958,8 @@ __device__ __forceinline__ void bk_grow()
             if (!has) { C_.kstamp[3 * rank] = S->serial; C_.nklist[t] = en | 0x40000000u; }       // checked_kmers is only read by the next snapshot
         }
         BK_SYNC();
+        if (BK_TID == 0) S->plan_ok = 0;                                           // a plan refers to one snapshot (and one contig)
+        BK_SYNC();
         uint32_t t = 0, en_next = C_.nklist[0];
         while (t < T) {
             if (S->status) return;
@@ -793,20 +985,21 @@ __device__ __forceinline__ void bk_grow()
                 BK_SYNC();
                 continue;
             }
+            const int vt = (int)t;
             t++;
             if (t < T) en_next = C_.nklist[t];                                     // fetched a whole visit ahead of its use
             bk_find_reads(rank, rev, true);                                    // get_mer_reads :604-614
             if (BK_TID == 0) bk_add_used_mer(rank);
             BK_SYNC();
-            // position of this k-mer in the contig (prediction seed); -1 disables the look-ahead, which needs >= 2 candidates
+            // position of this k-mer in the contig (prediction seed); -1 disables the look-ahead
             if ((BK_TID >> 6) == 0) {
                 int pc = -1;
-                if (S->ncand >= 2) { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank]; pc = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, key, C_.k); }
+                if (S->ncand >= 1) { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank]; pc = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, key, C_.k); }
                 if (BK_TID == 0) S->pc = pc;
             }
             BK_SYNC();
             BK_ACC(14);
-            bk_run_candidates(rank, 0, S->ncand, true);
+            bk_run_candidates(rank, 0, S->ncand, true, vt, (int)T);
             bk_finalize(false);
             if (BK_TID == 0) C_.kstamp[3 * rank] = S->serial;                       // checked_kmers.append(mer): read by the next snapshot only
         }
@@ -887,7 +1080,7 @@ __device__ inline void bk_setup_contigs(int rank)
     BK_SYNC();
     if (BK_TID == 0) S->pc = (int)(L_CANDU[0] >> 22);      // the contig IS the first read: the k-mer sits where it sits in that read
     BK_SYNC();
-    bk_run_candidates(rank, 1, n, false);
+    bk_run_candidates(rank, 1, n, false, -1, 0);
     bk_finalize(true);
     if (in_fifo) { bk_grow(); if (!S->status) bk_emit_contig(); }                // it is the FIFO head (:50-52)
     BK_ACC(8); BK_CTX(0);
@@ -910,7 +1103,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.o_bound = o; o += (BK_AT / 64) * 2 * (c.MAXR + 2) * 4;
         c.o_candu = o; o += c.MAXCAND * 4;
         c.o_cseq = o; o += 2 * c.MAXC;
-        c.o_rseq = o; o += BK_SPEC * (c.MAXR + 16);
+        c.o_rseq = o; o += (BK_SPEC + 1) * (c.MAXR + 16);
         c.reads = p.reads + d.reads_word_off; c.rlen = p.read_len + d.read_meta_off;
         c.nlist = p.nlist + d.nlist_off; c.n_nlist = d.n_nlist;
         const uint64_t mo = d.read_meta_off;
@@ -921,7 +1114,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
         c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
-        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0;
+        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->la_planned = 0; S->la_adopted = 0;
 #ifdef BK_PHASE_STAMPS
         for (int i = 0; i < 20; i++) S->acc[i] = 0; S->ctx = 0;
         S->last = __builtin_amdgcn_s_memrealtime();
