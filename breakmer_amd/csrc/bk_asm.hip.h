@@ -54,7 +54,8 @@ struct BkAsmShared {
     // look-ahead across k-mer visits of grow (bk_run_candidates): slots [plan_r, nb) hold reads of LATER visits, already aligned
     // against the predicted contig; plan_upto = last visit (index into the snapshot) whose candidate list the plan knows
     int ncur, plan_r, plan_upto, plan_ok, hit;
-    int la_planned, la_adopted;  // slots planned for later visits / retired from there: the look-ahead is paused while most are wasted
+    int la_planned, la_adopted;  // slots planned for later visits / retired from there, in the current window of 64 planned
+    int la_pause, la_backoff;    // rounds the look-ahead stays off after a window in which most of its slots were wasted (doubles)
     int la_n[BK_SPEC], la_t[BK_SPEC], la_rank[BK_SPEC], la_pc[BK_SPEC];
     int qslot;                   // position in the region queue this workgroup is working on
     uint32_t scan[24];
@@ -681,6 +682,79 @@ __device__ __forceinline__ int bk_retire_checked(int sl, bool grow)
     return 1;
 }
 
+// the plan of one round (thread 0): prediction chain over this visit's slots, then over the following visits' lists.  Out of
+// line: its loops over slots and lists would otherwise sit in the register budget of the state machine's hot loop.
+BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int la_on)
+{
+    BkAsmShared *S = S_;
+    if (BK_TID != 0) return;
+    int pb = S->cbase, plen = S->clen, ppc = S->pc, nb = 0;
+    bool go = true;
+    // both DPs of a slot run on one wavefront while the (predicted) contig fits its columns; else two wavefronts per slot
+    for (int sl = 0; sl < nbmax && go; sl++) {
+        if (sl >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
+        nb = sl + 1;
+        go = bk_predict(S->slot[sl], pb, plen, ppc);
+    }
+    const int ncur = nb;
+    int upto = vt;
+#ifdef BK_PHASE_STAMPS
+    if (la_on) S->acc[19] += 1ull;                                               // rounds with free slots
+    if (la_on && !(la && go && q + ncur == n)) S->acc[19] += 1ull << 16;          // ... not looked ahead (paused / STOP / round does not finish the visit)
+    else if (la_on && S->la_n[0] < 0) S->acc[19] += 1ull << 32;                  // ... next visit: none in the window or posting list too long
+    else if (la_on && S->la_n[0] == 0) S->acc[19] += 1ull << 48;                 // ... next visit has no eligible read
+#endif
+    if (la && go && q + ncur == n) {
+        for (int w = 0; w < BK_AT / 64 && go; w++) {
+            const int cn = S->la_n[w];
+            if (cn < 0) break;
+            // the visit's list once the reads planned before it are in the buffer
+            int keep = 0;
+            for (int i = 0; i < cn; i++) {
+                const int u = (int)(BK_LA_CU(w)[i] & 0x3FFFFFu); bool inflight = false;
+                for (int s2 = 0; s2 < nb; s2++) inflight = inflight || S->slot[s2].u == u;
+                keep += !inflight;
+            }
+            if (nb + keep > cap) break;
+            const int pc2 = S->la_pc[w];
+            if (keep > 0 && pc2 < 0) break;
+            ppc = pc2 + (S->cbase - pb);                    // the predicted contig starts cbase - pb bases before the current one
+            const int nb0 = nb;
+            for (int i = 0; i < cn && go; i++) {
+                const uint32_t cu = BK_LA_CU(w)[i]; const int u = (int)(cu & 0x3FFFFFu); bool inflight = false;
+                for (int s2 = 0; s2 < nb0; s2++) inflight = inflight || S->slot[s2].u == u;
+                if (inflight) continue;
+                if (nb >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
+                BkAsmShared::Slot &t = S->slot[nb];
+                const int fl = BK_LA_FL(w)[i];
+                t.u = u; t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
+                t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
+                t.vt = S->la_t[w]; t.rank = S->la_rank[w];
+                nb++;
+                go = bk_predict(t, pb, plen, ppc);
+            }
+            if (nb - nb0 != keep) { nb = nb0; break; }      // a visit is planned whole or not at all
+            upto = S->la_t[w];
+        }
+    }
+    int mx = 0;
+    for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen);
+    // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
+    // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
+    S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
+    int nc = ncur;
+    if (!S->dual && nb > BK_SPEC_WIDE) { nc = min(nc, BK_SPEC_WIDE); nb = nc; upto = vt; }      // two wavefronts per slot: this visit's reads only
+    S->nb = nb; S->ncur = nc;
+    S->plan_r = nc; S->plan_upto = upto; S->plan_ok = (nb > nc || upto > vt) ? 1 : 0;
+    S->la_planned += nb - nc;
+    if (la_on && S->la_pause > 0) S->la_pause--;
+    if (S->la_planned >= 64) {                      // one window: did the slots planned for later visits get used?
+        if (2 * S->la_adopted < S->la_planned) { S->la_pause = S->la_backoff; S->la_backoff = min(2 * S->la_backoff, 4096); }
+        else S->la_backoff = 32;
+        S->la_planned = 0; S->la_adopted = 0;
+    }
+}
+
 // vt / T: index of this visit in the snapshot and the snapshot's length (grow); vt < 0: setup_contigs
 __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bool grow, int vt, int T)
 {
@@ -711,11 +785,12 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         if (!adopt) {                               // ... or a fresh round:
         if (S->status) return;
         BK_ACC(S_->ctx);
-        const int cap = (C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC;
-        const int nbmax = min(cap, n - q);
+        // slots of a round: one per wavefront while both DPs of a slot fit one wavefront (contig <= BK_NW_DUAL_COLS), else half
+        const int cap = ((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) || S->clen > BK_NW_DUAL_COLS) ? BK_SPEC_WIDE : BK_SPEC;
+        const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
         // look into the following visits when this one leaves slots free (needs the scratch for BK_AT/64 lists of 64 reads)
         const bool la_on = vt >= 0 && n - q < cap && !(C_.flags & BK_F_NO_XVISIT) && 2 * C_.MAXCAND >= 4 * BK_AT;
-        const bool la = la_on && (S->la_planned < 32 || 2 * S->la_adopted >= S->la_planned);
+        const bool la = la_on && S->la_pause == 0;
         // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
         BK_SYNC();
         if (BK_TID < nbmax) {
@@ -728,69 +803,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         }
         if (la) bk_lookahead_wave(wv, vt, T);
         BK_SYNC();
-        if (BK_TID == 0) {
-            int pb = S->cbase, plen = S->clen, ppc = S->pc, nb = 0;
-            bool go = true;
-            // both DPs of a slot run on one wavefront while the (predicted) contig fits its columns; else two wavefronts per slot
-            for (int sl = 0; sl < nbmax && go; sl++) {
-                if (sl >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
-                nb = sl + 1;
-                go = bk_predict(S->slot[sl], pb, plen, ppc);
-            }
-            const int ncur = nb;
-            int upto = vt;
-#ifdef BK_PHASE_STAMPS
-            if (la_on) S->acc[19] += 1ull;                                               // rounds with free slots
-            if (la_on && !(la && go && q + ncur == n)) S->acc[19] += 1ull << 16;          // ... not looked ahead (paused / STOP / round does not finish the visit)
-            else if (la_on && S->la_n[0] < 0) S->acc[19] += 1ull << 32;                  // ... next visit: none in the window or posting list too long
-            else if (la_on && S->la_n[0] == 0) S->acc[19] += 1ull << 48;                 // ... next visit has no eligible read
-#endif
-            if (la && go && q + ncur == n) {
-                for (int w = 0; w < BK_AT / 64 && go; w++) {
-                    const int cn = S->la_n[w];
-                    if (cn < 0) break;
-                    // the visit's list once the reads planned before it are in the buffer
-                    int keep = 0;
-                    for (int i = 0; i < cn; i++) {
-                        const int u = (int)(BK_LA_CU(w)[i] & 0x3FFFFFu); bool inflight = false;
-                        for (int s2 = 0; s2 < nb; s2++) inflight = inflight || S->slot[s2].u == u;
-                        keep += !inflight;
-                    }
-                    if (nb + keep > cap) break;
-                    const int pc2 = S->la_pc[w];
-                    if (keep > 0 && pc2 < 0) break;
-                    ppc = pc2 + (S->cbase - pb);                    // the predicted contig starts cbase - pb bases before the current one
-                    const int nb0 = nb;
-                    for (int i = 0; i < cn && go; i++) {
-                        const uint32_t cu = BK_LA_CU(w)[i]; const int u = (int)(cu & 0x3FFFFFu); bool inflight = false;
-                        for (int s2 = 0; s2 < nb0; s2++) inflight = inflight || S->slot[s2].u == u;
-                        if (inflight) continue;
-                        if (nb >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
-                        BkAsmShared::Slot &t = S->slot[nb];
-                        const int fl = BK_LA_FL(w)[i];
-                        t.u = u; t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
-                        t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
-                        t.vt = S->la_t[w]; t.rank = S->la_rank[w];
-                        nb++;
-                        go = bk_predict(t, pb, plen, ppc);
-                    }
-                    if (nb - nb0 != keep) { nb = nb0; break; }      // a visit is planned whole or not at all
-                    upto = S->la_t[w];
-                }
-            }
-            int mx = 0;
-            for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen);
-            // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
-            // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
-            S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
-            int nc = ncur;
-            if (!S->dual && nb > BK_SPEC_WIDE) { nc = min(nc, BK_SPEC_WIDE); nb = nc; upto = vt; }      // two wavefronts per slot: this visit's reads only
-            S->nb = nb; S->ncur = nc;
-            S->plan_r = nc; S->plan_upto = upto; S->plan_ok = (nb > nc || upto > vt) ? 1 : 0;
-            S->la_planned += nb - nc;
-            if (la_on && !la) S->la_planned--;                      // paused: retried once the bad stretch has aged out
-            if (S->la_planned >= 256) { S->la_planned >>= 1; S->la_adopted >>= 1; }      // recent history counts
-        }
+        bk_plan_round(q, n, nbmax, cap, vt, la ? 1 : 0, la_on ? 1 : 0);
         BK_SYNC();
         const int nb = S->nb, ncur = S->ncur;
 #ifdef BK_PHASE_STAMPS
@@ -994,7 +1007,8 @@ __device__ __forceinline__ void bk_grow()
             // position of this k-mer in the contig (prediction seed); -1 disables the look-ahead
             if ((BK_TID >> 6) == 0) {
                 int pc = -1;
-                if (S->ncand >= 1) { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank]; pc = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, key, C_.k); }
+                // (a single candidate needs no prediction unless the round may go on into the following visits)
+                if (S->ncand >= 2 || (S->ncand == 1 && S->la_pause == 0 && !(C_.flags & BK_F_NO_XVISIT))) { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank]; pc = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, key, C_.k); }
                 if (BK_TID == 0) S->pc = pc;
             }
             BK_SYNC();
@@ -1114,7 +1128,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
         c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
-        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->la_planned = 0; S->la_adopted = 0;
+        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32;
 #ifdef BK_PHASE_STAMPS
         for (int i = 0; i < 20; i++) S->acc[i] = 0; S->ctx = 0;
         S->last = __builtin_amdgcn_s_memrealtime();

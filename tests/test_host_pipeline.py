@@ -276,3 +276,39 @@ def test_translocation_partner_discovery_from_files(tmp_path):
     run = sp.runner(cfg, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')))
     rows = run.run()
     check_trl_run(run, rows, r, tmp_path)
+
+
+def test_lazy_views_of_engine_records():
+    """hip_backend.KmerStrings / sv_assembly._KmerTuples / LazyContigs behave like the lists they stand for (the driver
+    builds per-target objects only when something looks at them)."""
+    from breakmer_amd import hip_backend as hb, sv_assembly as sa
+    ks = hb.KmerStrings(b"ACGTTGCAAAAA", 4, 3)
+    assert len(ks) == 3 and list(ks) == ["ACGT", "TGCA", "AAAA"] and ks[1] == "TGCA" and ks[-1] == "AAAA" and ks[0:2] == ["ACGT", "TGCA"]
+    assert ks == ["ACGT", "TGCA", "AAAA"]
+    with pytest.raises(IndexError):
+        ks[3]
+    kt = sa._KmerTuples(ks)
+    assert len(kt) == 3 and kt[0] == ("ACGT",) and [x[0] for x in kt] == list(ks) and kt[1:] == [("TGCA",), ("AAAA",)]
+
+    class Eng(object):
+        batch_serial = 4
+        calls = 0
+
+        def contig_count(self, region):
+            return 2
+
+        def contigs(self, region, lazy_kmers=False):
+            Eng.calls += 1
+            return [{"seq": "ACGTACGT", "indel_only": [0] * 8, "others": [2] * 8, "kmer_locs": [0] * 8, "kmers": hb.KmerStrings(b"ACGTCGTA", 4, 2), "reads": [0, 1]}] * 2
+
+    e = Eng()
+    reads = [sa.fq_read("@a/1_0", "ACGT", "IIII", False), sa.fq_read("@b/1_0", "ACGT", "IIII", False)]
+    lz = sa.LazyContigs(e, 0, reads, 4)
+    assert len(lz) == 2 and Eng.calls == 0                     # the count alone touches no record
+    assert lz[0].get_contig_seq() == "ACGTACGT" and Eng.calls == 1 and len(lz[0].kmers) == 2 and {r.id for r in lz[1].reads} == {"@a/1_0", "@b/1_0"}
+    lz2 = sa.LazyContigs(e, 0, reads, 4)
+    e.batch_serial = 5                                         # the engine took another batch before anything was read
+    with pytest.raises(RuntimeError):
+        lz2[0]
+    lz2.detach()
+    assert len(lz2) == 2
