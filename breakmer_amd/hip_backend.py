@@ -212,6 +212,8 @@ class Engine(object):
         cfg.reserved[0] = int(limits.get("flags", 0))
         cfg.reserved[1] = int(limits.get("wg_threads", 0))          # assembler workgroup size: 0 = library default, 256 (throughput) or 512 (latency)
         self.k = int(kmer_size)
+        self.rc_thresh, self.device = int(rc_thresh), int(device)
+        self._inputs = None
         self.h = C.c_void_p()
         self.batch_serial = 0
         rc = self.L.bk_create(int(device), C.byref(cfg), C.byref(self.h))
@@ -375,3 +377,38 @@ class Engine(object):
         self._chk(self.L.bk_nw_batch(self.h, bytes(blob), len(blob), o1.ctypes.data, l1.ctypes.data, o2.ctypes.data, l2.ctypes.data,
                                      len(pairs), reps, int(transposed), out.ctypes.data, C.byref(ms)), "bk_nw_batch")
         return out, ms.value
+
+
+# ---- handles kept between driver runs of one process ---------------------------------------------------------------------
+# Creating and destroying a handle costs ~35 ms (stream, pinned staging, device buffers sized by the first batch); a process
+# that runs the driver repeatedly (one sample after the other) keeps up to three per (device, k, rc_thresh).
+_POOL = {}
+_POOL_MAX = 3
+
+
+def acquire_engine(kmer_size, rc_thresh=2, device=0):
+    lst = _POOL.get((device, int(kmer_size), int(rc_thresh)))
+    if lst:
+        return lst.pop()
+    return Engine(kmer_size=kmer_size, rc_thresh=rc_thresh, device=device)
+
+
+def release_engine(eng):
+    key = (eng.device, eng.k, eng.rc_thresh)
+    lst = _POOL.setdefault(key, [])
+    if eng.h and len(lst) < _POOL_MAX:
+        eng._inputs = None                      # nothing of the last batch is pending on a handle the driver gives back
+        lst.append(eng)
+    else:
+        eng.close()
+
+
+def close_pool():
+    for lst in _POOL.values():
+        for e in lst:
+            e.close()
+    _POOL.clear()
+
+
+import atexit  # noqa: E402
+atexit.register(close_pool)

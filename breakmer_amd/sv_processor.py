@@ -605,6 +605,7 @@ class runner(object):                                               # sv_process
         self.engine_factory = engine_factory
         self.rank, self.world, self.collate = rank, world, collate
         self._ctx_head = None
+        self._pooled = []                       # handles to give back to hip_backend's pool when the run is over
         self.native_calls = native_calls        # SV-call tail in C++ (bk_call) instead of breakmer_amd/sv_caller.py; same rows
         self.engine = None
 
@@ -687,7 +688,9 @@ class runner(object):                                               # sv_process
             return self.engine_factory(self.params)
         from . import hip_backend
         dev = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0                # one process per GPU
-        return hip_backend.Engine(kmer_size=self.params.get_kmer_size(), rc_thresh=self.params.get_sr_thresh('min'), device=dev)
+        eng = hip_backend.acquire_engine(self.params.get_kmer_size(), self.params.get_sr_thresh('min'), dev)      # kept between runs of one process
+        self._pooled.append(eng)
+        return eng
 
     def run(self, start_time=None):                                  # :174-209
         names = self.create_targets()
@@ -711,28 +714,40 @@ class runner(object):                                               # sv_process
             self._launch_batch(eng, live)
             running.append((eng, live))
 
-        for b0 in range(0, len(mine), bsz):
-            live = []
-            for n in mine[b0:b0 + bsz]:
-                t = self.targets[n]
-                t.set_ref_data()
-                t.extract_bam_reads()
-                if not t.clean_reads():
-                    t.rm_output_dir()
+        ok = False
+        try:
+            for b0 in range(0, len(mine), bsz):
+                live = []
+                for n in mine[b0:b0 + bsz]:
+                    t = self.targets[n]
+                    t.set_ref_data()
+                    t.extract_bam_reads()
+                    if not t.clean_reads():
+                        t.rm_output_dir()
+                        continue
+                    live.append(t)
+                if not live:
                     continue
-                live.append(t)
-            if not live:
-                continue
-            eng = free.pop() if free else self._make_engine()
-            self.engine = eng
-            self._submit_batch(eng, live)
-            pending.append((eng, live))
-            if len(pending) > 1:
+                eng = free.pop() if free else self._make_engine()
+                self.engine = eng
+                self._submit_batch(eng, live)
+                pending.append((eng, live))
+                if len(pending) > 1:
+                    advance()
+            while pending:
                 advance()
-        while pending:
-            advance()
-        if running:
-            self._finish_batch(running[0][0], running[0][1], order)
+            if running:
+                self._finish_batch(running[0][0], running[0][1], order)
+            ok = True
+        finally:
+            from . import hip_backend
+            for eng in self._pooled:                                    # back to the pool after a clean run, closed otherwise
+                if ok:
+                    hip_backend.release_engine(eng)
+                else:
+                    eng.close()
+            self._pooled = []
+            self.engine = None
         if self.collate is not None and self.world > 1:               # collate per-region rows over ranks (RCCL all-gather)
             self.results, self.summary = self.collate(self.results, self.summary)
         self.results.sort(key=lambda x: x[0])                         # stable: target order (sv_processor.py:175-176), rows of a target as produced
