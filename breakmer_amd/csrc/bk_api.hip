@@ -433,7 +433,7 @@ static size_t asm_lds_bytes(const bk_handle *h, int threads)
 {
     const size_t waves = threads / 64;
     size_t o = threads == 512 ? at512::ctx_shared_bytes : at256::ctx_shared_bytes;
-    o += (size_t)h->cfg.max_candidates * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + (waves + 1) * (h->eff_max_read + 16);
+    o += (size_t)h->cfg.max_candidates * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + waves * 3 * (h->eff_max_read + 16) + (waves + 1) * (h->eff_max_read + 16);
     return (o + 15) / 16 * 16;
 }
 

@@ -49,11 +49,12 @@ struct BkAsmShared {
     unsigned long long cells, calls;
     BkNwResult v1, v2;
     // look-ahead slots (see bk_run_candidates): read q+s aligned against the PREDICTED contig after reads q..q+s-1
-    struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt, hasn, vt, rank; BkNwResult v1, v2; } slot[BK_SPEC];
+    struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt, hasn, vt, rank, fu, first; BkNwResult v1, v2; } slot[BK_SPEC];
     int nb, pc, last_dec, dual;
     // look-ahead across k-mer visits of grow (bk_run_candidates): slots [plan_r, nb) hold reads of LATER visits, already aligned
     // against the predicted contig; plan_upto = last visit (index into the snapshot) whose candidate list the plan knows
     int ncur, plan_r, plan_upto, plan_ok, hit;
+    int plan_kind;               // 0: slots of later visits of this grow snapshot; 1: slots of the first round of later SEEDS (vt = -2 - rank)
     int la_planned, la_adopted;  // slots planned for later visits / retired from there, in the current window of 64 planned
     int la_pause, la_backoff;    // rounds the look-ahead stays off after a window in which most of its slots were wasted (doubles)
     int la_n[BK_SPEC], la_t[BK_SPEC], la_rank[BK_SPEC], la_pc[BK_SPEC];
@@ -119,6 +120,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t bk_lds[];
 #define L_CSEQ (bk_lds + C_.o_cseq)
 #define L_RSEQ (bk_lds + C_.o_rseq + BK_SPEC * (C_.MAXR + 16))         // the generic read buffer (bk_load_read): not a slot's, slots outlive a visit
 #define L_RSEQ_S(s) (bk_lds + C_.o_rseq + (s) * (C_.MAXR + 16))
+#define BK_SEEDBUF(g) (2 * C_.MAXC + (g) * 3 * (C_.MAXR + 16))         // offset (from L_CSEQ) of the strip of look-ahead seed g
 #define L_BOUND ((int *)(bk_lds + C_.o_bound))
 #define L_BOUND_W(w) ((int *)(bk_lds + C_.o_bound) + (w) * 2 * (C_.MAXR + 2))
 #define L_CAND ((unsigned long long *)(bk_lds + C_.o_cand))
@@ -648,16 +650,76 @@ BK_COLD void bk_lookahead_wave(int w, int vt, int T)
     if (lane == 0) { S->la_n[w] = cnt; S->la_t[w] = tt; S->la_rank[w] = rank2; S->la_pc[w] = pc2; }
 }
 
+// The same for the SEEDS that follow (setup_contigs :11-26).  With sequencing noise most DP rounds are the first round of a
+// seed: an error k-mer shared by two or three reads, one of them the founder.  The seeds to come are the next live k-mers in
+// (count, mer) order, their candidate lists are find_reads results without a buffer filter (only deleted reads are left out).
+// Wavefront w takes the (w+1)-th live k-mer after `rank`: list in find_reads order (entry 0 = founder) with the slot fields.
+BK_COLD void bk_seedahead_wave(int w, int rank)
+{
+    BkAsmShared *S = S_;
+    const int lane = BK_TID & 63;
+    const int r = rank + 1 + lane;
+    const bool live = r < (int)C_.M && C_.kstate[r < (int)C_.M ? r : 0] == BK_K_LIVE && C_.kcnt[r < (int)C_.M ? r : 0] >= 2;
+    unsigned long long m = __ballot(live);
+    for (int i = 0; i < w; i++) m &= m - 1;
+    int cnt = -1, rank2 = 0;
+    if (m) {
+        rank2 = rank + 1 + (__ffsll((long long)m) - 1);
+        const uint32_t b = C_.poff[rank2], e = C_.poff[rank2 + 1];
+        if (e - b <= 64u * BK_LA_CH) {
+            const int np = (int)(e - b);
+            uint32_t pe[BK_LA_CH]; uint32_t fl[BK_LA_CH];
+#pragma unroll
+            for (int c = 0; c < BK_LA_CH; c++) pe[c] = lane + 64 * c < np ? C_.post[b + lane + 64 * c] : 0u;
+#pragma unroll
+            for (int c = 0; c < BK_LA_CH; c++) fl[c] = lane + 64 * c < np ? C_.ufl[pe[c] >> 10] : 0u;
+            int nv = 0;
+#pragma unroll
+            for (int c = 0; c < BK_LA_CH; c++) {
+                const bool okc = lane + 64 * c < np && !(fl[c] & BK_R_DELETED);             // used_reads = set(): no buffer filter
+                const unsigned long long vm = __ballot(okc);
+                const int at = nv + __popcll(vm & ((1ull << lane) - 1ull));
+                if (okc && at < 64) { BK_LA_RL(w)[at] = (int)pe[c]; BK_LA_FL(w)[at] = (int)fl[c]; }
+                nv += __popcll(vm);
+            }
+            if (nv <= 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const bool have = lane < nv;
+                const uint32_t mypost = have ? (uint32_t)BK_LA_RL(w)[lane] : 0u; const uint32_t myfl = have ? (uint32_t)BK_LA_FL(w)[lane] : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const uint32_t u = mypost >> 10; const int pos = (int)(mypost & 1023u);
+                uint32_t len = 0; int rn = 0;
+                if (have) { len = C_.ulen[u]; rn = (int)C_.unr[u]; }
+                bool drop = false;
+                for (int j = 0; j < nv; j++) {
+                    const uint32_t oen = (uint32_t)__builtin_amdgcn_readlane((int)mypost, j);
+                    drop = drop || ((oen >> 10) == u && (int)(oen & 1023u) < pos);
+                }
+                const bool valid = have && !drop;
+                const unsigned long long key = valid ? (((unsigned long long)pos << 40) | ((0xFFFFull - len) << 24) | u) : ~0ull;
+                int ord = 0;
+                for (int j = 0; j < nv; j++) {
+                    const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+                    ord += kj < key;
+                }
+                if (valid) { BK_LA_CU(w)[ord] = u | ((uint32_t)pos << 22); BK_LA_RL(w)[ord] = (int)len; BK_LA_RN(w)[ord] = rn; BK_LA_FL(w)[ord] = (int)myfl; }
+                cnt = __popcll(__ballot(valid));
+            }
+        }
+    }
+    if (lane == 0) { S->la_n[w] = cnt; S->la_t[w] = -2 - rank2; S->la_rank[w] = rank2; S->la_pc[w] = 0; }
+}
+
 // one step of the prediction chain (thread 0): slot t is aligned against the contig [pb, pb+plen) in which its k-mer sits
 // at ppc; what the read is predicted to do to it.  Returns false when nothing can be predicted past this slot.
-__device__ inline bool bk_predict(BkAsmShared::Slot &t, int &pb, int &plen, int &ppc)
+__device__ inline bool bk_predict(BkAsmShared::Slot &t, int &pb, int &plen, int &ppc, int lo, int hi)
 {
     const int pos = t.pos, rl = t.rl;
     t.pb = pb; t.plen = plen;
     const int left = pos - ppc, right = (rl - pos) - (plen - ppc);
     if (ppc < 0 || (left > 0 && right > 0)) { t.kind = BK_PK_STOP; t.amt = 0; return false; }
-    if (left > 0) { t.kind = BK_PK_PRE; t.amt = left; if (pb - left < 0 || plen + left > C_.MAXC) { t.kind = BK_PK_STOP; return false; } pb -= left; plen += left; ppc += left; }
-    else if (right > 0) { t.kind = BK_PK_POST; t.amt = right; if (pb + plen + right > 2 * C_.MAXC || plen + right > C_.MAXC) { t.kind = BK_PK_STOP; return false; } plen += right; }
+    if (left > 0) { t.kind = BK_PK_PRE; t.amt = left; if (pb - left < lo || plen + left > C_.MAXC) { t.kind = BK_PK_STOP; return false; } pb -= left; plen += left; ppc += left; }
+    else if (right > 0) { t.kind = BK_PK_POST; t.amt = right; if (pb + plen + right > hi || plen + right > C_.MAXC) { t.kind = BK_PK_STOP; return false; } plen += right; }
     else { t.kind = BK_PK_SAME; t.amt = 0; }
     return true;
 }
@@ -666,7 +728,9 @@ __device__ inline bool bk_predict(BkAsmShared::Slot &t, int &pb, int &plen, int 
 __device__ __forceinline__ int bk_retire_checked(int sl, bool grow)
 {
     BkAsmShared *S = S_;
-    if (sl > 0) {
+    if (S->slot[sl].first) {                        // first read of a seed planned ahead: the contig is its founder, nothing came before
+        if (S->cbase != S->slot[sl].pb || S->clen != S->slot[sl].plen) return 0;
+    } else if (sl > 0) {
         const int pk = S->slot[sl - 1].kind, ld = S->last_dec;
         const bool kind_ok = (pk == BK_PK_PRE && ld == BK_DEC_PRE) || (pk == BK_PK_POST && ld == BK_DEC_POST) ||
                              (pk == BK_PK_SAME && (ld == BK_DEC_NONE || ld == BK_DEC_SAME || ld == BK_DEC_SUB));
@@ -694,7 +758,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     for (int sl = 0; sl < nbmax && go; sl++) {
         if (sl >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
         nb = sl + 1;
-        go = bk_predict(S->slot[sl], pb, plen, ppc);
+        go = bk_predict(S->slot[sl], pb, plen, ppc, 0, 2 * C_.MAXC);
     }
     const int ncur = nb;
     int upto = vt;
@@ -704,7 +768,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     else if (la_on && S->la_n[0] < 0) S->acc[19] += 1ull << 32;                  // ... next visit: none in the window or posting list too long
     else if (la_on && S->la_n[0] == 0) S->acc[19] += 1ull << 48;                 // ... next visit has no eligible read
 #endif
-    if (la && go && q + ncur == n) {
+    if (la && vt >= 0 && go && q + ncur == n) {
         for (int w = 0; w < BK_AT / 64 && go; w++) {
             const int cn = S->la_n[w];
             if (cn < 0) break;
@@ -729,12 +793,41 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
                 const int fl = BK_LA_FL(w)[i];
                 t.u = u; t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
                 t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
-                t.vt = S->la_t[w]; t.rank = S->la_rank[w];
+                t.vt = S->la_t[w]; t.rank = S->la_rank[w]; t.fu = -1; t.first = 0;
                 nb++;
-                go = bk_predict(t, pb, plen, ppc);
+                go = bk_predict(t, pb, plen, ppc, 0, 2 * C_.MAXC);
             }
             if (nb - nb0 != keep) { nb = nb0; break; }      // a visit is planned whole or not at all
             upto = S->la_t[w];
+        }
+    }
+    int kind = 0;
+    if (la && vt < 0 && q + ncur == n) {
+        // the first round of the seeds that follow: a group per seed, aligned against its founder in a strip of its own
+        kind = 1;
+        int g = 0;
+        for (int w = 0; w < BK_AT / 64; w++) {
+            const int cn = S->la_n[w];
+            if (cn < 0) break;
+            if (cn < 2) continue;                                   // a seed with its founder only has no DP
+            if (nb + cn - 1 > cap) break;
+            const uint32_t fcu = BK_LA_CU(w)[0];
+            const int base = BK_SEEDBUF(g) + C_.MAXR + 16, lo = BK_SEEDBUF(g), hi = BK_SEEDBUF(g) + 3 * (C_.MAXR + 16);
+            int pb2 = base, plen2 = BK_LA_RL(w)[0], ppc2 = (int)(fcu >> 22);          // the contig IS the founder; the k-mer sits where it sits in that read
+            const int nb0 = nb; bool whole = true;
+            for (int i = 1; i < cn; i++) {
+                const uint32_t cu = BK_LA_CU(w)[i];
+                if (nb >= BK_SPEC_WIDE && plen2 > BK_NW_DUAL_COLS) { whole = false; break; }
+                BkAsmShared::Slot &t = S->slot[nb];
+                const int fl = BK_LA_FL(w)[i];
+                t.u = (int)(cu & 0x3FFFFFu); t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
+                t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
+                t.vt = S->la_t[w]; t.rank = S->la_rank[w]; t.fu = (int)(fcu & 0x3FFFFFu); t.first = (i == 1) ? 1 : 0;
+                nb++;
+                if (!bk_predict(t, pb2, plen2, ppc2, lo, hi) && i + 1 < cn) { whole = false; break; }
+            }
+            if (!whole) { nb = nb0; continue; }                     // a seed is planned whole or not at all
+            g++;
         }
     }
     int mx = 0;
@@ -745,7 +838,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     int nc = ncur;
     if (!S->dual && nb > BK_SPEC_WIDE) { nc = min(nc, BK_SPEC_WIDE); nb = nc; upto = vt; }      // two wavefronts per slot: this visit's reads only
     S->nb = nb; S->ncur = nc;
-    S->plan_r = nc; S->plan_upto = upto; S->plan_ok = (nb > nc || upto > vt) ? 1 : 0;
+    S->plan_r = nc; S->plan_upto = upto; S->plan_ok = (nb > nc || upto > vt) ? 1 : 0; S->plan_kind = kind;
     S->la_planned += nb - nc;
     if (la_on && S->la_pause > 0) S->la_pause--;
     if (S->la_planned >= 64) {                      // one window: did the slots planned for later visits get used?
@@ -765,7 +858,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
     //    (uniform: every thread evaluates the same LDS words)
     bool adopt = false;
     int r0 = 0;
-    if (vt >= 0 && S->plan_ok) {
+    if (vt >= 0 && S->plan_ok && S->plan_kind == 0) {
         r0 = S->plan_r;
         adopt = vt <= S->plan_upto;
         int g = 0;
@@ -778,10 +871,29 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             adopt = false;
         }
     }
+    if (vt == -1 && S->plan_ok && S->plan_kind == 1) {
+        // a setup round planned the first round of this seed ahead: same founder, same candidates -> adopt
+        const int nbp = S->nb;
+        int r = S->plan_r;
+        while (r < nbp && -2 - S->slot[r].vt < rank) r++;          // seeds that never came up (their k-mer was used up meanwhile)
+        int g = 0; bool ad = false;
+        if (r < nbp && -2 - S->slot[r].vt == rank) {
+            while (r + g < nbp && S->slot[r + g].vt == S->slot[r].vt) g++;
+            ad = n >= 2 && g == n - 1 && S->slot[r].first && S->slot[r].fu == (int)(L_CANDU[0] & 0x3FFFFFu);
+            for (int i = 0; ad && i < g; i++) { const uint32_t cu = L_CANDU[1 + i]; ad = S->slot[r + i].u == (int)(cu & 0x3FFFFFu) && S->slot[r + i].pos == (int)(cu >> 22); }
+        }
+        BK_SYNC();
+        if (BK_TID == 0) {
+            if (ad) { const int delta = S->cbase - S->slot[r].pb; for (int i = 0; i < g; i++) S->slot[r + i].pb += delta; S->plan_r = r; }      // strip -> contig deque coordinates
+            else { S->plan_r = r + g; if (S->plan_r >= nbp) S->plan_ok = 0; }
+        }
+        BK_SYNC();
+        if (ad) { adopt = true; r0 = r; }
+    }
     // one loop for both kinds of pass, so that the decision/apply step (bk_retire) is inlined once: a pass either retires
     // the adopted slots of this visit or plans, aligns and retires a fresh round
     while (adopt || q < n) {
-        int s0 = r0, s1 = r0 + n;                   // the adopted slots of this visit ...
+        int s0 = r0, s1 = r0 + (n - q);             // the adopted slots of this visit / seed ...
         if (!adopt) {                               // ... or a fresh round:
         if (S->status) return;
         BK_ACC(S_->ctx);
@@ -789,7 +901,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         const int cap = ((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) || S->clen > BK_NW_DUAL_COLS) ? BK_SPEC_WIDE : BK_SPEC;
         const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
         // look into the following visits when this one leaves slots free (needs the scratch for BK_AT/64 lists of 64 reads)
-        const bool la_on = vt >= 0 && n - q < cap && !(C_.flags & BK_F_NO_XVISIT) && 2 * C_.MAXCAND >= 4 * BK_AT;
+        const bool la_on = n - q < cap && !(C_.flags & (vt >= 0 ? BK_F_NO_XVISIT : BK_F_NO_XSEED)) && 2 * C_.MAXCAND >= 4 * BK_AT;
         const bool la = la_on && S->la_pause == 0;
         // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
         BK_SYNC();
@@ -799,9 +911,9 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             BkAsmShared::Slot &t = S->slot[BK_TID];
             t.u = u; t.pos = (int)(cu >> 22); t.rl = C_.rlen[ri]; t.rn = (int)C_.unr[u]; t.rindel = (C_.ufl[u] & BK_R_INDEL) ? 1 : 0;
             t.hasn = (C_.n_nlist && (C_.ufl[u] & BK_R_HASN)) ? 1 : 0;
-            t.vt = vt; t.rank = rank;
+            t.vt = vt; t.rank = rank; t.fu = -1; t.first = 0;
         }
-        if (la) bk_lookahead_wave(wv, vt, T);
+        if (la) { if (vt >= 0) bk_lookahead_wave(wv, vt, T); else bk_seedahead_wave(wv, rank); }
         BK_SYNC();
         bk_plan_round(q, n, nbmax, cap, vt, la ? 1 : 0, la_on ? 1 : 0);
         BK_SYNC();
@@ -816,6 +928,16 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
                 const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
                 const uint32_t *w = C_.reads + (uint64_t)C_.urep[S->slot[sl].u] * C_.read_words;
                 for (int t = ln; t < rl; t += 64) rs[t] = (uint8_t)seq_base(w, t);
+                if (S->slot[sl].first) {                 // founder of a seed planned ahead: the contig its reads are aligned against
+                    const uint32_t fri = C_.urep[S->slot[sl].fu];
+                    const uint32_t *fw = C_.reads + (uint64_t)fri * C_.read_words;
+                    uint8_t *fs = L_CSEQ + S->slot[sl].pb; const int fl2 = S->slot[sl].plen;
+                    for (int t = ln; t < fl2; t += 64) fs[t] = (uint8_t)seq_base(fw, t);
+                    if (C_.n_nlist && (C_.ufl[S->slot[sl].fu] & BK_R_HASN)) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                        if (ln == 0) bk_patch_n(fri, fs, 0, fl2);
+                    }
+                }
                 if (sl + 1 < nb) {
                     const int amt = S->slot[sl].amt, pb = S->slot[sl].pb, plen = S->slot[sl].plen;
                     if (S->slot[sl].kind == BK_PK_PRE) for (int t = ln; t < amt; t += 64) L_CSEQ[pb - amt + t] = (uint8_t)seq_base(w, t);
@@ -971,7 +1093,7 @@ __device__ __forceinline__ void bk_grow()
             if (!has) { C_.kstamp[3 * rank] = S->serial; C_.nklist[t] = en | 0x40000000u; }       // checked_kmers is only read by the next snapshot
         }
         BK_SYNC();
-        if (BK_TID == 0) S->plan_ok = 0;                                           // a plan refers to one snapshot (and one contig)
+        if (BK_TID == 0 && S->plan_kind == 0) S->plan_ok = 0;                      // a plan of visits refers to one snapshot (and one contig)
         BK_SYNC();
         uint32_t t = 0, en_next = C_.nklist[0];
         while (t < T) {
@@ -1116,7 +1238,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.o_cand = o; o += c.MAXCAND * 8;
         c.o_bound = o; o += (BK_AT / 64) * 2 * (c.MAXR + 2) * 4;
         c.o_candu = o; o += c.MAXCAND * 4;
-        c.o_cseq = o; o += 2 * c.MAXC;
+        c.o_cseq = o; o += 2 * c.MAXC + BK_SPEC * 3 * (c.MAXR + 16);      // + one [read | founder | read] strip per look-ahead seed
         c.o_rseq = o; o += (BK_SPEC + 1) * (c.MAXR + 16);
         c.reads = p.reads + d.reads_word_off; c.rlen = p.read_len + d.read_meta_off;
         c.nlist = p.nlist + d.nlist_off; c.n_nlist = d.n_nlist;
@@ -1128,7 +1250,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
         c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
-        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32;
+        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32;
 #ifdef BK_PHASE_STAMPS
         for (int i = 0; i < 20; i++) S->acc[i] = 0; S->ctx = 0;
         S->last = __builtin_amdgcn_s_memrealtime();

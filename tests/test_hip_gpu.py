@@ -691,15 +691,15 @@ def test_async_submit_gpu(hb):
 
 @pytest.mark.gpu
 def test_lookahead_across_visits_changes_nothing_gpu(hb):
-    """The look-ahead across k-mer visits only moves DPs to an earlier round: contigs, realign records and the DP work
-    counted (the reference's nw calls and cells) are the same with it switched off (bk_config.reserved[0] = 8), for both
-    workgroup sizes, on clean, noisy and N-carrying regions; and the round count really drops on deep clean regions."""
+    """The look-ahead across k-mer visits and into the next seeds only moves DPs to an earlier round: contigs, realign
+    records and the DP work counted (the reference's nw calls and cells) are the same with either or both switched off
+    (bk_config.reserved[0] = 8 / 16 / 24), for both workgroup sizes, on clean, noisy and N-carrying regions."""
     regions = [synth.make_region(7300 + i, sv_type=synth.SV_TYPES[i % 5], depth=(300 if i % 3 == 0 else 60), W=1200, L=100,
-                                 noise=(0.0, 0.0, 0.004, 0.03)[i % 4], n_frac=(0.2 if i % 7 == 0 else 0.0)) for i in range(40)]
+                                 noise=(0.0, 0.006, 0.004, 0.03)[i % 4], n_frac=(0.2 if i % 7 == 0 else 0.0)) for i in range(40)]
     ins = [hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only, partners=[p[4] for p in r.partners]) for r in regions]
     ref = None
     for wg in (512, 256):
-        for flags in (8, 0):
+        for flags in (24, 8, 16, 0):
             eng = hb.Engine(kmer_size=31, flags=flags, wg_threads=wg)
             eng.submit(ins)
             eng.run(7)

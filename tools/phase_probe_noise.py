@@ -4,7 +4,7 @@ from breakmer_amd import hip_backend as hb, synth
 hb.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libbk_stamps_probe")
 noise = float(sys.argv[1]) if len(sys.argv) > 1 else 0.005
 regions = [synth.make_region(900, sv_type="del", depth=500, W=3000, L=150, noise=noise)]
-eng = hb.Engine(kmer_size=31, wg_threads=int(os.environ.get("BK_WG", "0")))
+eng = hb.Engine(kmer_size=31, wg_threads=int(os.environ.get("BK_WG", "0")), flags=int(os.environ.get("BK_FLAGS", "0")))
 eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
 eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)
 eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)
