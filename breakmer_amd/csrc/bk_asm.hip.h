@@ -56,7 +56,8 @@ struct BkAsmShared {
     int ncur, plan_r, plan_upto, plan_ok, hit;
     int plan_kind;               // 0: slots of later visits of this grow snapshot; 1: slots of the first round of later SEEDS (vt = -2 - rank)
     int la_planned, la_adopted;  // slots planned for later visits / retired from there, in the current window of 64 planned
-    int la_pause, la_backoff;    // rounds the look-ahead stays off after a window in which most of its slots were wasted (doubles)
+    int la_pause, la_backoff;
+    int n_rej, n_acc;            // recent reads rejected / accepted by check_align: with most rejected, the prediction is "nothing changes"    // rounds the look-ahead stays off after a window in which most of its slots were wasted (doubles)
     int la_n[BK_SPEC], la_t[BK_SPEC], la_rank[BK_SPEC], la_pc[BK_SPEC];
     int qslot;                   // position in the region queue this workgroup is working on
     uint32_t scan[24];
@@ -520,6 +521,8 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
     // check_read bookkeeping (:552-565)
     if (BK_TID == 0) {
         S->last_dec = dec; S->hit = match ? 1 : 0;
+        if (match) S->n_acc++; else S->n_rej++;
+        if (S->n_acc + S->n_rej >= 64) { S->n_acc >>= 1; S->n_rej >>= 1; }
         C_.ubuf[u] = S->serial;                                                    // self.buffer.add(read.id)
         S->cells += 2ull * (unsigned long long)clen * (unsigned long long)rl; S->calls += 2;
         if (match) {
@@ -710,12 +713,17 @@ BK_COLD void bk_seedahead_wave(int w, int rank)
     if (lane == 0) { S->la_n[w] = cnt; S->la_t[w] = -2 - rank2; S->la_rank[w] = rank2; S->la_pc[w] = 0; }
 }
 
+__device__ inline bool bk_expect_reject() { return S_->n_rej >= 24 && S_->n_rej >= 3 * S_->n_acc; }
+
 // one step of the prediction chain (thread 0): slot t is aligned against the contig [pb, pb+plen) in which its k-mer sits
 // at ppc; what the read is predicted to do to it.  Returns false when nothing can be predicted past this slot.
 __device__ inline bool bk_predict(BkAsmShared::Slot &t, int &pb, int &plen, int &ppc, int lo, int hi)
 {
     const int pos = t.pos, rl = t.rl;
     t.pb = pb; t.plen = plen;
+    // noisy reads: where check_align has lately rejected three reads out of four, the best guess for the next one is that
+    // it is rejected too and the contig stays as it is (a rejection after a predicted extension would void the later slots)
+    if (bk_expect_reject()) { t.kind = BK_PK_SAME; t.amt = 0; return true; }
     const int left = pos - ppc, right = (rl - pos) - (plen - ppc);
     if (ppc < 0 || (left > 0 && right > 0)) { t.kind = BK_PK_STOP; t.amt = 0; return false; }
     if (left > 0) { t.kind = BK_PK_PRE; t.amt = left; if (pb - left < lo || plen + left > C_.MAXC) { t.kind = BK_PK_STOP; return false; } pb -= left; plen += left; ppc += left; }
@@ -781,7 +789,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
             }
             if (nb + keep > cap) break;
             const int pc2 = S->la_pc[w];
-            if (keep > 0 && pc2 < 0) break;
+            if (keep > 0 && pc2 < 0 && !bk_expect_reject()) break;
             ppc = pc2 + (S->cbase - pb);                    // the predicted contig starts cbase - pb bases before the current one
             const int nb0 = nb;
             for (int i = 0; i < cn && go; i++) {
@@ -1250,7 +1258,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
         c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
-        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32;
+        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32; S->n_rej = 0; S->n_acc = 0;
 #ifdef BK_PHASE_STAMPS
         for (int i = 0; i < 20; i++) S->acc[i] = 0; S->ctx = 0;
         S->last = __builtin_amdgcn_s_memrealtime();
