@@ -571,6 +571,9 @@ __device__ __noinline__ void bk_dp_round()
         }
     }
 }
+// noisy reads: check_align has lately rejected three reads out of four (prediction then is "nothing changes", bk_predict)
+__device__ inline bool bk_expect_reject() { return S_->n_rej >= 24 && S_->n_rej >= 3 * S_->n_acc; }
+
 // Look-ahead across the k-mer visits of grow.  A visit usually recruits only a handful of reads (clean data) or a single
 // one (sequencing noise), far fewer than there are look-ahead slots.  The visits of a snapshot are known in advance
 // (nklist), and so is the candidate list of a LATER visit: every read a visit looks at ends up in the contig's buffer
@@ -646,7 +649,7 @@ BK_COLD void bk_lookahead_wave(int w, int vt, int T)
                 if (valid) { BK_LA_CU(w)[ord] = u | ((uint32_t)pos << 22); BK_LA_RL(w)[ord] = (int)len; BK_LA_RN(w)[ord] = rn; BK_LA_FL(w)[ord] = (int)myfl; }
                 cnt = __popcll(__ballot(valid));
                 BkKey kk; kk.hi = C_.khi[rank2]; kk.lo = C_.klo[rank2];
-                pc2 = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, kk, C_.k);
+                if (!bk_expect_reject()) pc2 = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, kk, C_.k);      // the geometry is not used while rejections are expected
             }
         }
     }
@@ -712,8 +715,6 @@ BK_COLD void bk_seedahead_wave(int w, int rank)
     }
     if (lane == 0) { S->la_n[w] = cnt; S->la_t[w] = -2 - rank2; S->la_rank[w] = rank2; S->la_pc[w] = 0; }
 }
-
-__device__ inline bool bk_expect_reject() { return S_->n_rej >= 24 && S_->n_rej >= 3 * S_->n_acc; }
 
 // one step of the prediction chain (thread 0): slot t is aligned against the contig [pb, pb+plen) in which its k-mer sits
 // at ppc; what the read is predicted to do to it.  Returns false when nothing can be predicted past this slot.
@@ -786,6 +787,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
                 const int u = (int)(BK_LA_CU(w)[i] & 0x3FFFFFu); bool inflight = false;
                 for (int s2 = 0; s2 < nb; s2++) inflight = inflight || S->slot[s2].u == u;
                 keep += !inflight;
+                if (nb + keep > cap) break;                         // does not fit: no need to look at the rest of the list
             }
             if (nb + keep > cap) break;
             const int pc2 = S->la_pc[w];
@@ -850,7 +852,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     S->la_planned += nb - nc;
     if (la_on && S->la_pause > 0) S->la_pause--;
     if (S->la_planned >= 64) {                      // one window: did the slots planned for later visits get used?
-        if (2 * S->la_adopted < S->la_planned) { S->la_pause = S->la_backoff; S->la_backoff = min(2 * S->la_backoff, 4096); }
+        if (4 * S->la_adopted < S->la_planned) { S->la_pause = S->la_backoff; S->la_backoff = min(2 * S->la_backoff, 4096); }
         else S->la_backoff = 32;
         S->la_planned = 0; S->la_adopted = 0;
     }
@@ -1138,7 +1140,7 @@ __device__ __forceinline__ void bk_grow()
             if ((BK_TID >> 6) == 0) {
                 int pc = -1;
                 // (a single candidate needs no prediction unless the round may go on into the following visits)
-                if (S->ncand >= 2 || (S->ncand == 1 && S->la_pause == 0 && !(C_.flags & BK_F_NO_XVISIT))) { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank]; pc = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, key, C_.k); }
+                if (!bk_expect_reject() && (S->ncand >= 2 || (S->ncand == 1 && S->la_pause == 0 && !(C_.flags & BK_F_NO_XVISIT)))) { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank]; pc = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, key, C_.k); }
                 if (BK_TID == 0) S->pc = pc;
             }
             BK_SYNC();

@@ -2,7 +2,7 @@
 # "expect a rejection" predictor on noisy reads: noise probes, other configs, against the build before it
 for nz in 0.005 0.02 0.05; do echo NOISE $nz; BK_WG=512 timeout 300 python3 tools/phase_probe_noise.py $nz 2>&1 | grep -E "asm kernel|DP |rounds"; done
 B="--cpu-sample 0 --steps 40"
-for lib in "" "--lib oldlibs/lib_before_pess.so"; do
+for lib in "" "--lib oldlibs/lib_before_thr.so"; do
 python3 bench.py $B $lib 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1] or 'new', d['value'], d['one_step_at_a_time']['kernels_ms']['bk_asm_kernel']);
