@@ -51,7 +51,7 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (testing)")
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
     ap.add_argument("--cfg3-regions", type=int, default=4096, help="batch size of the configs[3] side measurement (heavy regions: the chip fills at a few thousand)")
-    ap.add_argument("--cfg4-regions", type=int, default=64)
+    ap.add_argument("--cfg4-regions", type=int, default=256, help="batch size of the configs[4] side measurement (one workgroup per region in the k-mer stage: 64 regions leave three quarters of the chip idle)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic library flags (bk_config.reserved[0]); 0 in every reported number")
     ap.add_argument("--lib", default=None, help="diagnostic: path of an alternative build of the library (A/B runs on one box)")
     ap.add_argument("--dump-collated", default=None, help="write the bytes collated in the last step to this file (testing)")
