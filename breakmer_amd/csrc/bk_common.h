@@ -171,7 +171,7 @@ struct BkParams {
     int32_t n_regions;
     int32_t flags;               // BK_F_*
 };
-enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16 };   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
+enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32 };   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
 
 __device__ inline uint64_t bk_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 

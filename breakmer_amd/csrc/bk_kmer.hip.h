@@ -213,6 +213,103 @@ __device__ inline bool bk_kmer_before(uint32_t ca, const BkKey &ka, uint32_t cb,
     return key_lt(kb, ka);
 }
 
+// ---- order of the seed-capable k-mers when they do not fit the LDS (regions with heavy sequencing noise: millions) ----
+// One workgroup cannot bitonic-sort millions of keys in global memory in reasonable time (0.2 s for 3.4 M).  The order is
+// (count, mer) descending and the k-mers are spread evenly over the mer space, so: histogram over the counts (<= 254
+// exact, the rest in one class), every class split by as many leading mer bits as make its buckets ~128 k-mers, one
+// counting pass and one scattering pass through global counters, then each bucket is sorted by ONE wavefront in LDS on
+// a 64-bit proxy (count and leading mer bits; ties settled on the full key).  A bucket that does not fit (more than
+// 512: skewed mers, many counts >= 255) makes the caller fall back to the global bitonic sort.
+#define BK_BS_CAP 512
+__device__ inline uint64_t bk_key_top64(const BkKey &key, int k)
+{
+    const int B = 2 * k;
+    return B <= 64 ? key.lo << (64 - B) : (B == 128 ? key.hi : ((key.hi << (128 - B)) | (key.lo >> (B - 64))));
+}
+// returns (uniform) whether perm[0..M2) is in order now; L: LDS scratch of LC words; bst/bcur: global scratch of `bcap` words each
+__device__ inline bool bk_bucket_sort(uint32_t *perm, uint32_t M2, const uint64_t *klo, const uint64_t *khi, const uint32_t *kcnt, int k,
+                                      uint32_t *L, uint32_t LC, uint32_t *bst, uint32_t *bcur, uint32_t bcap, uint32_t *scr)
+{
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6;
+    if (LC < 1024 + 1536) return false;
+    uint32_t *hc = L, *sb = L + 256, *bb = L + 512;            // per count class: size, split bits, first bucket
+    for (uint32_t c = tid; c < 256; c += nt) hc[c] = 0;
+    __syncthreads();
+    for (uint32_t j = tid; j < M2; j += nt) atomicAdd(&hc[min(kcnt[j], 255u)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t nbk = 0;
+        for (int c = 255; c >= 0; c--) {                         // descending count
+            uint32_t s = 0;
+            if (c < 255) while ((hc[c] >> s) > 128u && s < 24u) s++;
+            sb[c] = s; bb[c] = nbk; nbk += hc[c] ? (1u << s) : 0u;
+        }
+        scr[26] = nbk;
+    }
+    __syncthreads();
+    const uint32_t NB = scr[26];
+    if (NB + 1 > bcap) return false;
+    for (uint32_t b = tid; b <= NB; b += nt) bst[b] = 0;
+    __syncthreads();
+    auto bucket_of = [&](uint32_t j) -> uint32_t {
+        const uint32_t c = min(kcnt[j], 255u), s = sb[c];
+        const BkKey key{khi[j], klo[j]};
+        const uint32_t top = s ? (uint32_t)(bk_key_top64(key, k) >> (64 - s)) : 0u;
+        return bb[c] + ((1u << s) - 1u - top);                   // mer descending inside the class
+    };
+    for (uint32_t j = tid; j < M2; j += nt) atomicAdd(&bst[bucket_of(j)], 1u);
+    __syncthreads();
+    {   // exclusive prefix over the buckets -> first position of each; a copy serves as the scatter cursor
+        const uint32_t chunk = (NB + nt - 1) / nt, b0 = tid * chunk, b1 = min(NB, b0 + chunk);
+        uint32_t c = 0, tot = 0, big = 0;
+        for (uint32_t b = b0; b < b1; b++) { c += bst[b]; big |= bst[b] > BK_BS_CAP; }
+        uint32_t pre = bk_block_excl_scan(c, scr, &tot);
+        for (uint32_t b = b0; b < b1; b++) { const uint32_t n = bst[b]; bst[b] = pre; bcur[b] = pre; pre += n; }
+        if (tid == 0) { bst[NB] = tot; scr[27] = 0; }
+        __syncthreads();
+        if (big) scr[27] = 1;
+        __syncthreads();
+        if (scr[27]) return false;                               // some bucket is larger than a wavefront sorts
+    }
+    for (uint32_t j = tid; j < M2; j += nt) perm[atomicAdd(&bcur[bucket_of(j)], 1u)] = j;
+    __syncthreads();
+    // one wavefront per bucket; (proxy, index) pairs in LDS
+    const uint32_t stride = BK_BS_CAP * 3, nwv = min(nt >> 6, LC / stride);
+    if (wv < nwv) {
+        unsigned long long *K = (unsigned long long *)(L + wv * stride); uint32_t *P = L + wv * stride + 2 * BK_BS_CAP;
+        for (uint32_t b = wv; b < NB; b += nwv) {
+            const uint32_t start = bst[b], n = bst[b + 1] - start;
+            if (n < 2) continue;
+            uint32_t np2 = 2; while (np2 < n) np2 <<= 1;
+            for (uint32_t e = lane; e < np2; e += 64) {
+                if (e < n) {
+                    const uint32_t j = perm[start + e]; const BkKey key{khi[j], klo[j]};
+                    K[e] = ((unsigned long long)min(kcnt[j], 0xFFFFFu) << 44) | (bk_key_top64(key, k) >> 20); P[e] = j;
+                } else { K[e] = 0; P[e] = BK_EMPTY32; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            for (uint32_t sz = 2; sz <= np2; sz <<= 1)
+                for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+                    for (uint32_t i = lane; i < np2 / 2; i += 64) {
+                        const uint32_t lo = (i / st) * (st * 2) + (i % st), hi2 = lo + st;
+                        const bool up = (lo & sz) == 0;
+                        const unsigned long long ka = K[lo], kb = K[hi2]; const uint32_t a = P[lo], b2 = P[hi2];
+                        bool a_first;
+                        if (a == BK_EMPTY32) a_first = false; else if (b2 == BK_EMPTY32) a_first = true;
+                        else if (ka != kb) a_first = ka > kb;
+                        else { const BkKey fa{khi[a], klo[a]}, fb{khi[b2], klo[b2]}; a_first = bk_kmer_before(kcnt[a], fa, kcnt[b2], fb); }
+                        if (a_first != up) { K[lo] = kb; K[hi2] = ka; P[lo] = b2; P[hi2] = a; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                }
+            for (uint32_t e = lane; e < n; e += 64) perm[start + e] = P[e];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
 #ifdef BK_PHASE_STAMPS
 #define BK_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) wk->stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -556,14 +653,16 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     }
     uint32_t npad = 1; while (npad < M2) npad <<= 1;
     if (lds_tab) { perm_lds = tcnt; perm_cap = tcap; }         // the count words are free once the counts are materialised (npad <= tcap)
-    const bool perm_in_lds = npad <= perm_cap;                 // else the permutation is sorted in global memory (slow path)
+    const bool use_bucket = npad > perm_cap || ((p.flags & BK_F_BUCKET_SORT) && M2 >= 2);      // large regions: bk_bucket_sort
+    const bool perm_in_lds = !use_bucket;                      // else the permutation lives in global memory
+    const uint32_t bcap = use_bucket ? npad / 32 + 4096 : 0;   // buckets of bk_bucket_sort: <= M2 / 64 + 256
     const uint32_t tcap2 = [&] { uint32_t c = 64; while (c < 2 * M) c <<= 1; return c; }();      // compact table for the assembler (lds_tab)
-    const uint64_t b2 = (uint64_t)M * (8 + 8 + 4 + 1 + 12 + 4 + 4) + (uint64_t)T * 4 + 4096 + (perm_in_lds ? 0 : (uint64_t)npad * 4) + (lds_tab ? (uint64_t)tcap2 * 4 + 256 : 0);
+    const uint64_t b2 = (uint64_t)M * (8 + 8 + 4 + 1 + 12 + 4 + 4) + (uint64_t)T * 4 + 4096 + (perm_in_lds ? 0 : (uint64_t)npad * 4 + (uint64_t)bcap * 8 + 64) + (lds_tab ? (uint64_t)tcap2 * 4 + 256 : 0);
     uint64_t a1 = bk_arena_alloc(p, b2, scr + 20);
     if (a1 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
     const uint64_t o_klo = a1, o_khi = o_klo + (uint64_t)M * 8, o_kcnt = o_khi + (uint64_t)M * 8, o_kstamp = bk_align_up(o_kcnt + (uint64_t)M * 4, 16),
                    o_poff = o_kstamp + (uint64_t)M * 12, o_tmp = bk_align_up(o_poff + (uint64_t)(M + 1) * 4, 16), o_post = bk_align_up(o_tmp + (uint64_t)M * 4, 16),
-                   o_kstate = o_post + (uint64_t)T * 4, o_perm = bk_align_up(o_kstate + M, 16), o_tab2 = bk_align_up(o_perm + (perm_in_lds ? 0 : (uint64_t)npad * 4), 256);
+                   o_kstate = o_post + (uint64_t)T * 4, o_perm = bk_align_up(o_kstate + M, 16), o_bst = bk_align_up(o_perm + (perm_in_lds ? 0 : (uint64_t)npad * 4), 16), o_tab2 = bk_align_up(o_bst + (uint64_t)bcap * 8, 256);
     uint64_t *klo = (uint64_t *)(p.arena + o_klo), *khi = (uint64_t *)(p.arena + o_khi);
     uint32_t *kcnt = (uint32_t *)(p.arena + o_kcnt), *poff = (uint32_t *)(p.arena + o_poff), *ptmp = (uint32_t *)(p.arena + o_tmp), *post = (uint32_t *)(p.arena + o_post);
     int32_t *kstamp = (int32_t *)(p.arena + o_kstamp);
@@ -577,7 +676,9 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         klo[j] = key.lo; khi[j] = key.hi; kcnt[j] = tcnt[i]; ptmp[j] = i;
     }
     __syncthreads();
-    {
+    bool sorted = false;
+    if (use_bucket) sorted = bk_bucket_sort(perm, M2, klo, khi, kcnt, k, perm_lds, perm_cap, (uint32_t *)(p.arena + o_bst), (uint32_t *)(p.arena + o_bst) + bcap, bcap, scr);
+    if (!sorted) {
         for (uint32_t i = tid; i < npad; i += nt) perm[i] = i < M2 ? i : BK_EMPTY32;
         __syncthreads();
         for (uint32_t sz = 2; sz <= npad; sz <<= 1)

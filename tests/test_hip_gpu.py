@@ -713,3 +713,36 @@ def test_lookahead_across_visits_changes_nothing_gpu(hb):
             assert got[2:] == ref[2:], (wg, flags)
             eng.close()
     assert sum(len(c) for c in ref[0]) >= 20
+
+
+@pytest.mark.gpu
+def test_bucket_sort_of_seed_kmers_gpu(hb, golden_dir):
+    """Regions with millions of seed-capable k-mers order them with a bucket sort (count classes, leading mer bits, one
+    wavefront per bucket) instead of the in-LDS bitonic sort.  bk_config.reserved[0] = 32 forces that path on the small
+    G3 fixtures: same k-mer order ((count, mer) descending) and same contigs as the reference produced; on a noisy
+    region with ~10^5 seed k-mers the order is checked directly."""
+    d = _load(golden_dir, "assembly.json")
+    by_cfg = {}
+    for c in d["cases"]:
+        by_cfg.setdefault((c["k"], c["rc_thresh"]), []).append(c)
+    for (k, rc), cases in by_cfg.items():
+        regions = [synth.make_region(**c["gen"]) for c in cases]
+        eng = _run_regions(hb, regions, k, rc, flags=32)
+        for i, c in enumerate(cases):
+            mers, counts, U = eng.kmers(i)
+            got = dict(zip(mers, counts.tolist()))
+            assert len(mers) == c["n_mers"], c["tag"]
+            seeds = [(m, n) for m, n in zip(mers, counts.tolist()) if n >= 2]
+            assert [m for m, _ in seeds] == [m for m, _ in sorted(seeds, key=lambda x: (x[1], x[0]), reverse=True)], c["tag"]
+            assert hashlib.sha256(("\n".join("%s %d" % (m, got[m]) for m in sorted(got))).encode()).hexdigest() == c["mers_sha256"], c["tag"]
+            assert _strip(eng.contigs(i)) == c["contigs"], c["tag"]
+        eng.close()
+    noisy = [synth.make_region(7700 + i, sv_type="del", depth=300, W=2000, L=150, noise=0.02) for i in range(2)]
+    plain = _run_regions(hb, noisy, 31, stages=3)
+    forced = _run_regions(hb, noisy, 31, stages=3, flags=32)
+    for i in range(2):
+        mers, counts, _u = forced.kmers(i)
+        seeds = [(m, n) for m, n in zip(mers, counts.tolist()) if n >= 2]
+        assert len(seeds) > 20000
+        assert [m for m, _ in seeds] == [m for m, _ in sorted(seeds, key=lambda x: (x[1], x[0]), reverse=True)]
+        assert forced.contigs(i) == plain.contigs(i)
