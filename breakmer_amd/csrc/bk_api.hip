@@ -562,8 +562,9 @@ extern "C" int bk_sync(bk_handle *h)
         // bound of the demand, so grow to that (plus slack) when it is more than the usual factor
         unsigned long long tops[2] = {0, 0};
         HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
-        // (x4 while the arena is small, x2 beyond 4 GB: a 256-region configs[4] batch needs ~90 GB and must not jump from 42 to 166)
-        if (grow_arena) { h->arena_cap = std::max<uint64_t>(h->arena_cap * (h->arena_cap < (4ull << 30) ? 4 : 2), tops[0] + tops[0] / 4); HIPCHK(h, h->d_arena.ensure(h->arena_cap)); }
+        // (x4 while the arena is small, x1.5 beyond 4 GB or what was asked for + 25 %: a 256-region configs[4] batch needs ~90 GB
+        // and must not jump from 42 to 166)
+        if (grow_arena) { h->arena_cap = std::max<uint64_t>(h->arena_cap < (4ull << 30) ? h->arena_cap * 4 : h->arena_cap + h->arena_cap / 2, tops[0] + tops[0] / 4); HIPCHK(h, h->d_arena.ensure(h->arena_cap)); }
         if (grow_out) { h->out_cap = std::max<uint64_t>(h->out_cap * 4, tops[1] + tops[1] / 2); HIPCHK(h, h->d_out.ensure(h->out_cap)); }
         int rc = launch(h, h->ran_mask);
         if (rc != BK_OK) return rc;
