@@ -24,9 +24,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # The steps in flight live on separate HIP streams.  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
-# (default 4); once RCCL has created its own streams the default leaves the library's streams sharing queues and the
-# batches serialise (measured: 86 k -> 61 k regions/s).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (default 4); once torch and RCCL have created their own streams the library's 6 streams share queues and the batches
+# serialise.  Measured on one GPU through the multi-rank code path: 4 queues 121 k regions/s, 8 queues 158 k, 12 or more
+# 202 k (= the single-process figure).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 
@@ -271,33 +272,52 @@ def main():
             gather(blob)
         return ms
 
-    # Collation buffers: [8-byte length | records] per rank, fixed capacity, two slots so that the all-gather of step s
-    # overlaps the kernels of step s+1 (the records are only consumed after the run).  The general two-phase
-    # (sizes, then padded payload) exchange of the product path is breakmer_amd/collate.py.
-    CAP = 1 << 20
+    # Collation: the records of GATHER_EVERY steps go out in one all-gather, framed per step ([n_steps | (length, records)*]
+    # per rank, fixed capacity), two slots so that a gather overlaps the kernels of the following steps (the records are only
+    # consumed after the run).  The driver surface collates once per run (breakmer_amd/collate.py: sizes, then padded
+    # payload); one RCCL launch per step cost the host loop 0.25 ms of 1.3 ms on one GPU.
+    GATHER_EVERY = 8
+    CAP = GATHER_EVERY * (1 << 18) + 64
     slots = []
     if dist:
         for _ in range(2):
             slots.append({"host": torch.zeros(CAP, dtype=torch.uint8).pin_memory(), "dev": torch.zeros(CAP, dtype=torch.uint8, device="cuda"),
                           "out": torch.zeros(world * CAP, dtype=torch.uint8, device="cuda"), "work": None})
-    gstate = {"n": 0, "collated": 0, "last": b""}
+    gstate = {"n": 0, "collated": 0, "last": b"", "pending": []}
 
-    def gather(blob):
+    def flush_gather():
+        blobs = gstate["pending"]
+        if not blobs:
+            return
+        gstate["pending"] = []
         sl = slots[gstate["n"] % 2]
         gstate["n"] += 1
         if sl["work"] is not None:
             sl["work"].wait()
-        if blob.size + 8 > CAP:
-            raise RuntimeError("collation record larger than %d bytes" % CAP)
+        need = 8 + sum(8 + b.size for b in blobs)
+        if need > CAP:
+            raise RuntimeError("collation records larger than %d bytes" % CAP)
         hv = sl["host"].numpy()
-        hv[:8] = np.frombuffer(np.int64(blob.size).tobytes(), dtype=np.uint8)
-        hv[8:8 + blob.size] = blob
-        sl["dev"][:8 + blob.size].copy_(sl["host"][:8 + blob.size], non_blocking=True)
+        hv[:8] = np.frombuffer(np.int64(len(blobs)).tobytes(), dtype=np.uint8)
+        o = 8
+        for b in blobs:
+            hv[o:o + 8] = np.frombuffer(np.int64(b.size).tobytes(), dtype=np.uint8)
+            hv[o + 8:o + 8 + b.size] = b
+            o += 8 + b.size
+        sl["dev"][:o].copy_(sl["host"][:o], non_blocking=True)
         sl["work"] = td.all_gather_into_tensor(sl["out"], sl["dev"], async_op=True)
 
+    def gather(blob):
+        gstate["pending"].append(blob)
+        if len(gstate["pending"]) >= GATHER_EVERY:
+            flush_gather()
+
     def drain():
-        """wait for the outstanding all-gathers; returns the bytes collated by the last one (all ranks, rank order)"""
+        """send what is pending, wait for the outstanding all-gathers; returns the bytes of the LAST step collated over
+        all ranks (rank order)"""
         tot = 0
+        if dist:
+            flush_gather()
         for sl in slots:
             if sl["work"] is not None:
                 sl["work"].wait()
@@ -307,9 +327,16 @@ def main():
             allb = sl["out"].view(world, CAP).cpu().numpy()
             parts = []
             for r in range(world):
-                n = int(np.frombuffer(allb[r, :8].tobytes(), dtype=np.int64)[0])
-                parts.append(allb[r, 8:8 + n].tobytes())
-                tot += n
+                row = allb[r]
+                ns = int(np.frombuffer(row[:8].tobytes(), dtype=np.int64)[0])
+                o = 8
+                last = b""
+                for _i in range(ns):
+                    n = int(np.frombuffer(row[o:o + 8].tobytes(), dtype=np.int64)[0])
+                    last = row[o + 8:o + 8 + n].tobytes()
+                    o += 8 + n
+                parts.append(last)
+                tot += len(last)
             gstate["last"] = b"".join(parts)
         gstate["collated"] = tot
         return tot
@@ -472,9 +499,20 @@ def main():
                                              % (ns, ("%d regions over %d worker processes (all host cores)" % (allc["regions"], cores)) if allc else "single-core host"),
                                    "parity_on_sample": bool(ok),
                                    "context": "the reference's own Python path (lib2to3 translation, build container) runs 0.13-0.2 regions/s on one core"}
-        print(json.dumps(out))
+    else:
+        out = None
     if dist:
         td.destroy_process_group()
+    if out is not None:
+        # the ONE JSON line is the last thing on stdout: RCCL writes its version banner through C stdio, which a pipe
+        # buffers until exit -- push it out first
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
