@@ -65,7 +65,7 @@ __device__ __noinline__ int2 bk_nw_tile_st(const uint8_t *cols, const uint8_t *r
     const int lane = threadIdx.x & 63;
     const int lm = (mt - 1) / C;
     constexpr int GH = TR ? BK_NW_G1 : BK_NW_G2, GV = TR ? BK_NW_G2 : BK_NW_G1;
-    constexpr int TOPB = TR ? 0x8000 : 0, LEFTB = TR ? 0 : 0x8000;
+    constexpr int TOPB = TR ? 0x8000 : 0;
     int H[C]; int cb[C];
 #pragma unroll
     for (int x = 0; x < C; x++) {
