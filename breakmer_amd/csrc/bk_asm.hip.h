@@ -440,6 +440,10 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
     const uint8_t *cs = L_CSEQ + S->cbase;
     const int wv = BK_TID >> 6;
     const BkNwResult v1 = S->slot[sl].v1, v2 = S->slot[sl].v2;
+    // thread 0 asks now for the per-read words its bookkeeping at the end needs: nobody else writes them meanwhile, and the
+    // round trip hides behind the count updates instead of standing between two barriers
+    uint32_t pre_fl = 0, pre_kc = 0; int pre_ureads = 0, pre_found = -1;
+    if (BK_TID == 0) { pre_fl = C_.ufl[u]; pre_ureads = C_.ureads[u]; pre_kc = C_.kcnt[rank]; if (grow) pre_found = C_.ufound[u]; }
     int dec = BK_DEC_NONE, ds = 0, de = 0;          // uniform: computed identically by every thread
     bool tie = false;
     {
@@ -527,11 +531,12 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
         C_.ubuf[u] = S->serial;                                                    // self.buffer.add(read.id)
         S->cells += 2ull * (unsigned long long)clen * (unsigned long long)rl; S->calls += 2;
         if (match) {
-            C_.ufl[u] |= BK_R_USED;
-            if (C_.ureads[u] != S->serial) { C_.ureads[u] = S->serial; C_.readl[S->nr++] = (uint32_t)u; }
-        } else if (C_.kcnt[rank] > 2 && !(C_.ufl[u] & BK_R_USED)) {
+            C_.ufl[u] = (uint8_t)(pre_fl | BK_R_USED);
+            if (pre_ureads != S->serial) { C_.ureads[u] = S->serial; C_.readl[S->nr++] = (uint32_t)u; }
+            if (grow && pre_found >= 0) { C_.pend[2 * pre_found] = BK_EMPTY32; C_.ufound[u] = -1; }       // buff.remove_contig :638-639
+        } else if (pre_kc > 2 && !(pre_fl & BK_R_USED)) {
             if (S->nalt < C_.MAXCAND) C_.altl[S->nalt++] = (uint32_t)u; else S->status = BK_ST_CAND;
-        } else C_.ufl[u] |= BK_R_DELETED;                                          // rb.delete -> rb.clean :390
+        } else C_.ufl[u] = (uint8_t)(pre_fl | BK_R_DELETED);                       // rb.delete -> rb.clean :390
     }
     BK_SYNC();
     BK_ACC(3);
@@ -746,13 +751,10 @@ __device__ __forceinline__ int bk_retire_checked(int sl, bool grow)
                              (pk == BK_PK_SAME && (ld == BK_DEC_NONE || ld == BK_DEC_SAME || ld == BK_DEC_SUB));
         if (!kind_ok || S->cbase != S->slot[sl].pb || S->clen != S->slot[sl].plen) return 0;
     }
-    const int u = S->slot[sl].u;
-    const bool hit = bk_retire(S->slot[sl].rank, sl, grow);
+    (void)bk_retire(S->slot[sl].rank, sl, grow);    // ends with a barrier; the FIFO entry of a matched read is dropped in its bookkeeping
 #ifdef BK_PHASE_STAMPS
     if (BK_TID == 0) S->acc[17] += 1;
 #endif
-    if (grow && hit && BK_TID == 0) { int pidx = C_.ufound[u]; if (pidx >= 0) { C_.pend[2 * pidx] = BK_EMPTY32; C_.ufound[u] = -1; } }   // buff.remove_contig :638-639
-    BK_SYNC();
     return 1;
 }
 
