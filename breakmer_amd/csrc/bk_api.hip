@@ -82,7 +82,7 @@ struct bk_handle {
     std::vector<BkPartnerDesc> h_part;
     std::vector<std::vector<std::string>> h_targets;      // per region: target window + partner windows (ASCII), for PSL assembly
     uint32_t max_win = 0;
-    int eff_max_read = 64;          // batch maximum read length rounded up to 64: sizes the assembler's LDS buffers (occupancy)
+    int eff_max_read = 64;          // batch maximum read length rounded up to 32: sizes the assembler's LDS buffers (occupancy)
     uint64_t total_reads = 0, alg_bytes = 0;
     float ms[4] = {0, 0, 0, 0};
     double submit_pack_ms = 0, submit_h2d_ms = 0;   // host 2-bit packing / host-to-device copies of the last bk_submit_regions
@@ -356,7 +356,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     }
     if (nlist.empty()) nlist.push_back(0);
     h->total_reads = tot_reads; h->n_regions = n_regions;
-    { uint32_t mx = 0; for (auto &d : n_desc) mx = std::max(mx, d.max_len); h->eff_max_read = (int)std::min<uint32_t>((uint32_t)h->cfg.max_read_len, std::max<uint32_t>(64, (mx + 63) / 64 * 64)); }
+    { uint32_t mx = 0; for (auto &d : n_desc) mx = std::max(mx, d.max_len); h->eff_max_read = (int)std::min<uint32_t>((uint32_t)h->cfg.max_read_len, std::max<uint32_t>(64, (mx + 31) / 32 * 32)); }
     // reference k-mer table geometry (LDS): load factor <= 0.5.  Windows beyond the LDS budget (whole-gene targets)
     // are flagged `big` and go through bk_kmer_kernel_g (table in the scratch arena).
     auto lds_need = [&](uint32_t w, uint32_t &cap, uint32_t &words) {
@@ -433,7 +433,7 @@ static size_t asm_lds_bytes(const bk_handle *h, int threads)
 {
     const size_t waves = threads / 64;
     size_t o = threads == 512 ? at512::ctx_shared_bytes : at256::ctx_shared_bytes;
-    o += (size_t)h->cfg.max_candidates * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + waves * 3 * (h->eff_max_read + 16) + (waves + 1) * (h->eff_max_read + 16);
+    o += (size_t)h->cfg.max_candidates * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + waves * (h->eff_max_read + 16);
     return (o + 15) / 16 * 16;
 }
 

@@ -120,9 +120,9 @@ extern __shared__ __attribute__((aligned(16))) uint8_t bk_lds[];
 #define C_ (*(BkAsmCtx *)bk_lds)
 #define S_ ((BkAsmShared *)(bk_lds + BK_SH_OFF))
 #define L_CSEQ (bk_lds + C_.o_cseq)
-#define L_RSEQ (bk_lds + C_.o_rseq + BK_SPEC * (C_.MAXR + 16))         // the generic read buffer (bk_load_read): not a slot's, slots outlive a visit
+#define L_RSEQ (bk_lds + C_.o_bound)                                  // the generic read buffer (bk_load_read): not a slot's (slots outlive a visit); shares the DP scratch
 #define L_RSEQ_S(s) (bk_lds + C_.o_rseq + (s) * (C_.MAXR + 16))
-#define BK_SEEDBUF(g) (2 * C_.MAXC + (g) * 3 * (C_.MAXR + 16))         // offset (from L_CSEQ) of the strip of look-ahead seed g
+#define BK_SEEDBUF(g) (2 * C_.MAXC + (g) * 3 * (C_.MAXR + 16))         // offset (from L_CSEQ) of the strip of look-ahead seed g: in the DP scratch behind the deque
 #define L_BOUND ((int *)(bk_lds + C_.o_bound))
 #define L_BOUND_W(w) ((int *)(bk_lds + C_.o_bound) + (w) * 2 * (C_.MAXR + 2))
 #define L_CAND ((unsigned long long *)(bk_lds + C_.o_cand))
@@ -845,6 +845,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     }
     int mx = 0;
     for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen);
+    if (kind == 1 && mx > BK_NW_TILE_COLS) { nb = ncur; mx = 0; for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen); }      // a multi-tile DP would use the scratch the strips sit in
     // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
     // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
     S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
@@ -1248,11 +1249,15 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.read_words = d.read_words; c.max_len = d.max_len;
         c.flags = p.flags; c.MAXC = p.max_contig; c.MAXR = p.max_read; c.MAXCAND = p.max_cand; c.KCAP = 2 * p.max_contig; c.k = p.k;
         int o = BK_BUF_OFF;
+        // 40 KB at the 256-thread size (four workgroups per CU).  The DP tile-boundary scratch directly behind the contig deque
+        // doubles as (a) the [read | founder | read] strips of look-ahead seeds, which only live through the DPs of the round
+        // that plans them, all of them single-tile (bk_plan_round), and (b) the generic read buffer of bk_load_read, which
+        // is never used while a DP runs.
         c.o_cand = o; o += c.MAXCAND * 8;
-        c.o_bound = o; o += (BK_AT / 64) * 2 * (c.MAXR + 2) * 4;
         c.o_candu = o; o += c.MAXCAND * 4;
-        c.o_cseq = o; o += 2 * c.MAXC + BK_SPEC * 3 * (c.MAXR + 16);      // + one [read | founder | read] strip per look-ahead seed
-        c.o_rseq = o; o += (BK_SPEC + 1) * (c.MAXR + 16);
+        c.o_cseq = o; o += 2 * c.MAXC;
+        c.o_bound = o; o += (BK_AT / 64) * 2 * (c.MAXR + 2) * 4;
+        c.o_rseq = o; o += BK_SPEC * (c.MAXR + 16);
         c.reads = p.reads + d.reads_word_off; c.rlen = p.read_len + d.read_meta_off;
         c.nlist = p.nlist + d.nlist_off; c.n_nlist = d.n_nlist;
         const uint64_t mo = d.read_meta_off;
