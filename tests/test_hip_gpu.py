@@ -746,3 +746,14 @@ def test_bucket_sort_of_seed_kmers_gpu(hb, golden_dir):
         assert len(seeds) > 20000
         assert [m for m, _ in seeds] == [m for m, _ in sorted(seeds, key=lambda x: (x[1], x[0]), reverse=True)]
         assert forced.contigs(i) == plain.contigs(i)
+
+
+@pytest.mark.gpu
+def test_assembler_occupancy_of_the_headline_shape_gpu(hb):
+    """150 bp reads with the default limits: the 256-thread assembler build must fit four workgroups per CU (40 KB of LDS
+    each; look-ahead buffers once pushed it to 44 KB = three, 4 % fewer regions/s), the 512-thread build two."""
+    regions = [synth.make_region(7900 + i, sv_type="del", depth=60, W=1500, L=150) for i in range(8)]
+    for wg, want in ((256, 4), (512, 2)):
+        eng = _run_regions(hb, regions, 31, stages=7, wg_threads=wg)
+        assert eng.stat(25) == wg and eng.stat(23) == want, (wg, eng.stat(23))
+        eng.close()
