@@ -129,19 +129,29 @@ _ACGT = np.frombuffer(b"ACGTN", dtype=np.uint8)       # code 4 = N (reads only; 
 _CODE2ASCII = bytes(b"ACGTN"[i] if i < 5 else ord("?") for i in range(256))
 
 
+def _as_c(a, dtype):
+    """`a` as a C-contiguous array of `dtype`; the array itself when it already is one (the per-target fast path)"""
+    if type(a) is np.ndarray and a.dtype == dtype and a.flags.c_contiguous:
+        return a
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+_NO_PARTNERS = ((C.c_char_p * 1)(), np.zeros(1, dtype=np.int32))
+
+
 class RegionInput(object):
     """Host-side view of one target region, kept alive until submit returns."""
 
     def __init__(self, reads, window, *, read_lens=None, indel_only=None, sc_seqs=None, partners=()):
         self.codes = isinstance(reads, np.ndarray)          # uint8 codes 0..3 (4 = N), [N, L]: handed over as they are (bk_submit_regions_ex)
         if self.codes:
-            self.reads = np.ascontiguousarray(reads, dtype=np.uint8) if reads.size else np.zeros((0, 1), dtype=np.uint8)
-            self.lens = (np.asarray(read_lens, dtype=np.uint16) if read_lens is not None
+            self.reads = _as_c(reads, np.uint8) if reads.size else np.zeros((0, 1), dtype=np.uint8)
+            self.lens = (_as_c(read_lens, np.uint16) if read_lens is not None
                          else np.full(reads.shape[0], reads.shape[1], dtype=np.uint16))
         else:
             self.reads, self.lens = _ascii_matrix(list(reads))
-        self.lens = np.ascontiguousarray(self.lens, dtype=np.uint16)
-        self.indel_only = None if indel_only is None else np.ascontiguousarray(indel_only, dtype=np.uint8)
+            self.lens = _as_c(self.lens, np.uint16)
+        self.indel_only = None if indel_only is None else _as_c(indel_only, np.uint8)
         self.window = window.encode() if isinstance(window, str) else bytes(_ACGT[np.asarray(window)])
         if sc_seqs is None:
             self.sc, self.sc_lens = None, None
@@ -162,8 +172,11 @@ class RegionInput(object):
         g.window = self.window
         g.window_len = len(self.window)
         g.n_partners = len(self.partners)
-        self._parr = (C.c_char_p * max(len(self.partners), 1))(*self.partners)
-        self._plens = np.array([len(x) for x in self.partners] + [0], dtype=np.int32)
+        if self.partners:
+            self._parr = (C.c_char_p * len(self.partners))(*self.partners)
+            self._plens = np.array([len(x) for x in self.partners], dtype=np.int32)
+        else:                                               # the common case: nothing to build per target
+            self._parr, self._plens = _NO_PARTNERS
         g.partners = self._parr
         g.partner_lens = self._plens.ctypes.data
 

@@ -624,7 +624,7 @@ class runner(object):                                               # sv_process
             t.region_index, t.engine = i, eng
             d = t.data
             reads = d.read_codes if d.read_codes is not None else d.read_seqs
-            ins.append(hip_backend.RegionInput(reads, d.window, read_lens=d.read_lens, indel_only=_np.asarray(d.indel_only, dtype=_np.uint8), sc_seqs=d.sc_seqs,
+            ins.append(hip_backend.RegionInput(reads, d.window, read_lens=d.read_lens, indel_only=d.indel_only if type(d.indel_only) is _np.ndarray else _np.asarray(d.indel_only, dtype=_np.uint8), sc_seqs=d.sc_seqs,
                                                partners=[p[4] for p in d.partners]))
         try:
             eng.submit(ins, wait=False)

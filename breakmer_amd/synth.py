@@ -193,7 +193,7 @@ def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int =
             reads[i, L - c_:] = 0
             lens[i] = L - c_
     r.reads = reads
-    r.read_lens = lens
+    r.read_lens = lens.astype(np.uint16)            # the dtype the library takes: no conversion per submit
     r.indel_only = np.zeros(N, dtype=np.uint8)
     if indel_only_frac > 0.0:
         u = rand_u64(stream_key(global_seed, region_id, 5), N)
