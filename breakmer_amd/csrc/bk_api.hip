@@ -212,6 +212,16 @@ static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vecto
     return true;
 }
 
+extern "C" int bk_pack_sequence(const char *seq, int32_t len, uint32_t flags, uint32_t *words, int32_t n_words, uint32_t *n_pos, int32_t cap, int32_t *n_n)
+{
+    if (!seq || len < 0 || !words || n_words < (len + 15) / 16 || cap < 0 || (cap > 0 && !n_pos)) return BK_E_ARG;
+    std::vector<uint32_t> nl;
+    if (!pack_seq(seq, len, words, n_words, &nl, 0, (flags & BK_SUBMIT_READ_CODES) != 0)) return BK_E_ARG;
+    for (size_t i = 0; i < nl.size() && (int32_t)i < cap; i++) n_pos[i] = nl[i];                       // tag 0: the entry is the position
+    if (n_n) *n_n = (int32_t)nl.size();
+    return BK_OK;
+}
+
 template <class T> static hipError_t upload(bk_handle *h, DevBuf &b, const std::vector<T> &v)
 {
     hipError_t e = b.ensure(std::max<size_t>(v.size() * sizeof(T), 256));

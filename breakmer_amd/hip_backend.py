@@ -66,7 +66,7 @@ def call_text(text):
 EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_submit_regions_ex", "bk_run", "bk_sync", "bk_fetch",
            "bk_last_kernel_ms", "bk_get_region_status", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
            "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_get_calls",
-           "bk_nw_batch"]
+           "bk_nw_batch", "bk_pack_sequence"]
 
 _lib = None
 
@@ -103,6 +103,7 @@ def load_library():
     L.bk_get_hits.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BkPsl), C.c_int32]
     L.bk_get_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     L.bk_call_text.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    L.bk_pack_sequence.argtypes = [C.c_char_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.bk_set_call_context.argtypes = [C.c_void_p, C.c_char_p]
     L.bk_call.argtypes = [C.c_void_p]
     L.bk_get_calls.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -430,3 +431,18 @@ def close_pool():
 
 import atexit  # noqa: E402
 atexit.register(close_pool)
+
+
+def pack_sequence(seq, codes=False):
+    """(words, N positions) of one sequence as bk_submit_regions packs it (host code of the library, no GPU); raises on any
+    character other than A/C/G/T/N."""
+    L = load_library()
+    raw = seq if isinstance(seq, (bytes, bytearray)) else (bytes(bytearray(seq)) if codes else seq.encode())
+    n = len(raw)
+    words = np.zeros((n + 15) // 16 + 1, dtype=np.uint32)
+    npos = np.zeros(max(n, 1), dtype=np.uint32)
+    nn = C.c_int32()
+    rc = L.bk_pack_sequence(raw, n, 1 if codes else 0, words.ctypes.data, len(words), npos.ctypes.data, len(npos), C.byref(nn))
+    if rc != 0:
+        raise BreakmerHipError("bk_pack_sequence failed (%d)" % rc)
+    return words, npos[:nn.value].tolist()

@@ -177,6 +177,14 @@ int bk_call(bk_handle *h);                                      /* after bk_run:
 int bk_get_calls(bk_handle *h, char *buf, size_t cap, size_t *needed);   /* "<region>\t<contig>\t<13 fields>\n" ... */
 int bk_call_text(const char *text, char *out, size_t cap, int *target_hit);   /* one fully described contig; no GPU needed */
 
+/* The 2-bit packing bk_submit_regions applies to every sequence (16 bases per word, first base in the most significant
+ * bits; replaces the FASTA/FASTQ text the reference writes for Jellyfish and the assembler, utils.py:355-381), on one
+ * sequence: `words` receives n_words words (zero padded), an 'N' is packed as A and its position appended to n_pos
+ * (at most cap; *n_n = how many there are).  flags: BK_SUBMIT_READ_CODES = the bytes are base codes.  Returns BK_E_ARG for
+ * any other character.  No GPU needed (host utility; lets the SIMD and the table path be checked against each other). */
+int bk_pack_sequence(const char *seq, int32_t len, uint32_t flags, uint32_t *words, int32_t n_words,
+                     uint32_t *n_pos, int32_t cap, int32_t *n_n);
+
 /* batched olc.nw on explicit pairs (known-answer tests, DP micro-benchmark): out = 4 ints per pair
  * (j_start, i_end, i_start, score); transposed = 1 uses the sweep the assembler uses for nw(read, contig), 2 the
  * suffix-restricted direct sweep it uses for nw(contig, read) (same results by construction; tests compare all three) */

@@ -48,3 +48,38 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), fn
                 assert "bk_oracle" not in txt.replace("oracle/bk_oracle", ""), fn
+
+
+def test_pack_sequence_simd_equals_table_path():
+    """bk_pack_sequence (host code of the library, no GPU): the SSSE3 path of the 2-bit packing -- whole 16-base blocks of
+    plain A/C/G/T -- and the table path -- blocks with an N, tails -- against a Python restatement; other characters fail."""
+    import random
+    import numpy as np
+    from breakmer_amd import hip_backend as hb
+    rng = random.Random(5)
+
+    def ref(seq):
+        words = [0] * ((len(seq) + 15) // 16 + 1)
+        npos = []
+        for i, ch in enumerate(seq):
+            c = "ACGTN".index(ch)
+            if c == 4:
+                npos.append(i)
+                c = 0
+            words[i // 16] |= c << (30 - 2 * (i % 16))
+        return words, npos
+
+    for it in range(400):
+        n = rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 100, 150, 151, 250, 1000, 3000]) if it < 60 else rng.randrange(0, 400)
+        seq = "".join(rng.choice("ACGT") if rng.random() > 0.01 else "N" for _ in range(n))
+        want_w, want_n = ref(seq)
+        w, npos = hb.pack_sequence(seq)
+        assert w.tolist() == want_w and npos == want_n, (it, n)
+        codes = np.array(["ACGTN".index(ch) for ch in seq], dtype=np.uint8)
+        w2, npos2 = hb.pack_sequence(codes.tobytes(), codes=True)
+        assert w2.tolist() == want_w and npos2 == want_n, (it, n)
+    for bad in ("ACGTx", "acgt", "ACGTACGTACGTACGTACGR", "ACG-"):
+        with pytest.raises(hb.BreakmerHipError):
+            hb.pack_sequence(bad)
+    with pytest.raises(hb.BreakmerHipError):
+        hb.pack_sequence(bytes([0, 1, 2, 3, 7]), codes=True)
