@@ -137,8 +137,6 @@ def _as_c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
-_NO_PARTNERS = ((C.c_char_p * 1)(), np.zeros(1, dtype=np.int32))
-
 
 class RegionInput(object):
     """Host-side view of one target region, kept alive until submit returns."""
@@ -161,11 +159,12 @@ class RegionInput(object):
         self.partners = [pw.encode() if isinstance(pw, str) else bytes(_ACGT[np.asarray(pw)]) for pw in partners]
 
     def fill(self, g: BkRegion):
-        g.reads = self.reads.ctypes.data
+        """g: an element of a freshly made (zeroed) BkRegion array, or one this object filled before"""
+        reads = self.reads
+        g.reads = reads.ctypes.data
         g.read_lens = self.lens.ctypes.data
         g.indel_only = self.indel_only.ctypes.data if self.indel_only is not None else None
-        g.n_reads = self.reads.shape[0]
-        g.read_stride = self.reads.shape[1]
+        g.n_reads, g.read_stride = reads.shape
         if self.sc is None:
             g.sc_seqs, g.sc_lens, g.n_sc, g.sc_stride = None, None, -1, 0
         else:
@@ -176,10 +175,10 @@ class RegionInput(object):
         if self.partners:
             self._parr = (C.c_char_p * len(self.partners))(*self.partners)
             self._plens = np.array([len(x) for x in self.partners], dtype=np.int32)
-        else:                                               # the common case: nothing to build per target
-            self._parr, self._plens = _NO_PARTNERS
-        g.partners = self._parr
-        g.partner_lens = self._plens.ctypes.data
+            g.partners = self._parr
+            g.partner_lens = self._plens.ctypes.data
+        else:                                               # the common case: nothing to build per target (never dereferenced)
+            g.partners, g.partner_lens = None, None
 
 
 class KmerStrings(object):

@@ -76,7 +76,7 @@ typedef struct bk_region {
     const char *window;         /* forward target window, [start-200, end+200) (utils.py:367) */
     int32_t window_len;
     int32_t n_partners;         /* extra windows for realignment (whole-genome fallback stand-in, sv_processor.py:829-831) */
-    const char *const *partners;
+    const char *const *partners;   /* n_partners sequences (ASCII) and their lengths; both may be NULL when n_partners == 0 */
     const int32_t *partner_lens;
 } bk_region;
 
