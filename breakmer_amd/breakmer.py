@@ -80,7 +80,9 @@ def main(argv=None):
     r = runner(config_d, rank=rank, world=world, collate=collate)
     r.run(tic)
     logging.getLogger('root').info('Analysis complete, %s' % str(time.perf_counter() - tic))
+    return 3 if r.failed_targets else 0          # 3: the run is complete but some targets have no result (log: which and why)
 
 
 if __name__ == '__main__':
-    main()
+    import sys
+    sys.exit(main())

@@ -87,6 +87,7 @@ struct bk_handle {
     float ms[4] = {0, 0, 0, 0};
     double submit_pack_ms = 0, submit_h2d_ms = 0;   // host 2-bit packing / host-to-device copies of the last bk_submit_regions
     int n_failed = 0;                                // regions of the last run that hit a device limit (status per region)
+    std::vector<int> host_status;                    // per region: limits only the host half of a stage can hit (BK_ST_BLOCKS, set by bk_call)
     BkParams params{};
     bkcall::Context call_ctx; bool have_ctx = false; std::string calls_blob;
     // BK_SUBMIT_ASYNC: the submit runs on this thread; every later call on the handle joins it first (and reports its error)
@@ -259,7 +260,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     const int k = h->cfg.kmer_size;
     // a failed submit leaves the handle without a batch (never the old device results paired with new host mirrors):
     // the new host mirrors are built in locals and swapped in on success only
-    h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->hold_snapshot = false; h->have_ctx = false;
+    h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->hold_snapshot = false; h->have_ctx = false; h->host_status.clear();
     std::vector<uint32_t> sc, win; std::vector<uint16_t> sclen;
     std::vector<BkRegionDesc> n_desc(n_regions, BkRegionDesc{}); std::vector<BkPartnerDesc> n_part; std::vector<std::vector<std::string>> n_targets(n_regions);
     uint32_t n_max_win = 0; uint64_t n_alg_bytes = 0;
@@ -535,12 +536,13 @@ static const char *st_name(int s)
     case BK_ST_ARENA: return "device scratch arena exhausted"; case BK_ST_WINDOW: return "reference window too long";
     case BK_ST_CONTIG: return "contig longer than max_contig_len"; case BK_ST_CAND: return "more candidate reads for one k-mer than max_candidates";
     case BK_ST_KLIST: return "contig k-mer list overflow"; case BK_ST_READLEN: return "read longer than max_read_len";
-    case BK_ST_OUT: return "output arena exhausted"; case BK_ST_HITS: return "too many alignment hits"; default: return "unknown";
+    case BK_ST_OUT: return "output arena exhausted"; case BK_ST_HITS: return "realign: more than 32 step-1 hits or 256 secondary alignments for one contig";
+    case BK_ST_BLOCKS: return "realign: a chained record needs more than 32 blocks"; default: return "unknown";
     }
 }
 
 // wait, read back the work records and the result arena; grow arenas and rerun when they overflowed
-extern "C" int bk_sync(bk_handle *h)
+static int sync_impl(bk_handle *h)
 {
     BK_JOIN(h);
     if (!h) return BK_E_ARG;
@@ -582,11 +584,20 @@ extern "C" int bk_sync(bk_handle *h)
     return fail(h, BK_E_NOMEM, "bk_sync: arenas still too small after 12 growth steps");
 }
 
+// Public: like the internal wait, but says so when regions of the batch hit a cap: BK_W_REGIONS_FAILED (> 0; every other
+// result of the batch is valid, bk_get_region_status names the regions and the caps, bk_get_stat(22) counts them).
+extern "C" int bk_sync(bk_handle *h)
+{
+    const int rc = sync_impl(h);
+    if (rc != BK_OK) return rc;
+    return h->n_failed > 0 ? BK_W_REGIONS_FAILED : BK_OK;
+}
+
 static int fetch(bk_handle *h)
 {
     if (h->hold_snapshot) return BK_OK;             // explicit bk_fetch(): keep working on that copy
     HIPCHK(h, hipSetDevice(h->dev));                // entry points may be called from any host thread
-    int rc = bk_sync(h);
+    int rc = sync_impl(h);
     if (rc != BK_OK) return rc;
     if (h->fetched) return BK_OK;
     unsigned long long tops[2];
@@ -602,7 +613,7 @@ extern "C" int bk_last_kernel_ms(bk_handle *h, int which, float *ms)
 {
     BK_JOIN(h);
     if (!h || !ms || which < 0 || which > 3) return BK_E_ARG;
-    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    int rc = sync_impl(h); if (rc != BK_OK) return rc;
     *ms = h->ms[which]; return BK_OK;
 }
 
@@ -615,7 +626,7 @@ extern "C" int bk_get_kmer_count(bk_handle *h, int32_t region, int32_t *n_mers, 
 {
     BK_JOIN(h);
     if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
-    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    int rc = sync_impl(h); if (rc != BK_OK) return rc;
     if (n_mers) *n_mers = (int32_t)h->h_work[region].M;
     if (n_unique) *n_unique = (int32_t)h->h_work[region].U;
     return BK_OK;
@@ -625,7 +636,7 @@ extern "C" int bk_get_kmers(bk_handle *h, int32_t region, char *mers, int32_t *c
 {
     BK_JOIN(h);
     if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
-    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    int rc = sync_impl(h); if (rc != BK_OK) return rc;
     const BkRegionWork &w = h->h_work[region];
     const int M = (int)w.M, n = std::min<int>(M, cap), k = h->cfg.kmer_size;
     if (n <= 0) return BK_OK;
@@ -654,8 +665,9 @@ extern "C" int bk_get_region_status(bk_handle *h, int32_t region, int32_t *statu
 {
     BK_JOIN(h);
     if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
-    int rc = bk_sync(h); if (rc != BK_OK) return rc;
-    const int s = h->h_work[region].status;
+    int rc = sync_impl(h); if (rc != BK_OK) return rc;
+    int s = h->h_work[region].status;
+    if (s == BK_ST_OK && region < (int)h->host_status.size()) s = h->host_status[region];
     if (status) *status = s;
     if (text) *text = s == BK_ST_OK ? "ok" : st_name(s);
     return BK_OK;
@@ -665,7 +677,7 @@ extern "C" int bk_get_contig_count(bk_handle *h, int32_t region, int32_t *n)
 {
     BK_JOIN(h);
     if (!h || !n || region < 0 || region >= h->n_regions) return BK_E_ARG;
-    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    int rc = sync_impl(h); if (rc != BK_OK) return rc;
     *n = (int32_t)h->h_work[region].n_contigs; return BK_OK;
 }
 
@@ -712,7 +724,7 @@ static int fill_best(const char *q, const char *t, int qa, int qb, int ta, int t
         const int a0 = std::max(qa, ta - d), a1 = std::min(qb, tb - d);
         int h = 0, run = 0;
         for (int a = a0; a < a1; a++) {
-            h += q[a] == t[a + d] ? 1 : -2; run++;
+            h += (q[a] == t[a + d] && q[a] != 'N') ? 1 : -2; run++;
             if (h <= 0) { h = 0; run = 0; continue; }
             const int qe = a + 1, te = a + 1 + d;
             if (h > best || (h == best && (qe < out.qe || (qe == out.qe && te < out.te)))) { best = h; out.qs = qe - run; out.qe = qe; out.ts = te - run; out.te = te; out.score = h; }
@@ -731,13 +743,76 @@ static void fill_gap(const char *q, const char *t, const BkFillBlk *L, const BkF
 }
 
 // Chain the raw hits of one contig into PSL-equivalent records (contract: oracle/bk_oracle.h R2 steps 3 and 4).
-static int chain_hits(const char *contig, int Q, const std::vector<std::string> &targets, std::vector<BkHit> hits, bk_psl *out, int cap)
+// Secondary alignments (step 5) follow as one-block records, ordered by (score desc, target asc, '+' first, query end asc,
+// target end asc).  Returns the number of records, or -1 when a chained record needs more than BK_MAX_BLOCKS blocks.
+static int chain_hits(const char *contig, int Q, const std::vector<std::string> &targets, std::vector<BkHit> hits, std::vector<BkHit> sec, bk_psl *out, int cap)
 {
     std::string rc(Q, 'N');
     for (int i = 0; i < Q; i++) { char c = contig[Q - 1 - i]; rc[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
     std::stable_sort(hits.begin(), hits.end(), [](const BkHit &a, const BkHit &b) { return a.fq < b.fq; });
     const int nh = (int)hits.size();
-    int nrec = 0, i = 0;
+    auto sec_less = [](const BkHit &a, const BkHit &b) {
+        if (a.score != b.score) return a.score > b.score;
+        if (a.tidx != b.tidx) return a.tidx < b.tidx;
+        if (a.strand != b.strand) return a.strand < b.strand;
+        if (a.qe != b.qe) return a.qe < b.qe;
+        return a.te < b.te; };
+    std::sort(sec.begin(), sec.end(), sec_less);
+    // ---- step 6: placement of ambiguous hits (oracle/bk_oracle.h).  A step-1 hit with equal alternatives (a secondary alignment
+    // covering its query interval with the same score over it) chooses, together with its neighbours, the placement with the
+    // fewest chain breaks, then the smallest sum of diagonal shifts (dynamic programme over the hits in forward query order).
+    if (!sec.empty() && nh > 0) {
+        struct PCand { int qs, qe, ts, te, strand, tidx, from; };
+        std::vector<std::vector<PCand>> cd(nh); std::vector<std::vector<long long>> cost(nh); std::vector<std::vector<int>> back(nh);
+        for (int x = 0; x < nh; x++) {
+            const BkHit &hx = hits[x];
+            const int fs = hx.strand == 0 ? hx.qs : Q - hx.qe, fe = hx.strand == 0 ? hx.qe : Q - hx.qs;
+            cd[x].push_back(PCand{hx.qs, hx.qe, hx.ts, hx.te, hx.strand, hx.tidx, -1});
+            for (int y = 0; y < (int)sec.size(); y++) {
+                const BkHit &e = sec[y];
+                const int sfs = e.strand == 0 ? e.qs : Q - e.qe, sfe = e.strand == 0 ? e.qe : Q - e.qs;
+                if (sfs > fs || sfe < fe) continue;
+                const int cqs = e.strand == 0 ? fs : Q - fe, cqe = e.strand == 0 ? fe : Q - fs, dg = e.ts - e.qs;
+                const char *qstr = e.strand == 0 ? contig : rc.c_str(); const std::string &t = targets[e.tidx];
+                int sc = 0; for (int z = cqs; z < cqe; z++) sc += (qstr[z] == t[z + dg] && qstr[z] != 'N') ? 1 : -2;
+                if (sc != hx.score) continue;
+                cd[x].push_back(PCand{cqs, cqe, cqs + dg, cqe + dg, e.strand, e.tidx, y});
+            }
+            cost[x].assign(cd[x].size(), 0); back[x].assign(cd[x].size(), 0);
+        }
+        for (int x = 1; x < nh; x++) for (size_t b = 0; b < cd[x].size(); b++) {
+            long long bestc = -1; int besta = 0;
+            for (size_t a = 0; a < cd[x - 1].size(); a++) {
+                const PCand &A = cd[x - 1][a], &B = cd[x][b]; long long t = 1ll << 24;                 // a chain break
+                if (A.tidx == B.tidx && A.strand == B.strand) {
+                    const PCand &first = A.strand == 0 ? A : B, &second = A.strand == 0 ? B : A;
+                    const int ov = first.te - second.ts;
+                    if (!(ov > 0 && (2 * ov >= first.qe - first.qs || 2 * ov >= second.qe - second.qs)) && second.qs >= first.qe) {
+                        t = (long long)(second.ts - second.qs) - (long long)(first.ts - first.qs); if (t < 0) t = -t;
+                    }
+                }
+                if (bestc < 0 || cost[x - 1][a] + t < bestc) { bestc = cost[x - 1][a] + t; besta = (int)a; }
+            }
+            cost[x][b] = bestc; back[x][b] = besta;
+        }
+        int pick = 0; for (size_t b = 1; b < cd[nh - 1].size(); b++) if (cost[nh - 1][b] < cost[nh - 1][pick]) pick = (int)b;
+        std::vector<char> gone(sec.size(), 0); std::vector<BkHit> demoted;
+        for (int x = nh - 1; x >= 0; x--) {
+            const PCand c = cd[x][pick];
+            if (c.from >= 0) {
+                BkHit &hx = hits[x];
+                demoted.push_back(hx); gone[c.from] = 1;
+                hx.qs = c.qs; hx.qe = c.qe; hx.ts = c.ts; hx.te = c.te; hx.strand = c.strand; hx.tidx = c.tidx;      // fq (forward start) is unchanged
+            }
+            pick = back[x][pick];
+        }
+        if (!demoted.empty()) {
+            std::vector<BkHit> keep; for (size_t y = 0; y < sec.size(); y++) if (!gone[y]) keep.push_back(sec[y]);
+            keep.insert(keep.end(), demoted.begin(), demoted.end());
+            sec.swap(keep); std::sort(sec.begin(), sec.end(), sec_less);
+        }
+    }
+    int nrec = 0, i = 0; bool overflow = false;
     while (i < nh) {
         std::vector<BkHit> chain; chain.push_back(hits[i]);           // strand order
         int j = i + 1;
@@ -760,20 +835,21 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
             (void)l;
             std::vector<BkFillBlk> anch, blocks;
             for (const BkHit &c : chain) anch.push_back(BkFillBlk{c.qs, c.qe, c.ts, c.te, c.score});
-            const size_t bcap = BK_MAX_BLOCKS; const int T = (int)t.size(), na = (int)anch.size();
+            const size_t bcap = 2 * BK_MAX_BLOCKS - 1; const int T = (int)t.size(), na = (int)anch.size();      // more than BK_MAX_BLOCKS: the record is refused
             fill_gap(qstr, t.c_str(), nullptr, &anch[0], 0, anch[0].qs, std::max(0, anch[0].ts - anch[0].qs - BK_FILL_BAND), anch[0].ts, blocks, bcap);
             for (int c = 0; c < na; c++) {
                 if (blocks.size() < bcap) blocks.push_back(anch[c]);
                 if (c + 1 < na) fill_gap(qstr, t.c_str(), &anch[c], &anch[c + 1], anch[c].qe, anch[c + 1].qs, anch[c].te, anch[c + 1].ts, blocks, bcap);
             }
             fill_gap(qstr, t.c_str(), &anch[na - 1], nullptr, anch[na - 1].qe, Q, anch[na - 1].te, std::min(T, anch[na - 1].te + (Q - anch[na - 1].qe) + BK_FILL_BAND), blocks, bcap);
+            if (blocks.size() > (size_t)BK_MAX_BLOCKS) { overflow = true; blocks.resize(BK_MAX_BLOCKS); }
             r->t_start = blocks.front().ts; r->t_end = blocks.back().te;
             r->q_start = f.strand == 0 ? blocks.front().qs : Q - blocks.back().qe; r->q_end = f.strand == 0 ? blocks.back().qe : Q - blocks.front().qs;
             int nb = 0, pq = -1, pt = -1;
             for (const BkFillBlk &c : blocks) {
                 r->score += c.score;
                 const int bs = c.qe - c.qs;
-                for (int z = 0; z < bs; z++) { if (qstr[c.qs + z] == t[c.ts + z]) r->matches++; else r->mismatches++; }
+                for (int z = 0; z < bs; z++) { if (qstr[c.qs + z] == t[c.ts + z] && qstr[c.qs + z] != 'N') r->matches++; else r->mismatches++; }
                 if (pq >= 0) { if (c.qs > pq) { r->q_num_insert++; r->q_base_insert += c.qs - pq; } if (c.ts > pt) { r->t_num_insert++; r->t_base_insert += c.ts - pt; } }
                 r->block_sizes[nb] = bs; r->q_starts[nb] = c.qs; r->t_starts[nb] = c.ts; nb++;
                 pq = c.qe; pt = c.te;
@@ -783,7 +859,23 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
         nrec++;
         i = j;
     }
-    return nrec;
+    for (const BkHit &e : sec) {
+        if (nrec < cap) {
+            bk_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
+            const char *qstr = e.strand == 0 ? contig : rc.c_str(); const std::string &t = targets[e.tidx];
+            r->strand = e.strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = e.tidx; r->t_size = (int32_t)t.size();
+            r->t_start = e.ts; r->t_end = e.te; r->q_start = e.strand == 0 ? e.qs : Q - e.qe; r->q_end = e.strand == 0 ? e.qe : Q - e.qs;
+            for (int z = 0; z < e.qe - e.qs; z++) { if (qstr[e.qs + z] == t[e.ts + z] && qstr[e.qs + z] != 'N') r->matches++; else r->mismatches++; }
+            r->block_count = 1; r->block_sizes[0] = e.qe - e.qs; r->q_starts[0] = e.qs; r->t_starts[0] = e.ts; r->score = e.score;
+        }
+        nrec++;
+    }
+    return overflow ? -1 : nrec;
+}
+static void raw_hits_of(const bk_handle *h, const BkContigRec *c, std::vector<BkHit> &prim, std::vector<BkHit> &sec)
+{
+    prim.clear(); sec.clear();
+    if (c->n_hits > 0 && c->hits_off) { const BkHit *p = (const BkHit *)(h->h_out.data() + c->hits_off); prim.assign(p, p + c->n_hits); sec.assign(p + c->n_hits, p + c->n_hits + c->n_sec); }
 }
 
 extern "C" int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl *hits, int32_t cap)
@@ -793,11 +885,12 @@ extern "C" int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl 
     int rc = fetch(h); if (rc != BK_OK) return rc;
     const BkContigRec *c = find_contig(h, region, contig);
     if (!c) return fail(h, BK_E_ARG, "bk_get_hits: no such contig");
-    std::vector<BkHit> raw;
-    if (c->n_hits > 0 && c->hits_off) { const BkHit *p = (const BkHit *)(h->h_out.data() + c->hits_off); raw.assign(p, p + c->n_hits); }
+    std::vector<BkHit> raw, sec; raw_hits_of(h, c, raw, sec);
     const char *seq = (const char *)c + c->o_seq;
     std::string s(seq, c->seq_len);
-    return chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, hits, cap);   // returns the number of records (>= 0)
+    const int n = chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, sec, hits, cap);   // the number of records (>= 0)
+    if (n < 0) return fail(h, BK_E_LIMIT, "bk_get_hits: a chained record needs more than BK_MAX_BLOCKS blocks");
+    return n;
 }
 
 extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
@@ -805,7 +898,7 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     BK_JOIN(h);
     if (!h || !value) return BK_E_ARG;
     if (which == 20 || which == 21) { *value = (uint64_t)((which == 20 ? h->submit_pack_ms : h->submit_h2d_ms) * 1000.0); return BK_OK; }
-    int rc = bk_sync(h); if (rc != BK_OK) return rc;
+    int rc = sync_impl(h); if (rc != BK_OK) return rc;
     uint64_t v = 0;
     for (int r = 0; r < h->n_regions; r++) {
         const BkRegionWork &w = h->h_work[r];
@@ -814,7 +907,7 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     if (which == 3) v = h->alg_bytes;
     if (which == 20) v = (uint64_t)(h->submit_pack_ms * 1000.0);              // microseconds
     if (which == 21) v = (uint64_t)(h->submit_h2d_ms * 1000.0);
-    if (which == 22) v = (uint64_t)h->n_failed;
+    if (which == 22) { v = (uint64_t)h->n_failed; for (int r = 0; r < h->n_regions && r < (int)h->host_status.size(); r++) if (h->host_status[r] && h->h_work[r].status == BK_ST_OK) v++; }
     if (which == 23) v = (uint64_t)h->asm_wg_per_cu;                        // resident assembler / realign workgroups per CU (occupancy query)
     if (which == 24) v = (uint64_t)h->sw_wg_per_cu;
     if (which == 25) v = (uint64_t)h->asm_threads;
@@ -913,6 +1006,7 @@ extern "C" int bk_call(bk_handle *h)
     // regions are independent: a few host threads, results concatenated in region order
     const int nthreads = std::max(1, std::min<int>({8, (int)std::thread::hardware_concurrency(), (h->n_regions + 31) / 32}));
     std::vector<std::string> parts(h->n_regions);
+    h->host_status.assign(h->n_regions, 0);
     auto work = [&](int t) {
         for (int r = t; r < h->n_regions; r += nthreads) {
             const bkcall::Region &rg = cx.regions[r];
@@ -925,8 +1019,10 @@ extern "C" int bk_call(bk_handle *h)
                 ct.io = (const int *)(b + c->o_io); ct.ot = (const int *)(b + c->o_ot); ct.clen = c->counts_len; ct.klocs = (const int *)(b + c->o_klocs); ct.nkmers = c->n_kmers;
                 { const uint32_t *rd = (const uint32_t *)(b + c->o_reads); const std::string &tg = cx.rtags[r]; bool same = true; char first = 0;
                   for (int i = 0; i < c->n_reads; i++) { char tch = rd[i] < tg.size() ? tg[rd[i]] : '0'; if (i == 0) first = tch; else if (tch != first) same = false; } ct.same_read_tag = same && c->n_reads > 0; }
-                std::vector<BkHit> raw; if (c->n_hits > 0 && c->hits_off) { const BkHit *p = (const BkHit *)(h->h_out.data() + c->hits_off); raw.assign(p, p + c->n_hits); }
-                bk_psl recs[16]; int n = chain_hits(ct.seq.c_str(), c->seq_len, h->h_targets[r], raw, recs, 16); if (n > 16) n = 16;
+                std::vector<BkHit> raw, sec; raw_hits_of(h, c, raw, sec);
+                std::vector<bk_psl> recs(raw.size() + sec.size() + 1);
+                int n = chain_hits(ct.seq.c_str(), c->seq_len, h->h_targets[r], raw, sec, recs.data(), (int)recs.size());
+                if (n < 0) { h->host_status[r] = BK_ST_BLOCKS; blob.clear(); break; }                     // the region fails alone (bk_get_region_status)
                 auto to_psl = [&](const bk_psl &x, const std::string &tname, int offset) {
                     bkcall::Psl p; p.matches = x.matches; p.mis = x.mismatches; p.rep = x.rep_matches; p.qni = x.q_num_insert; p.qbi = x.q_base_insert; p.tni = x.t_num_insert; p.tbi = x.t_base_insert;
                     p.strand = (char)x.strand; p.qsize = x.q_size; p.qstart = x.q_start; p.qend = x.q_end; p.tname = bkcall::strip_chr(tname); p.tsize = x.t_size; p.tstart = x.t_start + offset; p.tend = x.t_end + offset;
@@ -949,6 +1045,24 @@ extern "C" int bk_call(bk_handle *h)
     else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
     for (auto &s2 : parts) h->calls_blob += s2;
     h->hold_snapshot = false;                       // the next getter refers to the newest run again
+    return BK_OK;
+}
+
+// Give the large device buffers back (a handle kept in a pool between runs would otherwise hold on to the arena its largest
+// batch grew: ~90 GB after one BASELINE configs[4] batch).  Buffers come back, sized by the next batch, with the next submit.
+extern "C" int bk_trim(bk_handle *h, uint64_t keep_bytes)
+{
+    BK_JOIN(h);
+    if (!h) return BK_E_ARG;
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_arena.bytes > keep_bytes) { h->d_arena.release(); h->arena_cap = 0; }
+    if (h->d_out.bytes > keep_bytes) { h->d_out.release(); h->out_cap = 0; h->d_clist.release(); }
+    DevBuf *bufs[] = {&h->d_reads, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt, &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos};
+    for (auto b : bufs) if (b->bytes > keep_bytes) b->release();
+    if (h->h_out.cap > keep_bytes) h->h_out.release();
+    if (h->hs_reads.cap > keep_bytes) { h->hs_reads.release(); }
+    h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->hold_snapshot = false;      // the batch is gone with its buffers
     return BK_OK;
 }
 

@@ -331,7 +331,10 @@ BK_COLD void bk_find_reads(int rank, bool rev, bool filter)
             if (lane == 0) S->ncand = __popcll(vm);
         }
         BK_SYNC();
-        if (S->ncand > C_.MAXCAND) { bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); }
+        // every thread reads ncand BEFORE thread 0 may reset it (the extra barrier is only taken on the failing path; the
+        // condition is uniform, so the workgroup's barriers stay aligned -- a late wavefront must not see the reset value)
+        const int nc_ = S->ncand;
+        if (nc_ > C_.MAXCAND) { BK_SYNC(); bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); }
         BK_ACC(4);
         return;
     }
@@ -355,7 +358,7 @@ BK_COLD void bk_find_reads(int rank, bool rev, bool filter)
     BK_SYNC();
     for (uint32_t i = b + BK_TID; i < e; i += BK_AT) C_.uminpos[C_.post[i] >> 10] = 0x7FFFFFFF;
     const int n = S->ncand;
-    if (n > C_.MAXCAND) { bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); return; }
+    if (n > C_.MAXCAND) { BK_SYNC(); bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); return; }      // barrier first: every thread has read ncand
     int npad = 1; while (npad < n) npad <<= 1;
     for (int i = n + BK_TID; i < npad; i += BK_AT) L_CAND[i] = ~0ull;
     BK_SYNC();
@@ -1201,7 +1204,7 @@ BK_COLD void bk_emit_contig()
     for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
     if (BK_TID == 0) {
         h->next = 0; h->hits_off = 0; h->seq_len = len; h->counts_len = nlen; h->n_kmers = nk; h->n_reads = nr; h->total_reads = total; h->n_hits = 0;
-        h->o_seq = o_seq; h->o_io = o_io; h->o_ot = o_ot; h->o_klocs = o_kl; h->o_kmers = o_km; h->o_reads = o_rd; h->o_hits = 0; h->size = size;
+        h->o_seq = o_seq; h->o_io = o_io; h->o_ot = o_ot; h->o_klocs = o_kl; h->o_kmers = o_km; h->o_reads = o_rd; h->n_sec = 0; h->size = size;
         if (C_.wk->o_first_contig == 0) C_.wk->o_first_contig = off; else ((BkContigRec *)(C_.out + C_.wk->o_last_contig))->next = off;
         C_.wk->o_last_contig = off; S->n_contigs++;
         const unsigned long long ci = atomicAdd(C_.n_clist, 1ull);              // work list of the realign stage (one workgroup per contig)

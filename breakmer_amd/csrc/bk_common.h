@@ -26,7 +26,8 @@ enum {
     BK_ST_KLIST = 5,          // contig k-mer list overflow
     BK_ST_READLEN = 6,        // read longer than max_read_len
     BK_ST_OUT = 7,            // output arena exhausted (host grows it and reruns)
-    BK_ST_HITS = 8            // too many alignment blocks/hits
+    BK_ST_HITS = 8,           // realign stage: more than BK_MAX_HITS step-1 hits or BK_MAX_SEC secondary alignments for one contig
+    BK_ST_BLOCKS = 9          // realign stage (host): a chained record needs more than BK_MAX_BLOCKS blocks
 };
 
 struct BkKey { uint64_t hi, lo; };
@@ -142,12 +143,13 @@ enum { BK_RF_INDEL = 1, BK_RF_HASN = 2 };
 // contig record in the `out` arena (o_* relative to the record start, 8-byte aligned; k-mers are
 // stored as (lo, hi) key pairs so the record is self-contained)
 struct BkHit { int32_t qs, qe, ts, te, strand, tidx, score, fq; };   // qs/qe in strand coordinates, fq = forward query start
-#define BK_MAX_HITS 8
+#define BK_MAX_HITS 32           // step-1 hits of one contig (they tile the query, >= 20 bases each); one more fails the REGION with BK_ST_HITS
+#define BK_MAX_SEC 256           // secondary alignments of one contig (realign contract step 5); one more fails the region with BK_ST_HITS
 struct BkContigRec {
     uint64_t next;               // `out` offset of the next contig record of the region (0 = end)
-    uint64_t hits_off;           // `out` offset of BkHit[n_hits] (realign stage), 0 = none
+    uint64_t hits_off;           // `out` offset of BkHit[n_hits + n_sec] (realign stage: step-1 hits, then secondary alignments in no particular order), 0 = none
     int32_t seq_len, counts_len, n_kmers, n_reads, total_reads, n_hits;
-    uint32_t o_seq, o_io, o_ot, o_klocs, o_kmers, o_reads, o_hits, size;
+    uint32_t o_seq, o_io, o_ot, o_klocs, o_kmers, o_reads, n_sec, size;
 };
 
 struct BkParams {

@@ -296,7 +296,7 @@ __device__ inline bool bk_bucket_sort(uint32_t *perm, uint32_t M2, const uint64_
                         const unsigned long long ka = K[lo], kb = K[hi2]; const uint32_t a = P[lo], b2 = P[hi2];
                         bool a_first;
                         if (a == BK_EMPTY32) a_first = false; else if (b2 == BK_EMPTY32) a_first = true;
-                        else if (ka != kb) a_first = ka > kb;
+                        else if (ka != kb && ((ka & kb) >> 44) != 0xFFFFFull) a_first = ka > kb;      // both counts saturate the proxy (>= 2^20): only the full comparison orders them
                         else { const BkKey fa{khi[a], klo[a]}, fb{khi[b2], klo[b2]}; a_first = bk_kmer_before(kcnt[a], fa, kcnt[b2], fb); }
                         if (a_first != up) { K[lo] = kb; K[hi2] = ka; P[lo] = b2; P[hi2] = a; }
                     }

@@ -15,6 +15,11 @@
 // across passes and contigs while it is the same chunk.
 // One workgroup per CONTIG: persistent workgroups pull entries of the contig list the assembler appended to
 // (contigs are independent; a noisy region has thousands of them), query intervals of a contig are processed in sequence.
+// Secondary alignments (contract step 5: BLAT prints every alignment >= -minScore and the caller counts them per query base):
+// after the iteration one more sweep over ALL diagonals of the WHOLE query reports every positive excursion whose peak is
+// >= min_score and that is not the same alignment as a step-1 hit (same target, strand, diagonal, overlapping query bases).
+// A diagonal is only walked when a word-granular upper bound of H (16 bases per step: matches by popcount) can reach
+// min_score somewhere on it -- on unrelated sequence it never does, so the sweep costs ~1 op per base of the matrix.
 // Chaining of collinear hits into PSL records is host code (bk_api.hip), restated in the oracle.
 #pragma once
 #include "bk_common.h"
@@ -25,6 +30,7 @@
 struct BkSwShared {
     int nseg; int seg[2 * (2 * BK_MAX_HITS + 4)];
     int nhits; BkHit hits[BK_MAX_HITS];
+    int nsec; BkHit sec[BK_MAX_SEC];             // secondary alignments (step 5), in no particular order
     unsigned long long red[BK_ST_T / 64]; int red_run[BK_ST_T / 64];
     unsigned long long best_key; int best_run;
     unsigned long long cells;
@@ -95,6 +101,73 @@ __device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *qn, const 
     }
 }
 
+// Can H = max(0, H + s) reach `thresh` anywhere on diagonal `off`?  Word-granular upper bound: inside a word H rises by at
+// most its matches; after the word it is at most max(H + matches - 2 mismatches, matches) (the second term: a fresh
+// start inside the word).  false => no excursion of the diagonal peaks at >= thresh (exact walks are only needed for `true`).
+__device__ inline bool bk_sw_diag_maybe(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int thresh)
+{
+    const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
+    if (a1 - a0 < thresh) return false;
+    int hub = 0;
+    for (int wq = a0 >> 4; wq <= (a1 - 1) >> 4; wq++) {
+        const int aw = wq << 4, pb = aw + off;
+        const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
+        const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
+        const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
+        const uint32_t x = qp[wq] ^ tb;
+        const uint32_t eq = ~(x | (x >> 1) | qn[wq]) & 0x55555555u;
+        const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
+        uint32_t vm = 0xFFFFFFFFu >> (2 * lo);
+        if (hi < 16) vm &= ~(0xFFFFFFFFu >> (2 * hi));
+        const int mm = __popc(eq & vm);
+        if (hub + mm >= thresh) return true;
+        hub = max(hub + mm - 2 * (hi - lo - mm), mm);
+    }
+    return false;
+}
+// walk one diagonal over the whole query and report every positive excursion (reset to reset / end of the diagonal) whose
+// peak is >= thresh: emit(peak, query end of the first position of the peak, length of the segment from the excursion's start)
+template <class F>
+__device__ inline void bk_sw_walk_all(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int thresh, F emit)
+{
+    const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
+    int h = 0, run = 0, bh = 0, ba = 0, br = 0;
+    if (a1 <= a0) return;
+    for (int wq = a0 >> 4; wq <= (a1 - 1) >> 4; wq++) {
+        const int aw = wq << 4, pb = aw + off;
+        const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
+        const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
+        const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
+        const uint32_t x = qp[wq] ^ tb;
+        const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
+        uint32_t stop = (x | (x >> 1) | qn[wq] | (hi < 16 ? 0xFFFFFFFFu >> (2 * hi) : 0u)) & 0x55555555u;
+        int pos = lo;
+        while (pos < hi) {
+            const uint32_t rest = stop & (0xFFFFFFFFu >> (2 * pos));
+            const int ts = rest ? (__clz((int)rest) - 1) >> 1 : 16;
+            const int r = ts - pos;
+            if (r > 0) { h += r; run += r; if (h > bh) { bh = h; ba = aw + ts; br = run; } }
+            if (ts >= hi) break;
+            h -= 2; run++;
+            if (h <= 0) { if (bh >= thresh) emit(bh, ba, br); h = 0; run = 0; bh = 0; }
+            pos = ts + 1;
+        }
+    }
+    if (bh >= thresh) emit(bh, ba, br);
+}
+// packed copies (and N masks) of query interval [qs, qe) of the contig, both strands
+__device__ inline void bk_sw_pack_query(const uint8_t *qf, const uint8_t *qr, int Q, int qs, int qe, uint32_t *qpk, uint32_t *qnm, int qpw, int tid)
+{
+    const int n = qe - qs;
+    for (int w = tid; w < 2 * ((n + 15) / 16); w += BK_ST_T) {
+        const int st = w >= (n + 15) / 16, wi = st ? w - (n + 15) / 16 : w;
+        const uint8_t *q = st ? qr + (Q - qe) : qf + qs;
+        uint32_t x = 0, nm = 0;
+        for (int t = 0; t < 16; t++) { const int a = wi * 16 + t; const uint32_t c = a < n ? (uint32_t)q[a] : 0u; x = (x << 2) | (c & 3u); nm = (nm << 2) | (c >> 2); }
+        qpk[st * qpw + wi] = x; qnm[st * qpw + wi] = nm;
+    }
+}
+
 extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, uint32_t tw_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sl[];
@@ -131,22 +204,16 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
         const int Q = rec->seq_len;
         const char *seq = (const char *)(p.out + roff + rec->o_seq);
         for (int i = tid; i < Q; i += BK_ST_T) { char ch = seq[i]; uint8_t c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : BK_CODE_N; qf[i] = c; qr[Q - 1 - i] = c == BK_CODE_N ? (uint8_t)BK_CODE_N : (uint8_t)(3 - c); }
-        if (tid == 0) { S->nseg = 1; S->seg[0] = 0; S->seg[1] = Q; S->nhits = 0; }
+        if (tid == 0) { S->nseg = 1; S->seg[0] = 0; S->seg[1] = Q; S->nhits = 0; S->nsec = 0; }
         __syncthreads();
-        while (S->nseg > 0 && S->nhits < BK_MAX_HITS) {
+        while (S->nseg > 0 && S->status == 0) {
             const int qs = S->seg[2 * (S->nseg - 1)], qe = S->seg[2 * (S->nseg - 1) + 1], n = qe - qs;
             __syncthreads();
             if (tid == 0) { S->nseg--; S->best_key = 0; S->best_run = 0; S->L = 0; }
             __syncthreads();
             if (n < BK_SW_MIN_SEG) continue;
             // packed copies of the query interval (both strands) for the match counts
-            for (int w = tid; w < 2 * ((n + 15) / 16); w += BK_ST_T) {
-                const int st = w >= (n + 15) / 16, wi = st ? w - (n + 15) / 16 : w;
-                const uint8_t *q = st ? qr + (Q - qe) : qf + qs;
-                uint32_t x = 0, nm = 0;
-                for (int t = 0; t < 16; t++) { const int a = wi * 16 + t; const uint32_t c = a < n ? (uint32_t)q[a] : 0u; x = (x << 2) | (c & 3u); nm = (nm << 2) | (c >> 2); }
-                qpk[st * qpw + wi] = x; qnm[st * qpw + wi] = nm;
-            }
+            bk_sw_pack_query(qf, qr, Q, qs, qe, qpk, qnm, qpw, tid);
             unsigned long long bkey = 0; int brun = 0;
             for (int ti = 0; ti <= (int)d.n_partners; ti++) {
                 const uint32_t *gw; int m;
@@ -209,23 +276,65 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     BkHit hgt; hgt.qs = offq + a1 - run; hgt.qe = offq + a1; hgt.ts = b1 - run; hgt.te = b1; hgt.strand = st; hgt.tidx = tidx; hgt.score = score;
                     const int fs = st ? Q - hgt.qe : hgt.qs, fe = st ? Q - hgt.qs : hgt.qe;
                     hgt.fq = fs;
-                    S->hits[S->nhits++] = hgt;
-                    S->seg[2 * S->nseg] = fe; S->seg[2 * S->nseg + 1] = qe; S->nseg++;      // right remainder (after the left one)
-                    S->seg[2 * S->nseg] = qs; S->seg[2 * S->nseg + 1] = fs; S->nseg++;
+                    if (S->nhits >= BK_MAX_HITS) S->status = BK_ST_HITS;                     // never a silent stop: the region reports it
+                    else {
+                        S->hits[S->nhits++] = hgt;
+                        S->seg[2 * S->nseg] = fe; S->seg[2 * S->nseg + 1] = qe; S->nseg++;      // right remainder (after the left one)
+                        S->seg[2 * S->nseg] = qs; S->seg[2 * S->nseg + 1] = fs; S->nseg++;
+                    }
                 }
             }
             __syncthreads();
         }
+        // ---- step 5: secondary alignments (a contig without a step-1 hit has none: the first pass saw every diagonal) ----
+        __syncthreads();
+        if (S->nhits > 0 && S->status == 0) {
+            const int n = Q, nh1 = S->nhits;
+            bk_sw_pack_query(qf, qr, Q, 0, Q, qpk, qnm, qpw, tid);
+            for (int ti = 0; ti <= (int)d.n_partners; ti++) {
+                const uint32_t *gw; int m;
+                if (ti == 0) { gw = p.windows + d.win_word_off; m = (int)d.win_len; }
+                else { const BkPartnerDesc pd = p.partners[d.part_desc_off + ti - 1]; gw = p.windows + pd.word_off; m = (int)pd.len; }
+                const int CH = (int)tw_cap - n, mw = (m + 15) / 16;
+                for (int o0 = -(n - 1); o0 < m; o0 += CH) {
+                    const int o1 = min(o0 + CH, m), t0 = max(o0, 0), t1 = min(m, o1 - 1 + n);
+                    const int tpw0 = t0 >> 4, tpn = ((t1 + 15) >> 4) - tpw0;
+                    __syncthreads();
+                    const bool staged = S->staged_ti == ti && S->staged_t0 == t0 && S->staged_t1 == t1;
+                    __syncthreads();
+                    if (!staged) for (int i = tid; i < tpn; i += BK_ST_T) tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u;
+                    if (tid == 0) { S->staged_ti = ti; S->staged_t0 = t0; S->staged_t1 = t1; }
+                    __syncthreads();
+                    const int nd = o1 - o0;
+                    for (int D = tid; D < 2 * nd; D += BK_ST_T) {
+                        const int st = D >= nd, off = o0 + (st ? D - nd : D);
+                        if (!bk_sw_diag_maybe(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, p.sw_min_score)) continue;
+                        bk_sw_walk_all(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, p.sw_min_score, [&](int sc, int aend, int run) {
+                            const int sqs = aend - run, sqe = aend;                      // strand coordinates (the whole query: no interval offset)
+                            for (int x = 0; x < nh1; x++) {
+                                const BkHit &an = S->hits[x];
+                                if (an.tidx == ti && an.strand == st && an.ts - an.qs == off && an.qs < sqe && sqs < an.qe) return;   // the same alignment
+                            }
+                            const int idx = atomicAdd(&S->nsec, 1);
+                            if (idx < BK_MAX_SEC) { BkHit e; e.qs = sqs; e.qe = sqe; e.ts = sqs + off; e.te = sqe + off; e.strand = st; e.tidx = ti; e.score = sc; e.fq = st ? Q - sqe : sqs; S->sec[idx] = e; }
+                        });
+                    }
+                }
+                if (tid == 0) S->cells += 2ull * (unsigned long long)n * (unsigned long long)m;
+                __syncthreads();
+            }
+        }
         // write the raw hits next to the contig record
         __syncthreads();
         if (tid == 0) {
-            const int nh = S->nhits;
-            rec->n_hits = nh; rec->hits_off = 0;
+            const int nh = S->nhits; int ns = S->nsec;
+            if (ns > BK_MAX_SEC) { S->status = BK_ST_HITS; ns = 0; }
+            rec->n_hits = nh; rec->n_sec = (uint32_t)ns; rec->hits_off = 0;
             if (nh > 0) {
-                uint64_t need = bk_align_up((uint64_t)nh * sizeof(BkHit), 256);
+                uint64_t need = bk_align_up((uint64_t)(nh + ns) * sizeof(BkHit), 256);
                 uint64_t off = atomicAdd(p.out_top, (unsigned long long)need);
-                if (off + need > p.out_cap) { S->status = BK_ST_OUT; rec->n_hits = 0; }
-                else { BkHit *o = (BkHit *)(p.out + off); for (int i = 0; i < nh; i++) o[i] = S->hits[i]; rec->hits_off = off; }
+                if (off + need > p.out_cap) { S->status = BK_ST_OUT; rec->n_hits = 0; rec->n_sec = 0; }
+                else { BkHit *o = (BkHit *)(p.out + off); for (int i = 0; i < nh; i++) o[i] = S->hits[i]; for (int i = 0; i < ns; i++) o[nh + i] = S->sec[i]; rec->hits_off = off; }
             }
             atomicAdd((unsigned long long *)&wk->sw_cells, S->cells);
             if (S->status) wk->status = S->status;

@@ -20,7 +20,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BREAKMER_HIP_LIB") or os.path.join(_HERE, "libbreakmer_hip.so")     # the override is for A/B builds (tools/)
 
 BK_STAGE_KMER, BK_STAGE_ASSEMBLE, BK_STAGE_REALIGN, BK_STAGE_ALL = 1, 2, 4, 7
-BK_MAX_BLOCKS = 16
+BK_MAX_BLOCKS = 32
+BK_ABI_VERSION = 2
+BK_W_REGIONS_FAILED = 1
 
 
 class BkConfig(C.Structure):
@@ -66,7 +68,7 @@ def call_text(text):
 EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_submit_regions_ex", "bk_run", "bk_sync", "bk_fetch",
            "bk_last_kernel_ms", "bk_get_region_status", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
            "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_get_calls",
-           "bk_nw_batch", "bk_pack_sequence"]
+           "bk_nw_batch", "bk_pack_sequence", "bk_trim"]
 
 _lib = None
 
@@ -104,6 +106,7 @@ def load_library():
     L.bk_get_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     L.bk_call_text.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
     L.bk_pack_sequence.argtypes = [C.c_char_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.bk_trim.argtypes = [C.c_void_p, C.c_uint64]
     L.bk_set_call_context.argtypes = [C.c_void_p, C.c_char_p]
     L.bk_call.argtypes = [C.c_void_p]
     L.bk_get_calls.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -218,7 +221,7 @@ class Engine(object):
     def __init__(self, kmer_size, rc_thresh=2, device=0, **limits):
         self.L = load_library()
         cfg = BkConfig()
-        cfg.abi_version = 1
+        cfg.abi_version = BK_ABI_VERSION
         cfg.kmer_size = int(kmer_size)
         cfg.rc_thresh = int(rc_thresh)
         cfg.max_contig_len = int(limits.get("max_contig_len", 0))
@@ -238,6 +241,7 @@ class Engine(object):
         if rc != 0:
             raise BreakmerHipError("bk_create failed (%d): %s" % (rc, self.L.bk_last_error(None).decode()))
         self.n_regions = 0
+        self.n_failed = 0
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -283,7 +287,20 @@ class Engine(object):
             self.sync()
 
     def sync(self):
-        self._chk(self.L.bk_sync(self.h), "bk_sync")
+        """waits for the run; returns the number of regions that hit a device cap (they report no contigs; region_status()
+        names the cap) -- 0 in the normal case"""
+        rc = self.L.bk_sync(self.h)
+        if rc == BK_W_REGIONS_FAILED:
+            self.n_failed = int(self.stat(22))
+            return self.n_failed
+        self._chk(rc, "bk_sync")
+        self.n_failed = 0
+        return 0
+
+    def trim(self, keep_bytes=1 << 30):
+        """free the device / pinned buffers larger than keep_bytes (they are sized anew by the next submit)"""
+        self._chk(self.L.bk_trim(self.h, int(keep_bytes)), "bk_trim")
+        self._inputs = None
 
     def fetch(self):
         """Wait for the last run and copy its records to the host; the handle may be run again before call()."""
@@ -365,12 +382,17 @@ class Engine(object):
 
     def hits(self, region, contig):
         """PSL-equivalent records of one contig (realign stage) as dicts."""
-        arr = (BkPsl * 16)()
-        n = self.L.bk_get_hits(self.h, region, contig, arr, 16)
-        if n < 0:
-            self._chk(n, "bk_get_hits")
+        cap = 16
+        while True:
+            arr = (BkPsl * cap)()
+            n = self.L.bk_get_hits(self.h, region, contig, arr, cap)
+            if n < 0:
+                self._chk(n, "bk_get_hits")
+            if n <= cap:
+                break
+            cap = n                                          # secondary alignments: as many records as BLAT would print lines
         out = []
-        for r in arr[:min(n, 16)]:
+        for r in arr[:n]:
             nb = r.block_count
             out.append({"matches": r.matches, "mismatches": r.mismatches, "rep_matches": r.rep_matches, "n_count": r.n_count,
                         "q_num_insert": r.q_num_insert, "q_base_insert": r.q_base_insert, "t_num_insert": r.t_num_insert,
@@ -399,13 +421,20 @@ class Engine(object):
 
 # ---- handles kept between driver runs of one process ---------------------------------------------------------------------
 # Creating and destroying a handle costs ~35 ms (stream, pinned staging, device buffers sized by the first batch); a process
-# that runs the driver repeatedly (one sample after the other) keeps up to three per (device, k, rc_thresh).
+# that runs the driver repeatedly (one sample after the other) keeps up to three per (device, k, rc_thresh) -- of ONE such
+# key at a time (a run with another k closes the others), and no pooled handle keeps a buffer above _POOL_KEEP_BYTES (the
+# scratch arena of a heavy batch can reach tens of GB: it is given back and re-sized by the next batch).
 _POOL = {}
 _POOL_MAX = 3
+_POOL_KEEP_BYTES = 2 << 30
 
 
 def acquire_engine(kmer_size, rc_thresh=2, device=0):
-    lst = _POOL.get((device, int(kmer_size), int(rc_thresh)))
+    key = (device, int(kmer_size), int(rc_thresh))
+    for other in [k_ for k_ in _POOL if k_ != key]:
+        for e in _POOL.pop(other):
+            e.close()
+    lst = _POOL.get(key)
     if lst:
         return lst.pop()
     return Engine(kmer_size=kmer_size, rc_thresh=rc_thresh, device=device)
@@ -416,6 +445,11 @@ def release_engine(eng):
     lst = _POOL.setdefault(key, [])
     if eng.h and len(lst) < _POOL_MAX:
         eng._inputs = None                      # nothing of the last batch is pending on a handle the driver gives back
+        try:
+            eng.trim(_POOL_KEEP_BYTES)
+        except BreakmerHipError:
+            eng.close()
+            return
         lst.append(eng)
     else:
         eng.close()

@@ -63,8 +63,9 @@ class FastaIndex(object):
     def length(self, chrom):
         return self.index[self._key(chrom)][0]
 
-    def fetch(self, chrom, start, end):
-        """bases [start, end) (0-based, clipped to the sequence), upper case"""
+    def fetch(self, chrom, start, end, upper=True):
+        """bases [start, end) (0-based, clipped to the sequence); upper case unless upper=False (the bytes of the file:
+        soft-masked genomes keep their lower case, as Biopython's str(seq) does in utils.extract_refseq_fa)"""
         length, offset, lb, lby = self.index[self._key(chrom)]
         start, end = max(0, int(start)), min(length, int(end))
         if end <= start or lb == 0:
@@ -72,7 +73,8 @@ class FastaIndex(object):
         b0 = offset + (start // lb) * lby + start % lb
         b1 = offset + ((end - 1) // lb) * lby + (end - 1) % lb + 1
         self._f.seek(b0)
-        return self._f.read(b1 - b0).replace(b"\n", b"").replace(b"\r", b"").decode().upper()
+        seq = self._f.read(b1 - b0).replace(b"\n", b"").replace(b"\r", b"").decode()
+        return seq.upper() if upper else seq
 
     def close(self):
         self._f.close()
@@ -87,7 +89,10 @@ def extract_refseq_fa(gene_coords, ref_path, fasta, direction):      # utils.py:
     fa_fn = os.path.join(ref_path, name + '_' + direction + '_refseq.fa')
     marker = os.path.join(ref_path, "." + name + '_' + direction + '_refseq.fa')
     if not os.path.isfile(marker):
-        seq = fasta.fetch(chrom, int(s) - 200, int(e) + 200)
+        # the bytes the reference writes: str(seq) keeps the case of a soft-masked genome (utils.py:366-371); readers of the
+        # file upper-case (sv_processor.read_fasta_first), as Jellyfish and BLAT ignore case.  Only difference: a window that
+        # starts before base 0 is clipped here, where Python's negative slice index would wrap around in the reference.
+        seq = fasta.fetch(chrom, int(s) - 200, int(e) + 200, upper=False)
         if direction == "reverse":
             seq = revcomp(seq)
         os.makedirs(ref_path, exist_ok=True)
@@ -97,7 +102,7 @@ def extract_refseq_fa(gene_coords, ref_path, fasta, direction):      # utils.py:
     return fa_fn
 
 
-def discover_partners(disc, fasta, annotations, target_chrom, target_start, target_end, min_pairs=2, join=1000, flank=1500, max_windows=8):
+def discover_partners(disc, fasta, annotations, target_chrom, target_start, target_end, min_pairs=2, join=1000, flank=1500, max_windows=8, skipped=None):
     """disc: {mate chromosome: [(read position, mate position), ...]} of one target (sv_processor.py:60-66).
     -> [(chrom, start, end, name, sequence)] in genome coordinates, most supported first: one window per cluster of mate
     positions (neighbours <= `join` apart) with >= `min_pairs` pairs, `flank` bases around it, clipped to the chromosome;
@@ -126,7 +131,9 @@ def discover_partners(disc, fasta, annotations, target_chrom, target_start, targ
             s, e = max(0, lo - flank), min(clen, hi + flank)
             seq = fasta.fetch(c, s, e)
             if len(seq) < 64 or seq.strip("ACGT"):
-                continue                                   # windows must be plain A/C/G/T for the device path
+                if skipped is not None and len(seq) >= 64:
+                    skipped.append((c, s, e))              # windows must be plain A/C/G/T for the device path: the caller logs these
+                continue
             name = annotations.set_gene(c, [(lo + hi) // 2]) if annotations is not None else "intergenic"
             out.append((n, (c, s, e, name, seq)))
     out.sort(key=lambda x: (-x[0], x[1][0], x[1][1]))

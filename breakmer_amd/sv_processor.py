@@ -49,12 +49,14 @@ class RegionData(object):
 
 
 def read_fasta_first(fn):
+    """the sequence of a one-record FASTA, upper case: a *_refseq.fa written by the reference from a soft-masked genome keeps
+    lower case (utils.py:366-371, str(seq)), and its consumers -- Jellyfish, BLAT -- do not care about case"""
     seq = []
     with open(fn) as f:
         for ln in f:
             if not ln.startswith(">"):
                 seq.append(ln.strip())
-    return "".join(seq)
+    return "".join(seq).upper()
 
 
 def read_fastq(fn):
@@ -467,12 +469,29 @@ class target(object):                                               # sv_process
         self.disc_reads = self.data.disc_reads
         if not self.data.partners and self.params.open_fasta() is not None and self.disc_reads.get('disc'):
             # N4: candidate partner windows from the discordant pairs (refseq.discover_partners) stand in for the whole-genome search
+            skipped = []
             self.data.partners = refseq.discover_partners(self.disc_reads['disc'], self.params.open_fasta(), self.params.gene_annotations,
-                                                          self.chrom, self.start, self.end, min_pairs=self.params.get_sr_thresh('trl'))
+                                                          self.chrom, self.start, self.end, min_pairs=self.params.get_sr_thresh('trl'), skipped=skipped)
+            for c_, s_, e_ in skipped:
+                self.logger.warning('target %s: partner window %s:%d-%d holds characters other than A/C/G/T (an assembly gap?) and is not realigned against' % (self.name, c_, s_, e_))
             if self.data.partners:
                 self.logger.info('target %s: %d partner window(s) from discordant pairs: %s' % (self.name, len(self.data.partners),
                                  ", ".join("%s:%d-%d" % (p[0], p[1], p[2]) for p in self.data.partners)))
         self.partner_windows = self.data.partners
+
+    def unsupported_reference(self):
+        """None, or why this target cannot go to the device: its window (or a partner window) holds a character other than
+        A/C/G/T -- an N of an assembly gap within 200 bp of the target.  The reference has no such limit (Jellyfish skips
+        k-mers with an N); here the target is skipped ALONE, with an error in the log and in runner.failed_targets."""
+        d = self.data
+        if not d.window:
+            return "empty reference window"
+        if isinstance(d.window, str) and d.window.strip("ACGT"):
+            return "reference window holds characters other than A/C/G/T (%s)" % ",".join(sorted(set(d.window.strip("ACGT")))[:5])
+        for p_ in d.partners:
+            if isinstance(p_[4], str) and p_[4].strip("ACGT"):
+                return "partner window %s:%s-%s holds characters other than A/C/G/T" % (p_[0], p_[1], p_[2])
+        return None
 
     def clean_reads(self):                                           # :584-606 (cutadapt out of scope) -> bool
         d = self.data
@@ -608,6 +627,8 @@ class runner(object):                                               # sv_process
         self._pooled = []                       # handles to give back to hip_backend's pool when the run is over
         self.native_calls = native_calls        # SV-call tail in C++ (bk_call) instead of breakmer_amd/sv_caller.py; same rows
         self.engine = None
+        self.failed_targets = {}                # name -> why the target has no result although it had reads (a device cap, an N in
+                                                # its window): logged as errors, listed at the end of the run, exit code 3 of breakmer.py
 
     def create_targets(self):                                        # :165-170
         names = sorted(self.params.targets.keys())
@@ -664,6 +685,7 @@ class runner(object):                                               # sv_process
                 if st != 0:
                     self.logger.error('target %s: not assembled on the device: %s' % (t.name, text))
                     t.failed = text
+                    self.failed_targets[t.name] = text
         if self.native_calls and hasattr(eng, 'set_call_context'):
             rows = eng.call()
             for i, t in enumerate(live):
@@ -725,6 +747,12 @@ class runner(object):                                               # sv_process
                     if not t.clean_reads():
                         t.rm_output_dir()
                         continue
+                    why = t.unsupported_reference()
+                    if why:                                           # this target only; the run goes on (summary + exit code report it)
+                        self.logger.error('target %s: skipped: %s' % (t.name, why))
+                        self.failed_targets[t.name] = why
+                        t.rm_output_dir()
+                        continue
                     live.append(t)
                 if not live:
                     continue
@@ -754,6 +782,9 @@ class runner(object):                                               # sv_process
         self.results = [r for _i, r in self.results]
         if self.rank == 0 and 'output' in self.params.paths:
             self.write_output()
+        if self.failed_targets:                                      # never silent: the reference has no caps, so these are results that are missing
+            self.logger.error('%d target(s) without result on rank %d: %s' % (len(self.failed_targets), self.rank,
+                              "; ".join("%s (%s)" % kv for kv in sorted(self.failed_targets.items()))))
         return self.results
 
     def write_output(self):                                          # :212-234

@@ -124,8 +124,16 @@ class Region(object):
 
 def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int = 150, depth: int = 500,
                 sv_type: str = "del", sv_size: int | None = None, noise: float = 0.0,
-                n_reads: int | None = None, var_len: float = 0.0, indel_only_frac: float = 0.0, n_frac: float = 0.0) -> Region:
-    """Generate region `region_id` (config 1-3 defaults)."""
+                n_reads: int | None = None, var_len: float = 0.0, indel_only_frac: float = 0.0, n_frac: float = 0.0,
+                flank_dups: int = 0, trl_repeat_copies: int = 0, microsat: int = 0) -> Region:
+    """Generate region `region_id` (config 1-3 defaults).
+
+    Multi-mapping variants (realign contract step 5; off by default, the default regions are unchanged):
+      flank_dups (del only): bit 0 = the L bases left of the deletion also sit at window[20:20+L], bit 1 = the L bases right
+        of it also at window[W-20-L:W-20], bit 2 = that right copy is reverse-complemented;
+      trl_repeat_copies (trl only): a second partner window holding that many copies of the partner half of the donor;
+      microsat (del only): the `microsat` bases left of the deletion are a (CA)n repeat -- a contig across the junction then
+        aligns on every second diagonal of the repeat (tens to hundreds of secondary alignments)."""
     assert sv_type in SV_TYPES
     r = Region()
     r.region_id = region_id
@@ -136,12 +144,24 @@ def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int =
     r.start = 100000 + 20000 * (region_id // 22) + flank
     r.end = r.start + (W - 2 * flank)
     win = rand_bases(stream_key(global_seed, region_id, 0), W)
-    r.window = win
     c = W // 2
     if sv_size is None:
         sv_size = 60 if sv_type == "ins" else 200
     h = sv_size // 2
     r.sv_size = sv_size
+    if flank_dups:
+        assert sv_type == "del" and W >= 2 * (h + 2 * L + 40)
+        win = win.copy()
+        if flank_dups & 1:
+            win[20:20 + L] = win[c - h - L:c - h]
+        if flank_dups & 2:
+            cp = win[c + h:c + h + L]
+            win[W - 20 - L:W - 20] = revcomp_codes(cp) if flank_dups & 4 else cp
+    if microsat:
+        assert sv_type == "del" and microsat <= c - h
+        win = win.copy()
+        win[c - h - microsat:c - h] = np.tile(np.array([1, 0], dtype=np.uint8), (microsat + 1) // 2)[:microsat]
+    r.window = win
     if sv_type == "del":
         donor = np.concatenate([win[:c - h], win[c + h:]])
     elif sv_type == "ins":
@@ -157,6 +177,15 @@ def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int =
         pstart = 50000000 + 20000 * region_id
         r.partners.append((pchrom, pstart, pstart + W, "PARTNER%05d" % region_id, pw))
         donor = np.concatenate([win[:c], pw[c:]])
+        if trl_repeat_copies:
+            sp = rand_bases(stream_key(global_seed, region_id, 7), 40 * (trl_repeat_copies + 1))
+            parts = [sp[:40]]
+            for i in range(trl_repeat_copies):
+                parts += [pw[c:], sp[40 * (i + 1):40 * (i + 2)]]
+            rw = np.concatenate(parts)
+            rchrom, rstart = "%d" % (1 + (region_id + 13) % 22), 90000000 + 20000 * region_id
+            r.partners.append((rchrom, rstart, rstart + len(rw), "REPEAT%05d" % region_id, rw))
+
     r.donor = donor
     N = n_reads if n_reads is not None else (depth * W) // L
     starts = rand_below(stream_key(global_seed, region_id, 2), N, len(donor) - L + 1)

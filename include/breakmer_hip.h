@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 1
+#define BK_ABI_VERSION 2       /* 2: bk_psl holds 32 blocks; bk_get_hits also returns secondary alignments; bk_sync reports regions that hit a cap (BK_W_REGIONS_FAILED) */
 
 enum {
     BK_OK = 0,
@@ -27,7 +27,9 @@ enum {
     BK_E_NOGPU = -3,        /* no usable gfx950 device: there is NO CPU fallback */
     BK_E_LIMIT = -4,        /* a documented device limit was exceeded (contig/read/candidate caps) */
     BK_E_STATE = -5,        /* call out of order (e.g. bk_run before bk_submit_regions) */
-    BK_E_NOMEM = -6
+    BK_E_NOMEM = -6,
+    BK_W_REGIONS_FAILED = 1 /* bk_sync only: the batch is done, but some regions hit a device cap and report no contigs
+                             * (bk_get_region_status says which and why; bk_get_stat(22) how many) */
 };
 
 /* stage mask for bk_run */
@@ -85,6 +87,10 @@ typedef struct bk_region {
 int bk_create(int device_id, const bk_config *cfg, bk_handle **out);
 int bk_destroy(bk_handle *h);
 const char *bk_last_error(const bk_handle *h);   /* h may be NULL: last error of bk_create */
+/* Free every device / pinned buffer of the handle larger than keep_bytes (the scratch arena grows with the largest batch it
+ * has seen and is otherwise only freed by bk_destroy); the submitted batch is dropped, the next bk_submit_regions sizes
+ * the buffers anew.  For callers that keep handles between runs (the reference creates everything per run). */
+int bk_trim(bk_handle *h, uint64_t keep_bytes);
 int bk_abi_version(void);
 
 /* Pack the regions' sequences to 2 bit/base and make them resident in HBM
@@ -107,7 +113,7 @@ int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int32_t n_regio
  *   BK_STAGE_REALIGN  contig.query_ref -> blat -> PSL, sv_processor.py:823-851).
  * Asynchronous on the handle's stream; bk_sync() or any bk_get_* waits. */
 int bk_run(bk_handle *h, uint32_t stage_mask);
-int bk_sync(bk_handle *h);
+int bk_sync(bk_handle *h);         /* BK_OK, BK_W_REGIONS_FAILED (see above) or a negative BK_E_* code */
 /* Wait for the last bk_run and copy its result records to the host.  The device buffers of the handle are free
  * for the next bk_run after this call: a following bk_call() works on the host copy even when a new run has been
  * started in between (the batching analogue of the reference's per-region loop moving on to the next target,
@@ -149,10 +155,14 @@ int bk_get_contig_info(bk_handle *h, int32_t region, int32_t contig, bk_contig_i
 int bk_get_contig(bk_handle *h, int32_t region, int32_t contig, char *seq, int32_t *indel_only, int32_t *others,
                   int32_t *kmer_locs, char *kmers, int32_t *reads);
 
-/* realign stage: PSL-equivalent records of one contig (fields consumed by sv_caller.py:911-936), i.e. the
- * raw device hits chained on the host.  Returns the number of records (>= 0, may exceed cap) or a
- * negative BK_E_* code.  q_starts are in strand coordinates as in PSL. */
-#define BK_MAX_BLOCKS 16
+/* realign stage: PSL-equivalent records of one contig (fields consumed by sv_caller.py:911-936): the chained
+ * records of the iterated search first (forward query order), then every SECONDARY alignment -- any other gap-free
+ * segment scoring >= sw_min_score on another diagonal, the other strand or another window, as BLAT prints every
+ * alignment >= -minScore (sv_processor.py:843) and the caller counts them per query base (sv_caller.py:593-594,
+ * 616-631, 430-432, 55-72) -- as one-block records ordered by (score desc, window asc, '+' first, query end, target
+ * end).  Returns the number of records (>= 0, may exceed cap) or a negative BK_E_* code (BK_E_LIMIT: a chained record
+ * needs more than BK_MAX_BLOCKS blocks).  q_starts are in strand coordinates as in PSL. */
+#define BK_MAX_BLOCKS 32
 typedef struct bk_psl {
     int32_t matches, mismatches, rep_matches, n_count;
     int32_t q_num_insert, q_base_insert, t_num_insert, t_base_insert;

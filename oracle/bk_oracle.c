@@ -690,7 +690,9 @@ int bko_check_align_case(const char *contig_seq, int clen, const char *read_seq,
 /* ------------------------------------------------------------------ R2 realign (see bk_oracle.h) */
 static uint64_t g_sw_cells = 0;
 uint64_t bko_sw_cells(int reset) { uint64_t v = g_sw_cells; if (reset) g_sw_cells = 0; return v; }
-#define SW_MAXHITS 8
+#define SW_MAXHITS 64        /* the oracle has no cap worth the name: it aborts beyond this (the library's BK_MAX_HITS is 32, reported per region) */
+#define SW_MAXSEC 65536
+#define SW_EQ(a, b) ((a) == (b) && (a) != 'N')      /* an N (contig or window) matches nothing in the realign stage */
 typedef struct { int qs, qe, ts, te, strand, tidx, score, nb; int bs[BKO_MAX_BLOCKS], bq[BKO_MAX_BLOCKS], bt[BKO_MAX_BLOCKS]; int fq; } swhit;   /* q coords are strand coords; fq = forward start */
 
 /* Gap-free local Smith-Waterman (maximal scoring segment): H[a][b] = max(0, H[a-1][b-1] + s(q_a, t_b)).
@@ -706,7 +708,7 @@ static int sw_local(const char *q, int n, const char *t, int m, int *a0, int *a1
         int *hp = H + ((a - 1) & 1) * (m + 1), *hc = H + (a & 1) * (m + 1), *rp = R + ((a - 1) & 1) * (m + 1), *rc_ = R + (a & 1) * (m + 1);
         hc[0] = 0; rc_[0] = 0;
         for (int b = 1; b <= m; b++) {
-            int s = hp[b - 1] + (q[a - 1] == t[b - 1] ? 1 : -2), run = rp[b - 1] + 1;
+            int s = hp[b - 1] + (SW_EQ(q[a - 1], t[b - 1]) ? 1 : -2), run = rp[b - 1] + 1;
             if (s <= 0) { s = 0; run = 0; }
             hc[b] = s; rc_[b] = run;
             if (s > best) { best = s; ba = a; bb = b; br = run; }    /* strict: smallest a, then smallest b */
@@ -724,6 +726,16 @@ static int sw_blocks(const char *q, const char *t, int a0, int a1, int b0, int b
     return 1;
 }
 static int cmp_hit_fq(const void *x, const void *y) { return ((const swhit *)x)->fq - ((const swhit *)y)->fq; }
+typedef struct { int qs, qe, ts, te, strand, tidx, score; } swsec;                  /* strand coordinates */
+static int cmp_sec(const void *x, const void *y)
+{
+    const swsec *a = (const swsec *)x, *b = (const swsec *)y;
+    if (a->score != b->score) return b->score - a->score;
+    if (a->tidx != b->tidx) return a->tidx - b->tidx;
+    if (a->strand != b->strand) return a->strand - b->strand;
+    if (a->qe != b->qe) return a->qe - b->qe;
+    return a->te - b->te;
+}
 
 /* ---- R2 step 4: island fill (bk_oracle.h).  A flank shorter than min_score between two differences cannot anchor a
  * segment of its own; it is recovered here, next to the anchors it belongs to: inside the unaligned rectangle between two
@@ -743,7 +755,7 @@ static int fill_best(const char *q, const char *t, int qa, int qb, int ta, int t
         if (!in1 && !in2) continue;
         int a0 = qa > ta - d ? qa : ta - d, a1 = qb < tb - d ? qb : tb - d, h = 0, run = 0;
         for (int a = a0; a < a1; a++) {
-            h += q[a] == t[a + d] ? 1 : -2; run++;
+            h += SW_EQ(q[a], t[a + d]) ? 1 : -2; run++;
             if (h <= 0) { h = 0; run = 0; continue; }
             int qe = a + 1, te = a + 1 + d;
             if (h > best || (h == best && (qe < out->qe || (qe == out->qe && te < out->te)))) { best = h; out->qs = qe - run; out->qe = qe; out->ts = te - run; out->te = te; out->score = h; }
@@ -770,7 +782,7 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
     swhit hits[SW_MAXHITS]; int nh = 0;
     int stk[2 * (SW_MAXHITS * 2 + 2)], sp = 0;
     stk[sp++] = 0; stk[sp++] = Q;
-    while (sp > 0 && nh < SW_MAXHITS) {
+    while (sp > 0) {
         int qe = stk[--sp], qs = stk[--sp];
         if (qe - qs < min_seg) continue;
         swhit best; best.score = 0; int have = 0;
@@ -787,13 +799,119 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
         best.nb = sw_blocks(qstr, targets[best.tidx], best.qs, best.qe, best.ts, best.te, best.score, best.bs, best.bq, best.bt);
         int fs = best.strand == 0 ? best.qs : Q - best.qe, fe = best.strand == 0 ? best.qe : Q - best.qs;   /* forward query interval */
         best.fq = fs;
+        if (nh >= SW_MAXHITS) { fprintf(stderr, "bk_oracle: more than %d primary hits\n", SW_MAXHITS); abort(); }
         hits[nh++] = best;
         stk[sp++] = fe; stk[sp++] = qe;                              /* right remainder (processed after the left one) */
         stk[sp++] = qs; stk[sp++] = fs;
     }
+    /* ---- step 5 (bk_oracle.h): secondary alignments.  BLAT prints EVERY alignment scoring >= -minScore, so a contig that
+     * also matches somewhere else in a window (a duplicated flank, a repeat, a partner window) gets further PSL lines and
+     * the caller counts them per query base (hit_freq, sv_caller.py:593-594; mean_cov :616,:631,:676; check_uniqueness
+     * :430-432; check_previous_add :55-72).  Here: every diagonal of every (target, strand) is walked over the WHOLE query
+     * with H = max(0, H + s); each positive excursion (from a reset to the next reset or the end of the diagonal) yields
+     * one segment [start of the excursion, first position of its highest H); it is a secondary alignment iff that peak
+     * is >= min_score and the segment does not overlap, on the same target / strand / diagonal, a hit of step 1 (that
+     * would be the same alignment).  Each is reported as a one-block record of its own, after the chained records, ordered
+     * by (score desc, target index asc, '+' first, query end asc, target end asc). */
+    swsec *sec = NULL; int nsec = 0, seccap = 0;
+    for (int ti = 0; ti < ntargets; ti++) for (int st = 0; st < 2; st++) {
+        const char *qq = st == 0 ? contig : rc; const char *tt = targets[ti]; const int m = tlens[ti];
+        for (int off = -(Q - 1); off < m; off++) {
+            const int a0 = off < 0 ? -off : 0, a1 = Q < m - off ? Q : m - off;
+            int h = 0, run = 0, ph = 0, pa = 0, prun = 0;
+            for (int a = a0; a <= a1; a++) {
+                int closed = a == a1;
+                if (!closed) {
+                    h += SW_EQ(qq[a], tt[a + off]) ? 1 : -2; run++;
+                    if (h <= 0) closed = 1;
+                    else if (h > ph) { ph = h; pa = a + 1; prun = run; }
+                }
+                if (closed) {
+                    if (ph >= min_score) {
+                        const int qs = pa - prun, qe = pa; int same = 0;
+                        for (int x = 0; x < nh && !same; x++)
+                            same = hits[x].tidx == ti && hits[x].strand == st && hits[x].ts - hits[x].qs == off && hits[x].qs < qe && qs < hits[x].qe;
+                        if (!same) {
+                            if (nsec == seccap) { seccap = seccap ? seccap * 2 : 64; sec = (swsec *)realloc(sec, (size_t)seccap * sizeof(swsec)); if (!sec || seccap > SW_MAXSEC) { fprintf(stderr, "bk_oracle: secondary hits overflow\n"); abort(); } }
+                            swsec *e = &sec[nsec++]; e->qs = qs; e->qe = qe; e->ts = qs + off; e->te = qe + off; e->strand = st; e->tidx = ti; e->score = ph;
+                        }
+                    }
+                    h = 0; run = 0; ph = 0; pa = 0; prun = 0;
+                }
+            }
+        }
+        g_sw_cells += (uint64_t)Q * (uint64_t)m;
+    }
+    qsort(sec, (size_t)nsec, sizeof(swsec), cmp_sec);
     qsort(hits, (size_t)nh, sizeof(swhit), cmp_hit_fq);
+    /* ---- step 6 (bk_oracle.h): placement of ambiguous hits.  When a step-1 hit has equal alternatives -- a secondary
+     * alignment that covers its query interval and scores the same over it (a duplicated flank) -- step 1's tie-break
+     * (smallest target end) is arbitrary; BLAT reports the chain with the smaller gaps.  The hits in forward query order each
+     * choose among {the hit, its alternatives in step-5 order} so that the number of chain breaks between consecutive hits,
+     * then the sum of |diagonal shifts| between chained neighbours, is smallest (ties: the earlier candidate).  A chosen
+     * alternative becomes the hit (restricted to the hit's query interval); the hit it replaces is listed with the secondary
+     * alignments instead, and the secondary it came from is dropped. */
+    if (nsec > 0 && nh > 0) {
+        typedef struct { int qs, qe, ts, te, strand, tidx, from; } pcand;
+        pcand **cd = (pcand **)xcalloc((size_t)nh, sizeof(pcand *)); int *ncd = (int *)xcalloc((size_t)nh, sizeof(int));
+        long long **cost = (long long **)xcalloc((size_t)nh, sizeof(long long *)); int **back = (int **)xcalloc((size_t)nh, sizeof(int *));
+        for (int x = 0; x < nh; x++) {
+            const swhit *hx = &hits[x];
+            const int fs = hx->strand == 0 ? hx->qs : Q - hx->qe, fe = hx->strand == 0 ? hx->qe : Q - hx->qs;
+            cd[x] = (pcand *)xmalloc((size_t)(nsec + 1) * sizeof(pcand));
+            pcand self = { hx->qs, hx->qe, hx->ts, hx->te, hx->strand, hx->tidx, -1 }; cd[x][0] = self; ncd[x] = 1;
+            for (int y = 0; y < nsec; y++) {
+                const swsec *e = &sec[y];
+                const int sfs = e->strand == 0 ? e->qs : Q - e->qe, sfe = e->strand == 0 ? e->qe : Q - e->qs;
+                if (sfs > fs || sfe < fe) continue;
+                const int cqs = e->strand == 0 ? fs : Q - fe, cqe = e->strand == 0 ? fe : Q - fs, dg = e->ts - e->qs;
+                const char *qstr = e->strand == 0 ? contig : rc; const char *tstr = targets[e->tidx];
+                int sc = 0; for (int z = cqs; z < cqe; z++) sc += SW_EQ(qstr[z], tstr[z + dg]) ? 1 : -2;
+                if (sc != hx->score) continue;
+                pcand c = { cqs, cqe, cqs + dg, cqe + dg, e->strand, e->tidx, y }; cd[x][ncd[x]++] = c;
+            }
+            cost[x] = (long long *)xcalloc((size_t)ncd[x], sizeof(long long)); back[x] = (int *)xcalloc((size_t)ncd[x], sizeof(int));
+        }
+        for (int x = 1; x < nh; x++) for (int b = 0; b < ncd[x]; b++) {
+            long long bestc = -1; int besta = 0;
+            for (int a = 0; a < ncd[x - 1]; a++) {
+                const pcand *A = &cd[x - 1][a], *B = &cd[x][b]; long long t = 1ll << 24;            /* a chain break */
+                if (A->tidx == B->tidx && A->strand == B->strand) {
+                    const pcand *first = A->strand == 0 ? A : B, *second = A->strand == 0 ? B : A;
+                    const int ov = first->te - second->ts;
+                    if (!(ov > 0 && (2 * ov >= first->qe - first->qs || 2 * ov >= second->qe - second->qs)) && second->qs >= first->qe) {
+                        t = (long long)(second->ts - second->qs) - (long long)(first->ts - first->qs); if (t < 0) t = -t;
+                    }
+                }
+                if (bestc < 0 || cost[x - 1][a] + t < bestc) { bestc = cost[x - 1][a] + t; besta = a; }
+            }
+            cost[x][b] = bestc; back[x][b] = besta;
+        }
+        int pick = 0; for (int b = 1; b < ncd[nh - 1]; b++) if (cost[nh - 1][b] < cost[nh - 1][pick]) pick = b;
+        unsigned char *gone = (unsigned char *)xcalloc((size_t)nsec + 1, 1); int nnew = 0; swsec *demoted = (swsec *)xmalloc((size_t)nh * sizeof(swsec));
+        for (int x = nh - 1; x >= 0; x--) {
+            const pcand *c = &cd[x][pick];
+            if (c->from >= 0) {
+                swhit *hx = &hits[x];
+                swsec dm = { hx->qs, hx->qe, hx->ts, hx->te, hx->strand, hx->tidx, hx->score }; demoted[nnew++] = dm;
+                gone[c->from] = 1;
+                hx->qs = c->qs; hx->qe = c->qe; hx->ts = c->ts; hx->te = c->te; hx->strand = c->strand; hx->tidx = c->tidx;
+                hx->bs[0] = c->qe - c->qs; hx->bq[0] = c->qs; hx->bt[0] = c->ts;                      /* fq (forward start) is unchanged */
+            }
+            pick = back[x][pick];
+        }
+        if (nnew > 0) {
+            int w = 0; for (int y = 0; y < nsec; y++) if (!gone[y]) sec[w++] = sec[y];
+            nsec = w;
+            sec = (swsec *)realloc(sec, (size_t)(nsec + nnew + 1) * sizeof(swsec));
+            for (int y = 0; y < nnew; y++) sec[nsec++] = demoted[y];
+            qsort(sec, (size_t)nsec, sizeof(swsec), cmp_sec);
+        }
+        for (int x = 0; x < nh; x++) { free(cd[x]); free(cost[x]); free(back[x]); }
+        free(cd); free(ncd); free(cost); free(back); free(gone); free(demoted);
+    }
     /* chain + emit: hits consecutive in forward query order, same target and strand, collinear on the strand */
-    int nrec = 0, i = 0;
+    int nrec = 0, i = 0, overflow = 0;
     while (i < nh) {
         swhit chain[2 * SW_MAXHITS + 1]; int head = SW_MAXHITS, tail = SW_MAXHITS;     /* deque [head, tail) in strand order */
         chain[tail++] = hits[i];
@@ -821,7 +939,7 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
             const int sq = f->qs, eq = l->qe;                            /* strand coordinates */
             r->q_start = f->strand == 0 ? sq : Q - eq; r->q_end = f->strand == 0 ? eq : Q - sq;
             /* anchors in strand order, islands between them and beyond the ends filled (step 4) */
-            fblk blocks[BKO_MAX_BLOCKS * 2]; int nbk = 0; const int bcap = BKO_MAX_BLOCKS;
+            fblk blocks[BKO_MAX_BLOCKS * 2]; int nbk = 0; const int bcap = BKO_MAX_BLOCKS * 2 - 1;      /* more than BKO_MAX_BLOCKS: the call fails (-2) */
             fblk anch[2 * SW_MAXHITS + 1]; int na = 0;
             for (int c = head; c < tail; c++) { anch[na].qs = chain[c].qs; anch[na].qe = chain[c].qe; anch[na].ts = chain[c].ts; anch[na].te = chain[c].te; anch[na].score = chain[c].score; na++; }
             { const int gq = anch[0].qs; int tlo = anch[0].ts - gq - FILL_BAND; if (tlo < 0) tlo = 0;
@@ -832,13 +950,14 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
             }
             { const int gq = Q - anch[na - 1].qe; int thi = anch[na - 1].te + gq + FILL_BAND; if (thi > tlens[f->tidx]) thi = tlens[f->tidx];
               fill_gap(qstr, tstr, &anch[na - 1], NULL, anch[na - 1].qe, Q, anch[na - 1].te, thi, blocks, &nbk, bcap); }
+            if (nbk > BKO_MAX_BLOCKS) { overflow = 1; nbk = BKO_MAX_BLOCKS; }
             r->t_start = blocks[0].ts; r->t_end = blocks[nbk - 1].te;
             { const int sq2 = blocks[0].qs, eq2 = blocks[nbk - 1].qe; r->q_start = f->strand == 0 ? sq2 : Q - eq2; r->q_end = f->strand == 0 ? eq2 : Q - sq2; }
             int nb = 0, pq = -1, pt = -1;
             for (int c = 0; c < nbk; c++) {
                 r->score += blocks[c].score;
                 const int bs = blocks[c].qe - blocks[c].qs, bq = blocks[c].qs, bt = blocks[c].ts;
-                for (int z = 0; z < bs; z++) { if (qstr[bq + z] == tstr[bt + z]) r->matches++; else r->mismatches++; }
+                for (int z = 0; z < bs; z++) { if (SW_EQ(qstr[bq + z], tstr[bt + z])) r->matches++; else r->mismatches++; }
                 if (pq >= 0) { if (bq > pq) { r->q_num_insert++; r->q_base_insert += bq - pq; } if (bt > pt) { r->t_num_insert++; r->t_base_insert += bt - pt; } }
                 r->block_sizes[nb] = bs; r->q_starts[nb] = bq; r->t_starts[nb] = bt; nb++;
                 pq = bq + bs; pt = bt + bs;
@@ -848,6 +967,17 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
         nrec++;
         i = j;
     }
+    for (int x = 0; x < nsec; x++, nrec++) {
+        if (nrec >= cap) continue;
+        bko_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
+        const swsec *e = &sec[x]; const char *qstr = e->strand == 0 ? contig : rc; const char *tstr = targets[e->tidx];
+        r->strand = e->strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = e->tidx; r->t_size = tlens[e->tidx];
+        r->t_start = e->ts; r->t_end = e->te;
+        r->q_start = e->strand == 0 ? e->qs : Q - e->qe; r->q_end = e->strand == 0 ? e->qe : Q - e->qs;
+        for (int z = 0; z < e->qe - e->qs; z++) { if (SW_EQ(qstr[e->qs + z], tstr[e->ts + z])) r->matches++; else r->mismatches++; }
+        r->block_count = 1; r->block_sizes[0] = e->qe - e->qs; r->q_starts[0] = e->qs; r->t_starts[0] = e->ts; r->score = e->score;
+    }
+    free(sec);
     free(rc);
-    return nrec;
+    return overflow ? -2 : nrec;
 }

@@ -80,8 +80,26 @@ void bko_asm_free(bko_asm *a);
  *      diagonal; it becomes a block of the record if it scores >= 8, and the two rectangles it leaves are filled the
  *      same way (ties: higher score, smaller query end, smaller target end).  tests/golden/realign_evidence.json holds
  *      what the reference's caller makes of these records next to BLAT-style records built from the known edits.
- * Output: PSL-equivalent records (fields consumed by sv_caller.py:911-936). */
-#define BKO_MAX_BLOCKS 16
+ *   5. secondary alignments (BLAT prints EVERY alignment scoring >= -minScore, sv_processor.py:843, and the caller
+ *      counts them per query base: hit_freq sv_caller.py:593-594, mean_cov :616/:631/:676, check_uniqueness :430-432,
+ *      check_previous_add :55-72): every diagonal of every (target, strand) is walked over the WHOLE query with
+ *      H = max(0, H + s); each positive excursion (reset to reset / end of the diagonal) yields the segment from its start
+ *      to the first position of its highest H; it is reported iff that peak is >= min_score and the segment does not
+ *      overlap a step-1 hit on the same target, strand and diagonal (that is the same alignment).  One-block records,
+ *      after the chained ones, ordered by (score desc, target index asc, '+' first, query end asc, target end asc).
+ *      Secondary segments are NOT chained with each other (BLAT would chain collinear ones): hit_freq is the same
+ *      either way, the number of records is not.
+ *   6. placement of ambiguous hits (applied before the chaining of step 3): when a step-1 hit has equal alternatives --
+ *      a secondary alignment that covers its query interval and scores the same over it, e.g. a duplicated flank -- step
+ *      1's tie-break (smallest target end) is arbitrary, while BLAT reports the chain with the smaller gaps.  The hits in
+ *      forward query order each choose among {the hit, its alternatives in step-5 order} such that the number of chain
+ *      breaks between consecutive hits, then the sum of |diagonal shift| between chained neighbours, is smallest (ties:
+ *      the earlier candidate).  A chosen alternative becomes the hit, restricted to the hit's query interval; the hit it
+ *      replaces is listed with the secondary alignments, the secondary it came from is dropped.
+ * An N (in the contig or in a window) matches nothing.
+ * Output: PSL-equivalent records (fields consumed by sv_caller.py:911-936).  Returns the number of records (may exceed
+ * cap), or -2 when a chained record would need more than BKO_MAX_BLOCKS blocks (the library reports that per region). */
+#define BKO_MAX_BLOCKS 32
 typedef struct bko_psl {
     int32_t matches, mismatches, rep_matches, n_count;
     int32_t q_num_insert, q_base_insert, t_num_insert, t_base_insert;

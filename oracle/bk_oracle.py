@@ -196,8 +196,8 @@ class OPsl(C.Structure):
                 ("q_num_insert", C.c_int32), ("q_base_insert", C.c_int32), ("t_num_insert", C.c_int32), ("t_base_insert", C.c_int32),
                 ("strand", C.c_int32), ("q_size", C.c_int32), ("q_start", C.c_int32), ("q_end", C.c_int32),
                 ("t_index", C.c_int32), ("t_size", C.c_int32), ("t_start", C.c_int32), ("t_end", C.c_int32),
-                ("block_count", C.c_int32), ("block_sizes", C.c_int32 * 16), ("q_starts", C.c_int32 * 16),
-                ("t_starts", C.c_int32 * 16), ("score", C.c_int32)]
+                ("block_count", C.c_int32), ("block_sizes", C.c_int32 * 32), ("q_starts", C.c_int32 * 32),
+                ("t_starts", C.c_int32 * 32), ("score", C.c_int32)]
 
 
 def psl_to_dict(r):
@@ -217,6 +217,12 @@ def realign(contig, targets, min_score=20, min_seg=20):
     tb = [t.encode() for t in targets]
     arr = (C.c_char_p * len(tb))(*tb)
     tl = (C.c_int * len(tb))(*[len(t) for t in tb])
-    out = (OPsl * 16)()
-    n = L.bko_realign(contig.encode(), len(contig), arr, tl, len(tb), min_score, min_seg, out, 16)
-    return [psl_to_dict(out[i]) for i in range(min(n, 16))]
+    cap = 64
+    while True:
+        out = (OPsl * cap)()
+        n = L.bko_realign(contig.encode(), len(contig), arr, tl, len(tb), min_score, min_seg, out, cap)
+        if n < 0:
+            raise RuntimeError("bko_realign: a chained record needs more than 32 blocks")
+        if n <= cap:
+            return [psl_to_dict(out[i]) for i in range(n)]
+        cap = n

@@ -124,3 +124,42 @@ def test_g8_realign_contract_evidence(golden_dir):
         assert a is not None and b is not None and a[1] == b[1] and a[6] == b[6] == "indel", c["tag"]       # same breakpoints, same call
         same += a == b
     assert same >= len(d["cases"]) - 1
+
+
+def test_g8m_multi_mapping_contigs(golden_dir):
+    """R2 steps 5-6 (secondary alignments, placement of ambiguous hits): BLAT prints every alignment >= -minScore and the
+    reference's caller counts them per query base.  The fixture holds, per case, the records of this build's contract and
+    BLAT-style records written down from the construction, each with the row the REAL reference's align_manager made of them:
+    both flanks duplicated -> mean_cov 2 -> the indel is filtered (sv_caller.py:631); a repeated partner half -> low uniqueness
+    (:430-432) filters a translocation without discordant pairs and shows as mean_cov 6.0 in the row of one with; the partner
+    half also present in the target window -> check_previous_add (:55-72) turns the event into an in-target rearrangement.
+    Checked here: the oracle still produces the contract records; the Python and the native call tail reproduce the
+    reference's rows for both record sets; both record sets give the same row in every case."""
+    from breakmer_amd import call_context as cc, hip_backend as hb
+    from oracle import bk_oracle as bo
+    with open(os.path.join(golden_dir, "realign_multihit.json")) as f:
+        d = json.load(f)
+    tags = {c["tag"]: c for c in d["cases"]}
+    assert tags["del_both_flanks_dup"]["contract"]["expected"] is None and tags["del_unique"]["contract"]["expected"] is not None
+    assert tags["del_left_flank_dup"]["contract"]["expected"] == tags["del_unique"]["contract"]["expected"]
+    assert tags["trl_partner_repeat_nodisc"]["contract"]["expected"] is None and tags["trl_unique_nodisc"]["contract"]["expected"] is not None
+    assert tags["trl_partner_repeat_disc"]["contract"]["expected"][5].endswith(":6.0")
+    assert tags["trl_partner_half_also_in_target"]["contract"]["expected"] is None
+    for c in d["cases"]:
+        assert bo.realign(c["contig"]["seq"], c["targets"]) == c["contract"]["records"], c["tag"]
+        assert c["contract"]["max_hit_freq"] == c["blat_style"]["max_hit_freq"], c["tag"]
+        for label in ("contract", "blat_style"):
+            e = c[label]
+            case = {"query_region": c["query_region"], "contig": c["contig"], "read_ids": c["read_ids"], "disc_reads": c["disc_reads"],
+                    "opts": d["opts"], "genes": c["genes"], "all_repeat_mask": None, "target_repeat_mask": None, "psl_rows": e["psl_rows"],
+                    "contig_id": "contig1", "offset": e["offset"], "tname": e["tname"]}
+            got, hit = run_case(case)
+            assert got == e["expected"], (c["tag"], label)
+            qr = c["query_region"]
+            query_region = (qr[0], qr[1], qr[2], qr[3], [tuple(x) for x in qr[4]])
+            cd = c["contig"]
+            lines = [cc.opts_line(d["opts"])] + cc.tables_lines(c["genes"], None) + cc.region_lines(0, query_region, None, c["disc_reads"])
+            lines += cc.contig_lines("contig1", cd["seq"], cd["indel_only"], cd["others"], cd["kmer_locs"], len(cd["kmers"]),
+                                     len(set(i.split("/")[1] for i in c["read_ids"])) == 1, e["psl_rows"], e["offset"], e["tname"])
+            assert hb.call_text("\n".join(lines) + "\n")[0] == e["expected"], (c["tag"], label, "native")
+        assert c["contract"]["expected"] == c["blat_style"]["expected"], c["tag"]

@@ -194,6 +194,89 @@ def test_realign_vs_oracle_gpu(hb):
     assert nrec > 14 and eng.stat(2) > 0
 
 
+def _multihit_regions():
+    mk = lambda i, **kw: synth.make_region(i, depth=60, W=1500, **kw)
+    return [mk(3, sv_type="del", flank_dups=1), mk(3, sv_type="del", flank_dups=2), mk(3, sv_type="del", flank_dups=3), mk(3, sv_type="del", flank_dups=6),
+            mk(3, sv_type="del", flank_dups=7), mk(3, sv_type="trl", trl_repeat_copies=5), mk(5, sv_type="trl", trl_repeat_copies=3),
+            synth.make_region(3, depth=60, W=3000, microsat=100), synth.make_region(4, depth=60, W=3000, microsat=250),
+            mk(7, sv_type="del", flank_dups=3, noise=0.01), mk(8, sv_type="del", flank_dups=5, noise=0.02), mk(3, sv_type="del")]
+
+
+def test_realign_secondary_alignments_vs_oracle_gpu(hb):
+    """R2 steps 5-6: secondary alignments (every other gap-free segment >= min_score: duplicated flanks on either strand, a
+    repeated partner half, a microsatellite next to the junction with ~100-200 of them) and the placement of ambiguous hits --
+    the kernel's sweep with its word-granular pruning + the host's chaining == the oracle's brute force, record for record."""
+    from oracle import bk_oracle as bo
+    regions = _multihit_regions()
+    eng = _run_regions(hb, regions, 31, stages=7)
+    assert eng.sync() == 0
+    nrec = 0
+    for i, r in enumerate(regions):
+        targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        cs = eng.contigs(i)
+        assert cs, i
+        for ci, c in enumerate(cs):
+            want = bo.realign(c["seq"], targets)
+            got = eng.hits(i, ci)
+            assert got == want, (i, ci)
+            nrec += len(got)
+        if i < 9:
+            assert max(len(eng.hits(i, ci)) for ci in range(len(cs))) >= 2, i       # these really have secondary alignments
+    assert nrec > 300
+
+
+def test_g8m_multi_mapping_rows_gpu(hb, golden_dir):
+    """The rows the REAL reference's caller made of multi-mapping contigs (tests/golden/realign_multihit.json) from the GPU
+    path end to end: assembly + realign with secondary alignments on the device, native call tail."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from breakmer_amd.sv_processor import params as bk_params
+    d = _load(golden_dir, "realign_multihit.json")
+    tags = {c["tag"]: c for c in d["cases"]}
+    mk = lambda **kw: synth.make_region(3, depth=60, W=1500, **kw)
+    cases = [("del_unique", mk(sv_type="del")), ("del_left_flank_dup", mk(sv_type="del", flank_dups=1)), ("del_both_flanks_dup", mk(sv_type="del", flank_dups=3)),
+             ("del_right_flank_dup_rc", mk(sv_type="del", flank_dups=6)), ("del_right_flank_dup", mk(sv_type="del", flank_dups=2)),
+             ("trl_partner_repeat_disc", mk(sv_type="trl", trl_repeat_copies=5))]
+    regions = [r for _t, r in cases]
+    opts = dict(bk_params.DEFAULTS); opts["var_filter"] = ["indel", "rearrangement", "trl"]
+    eng = hb.Engine(kmer_size=31)
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, partners=[p[4] for p in r.partners]) for r in regions])
+    eng.set_call_context(bench.call_context_text(regions, opts))
+    eng.run(hb.BK_STAGE_ALL)
+    rows = eng.call()
+    for i, (tag, r) in enumerate(cases):
+        c = tags[tag]
+        cs = eng.contigs(i)
+        assert len(cs) == 1 and cs[0]["seq"] == c["contig"]["seq"], tag
+        targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        assert targets == c["targets"], tag
+        assert eng.hits(i, 0) == c["contract"]["records"], tag
+        want = c["contract"]["expected"]
+        got = rows.get(i, [])
+        assert got == ([want] if want is not None else []), tag
+
+
+def test_realign_caps_fail_the_region_loudly_gpu(hb):
+    """More secondary alignments than the library keeps per contig (256; here ~350 from a 600-base microsatellite): the REGION
+    reports BK_ST_HITS -- never a silently shortened list --, bk_sync says that a region failed, the neighbours are untouched."""
+    from oracle import bk_oracle as bo
+    regions = [synth.make_region(3, depth=60, W=1500), synth.make_region(3, depth=60, W=3000, microsat=600), synth.make_region(4, depth=60, W=1500, sv_type="ins")]
+    assert len(bo.realign(bo.assemble_region(regions[1].read_strs(), [regions[1].window_str], 31, 2)[0][0]["seq"], [regions[1].window_str])) > 257
+    eng = hb.Engine(kmer_size=31)
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
+    eng.run(hb.BK_STAGE_ALL, sync=False)
+    assert eng.sync() == 1 and eng.stat(22) == 1
+    st, text = eng.region_status(1)
+    assert st == 8 and "secondary" in text
+    assert eng.contigs(1) == []
+    ok = _run_regions(hb, [regions[0], regions[2]], 31, stages=7)
+    for a, b in ((0, 0), (2, 1)):
+        assert eng.region_status(a)[0] == 0
+        assert eng.contigs(a) == ok.contigs(b) and eng.contigs(a)
+        assert [eng.hits(a, c) for c in range(len(eng.contigs(a)))] == [ok.hits(b, c) for c in range(len(ok.contigs(b)))]
+
+
 def test_runner_end_to_end_gpu(hb, golden_dir, tmp_path):
     """breakmer.py-level run on the GPU: config file + BED + annotation -> runner.run() -> the same
     13-field rows the REAL reference's caller produced for these contigs (tests/golden/caller.json),

@@ -312,3 +312,37 @@ def test_lazy_views_of_engine_records():
         lz2[0]
     lz2.detach()
     assert len(lz2) == 2
+
+
+def test_window_with_n_skips_that_target_only(tmp_path):
+    """A target whose reference window holds an N (an assembly gap within 200 bp) cannot go to the device.  It is skipped
+    ALONE -- error in the log, listed in runner.failed_targets -- and the other targets of the run come out as without it
+    (before: the submit of the whole batch failed and the run aborted)."""
+    cfg, data = make_inputs(tmp_path, [(3, "del"), (4, "del"), (5, "ins")])
+    names = sorted(data)
+    bad = data[names[1]]
+    bad.window = bad.window[:100] + "N" + bad.window[101:]
+    r = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+    rows = r.run()
+    assert [t.upper() for t in r.failed_targets] == [names[1]]
+    assert "A/C/G/T" in list(r.failed_targets.values())[0]
+    d2 = tmp_path / "clean"
+    d2.mkdir()
+    cfg2, data2 = make_inputs(d2, [(3, "del"), (5, "ins")])
+    r2 = sp.runner(cfg2, region_data=data2, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+    assert rows == r2.run() and len(rows) == 2 and not r2.failed_targets
+
+
+def test_soft_masked_refseq_file_is_read_upper_case(tmp_path):
+    """A <name>_forward_refseq.fa written by the reference tool from a soft-masked genome keeps lower case
+    (utils.py:366-371: str(seq)); its readers here upper-case, and refseq.extract_refseq_fa writes the bytes of the genome
+    file as the reference does."""
+    from breakmer_amd import refseq
+    (tmp_path / "g.fa").write_text(">chr1\nACGTacgtnnACGT\nggccAATT\n")
+    fa = refseq.FastaIndex(str(tmp_path / "g.fa"))
+    assert fa.fetch("1", 2, 18) == "GTACGTNNACGTGGCC" and fa.fetch("1", 2, 18, upper=False) == "GTacgtnnACGTggcc"
+    fn = refseq.extract_refseq_fa(("1", 204, 212, "T1", []), str(tmp_path / "ref"), fa, "forward")
+    assert open(fn).read() == ">T1\nacgtnnACGTggccAATT\n"
+    assert sp.read_fasta_first(fn) == "ACGTNNACGTGGCCAATT"
+    fn = refseq.extract_refseq_fa(("1", 204, 212, "T1", []), str(tmp_path / "ref"), fa, "reverse")
+    assert open(fn).read() == ">T1\nAATTggccACGTnnacgt\n"

@@ -619,6 +619,134 @@ def g8():
                                    "disc_reads": {"disc": {}, "inv": [], "td": [], "other": []}, "offset": r.start - 200, "tname": r.chrom})
 
 
+def g8m():
+    """G8m (R2, multi-mapping contigs): BLAT prints EVERY alignment >= -minScore (sv_processor.py:843) and the caller counts
+    them per query base -- hit_freq (sv_caller.py:593-594), mean_cov (:616) in the indel keep test (:631), in the
+    repeat_matching field (:224) and in check_uniqueness (:430-432), check_previous_add (:55-72).  Each case holds (A) the
+    records of this build's realign contract (steps 1-6 of oracle/bk_oracle.h, incl. secondary alignments and the placement
+    of ambiguous hits) and (B) BLAT-style records written down from how the sequences were constructed, with the row the
+    REAL reference's align_manager makes of each."""
+    import copy
+    from oracle import bk_oracle as bo
+    from breakmer_amd import sv_caller as my
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda x: "".join(comp[ch] for ch in reversed(x))
+    o = dict(rh.DEFAULT_OPTS)
+    cases = []
+
+    def block_rec(cs, targets, blocks, strand, tidx):
+        """PSL-equivalent record of ungapped blocks (strand-coordinate query start, target start, length) on one target"""
+        q = cs if strand == '+' else rc(cs)
+        t = targets[tidx]
+        mism = sum(1 for (q0, t0, ln) in blocks for z in range(ln) if q[q0 + z] != t[t0 + z])
+        match = sum(b[2] for b in blocks) - mism
+        qni = sum(1 for a, b in zip(blocks, blocks[1:]) if b[0] > a[0] + a[2]); qbi = sum(b[0] - a[0] - a[2] for a, b in zip(blocks, blocks[1:]))
+        tni = sum(1 for a, b in zip(blocks, blocks[1:]) if b[1] > a[1] + a[2]); tbi = sum(b[1] - a[1] - a[2] for a, b in zip(blocks, blocks[1:]))
+        sq, eq = blocks[0][0], blocks[-1][0] + blocks[-1][2]
+        return {"matches": match, "mismatches": mism, "rep_matches": 0, "n_count": 0, "q_num_insert": qni, "q_base_insert": qbi, "t_num_insert": tni,
+                "t_base_insert": tbi, "strand": strand, "q_size": len(cs), "q_start": sq if strand == '+' else len(cs) - eq,
+                "q_end": eq if strand == '+' else len(cs) - sq, "t_index": tidx, "t_size": len(t), "t_start": blocks[0][1],
+                "t_end": blocks[-1][1] + blocks[-1][2], "block_sizes": [b[2] for b in blocks], "q_starts": [b[0] for b in blocks],
+                "t_starts": [b[1] for b in blocks], "score": match - 2 * mism}
+
+    def run(tag, r, cd, co, targets, tinfo, truth, genes, disc, qr=None):
+        qr = qr or (r.chrom, r.start, r.end, r.name, [(r.chrom, r.start, r.end, r.name, 'exon')])
+        out = {"tag": tag, "contig": cd, "read_ids": sorted(x.id for x in co.reads), "targets": targets, "tinfo": [list(x) for x in tinfo],
+               "query_region": [qr[0], qr[1], qr[2], qr[3], [list(x) for x in qr[4]]], "genes": genes,
+               "disc_reads": {"disc": {k: [list(x) for x in v] for k, v in disc["disc"].items()}, "inv": [list(x) for x in disc["inv"]],
+                              "td": [list(x) for x in disc["td"]], "other": [list(x) for x in disc["other"]]}}
+        for label, recs in (("contract", bo.realign(cd["seq"], targets)), ("blat_style", truth)):
+            rows = [my.psl_fields(x, 'contig1', r.name, 0) for x in recs if x['t_index'] == 0]
+            offset, tname = r.start - 200, r.chrom
+            res, am = rh.ref_call(rows, co, 'contig1', qr, o, genes, disc, None, None, offset, tname)
+            hit = bool(am.bm.target_hit()) if am.bm.has_blat_results else None
+            if not hit:                                         # Q14: the reference goes to the whole genome: every record, genome coordinates
+                rows = [my.psl_fields(x, 'contig1', 'chr' + tinfo[x['t_index']][0], tinfo[x['t_index']][1]) for x in recs]
+                offset, tname = None, None
+                res, am = rh.ref_call(rows, co, 'contig1', qr, o, genes, disc, None, None, None, None)
+            br0 = am.bm.blat_results[0][3]
+            out[label] = {"records": recs, "psl_rows": rows, "offset": offset, "tname": tname, "expected": res, "target_hit": hit,
+                          "n_results": len(am.bm.blat_results), "top_mean_cov": getattr(br0, "mean_cov", None),
+                          "max_hit_freq": max(am.bm.hit_freq)}
+        a, b_ = out["contract"]["expected"], out["blat_style"]["expected"]
+        out["same_row"] = a == b_
+        print("  %-34s same=%s recs %d/%d max_hit_freq %d/%d\n      A %s\n      B %s" % (
+            tag, out["same_row"], len(out["contract"]["records"]), len(truth), out["contract"]["max_hit_freq"], out["blat_style"]["max_hit_freq"],
+            a and a[:8], b_ and b_[:8]))
+        cases.append(out)
+
+    # ---- deletions whose flanks also sit elsewhere in the window -------------------------------------------------------------
+    L, W = 150, 1500
+    for tag, fd in (("del_unique", 0), ("del_left_flank_dup", 1), ("del_both_flanks_dup", 3), ("del_right_flank_dup_rc", 6), ("del_right_flank_dup", 2)):
+        r = synth.make_region(3, sv_type="del", depth=60, W=W, flank_dups=fd)
+        reads = r.read_strs()
+        mers = rh.ref_kmer_select(reads, [r.window_str], 31)
+        cdicts, cobjs = rh.ref_init_assembly(r.read_ids, reads, mers, 31, 2, r.indel_only)
+        assert len(cdicts) == 1
+        cs, Wd = cdicts[0]["seq"], r.window_str
+        c, h = W // 2, 100
+        jq = cs.find(Wd[c + h:c + h + 40])                     # contig bases left of the junction
+        assert cs == Wd[c - h - jq:c - h] + Wd[c + h:c + h + len(cs) - jq]
+        truth = [block_rec(cs, [Wd], [(0, c - h - jq, jq), (jq, c + h, len(cs) - jq)], '+', 0)]
+        if fd & 1:
+            truth.append(block_rec(cs, [Wd], [(0, 20 + L - jq, jq)], '+', 0))
+        if fd & 2:
+            n2 = len(cs) - jq
+            truth.append(block_rec(cs, [Wd], [(jq, W - 20 - L, n2)], '+', 0) if not fd & 4 else block_rec(cs, [Wd], [(0, W - 20 - n2, n2)], '-', 0))
+        run(tag, r, cdicts[0], cobjs[0], [Wd], [(r.chrom, r.start - 200)], truth, {r.name: ['chr' + r.chrom, r.start, r.end]}, r.disc_reads)
+
+    # ---- translocation whose partner half is a repeat (check_uniqueness, sv_caller.py:430-432; the mean_cov of the row) -----
+    for tag, copies, with_disc in (("trl_unique_nodisc", 0, False), ("trl_partner_repeat_nodisc", 5, False), ("trl_partner_repeat_disc", 5, True),
+                                   ("trl_partner_repeat4_nodisc", 3, False)):
+        r = synth.make_region(3, sv_type="trl", depth=60, W=W, trl_repeat_copies=copies)
+        reads = r.read_strs()
+        mers = rh.ref_kmer_select(reads, [r.window_str], 31)
+        cdicts, cobjs = rh.ref_init_assembly(r.read_ids, reads, mers, 31, 2, r.indel_only)
+        assert len(cdicts) == 1
+        co = copy.deepcopy(cobjs[0])
+        for i, rd in enumerate(sorted(co.reads, key=lambda x: x.id)):      # reads of both strands: no read_strand_bias check (sv_caller.py:436-446)
+            if i % 2:
+                rd.id = rd.id.replace("/1_0", "/2_1")
+        cs = cdicts[0]["seq"]
+        targets = [r.window_str] + [synth.codes_to_str(p_[4]) for p_ in r.partners]
+        tinfo = [(r.chrom, r.start - 200)] + [(p_[0], p_[1]) for p_ in r.partners]
+        c = W // 2
+        ja = cs.find(targets[1][c:c + 40])
+        assert cs == targets[0][c - ja:c] + targets[1][c:c + len(cs) - ja]
+        truth = [block_rec(cs, targets, [(0, c - ja, ja)], '+', 0), block_rec(cs, targets, [(ja, c, len(cs) - ja)], '+', 1)]
+        for i in range(copies):
+            truth.append(block_rec(cs, targets, [(ja, 40 + i * (W - c + 40), len(cs) - ja)], '+', 2))
+        genes = {r.name: ['chr' + r.chrom, r.start, r.end]}
+        for p_ in r.partners:
+            genes[p_[3]] = ['chr' + p_[0], p_[1], p_[2]]
+        disc = r.disc_reads if with_disc else {"disc": {}, "inv": [], "td": [], "other": []}
+        run(tag, r, cdicts[0], co, targets, tinfo, truth, genes, disc)
+
+    # ---- the partner half also sits in the target window, a little less well (check_previous_add, sv_caller.py:55-72) -----
+    r = synth.make_region(3, sv_type="trl", depth=60, W=W)
+    reads = r.read_strs()
+    mers = rh.ref_kmer_select(reads, [r.window_str], 31)
+    cdicts, cobjs = rh.ref_init_assembly(r.read_ids, reads, mers, 31, 2, r.indel_only)
+    cs = cdicts[0]["seq"]
+    pw = synth.codes_to_str(r.partners[0][4])
+    c = W // 2
+    ja = cs.find(pw[c:c + 40])
+    cp = list(pw[c:c + len(cs) - ja])
+    for at in (300, 500):
+        cp[at] = comp[cp[at]]
+    spacer = synth.codes_to_str(synth.rand_bases(synth.stream_key(1, 3, 9), 50))
+    W2 = r.window_str + spacer + "".join(cp)
+    targets = [W2, pw]
+    tinfo = [(r.chrom, r.start - 200), (r.partners[0][0], r.partners[0][1])]
+    end2 = r.start + len(W2) - 400                              # the target interval covers the longer window
+    qr = (r.chrom, r.start, end2, r.name, [(r.chrom, r.start, end2, r.name, 'exon')])
+    genes = {r.name: ['chr' + r.chrom, r.start, end2], r.partners[0][3]: ['chr' + r.partners[0][0], r.partners[0][1], r.partners[0][2]]}
+    truth = [block_rec(cs, targets, [(0, c - ja, ja)], '+', 0), block_rec(cs, targets, [(ja, c, len(cs) - ja)], '+', 1),
+             block_rec(cs, targets, [(ja, W + 50, len(cs) - ja)], '+', 0)]
+    run("trl_partner_half_also_in_target", r, cdicts[0], cobjs[0], targets, tinfo, truth, genes, r.disc_reads, qr)
+    dump("realign_multihit.json", {"cases": cases, "opts": o})
+
+
 def g9():
     """G9 (N3): the file loaders in front of the caller's filters, executed by the REAL reference on synthetic files --
     utils.anno.add_genes / add_regions / set_gene (utils.py:727-773), setup_rmask_all (:302-316) and setup_rmask (:320-353,
@@ -672,7 +800,7 @@ def g9():
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g8m", "g9"]
     for w in which:
         print(w)
         globals()[w]()
