@@ -416,16 +416,28 @@ def main():
                     prof.update(json.load(open(fn)))
                 except Exception:
                     pass
-        traffic = prof.get("bk_asm_kernel_bytes_per_launch")
-        # integer-VALU roofline of the assembler: lane-ops per DP cell from the SQ_INSTS_VALU pass (profiles/valu.json:
-        # wave instructions x 64 lanes / algorithmic cells); `achieved` = algorithmic cells per second
-        lpc = prof.get("bk_asm_kernel_valu_laneops_per_cell")
-        valu = {"bound": "valu", "unit": "TCUPS", "peak_laneops_per_s": VALU_PEAK_LANEOPS, "laneops_per_cell": lpc,
-                "achieved_kernel": round(cells / asm_excl_s / 1e12, 4), "achieved_path": round(cells / step_s / 1e12, 4)}
+        # The dominant kernel OF THE TIMED REGION: the 256-thread build when batches are in flight (default), the 512-thread build
+        # otherwise.  Its average launch duration comes from the HIP events the library records on the handle's stream around
+        # every launch of the timed steps (bk_last_kernel_ms); the counters (HBM traffic, VALU instructions) are per-launch
+        # figures of THAT kernel from the committed rocprofv3 passes of the round (`source`), collected with one launch at a
+        # time because PMC collection serialises kernels (tools/profile_round.sh regenerates them with the bench line).
+        kname = "bk_asm_kernel_w4" if int(eng.stat(25)) == 256 else "bk_asm_kernel"
+        k_ms = asm_ms / a.steps
+        achieved = alg_bytes / (k_ms / 1e3) / 1e9
+        traffic = prof.get(kname + "_bytes_per_launch")
+        # integer-VALU roofline of the assembler.  Algorithmic lane-ops per DP cell of olc.nw (olc.py:62-74): three candidate
+        # sums, the match/mismatch compare + select, one three-way max = 6; `peak` = the chip's VALU issue rate / 6.  What the
+        # kernel really issues per algorithmic cell (SQ_INSTS_VALU x 64 / cells: the 7-op cell of this encoding, pipeline
+        # fill/drain, planning, retire) gives `utilisation` = issued lane-ops / issue peak.
+        ALG_OPS = 6.0
+        lpc = prof.get(kname + "_valu_laneops_per_cell")
+        valu = {"bound": "valu", "unit": "TCUPS", "kernel": kname, "peak_laneops_per_s": VALU_PEAK_LANEOPS, "algorithmic_laneops_per_cell": ALG_OPS,
+                "peak": round(VALU_PEAK_LANEOPS / ALG_OPS / 1e12, 3),
+                "achieved": round(cells / step_s / 1e12, 4), "achieved_kernel_exclusive": round(cells / asm_excl_s / 1e12, 4),
+                "measured_laneops_per_cell": lpc, "source": prof.get("valu_source")}
+        valu["frac"] = round(valu["achieved"] / valu["peak"], 4)
         if lpc:
-            valu["peak"] = round(VALU_PEAK_LANEOPS / lpc / 1e12, 3)
-            valu["frac_kernel"] = round(valu["achieved_kernel"] / valu["peak"], 4)
-            valu["frac"] = round(valu["achieved_path"] / valu["peak"], 4)
+            valu["utilisation"] = round(lpc * cells / step_s / VALU_PEAK_LANEOPS, 4)
         out = {
             "metric": "target regions/sec at 500x 150bp, 31-mers; achieved HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "regions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -443,10 +455,14 @@ def main():
                        "collated_bytes_per_step": collated if dist else None,
                        "parallelism": "regions sharded per GPU, all-gather of result records"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "bk_asm_kernel", "kernel_ms": round(s_a / ks, 3),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": prof.get("traffic_source"),
+                         "kernel": kname, "kernel_ms": round(k_ms, 3),
+                         "kernel_ms_note": "average launch duration of this kernel over the timed steps (HIP events on its stream; %d batches in flight stretch each other)" % len(engs),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "kernel_ms = exclusive (one handle in flight); the path is integer-VALU/latency bound, not HBM bound (SURVEY 8d): see roofline_valu"},
+                         "exclusive": {"kernel": "bk_asm_kernel", "kernel_ms": round(s_a / ks, 3), "achieved": round(alg_bytes / asm_excl_s / 1e9, 3),
+                                       "traffic": prof.get("bk_asm_kernel_bytes_per_launch"),
+                                       "note": "the one-step-at-a-time pass below (one handle, 512-thread build): nothing co-runs"},
+                         "note": "the path is integer-VALU/latency bound, not HBM bound (SURVEY 8d): see roofline_valu"},
             "roofline_valu": valu,
             "hbm_path": {"achieved": round(alg_bytes / step_s / 1e9, 3), "unit": "GB/s", "frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 6),
                          "note": "algorithmic bytes of one step / ms_per_step (all kernels, batches in flight)"},

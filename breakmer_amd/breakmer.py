@@ -68,16 +68,16 @@ def main(argv=None):
     tic = time.perf_counter()
     config_d = parse_config_f(config_fn, args)
     setup_logger(config_d, 'root')
-    rank, world, collate = 0, 1, None
+    rank, world, collate, status_exchange = 0, 1, None, None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:                   # one process per GPU, regions sharded by rank
         import torch
         import torch.distributed as td
-        from .collate import collate_results
+        from .collate import collate_results, exchange_status
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         td.init_process_group("nccl", device_id=torch.device("cuda", local))
-        rank, world, collate = td.get_rank(), td.get_world_size(), collate_results
-    r = runner(config_d, rank=rank, world=world, collate=collate)
+        rank, world, collate, status_exchange = td.get_rank(), td.get_world_size(), collate_results, exchange_status
+    r = runner(config_d, rank=rank, world=world, collate=collate, status_exchange=status_exchange)
     r.run(tic)
     logging.getLogger('root').info('Analysis complete, %s' % str(time.perf_counter() - tic))
     return 3 if r.failed_targets else 0          # 3: the run is complete but some targets have no result (log: which and why)

@@ -37,3 +37,11 @@ def collate_results(results, summary, device=None):
         all_results.extend(d["r"])
         all_summary.update(d["s"])
     return all_results, all_summary
+
+
+def exchange_status(err, device=None):
+    """runner hook, called by every rank before the collation: `err` = None (this rank is through its targets) or the text
+    of what stopped it; -> the list of all ranks' values (rank order).  A rank that failed still takes part, so nobody waits
+    in a collective for a rank that is gone."""
+    parts = all_gather_bytes(json.dumps(err).encode(), device)
+    return [json.loads(p.decode()) for p in parts]

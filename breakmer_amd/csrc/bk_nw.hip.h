@@ -408,6 +408,12 @@ __device__ __noinline__ void bk_nw_dual_c(int contig_off, int clen_, int off1_, 
         else { const int org = w2 & 0xFFFF; res[7] = w2 >> 18; res[5] = i2; if (org & 0x8000) { res[6] = org & 0x7FFF; res[4] = 0; } else { res[4] = org; res[6] = 0; } }
     }
 }
+// Tried in round 3 and not kept (tools/dp_bench_dual.py history, profiles/r03/valu_rate.txt): the same sweep with two rows per
+// iteration in a column-shifted frame (stored word = H + 2 j, so the left neighbour's word IS the horizontal candidate and the
+// chain along a row is max3 -> v_and_or), laid out cell by cell so that the two rows' chains interleave.  Bit-exact, but no
+// faster (0.9-1.0x): the loop is bound by instruction ISSUE, not by the dependency chain -- one wavefront alone issues a VALU
+// instruction every ~5 cycles whatever the dependencies, a saturated SIMD issues a 2-operand instruction every ~2.4 cycles
+// and a 3-operand one (v_max3_i32, v_and_or_b32) every ~4.2 -- and trading the add + and for one v_and_or saves nothing.
 template <int C>
 __device__ inline void bk_nw_dual_call(int c, int contig, int clen, int off1, int rows, int n, int res)
 {

@@ -26,11 +26,13 @@
 
 #define BK_ST_T 512
 #define BK_SW_MIN_SEG 20
+#define BK_SW_FLAGS 1024
 
 struct BkSwShared {
     int nseg; int seg[2 * (2 * BK_MAX_HITS + 4)];
     int nhits; BkHit hits[BK_MAX_HITS];
     int nsec; BkHit sec[BK_MAX_SEC];             // secondary alignments (step 5), in no particular order
+    int nflag; int flag_off[BK_SW_FLAGS]; int flag_ts[BK_SW_FLAGS];   // diagonals of the whole query on which H can reach min_score (found by the first pass): (offset, target << 1 | strand)
     unsigned long long red[BK_ST_T / 64]; int red_run[BK_ST_T / 64];
     unsigned long long best_key; int best_run;
     unsigned long long cells;
@@ -125,6 +127,32 @@ __device__ inline bool bk_sw_diag_maybe(const uint32_t *qp, const uint32_t *qn, 
     }
     return false;
 }
+// match count of a diagonal (as bk_sw_diag_matches) and, in the same pass over its words, the word-granular upper bound of
+// bk_sw_diag_maybe: `maybe` = H can reach thresh somewhere on it.  Branch-free (the loads of the next words are not held up).
+__device__ inline int bk_sw_diag_scan(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int thresh, bool &maybe)
+{
+    const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
+    maybe = false;
+    if (a1 <= a0) return 0;
+    int u = 0, hub = 0, top = 0;
+    for (int wq = a0 >> 4; wq <= (a1 - 1) >> 4; wq++) {
+        const int aw = wq << 4, pb = aw + off;
+        const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
+        const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
+        const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
+        const uint32_t x = qp[wq] ^ tb;
+        const uint32_t eq = ~(x | (x >> 1) | qn[wq]) & 0x55555555u;
+        const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
+        uint32_t vm = 0xFFFFFFFFu >> (2 * lo);
+        if (hi < 16) vm &= ~(0xFFFFFFFFu >> (2 * hi));
+        const int mm = __popc(eq & vm);
+        u += mm;
+        top = max(top, hub + mm);
+        hub = max(hub + 3 * mm - 2 * (hi - lo), mm);
+    }
+    maybe = top >= thresh;
+    return u;
+}
 // walk one diagonal over the whole query and report every positive excursion (reset to reset / end of the diagonal) whose
 // peak is >= thresh: emit(peak, query end of the first position of the peak, length of the segment from the excursion's start)
 template <class F>
@@ -204,7 +232,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
         const int Q = rec->seq_len;
         const char *seq = (const char *)(p.out + roff + rec->o_seq);
         for (int i = tid; i < Q; i += BK_ST_T) { char ch = seq[i]; uint8_t c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : BK_CODE_N; qf[i] = c; qr[Q - 1 - i] = c == BK_CODE_N ? (uint8_t)BK_CODE_N : (uint8_t)(3 - c); }
-        if (tid == 0) { S->nseg = 1; S->seg[0] = 0; S->seg[1] = Q; S->nhits = 0; S->nsec = 0; }
+        if (tid == 0) { S->nseg = 1; S->seg[0] = 0; S->seg[1] = Q; S->nhits = 0; S->nsec = 0; S->nflag = 0; }
         __syncthreads();
         while (S->nseg > 0 && S->status == 0) {
             const int qs = S->seg[2 * (S->nseg - 1)], qe = S->seg[2 * (S->nseg - 1) + 1], n = qe - qs;
@@ -212,6 +240,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
             if (tid == 0) { S->nseg--; S->best_key = 0; S->best_run = 0; S->L = 0; }
             __syncthreads();
             if (n < BK_SW_MIN_SEG) continue;
+            const bool first = qs == 0 && qe == Q && S->nhits == 0;              // the first pass: the whole query
             // packed copies of the query interval (both strands) for the match counts
             bk_sw_pack_query(qf, qr, Q, qs, qe, qpk, qnm, qpw, tid);
             unsigned long long bkey = 0; int brun = 0;
@@ -232,12 +261,19 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     if (tid == 0) { S->umax = 0; S->staged_ti = ti; S->staged_t0 = t0; S->staged_t1 = t1; }
                     __syncthreads();
                     const int nd = o1 - o0;
-                    // (1) match counts; this thread's best diagonal
-                    int myu = -1, myD = 0;
+                    // (1) match counts; this thread's two best diagonals and the largest count among its others.  The first pass
+                    // (the whole query) also notes the diagonals on which H can reach min_score at all: step 5 walks only those.
+                    int myu = -1, myD = 0, myu2 = -1, myD2 = 0, myu3 = -1;
                     for (int D = tid; D < 2 * nd; D += BK_ST_T) {
                         const int st = D >= nd, off = o0 + (st ? D - nd : D);
-                        const int u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off);
-                        if (u > myu) { myu = u; myD = D; }
+                        int u;
+                        if (first) {
+                            bool maybe; u = bk_sw_diag_scan(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, p.sw_min_score, maybe);
+                            if (maybe) { const int fi = atomicAdd(&S->nflag, 1); if (fi < BK_SW_FLAGS) { S->flag_off[fi] = off; S->flag_ts[fi] = (ti << 1) | st; } }
+                        } else u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off);
+                        if (u > myu) { myu3 = myu2; myu2 = myu; myD2 = myD; myu = u; myD = D; }
+                        else if (u > myu2) { myu3 = myu2; myu2 = u; myD2 = D; }
+                        else if (u > myu3) myu3 = u;
                     }
                     if (myu > 0) atomicMax(&S->umax, myu);
                     __syncthreads();
@@ -250,14 +286,24 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                         walked = myD;
                     }
                     __syncthreads();
-                    // (3) every diagonal that can still hold the maximum
-                    for (int D = tid; D < 2 * nd; D += BK_ST_T) {
+                    // (3) every diagonal that can still hold the maximum (count >= L; ties are walked): this thread's best one if (2)
+                    // did not take it, its second best, and -- only if even the largest of its other counts reaches L -- a
+                    // rescan of all its diagonals (rare: the counts of unrelated diagonals are far below an achieved score)
+                    auto walk_one = [&](int D) {
                         const int st = D >= nd, off = o0 + (st ? D - nd : D);
-                        if (D == walked) continue;
-                        const int u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off);
-                        if (u < *(volatile int *)&S->L || u == 0) continue;
                         int bh, ba, br; bk_sw_walk(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, bh, ba, br);
                         if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } if (bh > *(volatile int *)&S->L) atomicMax(&S->L, bh); }
+                    };
+                    if (walked < 0 && myu > 0 && myu >= *(volatile int *)&S->L) walk_one(myD);
+                    if (myu2 > 0 && myu2 >= *(volatile int *)&S->L) walk_one(myD2);
+                    if (myu3 > 0 && myu3 >= *(volatile int *)&S->L) {
+                        for (int D = tid; D < 2 * nd; D += BK_ST_T) {
+                            if (D == myD || D == myD2) continue;
+                            const int st = D >= nd, off = o0 + (st ? D - nd : D);
+                            const int u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off);
+                            if (u < *(volatile int *)&S->L || u == 0) continue;
+                            walk_one(D);
+                        }
                     }
                 }
                 if (tid == 0) S->cells += 2ull * (unsigned long long)n * (unsigned long long)m;
@@ -306,9 +352,16 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     if (tid == 0) { S->staged_ti = ti; S->staged_t0 = t0; S->staged_t1 = t1; }
                     __syncthreads();
                     const int nd = o1 - o0;
-                    for (int D = tid; D < 2 * nd; D += BK_ST_T) {
-                        const int st = D >= nd, off = o0 + (st ? D - nd : D);
-                        if (!bk_sw_diag_maybe(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, p.sw_min_score)) continue;
+                    const int nfl = S->nflag, nwork = nfl <= BK_SW_FLAGS ? nfl : 2 * nd;      // the diagonals the first pass flagged; all of them if that list overflowed
+                    for (int W = tid; W < nwork; W += BK_ST_T) {
+                        int st, off;
+                        if (nfl <= BK_SW_FLAGS) {
+                            const int ts = S->flag_ts[W]; off = S->flag_off[W]; st = ts & 1;
+                            if ((ts >> 1) != ti || off < o0 || off >= o1) continue;
+                        } else {
+                            st = W >= nd; off = o0 + (st ? W - nd : W);
+                            if (!bk_sw_diag_maybe(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, p.sw_min_score)) continue;
+                        }
                         bk_sw_walk_all(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, p.sw_min_score, [&](int sc, int aend, int run) {
                             const int sqs = aend - run, sqe = aend;                      // strand coordinates (the whole query: no interval offset)
                             for (int x = 0; x < nh1; x++) {

@@ -479,6 +479,24 @@ class target(object):                                               # sv_process
                                  ", ".join("%s:%d-%d" % (p[0], p[1], p[2]) for p in self.data.partners)))
         self.partner_windows = self.data.partners
 
+    def cost_estimate(self):
+        """what this target will roughly cost on the device, known on EVERY rank without communication (the ranks deal the
+        targets among themselves by it): the number of reads -- given with the region data, counted in the alignment file
+        (every rank has parsed it), or the size of an extracted read file -- else the length of the interval"""
+        d = self.data
+        if d is not None:
+            return len(d.read_ids)
+        bam_fn = self.params.opts.get('sample_bam_file')
+        try:
+            if bam_fn and os.path.isfile(bam_fn):
+                return sum(1 for _r in self.params.open_bam(bam_fn).fetch(self.chrom, self.start - 200, self.end + 200))
+            fq = os.path.join(self.paths.get('data', ''), self.name + "_sv_reads.fastq")
+            if os.path.isfile(fq):
+                return os.path.getsize(fq) // 300
+        except Exception:
+            pass
+        return max(1, (int(self.end) - int(self.start)) // 100)
+
     def unsupported_reference(self):
         """None, or why this target cannot go to the device: its window (or a partner window) holds a character other than
         A/C/G/T -- an N of an assembly gap within 200 bp of the target.  The reference has no such limit (Jellyfish skips
@@ -613,7 +631,7 @@ class target(object):                                               # sv_process
 
 # ------------------------------------------------------------------------------------------------ runner
 class runner(object):                                               # sv_processor.py:98-235
-    def __init__(self, config_d, region_data=None, engine_factory=None, rank=0, world=1, collate=None, native_calls=True):
+    def __init__(self, config_d, region_data=None, engine_factory=None, rank=0, world=1, collate=None, native_calls=True, status_exchange=None):
         self.params = params(config_d)
         self.results = []
         self.targets = {}
@@ -623,6 +641,8 @@ class runner(object):                                               # sv_process
         self.region_data = region_data or {}
         self.engine_factory = engine_factory
         self.rank, self.world, self.collate = rank, world, collate
+        self.status_exchange = status_exchange  # collate.exchange_status: every rank learns whether any rank failed BEFORE the collation
+        self.assigned_cost = 0                  # sum of the cost estimates of this rank's targets
         self._ctx_head = None
         self._pooled = []                       # handles to give back to hip_backend's pool when the run is over
         self.native_calls = native_calls        # SV-call tail in C++ (bk_call) instead of breakmer_amd/sv_caller.py; same rows
@@ -716,10 +736,24 @@ class runner(object):                                               # sv_process
 
     def run(self, start_time=None):                                  # :174-209
         names = self.create_targets()
-        # striped partition over the sorted target names: heavy targets tend to be neighbours (gene families,
-        # translocation partners), stripes spread them; the rows are put back into target order after the collation
+        # Partition over the ranks: regions differ in cost by orders of magnitude (depth, noise, SV type), so the
+        # targets are dealt heaviest first to the rank with the least load so far (cost = number of reads, known on every
+        # rank: no communication); ties and the order inside a rank follow the sorted names.  The rows are put back into
+        # target order after the collation.
         order = {n: i for i, n in enumerate(names)}
-        mine = [n for i, n in enumerate(names) if i % self.world == self.rank]
+        if self.world > 1:
+            cost = {n: int(self.targets[n].cost_estimate()) for n in names}
+            load = [0] * self.world
+            owner = {}
+            for n in sorted(names, key=lambda x: (-cost[x], x)):
+                rk = min(range(self.world), key=lambda r_: (load[r_], r_))
+                owner[n] = rk
+                load[rk] += max(1, cost[n])
+            mine = [n for n in names if owner[n] == self.rank]
+            self.assigned_cost = load[self.rank]
+            self.logger.info('rank %d of %d: %d of %d targets, estimated cost %d (all ranks: %s)' % (self.rank, self.world, len(mine), len(names), load[self.rank], load))
+        else:
+            mine = list(names)
         # Batching front-end: the reference handles one target at a time; here bounded batches of targets go through the HIP
         # library on up to three handles.  A batch is handed to the library one iteration before its kernels are launched
         # (its 2-bit packing and H2D copies run on a thread of the library meanwhile); in between, this thread picks up the
@@ -736,7 +770,7 @@ class runner(object):                                               # sv_process
             self._launch_batch(eng, live)
             running.append((eng, live))
 
-        ok = False
+        ok, failure = False, None
         try:
             for b0 in range(0, len(mine), bsz):
                 live = []
@@ -767,6 +801,11 @@ class runner(object):                                               # sv_process
             if running:
                 self._finish_batch(running[0][0], running[0][1], order)
             ok = True
+        except Exception as ex:                                        # with several ranks the others must hear of it (below) before this one stops
+            if self.world <= 1 or self.status_exchange is None:
+                raise
+            failure = ex
+            self.logger.error('rank %d failed: %s: %s' % (self.rank, type(ex).__name__, ex))
         finally:
             from . import hip_backend
             for eng in self._pooled:                                    # back to the pool after a clean run, closed otherwise
@@ -776,8 +815,23 @@ class runner(object):                                               # sv_process
                     eng.close()
             self._pooled = []
             self.engine = None
+        if self.world > 1 and self.status_exchange is not None:
+            # Every rank says whether it got through its targets BEFORE the collation: a rank that stopped with an exception
+            # would otherwise leave the others waiting in the all-gather until the launcher kills them.  One failed rank
+            # makes EVERY rank raise (exit code != 0); a fresh launch is the restart.
+            errs = self.status_exchange(None if failure is None else "%s: %s" % (type(failure).__name__, failure))
+            bad = ["rank %d: %s" % (rk, e) for rk, e in enumerate(errs) if e]
+            if failure is not None:
+                raise failure
+            if bad:
+                raise RuntimeError("multi-rank run aborted, " + "; ".join(bad))
         if self.collate is not None and self.world > 1:               # collate per-region rows over ranks (RCCL all-gather)
             self.results, self.summary = self.collate(self.results, self.summary)
+            if self.status_exchange is not None:                      # ... and which targets were skipped anywhere (exit code of every rank)
+                merged = {}
+                for d_ in self.status_exchange(self.failed_targets):
+                    merged.update(d_ or {})
+                self.failed_targets = merged
         self.results.sort(key=lambda x: x[0])                         # stable: target order (sv_processor.py:175-176), rows of a target as produced
         self.results = [r for _i, r in self.results]
         if self.rank == 0 and 'output' in self.params.paths:

@@ -55,7 +55,8 @@ typedef struct bk_config {
     int32_t out_kbytes;         /* initial result arena in KiB; 0 = choose from the batch; grown and retried on overflow */
     int32_t reserved[6];        /* [0]: diagnostic flags (0 in production; 1 = one overlap DP per wavefront even for short contigs,
                                  *      8 = no look-ahead across k-mer visits, 16 = no look-ahead into the next seeds: same results, more DP rounds;
-                                 *      32 = bucket sort of the seed k-mers whatever their number (the path of very large noisy regions))
+                                 *      32 = bucket sort of the seed k-mers whatever their number (the path of very large noisy regions),
+                                 *      64 = every read retired on its own (no run retire): same results)
                                  * [1]: assembler workgroup size: 512 = 8 wavefronts / 8 look-ahead slots / 2 per CU (one batch finishes soonest),
                                  *      256 = 4 wavefronts / 4 slots / 4 per CU (most regions/s when batches are in flight), 0 = library chooses */
 } bk_config;

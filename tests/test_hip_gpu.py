@@ -107,6 +107,12 @@ def test_nw_random_vs_oracle_gpu(hb):
         if t % 2:
             b = "".join((ch if rnd2.random() > 0.04 else rnd2.choice("ACGTN")) for ch in b)
         dual.append((a, b if b else "A"))
+    # odd and even read lengths, contigs around every register count (32 * C columns), the shapes of the headline
+    for m in list(range(60, 321, 13)) + [96, 97, 128, 129, 160, 161, 288, 289, 319, 320]:
+        for n in (149, 150, 151, 2, 1):
+            a = "".join(rnd2.choice("ACGT") for _ in range(m))
+            ov = min(m, n, rnd2.randint(1, 150))
+            dual.append((a, (a[:ov][::-1][::-1] if (m + n) % 3 == 0 else a[m - ov:]) + "".join(rnd2.choice("ACGT") for _ in range(n - ov))))
     d1, _ = eng.nw_batch(dual, transposed=3)
     d2, _ = eng.nw_batch(dual, transposed=4)
     for (a, b), x1, x2 in zip(dual, d1.tolist(), d2.tolist()):
@@ -776,13 +782,16 @@ def test_async_submit_gpu(hb):
 def test_lookahead_across_visits_changes_nothing_gpu(hb):
     """The look-ahead across k-mer visits and into the next seeds only moves DPs to an earlier round: contigs, realign
     records and the DP work counted (the reference's nw calls and cells) are the same with either or both switched off
-    (bk_config.reserved[0] = 8 / 16 / 24), for both workgroup sizes, on clean, noisy and N-carrying regions."""
+    (bk_config.reserved[0] = 8 / 16 / 24), for both workgroup sizes, on clean, noisy and N-carrying regions.  The same for
+    the run retire (64 = off: every read retired on its own): reads that leave the contig sequence as it is -- rejected,
+    identical, contained -- are retired together; on the noisy regions whole runs are rejections (the shape that made the
+    first, unguarded version of it crawl: a run without a contained read has an empty count range)."""
     regions = [synth.make_region(7300 + i, sv_type=synth.SV_TYPES[i % 5], depth=(300 if i % 3 == 0 else 60), W=1200, L=100,
                                  noise=(0.0, 0.006, 0.004, 0.03)[i % 4], n_frac=(0.2 if i % 7 == 0 else 0.0)) for i in range(40)]
     ins = [hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only, partners=[p[4] for p in r.partners]) for r in regions]
     ref = None
     for wg in (512, 256):
-        for flags in (24, 8, 16, 0):
+        for flags in (24 | 64, 24, 8, 16, 64, 0):
             eng = hb.Engine(kmer_size=31, flags=flags, wg_threads=wg)
             eng.submit(ins)
             eng.run(7)

@@ -66,43 +66,92 @@ def test_config_and_cli_parsing(tmp_path):
         breakmer.parse_config_f(str(tmp_path / "bad.cfg"), args)
 
 
-def _rank_main(rank, world, port, base, q):
+SKEW = [(3, "del"), (5, "ins"), (7, "inv"), (9, "del"), (11, "del"), (13, "ins")]
+
+
+def _skew_inputs(d):
+    """six targets, the first with ten times the reads of the others (depth 600 vs 60)"""
+    cfg, data = make_inputs(d, SKEW)
+    r = synth.make_region(3, sv_type="del", depth=600, W=1500)
+    data[r.name.upper()] = sp.RegionData(r.read_ids, r.read_strs(), r.indel_only.tolist(), None, r.window_str, [], r.disc_reads)
+    return cfg, data
+
+
+def _rank_main(rank, world, port, base, q, mode):
     import torch.distributed as td
-    from breakmer_amd.collate import collate_results
+    from breakmer_amd.collate import collate_results, exchange_status
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     td.init_process_group("gloo", rank=rank, world_size=world)
     import pathlib
     d = pathlib.Path(base) / ("rank%d" % rank)
     d.mkdir()
-    cfg, data = make_inputs(d, [(3, "del"), (5, "ins"), (7, "inv"), (9, "del")])
-    r = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')),
-                  rank=rank, world=world, collate=collate_results)
-    rows = r.run()
-    q.put((rank, rows, sorted(r.summary)))
+    cfg, data = _skew_inputs(d) if mode != "plain" else make_inputs(d, [(3, "del"), (5, "ins"), (7, "inv"), (9, "del")])
+
+    class Failing(FakeEngine):
+        def run(self, stages=7, sync=True):
+            raise RuntimeError("injected device failure")
+    def factory(prm):
+        cls = Failing if (mode == "fail" and rank == 1) else FakeEngine
+        return cls(prm.get_kmer_size(), prm.get_sr_thresh('min'))
+    r = sp.runner(cfg, region_data=data, engine_factory=factory, rank=rank, world=world, collate=collate_results, status_exchange=exchange_status)
+    try:
+        rows = r.run()
+        q.put((rank, "ok", rows, sorted(r.summary), r.assigned_cost))
+    except Exception as ex:
+        q.put((rank, "raised", "%s: %s" % (type(ex).__name__, ex), None, r.assigned_cost))
     td.destroy_process_group()
 
 
-def test_two_rank_collation_gloo(tmp_path):
-    """world_size 2 on CPU (gloo): regions sharded by rank, rows all-gathered == single-process run."""
+def _run_ranks(tmp_path, mode, tag):
     import torch.multiprocessing as mp
-    single = tmp_path / "single"
-    single.mkdir()
-    cfg, data = make_inputs(single, [(3, "del"), (5, "ins"), (7, "inv"), (9, "del")])
-    want = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min'))).run()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_rank_main, args=(rk, 2, port, str(tmp_path), q)) for rk in range(2)]
+    port = 29500 + (os.getpid() + hash(tag)) % 2000
+    base = tmp_path / tag
+    base.mkdir()
+    procs = [ctx.Process(target=_rank_main, args=(rk, 2, port, str(base), q, mode)) for rk in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(60)
-    for rank, rows, names in got:
-        assert rows == want, rank
+        assert not p.is_alive()
+    return sorted(got)
+
+
+def test_two_rank_collation_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): regions dealt to the ranks, rows all-gathered == single-process run."""
+    single = tmp_path / "single"
+    single.mkdir()
+    cfg, data = make_inputs(single, [(3, "del"), (5, "ins"), (7, "inv"), (9, "del")])
+    want = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min'))).run()
+    for rank, state, rows, names, _cost in _run_ranks(tmp_path, "plain", "plain"):
+        assert state == "ok" and rows == want, rank
         assert len(names) == 4
     assert len(want) >= 3
+
+
+def test_two_rank_cost_skew_and_failed_rank_gloo(tmp_path):
+    """(a) A 10:1 cost skew: the targets are dealt by estimated cost (number of reads), heaviest first to the least loaded
+    rank -- the heavy target sits alone on one rank, the five light ones on the other (name stripes would have put it with
+    two of them) -- and the collated rows equal the single-process run.  (b) A rank whose engine fails: EVERY rank raises
+    (naming the failed rank) instead of the healthy one waiting in the collation until the launcher kills it."""
+    single = tmp_path / "single"
+    single.mkdir()
+    cfg, data = _skew_inputs(single)
+    want = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min'))).run()
+    got = _run_ranks(tmp_path, "skew", "skew")
+    costs = sorted(g[4] for g in got)
+    light = 5 * ((60 * 1500) // 150)
+    assert costs == [light, (600 * 1500) // 150], costs
+    for rank, state, rows, names, _cost in got:
+        assert state == "ok" and rows == want, rank
+        assert len(names) == len(SKEW)
+    got = _run_ranks(tmp_path, "fail", "fail")
+    assert [g[1] for g in got] == ["raised", "raised"], got
+    assert "injected device failure" in got[1][2]                     # the failing rank re-raises its own exception
+    assert "rank 1" in got[0][2] and "injected device failure" in got[0][2]      # the healthy rank names it
 
 
 def make_sam_inputs(tmp_path, rid=3, sv="del", size=120, n_pairs=400):

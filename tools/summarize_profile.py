@@ -57,17 +57,19 @@ if tot:
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of the fetched bytes); the factor was re-measured for this "
                   "repo's 4 B/lane and row-strided loads with tools/pmc_calibrate.hip (profiles/r02/pmc_calibration.txt: 0.500-0.502); "
                   "WRITE_SIZE is exact for coalesced stores/atomics and counts a whole 64-B line per isolated 4-byte store")
+    tj["traffic_source"] = "profiles/%s/pmc_traffic_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh %s)" % (tag, tag)
     json.dump(tj, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 # ---- SQ instruction counters (one pass, one handle in flight): VALU issue roofline of the assembler
 cells = None
-bj0 = os.path.join(src, "bench_default.json")
-if os.path.isfile(bj0) and os.path.getsize(bj0):
-    try:
-        line = [ln for ln in open(bj0).read().splitlines() if ln.startswith("{")][-1]
-        cells = json.loads(line).get("dp_cells_per_step")
-    except Exception:
-        cells = None
-for sub, label in (("pmc_sq", "one handle in flight, 512-thread workgroups"), ("pmc_sq3", "default: 6 handles in flight, 256-thread workgroups")):
+for cand in ("bench_default.json", "pmc_sq.log", "stats.log"):      # the bench line of any of the runs: the algorithmic cell count is a property of the workload
+    bj0 = os.path.join(src, cand)
+    if cells is None and os.path.isfile(bj0) and os.path.getsize(bj0):
+        try:
+            line = [ln for ln in open(bj0, errors="replace").read().splitlines() if ln.startswith("{") and "dp_cells_per_step" in ln][-1]
+            cells = json.loads(line).get("dp_cells_per_step")
+        except Exception:
+            cells = None
+for sub, label in (("pmc_sq", "one launch at a time: the 256-thread build (timed loop) and the 512-thread build (one-step-at-a-time pass)"), ("pmc_sq3", "default: 6 handles in flight, 256-thread workgroups")):
     fn = one(sub + "/**/*_counter_collection.csv")
     if not fn:
         continue
@@ -83,18 +85,21 @@ for sub, label in (("pmc_sq", "one handle in flight, 512-thread workgroups"), ("
         f.write("kernel," + ",".join(n + "_per_launch" for n in names) + "\n")
         for k, a in sorted(acc.items()):
             f.write(k + "," + ",".join("%.0f" % (a[n][0] / max(1, len(a[n][1])) if n in a else 0.0) for n in names) + "\n")
-    if sub == "pmc_sq" and "bk_asm_kernel" in acc and "SQ_INSTS_VALU" in acc["bk_asm_kernel"] and cells:
-        a = acc["bk_asm_kernel"]
-        valu = a["SQ_INSTS_VALU"][0] / max(1, len(a["SQ_INSTS_VALU"][1]))
-        vj = {"bk_asm_kernel_valu_insts_per_launch": valu, "dp_cells_per_launch": cells,
-              "bk_asm_kernel_valu_laneops_per_cell": round(valu * 64.0 / cells, 3),
-              "valu_note": "rocprofv3 --pmc SQ_INSTS_VALU ... (bench.py --steps 6 --warmup 2 --inflight 1, 256 regions): wave-level VALU instructions "
-                           "of one bk_asm_kernel launch x 64 lanes / algorithmic DP cells of the launch (sum len(seq1)*len(seq2) over the reference's nw calls)"}
-        for n in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY"):
-            if n in a:
-                vj["bk_asm_kernel_" + n + "_per_launch"] = a[n][0] / max(1, len(a[n][1]))
+    if sub == "pmc_sq" and cells:
+        vj = {"dp_cells_per_launch": cells,
+              "valu_source": "profiles/%s/pmc_sq_summary.csv (rocprofv3 --pmc SQ_INSTS_VALU ... pass of tools/profile_round.sh %s, one launch at a time)" % (tag, tag),
+              "valu_note": "wave-level VALU instructions of one launch x 64 lanes / algorithmic DP cells of the launch (sum len(seq1)*len(seq2) over the reference's nw calls)"}
+        for kn in ("bk_asm_kernel", "bk_asm_kernel_w4"):
+            if kn in acc and "SQ_INSTS_VALU" in acc[kn]:
+                a = acc[kn]
+                valu = a["SQ_INSTS_VALU"][0] / max(1, len(a["SQ_INSTS_VALU"][1]))
+                vj[kn + "_valu_insts_per_launch"] = valu
+                vj[kn + "_valu_laneops_per_cell"] = round(valu * 64.0 / cells, 3)
+                for n in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+                    if n in a:
+                        vj[kn + "_" + n + "_per_launch"] = a[n][0] / max(1, len(a[n][1]))
+                print("valu", kn, vj[kn + "_valu_laneops_per_cell"], "lane-ops per algorithmic cell")
         json.dump(vj, open(os.path.join(root, "profiles", "valu.json"), "w"), indent=1)
-        print("valu", vj["bk_asm_kernel_valu_laneops_per_cell"], "lane-ops per algorithmic cell")
 bj = os.path.join(src, "bench_default.json")
 if os.path.isfile(bj) and os.path.getsize(bj):
     open(os.path.join(dst, "bench_default.json"), "w").write(open(bj).read())
