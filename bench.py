@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (testing)")
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
     ap.add_argument("--cfg3-regions", type=int, default=4096, help="batch size of the configs[3] side measurement (heavy regions: the chip fills at a few thousand)")
-    ap.add_argument("--cfg4-regions", type=int, default=256, help="batch size of the configs[4] side measurement (one workgroup per region in the k-mer stage: 64 regions leave three quarters of the chip idle)")
+    ap.add_argument("--cfg4-regions", type=int, default=512, help="batch size of the configs[4] side measurement: a region's chain of ~19,000 dependent rounds takes ~3 s whatever runs beside it, so regions in flight ARE the throughput (256: 69 regions/s, 512: 101) until the scratch arena (~350 MB per region) fills the HBM (640 no longer fit)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic library flags (bk_config.reserved[0]); 0 in every reported number")
     ap.add_argument("--lib", default=None, help="diagnostic: path of an alternative build of the library (A/B runs on one box)")
     ap.add_argument("--dump-collated", default=None, help="write the bytes collated in the last step to this file (testing)")
@@ -106,6 +106,23 @@ def cfg3_region(synth, i, depth=1000):
 def cfg4_region(synth, i, depth=2000):
     """BASELINE.json configs[4] (SURVEY 8d "Config 5"): 250 bp reads at 2,000x (24,000 reads), k = 41, 5 % substitutions."""
     return synth.make_region(40000 + i, sv_type="del", depth=depth, W=3000, L=250, noise=0.05)
+
+
+def _gen_region(spec):
+    kind, i = spec
+    from breakmer_amd import synth
+    return cfg4_region(synth, i) if kind == "cfg4" else cfg3_region(synth, i)
+
+
+def make_regions_parallel(kind, n):
+    """synthetic regions generated on the host cores (a configs[4] region is 6 M random draws: ~0.1-0.3 s in numpy); the workers
+    are SPAWNED and only run numpy -- nothing of this process's GPU state is inherited"""
+    import multiprocessing as mp
+    cores = usable_cores()
+    if cores <= 1 or n < 16:
+        return [_gen_region((kind, i)) for i in range(n)]
+    with mp.get_context("spawn").Pool(min(cores, 16)) as pool:
+        return pool.map(_gen_region, [(kind, i) for i in range(n)], chunksize=4)
 
 
 def time_other_config(hb, regions, k, opts, reps, device):
@@ -486,7 +503,7 @@ def main():
                 oc["configs[3]"] = time_other_config(hb, regs3, 31, opts, 2, local)
                 oc["configs[3]"]["workload"] = "mixed SV set (indel/inv/dup/trl + partner window), 1,000x 150 bp, k=31"
                 del regs3
-                regs4 = [cfg4_region(synth, i) for i in range(a.cfg4_regions)]
+                regs4 = make_regions_parallel("cfg4", a.cfg4_regions)
                 oc["configs[4]"] = time_other_config(hb, regs4, 41, opts, 1, local)
                 oc["configs[4]"]["workload"] = "250 bp reads at 2,000x, k=41, 5 % substitution noise"
                 del regs4

@@ -504,10 +504,10 @@ class target(object):                                               # sv_process
         d = self.data
         if not d.window:
             return "empty reference window"
-        if isinstance(d.window, str) and d.window.strip("ACGT"):
+        if isinstance(d.window, str) and d.window.encode().translate(None, b"ACGT"):      # C-speed scan (str.strip walks the characters one by one)
             return "reference window holds characters other than A/C/G/T (%s)" % ",".join(sorted(set(d.window.strip("ACGT")))[:5])
         for p_ in d.partners:
-            if isinstance(p_[4], str) and p_[4].strip("ACGT"):
+            if isinstance(p_[4], str) and p_[4].encode().translate(None, b"ACGT"):
                 return "partner window %s:%s-%s holds characters other than A/C/G/T" % (p_[0], p_[1], p_[2])
         return None
 
