@@ -17,12 +17,14 @@ static const size_t ctx_shared_bytes = (sizeof(BkAsmCtx) + 15) / 16 * 16 + (size
 #undef BK_WITH_NW_BATCH
 #define BK_AT 256
 #define BK_ASM_KERNEL bk_asm_kernel_w4
+#define BK_PAIR 1
 namespace at256 {
 #include "bk_asm.hip.h"
 static const size_t ctx_shared_bytes = (sizeof(BkAsmCtx) + 15) / 16 * 16 + (sizeof(BkAsmShared) + 15) / 16 * 16;
 }
 #undef BK_AT
 #undef BK_ASM_KERNEL
+#undef BK_PAIR
 using at512::bk_nw_batch_kernel;
 #include "bk_sw.hip.h"
 #include "bk_call.h"
@@ -442,9 +444,9 @@ static void fill_params(bk_handle *h)
 
 static size_t asm_lds_bytes(const bk_handle *h, int threads)
 {
-    const size_t waves = threads / 64;
+    const size_t waves = threads / 64, slots = threads == 512 ? waves : 2 * waves;      // the 256-thread build aligns two reads per wavefront (BK_PAIR)
     size_t o = threads == 512 ? at512::ctx_shared_bytes : at256::ctx_shared_bytes;
-    o += (size_t)h->cfg.max_candidates * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + waves * (h->eff_max_read + 16);
+    o += (size_t)h->cfg.max_candidates * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + slots * (h->eff_max_read + 16);
     return (o + 15) / 16 * 16;
 }
 
@@ -935,7 +937,8 @@ extern "C" int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, con
     HIPCHK(h, hipMemcpy(dc.p, codes.data(), seq_bytes, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d1.p, off1, nb, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(d2.p, len1, nb, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d3.p, off2, nb, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(d4.p, len2, nb, hipMemcpyHostToDevice));
-    const size_t lds = ((maxm + 15) & ~15u) + ((maxn + 15) & ~15u) + (size_t)2 * (std::max(maxm, maxn) + 2) * 4;
+    const size_t lds = transposed >= 5 ? (size_t)2 * (((maxm + 15) & ~15u) + ((maxn + 15) & ~15u)) + 256      // bk_nw_pair: two pairs of sequences, parameters, results
+                                       : ((maxm + 15) & ~15u) + ((maxn + 15) & ~15u) + (size_t)2 * (std::max(maxm, maxn) + 2) * 4;
     HIPCHK(h, hipFuncSetAttribute((const void *)bk_nw_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
     hipLaunchKernelGGL(bk_nw_batch_kernel, dim3(n_pairs), dim3(64), lds, h->stream, (const uint8_t *)dc.p, (const uint32_t *)d1.p, (const uint32_t *)d2.p,

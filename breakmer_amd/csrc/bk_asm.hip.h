@@ -22,7 +22,13 @@
 #endif
 #undef BK_SPEC
 #undef BK_SPEC_WIDE
+#undef BK_WAVES
+#define BK_WAVES (BK_AT / 64)
+#ifdef BK_PAIR                      // throughput build (bk_api.hip: the 256-thread kernel): a wavefront aligns TWO reads of a round (bk_nw_pair) ...
+#define BK_SPEC (2 * BK_WAVES)      // ... so a round has twice as many look-ahead slots as wavefronts
+#else
 #define BK_SPEC (BK_AT / 64)        // look-ahead slots, both overlap DPs of a slot on one wavefront (bk_nw_dual);
+#endif
 #define BK_SPEC_WIDE (BK_AT / 128)  // contigs beyond BK_NW_DUAL_COLS or few reads in a round: half as many slots x 2 wavefronts (one DP each)
 
 
@@ -58,7 +64,7 @@ struct BkAsmShared {
     int la_planned, la_adopted;  // slots planned for later visits / retired from there, in the current window of 64 planned
     int la_pause, la_backoff;
     int n_rej, n_acc;            // recent reads rejected / accepted by check_align: with most rejected, the prediction is "nothing changes"    // rounds the look-ahead stays off after a window in which most of its slots were wasted (doubles)
-    int la_n[BK_SPEC], la_t[BK_SPEC], la_rank[BK_SPEC], la_pc[BK_SPEC];
+    int la_n[BK_WAVES], la_t[BK_WAVES], la_rank[BK_WAVES], la_pc[BK_WAVES];      // one look-ahead list per wavefront
     int qslot;                   // position in the region queue this workgroup is working on
     uint32_t scan[24];
 #ifdef BK_PHASE_STAMPS
@@ -574,7 +580,16 @@ __device__ __noinline__ void bk_dp_round()
 {
     BkAsmShared *S = S_;
     const int wv = BK_TID >> 6, nb = S->nb;
-    if (S->dual) {                                       // both DPs of slot wv on this wavefront
+    if (S->dual && nb > BK_WAVES) {                      // more reads than wavefronts (BK_PAIR builds): one score matrix per read, wavefront w takes slots 2w, 2w+1 (bk_nw_pair)
+        const int a = 2 * wv, b = 2 * wv + 1;
+        if (a < nb) {
+            BkPairArgs A, B;
+            A.contig = C_.o_cseq + S->slot[a].pb; A.clen = S->slot[a].plen; A.read = C_.o_rseq + a * (C_.MAXR + 16); A.n = S->slot[a].rl; A.res = (int)((uint8_t *)&S->slot[a].v1 - bk_lds);
+            if (b < nb) { B.contig = C_.o_cseq + S->slot[b].pb; B.clen = S->slot[b].plen; B.read = C_.o_rseq + b * (C_.MAXR + 16); B.n = S->slot[b].rl; B.res = (int)((uint8_t *)&S->slot[b].v1 - bk_lds); }
+            else { B.contig = 0; B.clen = 0; B.read = 0; B.n = 0; B.res = 0; }
+            bk_nw_pair(A, B);
+        }
+    } else if (S->dual) {                                // both DPs of slot wv on this wavefront
         if (wv < nb) bk_nw_dual(C_.o_cseq + S->slot[wv].pb, S->slot[wv].plen, C_.o_rseq + wv * (C_.MAXR + 16), S->slot[wv].rl, (int)((uint8_t *)&S->slot[wv].v1 - bk_lds));
     } else {                                             // two wavefronts per slot, both with the contig on the tile columns
         const int sl = wv >> 1;
@@ -1036,8 +1051,8 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
 #endif
         {   // unpack the reads; pre-write the bytes slot sl is predicted to add.  One wavefront per slot: the global loads
             // of all slots are in flight together (slot after slot they were nb dependent round trips per round)
-            const int sl = BK_TID >> 6, ln = BK_TID & 63;
-            if (sl < nb) {
+            const int ln = BK_TID & 63;
+            for (int sl = BK_TID >> 6; sl < nb; sl += BK_WAVES) {
                 const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
                 const uint32_t *w = C_.reads + (uint64_t)C_.urep[S->slot[sl].u] * C_.read_words;
                 for (int t = ln; t < rl; t += 64) rs[t] = (uint8_t)seq_base(w, t);
@@ -1468,6 +1483,24 @@ extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_
     for (int t = threadIdx.x; t < m; t += 64) s1[t] = codes[off1[b] + t];
     for (int t = threadIdx.x; t < n; t += 64) s2[t] = codes[off2[b] + t];
     __syncthreads();
+    if (transposed >= 5) {                             // bk_nw_pair: half A = pair b, half B = pair b+1 (cyclic); 5 / 6 -> A's nw(seq1, seq2) / nw(seq2, seq1), 7 / 8 -> B's
+        const int b2 = (b + 1) % (int)gridDim.x, m2 = (int)len1[b2], n2 = (int)len2[b2];
+        const int mp = (int)((m + 15) & ~15), np_ = (int)((n + 15) & ~15), mp2 = (int)((m2 + 15) & ~15), np2 = (int)((n2 + 15) & ~15);
+        uint8_t *t1 = l + mp + np_, *t2 = t1 + mp2;
+        int *res = (int *)(l + mp + np_ + mp2 + np2);
+        for (int t = threadIdx.x; t < m2; t += 64) t1[t] = codes[off1[b2] + t];
+        for (int t = threadIdx.x; t < n2; t += 64) t2[t] = codes[off2[b2] + t];
+        BkPairArgs A, B;
+        A.contig = 0; A.clen = m; A.read = mp; A.n = n; A.res = (int)((uint8_t *)res - l);
+        B.contig = mp + np_; B.clen = m2; B.read = mp + np_ + mp2; B.n = n2; B.res = (int)((uint8_t *)(res + 8) - l);
+        __syncthreads();
+        if (m <= BK_NW_DUAL_COLS && m2 <= BK_NW_DUAL_COLS) {
+            for (int i = 0; i < reps; i++) bk_nw_pair(A, B);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[4 * b + q] = res[(transposed - 5) * 4 + q];
+        } else if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[4 * b + q] = -1;
+        return;
+    }
     if (transposed >= 3) {                             // both DPs of check_align on one wavefront: 3 -> nw(seq1, seq2), 4 -> nw(seq2, seq1)
         int *res = bound;
         if (m <= BK_NW_DUAL_COLS) {

@@ -408,6 +408,110 @@ __device__ __noinline__ void bk_nw_dual_c(int contig_off, int clen_, int off1_, 
         else { const int org = w2 & 0xFFFF; res[7] = w2 >> 18; res[5] = i2; if (org & 0x8000) { res[6] = org & 0x7FFF; res[4] = 0; } else { res[4] = org; res[6] = 0; } }
     }
 }
+// ---- ONE score matrix per read, both tie-break orders; TWO reads per wavefront ------------------------------------------
+// nw(read, contig) is nw(contig, read) transposed: the two reference matrices hold the SAME scores, only the pointers differ
+// where candidates tie (olc.py:69-74 in each call's own orientation: with the contig on the columns, nw(contig, read) prefers
+// diagonal > S[i][j-1] > S[i-1][j], nw(read, contig) prefers diagonal > S[i-1][j] > S[i][j-1]).  So a cell is computed once: the
+// word [score | priority | origin] follows the first order as in every sweep of this file, and a second register per cell
+// carries the border cell the traceback of the OTHER order would reach -- of the candidates that reach the cell's score:
+// the diagonal one, else the vertical one, else the horizontal one (two compares against the score, two selects).  End
+// cells: nw(contig, read) the last column (tracked per step), nw(read, contig) the last row (read out of the registers).
+// 12 instructions per cell for both DPs instead of 2 x 7, no column of the contig is swept twice, and with half a wavefront
+// per read (32 lanes, right-aligned columns as in bk_nw_dual_c) a wavefront aligns TWO reads of a round.  For the assembler's
+// throughput mode, where the SIMDs are bound by instruction issue; a round alone finishes sooner with bk_nw_dual_c (one read
+// per wavefront).  par_off: 10 ints in LDS, per half {contig offset, contig length, read offset, read length, result offset}
+// (offsets into the dynamic LDS block; read length 0 = this half is idle); results: v1 then v2 as (j_start, i_end, i_start, score).
+struct BkPairArgs { int contig, clen, read, n, res; };      // one half: offsets into the dynamic LDS block; n = 0: the half is idle
+template <int C>
+__device__ __noinline__ void bk_nw_pair_c(BkPairArgs A_, BkPairArgs B_)
+{
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    // the arguments of an out-of-line function arrive in vector registers: make them wave-uniform again, then every lane takes its half's
+    const int a0 = __builtin_amdgcn_readfirstlane(A_.contig), a1 = __builtin_amdgcn_readfirstlane(A_.clen), a2 = __builtin_amdgcn_readfirstlane(A_.read), a3 = __builtin_amdgcn_readfirstlane(A_.n), a4 = __builtin_amdgcn_readfirstlane(A_.res);
+    const int b0_ = __builtin_amdgcn_readfirstlane(B_.contig), b1 = __builtin_amdgcn_readfirstlane(B_.clen), b2 = __builtin_amdgcn_readfirstlane(B_.read), b3 = __builtin_amdgcn_readfirstlane(B_.n), b4 = __builtin_amdgcn_readfirstlane(B_.res);
+    const uint8_t *cols = bk_dyn_lds + (half ? b0_ : a0), *rows = bk_dyn_lds + (half ? b2 : a2);
+    const int mt = half ? b1 : a1, n = half ? b3 : a3;
+    int *res = (int *)(bk_dyn_lds + (half ? b4 : a4));
+    const int nmax = max(a3, b3);
+    const int nl = (mt + C - 1) / C, lm = nl - 1, pad = nl * C - mt;
+    const int lm_max = max((a1 + C - 1) / C, (b1 + C - 1) / C) - 1;
+    int H[C], O2[C], cb[C], gh[C];
+#pragma unroll
+    for (int x = 0; x < C; x++) {
+        const int jj = hl * C + x - pad;                                            // 0-based column, < 0: padding
+        const bool real = jj >= 0 && jj < mt && hl <= lm;
+        H[x] = real ? (jj + 1) : 0;                                                 // row 0: score 0, origin (first order) = column j; padding: the corner
+        O2[x] = real ? (0x8000 | (jj + 1)) : 0;                                     // the same border cell in the second order's encoding
+        cb[x] = real ? (int)cols[jj] : 8;
+        gh[x] = jj >= 0 ? BK_NW_G2 : 0;
+    }
+    const int c0 = hl * C - pad;
+    int dprev1 = c0 > 0 ? c0 : 0, dprev2 = c0 > 0 ? (0x8000 | c0) : 0;
+    int rb = 0, im1 = -hl;
+    int best_word = 0, best_im1 = -1;
+    const bool inl = hl <= lm && n > 0;
+    const int steps = nmax + lm_max;
+    for (int t0 = 0; t0 < steps; t0 += 32) {
+        const int rblk = (t0 + hl < n) ? (int)rows[t0 + hl] : 0;                     // lanes 0..31: symbols of read A for these 32 steps, lanes 32..63: of read B
+        const int te = min(32, steps - t0);
+        for (int tl = 0; tl < te; tl++) {
+            const int recv1 = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);
+            const int recv2 = __builtin_amdgcn_mov_dpp(O2[C - 1], 0x138, 0xf, 0xf, true);
+            rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
+            { const int ra = __builtin_amdgcn_readlane(rblk, tl), rbb = __builtin_amdgcn_readlane(rblk, 32 + tl); if (hl == 0) rb = half ? rbb : ra; }
+            if (inl && (unsigned)im1 < (unsigned)n) {
+                const int left1 = hl == 0 ? (0x8000 + 1) + im1 : recv1;              // border column (i, 0): score 0, origin 0x8000 | i
+                const int left2 = hl == 0 ? im1 + 1 : recv2;                        // ... = i in the second order's encoding
+                int u_in = left1, o_in = left2, hprev = dprev1, oprev = dprev2;        // this row's left neighbour; the previous row's (x-1) cell
+#pragma unroll
+                for (int x = 0; x < C; x++) {
+                    const int hold = H[x], oold = O2[x];
+                    const int cd = hprev + (cb[x] == rb ? BK_NW_MATCH : BK_NW_MISM);
+                    const int cu = hold + BK_NW_G1;
+                    const int nv = max(max(cd, u_in + gh[x]), cu) & ~BK_NW_PRIO_MASK;
+                    const int nvs = nv & ~0x3FFFF;                                  // the cell's score; a candidate word >= it reaches that score
+                    const int t = cu >= nvs ? oold : o_in;                          // second order: vertical before horizontal ...
+                    const int o2 = cd >= nvs ? oprev : t;                           // ... and the diagonal before both
+                    H[x] = nv; O2[x] = o2; u_in = nv; o_in = o2; hprev = hold; oprev = oold;
+                }
+                dprev1 = left1; dprev2 = left2;
+                const int v = H[C - 1];                                            // lane lm: the last column (olc.py:81 '>=': last row wins)
+                const bool take = v >= (best_word & ~0x3FFFF);
+                best_word = take ? v : best_word; best_im1 = take ? im1 : best_im1;
+            }
+            im1++;
+        }
+    }
+    // nw(contig, read): lane lm of the half
+    const int w1 = __shfl(best_word, (half << 5) + lm), i1 = __shfl(best_im1, (half << 5) + lm) + 1;
+    // nw(read, contig): the last row, columns ascending ('>=' keeps the largest index), reduced over the half
+    int w2 = 0, i2 = 0, o2s = 0;
+#pragma unroll
+    for (int x = 0; x < C; x++) {
+        const int jj = hl * C + x - pad;
+        if (jj >= 0 && jj < mt && inl && (H[x] >> 18) >= (w2 >> 18)) { w2 = H[x]; i2 = jj + 1; o2s = O2[x]; }
+    }
+    for (int o = 1; o < 32; o <<= 1) {
+        const int ow = __shfl_xor(w2, o), oi = __shfl_xor(i2, o), oo = __shfl_xor(o2s, o);
+        const int sc = w2 >> 18, os = ow >> 18;
+        if (os > sc || (os == sc && oi > i2)) { w2 = ow; i2 = oi; o2s = oo; }
+    }
+    if (hl == 0 && n > 0) {
+        if (i1 == 0) { res[0] = mt - 1; res[1] = 0; res[2] = 0; res[3] = 0; }
+        else { const int org = w1 & 0xFFFF; res[3] = w1 >> 18; res[1] = i1; if (org & 0x8000) { res[2] = org & 0x7FFF; res[0] = 0; } else { res[0] = org; res[2] = 0; } }
+        if (i2 == 0) { res[4] = n - 1; res[5] = 0; res[6] = 0; res[7] = 0; }
+        else { const int org = o2s & 0xFFFF; res[7] = w2 >> 18; res[5] = i2; if (org & 0x8000) { res[6] = org & 0x7FFF; res[4] = 0; } else { res[4] = org; res[6] = 0; } }
+    }
+}
+template <int C>
+__device__ inline void bk_nw_pair_call(int c, const BkPairArgs &A, const BkPairArgs &B)
+{
+    if (c <= C) { bk_nw_pair_c<C>(A, B); return; }
+    if constexpr (C < BK_NW_DUAL_C) bk_nw_pair_call<C + 1>(c, A, B);
+}
+// both contigs <= BK_NW_DUAL_COLS; registers per lane = ceil(longer contig / 32)
+__device__ inline void bk_nw_pair(const BkPairArgs &A, const BkPairArgs &B) { bk_nw_pair_call<3>((max(A.clen, B.n ? B.clen : 0) + 31) / 32, A, B); }
+
 // Tried in round 3 and not kept (tools/dp_bench_dual.py history, profiles/r03/valu_rate.txt): the same sweep with two rows per
 // iteration in a column-shifted frame (stored word = H + 2 j, so the left neighbour's word IS the horizontal candidate and the
 // chain along a row is max3 -> v_and_or), laid out cell by cell so that the two rows' chains interleave.  Bit-exact, but no

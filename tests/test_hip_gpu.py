@@ -36,6 +36,10 @@ def test_g1_nw_kats_gpu(hb, golden_dir):
     small = [p for p in pairs if len(p[0]) <= 320]                            # both DPs on one wavefront (contig <= 320 columns)
     o3, o4 = eng.nw_batch(small, transposed=3)[0].tolist(), eng.nw_batch(small, transposed=4)[0].tolist()
     assert o3 == eng.nw_batch(small)[0].tolist() and o4 == eng.nw_batch([(b, a) for a, b in small])[0].tolist()
+    # one score matrix with both tie-break orders, two pairs per wavefront (bk_nw_pair): pair i in half A, pair i+1 in half B
+    rot = lambda x: x[1:] + x[:1]
+    assert eng.nw_batch(small, transposed=5)[0].tolist() == o3 and eng.nw_batch(small, transposed=6)[0].tolist() == o4
+    assert eng.nw_batch(small, transposed=7)[0].tolist() == rot(o3) and eng.nw_batch(small, transposed=8)[0].tolist() == rot(o4)
     for c, o in zip(d["cases"], out.tolist()):
         exp = c["out"]
         assert o == [exp[3], exp[4], exp[5], exp[6]], c["tag"]
@@ -113,12 +117,14 @@ def test_nw_random_vs_oracle_gpu(hb):
             a = "".join(rnd2.choice("ACGT") for _ in range(m))
             ov = min(m, n, rnd2.randint(1, 150))
             dual.append((a, (a[:ov][::-1][::-1] if (m + n) % 3 == 0 else a[m - ov:]) + "".join(rnd2.choice("ACGT") for _ in range(n - ov))))
-    d1, _ = eng.nw_batch(dual, transposed=3)
-    d2, _ = eng.nw_batch(dual, transposed=4)
-    for (a, b), x1, x2 in zip(dual, d1.tolist(), d2.tolist()):
-        e1, e2 = bo.nw(a, b), bo.nw(b, a)
-        assert x1 == [e1[3], e1[4], e1[5], e1[6]], (len(a), len(b), "dual v1")
-        assert x2 == [e2[3], e2[4], e2[5], e2[6]], (len(a), len(b), "dual v2")
+    want = [(bo.nw(a, b), bo.nw(b, a)) for a, b in dual]
+    for mode1, mode2, shift, tag in ((3, 4, 0, "dual"), (5, 6, 0, "pair, half A"), (7, 8, 1, "pair, half B")):
+        d1, _ = eng.nw_batch(dual, transposed=mode1)
+        d2, _ = eng.nw_batch(dual, transposed=mode2)
+        for q, (x1, x2) in enumerate(zip(d1.tolist(), d2.tolist())):
+            (a, b), (e1, e2) = dual[(q + shift) % len(dual)], want[(q + shift) % len(dual)]
+            assert x1 == [e1[3], e1[4], e1[5], e1[6]], (len(a), len(b), "v1", tag)
+            assert x2 == [e2[3], e2[4], e2[5], e2[6]], (len(a), len(b), "v2", tag)
 
 
 def _run_regions(hb, regions, k, rc_thresh=2, stages=3, **limits):

@@ -13,6 +13,7 @@ for (m, n) in ((298, 150), (224, 150), (160, 150), (298, 151)):
         pairs = [(a, b)] * nb
         reps = 146
         out, ms = eng.nw_batch(pairs, reps=reps, transposed=3)
+        out2, ms2 = eng.nw_batch(pairs, reps=reps, transposed=5)          # bk_nw_pair: every wavefront aligns TWO reads (both DPs of each)
         cells = 2 * nb * reps * m * n
-        print("cols %d rows %d wavefronts %5d (%.1f per SIMD): %.3f ms, %.1f us per pair of DPs, %.0f GCUPS (algorithmic cells of both DPs)" % (
-            m, n, nb, nb / 1024.0, ms, ms * 1e3 / reps, cells / ms / 1e6))
+        print("cols %d rows %d wavefronts %5d (%.1f per SIMD): dual %.3f ms, %.1f us per read, %.0f GCUPS | pair %.3f ms, %.1f us per TWO reads, %.0f GCUPS (x%.2f)" % (
+            m, n, nb, nb / 1024.0, ms, ms * 1e3 / reps, cells / ms / 1e6, ms2, ms2 * 1e3 / reps, 2 * cells / ms2 / 1e6, 2 * ms / ms2))
