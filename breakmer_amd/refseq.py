@@ -9,8 +9,13 @@
                          windows.  They are found here from the evidence the reference itself collects while extracting reads
                          (read_d['disc'], sv_processor.py:58-66: pairs whose mate maps to another chromosome or > 1 kb away):
                          the mate positions are clustered and each cluster with enough pairs becomes a window of the genome.
-                         A heuristic stand-in for the genome-wide search -- translocations without discordant pairs are not
-                         found -- NOT pinned against gfServer (absent binary, no genome): DESIGN.md section 8.
+                         A heuristic stand-in for the genome-wide search, NOT pinned against gfServer (absent binary, no
+                         genome): DESIGN.md section 8.
+  * GenomeIndex       -- the genome-wide part of that search for contigs no discordant pair explains (a translocation
+                         supported by split reads only): a sampled k-mer index of the whole FASTA (every `step`-th 16-mer,
+                         sorted; the analogue of gfServer's -stepSize tiles, utils.py:620-657), queried with every k-mer of
+                         the contig segment the target window leaves unaligned; loci with >= 2 hits on one diagonal band (BLAT's
+                         -minMatch=2) become partner windows, and the target is run again with them.
 """
 from __future__ import annotations
 
@@ -78,6 +83,92 @@ class FastaIndex(object):
 
     def close(self):
         self._f.close()
+
+
+class GenomeIndex(object):
+    """Sampled k-mer index of a FastaIndex: the k-mers (k <= 16, 2 bit/base in a uint32) starting at every `step`-th base of
+    every sequence, N-free, sorted by code with (sequence number, position).  Built once per run, on first use (a 3 Gb genome
+    at step 8: ~375 M entries, ~3.4 GB, about a minute of numpy); tests use kilobase genomes."""
+
+    def __init__(self, fasta, k=16, step=8, max_occ=64):
+        import numpy as np
+        self.k, self.step, self.max_occ, self.fasta = int(k), int(step), int(max_occ), fasta
+        self.names = list(fasta.index.keys())
+        codes, seqno, pos = [], [], []
+        lut = np.full(256, 4, dtype=np.uint8)
+        for i, ch in enumerate(b"ACGT"):
+            lut[ch] = i
+            lut[ch + 32] = i                              # lower case (soft-masked genomes)
+        for si, name in enumerate(self.names):
+            length = fasta.index[name][0]
+            CH = 1 << 24                                  # chunks of 16 Mb (+ k - 1 bases of overlap)
+            for c0 in range(0, length, CH):
+                s_ = fasta.fetch(name, c0, min(length, c0 + CH + self.k - 1), upper=False)
+                b = lut[np.frombuffer(s_.encode(), dtype=np.uint8)]
+                n = len(b) - self.k + 1
+                if n <= 0:
+                    continue
+                first = (-c0) % self.step                 # positions that are multiples of `step` in sequence coordinates
+                starts = np.arange(first, n, self.step, dtype=np.int64)
+                if not len(starts):
+                    continue
+                code = np.zeros(len(starts), dtype=np.uint32)
+                bad = np.zeros(len(starts), dtype=bool)
+                for t in range(self.k):
+                    col = b[starts + t]
+                    bad |= col > 3
+                    code = (code << np.uint32(2)) | (col & 3).astype(np.uint32)
+                keep = ~bad
+                codes.append(code[keep]); seqno.append(np.full(int(keep.sum()), si, dtype=np.uint16)); pos.append((starts[keep] + c0).astype(np.uint32))
+        if codes:
+            code = np.concatenate(codes); order = np.argsort(code, kind="stable")
+            self.code, self.seqno, self.pos = code[order], np.concatenate(seqno)[order], np.concatenate(pos)[order]
+        else:
+            self.code = np.zeros(0, dtype=np.uint32); self.seqno = np.zeros(0, dtype=np.uint16); self.pos = np.zeros(0, dtype=np.uint32)
+
+    def _codes(self, seq):
+        import numpy as np
+        lut = np.full(256, 4, dtype=np.uint8)
+        for i, ch in enumerate(b"ACGT"):
+            lut[ch] = i
+        b = lut[np.frombuffer(seq.encode(), dtype=np.uint8)]
+        n = len(b) - self.k + 1
+        if n <= 0:
+            return np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=bool)
+        code = np.zeros(n, dtype=np.uint32); bad = np.zeros(n, dtype=bool)
+        for t in range(self.k):
+            col = b[t:t + n]
+            bad |= col > 3
+            code = (code << np.uint32(2)) | (col & 3).astype(np.uint32)
+        return code, ~bad
+
+    def find(self, seq, min_hits=2, band=32):
+        """loci of `seq` in the genome: [(hits, sequence name, strand, start, end)], best first; a locus = index hits of one
+        strand on diagonals within `band` of each other, `min_hits` or more (k-mers that occur more than max_occ times in
+        the index are repeats and do not count)"""
+        import numpy as np
+        out = []
+        for strand, q in (("+", seq), ("-", revcomp(seq))):
+            code, ok = self._codes(q)
+            if not len(code):
+                continue
+            lo = np.searchsorted(self.code, code, side="left"); hi = np.searchsorted(self.code, code, side="right")
+            hits = []
+            for qp in np.nonzero(ok & (hi > lo) & (hi - lo <= self.max_occ))[0]:
+                for e in range(int(lo[qp]), int(hi[qp])):
+                    hits.append((int(self.seqno[e]), int(self.pos[e]) - int(qp), int(self.pos[e])))
+            hits.sort()
+            i = 0
+            while i < len(hits):
+                j = i
+                while j + 1 < len(hits) and hits[j + 1][0] == hits[i][0] and hits[j + 1][1] - hits[j][1] <= band:
+                    j += 1
+                if j - i + 1 >= min_hits:
+                    ps = [h[2] for h in hits[i:j + 1]]
+                    out.append((j - i + 1, self.names[hits[i][0]], strand, min(ps), max(ps) + self.k))
+                i = j + 1
+        out.sort(key=lambda x: (-x[0], x[1], x[3]))
+        return out
 
 
 def revcomp(seq):

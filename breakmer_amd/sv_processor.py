@@ -236,6 +236,17 @@ class params(object):                                               # utils.py:5
             self._fasta = refseq.FastaIndex(fn)
         return self._fasta
 
+    def genome_index(self):
+        """sampled k-mer index of the whole `reference_fasta` (refseq.GenomeIndex), built on first use: the genome-wide part of
+        the realignment (N4) for contigs that neither the target window nor a discordant pair explains"""
+        if getattr(self, '_gindex', None) is None:
+            fa = self.open_fasta()
+            if fa is None:
+                return None
+            self.logger.info('indexing %s for the genome-wide realignment of unexplained contigs' % self.opts.get('reference_fasta'))
+            self._gindex = refseq.GenomeIndex(fa)
+        return self._gindex
+
     def open_bam(self, fn):                                          # one parse per alignment file, shared by all targets
         if fn not in self._bams:
             # only the records the targets can use are kept: their [start-200, end+200) windows (sv_processor.py:431) and the mates
@@ -497,6 +508,8 @@ class target(object):                                               # sv_process
             pass
         return max(1, (int(self.end) - int(self.start)) // 100)
 
+    genome_searched = False
+
     def unsupported_reference(self):
         """None, or why this target cannot go to the device: its window (or a partner window) holds a character other than
         A/C/G/T -- an N of an assembly gap within 200 bp of the target.  The reference has no such limit (Jellyfish skips
@@ -647,6 +660,7 @@ class runner(object):                                               # sv_process
         self._pooled = []                       # handles to give back to hip_backend's pool when the run is over
         self.native_calls = native_calls        # SV-call tail in C++ (bk_call) instead of breakmer_amd/sv_caller.py; same rows
         self.engine = None
+        self._retry = []                        # targets to run again with partner windows from the genome-wide search
         self.failed_targets = {}                # name -> why the target has no result although it had reads (a device cap, an N in
                                                 # its window): logged as errors, listed at the end of the run, exit code 3 of breakmer.py
 
@@ -716,6 +730,16 @@ class runner(object):                                               # sv_process
                 continue
             t.compare_kmers()
             t.resolve_sv()
+            if not t.has_results() and not t.genome_searched and self._wants_genome_search(t):
+                wins = self._genome_partners(eng, t)
+                t.genome_searched = True
+                if wins:                                              # run the target again, its contigs realigned against these windows too
+                    self.logger.info('target %s: %d partner window(s) from the genome-wide search: %s' % (t.name, len(wins), ", ".join("%s:%d-%d" % (w[0], w[1], w[2]) for w in wins)))
+                    t.data.partners = list(t.data.partners) + wins
+                    t.partner_windows = t.data.partners
+                    t.native_rows = None; t.results = []; t.kmers['clusters'] = []
+                    self._retry.append(t)
+                    continue
             self.summary_header, self.summary[t.name] = t.get_summary()
             if t.has_results():
                 if 'output' in t.paths:
@@ -724,6 +748,61 @@ class runner(object):                                               # sv_process
             else:
                 t.rm_output_dir()
             t.release()
+
+    def _wants_genome_search(self, t):
+        """the reference hands every contig its target window does not explain to the whole-genome gfServer
+        (sv_processor.py:829-831); here that costs an index of the genome, so it is done for targets that came out WITHOUT a
+        call and have contigs, when a `reference_fasta` is configured (`genome_search` = False switches it off)"""
+        if str(self.params.opts.get('genome_search', True)).lower() in ('false', '0', 'no') or self.params.open_fasta() is None or t.data is None:      # config files hold strings
+            return False
+        try:
+            return len(t.kmers.get('clusters') or []) > 0 and len(t.data.partners) < 8
+        except TypeError:
+            return False
+
+    def _genome_partners(self, eng, t):
+        """partner windows for the contig segments of target t that no record covers (>= trl_minseg_len bases): every k-mer of
+        such a segment is looked up in the genome index; loci with >= 2 index hits in one diagonal band, outside the target's
+        own window, become windows of +-1,500 bases (at most 4, best supported first)"""
+        gi = self.params.genome_index()
+        if gi is None or not hasattr(eng, 'hits'):
+            return []
+        minseg = max(20, self.params.get_min_segment_length('trl'))
+        loci = {}
+        for ci, c in enumerate(eng.contigs(t.region_index)):
+            seq = c["seq"]
+            cov = bytearray(len(seq))
+            for h in eng.hits(t.region_index, ci):
+                for x in range(h["q_start"], h["q_end"]):
+                    cov[x] = 1
+            a = 0
+            while a < len(seq):
+                if cov[a]:
+                    a += 1
+                    continue
+                b = a
+                while b < len(seq) and not cov[b]:
+                    b += 1
+                if b - a >= minseg:
+                    for nh, name, _strand, s0, e0 in gi.find(seq[a:b])[:4]:
+                        c_ = name.replace("chr", "")
+                        if c_ == str(t.chrom).replace("chr", "") and e0 >= t.start - 200 and s0 <= t.end + 200:
+                            continue
+                        key = (c_, s0 // 1000)
+                        if key not in loci or loci[key][0] < nh:
+                            loci[key] = (nh, c_, s0, e0)
+                a = b
+        fa = self.params.open_fasta()
+        out = []
+        for nh, c_, s0, e0 in sorted(loci.values(), key=lambda x: (-x[0], x[1], x[2]))[:4]:
+            s1, e1 = max(0, s0 - 1500), min(fa.length(c_), e0 + 1500)
+            wseq = fa.fetch(c_, s1, e1)
+            if len(wseq) < 64 or wseq.strip("ACGT"):
+                self.logger.warning('target %s: genome window %s:%d-%d holds characters other than A/C/G/T and is not realigned against' % (t.name, c_, s1, e1))
+                continue
+            name = self.params.gene_annotations.set_gene(c_, [(s0 + e0) // 2])
+            out.append((c_, s1, e1, name, wseq))
+        return out
 
     def _make_engine(self):
         if self.engine_factory:
@@ -799,7 +878,16 @@ class runner(object):                                               # sv_process
             while pending:
                 advance()
             if running:
-                self._finish_batch(running[0][0], running[0][1], order)
+                done = running.pop()
+                self._finish_batch(done[0], done[1], order)
+                free.append(done[0])
+            while self._retry:                                        # second pass (N4): targets with partner windows from the genome-wide search
+                again, self._retry = self._retry[:bsz], self._retry[bsz:]
+                eng = free.pop() if free else self._make_engine()
+                self.engine = eng
+                self._start_batch(eng, again)
+                self._finish_batch(eng, again, order)
+                free.append(eng)
             ok = True
         except Exception as ex:                                        # with several ranks the others must hear of it (below) before this one stops
             if self.world <= 1 or self.status_exchange is None:

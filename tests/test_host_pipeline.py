@@ -327,6 +327,52 @@ def test_translocation_partner_discovery_from_files(tmp_path):
     check_trl_run(run, rows, r, tmp_path)
 
 
+def test_translocation_without_discordant_pairs_genome_search(tmp_path):
+    """N4, the genome-wide part: the same translocation, but every pair of the alignment file that has its ends on two
+    chromosomes is removed -- only the split (soft-clipped) reads speak of it, so no partner window comes from discordant
+    pairs and the first pass leaves the partner half of the contig unaligned.  The driver then looks that segment up in a
+    sampled k-mer index of the whole genome FASTA (refseq.GenomeIndex; the reference asks a whole-genome gfServer,
+    sv_processor.py:829-831), finds the locus on chr2, runs the target again with that window, and the contig is explained:
+    one record on the target, one on chr2 at the planted breakpoint.  (Whether the reference's filter_trl then REPORTS a
+    translocation with zero discordant pairs is its own matter, sv_caller.py:383-422; `genome_search = False` switches the
+    second pass off.)"""
+    cfg, r = make_trl_inputs(tmp_path)
+    sam = (tmp_path / "sample.sam").read_text().splitlines()
+    kept = [ln for ln in sam if ln.startswith("@") or ln.split("\t")[6] == "="]
+    assert 0 < len(kept) < len(sam)
+    (tmp_path / "sample.sam").write_text("\n".join(kept) + "\n")
+    seen = []
+
+    class Spy(FakeEngine):
+        def run(self, stages=7, sync=True):
+            FakeEngine.run(self, stages, sync)
+            seen.append([(len(reg[4]), [[(h["t_index"], h["q_start"], h["q_end"], h["t_start"], h["t_end"]) for h in hs] for hs in out[4]])
+                         for reg, out in zip(self.regions, self.out)])
+    run = sp.runner(cfg, engine_factory=lambda prm: Spy(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+    run.run()
+    t = run.targets[r.name.upper()]
+    assert len(seen) == 2                                             # first pass without, second pass with the partner window
+    assert seen[0][0][0] == 0 and seen[1][0][0] == 1
+    assert len(t.partner_windows) == 1
+    pc, ps, pe, pn, pseq = t.partner_windows[0]
+    assert pc == "2" and pn == "PARTNERX" and ps < 5000 + 600 < pe
+    first = [h for hs in seen[0][0][1] for h in hs]
+    second = [h for hs in seen[1][0][1] for h in hs]
+    assert all(h[0] == 0 for h in first)
+    on_partner = [h for h in second if h[0] == 1]
+    assert on_partner and any(abs((ps + h[3]) - (5000 + 600)) <= 12 for h in on_partner), second      # the partner half starts at the planted breakpoint
+    # switched off: one pass, no partner window
+    d2 = tmp_path / "off"
+    d2.mkdir()
+    cfg2, r2 = make_trl_inputs(d2)
+    (d2 / "sample.sam").write_text("\n".join(kept) + "\n")
+    cfg2["genome_search"] = False
+    seen.clear()
+    run2 = sp.runner(cfg2, engine_factory=lambda prm: Spy(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+    run2.run()
+    assert len(seen) == 1 and not run2.targets[r2.name.upper()].partner_windows
+
+
 def test_lazy_views_of_engine_records():
     """hip_backend.KmerStrings / sv_assembly._KmerTuples / LazyContigs behave like the lists they stand for (the driver
     builds per-target objects only when something looks at them)."""
