@@ -148,6 +148,21 @@ def time_other_config(hb, regions, k, opts, reps, device):
     return out
 
 
+def reference_python_timing():
+    """the reference's OWN Python hot path timed on this workload -- in the build container, where the reference is (it cannot
+    travel to the GPU box in any form): the committed result of tools/time_reference.py, quoted with its source"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "reference_python_timing.json")))
+    if not fs:
+        return None
+    try:
+        d = json.load(open(fs[-1]))
+        return {"value": d["regions_per_s"], "unit": "regions/s", "cores": 1, "regions": d["regions"], "seconds": d["seconds"], "where": d["where"],
+                "what": d["what"], "source": os.path.relpath(fs[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def usable_cores():
     """cores this process may really use: the affinity mask, capped by the container's CPU quota (cgroup cpu.max)"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -531,7 +546,7 @@ def main():
                                    "sample": "oracle/bk_oracle.c (T1+K1/K2+init_assembly+realign): %d regions of the same batch on 1 core; %s"
                                              % (ns, ("%d regions over %d worker processes (all host cores)" % (allc["regions"], cores)) if allc else "single-core host"),
                                    "parity_on_sample": bool(ok),
-                                   "context": "the reference's own Python path (lib2to3 translation, build container) runs 0.13-0.2 regions/s on one core"}
+                                   "reference_python": reference_python_timing()}
     else:
         out = None
     if dist:

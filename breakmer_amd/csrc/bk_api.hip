@@ -751,6 +751,19 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
 {
     std::string rc(Q, 'N');
     for (int i = 0; i < Q; i++) { char c = contig[Q - 1 - i]; rc[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+    // ---- step 2b: BLAT's published seeding rule (sv_processor.py:843: -stepSize=10 -minMatch=2, tile 11): a hit is kept only if it
+    // holds two index tiles (target positions 10 j .. 10 j + 10 inside it, all eleven bases matching)
+    auto seedable = [&](const BkHit &e) {
+        const char *q = e.strand == 0 ? contig : rc.c_str(); const std::string &t = targets[e.tidx];
+        int tiles = 0;
+        for (int j = (e.ts + 9) / 10 * 10; j + 11 <= e.te; j += 10) {
+            bool ok = true;
+            for (int z = 0; z < 11 && ok; z++) { const char a = q[e.qs + (j - e.ts) + z]; ok = a == t[j + z] && a != 'N'; }
+            tiles += ok;
+        }
+        return tiles >= 2; };
+    hits.erase(std::remove_if(hits.begin(), hits.end(), [&](const BkHit &e) { return !seedable(e); }), hits.end());
+    sec.erase(std::remove_if(sec.begin(), sec.end(), [&](const BkHit &e) { return !seedable(e); }), sec.end());
     std::stable_sort(hits.begin(), hits.end(), [](const BkHit &a, const BkHit &b) { return a.fq < b.fq; });
     const int nh = (int)hits.size();
     auto sec_less = [](const BkHit &a, const BkHit &b) {
@@ -814,20 +827,23 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
             sec.swap(keep); std::sort(sec.begin(), sec.end(), sec_less);
         }
     }
-    int nrec = 0, i = 0; bool overflow = false;
-    while (i < nh) {
-        std::vector<BkHit> chain; chain.push_back(hits[i]);           // strand order
-        int j = i + 1;
-        while (j < nh) {
+    // a chain takes every later free hit that is collinear with it; one that is not is passed over and gets a record of its own
+    int nrec = 0; bool overflow = false;
+    std::vector<char> taken(nh, 0);
+    for (int i = 0; i < nh; i++) {
+        if (taken[i]) continue;
+        std::vector<BkHit> chain; chain.push_back(hits[i]); taken[i] = 1;           // strand order
+        for (int j = i + 1; j < nh; j++) {
+            if (taken[j]) continue;
             BkHit h = hits[j];
-            if (h.tidx != chain.front().tidx || h.strand != chain.front().strand) break;
+            if (h.tidx != chain.front().tidx || h.strand != chain.front().strand) continue;
             BkHit *first = h.strand == 0 ? &chain.back() : &h, *second = h.strand == 0 ? &h : &chain.front();
             const int ov = first->te - second->ts;
-            if (ov > 0 && (2 * ov >= first->qe - first->qs || 2 * ov >= second->qe - second->qs)) break;
-            if (second->qs < first->qe) break;
+            if (ov > 0 && (2 * ov >= first->qe - first->qs || 2 * ov >= second->qe - second->qs)) continue;
+            if (second->qs < first->qe) continue;
             if (ov > 0) { second->qs += ov; second->ts += ov; }         // trim micro-homology from the later hit
             if (h.strand == 0) chain.push_back(h); else chain.insert(chain.begin(), h);
-            j++;
+            taken[j] = 1;
         }
         if (nrec < cap) {
             bk_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
@@ -859,7 +875,6 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
             r->block_count = nb;
         }
         nrec++;
-        i = j;
     }
     for (const BkHit &e : sec) {
         if (nrec < cap) {

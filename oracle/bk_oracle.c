@@ -774,6 +774,24 @@ static void fill_gap(const char *q, const char *t, const fblk *L, const fblk *R,
     fill_gap(q, t, &nb, R, nb.qe, qhi, nb.te, thi, v, n, cap);
 }
 
+/* BLAT's published seeding rule for the command line the reference uses (sv_processor.py:843: -stepSize=10 -minMatch=2, tile size
+ * 11 by default): the target is indexed by the 11-mers that start at every 10th base of it, and an alignment is only ever looked
+ * for where TWO of those tiles match the query exactly on one diagonal.  A gap-free segment is seedable iff it holds two such
+ * tiles: target positions 10 j .. 10 j + 10 inside the segment, all eleven bases matching. */
+#define SEED_TILE 11
+#define SEED_STEP 10
+#define SEED_MIN 2
+static int sw_seedable(const char *q, const char *t, int qs, int ts, int len)
+{
+    int tiles = 0;
+    for (int j = (ts + SEED_STEP - 1) / SEED_STEP * SEED_STEP; j + SEED_TILE <= ts + len; j += SEED_STEP) {
+        int ok = 1;
+        for (int z = 0; z < SEED_TILE && ok; z++) ok = SW_EQ(q[qs + (j - ts) + z], t[j + z]);
+        tiles += ok;
+    }
+    return tiles >= SEED_MIN;
+}
+
 int bko_realign(const char *contig, int Q, const char *const *targets, const int *tlens, int ntargets,
                 int min_score, int min_seg, bko_psl *out, int cap)
 {
@@ -842,6 +860,11 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
         }
         g_sw_cells += (uint64_t)Q * (uint64_t)m;
     }
+    /* ---- step 2b (bk_oracle.h): only what BLAT could have seeded.  Step-1 hits and secondary alignments without two matching
+     * index tiles are dropped (the query bases of a dropped step-1 hit stay unaligned; island fill may still recover them
+     * next to a chained anchor, as BLAT's extension does). */
+    { int w = 0; for (int x = 0; x < nh; x++) if (sw_seedable(hits[x].strand == 0 ? contig : rc, targets[hits[x].tidx], hits[x].qs, hits[x].ts, hits[x].qe - hits[x].qs)) hits[w++] = hits[x]; nh = w; }
+    { int w = 0; for (int x = 0; x < nsec; x++) if (sw_seedable(sec[x].strand == 0 ? contig : rc, targets[sec[x].tidx], sec[x].qs, sec[x].ts, sec[x].qe - sec[x].qs)) sec[w++] = sec[x]; nsec = w; }
     qsort(sec, (size_t)nsec, sizeof(swsec), cmp_sec);
     qsort(hits, (size_t)nh, sizeof(swhit), cmp_hit_fq);
     /* ---- step 6 (bk_oracle.h): placement of ambiguous hits.  When a step-1 hit has equal alternatives -- a secondary
@@ -911,24 +934,30 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
         free(cd); free(ncd); free(cost); free(back); free(gone); free(demoted);
     }
     /* chain + emit: hits consecutive in forward query order, same target and strand, collinear on the strand */
-    int nrec = 0, i = 0, overflow = 0;
-    while (i < nh) {
+    /* A chain starts at the first hit not yet in a record and takes, going on in forward query order, every later free hit that
+     * is collinear with it; a hit that is not (another target or strand, out of order on the target) is passed over and left for
+     * a record of its own -- as BLAT's chaining does: a stretch copied from elsewhere in the middle of a contig does not
+     * split the alignment of its two flanks. */
+    int nrec = 0, overflow = 0;
+    unsigned char taken[SW_MAXHITS]; memset(taken, 0, sizeof(taken));
+    for (int i = 0; i < nh; i++) {
+        if (taken[i]) continue;
         swhit chain[2 * SW_MAXHITS + 1]; int head = SW_MAXHITS, tail = SW_MAXHITS;     /* deque [head, tail) in strand order */
-        chain[tail++] = hits[i];
-        int j = i + 1;
-        while (j < nh) {
+        chain[tail++] = hits[i]; taken[i] = 1;
+        for (int j = i + 1; j < nh; j++) {
+            if (taken[j]) continue;
             swhit h = hits[j];
-            if (h.tidx != chain[head].tidx || h.strand != chain[head].strand) break;
+            if (h.tidx != chain[head].tidx || h.strand != chain[head].strand) continue;
             /* '+': forward order == strand order; '-': the forward-later hit comes first on the strand */
             swhit *first = h.strand == 0 ? &chain[tail - 1] : &h, *second = h.strand == 0 ? &h : &chain[head];
             int ov = first->te - second->ts;
             if (ov > 0) {                                                 /* small target overlap (micro-homology): trim the later hit */
-                if (2 * ov >= first->qe - first->qs || 2 * ov >= second->qe - second->qs || second->bs[0] <= ov) break;
+                if (2 * ov >= first->qe - first->qs || 2 * ov >= second->qe - second->qs || second->bs[0] <= ov) continue;
             }
-            if (second->qs < first->qe) break;
+            if (second->qs < first->qe) continue;
             if (ov > 0) { second->bs[0] -= ov; second->bq[0] += ov; second->bt[0] += ov; second->qs += ov; second->ts += ov; }
             if (h.strand == 0) chain[tail++] = h; else chain[--head] = h;
-            j++;
+            taken[j] = 1;
         }
         if (nrec < cap) {
             bko_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
@@ -965,7 +994,6 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
             r->block_count = nb;
         }
         nrec++;
-        i = j;
     }
     for (int x = 0; x < nsec; x++, nrec++) {
         if (nrec >= cap) continue;

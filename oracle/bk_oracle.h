@@ -71,9 +71,15 @@ void bko_asm_free(bko_asm *a);
  *      best hit by (score desc, target index asc, '+' first); accepted iff score >= min_score;
  *      end cell = max score, then smallest query end, then smallest target end;
  *   2. every hit is one ungapped block (as BLAT's blocks are); gaps arise only from chaining;
+ *   2b. BLAT's published seeding rule (sv_processor.py:843: -stepSize=10 -minMatch=2, tile 11): a step-1 hit or a secondary
+ *      alignment (step 5) is kept only if it holds TWO index tiles -- target positions 10 j .. 10 j + 10 inside it, all eleven
+ *      bases matching the query; the query bases of a dropped step-1 hit stay unaligned (island fill, step 4, may still recover
+ *      them next to a chained anchor, as BLAT's extension does).  Without it a 20-29 base stretch copied from elsewhere (a
+ *      templated insertion) became a record of its own and split an indel contig into a "rearrangement";
  *   3. hits ordered by query position are chained into one PSL record when they are on the same
  *      target and strand and collinear (a target overlap smaller than half of either hit is trimmed
- *      from the later hit);
+ *      from the later hit); a chain passes over a hit that is not collinear with it (that hit gets a record of its own), as
+ *      BLAT's chaining does;
  *   4. island fill: the unaligned rectangle between two chained blocks (query AND target bases left over: an indel next
  *      to another difference, whose short flank cannot anchor a segment of its own) and the rectangles beyond the first
  *      and the last block are searched for the best gap-free segment on a diagonal within 16 of a neighbouring block's

@@ -695,6 +695,35 @@ def g8m():
             truth.append(block_rec(cs, [Wd], [(jq, W - 20 - L, n2)], '+', 0) if not fd & 4 else block_rec(cs, [Wd], [(0, W - 20 - n2, n2)], '-', 0))
         run(tag, r, cdicts[0], cobjs[0], [Wd], [(r.chrom, r.start - 200)], truth, {r.name: ['chr' + r.chrom, r.start, r.end]}, r.disc_reads)
 
+    # ---- a deletion with a TEMPLATED insertion at the junction: 25 bases copied from elsewhere in the window.  BLAT indexes the
+    # window by the 11-mers at every 10th base and needs two of them to match on a diagonal (sv_processor.py:843 -stepSize=10
+    # -minMatch=2): copied from a position 5 past a tile start the stretch holds ONE tile and BLAT never sees it (one record:
+    # flank, 25 inserted bases, 200 deleted, flank); copied from a tile start it holds two, and BLAT prints it as a second line.
+    for tag, src in (("del_templated_insert_unseedable", 105), ("del_templated_insert_seedable", 100)):
+        r = synth.make_region(3, sv_type="del", depth=60, W=W)
+        reads = r.read_strs()
+        mers = rh.ref_kmer_select(reads, [r.window_str], 31)
+        cdicts, cobjs = rh.ref_init_assembly(r.read_ids, reads, mers, 31, 2, r.indel_only)
+        cs0, Wd = cdicts[0]["seq"], r.window_str
+        c, h = W // 2, 100
+        jq = cs0.find(Wd[c + h:c + h + 40])
+        # a copy whose ends do not happen to continue either flank (a chance match there would move the block borders by a base in
+        # any aligner, BLAT included, and the hand-written records below do not model that)
+        while Wd[src] == Wd[c - h] or Wd[src + 24] == Wd[c + h - 1] or Wd[src - 1] == cs0[jq - 1] or Wd[src + 25] == cs0[jq]:
+            src += 10
+        ins = Wd[src:src + 25]
+        co = copy.deepcopy(cobjs[0])
+        cs = cs0[:jq] + ins + cs0[jq:]
+        io, ot, kl = list(co.aseq.counts.indel_only), list(co.aseq.counts.others), list(co.kmer_locs)
+        io[jq:jq] = [io[jq]] * 25; ot[jq:jq] = [ot[jq]] * 25; kl[jq:jq] = [kl[jq]] * 25
+        co.aseq.seq = cs
+        co.aseq.counts.indel_only, co.aseq.counts.others, co.kmer_locs = io, ot, kl
+        cd = {"seq": cs, "indel_only": io, "others": ot, "kmer_locs": kl, "kmers": cdicts[0]["kmers"], "reads": cdicts[0]["reads"]}
+        truth = [block_rec(cs, [Wd], [(0, c - h - jq, jq), (jq + 25, c + h, len(cs0) - jq)], '+', 0)]
+        if src % 10 == 0:
+            truth.append(block_rec(cs, [Wd], [(jq, src, 25)], '+', 0))
+        run(tag, r, cd, co, [Wd], [(r.chrom, r.start - 200)], truth, {r.name: ['chr' + r.chrom, r.start, r.end]}, r.disc_reads)
+
     # ---- translocation whose partner half is a repeat (check_uniqueness, sv_caller.py:430-432; the mean_cov of the row) -----
     for tag, copies, with_disc in (("trl_unique_nodisc", 0, False), ("trl_partner_repeat_nodisc", 5, False), ("trl_partner_repeat_disc", 5, True),
                                    ("trl_partner_repeat4_nodisc", 3, False)):
