@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (testing)")
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
     ap.add_argument("--cfg3-regions", type=int, default=4096, help="batch size of the configs[3] side measurement (heavy regions: the chip fills at a few thousand)")
-    ap.add_argument("--cfg4-regions", type=int, default=512, help="batch size of the configs[4] side measurement: a region's chain of ~19,000 dependent rounds takes ~3 s whatever runs beside it, so regions in flight ARE the throughput (256: 69 regions/s, 512: 101) until the scratch arena (~350 MB per region) fills the HBM (640 no longer fit)")
+    ap.add_argument("--cfg4-regions", type=int, default=768, help="batch size of the configs[4] side measurement: a region's chain of ~19,000 dependent rounds takes ~3 s whatever runs beside it, so regions in flight ARE the throughput (256: 69 regions/s, 512: 101, 768: 121) until the scratch arena (~270 MB per region) fills the HBM (896 no longer fit)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic library flags (bk_config.reserved[0]); 0 in every reported number")
     ap.add_argument("--lib", default=None, help="diagnostic: path of an alternative build of the library (A/B runs on one box)")
     ap.add_argument("--dump-collated", default=None, help="write the bytes collated in the last step to this file (testing)")

@@ -461,7 +461,7 @@ static int launch(bk_handle *h, uint32_t mask)
     HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     // workgroup sizes: latency mode (one batch at a time) or throughput mode (batches in flight / a batch that fills the chip)
-    const int asm_threads = h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions >= 4 * h->n_cu ? 256 : 512);
+    const int asm_threads = h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions > 2 * h->n_cu ? 256 : 512);      // more regions than 512-thread workgroups can be resident at once (2 per CU): the smaller ones keep them all in flight
     const int kmer_threads = asm_threads == 512 ? BK_KT_MAX : BK_KT;
     if (mask & BK_STAGE_KMER) {
         if (h->n_big < h->n_regions) {

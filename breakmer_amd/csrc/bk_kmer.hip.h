@@ -582,7 +582,10 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     }
     __syncthreads();
     const uint32_t T = scr[24];
-    uint32_t tcap = 256; while (tcap < 2 * T) tcap <<= 1;
+    // sized by the OCCURRENCES (their number is all that is known here), of which the distinct k-mers are a part (3/4 at 5 % noise):
+    // 1.5 T slots keep the load below 2/3 even if every occurrence were distinct; a power of two >= 2 T (round 2) doubled the
+    // largest array of a noisy region (configs[4]: 134 MB of its ~340 MB) for nothing
+    uint32_t tcap = 256; while (tcap < T + T / 2) tcap <<= 1;
     // The table is filled in LDS when it fits and the reference set is no longer needed (no separate soft-clip set to
     // scan): one CAS and one add per occurrence are device-scope atomics otherwise, each 64 B of write traffic.  In LDS
     // it also STAYS there: it is sized by the occurrences (their number is all that is known up front) but holds M
