@@ -71,7 +71,7 @@ struct bk_handle {
     // device
     DevBuf d_desc, d_work, d_part, d_reads, d_rlen, d_rflag, d_sc, d_sclen, d_win;
     DevBuf d_ddslot, d_ddrep, d_ddcnt, d_grp, d_urep, d_unr, d_ufl, d_ubuf, d_ureads, d_ufound, d_uminpos;
-    DevBuf d_arena, d_out, d_tops, d_order, d_skeys, d_clist, d_nlist;
+    DevBuf d_arena, d_out, d_tops, d_order, d_skeys, d_clist, d_nlist, d_wnlist;
     int n_cu = 256, asm_wg_per_cu = 0, sw_wg_per_cu = 0, asm_threads = 512;
     uint64_t arena_cap = 0, out_cap = 0;
     uint32_t ref_cap = 0, win_words_cap = 0;
@@ -147,7 +147,7 @@ extern "C" int bk_destroy(bk_handle *h)
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
-                      &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist, &h->d_nlist};
+                      &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist, &h->d_nlist, &h->d_wnlist};
     for (auto b : bufs) b->release();
     h->h_out.release(); h->hs_reads.release(); h->hs_rlen.release(); h->hs_rflag.release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -263,7 +263,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     // a failed submit leaves the handle without a batch (never the old device results paired with new host mirrors):
     // the new host mirrors are built in locals and swapped in on success only
     h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->hold_snapshot = false; h->have_ctx = false; h->host_status.clear();
-    std::vector<uint32_t> sc, win; std::vector<uint16_t> sclen;
+    std::vector<uint32_t> sc, win, wnlist; std::vector<uint16_t> sclen;
     std::vector<BkRegionDesc> n_desc(n_regions, BkRegionDesc{}); std::vector<BkPartnerDesc> n_part; std::vector<std::vector<std::string>> n_targets(n_regions);
     uint32_t n_max_win = 0; uint64_t n_alg_bytes = 0;
     uint64_t dd_total = 0; uint32_t max_w = 0;
@@ -324,16 +324,23 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
             }
         }
         d.win_len = g.window_len; d.win_word_off = win.size();
-        { size_t nw = (g.window_len + 15) / 16 + 2; win.resize(win.size() + nw); if (!pack_seq(g.window, g.window_len, win.data() + d.win_word_off, (int)nw)) return fail(h, BK_E_ARG, "bk_submit_regions: non-ACGT base in reference window"); }
+        {   // an N of the window (an assembly gap near the target) is packed as code 0 and listed: its k-mers do not exist, it matches nothing
+            size_t nw = (g.window_len + 15) / 16 + 2; win.resize(win.size() + nw);
+            std::vector<uint32_t> wn;
+            if (!pack_seq(g.window, g.window_len, win.data() + d.win_word_off, (int)nw, &wn, 0)) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": character other than A/C/G/T/N in the reference window");
+            d.win_n_off = wnlist.size(); d.n_win_n = (uint32_t)wn.size(); wnlist.insert(wnlist.end(), wn.begin(), wn.end());
+        }
         max_w = std::max<uint32_t>(max_w, g.window_len);
         n_max_win = std::max<uint32_t>(n_max_win, g.window_len);
         n_targets[r].emplace_back(g.window, g.window_len);
         if (g.n_partners > 15) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 15 partner windows");
         d.n_partners = g.n_partners; d.part_desc_off = n_part.size();
         for (int q = 0; q < g.n_partners; q++) {
-            BkPartnerDesc pd; pd.word_off = win.size(); pd.len = g.partner_lens[q]; pd.pad = 0;
+            BkPartnerDesc pd; pd.word_off = win.size(); pd.len = g.partner_lens[q];
             size_t nw = (pd.len + 15) / 16 + 2; win.resize(win.size() + nw);
-            if (!pack_seq(g.partners[q], pd.len, win.data() + pd.word_off, (int)nw)) return fail(h, BK_E_ARG, "bk_submit_regions: non-ACGT base in partner window");
+            std::vector<uint32_t> wn;
+            if (!pack_seq(g.partners[q], pd.len, win.data() + pd.word_off, (int)nw, &wn, 0)) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": character other than A/C/G/T/N in a partner window");
+            pd.n_off = wnlist.size(); pd.n_n = (uint32_t)wn.size(); wnlist.insert(wnlist.end(), wn.begin(), wn.end());
             n_part.push_back(pd);
             n_targets[r].emplace_back(g.partners[q], pd.len); n_max_win = std::max<uint32_t>(n_max_win, pd.len);
         }
@@ -394,13 +401,14 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     h->big_bytes = big_bytes;
     if (sc.empty()) sc.push_back(0);
     if (sclen.empty()) sclen.push_back(0);
-    if (n_part.empty()) n_part.push_back(BkPartnerDesc{0, 0, 0});
+    if (n_part.empty()) n_part.push_back(BkPartnerDesc{0, 0, 0, 0});
+    if (wnlist.empty()) wnlist.push_back(0);
     const auto t_h2d0 = std::chrono::steady_clock::now();
     HIPCHK(h, upload(h, h->d_desc, n_desc)); HIPCHK(h, upload(h, h->d_part, n_part));
     HIPCHK(h, upload_raw(h, h->d_reads, reads, std::max<size_t>(tot_words, 1) * 4)); HIPCHK(h, upload_raw(h, h->d_rlen, rlen, std::max<size_t>(tot_reads, 1) * 2));
     HIPCHK(h, upload_raw(h, h->d_rflag, rflag, std::max<size_t>(tot_reads, 1)));
     HIPCHK(h, upload(h, h->d_sc, sc)); HIPCHK(h, upload(h, h->d_sclen, sclen)); HIPCHK(h, upload(h, h->d_win, win));
-    HIPCHK(h, upload(h, h->d_nlist, nlist));
+    HIPCHK(h, upload(h, h->d_nlist, nlist)); HIPCHK(h, upload(h, h->d_wnlist, wnlist));
     const size_t nr = std::max<size_t>(h->total_reads, 1), nd = std::max<uint64_t>(dd_total, 1);
     HIPCHK(h, h->d_work.ensure(sizeof(BkRegionWork) * n_regions));
     HIPCHK(h, h->d_ddslot.ensure(nd * 8)); HIPCHK(h, h->d_ddrep.ensure(nd * 4)); HIPCHK(h, h->d_ddcnt.ensure(nd * 4));
@@ -429,7 +437,7 @@ static void fill_params(bk_handle *h)
     BkParams &p = h->params;
     p.desc = (const BkRegionDesc *)h->d_desc.p; p.work = (BkRegionWork *)h->d_work.p; p.partners = (const BkPartnerDesc *)h->d_part.p;
     p.reads = (const uint32_t *)h->d_reads.p; p.read_len = (const uint16_t *)h->d_rlen.p; p.read_flag = (const uint8_t *)h->d_rflag.p;
-    p.nlist = (const uint32_t *)h->d_nlist.p;
+    p.nlist = (const uint32_t *)h->d_nlist.p; p.wnlist = (const uint32_t *)h->d_wnlist.p;
     p.sc = (const uint32_t *)h->d_sc.p; p.sc_len = (const uint16_t *)h->d_sclen.p; p.windows = (const uint32_t *)h->d_win.p;
     p.dd_slot = (unsigned long long *)h->d_ddslot.p; p.dd_rep = (uint32_t *)h->d_ddrep.p; p.dd_cnt = (uint32_t *)h->d_ddcnt.p;
     p.grp_slot = (uint32_t *)h->d_grp.p; p.urep = (uint32_t *)h->d_urep.p; p.unreads = (uint32_t *)h->d_unr.p; p.uflag = (uint8_t *)h->d_ufl.p;
@@ -503,8 +511,8 @@ static int launch(bk_handle *h, uint32_t mask)
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if (mask & BK_STAGE_REALIGN) {
         // target staging buffer (packed, 4 bases per byte): the whole window when it fits, else chunks of diagonals
-        const uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)h->cfg.max_contig_len + 16, std::max<uint32_t>(262144, 4 * (uint32_t)h->cfg.max_contig_len));
-        const size_t lds = ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + 15) / 16) * 16 + 4 * (4 * ((size_t)h->cfg.max_contig_len / 16 + 2) + tw_cap / 16 + 8);
+        const uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)h->cfg.max_contig_len + 16, std::max<uint32_t>(131072, 4 * (uint32_t)h->cfg.max_contig_len));      // words + N mask: 2 x 32 KB
+        const size_t lds = ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + 15) / 16) * 16 + 4 * (4 * ((size_t)h->cfg.max_contig_len / 16 + 2) + 2 * (tw_cap / 16 + 8));      // staged target words + their N mask
         HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // one workgroup per contig, pulled from the list the assembler appended to; the number of contigs is only known
         // on the device, so a resident-sized grid of persistent workgroups is launched (idle ones exit at once)

@@ -102,8 +102,10 @@ struct BkRegionDesc {
     uint32_t big;                // window does not fit the LDS k-mer set: handled by bk_kmer_kernel_g
     uint32_t n_nlist;            // N calls in this region's reads
     uint64_t nlist_off;          // first entry of this region in BkParams.nlist
+    uint32_t n_win_n, pad_;      // N positions in the target window (an assembly gap near the target): sorted, in BkParams.wnlist
+    uint64_t win_n_off;
 };
-struct BkPartnerDesc { uint64_t word_off; uint32_t len, pad; };
+struct BkPartnerDesc { uint64_t word_off; uint32_t len, n_n; uint64_t n_off; };      // n_n / n_off: its N positions in BkParams.wnlist
 
 // ---- device-written per-region work record (k-mer stage -> assembler -> realign) -----------
 struct BkRegionWork {
@@ -156,6 +158,7 @@ struct BkParams {
     const BkRegionDesc *desc; BkRegionWork *work; const BkPartnerDesc *partners;
     const uint32_t *reads; const uint16_t *read_len; const uint8_t *read_flag;
     const uint32_t *nlist;                                             // N calls: (read index in region << 10 | position), sorted per region
+    const uint32_t *wnlist;                                            // N positions of the windows (target and partner), sorted per window
     const uint32_t *sc; const uint16_t *sc_len;
     const uint32_t *windows;
     // read grouping (sized by total reads / total dedup slots)

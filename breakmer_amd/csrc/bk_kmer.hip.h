@@ -23,6 +23,9 @@ template <bool GLB>
 struct BkRefTabT {
     typedef typename std::conditional<GLB, unsigned long long, uint32_t>::type E;
     const uint32_t *win_f, *win_r;   // packed
+    const uint32_t *nbits = nullptr; // windows with N (packed as code 0): bit i set = the k-mer at index i (forward 0..wk-1, reverse wk..2wk-1) covers an N: it
+                                     // does not exist (Jellyfish skips it, utils.py:151-178), is not in the table, and no shortcut may step onto it
+    __device__ inline bool dead(int idx) const { return nbits && ((nbits[idx >> 5] >> (idx & 31)) & 1u); }
     E *tab;
     uint32_t cap_mask; int wk;       // wk = W-k+1 k-mers per strand
     int k, nww;                      // nww = words of each packed window copy
@@ -60,8 +63,8 @@ struct BkRefTabT {
     // next k-mer on the same diagonal as the previous hit (seed-and-extend: skips the hash probe)
     __device__ inline int extend(int ridx, uint32_t c) const {
         if (ridx < 0) return -1;
-        if (ridx < wk) { int cand = ridx + 1; return (cand < wk && seq_base(win_f, cand + k - 1) == c) ? cand : -1; }
-        int cand = ridx - wk + 1; return (cand < wk && seq_base(win_r, cand + k - 1) == c) ? wk + cand : -1;
+        if (ridx < wk) { int cand = ridx + 1; return (cand < wk && seq_base(win_f, cand + k - 1) == c && !dead(cand)) ? cand : -1; }
+        int cand = ridx - wk + 1; return (cand < wk && seq_base(win_r, cand + k - 1) == c && !dead(wk + cand)) ? wk + cand : -1;
     }
 };
 
@@ -106,7 +109,7 @@ __device__ inline void bk_scan_nonref_regs(const uint32_t (&wb)[BK_RW_MAX], int 
             uint32_t word = wb[wi];
             const int e = min(16, len - wi * 16);
             bool fast = false;
-            if (e == 16 && ridx >= 0 && wi * 16 >= k) {
+            if (e == 16 && ridx >= 0 && wi * 16 >= k && !rt.nbits) {
                 const bool fw = ridx < rt.wk; const int loc = fw ? ridx : ridx - rt.wk;
                 if (loc + 16 < rt.wk) {                                    // the 16 next k-mers exist on this strand
                     const uint32_t *W = fw ? rt.win_f : rt.win_r;
@@ -152,6 +155,7 @@ __device__ inline bool bk_read_is_clean(const uint32_t (&wb)[BK_RW_MAX], int len
     if (ridx < 0) return false;
     const bool fw = ridx < rt.wk; const int loc = fw ? ridx : ridx - rt.wk;
     if (loc + len > rt.wk + k - 1) return false;            // runs off the window
+    if (rt.nbits) for (int x = ridx; x <= ridx + len - k; x++) if (rt.dead(x)) return false;      // the window has an N under this read
     const uint32_t *W = fw ? rt.win_f : rt.win_r;
     bool ok = true;
 #pragma unroll
@@ -502,7 +506,24 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * WK; i += nt) rt.insert((uint32_t)i);
+    if (d.n_win_n) {                                         // a window with N (rare): which window k-mers do not exist
+        const uint32_t nbw = (uint32_t)(2 * WK + 31) / 32 + 1;
+        const uint64_t o_nb = bk_arena_alloc(p, (uint64_t)nbw * 4, scr + 20);
+        if (o_nb == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
+        uint32_t *nb = (uint32_t *)(p.arena + o_nb);
+        for (uint32_t i = tid; i < nbw; i += nt) nb[i] = 0;
+        __syncthreads();
+        const uint32_t *wn = p.wnlist + d.win_n_off;
+        for (uint32_t e = tid; e < d.n_win_n; e += nt) {
+            const int pf = (int)wn[e], pr = W - 1 - pf;      // position in the forward / in the reverse-complement window
+            for (int x = max(pf - k + 1, 0); x <= min(pf, WK - 1); x++) atomicOr(&nb[x >> 5], 1u << (x & 31));
+            for (int x = max(pr - k + 1, 0); x <= min(pr, WK - 1); x++) atomicOr(&nb[(WK + x) >> 5], 1u << ((WK + x) & 31));
+        }
+        __threadfence();
+        __syncthreads();
+        rt.nbits = nb;
+    }
+    for (int i = tid; i < 2 * WK; i += nt) if (!rt.dead(i)) rt.insert((uint32_t)i);
     __syncthreads();
 
     BK_STAMP(3);

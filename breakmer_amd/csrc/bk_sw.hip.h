@@ -50,10 +50,18 @@ __device__ inline unsigned long long bk_sw_key(int score, int tidx, int strand, 
            ((unsigned long long)(0x1FFF - a) << 33) | (unsigned long long)(0x1FFFFFFFFll - b);
 }
 
+// N mask of the staged target under the 16 bases that start at word i0, shift sh (as the packed words themselves are fetched); bit
+// 2*(15-t) set where base t is an N.  tn == nullptr: the window has no N (the rule).
+__device__ inline uint32_t bk_sw_tn(const uint32_t *tn, int i0, int tpn, int sh)
+{
+    if (!tn) return 0u;
+    const uint32_t m0 = (unsigned)i0 < (unsigned)tpn ? tn[i0] : 0u, m1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tn[i0 + 1] : 0u;
+    return sh ? (m0 << sh) | (m1 >> (32 - sh)) : m0;
+}
 // matching positions on diagonal `off` (target b = query a + off) of a packed query interval (n bases, qp) against the
 // staged packed target words tp[0..tpn) = target words tpw0.. (16 bases per word, MSB first)
 // qn: N mask of the packed query (bit 2*(15-t) set where base t of the word is an N: an N matches nothing here)
-__device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off)
+__device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off)
 {
     const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
     if (a1 <= a0) return 0;
@@ -63,7 +71,7 @@ __device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *qn,
         const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
         const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
         const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
-        const uint32_t x = qp[wq] ^ tb;
+        const uint32_t x = (qp[wq] ^ tb) | bk_sw_tn(tn, i0, tpn, sh);        // an N of the window matches nothing
         const uint32_t eq = ~(x | (x >> 1) | qn[wq]) & 0x55555555u;
         const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
         uint32_t vm = 0xFFFFFFFFu >> (2 * lo);
@@ -75,7 +83,7 @@ __device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *qn,
 // walk one diagonal on the packed words: best positive run (strict '>': smallest query end among equal scores).  Inside
 // a run of matches the score rises strictly, so only the end of each run can become the new best: the loop advances
 // from mismatch to mismatch (count-leading-zeros on the mismatch mask) instead of base by base.
-__device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int &bh, int &ba, int &br)
+__device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off, int &bh, int &ba, int &br)
 {
     const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
     int h = 0, run = 0;
@@ -86,7 +94,7 @@ __device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *qn, const 
         const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
         const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
         const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
-        const uint32_t x = qp[wq] ^ tb;
+        const uint32_t x = (qp[wq] ^ tb) | bk_sw_tn(tn, i0, tpn, sh);        // an N of the window matches nothing
         const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
         uint32_t stop = (x | (x >> 1) | qn[wq] | (hi < 16 ? 0xFFFFFFFFu >> (2 * hi) : 0u)) & 0x55555555u;   // mismatches (an N is one) and everything from `hi` on
         int pos = lo;
@@ -106,7 +114,7 @@ __device__ inline void bk_sw_walk(const uint32_t *qp, const uint32_t *qn, const 
 // Can H = max(0, H + s) reach `thresh` anywhere on diagonal `off`?  Word-granular upper bound: inside a word H rises by at
 // most its matches; after the word it is at most max(H + matches - 2 mismatches, matches) (the second term: a fresh
 // start inside the word).  false => no excursion of the diagonal peaks at >= thresh (exact walks are only needed for `true`).
-__device__ inline bool bk_sw_diag_maybe(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int thresh)
+__device__ inline bool bk_sw_diag_maybe(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off, int thresh)
 {
     const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
     if (a1 - a0 < thresh) return false;
@@ -116,7 +124,7 @@ __device__ inline bool bk_sw_diag_maybe(const uint32_t *qp, const uint32_t *qn, 
         const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
         const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
         const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
-        const uint32_t x = qp[wq] ^ tb;
+        const uint32_t x = (qp[wq] ^ tb) | bk_sw_tn(tn, i0, tpn, sh);        // an N of the window matches nothing
         const uint32_t eq = ~(x | (x >> 1) | qn[wq]) & 0x55555555u;
         const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
         uint32_t vm = 0xFFFFFFFFu >> (2 * lo);
@@ -129,7 +137,7 @@ __device__ inline bool bk_sw_diag_maybe(const uint32_t *qp, const uint32_t *qn, 
 }
 // match count of a diagonal (as bk_sw_diag_matches) and, in the same pass over its words, the word-granular upper bound of
 // bk_sw_diag_maybe: `maybe` = H can reach thresh somewhere on it.  Branch-free (the loads of the next words are not held up).
-__device__ inline int bk_sw_diag_scan(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int thresh, bool &maybe)
+__device__ inline int bk_sw_diag_scan(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off, int thresh, bool &maybe)
 {
     const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
     maybe = false;
@@ -140,7 +148,7 @@ __device__ inline int bk_sw_diag_scan(const uint32_t *qp, const uint32_t *qn, co
         const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
         const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
         const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
-        const uint32_t x = qp[wq] ^ tb;
+        const uint32_t x = (qp[wq] ^ tb) | bk_sw_tn(tn, i0, tpn, sh);        // an N of the window matches nothing
         const uint32_t eq = ~(x | (x >> 1) | qn[wq]) & 0x55555555u;
         const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
         uint32_t vm = 0xFFFFFFFFu >> (2 * lo);
@@ -156,7 +164,7 @@ __device__ inline int bk_sw_diag_scan(const uint32_t *qp, const uint32_t *qn, co
 // walk one diagonal over the whole query and report every positive excursion (reset to reset / end of the diagonal) whose
 // peak is >= thresh: emit(peak, query end of the first position of the peak, length of the segment from the excursion's start)
 template <class F>
-__device__ inline void bk_sw_walk_all(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, int tpw0, int tpn, int n, int m, int off, int thresh, F emit)
+__device__ inline void bk_sw_walk_all(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off, int thresh, F emit)
 {
     const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
     int h = 0, run = 0, bh = 0, ba = 0, br = 0;
@@ -166,7 +174,7 @@ __device__ inline void bk_sw_walk_all(const uint32_t *qp, const uint32_t *qn, co
         const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
         const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
         const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
-        const uint32_t x = qp[wq] ^ tb;
+        const uint32_t x = (qp[wq] ^ tb) | bk_sw_tn(tn, i0, tpn, sh);        // an N of the window matches nothing
         const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
         uint32_t stop = (x | (x >> 1) | qn[wq] | (hi < 16 ? 0xFFFFFFFFu >> (2 * hi) : 0u)) & 0x55555555u;
         int pos = lo;
@@ -207,6 +215,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
     const int qpw = p.max_contig / 16 + 2;
     uint32_t *qnm = qpk + 2 * qpw;                                     // N masks of the packed query interval, both strands
     uint32_t *tp = qnm + 2 * qpw;                                      // staged target chunk, packed words (kept across passes and contigs)
+    uint32_t *tnb = tp + (tw_cap / 16 + 8);                            // its N mask, filled (and used) only for windows that hold an N
     if (tid == 0) { S->staged_ti = -1; S->staged_t0 = 0; S->staged_t1 = 0; S->staged_region = -1; }
     const unsigned long long n_list = min(*p.n_clist, (unsigned long long)p.clist_cap);
     for (;;) {
@@ -246,8 +255,10 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
             unsigned long long bkey = 0; int brun = 0;
             for (int ti = 0; ti <= (int)d.n_partners; ti++) {
                 const uint32_t *gw; int m;
-                if (ti == 0) { gw = p.windows + d.win_word_off; m = (int)d.win_len; }
-                else { const BkPartnerDesc pd = p.partners[d.part_desc_off + ti - 1]; gw = p.windows + pd.word_off; m = (int)pd.len; }
+                const uint32_t *wn; int nn;                                  // N positions of this window (none, as a rule)
+                if (ti == 0) { gw = p.windows + d.win_word_off; m = (int)d.win_len; wn = p.wnlist + d.win_n_off; nn = (int)d.n_win_n; }
+                else { const BkPartnerDesc pd = p.partners[d.part_desc_off + ti - 1]; gw = p.windows + pd.word_off; m = (int)pd.len; wn = p.wnlist + pd.n_off; nn = (int)pd.n_n; }
+                const uint32_t *tnp = nn ? tnb : nullptr;
                 // diagonals off = b - a in [-(n-1), m-1] are independent: they are processed in chunks whose target
                 // bases [o0, o0 + CH + n - 1) fit the staging buffer (one chunk when the window is short)
                 const int CH = (int)tw_cap - n, mw = (m + 15) / 16;
@@ -257,9 +268,13 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     __syncthreads();
                     const bool staged = S->staged_ti == ti && S->staged_t0 == t0 && S->staged_t1 == t1;   // e.g. one short window: staged once per region
                     __syncthreads();
-                    if (!staged) for (int i = tid; i < tpn; i += BK_ST_T) tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u;
+                    if (!staged) for (int i = tid; i < tpn; i += BK_ST_T) { tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u; if (nn) tnb[i] = 0u; }
                     if (tid == 0) { S->umax = 0; S->staged_ti = ti; S->staged_t0 = t0; S->staged_t1 = t1; }
                     __syncthreads();
+                    if (!staged && nn) {
+                        for (int e = tid; e < nn; e += BK_ST_T) { const int pn = (int)wn[e], wi = (pn >> 4) - tpw0; if ((unsigned)wi < (unsigned)tpn) atomicOr(&tnb[wi], 1u << (2 * (15 - (pn & 15)))); }
+                        __syncthreads();
+                    }
                     const int nd = o1 - o0;
                     // (1) match counts; this thread's two best diagonals and the largest count among its others.  The first pass
                     // (the whole query) also notes the diagonals on which H can reach min_score at all: step 5 walks only those.
@@ -268,9 +283,9 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                         const int st = D >= nd, off = o0 + (st ? D - nd : D);
                         int u;
                         if (first) {
-                            bool maybe; u = bk_sw_diag_scan(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, p.sw_min_score, maybe);
+                            bool maybe; u = bk_sw_diag_scan(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off, p.sw_min_score, maybe);
                             if (maybe) { const int fi = atomicAdd(&S->nflag, 1); if (fi < BK_SW_FLAGS) { S->flag_off[fi] = off; S->flag_ts[fi] = (ti << 1) | st; } }
-                        } else u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off);
+                        } else u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off);
                         if (u > myu) { myu3 = myu2; myu2 = myu; myD2 = myD; myu = u; myD = D; }
                         else if (u > myu2) { myu3 = myu2; myu2 = u; myD2 = D; }
                         else if (u > myu3) myu3 = u;
@@ -281,7 +296,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     int walked = -1;
                     if (myu == S->umax && myu >= S->L && myu > 0) {
                         const int st = myD >= nd, off = o0 + (st ? myD - nd : myD);
-                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, bh, ba, br);
+                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off, bh, ba, br);
                         if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } atomicMax(&S->L, bh); }
                         walked = myD;
                     }
@@ -291,7 +306,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     // rescan of all its diagonals (rare: the counts of unrelated diagonals are far below an achieved score)
                     auto walk_one = [&](int D) {
                         const int st = D >= nd, off = o0 + (st ? D - nd : D);
-                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, bh, ba, br);
+                        int bh, ba, br; bk_sw_walk(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off, bh, ba, br);
                         if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } if (bh > *(volatile int *)&S->L) atomicMax(&S->L, bh); }
                     };
                     if (walked < 0 && myu > 0 && myu >= *(volatile int *)&S->L) walk_one(myD);
@@ -300,7 +315,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                         for (int D = tid; D < 2 * nd; D += BK_ST_T) {
                             if (D == myD || D == myD2) continue;
                             const int st = D >= nd, off = o0 + (st ? D - nd : D);
-                            const int u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off);
+                            const int u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off);
                             if (u < *(volatile int *)&S->L || u == 0) continue;
                             walk_one(D);
                         }
@@ -339,8 +354,10 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
             bk_sw_pack_query(qf, qr, Q, 0, Q, qpk, qnm, qpw, tid);
             for (int ti = 0; ti <= (int)d.n_partners; ti++) {
                 const uint32_t *gw; int m;
-                if (ti == 0) { gw = p.windows + d.win_word_off; m = (int)d.win_len; }
-                else { const BkPartnerDesc pd = p.partners[d.part_desc_off + ti - 1]; gw = p.windows + pd.word_off; m = (int)pd.len; }
+                const uint32_t *wn; int nn;                                  // N positions of this window (none, as a rule)
+                if (ti == 0) { gw = p.windows + d.win_word_off; m = (int)d.win_len; wn = p.wnlist + d.win_n_off; nn = (int)d.n_win_n; }
+                else { const BkPartnerDesc pd = p.partners[d.part_desc_off + ti - 1]; gw = p.windows + pd.word_off; m = (int)pd.len; wn = p.wnlist + pd.n_off; nn = (int)pd.n_n; }
+                const uint32_t *tnp = nn ? tnb : nullptr;
                 const int CH = (int)tw_cap - n, mw = (m + 15) / 16;
                 for (int o0 = -(n - 1); o0 < m; o0 += CH) {
                     const int o1 = min(o0 + CH, m), t0 = max(o0, 0), t1 = min(m, o1 - 1 + n);
@@ -348,9 +365,13 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                     __syncthreads();
                     const bool staged = S->staged_ti == ti && S->staged_t0 == t0 && S->staged_t1 == t1;
                     __syncthreads();
-                    if (!staged) for (int i = tid; i < tpn; i += BK_ST_T) tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u;
+                    if (!staged) for (int i = tid; i < tpn; i += BK_ST_T) { tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u; if (nn) tnb[i] = 0u; }
                     if (tid == 0) { S->staged_ti = ti; S->staged_t0 = t0; S->staged_t1 = t1; }
                     __syncthreads();
+                    if (!staged && nn) {
+                        for (int e = tid; e < nn; e += BK_ST_T) { const int pn = (int)wn[e], wi = (pn >> 4) - tpw0; if ((unsigned)wi < (unsigned)tpn) atomicOr(&tnb[wi], 1u << (2 * (15 - (pn & 15)))); }
+                        __syncthreads();
+                    }
                     const int nd = o1 - o0;
                     const int nfl = S->nflag, nwork = nfl <= BK_SW_FLAGS ? nfl : 2 * nd;      // the diagonals the first pass flagged; all of them if that list overflowed
                     for (int W = tid; W < nwork; W += BK_ST_T) {
@@ -360,9 +381,9 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                             if ((ts >> 1) != ti || off < o0 || off >= o1) continue;
                         } else {
                             st = W >= nd; off = o0 + (st ? W - nd : W);
-                            if (!bk_sw_diag_maybe(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, p.sw_min_score)) continue;
+                            if (!bk_sw_diag_maybe(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off, p.sw_min_score)) continue;
                         }
-                        bk_sw_walk_all(qpk + st * qpw, qnm + st * qpw, tp, tpw0, tpn, n, m, off, p.sw_min_score, [&](int sc, int aend, int run) {
+                        bk_sw_walk_all(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off, p.sw_min_score, [&](int sc, int aend, int run) {
                             const int sqs = aend - run, sqe = aend;                      // strand coordinates (the whole query: no interval offset)
                             for (int x = 0; x < nh1; x++) {
                                 const BkHit &an = S->hits[x];

@@ -129,7 +129,7 @@ def _ascii_matrix(seqs):
     return m, lens
 
 
-_ACGT = np.frombuffer(b"ACGTN", dtype=np.uint8)       # code 4 = N (reads only; windows must be A/C/G/T)
+_ACGT = np.frombuffer(b"ACGTN", dtype=np.uint8)       # code 4 = N
 _CODE2ASCII = bytes(b"ACGTN"[i] if i < 5 else ord("?") for i in range(256))
 
 

@@ -221,9 +221,9 @@ def discover_partners(disc, fasta, annotations, target_chrom, target_start, targ
                 continue
             s, e = max(0, lo - flank), min(clen, hi + flank)
             seq = fasta.fetch(c, s, e)
-            if len(seq) < 64 or seq.strip("ACGT"):
+            if len(seq) < 64 or seq.strip("ACGTN"):
                 if skipped is not None and len(seq) >= 64:
-                    skipped.append((c, s, e))              # windows must be plain A/C/G/T for the device path: the caller logs these
+                    skipped.append((c, s, e))              # IUPAC codes other than N cannot be packed: the caller logs these
                 continue
             name = annotations.set_gene(c, [(lo + hi) // 2]) if annotations is not None else "intergenic"
             out.append((n, (c, s, e, name, seq)))

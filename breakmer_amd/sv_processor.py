@@ -484,7 +484,7 @@ class target(object):                                               # sv_process
             self.data.partners = refseq.discover_partners(self.disc_reads['disc'], self.params.open_fasta(), self.params.gene_annotations,
                                                           self.chrom, self.start, self.end, min_pairs=self.params.get_sr_thresh('trl'), skipped=skipped)
             for c_, s_, e_ in skipped:
-                self.logger.warning('target %s: partner window %s:%d-%d holds characters other than A/C/G/T (an assembly gap?) and is not realigned against' % (self.name, c_, s_, e_))
+                self.logger.warning('target %s: partner window %s:%d-%d holds characters other than A/C/G/T/N and is not realigned against' % (self.name, c_, s_, e_))
             if self.data.partners:
                 self.logger.info('target %s: %d partner window(s) from discordant pairs: %s' % (self.name, len(self.data.partners),
                                  ", ".join("%s:%d-%d" % (p[0], p[1], p[2]) for p in self.data.partners)))
@@ -512,16 +512,17 @@ class target(object):                                               # sv_process
 
     def unsupported_reference(self):
         """None, or why this target cannot go to the device: its window (or a partner window) holds a character other than
-        A/C/G/T -- an N of an assembly gap within 200 bp of the target.  The reference has no such limit (Jellyfish skips
-        k-mers with an N); here the target is skipped ALONE, with an error in the log and in runner.failed_targets."""
+        A/C/G/T/N.  (An N -- an assembly gap within 200 bp of the target -- is fine: the device carries the N positions of a
+        window as it carries those of the reads; no window k-mer spans one, it matches nothing in the realignment.)  Such a
+        target is skipped ALONE, with an error in the log and in runner.failed_targets."""
         d = self.data
         if not d.window:
             return "empty reference window"
-        if isinstance(d.window, str) and d.window.encode().translate(None, b"ACGT"):      # C-speed scan (str.strip walks the characters one by one)
-            return "reference window holds characters other than A/C/G/T (%s)" % ",".join(sorted(set(d.window.strip("ACGT")))[:5])
+        if isinstance(d.window, str) and d.window.encode().translate(None, b"ACGTN"):      # C-speed scan (str.strip walks the characters one by one)
+            return "reference window holds characters other than A/C/G/T/N (%s)" % ",".join(sorted(set(d.window.strip("ACGTN")))[:5])
         for p_ in d.partners:
-            if isinstance(p_[4], str) and p_[4].encode().translate(None, b"ACGT"):
-                return "partner window %s:%s-%s holds characters other than A/C/G/T" % (p_[0], p_[1], p_[2])
+            if isinstance(p_[4], str) and p_[4].encode().translate(None, b"ACGTN"):
+                return "partner window %s:%s-%s holds characters other than A/C/G/T/N" % (p_[0], p_[1], p_[2])
         return None
 
     def clean_reads(self):                                           # :584-606 (cutadapt out of scope) -> bool
@@ -797,8 +798,8 @@ class runner(object):                                               # sv_process
         for nh, c_, s0, e0 in sorted(loci.values(), key=lambda x: (-x[0], x[1], x[2]))[:4]:
             s1, e1 = max(0, s0 - 1500), min(fa.length(c_), e0 + 1500)
             wseq = fa.fetch(c_, s1, e1)
-            if len(wseq) < 64 or wseq.strip("ACGT"):
-                self.logger.warning('target %s: genome window %s:%d-%d holds characters other than A/C/G/T and is not realigned against' % (t.name, c_, s1, e1))
+            if len(wseq) < 64 or wseq.strip("ACGTN"):
+                self.logger.warning('target %s: genome window %s:%d-%d holds characters other than A/C/G/T/N and is not realigned against' % (t.name, c_, s1, e1))
                 continue
             name = self.params.gene_annotations.set_gene(c_, [(s0 + e0) // 2])
             out.append((c_, s1, e1, name, wseq))

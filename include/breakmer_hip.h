@@ -65,7 +65,8 @@ typedef struct bk_config {
  * (sv_processor.py:609-665): the cleaned reads (self.cleaned_read_recs before grouping,
  * utils.py:203-246), the soft-clip sequences behind case_sc (sv_processor.py:619-620) and the
  * forward reference window FASTA (sv_processor.py:291; the reverse file is derived).
- * Sequences are ASCII A/C/G/T, rows `stride` bytes apart with explicit lengths. */
+ * Sequences are ASCII A/C/G/T/N (an N in a read, a soft-clip sequence or a window matches nothing and no k-mer spans it, as for
+ * Jellyfish and BLAT), rows `stride` bytes apart with explicit lengths. */
 typedef struct bk_region {
     const char *reads;          /* n_reads rows */
     const uint16_t *read_lens;

@@ -408,7 +408,7 @@ def test_edge_cases_gpu(hb):
     with pytest.raises(hb.BreakmerHipError):
         hb.Engine(kmer_size=31).submit([hb.RegionInput(["ACGTR" * 10], w)])           # a character other than A/C/G/T/N
     with pytest.raises(hb.BreakmerHipError):
-        hb.Engine(kmer_size=31).submit([hb.RegionInput([w[:100]], w[:500] + "N" + w[501:])])   # windows must be A/C/G/T
+        hb.Engine(kmer_size=31).submit([hb.RegionInput([w[:100]], w[:500] + "Y" + w[501:])])   # ... in a window too (an N is fine there: test_windows_with_n_gpu)
     with pytest.raises(hb.BreakmerHipError):
         hb.Engine(kmer_size=31).submit([hb.RegionInput(["A" * 2000], w)])             # read longer than max_read_len
     e5 = hb.Engine(kmer_size=31)                                                      # 20 kb window of a 4-mer repeat: global-memory k-mer set
@@ -812,6 +812,44 @@ def test_reads_with_n_gpu(hb):
             assert eng.hits(i, ci) == bo.realign(c["seq"], targets), (i, ci)
             ncontig_n += "N" in c["seq"]
     assert ncontig_n >= 1
+
+
+def test_windows_with_n_gpu(hb):
+    """Reference windows (and a partner window) with N calls -- an assembly gap within reach of the target: no window k-mer spans an
+    N (Jellyfish skips them, utils.py:151-178), so the reads over the gap are sample-only there and get assembled; in the
+    realignment an N matches nothing.  K-mer sets, contigs and realign records against the oracle, for LDS-sized windows, a
+    whole-gene window (global-memory k-mer set, chunked realign), N next to the SV junction, runs of N, N at the window ends."""
+    import numpy as np
+    from oracle import bk_oracle as bo
+    regions = []
+    spots = [[700], [700, 701, 702, 703], [0, 1499], [640, 660], [300, 900, 1200], [745], [100 + 7 * j for j in range(40)]]
+    for i, sp_ in enumerate(spots):
+        r = synth.make_region(8100 + i, sv_type=synth.SV_TYPES[i % 5], depth=60, W=1500, noise=(0.01 if i == 4 else 0.0), n_frac=(0.2 if i == 3 else 0.0))
+        r.window = r.window.copy()
+        r.window[np.array(sp_)] = 4
+        if r.partners:
+            pw = r.partners[0][4].copy(); pw[[760, 761, 1100]] = 4
+            r.partners[0] = r.partners[0][:4] + (pw,)
+        regions.append(r)
+    r = synth.make_region(8120, sv_type="del", depth=60, W=1500)             # whole-gene sized window with N
+    fl = synth.rand_bases(synth.stream_key(5, 8120, 9), 2 * 15000)
+    r.window = np.concatenate([fl[:15000], r.window, fl[15000:]]).astype(np.uint8)
+    r.window[[15700, 15701, 200, 29000]] = 4
+    regions.append(r)
+    eng = _run_regions(hb, regions, 31, stages=7)
+    assert eng.sync() == 0
+    ncontig = 0
+    for i, r in enumerate(regions):
+        assert "N" in r.window_str
+        targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        want, info = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
+        assert eng.kmers(i)[0] == [m for m, _ in sorted(zip(info["mers"], info["counts"].tolist()), key=lambda x: (x[1], x[0]), reverse=True)], i
+        got = eng.contigs(i)
+        assert _strip(got) == want, i
+        for ci, c in enumerate(want):
+            assert eng.hits(i, ci) == bo.realign(c["seq"], targets), (i, ci)
+        ncontig += len(want)
+    assert ncontig >= len(regions) + 3                        # the gaps produce contigs of their own
 
 
 def test_translocation_partner_discovery_gpu(hb, tmp_path):
