@@ -8,6 +8,8 @@
 //   * N calls (the reference keeps reads with N: utils.py:203-246; Jellyfish skips k-mers that contain one; olc.nw
 //     compares characters, so N matches N and nothing else): packed as code 0, and listed per region as sorted
 //     (read index << 10 | position) words; reads that have any carry BK_RF_HASN.  Unpacked byte code of N = 4.
+//   * N in a reference / partner window: packed as code 0 too, positions listed per window (BkParams.wnlist): no window k-mer
+//     spans one (bk_kmer.hip.h: BkRefTabT::nbits), the realigner masks it (bk_sw.hip.h: bk_sw_tn).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
