@@ -160,9 +160,18 @@ class RegionInput(object):
         else:
             self.sc, self.sc_lens = _ascii_matrix(list(sc_seqs))
         self.partners = [pw.encode() if isinstance(pw, str) else bytes(_ACGT[np.asarray(pw)]) for pw in partners]
+        self._filled = None                                 # the bk_region of this object, made once (a driver that keeps the object submits it again)
 
     def fill(self, g: BkRegion):
-        """g: an element of a freshly made (zeroed) BkRegion array, or one this object filled before"""
+        """g: an element of a BkRegion array.  The struct is made once and copied: this object holds every buffer it points to."""
+        f = self._filled
+        if f is None:
+            f = BkRegion()
+            self._fill(f)
+            self._filled = f
+        C.memmove(C.addressof(g), C.addressof(f), C.sizeof(BkRegion))
+
+    def _fill(self, g: BkRegion):
         reads = self.reads
         g.reads = reads.ctypes.data
         g.read_lens = self.lens.ctypes.data
@@ -271,6 +280,7 @@ class Engine(object):
                 if r.codes:
                     r.reads = np.frombuffer(r.reads.tobytes().translate(_CODE2ASCII), dtype=np.uint8).reshape(r.reads.shape)
                     r.codes = False
+                    r._filled = None
                     r.fill(g)
             kinds = {False}
         flags = (1 if kinds == {True} else 0) | (0 if wait else 2)

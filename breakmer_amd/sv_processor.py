@@ -46,6 +46,30 @@ class RegionData(object):
         self.window = window
         self.partners = list(partners)          # (chrom, start, end, name, seq)
         self.disc_reads = disc_reads or {"disc": {}, "inv": [], "td": [], "other": []}
+        self._view = None                       # (the objects the view was made from ..., hip_backend.RegionInput)
+        self._refcheck = None                   # (window, number of partners, verdict of target.unsupported_reference)
+        self._maxlen = None                     # (read_lens, its maximum)
+
+    def device_view(self):
+        """the hip_backend.RegionInput of these inputs.  Made once per state of the inputs and kept with them: a driver that
+        runs the same RegionData again (several analyses over one set of extracted reads) does not rebuild it per run.  The
+        objects it was made from are kept and compared by identity, so any replacement of an input makes a new view."""
+        from . import hip_backend
+        reads = self.read_codes if self.read_codes is not None else self.read_seqs
+        v = self._view
+        if v is not None and v[0] is reads and v[1] is self.read_lens and v[2] is self.indel_only and v[3] is self.sc_seqs and v[4] is self.window and v[5] is self.partners and v[6] == len(self.partners) \
+                and (self.read_codes is not None or v[7] == len(reads)):
+            return v[8]
+        io = self.indel_only if type(self.indel_only) is _np.ndarray else _np.asarray(self.indel_only, dtype=_np.uint8)
+        ri = hip_backend.RegionInput(reads, self.window, read_lens=self.read_lens, indel_only=io, sc_seqs=self.sc_seqs, partners=[p[4] for p in self.partners])
+        self._view = (reads, self.read_lens, self.indel_only, self.sc_seqs, self.window, self.partners, len(self.partners), len(reads), ri)
+        return ri
+
+    def max_read_len(self):
+        m = self._maxlen
+        if m is None or m[0] is not self.read_lens:
+            m = self._maxlen = (self.read_lens, int(_np.asarray(self.read_lens).max()) if len(self.read_lens) else 0)
+        return m[1]
 
 
 def read_fasta_first(fn):
@@ -516,6 +540,15 @@ class target(object):                                               # sv_process
         window as it carries those of the reads; no window k-mer spans one, it matches nothing in the realignment.)  Such a
         target is skipped ALONE, with an error in the log and in runner.failed_targets."""
         d = self.data
+        c = d._refcheck
+        if c is not None and c[0] is d.window and c[1] is d.partners and c[2] == len(d.partners):
+            return c[3]
+        why = self._unsupported_reference(d)
+        d._refcheck = (d.window, d.partners, len(d.partners), why)
+        return why
+
+    @staticmethod
+    def _unsupported_reference(d):
         if not d.window:
             return "empty reference window"
         if isinstance(d.window, str) and d.window.encode().translate(None, b"ACGTN"):      # C-speed scan (str.strip walks the characters one by one)
@@ -560,7 +593,7 @@ class target(object):                                               # sv_process
             # code-matrix input (synthetic / pre-packed reads): nothing per read happens on the host; the fq_read objects the
             # writers and the caller need are made on demand (_LazyReads), cleaned_read_recs only exists as a count
             self.reads = _LazyReads(d)
-            self.read_len = int(_np.max(d.read_lens)) if len(d.read_lens) else 0
+            self.read_len = d.max_read_len()
             self.cleaned_read_recs = _LazyRecs(self.reads)
             return len(d.read_ids) > 0
         q = d.quals
@@ -678,10 +711,7 @@ class runner(object):                                               # sv_process
         ins = []
         for i, t in enumerate(live):
             t.region_index, t.engine = i, eng
-            d = t.data
-            reads = d.read_codes if d.read_codes is not None else d.read_seqs
-            ins.append(hip_backend.RegionInput(reads, d.window, read_lens=d.read_lens, indel_only=d.indel_only if type(d.indel_only) is _np.ndarray else _np.asarray(d.indel_only, dtype=_np.uint8), sc_seqs=d.sc_seqs,
-                                               partners=[p[4] for p in d.partners]))
+            ins.append(t.data.device_view())
         try:
             eng.submit(ins, wait=False)
         except TypeError:
