@@ -140,11 +140,30 @@ __device__ inline int32_t *bk_cnt_ot(int buf) { return C_.cnt + (size_t)buf * 4 
 __device__ inline void bk_fail(int st) { if (BK_TID == 0 && S_->status == 0) S_->status = st; }
 
 // k-mer key of LDS bytes s[0..k); false when the window holds an N (code 4): no such k-mer exists (Jellyfish skips them)
+// Four bases per step: aligned LDS words funnelled to the byte offset of s (v_alignbyte), the four 2-bit codes of a word
+// gathered with shifts -- ~12 instructions per four bases; base by base with a 128-bit rolling key it was ~10 per BASE, and
+// the k-mer searches of the planning code (bk_find_kmer_wave) were a tenth of all instructions of a clean region.
 __device__ inline bool bk_bytes_kmer(const uint8_t *s, int k, BkKey &key)
 {
-    key.hi = 0; key.lo = 0; uint32_t any = 0;
-    for (int i = 0; i < k; i++) { const uint32_t c = s[i]; any |= c; key_push(key, c & 3u, 64); }
-    return (any & BK_CODE_N) == 0;
+    const uint32_t off = (uint32_t)(s - bk_lds) & 3u;
+    const uint32_t *wp = (const uint32_t *)(s - off);
+    const int G = (k + 3) >> 2;
+    uint64_t hi = 0, lo = 0; uint32_t acc = 0, any = 0, w0 = wp[0];
+    for (int g = 0; g < G; g++) {
+        const uint32_t w1 = wp[g + 1];
+        uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, off);              // bytes s[4g .. 4g+3], the first base in the low byte
+        w0 = w1;
+        if (g == G - 1 && (k & 3)) x &= (1u << (8 * (k & 3))) - 1u;        // bases beyond k
+        any |= x;
+        x &= 0x03030303u;
+        acc = (acc << 8) | (((x << 6) | (x >> 4) | (x >> 14) | (x >> 24)) & 0xFFu);      // first base most significant, as key_push
+        if ((g & 3) == 3) { hi = (hi << 32) | (lo >> 32); lo = (lo << 32) | acc; acc = 0; }
+    }
+    if (G & 3) { const int sh = 8 * (G & 3); hi = (hi << sh) | (lo >> (64 - sh)); lo = (lo << sh) | acc; }
+    const int drop = 2 * (4 * G - k);                                      // the (zeroed) codes of the last group beyond k
+    if (drop) { lo = (lo >> drop) | (hi << (64 - drop)); hi >>= drop; }
+    key.hi = hi; key.lo = lo;
+    return (any & (0x01010101u * BK_CODE_N)) == 0;
 }
 // write code 4 over the N calls of read i (region index) that fall into bases [from, from + count) of the copy at dst
 __device__ inline void bk_patch_n(uint32_t i, uint8_t *dst, int from, int count)
