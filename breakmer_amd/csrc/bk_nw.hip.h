@@ -512,6 +512,13 @@ __device__ inline void bk_nw_pair_call(int c, const BkPairArgs &A, const BkPairA
 // both contigs <= BK_NW_DUAL_COLS; registers per lane = ceil(longer contig / 32)
 __device__ inline void bk_nw_pair(const BkPairArgs &A, const BkPairArgs &B) { bk_nw_pair_call<3>((max(A.clen, B.n ? B.clen : 0) + 31) / 32, A, B); }
 
+// Tried in round 3 and not kept, second attempt (profiles/r03/pair_two_word_ab.txt): bk_nw_pair_c with the second order carried as a
+// second WORD [score | priority | origin] through its own v_max3 (12 instructions per cell, no compares against the score, no
+// register copies, no hazard nops) instead of the origin register with its two compares and selects (14 + nops).  Bit-exact,
+// 23 % faster while the SIMDs have wavefronts to spare (54.7 vs 70.9 us per round), but 10 % SLOWER where this kernel is used,
+// at saturation (4.36 vs 4.85 TCUPS): 11 % fewer VALU instructions, each 24 % more expensive (SQ_INSTS_VALU, SQ_WAVE_CYCLES) --
+// a second v_max3 per cell costs more than the three compare/select/copy instructions it replaces; neither literals moved to
+// registers nor forming the next column's diagonal candidate early (which removes the copies of the kept version) changed that.
 // Tried in round 3 and not kept (tools/dp_bench_dual.py history, profiles/r03/valu_rate.txt): the same sweep with two rows per
 // iteration in a column-shifted frame (stored word = H + 2 j, so the left neighbour's word IS the horizontal candidate and the
 // chain along a row is max3 -> v_and_or), laid out cell by cell so that the two rows' chains interleave.  Bit-exact, but no

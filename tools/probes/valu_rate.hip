@@ -14,6 +14,7 @@ __global__ void __launch_bounds__(256) k_rate(int iters, int *out, unsigned long
 #pragma unroll
     for (int i = 0; i < 8; i++) a[i] = threadIdx.x * 7 + i;
     int b = threadIdx.x ^ 0x55, c = blockIdx.x + 3;
+    int sc; asm volatile("s_mov_b32 %0, 0xfff80000" : "=s"(sc));
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -26,6 +27,15 @@ __global__ void __launch_bounds__(256) k_rate(int iters, int *out, unsigned long
                 else if (OP == 3) a[i] = (a[i] == c) ? b : (a[i] + 1);                          // v_cmp + v_cndmask (+ add)
                 else if (OP == 4) a[i] = __builtin_amdgcn_update_dpp(a[i], a[i], 0x138, 0xf, 0xf, false) + 1;   // DPP wave_shr + add
                 else if (OP == 5) { a[i] = a[i] + b; a[i] = max(max(a[i], b), c) & 0xFFFCFFFF; }   // the chain: add, max3, and (dependent)
+                else if (OP == 6) asm volatile("v_add_u32 %0, 0xfff80000, %0" : "+v"(a[i]));     // 32-bit literal: 8-byte encoding
+                else if (OP == 7) asm volatile("v_and_b32 %0, 0xfffcffff, %0" : "+v"(a[i]));
+                else if (OP == 8) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "s"(sc));    // the constant in an SGPR
+                else if (OP == 9) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
+                else if (OP == 10) asm volatile("v_cmp_eq_u32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+                else if (OP == 11) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+                else if (OP == 12) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                else if (OP == 13) asm volatile("v_add_u32 %0, 64, %0" : "+v"(a[i]));              // inline constant
+                else if (OP == 14) asm volatile("v_cmp_lt_i32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");   // back to back: the hardware interlocks (or the assembler objects)
                 asm volatile("" : "+v"(a[i]));
             }
         }
@@ -71,5 +81,14 @@ int main()
     run<3>("v_cmp+v_cndmask+v_add", 3);
     run<4>("v_mov_dpp wave_shr + v_add", 2);
     run<5>("add, max3, and (dependent)", 3);
+    run<6>("v_add_u32 literal", 1);
+    run<7>("v_and_b32 literal", 1);
+    run<8>("v_add_u32 sgpr", 1);
+    run<9>("v_mov_b32", 1);
+    run<10>("v_cmp_eq_u32 vcc", 1);
+    run<11>("v_cndmask_b32 vcc", 1);
+    run<12>("v_max_i32", 1);
+    run<13>("v_add_u32 inline const", 1);
+    run<14>("v_cmp + v_cndmask adjacent", 2);
     return 0;
 }
