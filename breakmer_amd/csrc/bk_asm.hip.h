@@ -782,88 +782,128 @@ __device__ inline bool bk_predict(BkAsmShared::Slot &t, int &pb, int &plen, int 
     return true;
 }
 
-// Run retire (BK_F_NO_RUN_RETIRE switches it off).  Reads that leave the contig SEQUENCE as it is -- rejected,
-// identical, or contained (counts += over a span) -- are most of what a round retires, and their effects commute: the
-// decisions of slots sl .. s1-1 are taken at once (a lane each), the longest run from sl on that passes the prediction
-// checks and changes nothing is retired in ONE pass (one summed count update per base, one lane per read for the
-// per-read words, appends in slot order), and the caller goes on with the first slot that extends or replaces the contig.
+// Run retire (BK_F_NO_RUN_RETIRE switches it off).  The slots of a round are retired together for as long as every one of
+// them does what was predicted: the decisions of slots sl .. s1-1 are taken at once (a lane each, against the contig length
+// each was aligned to), thread 0 walks the prediction chain over them -- a rejected, identical or contained read leaves the
+// sequence alone, an extension (contig_overlap_read :520-527, read_overlap_contig :538-545) must be the predicted kind and
+// length, which makes the bytes the predicted ones -- and the run is applied in ONE pass: the appended / prepended bases, the
+// count entries of the new bases (assigned, extend_counts :201-221), then one summed count update per base over the ranges
+// of all reads of the run in the coordinates each range was taken in (set_counts :195-199; old coordinates before a
+// prepend), one lane per read for the per-read words, appends in slot order.  Left to the one-read path (bk_retire): a read
+// that replaces the contig (superseq), a tie of the two scores (k-mer position rule), the first read of a seed planned
+// ahead, an extension that fails a bound, and in grow mode an extension by two or more bases (it adds contig k-mers, in
+// order, bk_kmers_ordered; an extension by one base adds none, Q1).  Four barriers per run instead of two to three per read.
 // The number retired is left in S->tmp0 (uniform after the function's last barrier).
 __device__ __forceinline__ void bk_retire_run(int sl, int s1, bool grow)
 {
     BkAsmShared *S = S_;
     const int nbt = s1 - sl;
-    if (BK_TID < nbt) {
-        BkAsmShared::Slot &t = S->slot[sl + BK_TID];
-        int ds, de; bool tie;
-        const int dec = bk_decide(t.v1, t.v2, S->clen, t.rl, ds, de, tie);
-        t.dec = tie ? -1 : dec; t.ds = ds; t.de = de;
-    }
-    BK_SYNC();
-    if (BK_TID == 0) {
-        int m = 0, prev_dec = S->last_dec, lo = 0, hi = 0; bool any = false;
-        for (; m < nbt; m++) {
-            const BkAsmShared::Slot &t = S->slot[sl + m];
-            if (t.first) break;
-            if (sl + m > 0) {
-                const int pk = S->slot[sl + m - 1].kind;
-                const bool kind_ok = (pk == BK_PK_PRE && prev_dec == BK_DEC_PRE) || (pk == BK_PK_POST && prev_dec == BK_DEC_POST) ||
-                                     (pk == BK_PK_SAME && (prev_dec == BK_DEC_NONE || prev_dec == BK_DEC_SAME || prev_dec == BK_DEC_SUB));
-                if (!kind_ok || S->cbase != t.pb || S->clen != t.plen) break;
-            }
-            if (t.dec != BK_DEC_NONE && t.dec != BK_DEC_SAME && t.dec != BK_DEC_SUB) break;
-            if (t.dec == BK_DEC_SUB) { lo = any ? min(lo, t.ds) : t.ds; hi = max(hi, min(t.de, S->nlen)); any = true; }      // a run without a contained read has NO count range (not [INT_MAX, 0): lo + thread id would wrap)
-            prev_dec = t.dec;
+    const int cbase0 = S->cbase, clen0 = S->clen, nbase0 = S->nbase, nlen0 = S->nlen;      // read by every thread before thread 0 replaces them (two barriers on)
+    // wavefront 0, a lane per slot: the decision, whether the slot does what it may do here, whether the contig it was aligned
+    // against is what its predecessor leaves behind; the run = the slots before the first lane that says no.  The per-read
+    // words the bookkeeping at the end needs are asked for now (nobody writes them in between).
+    int my_u = 0, my_dec = BK_DEC_NONE, my_found = -1, my_ur = 0; uint32_t my_fl = 0, my_kc = 0; unsigned long long my_cells = 0;
+    if ((BK_TID >> 6) == 0) {
+        const int j = BK_TID;
+        const bool have = j < nbt;
+        bool ok = false; int dec = BK_DEC_NONE, pl = 0, a0 = 0, a1 = 0, cb_after = 0, cl_after = 0, pb = 0, plen = 0;
+        if (have) {
+            BkAsmShared::Slot &t = S->slot[sl + j];
+            my_u = t.u; my_fl = C_.ufl[my_u]; my_ur = C_.ureads[my_u]; my_kc = C_.kcnt[t.rank]; if (grow) my_found = C_.ufound[my_u];
+            pb = t.pb; plen = t.plen;
+            int ds, de; bool tie;
+            dec = bk_decide(t.v1, t.v2, plen, t.rl, ds, de, tie);
+            if (dec == BK_DEC_POST) { pl = max(t.rl - t.v1.i_end, 0); ds = t.v1.j_start; de = plen; }
+            else if (dec == BK_DEC_PRE) { pl = t.v2.j_start; ds = t.v2.i_start; de = t.v2.i_end; }
+            const int nb_ = nbase0 - (cbase0 - pb), nl_ = nlen0 + (plen - clen0);          // the count vectors move with the contig
+            ok = !t.first && !tie && dec != BK_DEC_SUPER && !(grow && pl >= 2);
+            if (dec == BK_DEC_POST) ok = ok && !(pb + plen + pl > 2 * C_.MAXC || plen + pl > C_.MAXC || nb_ + nl_ + pl > 2 * C_.MAXC);
+            else if (dec == BK_DEC_PRE) ok = ok && !(pb - pl < 0 || plen + pl > C_.MAXC || nb_ - pl < 0);
+            if (dec != BK_DEC_NONE && dec != BK_DEC_SAME) { a0 = nb_ + ds; a1 = max(nb_ + min(de, nl_), a0); }      // absolute span of the count update
+            cb_after = dec == BK_DEC_PRE ? pb - pl : pb; cl_after = (dec == BK_DEC_PRE || dec == BK_DEC_POST) ? plen + pl : plen;
+            my_dec = dec; my_cells = 2ull * (unsigned long long)plen * (unsigned long long)t.rl;
+            if (ok) { t.dec = dec; t.ds = a0; t.de = a1; t.hasn = pl; }      // hasn: only read when the slot is staged; from here on the length of the extension
         }
-        S->tmp0 = m; S->tmp1 = any ? lo : 0; S->tmp2 = any ? hi : 0;
+        // the contig this slot was aligned against = what the slot before it leaves (slot sl: the contig as it is)
+        int pcb = __shfl_up(cb_after, 1), pcl = __shfl_up(cl_after, 1), pdec = __shfl_up(dec, 1);
+        if (j == 0) { pcb = cbase0; pcl = clen0; pdec = S->last_dec; }
+        if (have) {
+            bool chain = pcb == pb && pcl == plen;
+            if (sl + j > 0) {
+                const int pk = S->slot[sl + j - 1].kind;
+                chain = chain && ((pk == BK_PK_PRE && pdec == BK_DEC_PRE) || (pk == BK_PK_POST && pdec == BK_DEC_POST) ||
+                                  (pk == BK_PK_SAME && (pdec == BK_DEC_NONE || pdec == BK_DEC_SAME || pdec == BK_DEC_SUB)));
+            }
+            ok = ok && chain;
+        }
+        const unsigned long long bad = ~__ballot(ok);
+        const int m = bad ? __ffsll((long long)bad) - 1 : 64;              // lanes >= nbt say no: m <= nbt
+        // span of all count updates of the run, geometry after its last slot
+        int lo = (j < m && a1 > a0) ? a0 : 0x7FFFFFFF, hi = (j < m && a1 > a0) ? a1 : 0;
+        for (int o = 1; o < 16; o <<= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }      // BK_SPEC <= 16 slots
+        if (j == 0) { S->tmp0 = m; S->tmp1 = hi > 0 ? lo : 0; S->tmp2 = hi; }
+        if (m > 0 && j == m - 1) { S->dstart = cb_after; S->dend = cl_after; }
     }
     BK_SYNC();
     const int m = S->tmp0;
     if (m == 0) return;
-    {
-        int32_t *io = bk_cnt_io(S->cbuf) + S->nbase, *ot = bk_cnt_ot(S->cbuf) + S->nbase;
-        const int nlen = S->nlen, lo = S->tmp1, hi = S->tmp2;
-        for (int t = lo + BK_TID; t < hi; t += BK_AT) {
-            int a = 0, b = 0;
-            for (int j = 0; j < m; j++) {
-                const BkAsmShared::Slot &q = S->slot[sl + j];
-                if (q.dec == BK_DEC_SUB && t >= q.ds && t < min(q.de, nlen)) { if (q.rindel) a += q.rn; else b += q.rn; }
-            }
-            if (a) io[t] += a;
-            if (b) ot[t] += b;
+    const int lo = S->tmp1, hi = S->tmp2, cbase1 = S->dstart, clen1 = S->dend;
+    int32_t *io = bk_cnt_io(S->cbuf), *ot = bk_cnt_ot(S->cbuf);
+    // new bases and their count entries: a wavefront per slot (the bases of all slots but the round's last were pre-written by the staging; the same bytes)
+    for (int j = BK_TID >> 6; j < m; j += BK_AT / 64) {
+        const BkAsmShared::Slot &q = S->slot[sl + j];
+        const int pl = q.hasn;
+        if ((q.dec != BK_DEC_POST && q.dec != BK_DEC_PRE) || pl == 0) continue;
+        const int nb_ = nbase0 - (cbase0 - q.pb), nl_ = nlen0 + (q.plen - clen0);
+        const uint8_t *rs = L_RSEQ_S(sl + j);
+        const int cat_io = q.rindel ? q.rn : 0, cat_ot = q.rindel ? 0 : q.rn;
+        if (q.dec == BK_DEC_POST) {
+            for (int t = BK_TID & 63; t < pl; t += 64) { L_CSEQ[q.pb + q.plen + t] = rs[q.rl - pl + t]; io[nb_ + nl_ + t] = cat_io; ot[nb_ + nl_ + t] = cat_ot; }
+        } else {
+            for (int t = BK_TID & 63; t < pl; t += 64) { L_CSEQ[q.pb - pl + t] = rs[t]; io[nb_ - pl + t] = cat_io; ot[nb_ - pl + t] = cat_ot; }
         }
+    }
+    BK_SYNC();
+    for (int t = lo + BK_TID; t < hi; t += BK_AT) {
+        int a = 0, b = 0;
+        for (int j = 0; j < m; j++) {
+            const BkAsmShared::Slot &q = S->slot[sl + j];
+            if (t >= q.ds && t < q.de) { if (q.rindel) a += q.rn; else b += q.rn; }      // empty span for a read that changes no count
+        }
+        if (a) io[t] += a;
+        if (b) ot[t] += b;
     }
     if ((BK_TID >> 6) == 0) {
         const int j = BK_TID;
         const bool have = j < m;
-        int u = 0, dec = BK_DEC_NONE; uint32_t fl = 0, kc = 0; int ur = 0, found = -1;
-        if (have) {
-            const BkAsmShared::Slot &q = S->slot[sl + j];
-            u = q.u; dec = q.dec; fl = C_.ufl[u]; ur = C_.ureads[u]; kc = C_.kcnt[q.rank]; if (grow) found = C_.ufound[u];
-        }
+        const int u = my_u, dec = my_dec;
         const bool match = have && dec != BK_DEC_NONE;
-        const bool to_list = match && ur != S->serial;
-        const bool to_alt = have && !match && kc > 2 && !(fl & BK_R_USED);
-        const unsigned long long lm = __ballot(to_list), am = __ballot(to_alt), below = (1ull << j) - 1ull;
+        const bool to_list = match && my_ur != S->serial;
+        const bool to_alt = have && !match && my_kc > 2 && !(my_fl & BK_R_USED);
+        const unsigned long long lm = __ballot(to_list), am = __ballot(to_alt), mm = __ballot(match), below = (1ull << j) - 1ull;
         if (have) {
             C_.ubuf[u] = S->serial;
             if (match) {
-                C_.ufl[u] = (uint8_t)(fl | BK_R_USED);
+                C_.ufl[u] = (uint8_t)(my_fl | BK_R_USED);
                 if (to_list) { C_.ureads[u] = S->serial; C_.readl[S->nr + __popcll(lm & below)] = (uint32_t)u; }
-                if (grow && found >= 0) { C_.pend[2 * found] = BK_EMPTY32; C_.ufound[u] = -1; }
+                if (grow && my_found >= 0) { C_.pend[2 * my_found] = BK_EMPTY32; C_.ufound[u] = -1; }
             } else if (to_alt) {
                 const int at = S->nalt + __popcll(am & below);
                 if (at < C_.MAXCAND) C_.altl[at] = (uint32_t)u; else S->status = BK_ST_CAND;
-            } else C_.ufl[u] = (uint8_t)(fl | BK_R_DELETED);
+            } else C_.ufl[u] = (uint8_t)(my_fl | BK_R_DELETED);
         }
+        unsigned long long cells = have ? my_cells : 0ull;
+        for (int o = 1; o < 16; o <<= 1) cells += __shfl_xor(cells, o);
         if (BK_TID == 0) {
             S->nr += __popcll(lm); S->nalt = min(S->nalt + __popcll(am), C_.MAXCAND);
-            for (int i = 0; i < m; i++) {
-                const BkAsmShared::Slot &q = S->slot[sl + i];
-                if (q.dec != BK_DEC_NONE) S->n_acc++; else S->n_rej++;
-                if (S->n_acc + S->n_rej >= 64) { S->n_acc >>= 1; S->n_rej >>= 1; }
-                S->cells += 2ull * (unsigned long long)S->clen * (unsigned long long)q.rl; S->calls += 2;
-            }
-            S->last_dec = S->slot[sl + m - 1].dec; S->hit = S->slot[sl + m - 1].dec != BK_DEC_NONE ? 1 : 0;
+            int na = S->n_acc, nr_ = S->n_rej;
+            for (int i = 0; i < m; i++) { if ((mm >> i) & 1ull) na++; else nr_++; if (na + nr_ >= 64) { na >>= 1; nr_ >>= 1; } }
+            S->n_acc = na; S->n_rej = nr_;
+            S->cells += cells; S->calls += 2 * m;
+            const bool lastm = ((mm >> (m - 1)) & 1ull) != 0;
+            S->last_dec = S->slot[sl + m - 1].dec; S->hit = lastm ? 1 : 0;
+            S->pc += cbase0 - cbase1;                                       // the recruiting k-mer moves with what was prepended
+            S->nbase = nbase0 - (cbase0 - cbase1); S->nlen = nlen0 + (clen1 - clen0); S->cbase = cbase1; S->clen = clen1;
 #ifdef BK_PHASE_STAMPS
             S->acc[17] += m;
 #endif
@@ -1122,7 +1162,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             // the reads that change nothing, together -- where there are runs of them: on clean data nearly every read
             // extends the contig by a base and the attempt only costs its two barriers (same-box A/B on the headline:
             // 1.82 ms with it always on, 1.70 ms without), so it waits until check_align has lately rejected most reads
-            if (!(C_.flags & BK_F_NO_RUN_RETIRE) && bk_expect_reject()) {
+            if (!(C_.flags & BK_F_NO_RUN_RETIRE) && (s1 - sl >= 2 || bk_expect_reject())) {
                 bk_retire_run(sl, s1, grow);
                 const int m = S->tmp0;
                 sl += m; q += m;
