@@ -66,9 +66,10 @@ struct BkAsmShared {
     int n_rej, n_acc;            // recent reads rejected / accepted by check_align: with most rejected, the prediction is "nothing changes"    // rounds the look-ahead stays off after a window in which most of its slots were wasted (doubles)
     int la_n[BK_WAVES], la_t[BK_WAVES], la_rank[BK_WAVES], la_pc[BK_WAVES];      // one look-ahead list per wavefront
     int qslot;                   // position in the region queue this workgroup is working on
+    int kscan;                   // contig k-mer list: the entries before this index are all in checked_kmers (grow snapshots only look at what came after)
     uint32_t scan[24];
 #ifdef BK_PHASE_STAMPS
-    unsigned long long acc[20], last; int ctx;
+    unsigned long long acc[24], last; int ctx;
 #endif
 };
 
@@ -317,7 +318,7 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
         q++;
     }
     BK_SYNC();
-    if (BK_TID == 0) { S->nk = base + (int)T; if (order == BK_ORD_MID) S->setup = 1; }
+    if (BK_TID == 0) { S->nk = base + (int)T; if (order == BK_ORD_MID) { S->setup = 1; S->kscan = 0; } }
     BK_SYNC();
     BK_ACC(5);
 }
@@ -436,7 +437,7 @@ __device__ inline void bk_contig_new(int rank, int u, bool in_fifo)             
     if (BK_TID == 0) {
         S->cbase = base; S->clen = len; S->nbase = base; S->nlen = len; S->cbuf = 0;
         S->serial = ++S->serial_ctr; S->setup = 0; S->founder = u; S->founder_added = 0; S->in_fifo = in_fifo ? 1 : 0;
-        S->nk = 0; S->nr = 0; S->nalt = 0;
+        S->nk = 0; S->nr = 0; S->nalt = 0; S->kscan = 0;
         C_.kstamp[3 * rank] = S->serial;                 // checked_kmers = [kmer_val]
         C_.ubuf[u] = S->serial;                          // buffer = set([read.id])
     }
@@ -1261,12 +1262,59 @@ __device__ __forceinline__ void bk_grow()
     for (;;) {
         if (S->status) return;
         // refresh_kmers :601-602 -> snapshot list
-        const int nk = S->nk;
+        const int nk = S->nk, k0 = S->kscan;
+        uint32_t T;
+        // Every k-mer of a snapshot is in checked_kmers when its visits are over, and the list only grows at its end (a
+        // replacement, set_kmers, starts it anew): the next snapshot can only hold what was appended since.  With sequencing
+        // noise that is a handful of k-mers after every extension, a snapshot per round -- one wavefront takes them, the
+        // candidate-less ones marked in the same pass (below), one barrier instead of seven.
+        const bool small = nk - k0 <= 64;
+        if (small) {
+            if ((BK_TID >> 6) == 0) {
+                const int idx = k0 + BK_TID;
+                uint32_t en = idx < nk ? C_.klist[idx] : 0u;
+                const bool unchecked = idx < nk && C_.kstamp[3 * (en & 0x7FFFFFFFu)] != S->serial;
+                const unsigned long long bm = __ballot(unchecked);
+                if (unchecked) {
+                    const int rank = (int)(en & 0x3FFFFFFFu);
+                    const uint32_t pb = C_.poff[rank], pe = C_.poff[rank + 1];
+                    bool has = pe - pb > 16u;
+                    for (uint32_t i = pb; !has && i < pe; i++) { const uint32_t u = C_.post[i] >> 10; has = !(C_.ufl[u] & BK_R_DELETED) && C_.ubuf[u] != S->serial; }
+                    if (!has) { C_.kstamp[3 * rank] = S->serial; en |= 0x40000000u; }
+                    C_.nklist[__popcll(bm & ((1ull << BK_TID) - 1ull))] = en;
+                }
+                if (BK_TID == 0) {
+#ifdef BK_PHASE_STAMPS
+                    S->acc[20] += 1; S->acc[22] += (unsigned long long)(nk - k0);
+#endif
+                    S->tmp0 = __popcll(bm); S->kscan = nk;
+                    if (bm) {
+                        if (!S->founder_added) { S->founder_added = 1; const int fu = S->founder; if (C_.ureads[fu] != S->serial) { C_.ureads[fu] = S->serial; C_.readl[S->nr++] = (uint32_t)fu; } }
+                        if (S->plan_kind == 0) S->plan_ok = 0;
+                    }
+                }
+            }
+            BK_SYNC();
+            T = (uint32_t)S->tmp0;
+            BK_ACC(13);
+            if (T == 0) break;
+        } else {
         const int chunk = (nk + BK_AT - 1) / BK_AT, b = BK_TID * chunk, e = min(nk, b + chunk);
-        uint32_t cnt = 0, T;
+        uint32_t cnt = 0;
+        if (chunk == 1) {                                   // the usual case: an entry per thread, looked at once
+            uint32_t en = 0;
+            if (b < e) { en = C_.klist[b]; cnt = C_.kstamp[3 * (en & 0x7FFFFFFFu)] != S->serial; }
+            const uint32_t pre = bk_scan256(cnt, S->scan, &T);
+            if (cnt) C_.nklist[pre] = en;
+        } else {
         for (int t = b; t < e; t++) cnt += C_.kstamp[3 * (C_.klist[t] & 0x7FFFFFFFu)] != S->serial;
         uint32_t pre = bk_scan256(cnt, S->scan, &T);
         for (int t = b; t < e; t++) { uint32_t en = C_.klist[t]; if (C_.kstamp[3 * (en & 0x7FFFFFFFu)] != S->serial) C_.nklist[pre++] = en; }
+        }
+#ifdef BK_PHASE_STAMPS
+        if (BK_TID == 0) { S->acc[21] += 1; S->acc[23] += (unsigned long long)nk; }
+#endif
+        if (BK_TID == 0) S->kscan = nk;
         BK_SYNC();
         BK_ACC(13);
         if (T == 0) break;
@@ -1291,6 +1339,7 @@ __device__ __forceinline__ void bk_grow()
         BK_SYNC();
         if (BK_TID == 0 && S->plan_kind == 0) S->plan_ok = 0;                      // a plan of visits refers to one snapshot (and one contig)
         BK_SYNC();
+        }
         uint32_t t = 0, en_next = C_.nklist[0];
         while (t < T) {
             if (S->status) return;
@@ -1452,7 +1501,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
         S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32; S->n_rej = 0; S->n_acc = 0;
 #ifdef BK_PHASE_STAMPS
-        for (int i = 0; i < 20; i++) S->acc[i] = 0; S->ctx = 0;
+        for (int i = 0; i < 24; i++) S->acc[i] = 0; S->ctx = 0;
         S->last = __builtin_amdgcn_s_memrealtime();
 #endif
         // per-region scratch from the arena
@@ -1512,6 +1561,9 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
     if (BK_TID == 0) { C_.wk->n_contigs = (uint32_t)S->n_contigs; C_.wk->nw_cells = S->cells; C_.wk->nw_calls = S->calls; if (S->status) C_.wk->status = S->status; }
 #ifdef BK_PHASE_STAMPS
     if (BK_TID == 0) for (int i = 0; i < 20; i++) C_.wk->stamps[i] = S->acc[i];
+#ifdef BK_SNAP_COUNT      // one-off: snapshots taken by one wavefront / by the workgroup, entries they looked at (in place of slots / retired / rounds / look-ahead counters)
+    if (BK_TID == 0) for (int i = 0; i < 4; i++) C_.wk->stamps[16 + i] = S->acc[20 + i];
+#endif
 #endif
 }
 
