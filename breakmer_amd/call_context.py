@@ -48,7 +48,7 @@ def region_lines(idx, query_region, target_repeat_mask, disc_reads, partners=(),
     for p in partners:
         out.append("partner %s %d" % (p[0], p[1]))
     if read_ids is not None and getattr(read_ids, "uniform_tag", None) is not None:
-        out.append("rtags " + ("0" * len(read_ids) if len(read_ids) else "0"))   # every id carries the same tag: one class
+        out.append("rtags 0")                                        # every id carries the same tag: one class (reads beyond the string read as class 0, bk_api.hip)
     elif read_ids is not None:                                       # classes of read.id.split("/")[1] (sv_caller.py:441)
         cls, tags = {}, []
         for rid in read_ids:
