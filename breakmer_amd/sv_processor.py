@@ -845,6 +845,21 @@ class runner(object):                                               # sv_process
         return eng
 
     def run(self, start_time=None):                                  # :174-209
+        # The batches make tens of thousands of small, short-lived, acyclic objects per second (targets, views, rows), and
+        # every so many allocations the cyclic collector walks EVERYTHING the process keeps alive to find nothing: in a
+        # process that has torch imported (bench.py, any torch.distributed launch) that was half of the driver's time --
+        # 15-17 k regions/s with the collector on, 30 k with it off, same box (tools/probes/runner_env_probe.py).  It is
+        # switched off for the duration of the run; what the run leaves behind is reference-counted like everything else.
+        import gc
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            return self._run(start_time)
+        finally:
+            if gc_was:
+                gc.enable()
+
+    def _run(self, start_time=None):
         names = self.create_targets()
         # Partition over the ranks: regions differ in cost by orders of magnitude (depth, noise, SV type), so the
         # targets are dealt heaviest first to the rank with the least load so far (cost = number of reads, known on every
