@@ -91,7 +91,7 @@ struct bk_handle {
     int n_failed = 0;                                // regions of the last run that hit a device limit (status per region)
     std::vector<int> host_status;                    // per region: limits only the host half of a stage can hit (BK_ST_BLOCKS, set by bk_call)
     BkParams params{};
-    bkcall::Context call_ctx; bool have_ctx = false; std::string calls_blob;
+    bkcall::Context call_ctx; bool have_ctx = false, have_tables = false; std::string calls_blob;
     // BK_SUBMIT_ASYNC: the submit runs on this thread; every later call on the handle joins it first (and reports its error)
     std::thread worker; bool has_worker = false; int worker_rc = 0; std::vector<bk_region> worker_regions;
 };
@@ -1012,8 +1012,14 @@ extern "C" int bk_set_call_context(bk_handle *h, const char *text)
 {
     BK_JOIN(h);
     if (!h || !text) return BK_E_ARG;
-    h->call_ctx = bkcall::Context(); std::string err;
+    bkcall::Tables prev = std::move(h->call_ctx.tables); const bool had = h->have_tables;
+    h->call_ctx = bkcall::Context(); h->have_ctx = false; h->have_tables = false; std::string err;
     if (!bkcall::parse_context(text, h->call_ctx, err)) return fail(h, BK_E_ARG, "bk_set_call_context: " + err);
+    if (h->call_ctx.keep_tables) {
+        if (!had) return fail(h, BK_E_STATE, "bk_set_call_context: keep_tables without an earlier context on this handle");
+        h->call_ctx.tables = std::move(prev);
+    }
+    h->have_tables = true;
     if ((int)h->call_ctx.regions.size() != h->n_regions) return fail(h, BK_E_ARG, "bk_set_call_context: region count differs from the submitted batch");
     h->have_ctx = true;
     return BK_OK;

@@ -478,7 +478,8 @@ inline bool target_hit(const Opts &o, const Region &rg, const Tables &tb, const 
 // ------------------------------------------------------------------------------------------------
 // text context: options, annotation tables, per-region query_region / repeat mask / discordant pairs
 struct Context {
-    Opts opts; Tables tables; std::vector<Region> regions; std::vector<std::vector<std::pair<std::string, int>>> partners; std::vector<std::string> rtags;
+    Opts opts; Tables tables; bool keep_tables = false;      // "keep_tables": the gene / repeat tables of the handle's previous context stay (the same for every batch of a run)
+    std::vector<Region> regions; std::vector<std::vector<std::pair<std::string, int>>> partners; std::vector<std::string> rtags;
     // single-contig section (CPU test entry)
     std::string c_id, c_seq; int c_nkmers = 0, c_same = 0; std::vector<int> c_io, c_ot, c_kl; std::vector<Psl> rows; bool has_offset = false; int offset = 0; bool has_tname = false; std::string tname;
 };
@@ -495,6 +496,7 @@ inline bool parse_context(const char *text, Context &cx, std::string &err)
         const std::string &k = t[0]; auto I = [&](size_t i) { return atoi(t[i].c_str()); };
         if (k == "opts" && t.size() >= 9) { cx.opts.indel_size = I(1); cx.opts.trl_sr = I(2); cx.opts.indel_sr = I(3); cx.opts.rearr_sr = I(4); cx.opts.rearr_minseg = I(5); cx.opts.trl_minseg = I(6); cx.opts.keep_intron = I(7); cx.opts.var_filter = I(8); }
         else if (k == "gene" && t.size() >= 5) cx.tables.genes.push_back({t[1], t[2], I(3), I(4)});
+        else if (k == "keep_tables") cx.keep_tables = true;
         else if (k == "arep_on") cx.tables.has_repeats = true;
         else if (k == "arep" && t.size() >= 5) cx.tables.repeats.push_back({t[1], I(2), I(3), I(4) != 0});
         else if (k == "region" && t.size() >= 6) { size_t idx = (size_t)I(1); if (cx.regions.size() <= idx) { cx.regions.resize(idx + 1); cx.partners.resize(idx + 1); cx.rtags.resize(idx + 1); } cur = &cx.regions[idx]; cur->chrom = t[2]; cur->start = I(3); cur->end = I(4); cur->name = t[5]; }

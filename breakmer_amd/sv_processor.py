@@ -691,6 +691,7 @@ class runner(object):                                               # sv_process
         self.status_exchange = status_exchange  # collate.exchange_status: every rank learns whether any rank failed BEFORE the collation
         self.assigned_cost = 0                  # sum of the cost estimates of this rank's targets
         self._ctx_head = None
+        self._ctx_token = object()              # which run's tables a handle holds (hip_backend's pool hands handles from run to run)
         self._pooled = []                       # handles to give back to hip_backend's pool when the run is over
         self.native_calls = native_calls        # SV-call tail in C++ (bk_call) instead of breakmer_amd/sv_caller.py; same rows
         self.engine = None
@@ -728,8 +729,14 @@ class runner(object):                                               # sv_process
         if self.native_calls and hasattr(eng, 'set_call_context'):
             from . import call_context as cc
             if self._ctx_head is None:                               # options + annotation tables: the same text for every batch
-                self._ctx_head = "\n".join([cc.opts_line(self.params.opts)] + cc.tables_lines(self.params.gene_annotations.genes, self.params.repeat_mask))
-            lines = [self._ctx_head]
+                self._ctx_opts = cc.opts_line(self.params.opts)
+                self._ctx_head = "\n".join([self._ctx_opts] + cc.tables_lines(self.params.gene_annotations.genes, self.params.repeat_mask))
+            # a handle keeps the tables of its previous context: they are sent (and parsed) once per handle and run
+            if getattr(eng, '_ctx_tables_of', None) is self._ctx_token and hasattr(eng, 'h'):
+                lines = [self._ctx_opts, "keep_tables"]
+            else:
+                lines = [self._ctx_head]
+                eng._ctx_tables_of = self._ctx_token
             for i, t in enumerate(live):
                 lines += cc.region_lines(i, t.get_values(), t.repeat_mask, t.disc_reads, t.partner_windows, t.data.read_ids)
             eng.set_call_context("\n".join(lines) + "\n")
@@ -881,18 +888,19 @@ class runner(object):                                               # sv_process
             mine = list(names)
         # Batching front-end: the reference handles one target at a time; here bounded batches of targets go through the HIP
         # library on up to three handles.  A batch is handed to the library one iteration before its kernels are launched
-        # (its 2-bit packing and H2D copies run on a thread of the library meanwhile); in between, this thread picks up the
-        # batch that is running (call tail, per-target objects, files).  Batches finish in the order they were started.
+        # (its 2-bit packing and H2D copies run on a thread of the library meanwhile); its kernels are launched BEFORE this
+        # thread picks up the batch launched one iteration earlier (call tail, per-target objects, files), so the GPU is never
+        # waited for.  Batches finish in the order they were started.
         bsz = max(1, int(self.params.opts.get('batch_regions', 256)))
         free, pending, running = [], [], []                         # handles; submitted batches; the launched batch
 
         def advance():
             eng, live = pending.pop(0)
-            if running:
+            self._launch_batch(eng, live)                            # the GPU starts on this batch ...
+            if running:                                               # ... while the one before it (long finished) is picked up
                 done = running.pop()
                 self._finish_batch(done[0], done[1], order)
                 free.append(done[0])
-            self._launch_batch(eng, live)
             running.append((eng, live))
 
         ok, failure = False, None

@@ -183,7 +183,8 @@ int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl *hits, int3
  * (sv_processor.py:823-866, sv_caller.py:785-833).  Host code; same semantics as breakmer_amd/sv_caller.py.
  * The context is a line-based text (breakmer_amd/call_context.py): options (breakmer.py:73-86), gene table
  * (utils.py:727-773), repeat masks (utils.py:302-353) and per region query_region / discordant pairs
- * (sv_processor.py:376-408) / placement of the partner windows / read-id classes. */
+ * (sv_processor.py:376-408) / placement of the partner windows / read-id classes.  A line `keep_tables` in place of the
+ * gene / repeat lines keeps the tables of the handle's previous context (they are the same for every batch of a run). */
 int bk_set_call_context(bk_handle *h, const char *text);
 int bk_call(bk_handle *h);                                      /* after bk_run: calls for every contig of the batch */
 int bk_get_calls(bk_handle *h, char *buf, size_t cap, size_t *needed);   /* "<region>\t<contig>\t<13 fields>\n" ... */
