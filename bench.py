@@ -522,6 +522,11 @@ def main():
                 oc["configs[4]"] = time_other_config(hb, regs4, 41, opts, 1, local)
                 oc["configs[4]"]["workload"] = "250 bp reads at 2,000x, k=41, 5 % substitution noise"
                 del regs4
+                # the standing round-1 bar: one launch of 64 configs[1]-shaped regions at 0.5 % substitution noise (< 0.1 s asked for)
+                regsn = [synth.make_region(50000 + i, depth=a.depth, L=a.read_len, sv_type="del", noise=0.005) for i in range(64)]
+                oc["noise_0.5pct_64_regions"] = time_other_config(hb, regsn, a.kmer, opts, 2, local)
+                oc["noise_0.5pct_64_regions"]["workload"] = "64 regions of the configs[1] shape with 0.5 % substitution noise per base, one launch (seconds per launch = ms_per_batch / 1000)"
+                del regsn
             except Exception as ex:                      # never lose the headline line to a side measurement
                 oc["error"] = repr(ex)
             out["other_configs"] = oc
