@@ -1036,7 +1036,10 @@ extern "C" int bk_call(bk_handle *h)
     h->calls_blob.clear();
     const bkcall::Context &cx = h->call_ctx;
     // regions are independent: a few host threads, results concatenated in region order
-    const int nthreads = std::max(1, std::min<int>({8, (int)std::thread::hardware_concurrency(), (h->n_regions + 31) / 32}));
+    // (a thread per 32 regions, or per 512 contigs where the regions are few and heavy: 64 noisy regions are 76,000 contigs)
+    uint64_t n_contigs = 0; for (int r = 0; r < h->n_regions; r++) n_contigs += h->h_work[r].n_contigs;
+    const int want = std::max<int>((h->n_regions + 31) / 32, (int)std::min<uint64_t>(n_contigs / 512, 16));
+    const int nthreads = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), h->n_regions, want}));
     std::vector<std::string> parts(h->n_regions);
     h->host_status.assign(h->n_regions, 0);
     auto work = [&](int t) {
