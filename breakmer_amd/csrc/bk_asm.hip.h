@@ -186,6 +186,24 @@ __device__ inline int bk_lookup(const BkKey &key)
     }
 }
 
+// ... and its state, asked for together with the key words: every table lookup of a noisy region's chain is a string of
+// dependent global round trips (slot -> key -> state), and this is one less
+__device__ inline int bk_lookup_state(const BkKey &key, uint32_t &state)
+{
+    state = 0;
+    if (C_.M == 0) return -1;
+    uint32_t s = key_hash(key) & C_.tmask;
+    for (;;) {
+        const uint32_t rk = C_.tslot[s];
+        if (rk == BK_EMPTY32) return -1;
+        if (rk != BK_EMPTY32 - 1) {                         // EMPTY-1: tombstone
+            const unsigned long long lo = C_.klo[rk], hi = C_.khi[rk]; const uint32_t st = C_.kstate[rk];
+            if (lo == key.lo && hi == key.hi) { state = st; return (int)rk; }
+        }
+        s = (s + 1) & C_.tmask;
+    }
+}
+
 __device__ inline uint32_t bk_scan256(uint32_t v, uint32_t *scr, uint32_t *total)
 {
     const int lane = BK_TID & 63, wv = BK_TID >> 6;
@@ -287,8 +305,8 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
     if (np > 2 * C_.MAXCAND) { bk_fail(BK_ST_KLIST); BK_SYNC(); return; }
     if (np <= 0 && order != BK_ORD_MID) return;         // a one-base extension has no new k-mer (Q1: range(0, L-k) of a window of k bases): nothing to append, six barriers saved
     for (int x = BK_TID; x < np; x += BK_AT) {
-        BkKey key; int rk = bk_bytes_kmer(L_CSEQ + s0 + x, k, key) ? bk_lookup(key) : -1;
-        if (rk >= 0 && C_.kstate[rk] == BK_K_REMOVED) rk = -1;          // not in akmers.smers_set
+        BkKey key; uint32_t st = 0; int rk = bk_bytes_kmer(L_CSEQ + s0 + x, k, key) ? bk_lookup_state(key, st) : -1;
+        if (rk >= 0 && st == BK_K_REMOVED) rk = -1;                     // not in akmers.smers_set
         tmp[x] = rk;
     }
     BK_SYNC();
@@ -1205,8 +1223,8 @@ BK_COLD void bk_check_alt_reads()
         // x = get_read_kmers(read) - used_mers - mer_set   (set(self.kmers) holds tuples: removes nothing)
         BkKey best; best.hi = ~0ull; best.lo = ~0ull; int bestrk = -1; int anyx = 0;
         for (int x = BK_TID; x < np; x += BK_AT) {
-            BkKey key; int rk = bk_bytes_kmer(L_RSEQ + x, k, key) ? bk_lookup(key) : -1;
-            if (rk >= 0 && (C_.kstate[rk] != BK_K_LIVE || C_.kstamp[3 * rk + 1] == fin)) rk = -1;
+            BkKey key; uint32_t st = 0; int rk = bk_bytes_kmer(L_RSEQ + x, k, key) ? bk_lookup_state(key, st) : -1;
+            if (rk >= 0 && (st != BK_K_LIVE || C_.kstamp[3 * rk + 1] == fin)) rk = -1;
             tmp[x] = rk;
             if (rk >= 0) { anyx = 1; if (C_.kcnt[rk] > 1 && key_lt(key, best)) { best = key; bestrk = rk; } }   // sorted(x) (P2): smallest mer with count > 1
         }
