@@ -51,6 +51,20 @@ static void make_batch(Batch &b, int n, int nreads, int L, unsigned seed, bool c
     }
 }
 
+// the same context with the annotation tables replaced by "keep_tables" (what the driver sends from the second batch of a run on)
+static std::string keep_variant(const std::string &ctx)
+{
+    std::string out; size_t pos = 0; bool said = false;
+    while (pos < ctx.size()) {
+        size_t nl = ctx.find('\n', pos); if (nl == std::string::npos) nl = ctx.size();
+        const std::string ln = ctx.substr(pos, nl - pos); pos = nl + 1;
+        if (ln.rfind("gene ", 0) == 0 || ln.rfind("arep", 0) == 0) continue;
+        out += ln; out += '\n';
+        if (!said && ln.rfind("opts ", 0) == 0) { out += "keep_tables\n"; said = true; }
+    }
+    return out;
+}
+
 static void one_handle(const std::string &dir, unsigned seed)
 {
     bk_config cfg{}; cfg.abi_version = BK_ABI_VERSION; cfg.kmer_size = 31; cfg.rc_thresh = 2;
@@ -72,8 +86,10 @@ static void one_handle(const std::string &dir, unsigned seed)
             CHECK(bk_get_contig_count(h, r, &nc) == BK_OK && nc == 0);
             bk_contig_info info; CHECK(bk_get_contig_info(h, r, 0, &info) != BK_OK);       // no such contig: an error, not a crash
         }
+        if (round == 0) CHECK(bk_set_call_context(h, keep_variant(ctx8).c_str()) == BK_E_STATE);     // keep_tables before the handle has seen any tables
         CHECK(bk_set_call_context(h, (n == 8 ? ctx8 : ctx5).c_str()) == BK_OK);
         CHECK(bk_set_call_context(h, (n == 8 ? ctx5 : ctx8).c_str()) != BK_OK);            // region count mismatch is refused
+        if (round >= 1) CHECK(bk_set_call_context(h, keep_variant(n == 8 ? ctx8 : ctx5).c_str()) == BK_OK);      // the tables of the context before stay
         CHECK(bk_set_call_context(h, (n == 8 ? ctx8 : ctx5).c_str()) == BK_OK);
         CHECK(bk_fetch(h) == BK_OK);
         CHECK(bk_call(h) == BK_OK);
