@@ -53,6 +53,32 @@ def test_runner_matches_reference_rows(tmp_path, golden_dir):
             assert lines[0].split("\t") == sp.HEADER_FIELDS and lines[1].split("\t") == rows[0]
 
 
+def test_runner_leaves_the_garbage_collector_as_it_found_it(tmp_path):
+    """runner.run switches the cyclic collector off while it runs (its passes over a large heap were half of the driver's time
+    in a process with torch imported) and restores the state it found -- on success and on failure"""
+    import gc
+    cfg, data = make_inputs(tmp_path, [(3, "del")])
+    seen = []
+
+    class Watching(FakeEngine):
+        def submit(self, *a, **k):
+            seen.append(gc.isenabled())
+            return FakeEngine.submit(self, *a, **k)
+
+    for was in (True, False):
+        (gc.enable if was else gc.disable)()
+        try:
+            sp.runner(cfg, region_data=data, engine_factory=lambda prm: Watching(prm.get_kmer_size(), prm.get_sr_thresh('min'))).run()
+            assert gc.isenabled() == was
+            bad = sp.runner(cfg, region_data=data, engine_factory=lambda prm: (_ for _ in ()).throw(RuntimeError("no device")))
+            with pytest.raises(RuntimeError):
+                bad.run()
+            assert gc.isenabled() == was
+        finally:
+            gc.enable()
+    assert seen and not any(seen)
+
+
 def test_config_and_cli_parsing(tmp_path):
     from breakmer_amd import breakmer
     (tmp_path / "c.cfg").write_text("analysis_name=x\nkmer_size=31\n")
