@@ -19,7 +19,7 @@ def _stale(target, deps):
 
 def build_hip(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "breakmer_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "breakmer_hip.h")]
     if force or _stale(HIP_LIB, deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result",
                "-o", HIP_LIB, HIP_SRC]
