@@ -9,7 +9,7 @@ touches the GPU) and exits with its code; under a launcher (RANK set) the proces
 A "step" is one pass of the hot path (read grouping -> k-mer selection -> assembly -> realign on the GPU,
 SV-call tail in host C++) over one batch of synthetic regions, inputs already packed and resident in HBM:
   N = 1 : BASELINE.json configs[1], 256 regions x 10,000 x 150 bp reads (500x), planted 200 bp deletion, k = 31;
-  N > 1 : 512 regions per GPU per step (N = 8 is configs[2]: 4,096 regions sharded region-per-GPU).
+  N > 1 : the SAME 256 regions per GPU per step (N = 8: configs[2]'s 4,096 regions sharded region-per-GPU = two steps of 8 x 256).
 Regions are independent, so ranks get disjoint region ids (weak scaling) and the only exchange is the
 all-gather of the per-region result records at the end of each step.  Rank 0 prints ONE JSON line.
 """
@@ -41,7 +41,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--regions", type=int, default=0, help="regions per GPU per step (0: 256 = configs[1] at one GPU, 512 at several: configs[2] at 8)")
+    ap.add_argument("--regions", type=int, default=0, help="regions per GPU per step (0: 256 = configs[1] on every GPU, whatever N: the scaling curve compares equal per-GPU batches)")
     ap.add_argument("--depth", type=int, default=500)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--kmer", type=int, default=31)
@@ -264,10 +264,13 @@ def main():
             td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
         else:
             td.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from breakmer_amd import hip_backend as hb, synth
+    from breakmer_amd import hip_backend as hb, synth, collate
     if a.lib:
         hb.LIB_PATH = os.path.abspath(a.lib)
-    n_regions = a.regions if a.regions > 0 else (256 if world == 1 else 512)
+    # The SAME batch per GPU per step at every N (weak scaling: the 1 -> 8 GPU curve compares like with like; a larger batch
+    # raises per-GPU throughput by itself on this latency-bound path).  256 = configs[1] on each GPU; at N = 8 configs[2]'s
+    # 4,096 regions are two consecutive steps of 8 x 256 (with 6 steps in flight 1,536 regions per GPU are resident anyway).
+    n_regions = a.regions if a.regions > 0 else 256
 
     # ---- inputs: disjoint region ids per rank (weak scaling), packed + resident before timing -------
     ids = range(rank * n_regions, (rank + 1) * n_regions)
@@ -326,16 +329,7 @@ def main():
         gstate["n"] += 1
         if sl["work"] is not None:
             sl["work"].wait()
-        need = 8 + sum(8 + b.size for b in blobs)
-        if need > CAP:
-            raise RuntimeError("collation records larger than %d bytes" % CAP)
-        hv = sl["host"].numpy()
-        hv[:8] = np.frombuffer(np.int64(len(blobs)).tobytes(), dtype=np.uint8)
-        o = 8
-        for b in blobs:
-            hv[o:o + 8] = np.frombuffer(np.int64(b.size).tobytes(), dtype=np.uint8)
-            hv[o + 8:o + 8 + b.size] = b
-            o += 8 + b.size
+        _hv, o = collate.frame_steps(blobs, CAP, out=sl["host"].numpy())
         sl["dev"][:o].copy_(sl["host"][:o], non_blocking=True)
         sl["work"] = td.all_gather_into_tensor(sl["out"], sl["dev"], async_op=True)
 
@@ -356,19 +350,8 @@ def main():
                 sl["work"] = None
         if slots and gstate["n"]:
             sl = slots[(gstate["n"] - 1) % 2]
-            allb = sl["out"].view(world, CAP).cpu().numpy()
-            parts = []
-            for r in range(world):
-                row = allb[r]
-                ns = int(np.frombuffer(row[:8].tobytes(), dtype=np.int64)[0])
-                o = 8
-                last = b""
-                for _i in range(ns):
-                    n = int(np.frombuffer(row[o:o + 8].tobytes(), dtype=np.int64)[0])
-                    last = row[o + 8:o + 8 + n].tobytes()
-                    o += 8 + n
-                parts.append(last)
-                tot += len(last)
+            parts = [steps[-1] if steps else b"" for steps in collate.deframe_gathered(sl["out"].cpu().numpy(), world, CAP)]
+            tot = sum(len(x) for x in parts)
             gstate["last"] = b"".join(parts)
         gstate["collated"] = tot
         return tot
@@ -476,10 +459,10 @@ def main():
             "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%s: %d regions/GPU x %d reads x %d bp (%dx), planted 200 bp deletion, k=%d"
-                                   % ("configs[1]" if world == 1 else ("configs[2]" if world * n_regions == 4096 else "configs[2]-shaped"),
+                                   % ("configs[1]" if world == 1 else ("configs[2] (4,096 regions = %d steps)" % (4096 // (world * n_regions)) if 4096 % (world * n_regions) == 0 else "configs[2]-shaped"),
                                       n_regions, regions[0].reads.shape[0], a.read_len, a.depth, a.kmer),
                        "stages": "group reads + k-mer select + assemble (olc.nw) + realign on the GPU, SV-call tail in host C++, rows collated",
-                       "regions_total_per_step": n_regions * world,
+                       "regions_per_gpu_per_step": n_regions, "regions_total_per_step": n_regions * world,
                        "sv_calls_per_step": last_rows.get("n", 0),
                        "steps_in_flight": len(engs),
                        "asm_workgroup_threads": int(eng.stat(25)), "asm_workgroups_per_cu": int(eng.stat(23)),

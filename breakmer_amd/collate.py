@@ -45,3 +45,43 @@ def exchange_status(err, device=None):
     in a collective for a rank that is gone."""
     parts = all_gather_bytes(json.dumps(err).encode(), device)
     return [json.loads(p.decode()) for p in parts]
+
+
+# ---- framed step buffers (bench.py's multi-rank path): the records of several steps travel in ONE fixed-capacity buffer per
+#      rank, [n_steps:int64 | (length:int64, records)*], gathered with all_gather_into_tensor (equal sizes: no size exchange)
+def frame_steps(blobs, cap, out=None):
+    """-> (uint8 numpy array of `cap` bytes, bytes used).  `blobs`: one bytes-like / uint8 array per step, step order;
+    `out`: write into this uint8 array of at least `cap` bytes (a pinned staging buffer) instead of a fresh one."""
+    import numpy as np
+    need = 8 + sum(8 + len(b) for b in blobs)
+    if need > cap:
+        raise RuntimeError("collation records larger than %d bytes" % cap)
+    hv = np.zeros(cap, dtype=np.uint8) if out is None else out
+    hv[:8] = np.frombuffer(np.int64(len(blobs)).tobytes(), dtype=np.uint8)
+    o = 8
+    for b in blobs:
+        b = np.frombuffer(bytes(b), dtype=np.uint8) if not hasattr(b, "dtype") else b
+        hv[o:o + 8] = np.frombuffer(np.int64(b.size).tobytes(), dtype=np.uint8)
+        hv[o + 8:o + 8 + b.size] = b
+        o += 8 + b.size
+    return hv, o
+
+
+def deframe_steps(row):
+    """one rank's framed buffer -> list of bytes, one per step (step order)"""
+    import numpy as np
+    row = np.asarray(row, dtype=np.uint8)
+    ns = int(np.frombuffer(row[:8].tobytes(), dtype=np.int64)[0])
+    o, out = 8, []
+    for _ in range(ns):
+        n = int(np.frombuffer(row[o:o + 8].tobytes(), dtype=np.int64)[0])
+        out.append(row[o + 8:o + 8 + n].tobytes())
+        o += 8 + n
+    return out
+
+
+def deframe_gathered(allbuf, world, cap):
+    """the output of all_gather_into_tensor over the ranks' framed buffers -> per rank (rank order) the list of its steps"""
+    import numpy as np
+    a = np.asarray(allbuf, dtype=np.uint8).reshape(world, cap)
+    return [deframe_steps(a[r]) for r in range(world)]

@@ -472,3 +472,51 @@ def test_soft_masked_refseq_file_is_read_upper_case(tmp_path):
     assert sp.read_fasta_first(fn) == "ACGTNNACGTGGCCAATT"
     fn = refseq.extract_refseq_fa(("1", 204, 212, "T1", []), str(tmp_path / "ref"), fa, "reverse")
     assert open(fn).read() == ">T1\nAATTggccACGTnnacgt\n"
+
+
+def _frame_rank(rank, world, port, q):
+    """one rank of the bench.py collation: frame this rank's steps, all_gather_into_tensor, de-frame every rank's buffer"""
+    import numpy as np
+    import torch
+    import torch.distributed as td
+    from breakmer_amd import collate
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cap = 4096
+        steps = [("rank%d step%d " % (rank, s)).encode() * (s + 1 + rank) for s in range(3 + rank)]      # ragged: counts and lengths differ per rank
+        steps.insert(1, b"")                                                                              # a step without a call
+        hv, used = collate.frame_steps([np.frombuffer(b, dtype=np.uint8) for b in steps], cap)
+        dev = torch.from_numpy(hv.copy())
+        out = torch.zeros(world * cap, dtype=torch.uint8)
+        td.all_gather_into_tensor(out, dev)
+        got = collate.deframe_gathered(out.numpy(), world, cap)
+        q.put((rank, used, got, steps))
+    finally:
+        td.destroy_process_group()
+
+
+def test_framed_step_buffers_of_two_ranks_deframe_in_rank_order_gloo():
+    """bench.py's multi-rank collation ([n_steps | (length, records)*] per rank, one all_gather_into_tensor of fixed-capacity
+    buffers): two gloo ranks with different step counts and record lengths; every rank recovers every rank's steps, in rank
+    order and step order, byte for byte."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frame_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert not p.is_alive()
+    want = [res[0][3], res[1][3]]
+    for rank, used, got, _mine in res:
+        assert got == want, rank
+        assert used == 8 + sum(8 + len(b) for b in want[rank])
+    from breakmer_amd import collate
+    with pytest.raises(RuntimeError):
+        collate.frame_steps([b"x" * 100], 64)
