@@ -41,6 +41,8 @@ using at512::bk_nw_batch_kernel;
 #include <vector>
 
 static std::string g_create_err;
+#define BK_MAX_CONTIG_ABS 32704      // the realign kernel's 64-bit hit key holds 15 bits of query position
+#define BK_LDS_MAX (160 * 1024)      // LDS of a gfx950 CU = the most one workgroup can have
 
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
@@ -62,6 +64,10 @@ struct HostVec {            // pinned host mirror of the result arena (faster D2
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; }
 };
 
+// One target window as the host keeps it for the chaining: the bases upper-cased, and where the caller's FASTA was soft-masked
+// (lower case: BLAT's -repeats=lower, sv_processor.py:843) a 0/1 byte per base -- a match on such a base counts as repMatches.
+struct BkTarget { std::string seq; std::string soft; bool masked(int i) const { return !soft.empty() && soft[(size_t)i] != 0; } size_t size() const { return seq.size(); } char operator[](size_t i) const { return seq[i]; } const char *c_str() const { return seq.c_str(); } };
+
 struct bk_handle {
     int dev = 0; hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
     bk_config cfg{}; std::string err;
@@ -82,14 +88,15 @@ struct bk_handle {
     HostVec hs_reads, hs_rlen, hs_rflag;        // pinned staging of a submit (packed reads, lengths, flags): kept and reused, so a
                                                 // submit neither page-faults a fresh 100 MB vector nor copies from pageable memory
     std::vector<BkPartnerDesc> h_part;
-    std::vector<std::vector<std::string>> h_targets;      // per region: target window + partner windows (ASCII), for PSL assembly
+    std::vector<std::vector<BkTarget>> h_targets;         // per region: target window + partner windows (upper case + soft-mask flags), for PSL assembly
     uint32_t max_win = 0;
     int eff_max_read = 64;          // batch maximum read length rounded up to 32: sizes the assembler's LDS buffers (occupancy)
     uint64_t total_reads = 0, alg_bytes = 0;
     float ms[4] = {0, 0, 0, 0};
     double submit_pack_ms = 0, submit_h2d_ms = 0;   // host 2-bit packing / host-to-device copies of the last bk_submit_regions
     int n_failed = 0;                                // regions of the last run that hit a device limit (status per region)
-    std::vector<int> host_status;                    // per region: limits only the host half of a stage can hit (BK_ST_BLOCKS, set by bk_call)
+    int n_escalated = 0;                             // regions of the last run that were run again with larger assembler caps
+    DevBuf d_rmap;                                   // their indices (k-mer kernels of the re-run)
     BkParams params{};
     bkcall::Context call_ctx; bool have_ctx = false, have_tables = false; std::string calls_blob;
     // BK_SUBMIT_ASYNC: the submit runs on this thread; every later call on the handle joins it first (and reports its error)
@@ -131,8 +138,8 @@ extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
     if (h->cfg.max_candidates <= 0) h->cfg.max_candidates = 2048;
     if (h->cfg.sw_min_score <= 0) h->cfg.sw_min_score = 20;
     if (h->cfg.rc_thresh <= 0) h->cfg.rc_thresh = 2;
-    if (h->cfg.max_read_len > 1024 || h->cfg.max_contig_len > 4095 + 1 || h->cfg.max_contig_len > 2 * h->cfg.max_candidates) {
-        delete h; return fail(nullptr, BK_E_ARG, "bk_create: limits: max_read_len <= 1024, max_contig_len <= 4096 and <= 2*max_candidates");
+    if (h->cfg.max_read_len > 1024 || h->cfg.max_contig_len > BK_MAX_CONTIG_ABS || h->cfg.max_contig_len > 2 * h->cfg.max_candidates) {
+        delete h; return fail(nullptr, BK_E_ARG, "bk_create: limits: max_read_len <= 1024, max_contig_len <= 32,704 and <= 2*max_candidates");
     }
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, BK_E_HIP, "stream creation failed"); }
     for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { (void)bk_destroy(h); return fail(nullptr, BK_E_HIP, "event creation failed"); }
@@ -147,7 +154,7 @@ extern "C" int bk_destroy(bk_handle *h)
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
-                      &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist, &h->d_nlist, &h->d_wnlist};
+                      &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist, &h->d_nlist, &h->d_wnlist, &h->d_rmap};
     for (auto b : bufs) b->release();
     h->h_out.release(); h->hs_reads.release(); h->hs_rlen.release(); h->hs_rflag.release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -162,6 +169,9 @@ extern "C" int bk_destroy(bk_handle *h)
 // branch and the flag bits of the whole word are tested once.
 struct BkPackLut { uint8_t v[256]; BkPackLut() { for (int i = 0; i < 256; i++) v[i] = 8; v[(int)'A'] = 0; v[(int)'C'] = 1; v[(int)'G'] = 2; v[(int)'T'] = 3; v[(int)'N'] = 4; } };
 static const BkPackLut g_pack_lut;
+// reference / partner windows: soft-masked (lower-case) bases are the same bases (BLAT's -repeats=lower only reports matches on them separately)
+struct BkWinLut { uint8_t v[256]; BkWinLut() { for (int i = 0; i < 256; i++) v[i] = 8; const char *u = "ACGTN", *l = "acgtn"; for (int i = 0; i < 5; i++) { v[(int)u[i]] = (uint8_t)i; v[(int)l[i]] = (uint8_t)i; } } };
+static const BkWinLut g_win_lut;
 struct BkCodeLut { uint8_t v[256]; BkCodeLut() { for (int i = 0; i < 256; i++) v[i] = 8; for (int i = 0; i < 5; i++) v[i] = (uint8_t)i; } };   // bytes are base codes 0..3, 4 = N
 static const BkCodeLut g_code_lut;
 // 16 bases -> one word with SSSE3 (two multiply-adds fold 16 two-bit codes, one byte shuffle orders them); returns false
@@ -187,9 +197,9 @@ __attribute__((target("ssse3"))) static inline bool pack16_ssse3(const unsigned 
 }
 static const bool g_have_ssse3 = __builtin_cpu_supports("ssse3");
 
-static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vector<uint32_t> *nlist = nullptr, uint32_t tag = 0, bool codes = false)
+static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vector<uint32_t> *nlist = nullptr, uint32_t tag = 0, bool codes = false, bool window = false)
 {
-    const uint8_t *lut = codes ? g_code_lut.v : g_pack_lut.v; const unsigned char *u = (const unsigned char *)s;
+    const uint8_t *lut = codes ? g_code_lut.v : window ? g_win_lut.v : g_pack_lut.v; const unsigned char *u = (const unsigned char *)s;
     int i = 0, wi = 0;
     for (; i + 16 <= len; i += 16, wi++) {
         if (g_have_ssse3 && pack16_ssse3(u + i, codes, w + wi)) continue;
@@ -225,6 +235,7 @@ extern "C" int bk_pack_sequence(const char *seq, int32_t len, uint32_t flags, ui
     return BK_OK;
 }
 
+static BkTarget make_target(const char *s, int len);
 template <class T> static hipError_t upload(bk_handle *h, DevBuf &b, const std::vector<T> &v)
 {
     hipError_t e = b.ensure(std::max<size_t>(v.size() * sizeof(T), 256));
@@ -262,9 +273,9 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     const int k = h->cfg.kmer_size;
     // a failed submit leaves the handle without a batch (never the old device results paired with new host mirrors):
     // the new host mirrors are built in locals and swapped in on success only
-    h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->hold_snapshot = false; h->have_ctx = false; h->host_status.clear();
+    h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->hold_snapshot = false; h->have_ctx = false;
     std::vector<uint32_t> sc, win, wnlist; std::vector<uint16_t> sclen;
-    std::vector<BkRegionDesc> n_desc(n_regions, BkRegionDesc{}); std::vector<BkPartnerDesc> n_part; std::vector<std::vector<std::string>> n_targets(n_regions);
+    std::vector<BkRegionDesc> n_desc(n_regions, BkRegionDesc{}); std::vector<BkPartnerDesc> n_part; std::vector<std::vector<BkTarget>> n_targets(n_regions);
     uint32_t n_max_win = 0; uint64_t n_alg_bytes = 0;
     uint64_t dd_total = 0; uint32_t max_w = 0;
     size_t tot_reads = 0, tot_words = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;
@@ -327,22 +338,22 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
         {   // an N of the window (an assembly gap near the target) is packed as code 0 and listed: its k-mers do not exist, it matches nothing
             size_t nw = (g.window_len + 15) / 16 + 2; win.resize(win.size() + nw);
             std::vector<uint32_t> wn;
-            if (!pack_seq(g.window, g.window_len, win.data() + d.win_word_off, (int)nw, &wn, 0)) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": character other than A/C/G/T/N in the reference window");
+            if (!pack_seq(g.window, g.window_len, win.data() + d.win_word_off, (int)nw, &wn, 0, false, true)) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": character other than A/C/G/T/N in the reference window");
             d.win_n_off = wnlist.size(); d.n_win_n = (uint32_t)wn.size(); wnlist.insert(wnlist.end(), wn.begin(), wn.end());
         }
         max_w = std::max<uint32_t>(max_w, g.window_len);
         n_max_win = std::max<uint32_t>(n_max_win, g.window_len);
-        n_targets[r].emplace_back(g.window, g.window_len);
+        n_targets[r].push_back(make_target(g.window, g.window_len));
         if (g.n_partners > 15) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 15 partner windows");
         d.n_partners = g.n_partners; d.part_desc_off = n_part.size();
         for (int q = 0; q < g.n_partners; q++) {
             BkPartnerDesc pd; pd.word_off = win.size(); pd.len = g.partner_lens[q];
             size_t nw = (pd.len + 15) / 16 + 2; win.resize(win.size() + nw);
             std::vector<uint32_t> wn;
-            if (!pack_seq(g.partners[q], pd.len, win.data() + pd.word_off, (int)nw, &wn, 0)) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": character other than A/C/G/T/N in a partner window");
+            if (!pack_seq(g.partners[q], pd.len, win.data() + pd.word_off, (int)nw, &wn, 0, false, true)) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": character other than A/C/G/T/N in a partner window");
             pd.n_off = wnlist.size(); pd.n_n = (uint32_t)wn.size(); wnlist.insert(wnlist.end(), wn.begin(), wn.end());
             n_part.push_back(pd);
-            n_targets[r].emplace_back(g.partners[q], pd.len); n_max_win = std::max<uint32_t>(n_max_win, pd.len);
+            n_targets[r].push_back(make_target(g.partners[q], (int)pd.len)); n_max_win = std::max<uint32_t>(n_max_win, pd.len);
         }
         uint32_t cap = 64; while ((uint64_t)cap * 7 < (uint64_t)std::max(g.n_reads, 1) * 10) cap <<= 1;      // load factor <= 0.7 even if every read is unique
         d.dedup_cap = cap; d.dedup_off = dd_total; dd_total += cap;
@@ -448,28 +459,61 @@ static void fill_params(bk_handle *h)
     p.order = (uint32_t *)h->d_order.p; p.clist = (unsigned long long *)h->d_clist.p; p.clist_cap = h->d_clist.bytes / 8;
     p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->eff_max_read;
     p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions; p.flags = h->cfg.reserved[0];
+    p.rmap = nullptr;
 }
 
-static size_t asm_lds_bytes(const bk_handle *h, int threads)
+static size_t asm_lds_bytes(const bk_handle *h, int threads, int max_cand, int max_contig)
 {
     const size_t waves = threads / 64, slots = threads == 512 ? waves : 2 * waves;      // the 256-thread build aligns two reads per wavefront (BK_PAIR)
     size_t o = threads == 512 ? at512::ctx_shared_bytes : at256::ctx_shared_bytes;
-    o += (size_t)h->cfg.max_candidates * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)h->cfg.max_candidates * 4 + (size_t)2 * h->cfg.max_contig_len + slots * (h->eff_max_read + 16);
+    o += (size_t)max_cand * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)max_cand * 4 + (size_t)2 * max_contig + slots * (h->eff_max_read + 16);
     return (o + 15) / 16 * 16;
 }
+// LDS of the realign kernel for a contig cap and a target staging capacity (bases)
+static size_t sw_lds_bytes(int max_contig, uint32_t tw_cap)
+{
+    const size_t mh = (size_t)bk_sw_max_hits(max_contig);
+    return ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)max_contig + 15) / 16) * 16 + 4 * (4 * ((size_t)max_contig / 16 + 2) + 2 * (tw_cap / 16 + 8))      // staged target words + their N mask
+           + mh * sizeof(BkHit) + 2 * (2 * mh + 4) * sizeof(int);                                                                                                     // step-1 hits + interval stack
+}
+// The caps of the re-run of regions that overflowed one (bk_get_region_status): 4x the configured ones as far as one 512-thread
+// workgroup's LDS (the whole CU's) holds them.  false: nothing larger fits (very long reads), the regions fail as they are.
+static bool escalated_caps(const bk_handle *h, int &max_cand, int &max_contig)
+{
+    max_cand = 4 * h->cfg.max_candidates; max_contig = std::min(4 * h->cfg.max_contig_len, BK_MAX_CONTIG_ABS);
+    while (max_cand > h->cfg.max_candidates && asm_lds_bytes(h, 512, max_cand, std::min(max_contig, 2 * max_cand)) > BK_LDS_MAX) max_cand /= 2;
+    max_contig = std::min(max_contig, 2 * max_cand);
+    return max_cand > h->cfg.max_candidates || max_contig > h->cfg.max_contig_len;
+}
 
-static int launch(bk_handle *h, uint32_t mask)
+// subset == nullptr: the whole batch.  Else: only these regions, from the k-mer stage on (it resets their state), with the
+// escalated caps, on top of what the batch's run left in the arenas (bump pointers and the contig list go on).
+static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subset = nullptr)
 {
     // every contig record takes >= 256 B of the result arena, so out_cap / 256 list entries can never overflow
     HIPCHK(h, h->d_clist.ensure(std::max<uint64_t>(h->out_cap / 256, 1024) * 8));
     uint32_t npad = 1; while ((int)npad < h->n_regions) npad <<= 1;
     HIPCHK(h, h->d_order.ensure((size_t)h->n_regions * 4)); HIPCHK(h, h->d_skeys.ensure((size_t)npad * 8));
     fill_params(h);
-    static const unsigned long long tops[5] = {256, 256, 0, 0, 0};      // arena top, out top, contigs listed, region queue head, contig queue head
-    HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
+    const int n_launch = subset ? (int)subset->size() : h->n_regions;
+    int max_cand = h->cfg.max_candidates, max_contig = h->cfg.max_contig_len;
+    if (subset) {
+        escalated_caps(h, max_cand, max_contig);
+        HIPCHK(h, h->d_rmap.ensure(subset->size() * 4));
+        HIPCHK(h, hipMemcpyAsync(h->d_rmap.p, subset->data(), subset->size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_order.p, subset->data(), subset->size() * 4, hipMemcpyHostToDevice, h->stream));      // the assembler's queue: these regions, in index order
+        unsigned long long tops[5];
+        HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
+        tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 8);      // region queue from its start; the realigner goes on behind the contigs it has seen
+        HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        h->params.rmap = (const uint32_t *)h->d_rmap.p; h->params.n_regions = n_launch; h->params.max_cand = max_cand; h->params.max_contig = max_contig;
+    } else {
+        static const unsigned long long tops[5] = {256, 256, 0, 0, 0};      // arena top, out top, contigs listed, region queue head, contig queue head
+        HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     // workgroup sizes: latency mode (one batch at a time) or throughput mode (batches in flight / a batch that fills the chip)
-    const int asm_threads = h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions > 2 * h->n_cu ? 256 : 512);      // more regions than 512-thread workgroups can be resident at once (2 per CU): the smaller ones keep them all in flight
+    const int asm_threads = subset ? 512 : h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions > 2 * h->n_cu ? 256 : 512);      // more regions than 512-thread workgroups can be resident at once (2 per CU): the smaller ones keep them all in flight
     const int kmer_threads = asm_threads == 512 ? BK_KT_MAX : BK_KT;
     if (mask & BK_STAGE_KMER) {
         if (h->n_big < h->n_regions) {
@@ -477,33 +521,35 @@ static int launch(bk_handle *h, uint32_t mask)
             const uint32_t lds_words = std::max<uint32_t>(32 + 256 + 2 * h->win_words_cap + h->ref_cap, h->group_words);
             const size_t lds = (size_t)lds_words * 4;
             HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(bk_kmer_kernel, dim3(h->n_regions), dim3(kmer_threads), lds, h->stream, h->params, h->ref_cap, h->win_words_cap, lds_words);
+            hipLaunchKernelGGL(bk_kmer_kernel, dim3(n_launch), dim3(kmer_threads), lds, h->stream, h->params, h->ref_cap, h->win_words_cap, lds_words);
             HIPCHK(h, hipGetLastError());
         }
         if (h->n_big > 0) {
             const size_t lds = (32 + 256 + (size_t)BK_K_PERM_G) * 4;
             HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(bk_kmer_kernel_g, dim3(h->n_regions), dim3(kmer_threads), lds, h->stream, h->params);
+            hipLaunchKernelGGL(bk_kmer_kernel_g, dim3(n_launch), dim3(kmer_threads), lds, h->stream, h->params);
             HIPCHK(h, hipGetLastError());
         }
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if (mask & BK_STAGE_ASSEMBLE) {
         // regions ordered by estimated cost, heaviest first (part of the assembler's measured time: ev[1]..ev[2])
-        hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad);
-        HIPCHK(h, hipGetLastError());
+        if (!subset) {
+            hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad);
+            HIPCHK(h, hipGetLastError());
+        }
         // Workgroup size: 512 threads (8 wavefronts, 8 look-ahead slots, 2 per CU) finish ONE batch soonest; 256 threads (4
         // wavefronts, 4 slots, 4 per CU) give more regions per CU whose serial phases overlap: +14 % regions/s once the
         // chip is full.  bk_config.reserved[1] = 256 / 512 chooses; 0 = 512 unless the batch alone fills the chip twice.
         const int threads = asm_threads;
         const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
-        const size_t lds = asm_lds_bytes(h, threads);
+        const size_t lds = asm_lds_bytes(h, threads, max_cand, max_contig);
         HIPCHK(h, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        h->asm_wg_per_cu = per_cu; h->asm_threads = threads;
-        const int grid = std::min<long long>(h->n_regions, (long long)per_cu * h->n_cu);
+        if (!subset) { h->asm_wg_per_cu = per_cu; h->asm_threads = threads; }
+        const int grid = std::min<long long>(n_launch, (long long)per_cu * h->n_cu);
         if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
         else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
         HIPCHK(h, hipGetLastError());
@@ -511,14 +557,15 @@ static int launch(bk_handle *h, uint32_t mask)
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if (mask & BK_STAGE_REALIGN) {
         // target staging buffer (packed, 4 bases per byte): the whole window when it fits, else chunks of diagonals
-        const uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)h->cfg.max_contig_len + 16, std::max<uint32_t>(131072, 4 * (uint32_t)h->cfg.max_contig_len));      // words + N mask: 2 x 32 KB
-        const size_t lds = ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)h->cfg.max_contig_len + 15) / 16) * 16 + 4 * (4 * ((size_t)h->cfg.max_contig_len / 16 + 2) + 2 * (tw_cap / 16 + 8));      // staged target words + their N mask
+        uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)max_contig + 16, std::max<uint32_t>(131072, 4 * (uint32_t)max_contig));      // words + N mask: 2 x 32 KB
+        while (sw_lds_bytes(max_contig, tw_cap) > BK_LDS_MAX && tw_cap > 2 * (uint32_t)max_contig + 4096) tw_cap -= 4096;      // long contig caps: shorter chunks of a long window
+        const size_t lds = sw_lds_bytes(max_contig, tw_cap);
         HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // one workgroup per contig, pulled from the list the assembler appended to; the number of contigs is only known
         // on the device, so a resident-sized grid of persistent workgroups is launched (idle ones exit at once)
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bk_sw_kernel, BK_ST_T, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        h->sw_wg_per_cu = per_cu;
+        if (!subset) h->sw_wg_per_cu = per_cu;
         hipLaunchKernelGGL(bk_sw_kernel, dim3(per_cu * h->n_cu), dim3(BK_ST_T), lds, h->stream, h->params, tw_cap);
         HIPCHK(h, hipGetLastError());
     }
@@ -546,8 +593,7 @@ static const char *st_name(int s)
     case BK_ST_ARENA: return "device scratch arena exhausted"; case BK_ST_WINDOW: return "reference window too long";
     case BK_ST_CONTIG: return "contig longer than max_contig_len"; case BK_ST_CAND: return "more candidate reads for one k-mer than max_candidates";
     case BK_ST_KLIST: return "contig k-mer list overflow"; case BK_ST_READLEN: return "read longer than max_read_len";
-    case BK_ST_OUT: return "output arena exhausted"; case BK_ST_HITS: return "realign: more than 32 step-1 hits or 256 secondary alignments for one contig";
-    case BK_ST_BLOCKS: return "realign: a chained record needs more than 32 blocks"; default: return "unknown";
+    case BK_ST_OUT: return "output arena exhausted"; default: return "unknown";
     }
 }
 
@@ -560,23 +606,36 @@ static int sync_impl(bk_handle *h)
     if (h->synced) return BK_OK;
     h->hold_snapshot = false;                       // the work records below replace the fetched copy's
     HIPCHK(h, hipSetDevice(h->dev));
-    for (int attempt = 0; attempt < 12; attempt++) {
+    bool escalated = false; float ms_first[4] = {0, 0, 0, 0};
+    h->n_escalated = 0;
+    for (int attempt = 0; attempt < 16; attempt++) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->h_work.resize(h->n_regions);
         HIPCHK(h, hipMemcpy(h->h_work.data(), h->d_work.p, sizeof(BkRegionWork) * h->n_regions, hipMemcpyDeviceToHost));
-        // A region that hit a device cap (candidates per k-mer, contig length, k-mer list) fails ALONE: its status is
-        // kept (bk_get_region_status), it reports no contigs, the other regions of the batch are unaffected.  The
-        // reference has no such caps; the caller logs and skips the target (or raises the cap and resubmits it).
+        // A region that overflowed an assembler cap (candidates per k-mer visit, contig length, k-mer list) is run again, with
+        // the others that did, under caps 4x larger (below).  One that overflows those too fails ALONE: its status is kept
+        // (bk_get_region_status), it reports no contigs, the other regions of the batch are unaffected.
         bool grow_arena = false, grow_out = false; int bad = 0;
+        std::vector<uint32_t> over;
         for (int r = 0; r < h->n_regions; r++) {
             int s = h->h_work[r].status;
-            if (s == BK_ST_ARENA) grow_arena = true; else if (s == BK_ST_OUT) grow_out = true; else if (s != BK_ST_OK) bad++;
+            if (s == BK_ST_ARENA) grow_arena = true; else if (s == BK_ST_OUT) grow_out = true; else if (s != BK_ST_OK) { bad++; if (s == BK_ST_CAND || s == BK_ST_CONTIG || s == BK_ST_KLIST) over.push_back((uint32_t)r); }
         }
         h->n_failed = bad;
         if (!grow_arena && !grow_out) {
+            float ms[4];
+            for (int i = 0; i < 3; i++) { ms[i + 1] = 0; (void)hipEventElapsedTime(&ms[i + 1], h->ev[i], h->ev[i + 1]); }
+            ms[0] = 0; (void)hipEventElapsedTime(&ms[0], h->ev[0], h->ev[3]);
+            int mc, ml;
+            if (!over.empty() && !escalated && h->cfg.reserved[2] != 1 && (h->ran_mask & BK_STAGE_ASSEMBLE) && escalated_caps(h, mc, ml)) {
+                for (int i = 0; i < 4; i++) ms_first[i] = ms[i];
+                escalated = true; h->n_escalated = (int)over.size();
+                int rc = launch(h, h->ran_mask, &over);
+                if (rc != BK_OK) return rc;
+                continue;
+            }
             for (int r = 0; r < h->n_regions; r++) if (h->h_work[r].status != BK_ST_OK) { h->h_work[r].n_contigs = 0; h->h_work[r].o_first_contig = 0; }
-            for (int i = 0; i < 3; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]); h->ms[i + 1] = ms; }
-            (void)hipEventElapsedTime(&h->ms[0], h->ev[0], h->ev[3]);
+            for (int i = 0; i < 4; i++) h->ms[i] = ms[i] + ms_first[i];          // the re-run's kernels count
             h->synced = true;
             return BK_OK;
         }
@@ -588,10 +647,11 @@ static int sync_impl(bk_handle *h)
         // and must not jump from 42 to 166)
         if (grow_arena) { h->arena_cap = std::max<uint64_t>(h->arena_cap < (4ull << 30) ? h->arena_cap * 4 : h->arena_cap + h->arena_cap / 2, tops[0] + tops[0] / 4); HIPCHK(h, h->d_arena.ensure(h->arena_cap)); }
         if (grow_out) { h->out_cap = std::max<uint64_t>(h->out_cap * 4, tops[1] + tops[1] / 2); HIPCHK(h, h->d_out.ensure(h->out_cap)); }
+        escalated = false; h->n_escalated = 0; for (float &m : ms_first) m = 0;      // the whole batch again: regions that overflow a cap will be re-run again
         int rc = launch(h, h->ran_mask);
         if (rc != BK_OK) return rc;
     }
-    return fail(h, BK_E_NOMEM, "bk_sync: arenas still too small after 12 growth steps");
+    return fail(h, BK_E_NOMEM, "bk_sync: arenas still too small after 16 growth steps");
 }
 
 // Public: like the internal wait, but says so when regions of the batch hit a cap: BK_W_REGIONS_FAILED (> 0; every other
@@ -677,7 +737,6 @@ extern "C" int bk_get_region_status(bk_handle *h, int32_t region, int32_t *statu
     if (!h || region < 0 || region >= h->n_regions) return BK_E_ARG;
     int rc = sync_impl(h); if (rc != BK_OK) return rc;
     int s = h->h_work[region].status;
-    if (s == BK_ST_OK && region < (int)h->host_status.size()) s = h->host_status[region];
     if (status) *status = s;
     if (text) *text = s == BK_ST_OK ? "ok" : st_name(s);
     return BK_OK;
@@ -755,14 +814,21 @@ static void fill_gap(const char *q, const char *t, const BkFillBlk *L, const BkF
 // Chain the raw hits of one contig into PSL-equivalent records (contract: oracle/bk_oracle.h R2 steps 3 and 4).
 // Secondary alignments (step 5) follow as one-block records, ordered by (score desc, target asc, '+' first, query end asc,
 // target end asc).  Returns the number of records, or -1 when a chained record needs more than BK_MAX_BLOCKS blocks.
-static int chain_hits(const char *contig, int Q, const std::vector<std::string> &targets, std::vector<BkHit> hits, std::vector<BkHit> sec, bk_psl *out, int cap)
+// A record as chain_hits makes it: the scalar fields of bk_psl, blocks without a limit (bk_psl holds BK_MAX_BLOCKS of them).
+struct BkPslV {
+    int matches = 0, mismatches = 0, rep_matches = 0, q_num_insert = 0, q_base_insert = 0, t_num_insert = 0, t_base_insert = 0;
+    int strand = '+', q_size = 0, q_start = 0, q_end = 0, t_index = 0, t_size = 0, t_start = 0, t_end = 0, score = 0;
+    std::vector<int> block_sizes, q_starts, t_starts;
+};
+static void chain_hits(const char *contig, int Q, const std::vector<BkTarget> &targets, std::vector<BkHit> hits, std::vector<BkHit> sec, std::vector<BkPslV> &out)
 {
+    out.clear();
     std::string rc(Q, 'N');
     for (int i = 0; i < Q; i++) { char c = contig[Q - 1 - i]; rc[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
     // ---- step 2b: BLAT's published seeding rule (sv_processor.py:843: -stepSize=10 -minMatch=2, tile 11): a hit is kept only if it
     // holds two index tiles (target positions 10 j .. 10 j + 10 inside it, all eleven bases matching)
     auto seedable = [&](const BkHit &e) {
-        const char *q = e.strand == 0 ? contig : rc.c_str(); const std::string &t = targets[e.tidx];
+        const char *q = e.strand == 0 ? contig : rc.c_str(); const BkTarget &t = targets[e.tidx];
         int tiles = 0;
         for (int j = (e.ts + 9) / 10 * 10; j + 11 <= e.te; j += 10) {
             bool ok = true;
@@ -796,7 +862,7 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
                 const int sfs = e.strand == 0 ? e.qs : Q - e.qe, sfe = e.strand == 0 ? e.qe : Q - e.qs;
                 if (sfs > fs || sfe < fe) continue;
                 const int cqs = e.strand == 0 ? fs : Q - fe, cqe = e.strand == 0 ? fe : Q - fs, dg = e.ts - e.qs;
-                const char *qstr = e.strand == 0 ? contig : rc.c_str(); const std::string &t = targets[e.tidx];
+                const char *qstr = e.strand == 0 ? contig : rc.c_str(); const BkTarget &t = targets[e.tidx];
                 int sc = 0; for (int z = cqs; z < cqe; z++) sc += (qstr[z] == t[z + dg] && qstr[z] != 'N') ? 1 : -2;
                 if (sc != hx.score) continue;
                 cd[x].push_back(PCand{cqs, cqe, cqs + dg, cqe + dg, e.strand, e.tidx, y});
@@ -836,7 +902,6 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
         }
     }
     // a chain takes every later free hit that is collinear with it; one that is not is passed over and gets a record of its own
-    int nrec = 0; bool overflow = false;
     std::vector<char> taken(nh, 0);
     for (int i = 0; i < nh; i++) {
         if (taken[i]) continue;
@@ -853,49 +918,47 @@ static int chain_hits(const char *contig, int Q, const std::vector<std::string> 
             if (h.strand == 0) chain.push_back(h); else chain.insert(chain.begin(), h);
             taken[j] = 1;
         }
-        if (nrec < cap) {
-            bk_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
-            const BkHit &f = chain.front(), &l = chain.back();
-            const char *qstr = f.strand == 0 ? contig : rc.c_str(); const std::string &t = targets[f.tidx];
-            r->strand = f.strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = f.tidx; r->t_size = (int32_t)t.size();
-            (void)l;
-            std::vector<BkFillBlk> anch, blocks;
-            for (const BkHit &c : chain) anch.push_back(BkFillBlk{c.qs, c.qe, c.ts, c.te, c.score});
-            const size_t bcap = 2 * BK_MAX_BLOCKS - 1; const int T = (int)t.size(), na = (int)anch.size();      // more than BK_MAX_BLOCKS: the record is refused
-            fill_gap(qstr, t.c_str(), nullptr, &anch[0], 0, anch[0].qs, std::max(0, anch[0].ts - anch[0].qs - BK_FILL_BAND), anch[0].ts, blocks, bcap);
-            for (int c = 0; c < na; c++) {
-                if (blocks.size() < bcap) blocks.push_back(anch[c]);
-                if (c + 1 < na) fill_gap(qstr, t.c_str(), &anch[c], &anch[c + 1], anch[c].qe, anch[c + 1].qs, anch[c].te, anch[c + 1].ts, blocks, bcap);
-            }
-            fill_gap(qstr, t.c_str(), &anch[na - 1], nullptr, anch[na - 1].qe, Q, anch[na - 1].te, std::min(T, anch[na - 1].te + (Q - anch[na - 1].qe) + BK_FILL_BAND), blocks, bcap);
-            if (blocks.size() > (size_t)BK_MAX_BLOCKS) { overflow = true; blocks.resize(BK_MAX_BLOCKS); }
-            r->t_start = blocks.front().ts; r->t_end = blocks.back().te;
-            r->q_start = f.strand == 0 ? blocks.front().qs : Q - blocks.back().qe; r->q_end = f.strand == 0 ? blocks.back().qe : Q - blocks.front().qs;
-            int nb = 0, pq = -1, pt = -1;
-            for (const BkFillBlk &c : blocks) {
-                r->score += c.score;
-                const int bs = c.qe - c.qs;
-                for (int z = 0; z < bs; z++) { if (qstr[c.qs + z] == t[c.ts + z] && qstr[c.qs + z] != 'N') r->matches++; else r->mismatches++; }
-                if (pq >= 0) { if (c.qs > pq) { r->q_num_insert++; r->q_base_insert += c.qs - pq; } if (c.ts > pt) { r->t_num_insert++; r->t_base_insert += c.ts - pt; } }
-                r->block_sizes[nb] = bs; r->q_starts[nb] = c.qs; r->t_starts[nb] = c.ts; nb++;
-                pq = c.qe; pt = c.te;
-            }
-            r->block_count = nb;
+        out.emplace_back(); BkPslV *r = &out.back();
+        const BkHit &f = chain.front();
+        const char *qstr = f.strand == 0 ? contig : rc.c_str(); const BkTarget &t = targets[f.tidx];
+        r->strand = f.strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = f.tidx; r->t_size = (int32_t)t.size();
+        std::vector<BkFillBlk> anch, blocks;
+        for (const BkHit &c : chain) anch.push_back(BkFillBlk{c.qs, c.qe, c.ts, c.te, c.score});
+        const size_t bcap = (size_t)Q + 2; const int T = (int)t.size(), na = (int)anch.size();      // blocks are disjoint on the query: never reached
+        fill_gap(qstr, t.c_str(), nullptr, &anch[0], 0, anch[0].qs, std::max(0, anch[0].ts - anch[0].qs - BK_FILL_BAND), anch[0].ts, blocks, bcap);
+        for (int c = 0; c < na; c++) {
+            blocks.push_back(anch[c]);
+            if (c + 1 < na) fill_gap(qstr, t.c_str(), &anch[c], &anch[c + 1], anch[c].qe, anch[c + 1].qs, anch[c].te, anch[c + 1].ts, blocks, bcap);
         }
-        nrec++;
+        fill_gap(qstr, t.c_str(), &anch[na - 1], nullptr, anch[na - 1].qe, Q, anch[na - 1].te, std::min(T, anch[na - 1].te + (Q - anch[na - 1].qe) + BK_FILL_BAND), blocks, bcap);
+        r->t_start = blocks.front().ts; r->t_end = blocks.back().te;
+        r->q_start = f.strand == 0 ? blocks.front().qs : Q - blocks.back().qe; r->q_end = f.strand == 0 ? blocks.back().qe : Q - blocks.front().qs;
+        int pq = -1, pt = -1;
+        for (const BkFillBlk &c : blocks) {
+            r->score += c.score;
+            const int bs = c.qe - c.qs;
+            for (int z = 0; z < bs; z++) { if (qstr[c.qs + z] == t[c.ts + z] && qstr[c.qs + z] != 'N') { if (t.masked(c.ts + z)) r->rep_matches++; else r->matches++; } else r->mismatches++; }
+            if (pq >= 0) { if (c.qs > pq) { r->q_num_insert++; r->q_base_insert += c.qs - pq; } if (c.ts > pt) { r->t_num_insert++; r->t_base_insert += c.ts - pt; } }
+            r->block_sizes.push_back(bs); r->q_starts.push_back(c.qs); r->t_starts.push_back(c.ts);
+            pq = c.qe; pt = c.te;
+        }
     }
     for (const BkHit &e : sec) {
-        if (nrec < cap) {
-            bk_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
-            const char *qstr = e.strand == 0 ? contig : rc.c_str(); const std::string &t = targets[e.tidx];
-            r->strand = e.strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = e.tidx; r->t_size = (int32_t)t.size();
-            r->t_start = e.ts; r->t_end = e.te; r->q_start = e.strand == 0 ? e.qs : Q - e.qe; r->q_end = e.strand == 0 ? e.qe : Q - e.qs;
-            for (int z = 0; z < e.qe - e.qs; z++) { if (qstr[e.qs + z] == t[e.ts + z] && qstr[e.qs + z] != 'N') r->matches++; else r->mismatches++; }
-            r->block_count = 1; r->block_sizes[0] = e.qe - e.qs; r->q_starts[0] = e.qs; r->t_starts[0] = e.ts; r->score = e.score;
-        }
-        nrec++;
+        out.emplace_back(); BkPslV *r = &out.back();
+        const char *qstr = e.strand == 0 ? contig : rc.c_str(); const BkTarget &t = targets[e.tidx];
+        r->strand = e.strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = e.tidx; r->t_size = (int32_t)t.size();
+        r->t_start = e.ts; r->t_end = e.te; r->q_start = e.strand == 0 ? e.qs : Q - e.qe; r->q_end = e.strand == 0 ? e.qe : Q - e.qs;
+        for (int z = 0; z < e.qe - e.qs; z++) { if (qstr[e.qs + z] == t[e.ts + z] && qstr[e.qs + z] != 'N') { if (t.masked(e.ts + z)) r->rep_matches++; else r->matches++; } else r->mismatches++; }
+        r->block_sizes.push_back(e.qe - e.qs); r->q_starts.push_back(e.qs); r->t_starts.push_back(e.ts); r->score = e.score;
     }
-    return overflow ? -1 : nrec;
+}
+static BkTarget make_target(const char *s, int len)
+{
+    BkTarget t; t.seq.assign(s, (size_t)len);
+    bool any = false;
+    for (int i = 0; i < len; i++) if (t.seq[(size_t)i] >= 'a' && t.seq[(size_t)i] <= 'z') { any = true; break; }
+    if (any) { t.soft.assign((size_t)len, 0); for (int i = 0; i < len; i++) { char &c = t.seq[(size_t)i]; if (c >= 'a' && c <= 'z') { t.soft[(size_t)i] = 1; c = (char)(c - 'a' + 'A'); } } }
+    return t;
 }
 static void raw_hits_of(const bk_handle *h, const BkContigRec *c, std::vector<BkHit> &prim, std::vector<BkHit> &sec)
 {
@@ -913,9 +976,45 @@ extern "C" int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl 
     std::vector<BkHit> raw, sec; raw_hits_of(h, c, raw, sec);
     const char *seq = (const char *)c + c->o_seq;
     std::string s(seq, c->seq_len);
-    const int n = chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, sec, hits, cap);   // the number of records (>= 0)
-    if (n < 0) return fail(h, BK_E_LIMIT, "bk_get_hits: a chained record needs more than BK_MAX_BLOCKS blocks");
-    return n;
+    std::vector<BkPslV> recs;
+    chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, sec, recs);
+    for (const BkPslV &x : recs) if (x.block_sizes.size() > (size_t)BK_MAX_BLOCKS) return fail(h, BK_E_LIMIT, "bk_get_hits: a chained record of this contig has more than BK_MAX_BLOCKS blocks (bk_psl cannot hold it; bk_call has no such limit)");
+    for (size_t i = 0; i < recs.size() && (int32_t)i < cap; i++) {
+        const BkPslV &x = recs[i]; bk_psl *r = &hits[i]; memset(r, 0, sizeof(*r));
+        r->matches = x.matches; r->mismatches = x.mismatches; r->rep_matches = x.rep_matches; r->q_num_insert = x.q_num_insert; r->q_base_insert = x.q_base_insert;
+        r->t_num_insert = x.t_num_insert; r->t_base_insert = x.t_base_insert; r->strand = x.strand; r->q_size = x.q_size; r->q_start = x.q_start; r->q_end = x.q_end;
+        r->t_index = x.t_index; r->t_size = x.t_size; r->t_start = x.t_start; r->t_end = x.t_end; r->score = x.score; r->block_count = (int32_t)x.block_sizes.size();
+        for (size_t b = 0; b < x.block_sizes.size(); b++) { r->block_sizes[b] = x.block_sizes[b]; r->q_starts[b] = x.q_starts[b]; r->t_starts[b] = x.t_starts[b]; }
+    }
+    return (int)recs.size();                                                 // the number of records (>= 0, may exceed cap)
+}
+
+// The same records without a block limit, as a flat int32 stream: per record BK_PSL_FLAT_HEAD scalars (matches, mismatches,
+// rep_matches, n_count, q_num_insert, q_base_insert, t_num_insert, t_base_insert, strand, q_size, q_start, q_end, t_index, t_size,
+// t_start, t_end, score, block_count) followed by block_count block sizes, q starts and t starts.
+extern "C" int bk_get_hits_flat(bk_handle *h, int32_t region, int32_t contig, int32_t *buf, size_t cap, size_t *needed)
+{
+    BK_JOIN(h);
+    if (!h || region < 0 || region >= h->n_regions || !needed || (cap > 0 && !buf)) return BK_E_ARG;
+    int rc = fetch(h); if (rc != BK_OK) return rc;
+    const BkContigRec *c = find_contig(h, region, contig);
+    if (!c) return fail(h, BK_E_ARG, "bk_get_hits_flat: no such contig");
+    std::vector<BkHit> raw, sec; raw_hits_of(h, c, raw, sec);
+    std::string s((const char *)c + c->o_seq, c->seq_len);
+    std::vector<BkPslV> recs;
+    chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, sec, recs);
+    size_t need = 0; for (const BkPslV &x : recs) need += BK_PSL_FLAT_HEAD + 3 * x.block_sizes.size();
+    *needed = need;
+    if (need <= cap) {
+        int32_t *o = buf;
+        for (const BkPslV &x : recs) {
+            const int32_t head[BK_PSL_FLAT_HEAD] = {x.matches, x.mismatches, x.rep_matches, 0, x.q_num_insert, x.q_base_insert, x.t_num_insert, x.t_base_insert, x.strand, x.q_size, x.q_start, x.q_end,
+                                                    x.t_index, x.t_size, x.t_start, x.t_end, x.score, (int32_t)x.block_sizes.size()};
+            memcpy(o, head, sizeof(head)); o += BK_PSL_FLAT_HEAD;
+            for (int v : x.block_sizes) *o++ = v; for (int v : x.q_starts) *o++ = v; for (int v : x.t_starts) *o++ = v;
+        }
+    }
+    return (int)recs.size();
 }
 
 extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
@@ -932,7 +1031,8 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     if (which == 3) v = h->alg_bytes;
     if (which == 20) v = (uint64_t)(h->submit_pack_ms * 1000.0);              // microseconds
     if (which == 21) v = (uint64_t)(h->submit_h2d_ms * 1000.0);
-    if (which == 22) { v = (uint64_t)h->n_failed; for (int r = 0; r < h->n_regions && r < (int)h->host_status.size(); r++) if (h->host_status[r] && h->h_work[r].status == BK_ST_OK) v++; }
+    if (which == 22) v = (uint64_t)h->n_failed;
+    if (which == 26) v = (uint64_t)h->n_escalated;
     if (which == 23) v = (uint64_t)h->asm_wg_per_cu;                        // resident assembler / realign workgroups per CU (occupancy query)
     if (which == 24) v = (uint64_t)h->sw_wg_per_cu;
     if (which == 25) v = (uint64_t)h->asm_threads;
@@ -1041,7 +1141,6 @@ extern "C" int bk_call(bk_handle *h)
     const int want = std::max<int>((h->n_regions + 31) / 32, (int)std::min<uint64_t>(n_contigs / 512, 16));
     const int nthreads = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), h->n_regions, want}));
     std::vector<std::string> parts(h->n_regions);
-    h->host_status.assign(h->n_regions, 0);
     auto work = [&](int t) {
         for (int r = t; r < h->n_regions; r += nthreads) {
             const bkcall::Region &rg = cx.regions[r];
@@ -1055,21 +1154,23 @@ extern "C" int bk_call(bk_handle *h)
                 { const uint32_t *rd = (const uint32_t *)(b + c->o_reads); const std::string &tg = cx.rtags[r]; bool same = true; char first = 0;
                   for (int i = 0; i < c->n_reads; i++) { char tch = rd[i] < tg.size() ? tg[rd[i]] : '0'; if (i == 0) first = tch; else if (tch != first) same = false; } ct.same_read_tag = same && c->n_reads > 0; }
                 std::vector<BkHit> raw, sec; raw_hits_of(h, c, raw, sec);
-                std::vector<bk_psl> recs(raw.size() + sec.size() + 1);
-                int n = chain_hits(ct.seq.c_str(), c->seq_len, h->h_targets[r], raw, sec, recs.data(), (int)recs.size());
-                if (n < 0) { h->host_status[r] = BK_ST_BLOCKS; blob.clear(); break; }                     // the region fails alone (bk_get_region_status)
-                auto to_psl = [&](const bk_psl &x, const std::string &tname, int offset) {
-                    bkcall::Psl p; p.matches = x.matches; p.mis = x.mismatches; p.rep = x.rep_matches; p.qni = x.q_num_insert; p.qbi = x.q_base_insert; p.tni = x.t_num_insert; p.tbi = x.t_base_insert;
+                std::vector<BkPslV> recs;
+                chain_hits(ct.seq.c_str(), c->seq_len, h->h_targets[r], raw, sec, recs);
+                const int n = (int)recs.size();
+                // repeats_lower: the BLAT call against the target window has -repeats=lower (sv_processor.py:843), the genome-wide gfClient
+                // call (:840) has not -- there a match on a soft-masked base is a plain match
+                auto to_psl = [&](const BkPslV &x, const std::string &tname, int offset, bool repeats_lower) {
+                    bkcall::Psl p; p.matches = repeats_lower ? x.matches : x.matches + x.rep_matches; p.mis = x.mismatches; p.rep = repeats_lower ? x.rep_matches : 0; p.qni = x.q_num_insert; p.qbi = x.q_base_insert; p.tni = x.t_num_insert; p.tbi = x.t_base_insert;
                     p.strand = (char)x.strand; p.qsize = x.q_size; p.qstart = x.q_start; p.qend = x.q_end; p.tname = bkcall::strip_chr(tname); p.tsize = x.t_size; p.tstart = x.t_start + offset; p.tend = x.t_end + offset;
-                    for (int i = 0; i < x.block_count; i++) { p.bs.push_back(x.block_sizes[i]); p.qs.push_back(x.q_starts[i]); p.ts.push_back(x.t_starts[i] + offset); }
+                    for (size_t i = 0; i < x.block_sizes.size(); i++) { p.bs.push_back(x.block_sizes[i]); p.qs.push_back(x.q_starts[i]); p.ts.push_back(x.t_starts[i] + offset); }
                     return p; };
                 std::vector<bkcall::Psl> own, rows;
-                for (int i = 0; i < n; i++) if (recs[i].t_index == 0) own.push_back(to_psl(recs[i], rg.chrom, rg.start - 200));
+                for (int i = 0; i < n; i++) if (recs[i].t_index == 0) own.push_back(to_psl(recs[i], rg.chrom, rg.start - 200, true));
                 if (!own.empty() && bkcall::target_hit(cx.opts, rg, cx.tables, ct, own)) rows = own;          // the '.mod' rows (Q14)
                 else for (int i = 0; i < n; i++) {
                     const int ti = recs[i].t_index;
-                    if (ti == 0) rows.push_back(to_psl(recs[i], rg.chrom, rg.start - 200));
-                    else if (ti - 1 < (int)cx.partners[r].size()) rows.push_back(to_psl(recs[i], cx.partners[r][ti - 1].first, cx.partners[r][ti - 1].second));
+                    if (ti == 0) rows.push_back(to_psl(recs[i], rg.chrom, rg.start - 200, false));
+                    else if (ti - 1 < (int)cx.partners[r].size()) rows.push_back(to_psl(recs[i], cx.partners[r][ti - 1].first, cx.partners[r][ti - 1].second, false));
                 }
                 std::vector<std::string> row;
                 if (bkcall::get_result(cx.opts, rg, cx.tables, ct, rows, row)) { blob += std::to_string(r) + "\t" + std::to_string(ci) + "\t" + bkcall::join_row(row) + "\n"; }

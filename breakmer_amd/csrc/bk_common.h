@@ -28,8 +28,8 @@ enum {
     BK_ST_KLIST = 5,          // contig k-mer list overflow
     BK_ST_READLEN = 6,        // read longer than max_read_len
     BK_ST_OUT = 7,            // output arena exhausted (host grows it and reruns)
-    BK_ST_HITS = 8,           // realign stage: more than BK_MAX_HITS step-1 hits or BK_MAX_SEC secondary alignments for one contig
-    BK_ST_BLOCKS = 9          // realign stage (host): a chained record needs more than BK_MAX_BLOCKS blocks
+    BK_ST_HITS = 8,           // (ABI 2: realign stage, hit lists full.  No longer produced: the step-1 list is sized by the contig cap, secondary alignments spill to the result arena)
+    BK_ST_BLOCKS = 9          // (ABI 2: a chained record with more than BK_MAX_BLOCKS blocks.  No longer a region status: bk_call has no block limit; bk_get_hits alone returns BK_E_LIMIT for such a contig)
 };
 
 struct BkKey { uint64_t hi, lo; };
@@ -147,8 +147,6 @@ enum { BK_RF_INDEL = 1, BK_RF_HASN = 2 };
 // contig record in the `out` arena (o_* relative to the record start, 8-byte aligned; k-mers are
 // stored as (lo, hi) key pairs so the record is self-contained)
 struct BkHit { int32_t qs, qe, ts, te, strand, tidx, score, fq; };   // qs/qe in strand coordinates, fq = forward query start
-#define BK_MAX_HITS 32           // step-1 hits of one contig (they tile the query, >= 20 bases each); one more fails the REGION with BK_ST_HITS
-#define BK_MAX_SEC 256           // secondary alignments of one contig (realign contract step 5); one more fails the region with BK_ST_HITS
 struct BkContigRec {
     uint64_t next;               // `out` offset of the next contig record of the region (0 = end)
     uint64_t hits_off;           // `out` offset of BkHit[n_hits + n_sec] (realign stage: step-1 hits, then secondary alignments in no particular order), 0 = none
@@ -175,8 +173,9 @@ struct BkParams {
     // workgroups; every emitted contig is appended to `clist` (its `out` offset | region << 40), pulled by the realigner
     uint32_t *order; unsigned long long *asm_head, *sw_head, *n_clist; unsigned long long *clist; uint64_t clist_cap;
     int32_t k, rc_thresh, max_contig, max_read, max_cand, sw_min_score;
-    int32_t n_regions;
+    int32_t n_regions;           // regions of this launch (= length of the assembler's queue `order`)
     int32_t flags;               // BK_F_*
+    const uint32_t *rmap;        // launch over a subset of the batch (re-run of regions that overflowed a cap): workgroup b of the k-mer kernels takes region rmap[b]; nullptr = region b
 };
 enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64 };   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
 

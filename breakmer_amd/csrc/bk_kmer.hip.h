@@ -394,7 +394,7 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
     }
     __syncthreads();
 #ifdef BK_PHASE_STAMPS
-    if (threadIdx.x == 0) p.work[blockIdx.x].stamps[2] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) p.work[p.rmap ? p.rmap[blockIdx.x] : blockIdx.x].stamps[2] = __builtin_amdgcn_s_memrealtime();
 #endif
     auto rep_of = [&](uint32_t sl) -> uint32_t { if constexpr (LG) return lslot[sl] & 0x3FFFu; else return (uint32_t)dslot[sl]; };
     auto cnt_of = [&](uint32_t sl) -> uint32_t { if constexpr (LG) return lslot[sl]; else return dcnt[sl]; };
@@ -450,7 +450,7 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
 template <bool GLB>
 __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_t win_words_cap, uint32_t lds_words, uint32_t *lds)
 {
-    const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int r = p.rmap ? (int)p.rmap[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const BkRegionDesc d = p.desc[r];
     if ((d.big != 0) != GLB) return;
     BkRegionWork *wk = &p.work[r];

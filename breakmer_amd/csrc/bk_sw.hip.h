@@ -28,10 +28,17 @@
 #define BK_SW_MIN_SEG 20
 #define BK_SW_FLAGS 1024
 
+// Step-1 hits tile the query with >= BK_SW_MIN_SEG bases each (a hit scores >= min_score >= its length's worth of matches), so a
+// contig of at most max_contig bases has at most max_contig / BK_SW_MIN_SEG of them: the hit list and the interval stack are
+// sized for that in the dynamic LDS block and cannot overflow.  Secondary alignments have no such bound (a microsatellite in
+// the window: hundreds per contig): BK_SEC_LDS of them are collected in LDS; when there are more the sweep is repeated
+// writing straight into the result arena (their number is known by then).  Neither is a cap.
+#define BK_SEC_LDS 256
+__host__ __device__ inline int bk_sw_max_hits(int max_contig) { return max_contig / BK_SW_MIN_SEG + 2; }
 struct BkSwShared {
-    int nseg; int seg[2 * (2 * BK_MAX_HITS + 4)];
-    int nhits; BkHit hits[BK_MAX_HITS];
-    int nsec; BkHit sec[BK_MAX_SEC];             // secondary alignments (step 5), in no particular order
+    int nseg;
+    int nhits;
+    int nsec; BkHit sec[BK_SEC_LDS];             // secondary alignments (step 5), in no particular order
     int nflag; int flag_off[BK_SW_FLAGS]; int flag_ts[BK_SW_FLAGS];   // diagonals of the whole query on which H can reach min_score (found by the first pass): (offset, target << 1 | strand)
     unsigned long long red[BK_ST_T / 64]; int red_run[BK_ST_T / 64];
     unsigned long long best_key; int best_run;
@@ -45,9 +52,9 @@ struct BkSwShared {
 
 __device__ inline unsigned long long bk_sw_key(int score, int tidx, int strand, int a, long long b)
 {   // larger key wins: score desc, target index asc, '+' first, smallest query end, smallest target end
-    // [score:13 | 15-tidx:4 | 1-strand:1 | 0x1FFF-a:13 | 0x1FFFFFFFF-b:33]
-    return ((unsigned long long)score << 51) | ((unsigned long long)(15 - tidx) << 47) | ((unsigned long long)(1 - strand) << 46) |
-           ((unsigned long long)(0x1FFF - a) << 33) | (unsigned long long)(0x1FFFFFFFFll - b);
+    // [score:15 | 15-tidx:4 | 1-strand:1 | 0x7FFF-a:15 | 0x1FFFFFFF-b:29]   (contigs < 32,768 bases, windows < 512 Mb)
+    return ((unsigned long long)score << 49) | ((unsigned long long)(15 - tidx) << 45) | ((unsigned long long)(1 - strand) << 44) |
+           ((unsigned long long)(0x7FFF - a) << 29) | (unsigned long long)(0x1FFFFFFFll - b);
 }
 
 // N mask of the staged target under the 16 bases that start at word i0, shift sh (as the packed words themselves are fetched); bit
@@ -216,6 +223,9 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
     uint32_t *qnm = qpk + 2 * qpw;                                     // N masks of the packed query interval, both strands
     uint32_t *tp = qnm + 2 * qpw;                                      // staged target chunk, packed words (kept across passes and contigs)
     uint32_t *tnb = tp + (tw_cap / 16 + 8);                            // its N mask, filled (and used) only for windows that hold an N
+    const int max_hits = bk_sw_max_hits(p.max_contig);
+    BkHit *hits = (BkHit *)(tnb + (tw_cap / 16 + 8));                  // step-1 hits of the contig (cannot overflow: see BkSwShared)
+    int *seg = (int *)(hits + max_hits);                               // stack of query intervals still to be aligned: 2 * (2 * max_hits + 4) ints
     if (tid == 0) { S->staged_ti = -1; S->staged_t0 = 0; S->staged_t1 = 0; S->staged_region = -1; }
     const unsigned long long n_list = min(*p.n_clist, (unsigned long long)p.clist_cap);
     for (;;) {
@@ -241,10 +251,10 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
         const int Q = rec->seq_len;
         const char *seq = (const char *)(p.out + roff + rec->o_seq);
         for (int i = tid; i < Q; i += BK_ST_T) { char ch = seq[i]; uint8_t c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : BK_CODE_N; qf[i] = c; qr[Q - 1 - i] = c == BK_CODE_N ? (uint8_t)BK_CODE_N : (uint8_t)(3 - c); }
-        if (tid == 0) { S->nseg = 1; S->seg[0] = 0; S->seg[1] = Q; S->nhits = 0; S->nsec = 0; S->nflag = 0; }
+        if (tid == 0) { S->nseg = 1; seg[0] = 0; seg[1] = Q; S->nhits = 0; S->nsec = 0; S->nflag = 0; }
         __syncthreads();
         while (S->nseg > 0 && S->status == 0) {
-            const int qs = S->seg[2 * (S->nseg - 1)], qe = S->seg[2 * (S->nseg - 1) + 1], n = qe - qs;
+            const int qs = seg[2 * (S->nseg - 1)], qe = seg[2 * (S->nseg - 1) + 1], n = qe - qs;
             __syncthreads();
             if (tid == 0) { S->nseg--; S->best_key = 0; S->best_run = 0; S->L = 0; }
             __syncthreads();
@@ -330,18 +340,17 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
             __syncthreads();
             if (tid == 0) {
                 for (int w = 0; w < BK_ST_T / 64; w++) if (S->red[w] > S->best_key) { S->best_key = S->red[w]; S->best_run = S->red_run[w]; }
-                const unsigned long long key = S->best_key; const int score = (int)(key >> 51);
+                const unsigned long long key = S->best_key; const int score = (int)(key >> 49);
                 if (score >= p.sw_min_score) {
-                    const int tidx = 15 - (int)((key >> 47) & 15), st = 1 - (int)((key >> 46) & 1), a1 = 0x1FFF - (int)((key >> 33) & 0x1FFF), b1 = (int)(0x1FFFFFFFFll - (long long)(key & 0x1FFFFFFFFull)), run = S->best_run;
+                    const int tidx = 15 - (int)((key >> 45) & 15), st = 1 - (int)((key >> 44) & 1), a1 = 0x7FFF - (int)((key >> 29) & 0x7FFF), b1 = (int)(0x1FFFFFFFll - (long long)(key & 0x1FFFFFFFull)), run = S->best_run;
                     const int offq = st ? Q - qe : qs;
                     BkHit hgt; hgt.qs = offq + a1 - run; hgt.qe = offq + a1; hgt.ts = b1 - run; hgt.te = b1; hgt.strand = st; hgt.tidx = tidx; hgt.score = score;
                     const int fs = st ? Q - hgt.qe : hgt.qs, fe = st ? Q - hgt.qs : hgt.qe;
                     hgt.fq = fs;
-                    if (S->nhits >= BK_MAX_HITS) S->status = BK_ST_HITS;                     // never a silent stop: the region reports it
-                    else {
-                        S->hits[S->nhits++] = hgt;
-                        S->seg[2 * S->nseg] = fe; S->seg[2 * S->nseg + 1] = qe; S->nseg++;      // right remainder (after the left one)
-                        S->seg[2 * S->nseg] = qs; S->seg[2 * S->nseg + 1] = fs; S->nseg++;
+                    if (S->nhits < max_hits) {                                                // always (the hits tile the query)
+                        hits[S->nhits++] = hgt;
+                        seg[2 * S->nseg] = fe; seg[2 * S->nseg + 1] = qe; S->nseg++;            // right remainder (after the left one)
+                        seg[2 * S->nseg] = qs; seg[2 * S->nseg + 1] = fs; S->nseg++;
                     }
                 }
             }
@@ -352,6 +361,8 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
         if (S->nhits > 0 && S->status == 0) {
             const int n = Q, nh1 = S->nhits;
             bk_sw_pack_query(qf, qr, Q, 0, Q, qpk, qnm, qpw, tid);
+            // dst / cap: where the segments go (the LDS list first; the result arena when that list was too short)
+            auto sweep = [&](BkHit *dst, int cap, bool count_cells) {
             for (int ti = 0; ti <= (int)d.n_partners; ti++) {
                 const uint32_t *gw; int m;
                 const uint32_t *wn; int nn;                                  // N positions of this window (none, as a rule)
@@ -386,29 +397,50 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                         bk_sw_walk_all(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off, p.sw_min_score, [&](int sc, int aend, int run) {
                             const int sqs = aend - run, sqe = aend;                      // strand coordinates (the whole query: no interval offset)
                             for (int x = 0; x < nh1; x++) {
-                                const BkHit &an = S->hits[x];
+                                const BkHit &an = hits[x];
                                 if (an.tidx == ti && an.strand == st && an.ts - an.qs == off && an.qs < sqe && sqs < an.qe) return;   // the same alignment
                             }
                             const int idx = atomicAdd(&S->nsec, 1);
-                            if (idx < BK_MAX_SEC) { BkHit e; e.qs = sqs; e.qe = sqe; e.ts = sqs + off; e.te = sqe + off; e.strand = st; e.tidx = ti; e.score = sc; e.fq = st ? Q - sqe : sqs; S->sec[idx] = e; }
+                            if (idx < cap) { BkHit e; e.qs = sqs; e.qe = sqe; e.ts = sqs + off; e.te = sqe + off; e.strand = st; e.tidx = ti; e.score = sc; e.fq = st ? Q - sqe : sqs; dst[idx] = e; }
                         });
                     }
                 }
-                if (tid == 0) S->cells += 2ull * (unsigned long long)n * (unsigned long long)m;
+                if (tid == 0 && count_cells) S->cells += 2ull * (unsigned long long)n * (unsigned long long)m;
                 __syncthreads();
+            }
+            };
+            sweep(S->sec, BK_SEC_LDS, true);
+            __syncthreads();
+            const int total = S->nsec;                                       // every thread reads it before it is reset
+            __syncthreads();
+            if (total > BK_SEC_LDS) {
+                // more than the LDS list holds: room for all of them (behind the step-1 hits) in the result arena, same sweep again
+                if (tid == 0) {
+                    const uint64_t need = bk_align_up((uint64_t)(nh1 + total) * sizeof(BkHit), 256);
+                    const uint64_t off = atomicAdd(p.out_top, (unsigned long long)need);
+                    S->rec_off = off + need > p.out_cap ? 0ull : off;
+                    if (!S->rec_off) S->status = BK_ST_OUT;
+                    S->nsec = 0;
+                }
+                __syncthreads();
+                if (S->rec_off) sweep((BkHit *)(p.out + S->rec_off) + nh1, total, false);
+                __syncthreads();
+                if (tid == 0) S->nsec = S->rec_off ? -total : 0;             // negative: already in the arena
             }
         }
         // write the raw hits next to the contig record
         __syncthreads();
         if (tid == 0) {
             const int nh = S->nhits; int ns = S->nsec;
-            if (ns > BK_MAX_SEC) { S->status = BK_ST_HITS; ns = 0; }
-            rec->n_hits = nh; rec->n_sec = (uint32_t)ns; rec->hits_off = 0;
-            if (nh > 0) {
+            rec->n_hits = nh; rec->n_sec = (uint32_t)(ns < 0 ? -ns : ns); rec->hits_off = 0;
+            if (S->status == BK_ST_OUT) { rec->n_hits = 0; rec->n_sec = 0; }
+            else if (ns < 0) {                                                  // the secondary alignments are in the arena already: the step-1 hits go in front of them
+                BkHit *o = (BkHit *)(p.out + S->rec_off); for (int i = 0; i < nh; i++) o[i] = hits[i]; rec->hits_off = S->rec_off;
+            } else if (nh > 0) {
                 uint64_t need = bk_align_up((uint64_t)(nh + ns) * sizeof(BkHit), 256);
                 uint64_t off = atomicAdd(p.out_top, (unsigned long long)need);
                 if (off + need > p.out_cap) { S->status = BK_ST_OUT; rec->n_hits = 0; rec->n_sec = 0; }
-                else { BkHit *o = (BkHit *)(p.out + off); for (int i = 0; i < nh; i++) o[i] = S->hits[i]; for (int i = 0; i < ns; i++) o[nh + i] = S->sec[i]; rec->hits_off = off; }
+                else { BkHit *o = (BkHit *)(p.out + off); for (int i = 0; i < nh; i++) o[i] = hits[i]; for (int i = 0; i < ns; i++) o[nh + i] = S->sec[i]; rec->hits_off = off; }
             }
             atomicAdd((unsigned long long *)&wk->sw_cells, S->cells);
             if (S->status) wk->status = S->status;

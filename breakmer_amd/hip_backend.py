@@ -21,7 +21,8 @@ LIB_PATH = os.environ.get("BREAKMER_HIP_LIB") or os.path.join(_HERE, "libbreakme
 
 BK_STAGE_KMER, BK_STAGE_ASSEMBLE, BK_STAGE_REALIGN, BK_STAGE_ALL = 1, 2, 4, 7
 BK_MAX_BLOCKS = 32
-BK_ABI_VERSION = 2
+BK_ABI_VERSION = 3
+BK_PSL_FLAT_HEAD = 18
 BK_W_REGIONS_FAILED = 1
 
 
@@ -68,7 +69,7 @@ def call_text(text):
 EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_submit_regions_ex", "bk_run", "bk_sync", "bk_fetch",
            "bk_last_kernel_ms", "bk_get_region_status", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
            "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_get_calls",
-           "bk_nw_batch", "bk_pack_sequence", "bk_trim"]
+           "bk_nw_batch", "bk_pack_sequence", "bk_trim", "bk_get_hits_flat"]
 
 _lib = None
 
@@ -104,6 +105,7 @@ def load_library():
     L.bk_get_contig.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6
     L.bk_get_hits.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BkPsl), C.c_int32]
     L.bk_get_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.bk_get_hits_flat.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.bk_call_text.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
     L.bk_pack_sequence.argtypes = [C.c_char_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.bk_trim.argtypes = [C.c_void_p, C.c_uint64]
@@ -241,6 +243,7 @@ class Engine(object):
         cfg.sw_min_score = int(limits.get("sw_min_score", 0))
         cfg.reserved[0] = int(limits.get("flags", 0))
         cfg.reserved[1] = int(limits.get("wg_threads", 0))          # assembler workgroup size: 0 = library default, 256 (throughput) or 512 (latency)
+        cfg.reserved[2] = int(limits.get("no_escalation", 0))       # 1: regions that overflow an assembler cap fail at once instead of being re-run under larger caps
         self.k = int(kmer_size)
         self.rc_thresh, self.device = int(rc_thresh), int(device)
         self._inputs = None
@@ -391,7 +394,32 @@ class Engine(object):
         return out
 
     def hits(self, region, contig):
-        """PSL-equivalent records of one contig (realign stage) as dicts."""
+        """PSL-equivalent records of one contig (realign stage) as dicts (any number of blocks: bk_get_hits_flat)."""
+        need = C.c_size_t()
+        n = self.L.bk_get_hits_flat(self.h, region, contig, None, 0, C.byref(need))
+        if n < 0:
+            self._chk(n, "bk_get_hits_flat")
+        buf = np.zeros(max(need.value, 1), dtype=np.int32)
+        if n > 0:
+            n = self.L.bk_get_hits_flat(self.h, region, contig, buf.ctypes.data, buf.size, C.byref(need))
+            if n < 0:
+                self._chk(n, "bk_get_hits_flat")
+        out, o = [], 0
+        v = buf.tolist()
+        for _ in range(n):
+            hd = v[o:o + BK_PSL_FLAT_HEAD]
+            nb = hd[17]
+            o += BK_PSL_FLAT_HEAD
+            out.append({"matches": hd[0], "mismatches": hd[1], "rep_matches": hd[2], "n_count": hd[3],
+                        "q_num_insert": hd[4], "q_base_insert": hd[5], "t_num_insert": hd[6], "t_base_insert": hd[7],
+                        "strand": chr(hd[8]), "q_size": hd[9], "q_start": hd[10], "q_end": hd[11], "t_index": hd[12], "t_size": hd[13],
+                        "t_start": hd[14], "t_end": hd[15], "block_sizes": v[o:o + nb], "q_starts": v[o + nb:o + 2 * nb],
+                        "t_starts": v[o + 2 * nb:o + 3 * nb], "score": hd[16]})
+            o += 3 * nb
+        return out
+
+    def hits_fixed(self, region, contig):
+        """the same through bk_get_hits (bk_psl: at most BK_MAX_BLOCKS blocks per record; raises BK_E_LIMIT beyond)"""
         cap = 16
         while True:
             arr = (BkPsl * cap)()
@@ -400,7 +428,7 @@ class Engine(object):
                 self._chk(n, "bk_get_hits")
             if n <= cap:
                 break
-            cap = n                                          # secondary alignments: as many records as BLAT would print lines
+            cap = n
         out = []
         for r in arr[:n]:
             nb = r.block_count

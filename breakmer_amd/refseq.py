@@ -221,7 +221,7 @@ def discover_partners(disc, fasta, annotations, target_chrom, target_start, targ
                 continue
             s, e = max(0, lo - flank), min(clen, hi + flank)
             seq = fasta.fetch(c, s, e)
-            if len(seq) < 64 or seq.strip("ACGTN"):
+            if len(seq) < 64 or seq.strip("ACGTNacgtn"):
                 if skipped is not None and len(seq) >= 64:
                     skipped.append((c, s, e))              # IUPAC codes other than N cannot be packed: the caller logs these
                 continue

@@ -767,13 +767,15 @@ class align_manager(object):                                        # sv_caller.
 
 
 # --------------------------------------------------------------------------- realign records -> PSL columns
-def psl_fields(rec, qname, tname, t_offset=0):
+def psl_fields(rec, qname, tname, t_offset=0, repeats_lower=True):
     """One realign record (dict from hip_backend.Engine.hits / oracle realign) -> the 21 PSL columns
-    BLAT writes (sv_processor.py:843), target coordinates shifted by t_offset."""
+    BLAT writes (sv_processor.py:843), target coordinates shifted by t_offset.  repeats_lower=False: the genome-wide
+    gfClient call (sv_processor.py:840) has no -repeats=lower, so matches on soft-masked bases are plain matches there."""
     bs = ",".join(str(x) for x in rec["block_sizes"]) + ","
     qs = ",".join(str(x) for x in rec["q_starts"]) + ","
     ts = ",".join(str(x + t_offset) for x in rec["t_starts"]) + ","
-    return [str(rec["matches"]), str(rec["mismatches"]), str(rec["rep_matches"]), str(rec["n_count"]),
+    m, rp = (rec["matches"], rec["rep_matches"]) if repeats_lower else (rec["matches"] + rec["rep_matches"], 0)
+    return [str(m), str(rec["mismatches"]), str(rp), str(rec["n_count"]),
             str(rec["q_num_insert"]), str(rec["q_base_insert"]), str(rec["t_num_insert"]), str(rec["t_base_insert"]),
             rec["strand"], qname, str(rec["q_size"]), str(rec["q_start"]), str(rec["q_end"]),
             tname, str(rec["t_size"]), str(rec["t_start"] + t_offset), str(rec["t_end"] + t_offset),

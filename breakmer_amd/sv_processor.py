@@ -73,14 +73,16 @@ class RegionData(object):
 
 
 def read_fasta_first(fn):
-    """the sequence of a one-record FASTA, upper case: a *_refseq.fa written by the reference from a soft-masked genome keeps
-    lower case (utils.py:366-371, str(seq)), and its consumers -- Jellyfish, BLAT -- do not care about case"""
+    """the sequence of a one-record FASTA AS WRITTEN: a *_refseq.fa written by the reference from a soft-masked genome keeps
+    lower case (utils.py:366-371, str(seq)).  Jellyfish does not care about case; BLAT is run with -repeats=lower
+    (sv_processor.py:843) and reports matches on lower-case target bases as repMatches, which the caller reads
+    (sv_caller.py:913, 975-986): the library takes the window with its case (include/breakmer_hip.h)."""
     seq = []
     with open(fn) as f:
         for ln in f:
             if not ln.startswith(">"):
                 seq.append(ln.strip())
-    return "".join(seq).upper()
+    return "".join(seq)
 
 
 def read_fastq(fn):
@@ -378,7 +380,7 @@ class contig(object):
                 self.psl_rows = [r[3].blat_values for r in am.bm.blat_results]      # the '.mod' rows (:802)
                 return
         tinfo = [(qr[0], qr[1] - 200)] + [(p[0], p[1]) for p in t.partner_windows]
-        self.psl_rows = [sv_caller.psl_fields(h, 'contig1', 'chr' + str(tinfo[h["t_index"]][0]).replace('chr', ''), tinfo[h["t_index"]][1]) for h in self.hits]
+        self.psl_rows = [sv_caller.psl_fields(h, 'contig1', 'chr' + str(tinfo[h["t_index"]][0]).replace('chr', ''), tinfo[h["t_index"]][1], repeats_lower=False) for h in self.hits]
 
     def make_calls(self, disc_reads, rep_mask):                      # :863-866
         meta = {'params': self.params, 'repeat_mask': rep_mask, 'query_region': self.query_region, 'psl_records': self.psl_rows,
@@ -551,10 +553,10 @@ class target(object):                                               # sv_process
     def _unsupported_reference(d):
         if not d.window:
             return "empty reference window"
-        if isinstance(d.window, str) and d.window.encode().translate(None, b"ACGTN"):      # C-speed scan (str.strip walks the characters one by one)
-            return "reference window holds characters other than A/C/G/T/N (%s)" % ",".join(sorted(set(d.window.strip("ACGTN")))[:5])
+        if isinstance(d.window, str) and d.window.encode().translate(None, b"ACGTNacgtn"):      # C-speed scan (str.strip walks the characters one by one); lower case = soft-masked
+            return "reference window holds characters other than A/C/G/T/N (%s)" % ",".join(sorted(set(d.window.strip("ACGTNacgtn")))[:5])
         for p_ in d.partners:
-            if isinstance(p_[4], str) and p_[4].encode().translate(None, b"ACGTN"):
+            if isinstance(p_[4], str) and p_[4].encode().translate(None, b"ACGTNacgtn"):
                 return "partner window %s:%s-%s holds characters other than A/C/G/T/N" % (p_[0], p_[1], p_[2])
         return None
 
@@ -835,7 +837,7 @@ class runner(object):                                               # sv_process
         for nh, c_, s0, e0 in sorted(loci.values(), key=lambda x: (-x[0], x[1], x[2]))[:4]:
             s1, e1 = max(0, s0 - 1500), min(fa.length(c_), e0 + 1500)
             wseq = fa.fetch(c_, s1, e1)
-            if len(wseq) < 64 or wseq.strip("ACGTN"):
+            if len(wseq) < 64 or wseq.strip("ACGTNacgtn"):
                 self.logger.warning('target %s: genome window %s:%d-%d holds characters other than A/C/G/T/N and is not realigned against' % (t.name, c_, s1, e1))
                 continue
             name = self.params.gene_annotations.set_gene(c_, [(s0 + e0) // 2])

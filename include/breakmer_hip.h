@@ -18,7 +18,10 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 2       /* 2: bk_psl holds 32 blocks; bk_get_hits also returns secondary alignments; bk_sync reports regions that hit a cap (BK_W_REGIONS_FAILED) */
+#define BK_ABI_VERSION 3       /* 2: bk_psl holds 32 blocks; bk_get_hits also returns secondary alignments; bk_sync reports regions that hit a cap (BK_W_REGIONS_FAILED)
+                                * 3: the realign stage has no hit / block caps any more (bk_get_hits_flat returns records of any size, bk_call uses them);
+                                *    reference / partner windows may be soft-masked (lower case => rep_matches); regions that overflow an assembler cap are
+                                *    re-run by the library with larger ones (bk_config.reserved[2]); BK_SUBMIT_PACKED */
 
 enum {
     BK_OK = 0,
@@ -58,15 +61,19 @@ typedef struct bk_config {
                                  *      32 = bucket sort of the seed k-mers whatever their number (the path of very large noisy regions),
                                  *      64 = every read retired on its own (no run retire): same results)
                                  * [1]: assembler workgroup size: 512 = 8 wavefronts / 8 look-ahead slots / 2 per CU (one batch finishes soonest),
-                                 *      256 = 4 wavefronts / 4 slots / 4 per CU (most regions/s when batches are in flight), 0 = library chooses */
+                                 *      256 = 4 wavefronts / 4 slots / 4 per CU (most regions/s when batches are in flight), 0 = library chooses
+                                 * [2]: 1 = do NOT re-run regions that overflow an assembler cap with larger caps (they fail at once: bk_get_region_status) */
 } bk_config;
 
 /* One target region = what sv_processor.target hands to compare_kmers()/resolve_sv()
  * (sv_processor.py:609-665): the cleaned reads (self.cleaned_read_recs before grouping,
  * utils.py:203-246), the soft-clip sequences behind case_sc (sv_processor.py:619-620) and the
  * forward reference window FASTA (sv_processor.py:291; the reverse file is derived).
- * Sequences are ASCII A/C/G/T/N (an N in a read, a soft-clip sequence or a window matches nothing and no k-mer spans it, as for
- * Jellyfish and BLAT), rows `stride` bytes apart with explicit lengths. */
+ * Sequences are ASCII A/C/G/T/N (an N in a read or a window matches nothing and no k-mer spans it, as for Jellyfish and BLAT;
+ * soft-clip sequences must be A/C/G/T: a caller splits them at any other character, which yields the same k-mer set), rows
+ * `stride` bytes apart with explicit lengths.  Windows (target and partners) may be soft-masked: a lower-case base is the same
+ * base, and a realign match on it is reported in bk_psl.rep_matches instead of .matches -- what BLAT's -repeats=lower
+ * (sv_processor.py:843) does and sv_caller.py:913, 975-986 reads. */
 typedef struct bk_region {
     const char *reads;          /* n_reads rows */
     const uint16_t *read_lens;
@@ -125,10 +132,12 @@ int bk_fetch(bk_handle *h);
  * stream (ms); which = 0 total, 1 k-mer kernel, 2 assembler kernel, 3 realign kernel */
 int bk_last_kernel_ms(bk_handle *h, int which, float *ms);
 
-/* Per-region outcome of the last bk_run.  The reference has no size caps; this implementation has a few
- * (max_candidates reads per k-mer, max_contig_len, the contig k-mer list): a region that hits one fails ALONE --
- * status != 0, text says which cap, it reports zero contigs -- and bk_run/bk_sync still succeed for the batch
- * (the per-target analogue of the reference skipping a target, sv_processor.py:190-192).  status 0 = ok. */
+/* Per-region outcome of the last bk_run.  The reference has no size caps; this implementation sizes its LDS buffers by a few
+ * (max_candidates reads per k-mer visit, max_contig_len, the contig k-mer list).  A region that overflows one is RUN AGAIN by the
+ * library, alone with the others that did, with caps 4x larger (8,192 candidates, 16,384-base contigs with the defaults; one
+ * workgroup per CU; bk_config.reserved[2] = 1 switches that off) -- bk_sync does it before it returns.  Only a region that
+ * overflows those too fails: ALONE -- status != 0, text says which cap, it reports zero contigs -- and bk_run/bk_sync still
+ * succeed for the batch (the per-target analogue of the reference skipping a target, sv_processor.py:190-192).  status 0 = ok. */
 int bk_get_region_status(bk_handle *h, int32_t region, int32_t *status, const char **text);
 
 /* ---- results, region-major -------------------------------------------------------------- */
@@ -162,8 +171,9 @@ int bk_get_contig(bk_handle *h, int32_t region, int32_t contig, char *seq, int32
  * segment scoring >= sw_min_score on another diagonal, the other strand or another window, as BLAT prints every
  * alignment >= -minScore (sv_processor.py:843) and the caller counts them per query base (sv_caller.py:593-594,
  * 616-631, 430-432, 55-72) -- as one-block records ordered by (score desc, window asc, '+' first, query end, target
- * end).  Returns the number of records (>= 0, may exceed cap) or a negative BK_E_* code (BK_E_LIMIT: a chained record
- * needs more than BK_MAX_BLOCKS blocks).  q_starts are in strand coordinates as in PSL. */
+ * end).  Returns the number of records (>= 0, may exceed cap) or a negative BK_E_* code (BK_E_LIMIT: a chained record of THIS
+ * contig has more than BK_MAX_BLOCKS blocks and does not fit bk_psl -- bk_get_hits_flat and bk_call have no such limit).
+ * q_starts are in strand coordinates as in PSL. */
 #define BK_MAX_BLOCKS 32
 typedef struct bk_psl {
     int32_t matches, mismatches, rep_matches, n_count;
@@ -177,6 +187,11 @@ typedef struct bk_psl {
     int32_t score;
 } bk_psl;
 int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl *hits, int32_t cap);
+/* The same records without a block limit, as a flat int32 stream: per record BK_PSL_FLAT_HEAD scalars -- the fields of bk_psl
+ * up to t_end in its order, then score and block_count -- followed by block_count block sizes, q starts and t starts.
+ * *needed = ints of the whole stream (call with cap = 0 to size the buffer); returns the number of records. */
+#define BK_PSL_FLAT_HEAD 18
+int bk_get_hits_flat(bk_handle *h, int32_t region, int32_t contig, int32_t *buf, size_t cap, size_t *needed);
 
 /* ---- SV-call tail (C1-C3): contig + PSL-equivalent records -> the 13-field result row -------------------
  * Replaces, per contig, contig.query_ref/check_target_blat/make_calls -> align_manager(meta_dict).get_result()
@@ -210,7 +225,8 @@ int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, const uint32_t
  *   which = 0: olc.nw DP cells (sum len(seq1)*len(seq2)), 1: olc.nw calls, 2: SW cells,
  *           3: algorithmic HBM bytes (SURVEY 8d formula), 4: unique reads, 5: sample k-mers, 6: contigs,
  *           20/21: host packing / host-to-device copy time of the last bk_submit_regions (microseconds),
- *           22: regions of the last run that failed on a device cap (bk_get_region_status) */
+ *           22: regions of the last run that failed on a device cap (bk_get_region_status),
+ *           26: regions the library re-ran with larger assembler caps (bk_config.reserved[2]) */
 int bk_get_stat(bk_handle *h, int which, uint64_t *value);
 
 #ifdef __cplusplus

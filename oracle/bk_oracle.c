@@ -690,10 +690,10 @@ int bko_check_align_case(const char *contig_seq, int clen, const char *read_seq,
 /* ------------------------------------------------------------------ R2 realign (see bk_oracle.h) */
 static uint64_t g_sw_cells = 0;
 uint64_t bko_sw_cells(int reset) { uint64_t v = g_sw_cells; if (reset) g_sw_cells = 0; return v; }
-#define SW_MAXHITS 64        /* the oracle has no cap worth the name: it aborts beyond this (the library's BK_MAX_HITS is 32, reported per region) */
-#define SW_MAXSEC 65536
+#define SW_MAXHITS 2048      /* the hits tile the query (>= 20 bases each): contigs up to 40,000 bases; the oracle aborts beyond */
+#define SW_MAXSEC (1 << 22)
 #define SW_EQ(a, b) ((a) == (b) && (a) != 'N')      /* an N (contig or window) matches nothing in the realign stage */
-typedef struct { int qs, qe, ts, te, strand, tidx, score, nb; int bs[BKO_MAX_BLOCKS], bq[BKO_MAX_BLOCKS], bt[BKO_MAX_BLOCKS]; int fq; } swhit;   /* q coords are strand coords; fq = forward start */
+typedef struct { int qs, qe, ts, te, strand, tidx, score, nb; int bs[1], bq[1], bt[1]; int fq; } swhit;   /* q coords are strand coords; fq = forward start */
 
 /* Gap-free local Smith-Waterman (maximal scoring segment): H[a][b] = max(0, H[a-1][b-1] + s(q_a, t_b)).
  * Gaps are NOT opened inside a hit -- like BLAT, hits are ungapped blocks and gaps only appear when
@@ -792,13 +792,21 @@ static int sw_seedable(const char *q, const char *t, int qs, int ts, int len)
     return tiles >= SEED_MIN;
 }
 
-int bko_realign(const char *contig, int Q, const char *const *targets, const int *tlens, int ntargets,
+int bko_realign(const char *contig, int Q, const char *const *targets_in, const int *tlens, int ntargets,
                 int min_score, int min_seg, bko_psl *out, int cap)
 {
+    /* soft-masked (lower-case) window bases are the same bases; a match on one is reported as repMatches (BLAT -repeats=lower,
+     * sv_processor.py:843; consumed at sv_caller.py:913, 975-986): upper-cased copies + one flag byte per base */
+    char **targets = (char **)xmalloc((size_t)ntargets * sizeof(char *)); unsigned char **soft = (unsigned char **)xmalloc((size_t)ntargets * sizeof(unsigned char *));
+    for (int ti = 0; ti < ntargets; ti++) {
+        targets[ti] = (char *)xmalloc((size_t)tlens[ti] + 1); soft[ti] = (unsigned char *)xcalloc((size_t)tlens[ti] + 1, 1);
+        for (int z = 0; z < tlens[ti]; z++) { char c = targets_in[ti][z]; if (c >= 'a' && c <= 'z') { soft[ti][z] = 1; c = (char)(c - 'a' + 'A'); } targets[ti][z] = c; }
+        targets[ti][tlens[ti]] = 0;
+    }
     char *rc = (char *)xmalloc((size_t)Q + 1);
     for (int i = 0; i < Q; i++) { char c = contig[Q - 1 - i]; rc[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
-    swhit hits[SW_MAXHITS]; int nh = 0;
-    int stk[2 * (SW_MAXHITS * 2 + 2)], sp = 0;
+    swhit *hits = (swhit *)xmalloc(sizeof(swhit) * SW_MAXHITS); int nh = 0;
+    int *stk = (int *)xmalloc(sizeof(int) * 2 * (SW_MAXHITS * 2 + 2)), sp = 0;
     stk[sp++] = 0; stk[sp++] = Q;
     while (sp > 0) {
         int qe = stk[--sp], qs = stk[--sp];
@@ -939,10 +947,12 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
      * a record of its own -- as BLAT's chaining does: a stretch copied from elsewhere in the middle of a contig does not
      * split the alignment of its two flanks. */
     int nrec = 0, overflow = 0;
-    unsigned char taken[SW_MAXHITS]; memset(taken, 0, sizeof(taken));
+    unsigned char *taken = (unsigned char *)xcalloc(SW_MAXHITS, 1);
+    swhit *chain = (swhit *)xmalloc(sizeof(swhit) * (2 * SW_MAXHITS + 1));
+    fblk *blocks = (fblk *)xmalloc(sizeof(fblk) * (BKO_MAX_BLOCKS * 2)), *anch = (fblk *)xmalloc(sizeof(fblk) * (2 * SW_MAXHITS + 1));
     for (int i = 0; i < nh; i++) {
         if (taken[i]) continue;
-        swhit chain[2 * SW_MAXHITS + 1]; int head = SW_MAXHITS, tail = SW_MAXHITS;     /* deque [head, tail) in strand order */
+        int head = SW_MAXHITS, tail = SW_MAXHITS;     /* deque [head, tail) in strand order */
         chain[tail++] = hits[i]; taken[i] = 1;
         for (int j = i + 1; j < nh; j++) {
             if (taken[j]) continue;
@@ -968,8 +978,8 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
             const int sq = f->qs, eq = l->qe;                            /* strand coordinates */
             r->q_start = f->strand == 0 ? sq : Q - eq; r->q_end = f->strand == 0 ? eq : Q - sq;
             /* anchors in strand order, islands between them and beyond the ends filled (step 4) */
-            fblk blocks[BKO_MAX_BLOCKS * 2]; int nbk = 0; const int bcap = BKO_MAX_BLOCKS * 2 - 1;      /* more than BKO_MAX_BLOCKS: the call fails (-2) */
-            fblk anch[2 * SW_MAXHITS + 1]; int na = 0;
+            int nbk = 0; const int bcap = BKO_MAX_BLOCKS * 2 - 1;      /* more than BKO_MAX_BLOCKS: the call fails (-2) */
+            int na = 0;
             for (int c = head; c < tail; c++) { anch[na].qs = chain[c].qs; anch[na].qe = chain[c].qe; anch[na].ts = chain[c].ts; anch[na].te = chain[c].te; anch[na].score = chain[c].score; na++; }
             { const int gq = anch[0].qs; int tlo = anch[0].ts - gq - FILL_BAND; if (tlo < 0) tlo = 0;
               fill_gap(qstr, tstr, NULL, &anch[0], 0, anch[0].qs, tlo, anch[0].ts, blocks, &nbk, bcap); }
@@ -986,7 +996,7 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
             for (int c = 0; c < nbk; c++) {
                 r->score += blocks[c].score;
                 const int bs = blocks[c].qe - blocks[c].qs, bq = blocks[c].qs, bt = blocks[c].ts;
-                for (int z = 0; z < bs; z++) { if (SW_EQ(qstr[bq + z], tstr[bt + z])) r->matches++; else r->mismatches++; }
+                for (int z = 0; z < bs; z++) { if (SW_EQ(qstr[bq + z], tstr[bt + z])) { if (soft[f->tidx][bt + z]) r->rep_matches++; else r->matches++; } else r->mismatches++; }
                 if (pq >= 0) { if (bq > pq) { r->q_num_insert++; r->q_base_insert += bq - pq; } if (bt > pt) { r->t_num_insert++; r->t_base_insert += bt - pt; } }
                 r->block_sizes[nb] = bs; r->q_starts[nb] = bq; r->t_starts[nb] = bt; nb++;
                 pq = bq + bs; pt = bt + bs;
@@ -1002,10 +1012,12 @@ int bko_realign(const char *contig, int Q, const char *const *targets, const int
         r->strand = e->strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = e->tidx; r->t_size = tlens[e->tidx];
         r->t_start = e->ts; r->t_end = e->te;
         r->q_start = e->strand == 0 ? e->qs : Q - e->qe; r->q_end = e->strand == 0 ? e->qe : Q - e->qs;
-        for (int z = 0; z < e->qe - e->qs; z++) { if (SW_EQ(qstr[e->qs + z], tstr[e->ts + z])) r->matches++; else r->mismatches++; }
+        for (int z = 0; z < e->qe - e->qs; z++) { if (SW_EQ(qstr[e->qs + z], tstr[e->ts + z])) { if (soft[e->tidx][e->ts + z]) r->rep_matches++; else r->matches++; } else r->mismatches++; }
         r->block_count = 1; r->block_sizes[0] = e->qe - e->qs; r->q_starts[0] = e->qs; r->t_starts[0] = e->ts; r->score = e->score;
     }
     free(sec);
-    free(rc);
+    free(rc); free(hits); free(stk); free(taken); free(chain); free(blocks); free(anch);
+    for (int ti = 0; ti < ntargets; ti++) { free(targets[ti]); free(soft[ti]); }
+    free(targets); free(soft);
     return overflow ? -2 : nrec;
 }

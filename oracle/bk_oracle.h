@@ -102,10 +102,11 @@ void bko_asm_free(bko_asm *a);
  *      breaks between consecutive hits, then the sum of |diagonal shift| between chained neighbours, is smallest (ties:
  *      the earlier candidate).  A chosen alternative becomes the hit, restricted to the hit's query interval; the hit it
  *      replaces is listed with the secondary alignments, the secondary it came from is dropped.
- * An N (in the contig or in a window) matches nothing.
+ * An N (in the contig or in a window) matches nothing.  A lower-case (soft-masked) window base is the same base; a match on
+ * one is counted in rep_matches instead of matches (BLAT's -repeats=lower, sv_processor.py:843).
  * Output: PSL-equivalent records (fields consumed by sv_caller.py:911-936).  Returns the number of records (may exceed
  * cap), or -2 when a chained record would need more than BKO_MAX_BLOCKS blocks (the library reports that per region). */
-#define BKO_MAX_BLOCKS 32
+#define BKO_MAX_BLOCKS 512     /* the library's bk_call has no limit; its bk_psl (bk_get_hits) holds 32 */
 typedef struct bko_psl {
     int32_t matches, mismatches, rep_matches, n_count;
     int32_t q_num_insert, q_base_insert, t_num_insert, t_base_insert;

@@ -15,7 +15,8 @@ _LIB = None
 def build(force=False):
     so = os.path.join(_HERE, "libbk_oracle.so")
     src = os.path.join(_HERE, "bk_oracle.c")
-    if force or not os.path.isfile(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    hdr = os.path.join(_HERE, "bk_oracle.h")
+    if force or not os.path.isfile(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src], cwd=_HERE)
     return so
 
@@ -164,7 +165,7 @@ def assemble_region(read_seqs, refs, k, rc_thresh=2, indel_only=None, sc_seqs=No
         useqs = [read_seqs[i] for i in rep]
         read_len = max(len(s) for s in read_seqs) if len(read_seqs) else 0
     uind = np.zeros(len(rep), dtype=np.uint8) if indel_only is None else np.asarray(indel_only, dtype=np.uint8)[rep]
-    mers, counts = kmer_select(read_seqs, refs, k, sc_seqs)
+    mers, counts = kmer_select(read_seqs, [r.upper() for r in refs], k, sc_seqs)      # Jellyfish counts soft-masked (lower-case) bases like any others
     contigs, flags = init_assembly(useqs, cnt, uind, mers, counts, k, rc_thresh, read_len)
     for c in contigs:
         c["reads"] = [int(rep[u]) for u in c["reads"]]          # representative read index (FASTQ order)
@@ -196,8 +197,8 @@ class OPsl(C.Structure):
                 ("q_num_insert", C.c_int32), ("q_base_insert", C.c_int32), ("t_num_insert", C.c_int32), ("t_base_insert", C.c_int32),
                 ("strand", C.c_int32), ("q_size", C.c_int32), ("q_start", C.c_int32), ("q_end", C.c_int32),
                 ("t_index", C.c_int32), ("t_size", C.c_int32), ("t_start", C.c_int32), ("t_end", C.c_int32),
-                ("block_count", C.c_int32), ("block_sizes", C.c_int32 * 32), ("q_starts", C.c_int32 * 32),
-                ("t_starts", C.c_int32 * 32), ("score", C.c_int32)]
+                ("block_count", C.c_int32), ("block_sizes", C.c_int32 * 512), ("q_starts", C.c_int32 * 512),
+                ("t_starts", C.c_int32 * 512), ("score", C.c_int32)]
 
 
 def psl_to_dict(r):
@@ -222,7 +223,7 @@ def realign(contig, targets, min_score=20, min_seg=20):
         out = (OPsl * cap)()
         n = L.bko_realign(contig.encode(), len(contig), arr, tl, len(tb), min_score, min_seg, out, cap)
         if n < 0:
-            raise RuntimeError("bko_realign: a chained record needs more than 32 blocks")
+            raise RuntimeError("bko_realign: a chained record needs more than 512 blocks")
         if n <= cap:
             return [psl_to_dict(out[i]) for i in range(n)]
         cap = n

@@ -269,24 +269,118 @@ def test_g8m_multi_mapping_rows_gpu(hb, golden_dir):
         assert got == ([want] if want is not None else []), tag
 
 
-def test_realign_caps_fail_the_region_loudly_gpu(hb):
-    """More secondary alignments than the library keeps per contig (256; here ~350 from a 600-base microsatellite): the REGION
-    reports BK_ST_HITS -- never a silently shortened list --, bk_sync says that a region failed, the neighbours are untouched."""
+def test_realign_has_no_hit_caps_gpu(hb):
+    """The reference's BLAT prints as many alignments as there are.  (a) A 600-base microsatellite: ~350 secondary alignments of one
+    contig (more than the 256 the kernel collects in LDS: they spill to the result arena) -- every record equals the oracle's,
+    the neighbours in the batch are untouched, no region fails.  (b) A contig with more step-1 hits than the 32 the library used
+    to keep: a window made of the contig's 24-base pieces in shuffled order with spacers; (c) a chained record with more than the
+    32 blocks bk_psl holds: the same pieces in order, one base deleted between neighbours -- bk_get_hits_flat returns it whole,
+    bk_get_hits says BK_E_LIMIT for that contig only."""
     from oracle import bk_oracle as bo
     regions = [synth.make_region(3, depth=60, W=1500), synth.make_region(3, depth=60, W=3000, microsat=600), synth.make_region(4, depth=60, W=1500, sv_type="ins")]
-    assert len(bo.realign(bo.assemble_region(regions[1].read_strs(), [regions[1].window_str], 31, 2)[0][0]["seq"], [regions[1].window_str])) > 257
+    want1 = bo.realign(bo.assemble_region(regions[1].read_strs(), [regions[1].window_str], 31, 2)[0][0]["seq"], [regions[1].window_str])
+    assert len(want1) > 257
     eng = hb.Engine(kmer_size=31)
     eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
     eng.run(hb.BK_STAGE_ALL, sync=False)
-    assert eng.sync() == 1 and eng.stat(22) == 1
-    st, text = eng.region_status(1)
-    assert st == 8 and "secondary" in text
-    assert eng.contigs(1) == []
-    ok = _run_regions(hb, [regions[0], regions[2]], 31, stages=7)
-    for a, b in ((0, 0), (2, 1)):
-        assert eng.region_status(a)[0] == 0
-        assert eng.contigs(a) == ok.contigs(b) and eng.contigs(a)
-        assert [eng.hits(a, c) for c in range(len(eng.contigs(a)))] == [ok.hits(b, c) for c in range(len(ok.contigs(b)))]
+    assert eng.sync() == 0 and eng.stat(22) == 0
+    for i, r in enumerate(regions):
+        assert eng.region_status(i) == (0, "ok")
+        cs = eng.contigs(i)
+        assert cs
+        for ci, c in enumerate(cs):
+            assert eng.hits(i, ci) == bo.realign(c["seq"], [r.window_str]), (i, ci)
+    assert eng.hits(1, 0) == want1
+    # (b), (c): a 1,040-base sequence of 40 random 26-mers; the reads are its own 150-mers, the window is built from its pieces
+    rnd = random.Random(5)
+    sp = lambda n: "".join(rnd.choice("ACGT") for _ in range(n))
+    q = "".join(sp(26) for _ in range(40))
+    lp = [q[i:i + 26] for i in range(0, len(q), 26)]
+    order = list(range(len(lp))); rnd.shuffle(order)
+    win_b = sp(40) + "".join(lp[j] + sp(30) for j in order)       # shuffled, 30 random bases between them: every piece is a step-1 hit of its own
+    win_c = sp(50) + "A".join(lp) + sp(50)                        # in order, one extra window base between neighbours: ONE chained record, a block per piece
+    reads = [q[i:i + 150] for i in range(0, len(q) - 149, 3)] * 2
+    for name, win in (("many hits", win_b), ("many blocks", win_c)):
+        e2 = hb.Engine(kmer_size=31)
+        e2.submit([hb.RegionInput(reads, win)])
+        e2.run(hb.BK_STAGE_ALL, sync=False)
+        assert e2.sync() == 0, name
+        cs = e2.contigs(0)
+        assert cs and max(len(c["seq"]) for c in cs) > 1000, name
+        seen = 0
+        for ci, c in enumerate(cs):
+            w2 = bo.realign(c["seq"], [win])
+            got = e2.hits(0, ci)
+            assert got == w2, (name, ci)
+            if name == "many hits":
+                seen += sum(len(x["block_sizes"]) for x in w2)
+            else:
+                nb = max([len(x["block_sizes"]) for x in w2] + [0])
+                seen = max(seen, nb)
+                if nb > 32:
+                    with pytest.raises(hb.BreakmerHipError):
+                        e2.hits_fixed(0, ci)
+                else:
+                    assert e2.hits_fixed(0, ci) == w2
+        assert seen > (20 if name == "many hits" else 32), (name, seen)
+        e2.close()
+
+
+def test_soft_masked_window_reports_rep_matches_gpu(hb):
+    """BLAT is run with -repeats=lower (sv_processor.py:843): matches on lower-case target bases are PSL column 3 (repMatches),
+    which the caller reads (sv_caller.py:913, 975-986).  A window whose left flank is soft-masked: same contigs and hits as the
+    upper-case window, matches split into matches + rep_matches exactly as the oracle's contract does; the native call tail
+    and the Python tail agree on the rows."""
+    from oracle import bk_oracle as bo
+    r = synth.make_region(3, depth=60, W=1500)
+    w = r.window_str
+    c = len(w) // 2
+    soft = w[:c - 160] + w[c - 160:c - 100].lower() + w[c - 100:]
+    e_up, e_lo = hb.Engine(kmer_size=31), hb.Engine(kmer_size=31)
+    for e, win in ((e_up, w), (e_lo, soft)):
+        e.submit([hb.RegionInput(r.reads, win, read_lens=r.read_lens)])
+        e.run(hb.BK_STAGE_ALL)
+    assert e_up.contigs(0) == e_lo.contigs(0) and len(e_lo.contigs(0)) == 1
+    up, lo = e_up.hits(0, 0), e_lo.hits(0, 0)
+    assert lo == bo.realign(e_lo.contigs(0)[0]["seq"], [soft])
+    assert up == bo.realign(e_up.contigs(0)[0]["seq"], [w])
+    assert sum(x["rep_matches"] for x in up) == 0 and lo[0]["rep_matches"] == 60
+    for a, b in zip(up, lo):
+        assert a["matches"] == b["matches"] + b["rep_matches"]
+        assert {k: v for k, v in a.items() if k not in ("matches", "rep_matches")} == {k: v for k, v in b.items() if k not in ("matches", "rep_matches")}
+
+
+def test_regions_that_overflow_a_cap_are_rerun_with_larger_caps_gpu(hb):
+    """The reference has no caps (find_reads sv_assembly.py:111-122, contig growth :506-546).  (a) 6,000x of ragged reads: more
+    than 3,000 unique reads hold the seed k-mer (default cap 2,048 candidates per visit); (b) a 5,000-base insertion: a contig of
+    more than 4,096 bases.  Both overflow the default LDS-sized caps, are run again by the library under the larger ones and
+    come out bit-exact against the oracle; the clean neighbour is untouched; with the re-run switched off they fail loudly."""
+    from oracle import bk_oracle as bo
+    deep = synth.make_region(21, depth=6000, W=800, var_len=1.0)
+    longc = synth.make_region(22, sv_type="ins", sv_size=5000, W=1200, n_reads=1600)
+    plain = synth.make_region(3, depth=60, W=1500)
+    regions = [deep, plain, longc]
+    wants = [bo.assemble_region(r.read_strs(), [r.window_str], 31, 2) for r in regions]
+    # the seed k-mer of (a): how many unique reads hold it
+    seed = wants[0][1]["mers"][0]
+    assert len({s for s in deep.read_strs() if seed in s}) >= 3000
+    assert max(len(c["seq"]) for c in wants[2][0]) > 4096
+    eng = hb.Engine(kmer_size=31)
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
+    eng.run(hb.BK_STAGE_ALL, sync=False)
+    assert eng.sync() == 0 and eng.stat(22) == 0 and eng.stat(26) == 2
+    for i, r in enumerate(regions):
+        assert eng.region_status(i) == (0, "ok")
+        got = eng.contigs(i)
+        assert _strip(got) == wants[i][0], i
+        for ci, c in enumerate(got):
+            assert eng.hits(i, ci) == bo.realign(c["seq"], [r.window_str]), (i, ci)
+    off = hb.Engine(kmer_size=31, no_escalation=1)
+    off.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
+    off.run(hb.BK_STAGE_ALL, sync=False)
+    assert off.sync() == 2
+    assert off.region_status(0)[0] == 4 and off.region_status(2)[0] == 3 and off.region_status(1) == (0, "ok")
+    assert off.contigs(0) == [] and _strip(off.contigs(1)) == wants[1][0]
 
 
 def test_runner_end_to_end_gpu(hb, golden_dir, tmp_path):

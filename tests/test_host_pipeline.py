@@ -459,17 +459,17 @@ def test_window_with_n_is_processed_and_other_characters_skip_that_target_only(t
     assert [x for x in rows if x[0] == rows2[-1][0]] == [rows2[-1]]                  # the untouched target: the same row
 
 
-def test_soft_masked_refseq_file_is_read_upper_case(tmp_path):
+def test_soft_masked_refseq_file_keeps_its_case(tmp_path):
     """A <name>_forward_refseq.fa written by the reference tool from a soft-masked genome keeps lower case
-    (utils.py:366-371: str(seq)); its readers here upper-case, and refseq.extract_refseq_fa writes the bytes of the genome
-    file as the reference does."""
+    (utils.py:366-371: str(seq)); refseq.extract_refseq_fa writes the bytes of the genome file as the reference does, and the
+    window goes to the library WITH its case (BLAT -repeats=lower reports matches on lower-case bases as repMatches)."""
     from breakmer_amd import refseq
     (tmp_path / "g.fa").write_text(">chr1\nACGTacgtnnACGT\nggccAATT\n")
     fa = refseq.FastaIndex(str(tmp_path / "g.fa"))
     assert fa.fetch("1", 2, 18) == "GTACGTNNACGTGGCC" and fa.fetch("1", 2, 18, upper=False) == "GTacgtnnACGTggcc"
     fn = refseq.extract_refseq_fa(("1", 204, 212, "T1", []), str(tmp_path / "ref"), fa, "forward")
     assert open(fn).read() == ">T1\nacgtnnACGTggccAATT\n"
-    assert sp.read_fasta_first(fn) == "ACGTNNACGTGGCCAATT"
+    assert sp.read_fasta_first(fn) == "acgtnnACGTggccAATT"
     fn = refseq.extract_refseq_fa(("1", 204, 212, "T1", []), str(tmp_path / "ref"), fa, "reverse")
     assert open(fn).read() == ">T1\nAATTggccACGTnnacgt\n"
 
