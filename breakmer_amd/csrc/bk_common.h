@@ -29,7 +29,11 @@ enum {
     BK_ST_READLEN = 6,        // read longer than max_read_len
     BK_ST_OUT = 7,            // output arena exhausted (host grows it and reruns)
     BK_ST_HITS = 8,           // (ABI 2: realign stage, hit lists full.  No longer produced: the step-1 list is sized by the contig cap, secondary alignments spill to the result arena)
-    BK_ST_BLOCKS = 9          // (ABI 2: a chained record with more than BK_MAX_BLOCKS blocks.  No longer a region status: bk_call has no block limit; bk_get_hits alone returns BK_E_LIMIT for such a contig)
+    BK_ST_BLOCKS = 9,         // (ABI 2: a chained record with more than BK_MAX_BLOCKS blocks.  No longer a region status: bk_call has no block limit; bk_get_hits alone returns BK_E_LIMIT for such a contig)
+    // internal (never seen by a caller: bk_sync resolves them before it returns)
+    BK_ST_REDO = 20,          // split region: components touched each other across units; they are merged and run again (bk_comp.hip.h)
+    BK_ST_UNSPLIT = 21,       // split region: bookkeeping of the split overflowed; the region is run again as one unit
+    BK_ST_CONFLICT = 22       // assembler-internal: the current seed iteration reached a k-mer of another unit's component
 };
 
 struct BkKey { uint64_t hi, lo; };
@@ -133,6 +137,15 @@ struct BkRegionWork {
     uint64_t o_post;             // uint32[T]
     uint64_t o_first_contig;     // `out` offset of first contig record (linked list), 0 = none
     uint64_t o_last_contig;
+    // split regions (bk_comp.hip.h): the read / k-mer graph of a noisy region falls into components that never meet; G units
+    // (workgroups) assemble disjoint sets of them side by side.  split = G (0: the region is one unit)
+    uint32_t split, pass;        // pass: 0 = first execution; k = k-th repair pass (components that met across units, merged, run again)
+    uint32_t units_done, n_cidx, n_pairs, n_conf, cidx_cap, pairs_cap;
+    uint64_t o_rroot;            // uint32[U]  component root (a read index) of every unique read
+    uint64_t o_kroot;            // uint32[M]  component root of every sample k-mer (BK_EMPTY32: homopolymer, never in the graph)
+    uint64_t o_cinfo;            // uint32[U]  per component, at its root: unit | pass << 8 | flags (BK_CI_*)
+    uint64_t o_cidx;             // 2 x uint64[cidx_cap]  contigs as emitted: (seed rank << 20 | sequence in the seed iteration, `out` offset)
+    uint64_t o_pairs;            // uint32[3 * pairs_cap]  (root a, root b, kind): components that met (kind 1: across units = conflict)
     uint64_t stamps[20];         // diagnostic builds only (-DBK_PHASE_STAMPS): s_memrealtime at phase boundaries
 };
 
@@ -149,6 +162,7 @@ enum { BK_RF_INDEL = 1, BK_RF_HASN = 2 };
 struct BkHit { int32_t qs, qe, ts, te, strand, tidx, score, fq; };   // qs/qe in strand coordinates, fq = forward query start
 struct BkContigRec {
     uint64_t next;               // `out` offset of the next contig record of the region (0 = end)
+    uint32_t root, pass;         // split regions: the component the contig belongs to (its root when it was emitted) and the pass that made it
     uint64_t hits_off;           // `out` offset of BkHit[n_hits + n_sec] (realign stage: step-1 hits, then secondary alignments in no particular order), 0 = none
     int32_t seq_len, counts_len, n_kmers, n_reads, total_reads, n_hits;
     uint32_t o_seq, o_io, o_ot, o_klocs, o_kmers, o_reads, n_sec, size;
@@ -171,13 +185,22 @@ struct BkParams {
     uint8_t *out; unsigned long long *out_top; uint64_t out_cap;           // results: contig records, hits (copied to the host)
     // scheduling (bk_sched.hip.h): regions in descending order of estimated assembler cost, pulled by persistent
     // workgroups; every emitted contig is appended to `clist` (its `out` offset | region << 40), pulled by the realigner
-    uint32_t *order; unsigned long long *asm_head, *sw_head, *n_clist; unsigned long long *clist; uint64_t clist_cap;
+    uint32_t *order; unsigned long long *asm_head, *sw_head, *n_clist, *n_queue; unsigned long long *clist; uint64_t clist_cap;      // order: (region | unit << 24) entries, *n_queue of them
     int32_t k, rc_thresh, max_contig, max_read, max_cand, sw_min_score;
     int32_t n_regions;           // regions of this launch (= length of the assembler's queue `order`)
     int32_t flags;               // BK_F_*
     const uint32_t *rmap;        // launch over a subset of the batch (re-run of regions that overflowed a cap): workgroup b of the k-mer kernels takes region rmap[b]; nullptr = region b
 };
-enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64 };   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
+enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64, BK_F_NO_SPLIT = 128, BK_F_SPLIT_ALWAYS = 256 };   // 128: every region is one unit (no component split); 256: split whatever the size (diagnostic: the split path on small fixtures)   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
+
+// component info word (BkRegionWork.o_cinfo, at the component's root read)
+#define BK_SPLIT_G 16                 // units of a split region
+#define BK_CI_UNIT 0xFFu
+#define BK_CI_NOUNIT 0xFFu            // no unit owns it: a component without seed k-mers, until a unit's contig reaches it and claims it
+#define BK_CI_ACTIVE 0x10000u         // has seed k-mers (count >= 2)
+#define BK_CI_REDO 0x20000u           // resolve kernel: merged with a component it met across units; runs again in the next pass
+#define BK_CI_ABORT 0x40000u          // its unit gave it up in this pass (it met another unit's component)
+#define BK_QUEUE_UNIT_SHIFT 24
 
 __device__ inline uint64_t bk_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 

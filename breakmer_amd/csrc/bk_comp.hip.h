@@ -1,0 +1,222 @@
+// bk_comp.hip.h -- splitting a noisy region over several assembler workgroups ("units").
+//
+// init_assembly (sv_assembly.py:30-63) is a serial chain over the seed k-mers: with sequencing noise a region has
+// thousands of seed iterations (an error shared by two or three reads each) and ONE workgroup walks them one after the
+// other -- 0.2 s per region at 0.5 % substitutions whatever else the chip does.  But an iteration only ever touches the
+// reads that hold its seed k-mer, the k-mers of the contig those reads build, the reads that hold those, and so on: the
+// CONNECTED COMPONENT of its seed in the graph {unique reads} -- {sample k-mers} (edge = the read holds the k-mer;
+// homopolymer k-mers, which the assembler never uses, left out).  Iterations in different components read and write
+// disjoint state and commute; the order of the contigs in the result follows from their seed ranks.  Up to ~0.5 % noise
+// that graph has hundreds to a thousand components with seeds (the SV's own is the largest, < 10 % of the seed k-mers; at 1 % it
+// percolates), so BK_SPLIT_G units take disjoint sets of components and each walks its seeds in rank order -- exactly the
+// serial order restricted to what it owns.
+//
+// What the static graph does not know: a contig is built from PIECES of reads, and a k-mer across the seam of two pieces
+// may belong to a read of another component (measured with the oracle at 0.5 %: ~35 such meetings per region).  So the
+// assembler checks every contig k-mer (bk_kmers_ordered): a k-mer of
+//   * a component of the same unit          -> fine (the unit IS the serial order over everything it owns); noted as a merge;
+//   * a component without seeds (no unit)   -> claimed by this unit (atomic), then as above;
+//   * a component of another unit           -> CONFLICT: the unit gives the current component up (nothing of the other
+//                                              unit's state has been touched), notes the pair and goes on with its others.
+// After the pass, bk_resolve_kernel merges the components that met, resets the state of every merged set that holds a
+// conflict (reads, k-mers; its contigs are dropped) and they run again in the next pass -- a few per cent of the work,
+// itself spread over the units.  Passes repeat until none is left (components only ever merge).  bk_link_kernel finally
+// orders the surviving contigs by (seed rank, emission order) = the order init_assembly returns them in.
+// Results are bit-identical to the one-unit run (tests: every noisy fixture with BK_F_NO_SPLIT on and off).
+#pragma once
+#include "bk_common.h"
+
+#define BK_SPLIT_MIN_SEEDS 1024        // regions with fewer seed k-mers stay one unit (a clean SV has 30)
+
+__device__ inline uint32_t bk_ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// lock-free union-find on read indices: roots point to themselves, a root is only ever hooked under a SMALLER root
+__device__ inline uint32_t bk_uf_find(uint32_t *par, uint32_t x)
+{
+    for (;;) {
+        const uint32_t p = bk_ld_agent(&par[x]);
+        if (p == x) return x;
+        const uint32_t gp = bk_ld_agent(&par[p]);
+        if (gp != p) atomicMin(&par[x], gp);                     // path halving (an ancestor: never wrong)
+        x = p;
+    }
+}
+__device__ inline void bk_uf_union(uint32_t *par, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = bk_uf_find(par, a); b = bk_uf_find(par, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }       // a > b: hook a under b
+        if (atomicCAS(&par[a], a, b) == a) return;
+    }
+}
+
+// Called by every thread of the k-mer workgroup at the end of bk_kmer_body.  Decides whether the region is split and, if so,
+// labels the components and deals them to the units.  M2 = number of seed-capable k-mers (ranks 0 .. M2-1, count >= 2).
+// Needs block-wide helpers of bk_kmer.hip.h (bk_arena_alloc, bk_block_sum).  Returns with wk->split set (thread 0).
+__device__ inline void bk_label_components(const BkParams &p, BkRegionWork *wk, uint32_t U, uint32_t M, uint32_t M2,
+                                           const uint32_t *poff, const uint32_t *post, const uint8_t *kstate, uint32_t *scr)
+{
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) { wk->split = 0; wk->pass = 0; wk->units_done = 0; wk->n_cidx = 0; wk->n_pairs = 0; wk->n_conf = 0; }
+    if ((p.flags & BK_F_NO_SPLIT) || p.rmap || U < 4 || (M2 < BK_SPLIT_MIN_SEEDS && !(p.flags & BK_F_SPLIT_ALWAYS)) || M2 < 2) return;      // uniform
+    uint32_t cidx_cap = 64; while (cidx_cap < 2 * U + 64) cidx_cap <<= 1;              // power of two: sorted in place by bk_link_kernel
+    const uint32_t pairs_cap = 4096;
+    const uint64_t b_r = bk_align_up((uint64_t)U * 4, 256), b_k = bk_align_up((uint64_t)M * 4, 256), b_x = (uint64_t)cidx_cap * 16, b_p = bk_align_up((uint64_t)pairs_cap * 12, 256);
+    const uint64_t a0 = bk_arena_alloc(p, 2 * b_r + b_k + b_x + b_p, scr + 20);
+    if (a0 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
+    uint32_t *rroot = (uint32_t *)(p.arena + a0), *cinfo = (uint32_t *)(p.arena + a0 + b_r), *kroot = (uint32_t *)(p.arena + a0 + 2 * b_r);
+    uint32_t *csz = (uint32_t *)(p.arena + a0 + 2 * b_r + b_k);                        // seed k-mers per component: the contig index area, free until the assembler runs
+    for (uint32_t u = tid; u < U; u += nt) { rroot[u] = u; csz[u] = 0; }
+    __threadfence(); __syncthreads();
+    // edges: every read of a k-mer's posting list with the list's first read
+    for (uint32_t j = tid; j < M; j += nt) {
+        if (kstate[j] == BK_K_REMOVED) continue;                                       // homopolymer k-mers: dropped at the start, never used (sv_assembly.py:277)
+        const uint32_t b = poff[j], e = poff[j + 1];
+        if (e - b < 2) continue;
+        const uint32_t a = post[b] >> 10;
+        uint32_t last = a;
+        for (uint32_t i = b + 1; i < e; i++) { const uint32_t v = post[i] >> 10; if (v != last) { bk_uf_union(rroot, a, v); last = v; } }
+    }
+    __threadfence(); __syncthreads();
+    for (uint32_t u = tid; u < U; u += nt) { const uint32_t r = bk_uf_find(rroot, u); atomicMin(&rroot[u], r); }
+    __threadfence(); __syncthreads();
+    uint32_t seeds = 0;
+    for (uint32_t j = tid; j < M; j += nt) {
+        uint32_t r = BK_EMPTY32;
+        if (kstate[j] != BK_K_REMOVED && poff[j + 1] > poff[j]) r = bk_ld_agent(&rroot[post[poff[j]] >> 10]);
+        kroot[j] = r;
+        if (j < M2 && r != BK_EMPTY32) { atomicAdd(&csz[r], 1u); seeds++; }
+    }
+    const uint32_t total = bk_block_sum(seeds, scr);
+    __threadfence(); __syncthreads();
+    // the largest component gets a unit of its own (unit 0), the others are dealt by a hash of their root
+    unsigned long long best = 0;
+    for (uint32_t u = tid; u < U; u += nt) { const uint32_t c = bk_ld_agent(&csz[u]); if (c) { const unsigned long long key = ((unsigned long long)c << 32) | (0xFFFFFFFFu - u); if (key > best) best = key; } }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long ok = __shfl_xor(best, o); if (ok > best) best = ok; }
+    __syncthreads();
+    if ((tid & 63) == 0) { scr[2 * (tid >> 6)] = (uint32_t)best; scr[2 * (tid >> 6) + 1] = (uint32_t)(best >> 32); }
+    __syncthreads();
+    for (uint32_t w = 0; w < (nt >> 6); w++) { const unsigned long long ok = ((unsigned long long)scr[2 * w + 1] << 32) | scr[2 * w]; if (ok > best) best = ok; }
+    __syncthreads();
+    const uint32_t big_root = 0xFFFFFFFFu - (uint32_t)best, big_n = (uint32_t)(best >> 32);
+    // not worth it when one component holds most of the seeds (the graph has percolated: 1 % noise and beyond)
+    const bool split = total >= 2 && (10ull * big_n <= 7ull * total || (p.flags & BK_F_SPLIT_ALWAYS));
+    if (!split) return;                                                                 // uniform; the arena block is simply left unused
+    for (uint32_t u = tid; u < U; u += nt) {
+        uint32_t ci = BK_CI_NOUNIT;
+        if (bk_ld_agent(&csz[u])) ci = (u == big_root ? 0u : 1u + (uint32_t)(mix64(0x9E3779B97F4A7C15ull ^ u) % (BK_SPLIT_G - 1))) | BK_CI_ACTIVE;
+        cinfo[u] = ci;
+    }
+    __threadfence(); __syncthreads();
+    if (tid == 0) {
+        wk->o_rroot = a0; wk->o_cinfo = a0 + b_r; wk->o_kroot = a0 + 2 * b_r; wk->o_cidx = a0 + 2 * b_r + b_k; wk->o_pairs = a0 + 2 * b_r + b_k + b_x;
+        wk->cidx_cap = cidx_cap; wk->pairs_cap = pairs_cap; wk->split = BK_SPLIT_G;
+    }
+}
+
+// ---- after a pass in which components met across units: merge what met, reset and re-deal the sets that hold a conflict ----
+// One workgroup per entry of `list` (regions with status BK_ST_REDO).
+#define BK_RESOLVE_T 512
+extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkParams p, const uint32_t *list)
+{
+    const uint32_t tid = threadIdx.x, nt = BK_RESOLVE_T;
+    const uint32_t r = list[blockIdx.x];
+    BkRegionWork *wk = &p.work[r];
+    const BkRegionDesc d = p.desc[r];
+    const uint32_t U = wk->U, M = wk->M;
+    uint32_t *rroot = (uint32_t *)(p.arena + wk->o_rroot), *cinfo = (uint32_t *)(p.arena + wk->o_cinfo), *kroot = (uint32_t *)(p.arena + wk->o_kroot);
+    const uint32_t *pairs = (const uint32_t *)(p.arena + wk->o_pairs);
+    const uint32_t np = min(wk->n_pairs, wk->pairs_cap), pass = wk->pass + 1;
+    // 1. everything that met becomes one component (merges inside a unit included: their contigs mixed their reads)
+    for (uint32_t i = tid; i < np; i += nt) bk_uf_union(rroot, pairs[3 * i], pairs[3 * i + 1]);
+    __threadfence(); __syncthreads();
+    // 2. a merged set that holds a conflict (or a component its unit gave up) runs again
+    for (uint32_t i = tid; i < np; i += nt) if (pairs[3 * i + 2]) atomicOr(&cinfo[bk_uf_find(rroot, pairs[3 * i])], BK_CI_REDO);
+    for (uint32_t u = tid; u < U; u += nt) if (bk_ld_agent(&rroot[u]) == u && (bk_ld_agent(&cinfo[u]) & BK_CI_ABORT)) atomicOr(&cinfo[bk_uf_find(rroot, u)], BK_CI_REDO);
+    __threadfence(); __syncthreads();
+    for (uint32_t u = tid; u < U; u += nt) {
+        const uint32_t old = bk_ld_agent(&rroot[u]);
+        const uint32_t nr = bk_uf_find(rroot, u);
+        // a root that is hooked under another hands its unit / pass to the new root unless that one runs again anyway (same
+        // unit and pass by construction when neither holds a conflict)
+        if (old == u && nr != u) { const uint32_t ci = bk_ld_agent(&cinfo[u]); if (!(bk_ld_agent(&cinfo[nr]) & BK_CI_REDO) && (ci & BK_CI_UNIT) != BK_CI_NOUNIT) atomicMin(&cinfo[nr], (bk_ld_agent(&cinfo[nr]) & BK_CI_UNIT) == BK_CI_NOUNIT ? (ci & ~BK_CI_ABORT) : 0xFFFFFFFFu); }
+    }
+    __threadfence(); __syncthreads();
+    for (uint32_t u = tid; u < U; u += nt) atomicMin(&rroot[u], bk_uf_find(rroot, u));
+    __threadfence(); __syncthreads();
+    for (uint32_t j = tid; j < M; j += nt) { const uint32_t k0 = kroot[j]; if (k0 != BK_EMPTY32) kroot[j] = bk_ld_agent(&rroot[k0]); }
+    __threadfence(); __syncthreads();
+    // 3. reset the state the assembler keeps per read and per k-mer (as the k-mer stage left it) for what runs again
+    uint8_t *ufl = p.uflag + d.read_meta_off; int32_t *ubuf = p.ubuf + d.read_meta_off, *ureads = p.ureads + d.read_meta_off, *ufound = p.ufound + d.read_meta_off, *uminpos = p.uminpos + d.read_meta_off;
+    uint8_t *kstate = p.arena + wk->o_kstate; int32_t *kstamp = (int32_t *)(p.arena + wk->o_kstamp);
+    for (uint32_t u = tid; u < U; u += nt) {
+        if (!(bk_ld_agent(&cinfo[bk_ld_agent(&rroot[u])]) & BK_CI_REDO)) continue;
+        ufl[u] &= (uint8_t)(BK_R_INDEL | BK_R_HASN); ubuf[u] = 0; ureads[u] = 0; ufound[u] = -1; uminpos[u] = 0x7FFFFFFF;
+    }
+    for (uint32_t j = tid; j < M; j += nt) {
+        const uint32_t k0 = kroot[j];
+        if (k0 == BK_EMPTY32 || !(bk_ld_agent(&cinfo[k0]) & BK_CI_REDO)) continue;
+        kstate[j] = BK_K_LIVE; kstamp[3 * j] = 0; kstamp[3 * j + 1] = 0; kstamp[3 * j + 2] = 0x7FFFFFFF;
+    }
+    __threadfence(); __syncthreads();
+    // 4. deal them to the units of the next pass
+    for (uint32_t u = tid; u < U; u += nt) {
+        if (bk_ld_agent(&rroot[u]) != u) continue;
+        const uint32_t ci = bk_ld_agent(&cinfo[u]);
+        if (ci & BK_CI_REDO) cinfo[u] = (uint32_t)(mix64(0xD1B54A32D192ED03ull * (pass + 1) ^ u) % BK_SPLIT_G) | (pass << 8) | BK_CI_ACTIVE;
+    }
+    __threadfence(); __syncthreads();
+    if (tid == 0) { wk->pass = pass; wk->n_pairs = 0; wk->n_conf = 0; wk->units_done = 0; wk->status = pass >= 200 ? BK_ST_UNSPLIT : BK_ST_OK; }
+}
+
+// ---- the contigs of a split region in the order init_assembly returns them: by (seed rank, emission order); contigs of
+//      components that ran again are dropped (their pass is not the component's last) ----
+#define BK_LINK_T 256
+extern "C" __global__ void __launch_bounds__(BK_LINK_T) bk_link_kernel(BkParams p, int n_regions)
+{
+    const uint32_t tid = threadIdx.x, nt = BK_LINK_T;
+    for (int r = blockIdx.x; r < n_regions; r += gridDim.x) {
+        BkRegionWork *wk = &p.work[r];
+        if (!wk->split || wk->status != BK_ST_OK) continue;                            // uniform
+        const uint32_t *rroot = (const uint32_t *)(p.arena + wk->o_rroot), *cinfo = (const uint32_t *)(p.arena + wk->o_cinfo);
+        unsigned long long *key = (unsigned long long *)(p.arena + wk->o_cidx), *off = key + wk->cidx_cap;
+        const uint32_t n = wk->n_cidx;
+        if (n > wk->cidx_cap) { if (tid == 0) wk->status = BK_ST_UNSPLIT; continue; }
+        uint32_t npad = 1; while (npad < n) npad <<= 1;
+        // dead contigs sort last
+        for (uint32_t i = tid; i < npad; i += nt) {
+            if (i >= n) { key[i] = ~0ull; continue; }
+            const BkContigRec *c = (const BkContigRec *)(p.out + off[i]);
+            if (((cinfo[rroot[c->root]] >> 8) & 0xFFu) != c->pass) key[i] = ~0ull;
+        }
+        __threadfence(); __syncthreads();
+        for (uint32_t sz = 2; sz <= npad; sz <<= 1)
+            for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+                for (uint32_t i = tid; i < npad / 2; i += nt) {
+                    const uint32_t lo = (i / st) * (st * 2) + (i % st), hi = lo + st;
+                    const bool up = (lo & sz) == 0;
+                    const unsigned long long a = key[lo], b = key[hi];
+                    if ((a > b) == up) { key[lo] = b; key[hi] = a; const unsigned long long oa = off[lo]; off[lo] = off[hi]; off[hi] = oa; }
+                }
+                __threadfence(); __syncthreads();
+            }
+        uint32_t live = 0;
+        for (uint32_t i = tid; i < n; i += nt) {
+            if (key[i] == ~0ull) continue;
+            live++;
+            BkContigRec *c = (BkContigRec *)(p.out + off[i]);
+            c->next = (i + 1 < n && key[i + 1] != ~0ull) ? off[i + 1] : 0ull;
+        }
+        for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
+        __shared__ uint32_t red[BK_LINK_T / 64];
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = live;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0; for (uint32_t w = 0; w < nt / 64; w++) tot += red[w];
+            wk->n_contigs = tot; wk->o_first_contig = tot ? off[0] : 0ull; wk->o_last_contig = tot ? off[tot - 1] : 0ull;
+        }
+        __syncthreads();
+    }
+}
