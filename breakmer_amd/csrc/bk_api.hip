@@ -96,6 +96,7 @@ struct bk_handle {
     double submit_pack_ms = 0, submit_h2d_ms = 0;   // host 2-bit packing / host-to-device copies of the last bk_submit_regions
     int n_failed = 0;                                // regions of the last run that hit a device limit (status per region)
     int n_escalated = 0;                             // regions of the last run that were run again with larger assembler caps
+    int n_repair_passes = 0;                         // extra passes over split regions (components that met across units)
     DevBuf d_rmap;                                   // their indices (k-mer kernels of the re-run)
     BkParams params{};
     bkcall::Context call_ctx; bool have_ctx = false, have_tables = false; std::string calls_blob;
@@ -455,7 +456,7 @@ static void fill_params(bk_handle *h)
     p.ubuf = (int32_t *)h->d_ubuf.p; p.ureads = (int32_t *)h->d_ureads.p; p.ufound = (int32_t *)h->d_ufound.p; p.uminpos = (int32_t *)h->d_uminpos.p;
     p.arena = (uint8_t *)h->d_arena.p; p.arena_top = (unsigned long long *)h->d_tops.p; p.arena_cap = h->arena_cap;
     p.out = (uint8_t *)h->d_out.p; p.out_top = (unsigned long long *)h->d_tops.p + 1; p.out_cap = h->out_cap;
-    p.n_clist = (unsigned long long *)h->d_tops.p + 2; p.asm_head = (unsigned long long *)h->d_tops.p + 3; p.sw_head = (unsigned long long *)h->d_tops.p + 4;
+    p.n_clist = (unsigned long long *)h->d_tops.p + 2; p.asm_head = (unsigned long long *)h->d_tops.p + 3; p.sw_head = (unsigned long long *)h->d_tops.p + 4; p.n_queue = (unsigned long long *)h->d_tops.p + 5;
     p.order = (uint32_t *)h->d_order.p; p.clist = (unsigned long long *)h->d_clist.p; p.clist_cap = h->d_clist.bytes / 8;
     p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->eff_max_read;
     p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions; p.flags = h->cfg.reserved[0];
@@ -486,29 +487,30 @@ static bool escalated_caps(const bk_handle *h, int &max_cand, int &max_contig)
     return max_cand > h->cfg.max_candidates || max_contig > h->cfg.max_contig_len;
 }
 
-// subset == nullptr: the whole batch.  Else: only these regions, from the k-mer stage on (it resets their state), with the
-// escalated caps, on top of what the batch's run left in the arenas (bump pointers and the contig list go on).
-static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subset = nullptr)
+// subset == nullptr: the whole batch.  Else: only these regions, from the k-mer stage on (it resets their state), each as ONE unit
+// (no component split), with the escalated caps if `escalate`, on top of what the batch's run left in the arenas (bump
+// pointers and the contig list go on).
+static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subset = nullptr, bool escalate = true)
 {
     // every contig record takes >= 256 B of the result arena, so out_cap / 256 list entries can never overflow
     HIPCHK(h, h->d_clist.ensure(std::max<uint64_t>(h->out_cap / 256, 1024) * 8));
     uint32_t npad = 1; while ((int)npad < h->n_regions) npad <<= 1;
-    HIPCHK(h, h->d_order.ensure((size_t)h->n_regions * 4)); HIPCHK(h, h->d_skeys.ensure((size_t)npad * 8));
+    HIPCHK(h, h->d_order.ensure((size_t)h->n_regions * 4 * BK_SPLIT_G)); HIPCHK(h, h->d_skeys.ensure((size_t)npad * 8));      // queue: up to BK_SPLIT_G units per region
     fill_params(h);
     const int n_launch = subset ? (int)subset->size() : h->n_regions;
     int max_cand = h->cfg.max_candidates, max_contig = h->cfg.max_contig_len;
     if (subset) {
-        escalated_caps(h, max_cand, max_contig);
+        if (escalate) escalated_caps(h, max_cand, max_contig);
         HIPCHK(h, h->d_rmap.ensure(subset->size() * 4));
-        HIPCHK(h, hipMemcpyAsync(h->d_rmap.p, subset->data(), subset->size() * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_order.p, subset->data(), subset->size() * 4, hipMemcpyHostToDevice, h->stream));      // the assembler's queue: these regions, in index order
-        unsigned long long tops[5];
+        HIPCHK(h, hipMemcpy(h->d_rmap.p, subset->data(), subset->size() * 4, hipMemcpyHostToDevice));       // (the stream is idle: bk_sync has just waited for it)
+        HIPCHK(h, hipMemcpy(h->d_order.p, subset->data(), subset->size() * 4, hipMemcpyHostToDevice));      // the assembler's queue: these regions, in index order
+        unsigned long long tops[6];
         HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
-        tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 8);      // region queue from its start; the realigner goes on behind the contigs it has seen
-        HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 8); tops[5] = (unsigned long long)n_launch;      // unit queue from its start; the realigner goes on behind the contigs it has seen
+        HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
         h->params.rmap = (const uint32_t *)h->d_rmap.p; h->params.n_regions = n_launch; h->params.max_cand = max_cand; h->params.max_contig = max_contig;
     } else {
-        static const unsigned long long tops[5] = {256, 256, 0, 0, 0};      // arena top, out top, contigs listed, region queue head, contig queue head
+        static const unsigned long long tops[6] = {256, 256, 0, 0, 0, 0};      // arena top, out top, contigs listed, unit queue head, contig queue head, units queued (bk_sched_kernel)
         HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
@@ -549,10 +551,16 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         if (!subset) { h->asm_wg_per_cu = per_cu; h->asm_threads = threads; }
-        const int grid = std::min<long long>(n_launch, (long long)per_cu * h->n_cu);
+        // (a noisy region is split into up to BK_SPLIT_G units on the device, bk_comp.hip.h: the host only knows the bound)
+        const bool may_split = !subset && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
+        const int grid = std::min<long long>((long long)n_launch * (may_split ? BK_SPLIT_G : 1), (long long)per_cu * h->n_cu);
         if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
         else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
         HIPCHK(h, hipGetLastError());
+        if (may_split) {          // contigs of split regions in the reference's order (idle for the others)
+            hipLaunchKernelGGL(bk_link_kernel, dim3(std::min(h->n_regions, h->n_cu)), dim3(BK_LINK_T), 0, h->stream, h->params, h->n_regions);
+            HIPCHK(h, hipGetLastError());
+        }
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if (mask & BK_STAGE_REALIGN) {
@@ -567,6 +575,48 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bk_sw_kernel, BK_ST_T, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         if (!subset) h->sw_wg_per_cu = per_cu;
         hipLaunchKernelGGL(bk_sw_kernel, dim3(per_cu * h->n_cu), dim3(BK_ST_T), lds, h->stream, h->params, tw_cap);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    return BK_OK;
+}
+
+// Another pass over split regions whose components met across units (status BK_ST_REDO): merge + reset on the device
+// (bk_resolve_kernel), every unit of those regions again (it takes what was re-dealt to it), contigs re-linked, the new ones
+// realigned.  Same kernels and caps as the batch's run.
+static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t> &redo)
+{
+    fill_params(h);
+    const int n = (int)redo.size();
+    HIPCHK(h, h->d_rmap.ensure(redo.size() * 4));
+    HIPCHK(h, hipMemcpy(h->d_rmap.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));             // (the stream is idle: bk_sync has just waited for it)
+    std::vector<uint32_t> q; q.reserve((size_t)n * BK_SPLIT_G);
+    for (uint32_t r : redo) for (uint32_t g = 0; g < BK_SPLIT_G; g++) q.push_back(r | (g << BK_QUEUE_UNIT_SHIFT));
+    HIPCHK(h, hipMemcpy(h->d_order.p, q.data(), q.size() * 4, hipMemcpyHostToDevice));
+    unsigned long long tops[6];
+    HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
+    tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 8); tops[5] = (unsigned long long)q.size();
+    HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    hipLaunchKernelGGL(bk_resolve_kernel, dim3(n), dim3(BK_RESOLVE_T), 0, h->stream, h->params, (const uint32_t *)h->d_rmap.p);
+    HIPCHK(h, hipGetLastError());
+    const int threads = h->asm_threads;
+    const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
+    const size_t lds = asm_lds_bytes(h, threads, h->cfg.max_candidates, h->cfg.max_contig_len);
+    const int grid = std::min<long long>((long long)q.size(), (long long)std::max(1, h->asm_wg_per_cu) * h->n_cu);
+    if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
+    else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(bk_link_kernel, dim3(std::min(h->n_regions, h->n_cu)), dim3(BK_LINK_T), 0, h->stream, h->params, h->n_regions);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    if (mask & BK_STAGE_REALIGN) {
+        const int max_contig = h->cfg.max_contig_len;
+        uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)max_contig + 16, std::max<uint32_t>(131072, 4 * (uint32_t)max_contig));
+        while (sw_lds_bytes(max_contig, tw_cap) > BK_LDS_MAX && tw_cap > 2 * (uint32_t)max_contig + 4096) tw_cap -= 4096;
+        const size_t slds = sw_lds_bytes(max_contig, tw_cap);
+        hipLaunchKernelGGL(bk_sw_kernel, dim3(std::max(1, h->sw_wg_per_cu) * h->n_cu), dim3(BK_ST_T), slds, h->stream, h->params, tw_cap);
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
@@ -607,7 +657,7 @@ static int sync_impl(bk_handle *h)
     h->hold_snapshot = false;                       // the work records below replace the fetched copy's
     HIPCHK(h, hipSetDevice(h->dev));
     bool escalated = false; float ms_first[4] = {0, 0, 0, 0};
-    h->n_escalated = 0;
+    h->n_escalated = 0; h->n_repair_passes = 0;
     for (int attempt = 0; attempt < 16; attempt++) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->h_work.resize(h->n_regions);
@@ -616,19 +666,39 @@ static int sync_impl(bk_handle *h)
         // the others that did, under caps 4x larger (below).  One that overflows those too fails ALONE: its status is kept
         // (bk_get_region_status), it reports no contigs, the other regions of the batch are unaffected.
         bool grow_arena = false, grow_out = false; int bad = 0;
-        std::vector<uint32_t> over;
+        std::vector<uint32_t> over, redo, unsplit;
         for (int r = 0; r < h->n_regions; r++) {
             int s = h->h_work[r].status;
-            if (s == BK_ST_ARENA) grow_arena = true; else if (s == BK_ST_OUT) grow_out = true; else if (s != BK_ST_OK) { bad++; if (s == BK_ST_CAND || s == BK_ST_CONTIG || s == BK_ST_KLIST) over.push_back((uint32_t)r); }
+            if (s == BK_ST_ARENA) grow_arena = true; else if (s == BK_ST_OUT) grow_out = true;
+            else if (s == BK_ST_REDO) redo.push_back((uint32_t)r); else if (s == BK_ST_UNSPLIT) unsplit.push_back((uint32_t)r);
+            else if (s != BK_ST_OK) { bad++; if (s == BK_ST_CAND || s == BK_ST_CONTIG || s == BK_ST_KLIST) over.push_back((uint32_t)r); }
         }
         h->n_failed = bad;
         if (!grow_arena && !grow_out) {
             float ms[4];
             for (int i = 0; i < 3; i++) { ms[i + 1] = 0; (void)hipEventElapsedTime(&ms[i + 1], h->ev[i], h->ev[i + 1]); }
             ms[0] = 0; (void)hipEventElapsedTime(&ms[0], h->ev[0], h->ev[3]);
+            if (getenv("BK_DEBUG_SPLIT")) {
+                unsigned long long np_ = 0, nc_ = 0, nx_ = 0, ns_ = 0; for (int r = 0; r < h->n_regions; r++) { const BkRegionWork &w = h->h_work[r]; if (w.split) { ns_++; np_ += w.n_pairs; nc_ += w.n_conf; nx_ += w.n_cidx; } }
+                fprintf(stderr, "[bk split] pass %d: %zu region(s) to repair, %zu to unsplit; split regions %llu, meetings noted %llu (conflicts %llu), contigs emitted so far %llu; kernels %.2f / %.2f / %.2f ms\n",
+                        h->n_repair_passes, redo.size(), unsplit.size(), ns_, np_, nc_, nx_, ms[1], ms[2], ms[3]);
+                for (int r = 0; r < h->n_regions && r < 4; r++) { const BkRegionWork &w = h->h_work[r]; if (!w.split) continue;
+                    fprintf(stderr, "   region %d  U %u M %u M2 %u  unit us/iters:", r, w.U, w.M, w.M2); for (int g = 0; g < BK_SPLIT_G; g++) fprintf(stderr, " %u/%u", w.unit_us[g], w.unit_iters[g]); fprintf(stderr, "\n"); }
+            }
+            if (!redo.empty() || !unsplit.empty()) {
+                // split regions (bk_comp.hip.h): components that met across units are merged and run again (a few per cent of the
+                // region's work per pass); a region whose split bookkeeping overflowed is run again as one unit
+                for (int i = 0; i < 4; i++) ms_first[i] += ms[i];
+                h->n_repair_passes++;
+                int rc = !redo.empty() ? launch_repair(h, h->ran_mask, redo) : launch(h, h->ran_mask, &unsplit, false);
+                if (rc != BK_OK) return rc;
+                attempt--;                                   // bounded by the passes themselves (components only ever merge)
+                if (h->n_repair_passes > 400) return fail(h, BK_E_HIP, "bk_sync: split regions did not settle");
+                continue;
+            }
             int mc, ml;
             if (!over.empty() && !escalated && h->cfg.reserved[2] != 1 && (h->ran_mask & BK_STAGE_ASSEMBLE) && escalated_caps(h, mc, ml)) {
-                for (int i = 0; i < 4; i++) ms_first[i] = ms[i];
+                for (int i = 0; i < 4; i++) ms_first[i] += ms[i];
                 escalated = true; h->n_escalated = (int)over.size();
                 int rc = launch(h, h->ran_mask, &over);
                 if (rc != BK_OK) return rc;
@@ -647,7 +717,7 @@ static int sync_impl(bk_handle *h)
         // and must not jump from 42 to 166)
         if (grow_arena) { h->arena_cap = std::max<uint64_t>(h->arena_cap < (4ull << 30) ? h->arena_cap * 4 : h->arena_cap + h->arena_cap / 2, tops[0] + tops[0] / 4); HIPCHK(h, h->d_arena.ensure(h->arena_cap)); }
         if (grow_out) { h->out_cap = std::max<uint64_t>(h->out_cap * 4, tops[1] + tops[1] / 2); HIPCHK(h, h->d_out.ensure(h->out_cap)); }
-        escalated = false; h->n_escalated = 0; for (float &m : ms_first) m = 0;      // the whole batch again: regions that overflow a cap will be re-run again
+        escalated = false; h->n_escalated = 0; h->n_repair_passes = 0; for (float &m : ms_first) m = 0;      // the whole batch again: regions that overflow a cap will be re-run again
         int rc = launch(h, h->ran_mask);
         if (rc != BK_OK) return rc;
     }
@@ -1033,6 +1103,8 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     if (which == 21) v = (uint64_t)(h->submit_h2d_ms * 1000.0);
     if (which == 22) v = (uint64_t)h->n_failed;
     if (which == 26) v = (uint64_t)h->n_escalated;
+    if (which == 27) v = (uint64_t)h->n_repair_passes;
+    if (which == 28) { v = 0; for (int r = 0; r < h->n_regions; r++) v += h->h_work[r].split ? 1 : 0; }          // regions that were split into units
     if (which == 23) v = (uint64_t)h->asm_wg_per_cu;                        // resident assembler / realign workgroups per CU (occupancy query)
     if (which == 24) v = (uint64_t)h->sw_wg_per_cu;
     if (which == 25) v = (uint64_t)h->asm_threads;

@@ -32,6 +32,7 @@
 #define BK_SPEC_WIDE (BK_AT / 128)  // contigs beyond BK_NW_DUAL_COLS or few reads in a round: half as many slots x 2 wavefronts (one DP each)
 
 
+#define BK_ACC_MAX 32
 enum { BK_ORD_FOR = 0, BK_ORD_REV = 1, BK_ORD_MID = 2 };
 enum { BK_DEC_NONE = 0, BK_DEC_SAME = 1, BK_DEC_SUPER = 2, BK_DEC_SUB = 3, BK_DEC_POST = 4, BK_DEC_PRE = 5 };
 
@@ -53,7 +54,6 @@ struct BkAsmShared {
     int ncand, dec, dstart, dend, tmp0, tmp1, tmp2;
     int n_contigs;
     unsigned long long cells, calls;
-    BkNwResult v1, v2;
     // look-ahead slots (see bk_run_candidates): read q+s aligned against the PREDICTED contig after reads q..q+s-1
     struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt, hasn, vt, rank, fu, first, dec, ds, de; BkNwResult v1, v2; } slot[BK_SPEC];
     int nb, pc, last_dec, dual;
@@ -67,7 +67,11 @@ struct BkAsmShared {
     int la_n[BK_WAVES], la_t[BK_WAVES], la_rank[BK_WAVES], la_pc[BK_WAVES];      // one look-ahead list per wavefront
     int qslot;                   // position in the region queue this workgroup is working on
     int kscan;                   // contig k-mer list: the entries before this index are all in checked_kmers (grow snapshots only look at what came after)
-    uint32_t scan[24];
+    // split regions (bk_comp.hip.h): the component of the current seed, the components its contigs have taken in (same unit or
+    // claimed), what bk_kmers_ordered found beyond them
+    int seed_rank, emit_seq, t0;
+    uint32_t ccomp, acc_n, foreign, foreign_root;       // (the list of taken-in components itself: C_.acc_root, global scratch -- it is only looked at when a k-mer of another component turns up)
+    uint32_t scan[10];
 #ifdef BK_PHASE_STAMPS
     unsigned long long acc[24], last; int ctx;
 #endif
@@ -89,7 +93,7 @@ struct BkAsmCtx {
     const uint32_t *nlist; uint32_t n_nlist;   // N calls of the region's reads (read index << 10 | position), sorted
     uint32_t *urep, *unr; uint8_t *ufl; int32_t *ubuf, *ureads, *ufound, *uminpos;
     const uint32_t *ulen;                      // length of unique read u (k-mer stage)
-    const uint32_t *tslot, *trank; const uint64_t *klo, *khi; const uint32_t *kcnt; uint8_t *kstate; int32_t *kstamp;
+    const uint32_t *tslot; const uint64_t *klo, *khi; const uint32_t *kcnt; uint8_t *kstate; int32_t *kstamp;
     const uint32_t *poff, *post;
     uint32_t U, M, tmask;
     // per-region scratch (arena)
@@ -98,6 +102,9 @@ struct BkAsmCtx {
     uint32_t *pend;              // FIFO: 2 words per entry (rank, u)
     uint32_t *altl, *readl, *usedl;
     int MAXC, MAXR, MAXCAND, KCAP, k, flags;
+    // split regions: this workgroup is unit `unit` of `split`; it owns the components whose info word reads `want`
+    int split, unit, pass; uint32_t want, M2;
+    const uint32_t *kroot; uint32_t *cinfo; unsigned long long *cidx_key; uint32_t *pairs, *acc_root;
 };
 
 // Functions off the DP round trip (emit, alt reads, find_reads, contig k-mer lists) are kept out of line: inlined into
@@ -172,6 +179,16 @@ __device__ inline void bk_patch_n(uint32_t i, uint8_t *dst, int from, int count)
     uint32_t lo, hi; bk_nlist_range(C_.nlist, C_.n_nlist, i, lo, hi);
     for (uint32_t e = lo; e < hi; e++) { const int q = (int)(C_.nlist[e] & 1023u) - from; if (q >= 0 && q < count) dst[q] = BK_CODE_N; }
 }
+
+// split regions: does k-mer `rk` belong to a component this unit owns in this pass (always true for an unsplit region)
+__device__ inline bool bk_mine(int rk)
+{
+    if (!C_.split) return true;
+    const uint32_t root = C_.kroot[rk];
+    if (root == BK_EMPTY32) return false;
+    return (__hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (0xFFFFu | BK_CI_ABORT)) == C_.want;
+}
+__device__ inline bool bk_acc_has(uint32_t root) { BkAsmShared *S = S_; if (root == S->ccomp) return true; for (uint32_t i = 0; i < S->acc_n; i++) if (C_.acc_root[i] == root) return true; return false; }
 
 // sample k-mer table lookup -> rank or -1 (any state)
 __device__ inline int bk_lookup(const BkKey &key)
@@ -304,12 +321,41 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
     const int m = L / 2;
     if (np > 2 * C_.MAXCAND) { bk_fail(BK_ST_KLIST); BK_SYNC(); return; }
     if (np <= 0 && order != BK_ORD_MID) return;         // a one-base extension has no new k-mer (Q1: range(0, L-k) of a window of k bases): nothing to append, six barriers saved
+    if (S->status) return;                              // (uniform) a conflict is being unwound
+    // Split regions: a k-mer of a component this unit does not hold counts as a meeting WHATEVER its state says -- the other unit
+    // may be ahead of this one in seed order, and what it has removed by now may still have been there at this seed's turn in
+    // the serial order.  (Homopolymer k-mers are in no component: kroot = BK_EMPTY32.)  Bit 30 of tmp[x]: removed.
     for (int x = BK_TID; x < np; x += BK_AT) {
         BkKey key; uint32_t st = 0; int rk = bk_bytes_kmer(L_CSEQ + s0 + x, k, key) ? bk_lookup_state(key, st) : -1;
-        if (rk >= 0 && st == BK_K_REMOVED) rk = -1;                     // not in akmers.smers_set
+        if (C_.split && rk >= 0) { const uint32_t root = C_.kroot[rk]; if (root != BK_EMPTY32 && root != S->ccomp && !bk_acc_has(root)) { S->foreign = 1; atomicMin(&S->foreign_root, root); } }
+        if (rk >= 0 && st == BK_K_REMOVED) rk = C_.split ? (rk | 0x40000000) : -1;                     // not in akmers.smers_set
         tmp[x] = rk;
     }
     BK_SYNC();
+    if (C_.split && S->foreign) {
+        // The contig holds k-mers of components other than the seed's (a k-mer across the seam of two read pieces).  One new
+        // component per turn, smallest root first: same unit -> taken in; no unit (it has no seeds) -> claimed, taken in;
+        // another unit's -> the current component is given up (bk_comp.hip.h).  Rare: thread 0 decides, everyone re-checks.
+        for (;;) {
+            if (BK_TID == 0) {
+                const uint32_t root = S->foreign_root;
+                uint32_t ci = __hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((ci & BK_CI_UNIT) == BK_CI_NOUNIT) { const uint32_t old = atomicCAS(&C_.cinfo[root], ci, C_.want); ci = old == ci ? C_.want : old; }
+                const bool mine = (ci & (0xFFFFu | BK_CI_ABORT)) == C_.want && S->acc_n < BK_ACC_MAX;
+                const uint32_t at = atomicAdd(&C_.wk->n_pairs, 1u);
+                if (at < C_.wk->pairs_cap) { C_.pairs[3 * at] = S->ccomp; C_.pairs[3 * at + 1] = root; C_.pairs[3 * at + 2] = mine ? 0u : 1u; }
+                if (mine) { C_.acc_root[S->acc_n] = root; __threadfence_block(); S->acc_n++; }
+                else { atomicAdd(&C_.wk->n_conf, 1u); S->status = BK_ST_CONFLICT; }
+                S->foreign = 0; S->foreign_root = BK_EMPTY32;
+            }
+            BK_SYNC();
+            if (S->status) return;
+            for (int x = BK_TID; x < np; x += BK_AT) { const int rk = tmp[x]; if (rk >= 0) { const uint32_t root = C_.kroot[rk & 0x3FFFFFFF]; if (root != BK_EMPTY32 && root != S->ccomp && !bk_acc_has(root)) { S->foreign = 1; atomicMin(&S->foreign_root, root); } } }
+            BK_SYNC();
+            if (!S->foreign) break;
+        }
+    }
+    if (C_.split) { for (int x = BK_TID; x < np; x += BK_AT) if (tmp[x] >= 0 && (tmp[x] & 0x40000000)) tmp[x] = -1; BK_SYNC(); }
     const int chunk = (max(np, 0) + BK_AT - 1) / BK_AT, b = BK_TID * chunk, e = min(np, b + chunk);
     uint32_t cnt = 0, T;
     for (int x = b; x < e; x++) cnt += tmp[x] >= 0;
@@ -733,7 +779,7 @@ BK_COLD void bk_seedahead_wave(int w, int rank)
     BkAsmShared *S = S_;
     const int lane = BK_TID & 63;
     const int r = rank + 1 + lane;
-    const bool live = r < (int)C_.M && C_.kstate[r < (int)C_.M ? r : 0] == BK_K_LIVE && C_.kcnt[r < (int)C_.M ? r : 0] >= 2;
+    const bool live = r < (int)C_.M2 && C_.kstate[r < (int)C_.M2 ? r : 0] == BK_K_LIVE && C_.kcnt[r < (int)C_.M2 ? r : 0] >= 2 && bk_mine(r < (int)C_.M2 ? r : 0);
     unsigned long long m = __ballot(live);
     for (int i = 0; i < w; i++) m &= m - 1;
     int cnt = -1, rank2 = 0;
@@ -1423,10 +1469,10 @@ BK_COLD void bk_emit_contig()
         uint64_t need = bk_align_up(size, 256);
         uint64_t off = atomicAdd(C_.out_top, (unsigned long long)need);
         if (off + need > C_.out_cap) { off = 0; S->status = BK_ST_OUT; }
-        S->scan[20] = (uint32_t)off; S->scan[21] = (uint32_t)(off >> 32);
+        S->scan[8] = (uint32_t)off; S->scan[9] = (uint32_t)(off >> 32);
     }
     BK_SYNC();
-    const uint64_t off = ((uint64_t)S->scan[21] << 32) | S->scan[20];
+    const uint64_t off = ((uint64_t)S->scan[9] << 32) | S->scan[8];
     if (off == 0) return;                                 // offset 0 is reserved (out_top starts at 256)
     uint8_t *rec = C_.out + off;
     BkContigRec *h = (BkContigRec *)rec;
@@ -1439,7 +1485,9 @@ BK_COLD void bk_emit_contig()
     for (int t = BK_TID; t < nk; t += BK_AT) { uint32_t rk = C_.klist[t] & 0x7FFFFFFFu; okm[2 * t] = C_.klo[rk]; okm[2 * t + 1] = C_.khi[rk]; }
     for (int t = BK_TID; t < nr; t += BK_AT) ord_[t] = C_.urep[C_.readl[t]];
     // first occurrence of every sample k-mer in the contig (str.find over all len-k+1 positions)
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0) atomicMin(&C_.kstamp[3 * rk + 2], x); }
+    // (split regions: the stamps of other units' k-mers are left alone -- only the contig's own k-mers are read back below, and
+    // those all belong to components this unit holds)
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.split || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_has(C_.kroot[rk])))) atomicMin(&C_.kstamp[3 * rk + 2], x); }
     BK_SYNC();
     for (int t = BK_TID; t < nk; t += BK_AT) {
         int pos = C_.kstamp[3 * (C_.klist[t] & 0x7FFFFFFFu) + 2];
@@ -1447,12 +1495,20 @@ BK_COLD void bk_emit_contig()
         for (int q = pos; q < min(pos + k, len); q++) atomicAdd(&okl[q], 1);
     }
     BK_SYNC();
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.split || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_has(C_.kroot[rk])))) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
     if (BK_TID == 0) {
+        h->root = S->ccomp; h->pass = (uint32_t)C_.pass;
         h->next = 0; h->hits_off = 0; h->seq_len = len; h->counts_len = nlen; h->n_kmers = nk; h->n_reads = nr; h->total_reads = total; h->n_hits = 0;
         h->o_seq = o_seq; h->o_io = o_io; h->o_ot = o_ot; h->o_klocs = o_kl; h->o_kmers = o_km; h->o_reads = o_rd; h->n_sec = 0; h->size = size;
-        if (C_.wk->o_first_contig == 0) C_.wk->o_first_contig = off; else ((BkContigRec *)(C_.out + C_.wk->o_last_contig))->next = off;
-        C_.wk->o_last_contig = off; S->n_contigs++;
+        if (C_.split) {       // the units of a region emit side by side: (order key, record) pairs, ordered and linked by bk_link_kernel
+            const uint32_t at = atomicAdd(&C_.wk->n_cidx, 1u);
+            if (at < C_.wk->cidx_cap) { C_.cidx_key[at] = ((unsigned long long)(uint32_t)S->seed_rank << 20) | (unsigned long long)(uint32_t)min(S->emit_seq, 0xFFFFF); C_.cidx_key[C_.wk->cidx_cap + at] = off; }
+            S->emit_seq++;
+        } else {
+            if (C_.wk->o_first_contig == 0) C_.wk->o_first_contig = off; else ((BkContigRec *)(C_.out + C_.wk->o_last_contig))->next = off;
+            C_.wk->o_last_contig = off;
+        }
+        S->n_contigs++;
         const unsigned long long ci = atomicAdd(C_.n_clist, 1ull);              // work list of the realign stage (one workgroup per contig)
         if (ci < C_.clist_cap) C_.clist[ci] = off | ((unsigned long long)C_.region << 40);
     }
@@ -1485,11 +1541,11 @@ __device__ inline void bk_setup_contigs(int rank)
     BK_ACC(8); BK_CTX(0);
 }
 
-__device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
+__device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, const int unit)
 {
     BkAsmShared *S = S_;
     BkRegionWork *wk = &p.work[r];
-    if (wk->status != BK_ST_OK) return;                                            // k-mer stage failed for this region
+    if (__hip_atomic_load(&wk->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BK_ST_OK && !wk->split) return;              // k-mer stage failed for this region (a split region: another unit may have failed meanwhile; this one still reports in below)
     if (BK_TID == 0) {
         const BkRegionDesc d = p.desc[r];
         BkAsmCtx &c = C_;
@@ -1511,8 +1567,15 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         c.nlist = p.nlist + d.nlist_off; c.n_nlist = d.n_nlist;
         const uint64_t mo = d.read_meta_off;
         c.urep = p.urep + mo; c.unr = p.unreads + mo; c.ufl = p.uflag + mo; c.ubuf = p.ubuf + mo; c.ureads = p.ureads + mo; c.ufound = p.ufound + mo; c.uminpos = p.uminpos + mo; c.ulen = p.dd_rep + d.dedup_off;
-        c.U = wk->U; c.M = wk->M; c.tmask = wk->tcap - 1;
-        c.tslot = (const uint32_t *)(p.arena + wk->o_tslot); c.trank = (const uint32_t *)(p.arena + wk->o_trank);
+        c.U = wk->U; c.M = wk->M; c.tmask = wk->tcap - 1; c.M2 = wk->M2;
+        c.split = (int)wk->split; c.unit = unit; c.pass = (int)wk->pass; c.want = (uint32_t)unit | ((uint32_t)wk->pass << 8);
+        if (c.split) {
+            c.kroot = (const uint32_t *)(p.arena + wk->o_kroot); c.cinfo = (uint32_t *)(p.arena + wk->o_cinfo);
+            c.cidx_key = (unsigned long long *)(p.arena + wk->o_cidx); c.pairs = (uint32_t *)(p.arena + wk->o_pairs);
+        }
+        S->ccomp = 0; S->acc_n = 0; S->foreign = 0; S->foreign_root = BK_EMPTY32; S->seed_rank = 0; S->emit_seq = 0;
+        S->t0 = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull);      // diagnostic: when the unit started
+        c.tslot = (const uint32_t *)(p.arena + wk->o_tslot);
         c.klo = (const uint64_t *)(p.arena + wk->o_key_lo); c.khi = (const uint64_t *)(p.arena + wk->o_key_hi);
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
         c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
@@ -1525,32 +1588,33 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
         // per-region scratch from the arena
         const uint64_t b_cnt = (uint64_t)8 * c.MAXC * 4, b_kl = (uint64_t)c.KCAP * 4, b_pend = (uint64_t)2 * (c.U + 1) * 4, b_alt = (uint64_t)c.MAXCAND * 4,
                        b_rd = (uint64_t)(c.U + 1) * 4, b_used = (uint64_t)(c.M + 1) * 4;
-        uint64_t need = bk_align_up(b_cnt + 2 * b_kl + b_pend + b_alt + b_rd + b_used + 64, 256);
+        uint64_t need = bk_align_up(b_cnt + 2 * b_kl + b_pend + b_alt + b_rd + b_used + 64 + BK_ACC_MAX * 4, 256);
         uint64_t off = atomicAdd(p.arena_top, (unsigned long long)need);
         if (off + need > p.arena_cap) S->status = BK_ST_ARENA;
         else {
             uint8_t *sp = p.arena + off;
             c.cnt = (int32_t *)sp; sp += b_cnt; c.klist = (uint32_t *)sp; sp += b_kl; c.nklist = (uint32_t *)sp; sp += b_kl;
-            c.pend = (uint32_t *)sp; sp += b_pend; c.altl = (uint32_t *)sp; sp += b_alt; c.readl = (uint32_t *)sp; sp += b_rd; c.usedl = (uint32_t *)sp;
+            c.pend = (uint32_t *)sp; sp += b_pend; c.altl = (uint32_t *)sp; sp += b_alt; c.readl = (uint32_t *)sp; sp += b_rd; c.usedl = (uint32_t *)sp; sp += b_used; c.acc_root = (uint32_t *)sp;
         }
     }
     BK_SYNC();
-    if (C_.M == 0) { if (BK_TID == 0) wk->n_contigs = 0; return; }                 // init_assembly :33-34
-    if (S->status) { if (BK_TID == 0) wk->status = S->status; return; }
+    if (C_.M == 0 && !C_.split) { if (BK_TID == 0) wk->n_contigs = 0; return; }                 // init_assembly :33-34
+    if (S->status && !C_.split) { if (BK_TID == 0) wk->status = S->status; return; }
     // ---- init_assembly main loop (:43-62) --------------------------------------------------------------
-    for (;;) {
+    while (!S->status) {
         // first k-mer still in akmers.mers in (count, mer) descending order; has_mers (:318-322) <=> its count > 1
+        // (the seed-capable k-mers are ranks 0 .. M2-1; a unit of a split region takes those of its own components)
         int head = S->head, found = -1;
-        while (head < (int)C_.M) {
+        while (head < (int)C_.M2) {
             int cand_rk = head + BK_TID;
-            int mine = (cand_rk < (int)C_.M && C_.kstate[cand_rk] != BK_K_REMOVED) ? cand_rk : 0x7FFFFFFF;
+            int mine = (cand_rk < (int)C_.M2 && C_.kstate[cand_rk] != BK_K_REMOVED && bk_mine(cand_rk)) ? cand_rk : 0x7FFFFFFF;
             int mn = -bk_max256(-mine, S->scan);
             if (mn != 0x7FFFFFFF) { found = mn; break; }
             head += BK_AT;
         }
         if (found < 0 || C_.kcnt[found] < 2) break;
         BK_SYNC();
-        if (BK_TID == 0) S->head = found;
+        if (BK_TID == 0) { S->head = found; S->seed_rank = found; S->emit_seq = 0; S->acc_n = 0; S->ccomp = C_.split ? C_.kroot[found] : 0u; if (C_.split) C_.wk->unit_iters[C_.unit]++; }
         BK_SYNC();
         BK_ACC(11);
         bk_setup_contigs(found);
@@ -1565,6 +1629,19 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
             bk_grow();
             if (!S->status) bk_emit_contig();
         }
+        if (S->status == BK_ST_CONFLICT) {
+            // The iteration met a component of another unit: nothing of that unit's state was touched.  The seed's component and
+            // what its contigs had taken in are given up for this pass (bk_resolve_kernel merges them with what they met and
+            // they run again); the unit goes on with its other components.
+            BK_SYNC();
+            if (BK_TID == 0) {
+                atomicOr(&C_.cinfo[S->ccomp], BK_CI_ABORT);
+                for (uint32_t i = 0; i < S->acc_n; i++) atomicOr(&C_.cinfo[C_.acc_root[i]], BK_CI_ABORT);
+                S->status = 0; S->phead = S->ptail; S->nused = 0; S->nalt = 0; S->plan_ok = 0;
+            }
+            BK_SYNC();
+            continue;
+        }
         if (S->status) break;
         BK_SYNC();
         const int nu = S->nused;
@@ -1576,7 +1653,25 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r)
     }
     BK_SYNC();
     BK_ACC(S_->ctx);
-    if (BK_TID == 0) { C_.wk->n_contigs = (uint32_t)S->n_contigs; C_.wk->nw_cells = S->cells; C_.wk->nw_calls = S->calls; if (S->status) C_.wk->status = S->status; }
+    if (BK_TID == 0) {
+        if (!C_.split) { C_.wk->n_contigs = (uint32_t)S->n_contigs; C_.wk->nw_cells = S->cells; C_.wk->nw_calls = S->calls; if (S->status) C_.wk->status = S->status; }
+        else {
+            // a unit reports in; the last one of the region decides what the host sees: a failed unit fails the region (the library
+            // runs it again as one unit under larger caps), components that met across units mean another pass
+            atomicAdd((unsigned long long *)&C_.wk->nw_cells, S->cells); atomicAdd((unsigned long long *)&C_.wk->nw_calls, S->calls);
+            C_.wk->unit_us[C_.unit] = (uint32_t)((((__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull) - (unsigned long long)(uint32_t)S->t0) & 0x7FFFFFFFull) / 100ull);
+            if (S->status) atomicCAS((int *)&C_.wk->status, BK_ST_OK, S->status);
+            __threadfence();
+            const uint32_t done = atomicAdd(&C_.wk->units_done, 1u) + 1u;
+            if (done == (uint32_t)C_.split) {
+                __threadfence();
+                const uint32_t np_ = __hip_atomic_load(&C_.wk->n_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nc_ = __hip_atomic_load(&C_.wk->n_conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               nx_ = __hip_atomic_load(&C_.wk->n_cidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (np_ > C_.wk->pairs_cap || nx_ > C_.wk->cidx_cap) atomicCAS((int *)&C_.wk->status, BK_ST_OK, BK_ST_UNSPLIT);
+                else if (nc_ > 0) atomicCAS((int *)&C_.wk->status, BK_ST_OK, BK_ST_REDO);
+            }
+        }
+    }
 #ifdef BK_PHASE_STAMPS
     if (BK_TID == 0) for (int i = 0; i < 20; i++) C_.wk->stamps[i] = S->acc[i];
 #ifdef BK_SNAP_COUNT      // one-off: snapshots taken by one wavefront / by the workgroup, entries they looked at (in place of slots / retired / rounds / look-ahead counters)
@@ -1595,8 +1690,9 @@ extern "C" __global__ void __launch_bounds__(BK_AT, 4) BK_ASM_KERNEL(BkParams p)
         if (BK_TID == 0) S_->qslot = (int)atomicAdd(p.asm_head, 1ull);
         BK_SYNC();
         const int q = S_->qslot;
-        if (q >= p.n_regions) break;
-        bk_asm_region(p, (int)p.order[q]);
+        if (q >= (int)*p.n_queue) break;
+        const uint32_t e = p.order[q];
+        bk_asm_region(p, (int)(e & ((1u << BK_QUEUE_UNIT_SHIFT) - 1u)), (int)(e >> BK_QUEUE_UNIT_SHIFT));
     }
 }
 

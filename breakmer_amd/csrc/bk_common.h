@@ -36,6 +36,7 @@ enum {
     BK_ST_CONFLICT = 22       // assembler-internal: the current seed iteration reached a k-mer of another unit's component
 };
 
+#define BK_SPLIT_G 16                 // units of a split region (bk_comp.hip.h)
 struct BkKey { uint64_t hi, lo; };
 
 __host__ __device__ inline bool key_eq(const BkKey &a, const BkKey &b) { return a.lo == b.lo && a.hi == b.hi; }
@@ -119,6 +120,7 @@ struct BkRegionWork {
     uint32_t U;                  // unique read sequences (fq_recs keys)
     uint32_t T;                  // non-reference k-mer occurrences in unique reads
     uint32_t M;                  // sample-only k-mers (incl. homopolymers, which start REMOVED)
+    uint32_t M2;                 // ... of which can seed a contig (count >= 2): ranks 0 .. M2-1, ordered by (count, mer) descending
     uint32_t tcap;               // k-mer table capacity (power of two)
     uint32_t n_contigs;
     uint64_t nw_cells, nw_calls; // algorithmic DP work
@@ -145,6 +147,7 @@ struct BkRegionWork {
     uint64_t o_kroot;            // uint32[M]  component root of every sample k-mer (BK_EMPTY32: homopolymer, never in the graph)
     uint64_t o_cinfo;            // uint32[U]  per component, at its root: unit | pass << 8 | flags (BK_CI_*)
     uint64_t o_cidx;             // 2 x uint64[cidx_cap]  contigs as emitted: (seed rank << 20 | sequence in the seed iteration, `out` offset)
+    uint32_t unit_us[BK_SPLIT_G], unit_iters[BK_SPLIT_G];      // diagnostic (BK_DEBUG_SPLIT): time and seed iterations of each unit in the last pass
     uint64_t o_pairs;            // uint32[3 * pairs_cap]  (root a, root b, kind): components that met (kind 1: across units = conflict)
     uint64_t stamps[20];         // diagnostic builds only (-DBK_PHASE_STAMPS): s_memrealtime at phase boundaries
 };
@@ -194,7 +197,6 @@ struct BkParams {
 enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64, BK_F_NO_SPLIT = 128, BK_F_SPLIT_ALWAYS = 256 };   // 128: every region is one unit (no component split); 256: split whatever the size (diagnostic: the split path on small fixtures)   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
 
 // component info word (BkRegionWork.o_cinfo, at the component's root read)
-#define BK_SPLIT_G 16                 // units of a split region
 #define BK_CI_UNIT 0xFFu
 #define BK_CI_NOUNIT 0xFFu            // no unit owns it: a component without seed k-mers, until a unit's contig reaches it and claims it
 #define BK_CI_ACTIVE 0x10000u         // has seed k-mers (count >= 2)

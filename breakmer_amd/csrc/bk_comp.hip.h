@@ -59,6 +59,7 @@ __device__ inline void bk_label_components(const BkParams &p, BkRegionWork *wk, 
 {
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) { wk->split = 0; wk->pass = 0; wk->units_done = 0; wk->n_cidx = 0; wk->n_pairs = 0; wk->n_conf = 0; }
+    if (tid < BK_SPLIT_G) { wk->unit_us[tid] = 0; wk->unit_iters[tid] = 0; }
     if ((p.flags & BK_F_NO_SPLIT) || p.rmap || U < 4 || (M2 < BK_SPLIT_MIN_SEEDS && !(p.flags & BK_F_SPLIT_ALWAYS)) || M2 < 2) return;      // uniform
     uint32_t cidx_cap = 64; while (cidx_cap < 2 * U + 64) cidx_cap <<= 1;              // power of two: sorted in place by bk_link_kernel
     const uint32_t pairs_cap = 4096;
@@ -131,17 +132,8 @@ extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkP
     // 1. everything that met becomes one component (merges inside a unit included: their contigs mixed their reads)
     for (uint32_t i = tid; i < np; i += nt) bk_uf_union(rroot, pairs[3 * i], pairs[3 * i + 1]);
     __threadfence(); __syncthreads();
-    // 2. a merged set that holds a conflict (or a component its unit gave up) runs again
+    // 2. a merged set that holds a conflict runs again (a component its unit gave up is always in one: the pair that made it give up)
     for (uint32_t i = tid; i < np; i += nt) if (pairs[3 * i + 2]) atomicOr(&cinfo[bk_uf_find(rroot, pairs[3 * i])], BK_CI_REDO);
-    for (uint32_t u = tid; u < U; u += nt) if (bk_ld_agent(&rroot[u]) == u && (bk_ld_agent(&cinfo[u]) & BK_CI_ABORT)) atomicOr(&cinfo[bk_uf_find(rroot, u)], BK_CI_REDO);
-    __threadfence(); __syncthreads();
-    for (uint32_t u = tid; u < U; u += nt) {
-        const uint32_t old = bk_ld_agent(&rroot[u]);
-        const uint32_t nr = bk_uf_find(rroot, u);
-        // a root that is hooked under another hands its unit / pass to the new root unless that one runs again anyway (same
-        // unit and pass by construction when neither holds a conflict)
-        if (old == u && nr != u) { const uint32_t ci = bk_ld_agent(&cinfo[u]); if (!(bk_ld_agent(&cinfo[nr]) & BK_CI_REDO) && (ci & BK_CI_UNIT) != BK_CI_NOUNIT) atomicMin(&cinfo[nr], (bk_ld_agent(&cinfo[nr]) & BK_CI_UNIT) == BK_CI_NOUNIT ? (ci & ~BK_CI_ABORT) : 0xFFFFFFFFu); }
-    }
     __threadfence(); __syncthreads();
     for (uint32_t u = tid; u < U; u += nt) atomicMin(&rroot[u], bk_uf_find(rroot, u));
     __threadfence(); __syncthreads();
@@ -167,6 +159,7 @@ extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkP
         if (ci & BK_CI_REDO) cinfo[u] = (uint32_t)(mix64(0xD1B54A32D192ED03ull * (pass + 1) ^ u) % BK_SPLIT_G) | (pass << 8) | BK_CI_ACTIVE;
     }
     __threadfence(); __syncthreads();
+    if (tid < BK_SPLIT_G) { wk->unit_us[tid] = 0; wk->unit_iters[tid] = 0; }
     if (tid == 0) { wk->pass = pass; wk->n_pairs = 0; wk->n_conf = 0; wk->units_done = 0; wk->status = pass >= 200 ? BK_ST_UNSPLIT : BK_ST_OK; }
 }
 

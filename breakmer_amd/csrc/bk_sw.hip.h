@@ -235,7 +235,8 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
             S->qidx = qi; S->cells = 0; S->status = 0; S->skip = 0;
             if (qi < n_list) {                                          // one reader of the (concurrently written) region status
                 const int rr = (int)(p.clist[qi] >> 40);
-                S->skip = p.work[rr].status != BK_ST_OK;
+                const int rst = p.work[rr].status;
+                S->skip = rst != BK_ST_OK && rst != BK_ST_REDO;          // (a split region that awaits a repair pass: most of its contigs stay, and this launch is the one that sees them)
                 if (S->staged_region != rr) { S->staged_ti = -1; S->staged_region = rr; }
             }
         }

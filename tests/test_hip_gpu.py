@@ -179,6 +179,54 @@ def test_both_workgroup_sizes_gpu(hb, golden_dir):
             assert _strip(eng.contigs(len(cases) + j)) == want and len(want) >= 1, (wg, j)
 
 
+def test_split_regions_are_bit_identical_gpu(hb, golden_dir):
+    """Noisy regions are split over up to 16 assembler workgroups along the components of their read / k-mer graph
+    (bk_comp.hip.h); components that meet across units are merged and run again.  The result must be the serial one:
+    (a) every reference fixture (G3) with the split FORCED on its small graph (flag 256), both workgroup sizes;
+    (b) a mixed batch with mid-size noisy regions against the oracle, split forced;
+    (c) full-size regions at 0.2 % / 0.5 % / 1 % substitutions, split (the default) against one unit (flag 128): the same
+        contigs in the same order, the same realign records -- and the split really happened, with repair passes."""
+    from oracle import bk_oracle as bo
+    d = _load(golden_dir, "assembly.json")
+    by_cfg = {}
+    for c in d["cases"]:
+        by_cfg.setdefault((c["k"], c["rc_thresh"]), []).append(c)
+    nsplit = 0
+    for (k, rc), cases in by_cfg.items():
+        regions = [synth.make_region(**c["gen"]) for c in cases]
+        for wg in (256, 512):
+            eng = _run_regions(hb, regions, k, rc, flags=256, wg_threads=wg)
+            assert eng.sync() == 0
+            for i, c in enumerate(cases):
+                assert _strip(eng.contigs(i)) == c["contigs"], (c["tag"], wg)
+            nsplit += eng.stat(28)
+            eng.close()
+    assert nsplit > 0
+    regions = [synth.make_region(600 + i, sv_type=synth.SV_TYPES[i % 5], depth=(200, 300)[i % 2], W=1200, noise=(0.004, 0.008, 0.015)[i % 3]) for i in range(9)]
+    eng = _run_regions(hb, regions, 31, stages=7, flags=256)
+    assert eng.sync() == 0 and eng.stat(28) >= 6
+    for i, r in enumerate(regions):
+        want, _ = bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
+        got = eng.contigs(i)
+        assert _strip(got) == want, (i, len(got), len(want))
+        targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        for ci in range(0, len(got), 7):
+            assert eng.hits(i, ci) == bo.realign(got[ci]["seq"], targets), (i, ci)
+    eng.close()
+    full = [synth.make_region(50000 + i, depth=500, L=150, sv_type=("del", "ins", "inv")[i % 3], noise=nz) for i, nz in enumerate((0.002, 0.005, 0.005, 0.005, 0.01, 0.0))]
+    one = _run_regions(hb, full, 31, stages=7, flags=128)
+    many = _run_regions(hb, full, 31, stages=7)
+    assert one.sync() == 0 and many.sync() == 0
+    assert one.stat(28) == 0 and many.stat(28) >= 4, many.stat(28)          # the clean region and the percolated one (1 %) stay one unit
+    assert many.stat(27) >= 1                                                # components met across units: at least one repair pass
+    assert many.stat(1) >= one.stat(1)                                       # (the DPs of components that ran again are counted too)
+    for i in range(len(full)):
+        a, b = one.contigs(i), many.contigs(i)
+        assert len(a) == len(b) and a == b, (i, len(a), len(b))
+        for ci in range(0, len(a), 50):
+            assert one.hits(i, ci) == many.hits(i, ci), (i, ci)
+
+
 def test_batch_vs_oracle_gpu(hb):
     """A mixed batch (config-2-like regions at reduced depth) against the C oracle."""
     from oracle import bk_oracle as bo
