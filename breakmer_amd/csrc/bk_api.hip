@@ -599,8 +599,10 @@ static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t
     HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    const bool dbg = getenv("BK_DEBUG_SPLIT") != nullptr;
     hipLaunchKernelGGL(bk_resolve_kernel, dim3(n), dim3(BK_RESOLVE_T), 0, h->stream, h->params, (const uint32_t *)h->d_rmap.p);
     HIPCHK(h, hipGetLastError());
+    if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk split]   resolve done\n"); }
     const int threads = h->asm_threads;
     const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
     const size_t lds = asm_lds_bytes(h, threads, h->cfg.max_candidates, h->cfg.max_contig_len);
@@ -608,8 +610,10 @@ static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t
     if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
     else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
     HIPCHK(h, hipGetLastError());
+    if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk split]   assembler pass done\n"); }
     hipLaunchKernelGGL(bk_link_kernel, dim3(std::min(h->n_regions, h->n_cu)), dim3(BK_LINK_T), 0, h->stream, h->params, h->n_regions);
     HIPCHK(h, hipGetLastError());
+    if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk split]   link done\n"); }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if (mask & BK_STAGE_REALIGN) {
         const int max_contig = h->cfg.max_contig_len;
@@ -683,7 +687,7 @@ static int sync_impl(bk_handle *h)
                 fprintf(stderr, "[bk split] pass %d: %zu region(s) to repair, %zu to unsplit; split regions %llu, meetings noted %llu (conflicts %llu), contigs emitted so far %llu; kernels %.2f / %.2f / %.2f ms\n",
                         h->n_repair_passes, redo.size(), unsplit.size(), ns_, np_, nc_, nx_, ms[1], ms[2], ms[3]);
                 for (int r = 0; r < h->n_regions && r < 4; r++) { const BkRegionWork &w = h->h_work[r]; if (!w.split) continue;
-                    fprintf(stderr, "   region %d  U %u M %u M2 %u  unit us/iters:", r, w.U, w.M, w.M2); for (int g = 0; g < BK_SPLIT_G; g++) fprintf(stderr, " %u/%u", w.unit_us[g], w.unit_iters[g]); fprintf(stderr, "\n"); }
+                    fprintf(stderr, "   region %d  U %u M %u M2 %u  open conflicts %u; unit 0: prefix %u us, labelling %u us, seed list %u us; unit us/iterations:", r, w.U, w.M, w.M2, w.n_conf, w.dbg_us[0], w.dbg_us[1], w.dbg_us[2]); for (int g = 0; g < BK_SPLIT_G; g++) fprintf(stderr, " %u/%u", w.unit_us[g], w.unit_iters[g]); fprintf(stderr, "\n"); }
             }
             if (!redo.empty() || !unsplit.empty()) {
                 // split regions (bk_comp.hip.h): components that met across units are merged and run again (a few per cent of the

@@ -70,7 +70,7 @@ struct BkAsmShared {
     // split regions (bk_comp.hip.h): the component of the current seed, the components its contigs have taken in (same unit or
     // claimed), what bk_kmers_ordered found beyond them
     int seed_rank, emit_seq, t0;
-    uint32_t ccomp, acc_n, foreign, foreign_root;       // (the list of taken-in components itself: C_.acc_root, global scratch -- it is only looked at when a k-mer of another component turns up)
+    uint32_t ccomp, acc_n, foreign, foreign_root;
     uint32_t scan[10];
 #ifdef BK_PHASE_STAMPS
     unsigned long long acc[24], last; int ctx;
@@ -80,10 +80,10 @@ struct BkAsmShared {
 // The context lives in LDS (not in registers: ~60 uniform pointers would spill the SGPR file) at the
 // start of the dynamic LDS block, followed by BkAsmShared and the byte/word buffers (offsets below).
 struct BkAsmCtx {
-    int o_cseq, o_rseq;          // LDS: contig deque (2*MAXC bytes), current read
-    int o_bound;                 // LDS: DP tile boundary
-    int o_cand;                  // LDS: candidate sort keys (max_cand); afterwards int scratch[2*max_cand]
-    int o_candu;                 // LDS: sorted candidate reads (unique-read index)
+    // LDS offsets in units of 16 bytes (BK_O_*): contig deque (2*MAXC bytes) and the reads of the slots; DP tile boundary; candidate sort
+    // keys (max_cand; afterwards int scratch[2*max_cand]); sorted candidate reads (unique-read index)
+    uint16_t o_cseq16, o_rseq16, o_bound16, o_cand16, o_candu16;
+    uint16_t MAXR, MAXCAND;
     // region data
     BkRegionWork *wk;
     uint8_t *out; unsigned long long *out_top; uint64_t out_cap;
@@ -101,9 +101,10 @@ struct BkAsmCtx {
     uint32_t *klist, *nklist;    // contig.kmers / refresh snapshot (rank | rev << 31)
     uint32_t *pend;              // FIFO: 2 words per entry (rank, u)
     uint32_t *altl, *readl, *usedl;
-    int MAXC, MAXR, MAXCAND, KCAP, k, flags;
+    int MAXC, k, flags;
+    int32_t *myseeds; int n_my;      // split regions, once the components are labelled (own): the seed ranks of this unit's components, ascending (M2 + 64 entries of scratch); else every rank 0 .. n_my-1 is a candidate
     // split regions: this workgroup is unit `unit` of `split`; it owns the components whose info word reads `want`
-    int split, unit, pass; uint32_t want, M2;
+    uint8_t split, unit, pass, own; uint32_t want, M2;      // own: the components are labelled and this unit only touches its own (off while unit 0 runs the serial prefix)
     const uint32_t *kroot; uint32_t *cinfo; unsigned long long *cidx_key; uint32_t *pairs, *acc_root;
 };
 
@@ -129,18 +130,23 @@ struct BkAsmCtx {
 #endif
 
 extern __shared__ __attribute__((aligned(16))) uint8_t bk_lds[];
+#define BK_O_CSEQ ((int)C_.o_cseq16 << 4)
+#define BK_O_RSEQ ((int)C_.o_rseq16 << 4)
+#define BK_O_BOUND ((int)C_.o_bound16 << 4)
+#define BK_O_CAND ((int)C_.o_cand16 << 4)
+#define BK_O_CANDU ((int)C_.o_candu16 << 4)
 #define BK_SH_OFF ((int)((sizeof(BkAsmCtx) + 15) / 16 * 16))
 #define BK_BUF_OFF ((int)(BK_SH_OFF + (sizeof(BkAsmShared) + 15) / 16 * 16))
 #define C_ (*(BkAsmCtx *)bk_lds)
 #define S_ ((BkAsmShared *)(bk_lds + BK_SH_OFF))
-#define L_CSEQ (bk_lds + C_.o_cseq)
-#define L_RSEQ (bk_lds + C_.o_bound)                                  // the generic read buffer (bk_load_read): not a slot's (slots outlive a visit); shares the DP scratch
-#define L_RSEQ_S(s) (bk_lds + C_.o_rseq + (s) * (C_.MAXR + 16))
+#define L_CSEQ (bk_lds + BK_O_CSEQ)
+#define L_RSEQ (bk_lds + BK_O_BOUND)                                  // the generic read buffer (bk_load_read): not a slot's (slots outlive a visit); shares the DP scratch
+#define L_RSEQ_S(s) (bk_lds + BK_O_RSEQ + (s) * (C_.MAXR + 16))
 #define BK_SEEDBUF(g) (2 * C_.MAXC + (g) * 3 * (C_.MAXR + 16))         // offset (from L_CSEQ) of the strip of look-ahead seed g: in the DP scratch behind the deque
-#define L_BOUND ((int *)(bk_lds + C_.o_bound))
-#define L_BOUND_W(w) ((int *)(bk_lds + C_.o_bound) + (w) * 2 * (C_.MAXR + 2))
-#define L_CAND ((unsigned long long *)(bk_lds + C_.o_cand))
-#define L_CANDU ((uint32_t *)(bk_lds + C_.o_candu))
+#define L_BOUND ((int *)(bk_lds + BK_O_BOUND))
+#define L_BOUND_W(w) ((int *)(bk_lds + BK_O_BOUND) + (w) * 2 * (C_.MAXR + 2))
+#define L_CAND ((unsigned long long *)(bk_lds + BK_O_CAND))
+#define L_CANDU ((uint32_t *)(bk_lds + BK_O_CANDU))
 
 __device__ inline int32_t *bk_cnt_io(int buf) { return C_.cnt + (size_t)buf * 4 * C_.MAXC; }
 __device__ inline int32_t *bk_cnt_ot(int buf) { return C_.cnt + (size_t)buf * 4 * C_.MAXC + 2 * C_.MAXC; }
@@ -183,11 +189,13 @@ __device__ inline void bk_patch_n(uint32_t i, uint8_t *dst, int from, int count)
 // split regions: does k-mer `rk` belong to a component this unit owns in this pass (always true for an unsplit region)
 __device__ inline bool bk_mine(int rk)
 {
-    if (!C_.split) return true;
+    if (!C_.own) return true;
     const uint32_t root = C_.kroot[rk];
     if (root == BK_EMPTY32) return false;
     return (__hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (0xFFFFu | BK_CI_ABORT)) == C_.want;
 }
+#define BK_UFL0 ((uint8_t *)C_.pairs + bk_align_up((uint64_t)C_.wk->pairs_cap * 12, 256))      // the read flags as they were when the graph was labelled (bk_comp.hip.h: bk_ufl0)
+__device__ inline int bk_seed_at(int i) { return C_.own ? C_.myseeds[i] : i; }      // the i-th seed candidate of this unit (rank; -1: none)
 __device__ inline bool bk_acc_has(uint32_t root) { BkAsmShared *S = S_; if (root == S->ccomp) return true; for (uint32_t i = 0; i < S->acc_n; i++) if (C_.acc_root[i] == root) return true; return false; }
 
 // sample k-mer table lookup -> rank or -1 (any state)
@@ -309,7 +317,31 @@ __device__ inline int bk_total_reads()                                          
     return a + b;
 }
 
-// ---- get_read_kmers_ordered (sv_assembly.py:126-143) on cseq[s0 .. s0+L) ---------------------------------
+// ---- split regions: the contig of the running seed iteration holds a k-mer of component `root`, which is neither the seed's
+//      nor one it has taken in.  Thread 0 decides (bk_comp.hip.h):
+//   no unit (no seeds)              -> claimed, taken in;
+//   this unit's                     -> taken in (the unit walks its seeds in rank order: the other component stands where the
+//                                      serial run would have it); noted: the two are one component from now on;
+//   anything else                   -> the seed's component is given up, the pair noted for the repair pass.
+__device__ inline void bk_note_pair(uint32_t a, uint32_t b, uint32_t kind)
+{
+    const uint32_t at = atomicAdd(&C_.wk->n_pairs, 1u);
+    if (at < C_.wk->pairs_cap) { C_.pairs[3 * at] = a; C_.pairs[3 * at + 1] = b; C_.pairs[3 * at + 2] = kind; }
+    if (kind) atomicAdd(&C_.wk->n_conf, 1u);
+}
+__device__ inline void bk_meet(uint32_t root)
+{
+    BkAsmShared *S = S_;
+    uint32_t ci = __hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((ci & BK_CI_UNIT) == BK_CI_NOUNIT) { const uint32_t old = atomicCAS(&C_.cinfo[root], ci, C_.want); ci = old == ci ? C_.want : old; }
+    if ((ci & (0xFFFFu | BK_CI_ABORT)) == C_.want && S->acc_n < BK_ACC_MAX) {
+        bk_note_pair(S->ccomp, root, 0u);
+        C_.acc_root[S->acc_n] = root; __threadfence_block(); S->acc_n++;
+    } else { bk_note_pair(S->ccomp, root, 1u); S->status = BK_ST_CONFLICT; }
+    S->foreign = 0; S->foreign_root = BK_EMPTY32;
+}
+
+BK_COLD void bk_build_myseeds(int fresh);
 // order MID replaces contig.kmers (set_kmers :548-550), FOR/REV extend it (:525-527, :543-545).
 // P1: m = L // 2 ; Q1: positions range(0, L-k).
 BK_COLD void bk_kmers_ordered(int s0, int L, int order)
@@ -327,27 +359,17 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
     // the serial order.  (Homopolymer k-mers are in no component: kroot = BK_EMPTY32.)  Bit 30 of tmp[x]: removed.
     for (int x = BK_TID; x < np; x += BK_AT) {
         BkKey key; uint32_t st = 0; int rk = bk_bytes_kmer(L_CSEQ + s0 + x, k, key) ? bk_lookup_state(key, st) : -1;
-        if (C_.split && rk >= 0) { const uint32_t root = C_.kroot[rk]; if (root != BK_EMPTY32 && root != S->ccomp && !bk_acc_has(root)) { S->foreign = 1; atomicMin(&S->foreign_root, root); } }
-        if (rk >= 0 && st == BK_K_REMOVED) rk = C_.split ? (rk | 0x40000000) : -1;                     // not in akmers.smers_set
+        if (C_.own && rk >= 0) { const uint32_t root = C_.kroot[rk]; if (root != BK_EMPTY32 && root != S->ccomp && !bk_acc_has(root)) { S->foreign = 1; atomicMin(&S->foreign_root, root); } }
+        if (rk >= 0 && st == BK_K_REMOVED) rk = C_.own ? (rk | 0x40000000) : -1;                     // not in akmers.smers_set
         tmp[x] = rk;
     }
     BK_SYNC();
-    if (C_.split && S->foreign) {
+    if (C_.own && S->foreign) {
         // The contig holds k-mers of components other than the seed's (a k-mer across the seam of two read pieces).  One new
         // component per turn, smallest root first: same unit -> taken in; no unit (it has no seeds) -> claimed, taken in;
         // another unit's -> the current component is given up (bk_comp.hip.h).  Rare: thread 0 decides, everyone re-checks.
         for (;;) {
-            if (BK_TID == 0) {
-                const uint32_t root = S->foreign_root;
-                uint32_t ci = __hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((ci & BK_CI_UNIT) == BK_CI_NOUNIT) { const uint32_t old = atomicCAS(&C_.cinfo[root], ci, C_.want); ci = old == ci ? C_.want : old; }
-                const bool mine = (ci & (0xFFFFu | BK_CI_ABORT)) == C_.want && S->acc_n < BK_ACC_MAX;
-                const uint32_t at = atomicAdd(&C_.wk->n_pairs, 1u);
-                if (at < C_.wk->pairs_cap) { C_.pairs[3 * at] = S->ccomp; C_.pairs[3 * at + 1] = root; C_.pairs[3 * at + 2] = mine ? 0u : 1u; }
-                if (mine) { C_.acc_root[S->acc_n] = root; __threadfence_block(); S->acc_n++; }
-                else { atomicAdd(&C_.wk->n_conf, 1u); S->status = BK_ST_CONFLICT; }
-                S->foreign = 0; S->foreign_root = BK_EMPTY32;
-            }
+            if (BK_TID == 0) bk_meet(S->foreign_root);
             BK_SYNC();
             if (S->status) return;
             for (int x = BK_TID; x < np; x += BK_AT) { const int rk = tmp[x]; if (rk >= 0) { const uint32_t root = C_.kroot[rk & 0x3FFFFFFF]; if (root != BK_EMPTY32 && root != S->ccomp && !bk_acc_has(root)) { S->foreign = 1; atomicMin(&S->foreign_root, root); } } }
@@ -355,7 +377,7 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
             if (!S->foreign) break;
         }
     }
-    if (C_.split) { for (int x = BK_TID; x < np; x += BK_AT) if (tmp[x] >= 0 && (tmp[x] & 0x40000000)) tmp[x] = -1; BK_SYNC(); }
+    if (C_.own) { for (int x = BK_TID; x < np; x += BK_AT) if (tmp[x] >= 0 && (tmp[x] & 0x40000000)) tmp[x] = -1; BK_SYNC(); }
     const int chunk = (max(np, 0) + BK_AT - 1) / BK_AT, b = BK_TID * chunk, e = min(np, b + chunk);
     uint32_t cnt = 0, T;
     for (int x = b; x < e; x++) cnt += tmp[x] >= 0;
@@ -369,7 +391,7 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
     }
     const int pre_m = S->tmp0;
     const int base = (order == BK_ORD_MID) ? 0 : S->nk;
-    if (base + (int)T > C_.KCAP) { bk_fail(BK_ST_KLIST); BK_SYNC(); return; }
+    if (base + (int)T > (2 * C_.MAXC)) { bk_fail(BK_ST_KLIST); BK_SYNC(); return; }
     uint32_t q = pre;
     for (int x = b; x < e; x++) {
         int rk = tmp[x];
@@ -668,13 +690,13 @@ __device__ __noinline__ void bk_dp_round()
         const int a = 2 * wv, b = 2 * wv + 1;
         if (a < nb) {
             BkPairArgs A, B;
-            A.contig = C_.o_cseq + S->slot[a].pb; A.clen = S->slot[a].plen; A.read = C_.o_rseq + a * (C_.MAXR + 16); A.n = S->slot[a].rl; A.res = (int)((uint8_t *)&S->slot[a].v1 - bk_lds);
-            if (b < nb) { B.contig = C_.o_cseq + S->slot[b].pb; B.clen = S->slot[b].plen; B.read = C_.o_rseq + b * (C_.MAXR + 16); B.n = S->slot[b].rl; B.res = (int)((uint8_t *)&S->slot[b].v1 - bk_lds); }
+            A.contig = BK_O_CSEQ + S->slot[a].pb; A.clen = S->slot[a].plen; A.read = BK_O_RSEQ + a * (C_.MAXR + 16); A.n = S->slot[a].rl; A.res = (int)((uint8_t *)&S->slot[a].v1 - bk_lds);
+            if (b < nb) { B.contig = BK_O_CSEQ + S->slot[b].pb; B.clen = S->slot[b].plen; B.read = BK_O_RSEQ + b * (C_.MAXR + 16); B.n = S->slot[b].rl; B.res = (int)((uint8_t *)&S->slot[b].v1 - bk_lds); }
             else { B.contig = 0; B.clen = 0; B.read = 0; B.n = 0; B.res = 0; }
             bk_nw_pair(A, B);
         }
     } else if (S->dual) {                                // both DPs of slot wv on this wavefront
-        if (wv < nb) bk_nw_dual(C_.o_cseq + S->slot[wv].pb, S->slot[wv].plen, C_.o_rseq + wv * (C_.MAXR + 16), S->slot[wv].rl, (int)((uint8_t *)&S->slot[wv].v1 - bk_lds));
+        if (wv < nb) bk_nw_dual(BK_O_CSEQ + S->slot[wv].pb, S->slot[wv].plen, BK_O_RSEQ + wv * (C_.MAXR + 16), S->slot[wv].rl, (int)((uint8_t *)&S->slot[wv].v1 - bk_lds));
     } else {                                             // two wavefronts per slot, both with the contig on the tile columns
         const int sl = wv >> 1;
         if (sl < nb) {
@@ -778,13 +800,16 @@ BK_COLD void bk_seedahead_wave(int w, int rank)
 {
     BkAsmShared *S = S_;
     const int lane = BK_TID & 63;
-    const int r = rank + 1 + lane;
-    const bool live = r < (int)C_.M2 && C_.kstate[r < (int)C_.M2 ? r : 0] == BK_K_LIVE && C_.kcnt[r < (int)C_.M2 ? r : 0] >= 2 && bk_mine(r < (int)C_.M2 ? r : 0);
+    // (the seeds that follow in THIS unit's list: S->head is where the running seed sits in it)
+    const int li = S->head + 1 + lane;
+    const int r = li < C_.n_my ? bk_seed_at(li) : -1;
+    const bool live = r >= 0 && C_.kstate[r] == BK_K_LIVE && C_.kcnt[r] >= 2;
     unsigned long long m = __ballot(live);
     for (int i = 0; i < w; i++) m &= m - 1;
     int cnt = -1, rank2 = 0;
+    (void)rank;
     if (m) {
-        rank2 = rank + 1 + (__ffsll((long long)m) - 1);
+        rank2 = __shfl(r, __ffsll((long long)m) - 1);
         const uint32_t b = C_.poff[rank2], e = C_.poff[rank2 + 1];
         if (e - b <= 64u * BK_LA_CH) {
             const int np = (int)(e - b);
@@ -1487,7 +1512,7 @@ BK_COLD void bk_emit_contig()
     // first occurrence of every sample k-mer in the contig (str.find over all len-k+1 positions)
     // (split regions: the stamps of other units' k-mers are left alone -- only the contig's own k-mers are read back below, and
     // those all belong to components this unit holds)
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.split || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_has(C_.kroot[rk])))) atomicMin(&C_.kstamp[3 * rk + 2], x); }
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.own || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_has(C_.kroot[rk])))) atomicMin(&C_.kstamp[3 * rk + 2], x); }
     BK_SYNC();
     for (int t = BK_TID; t < nk; t += BK_AT) {
         int pos = C_.kstamp[3 * (C_.klist[t] & 0x7FFFFFFFu) + 2];
@@ -1495,9 +1520,9 @@ BK_COLD void bk_emit_contig()
         for (int q = pos; q < min(pos + k, len); q++) atomicAdd(&okl[q], 1);
     }
     BK_SYNC();
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.split || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_has(C_.kroot[rk])))) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.own || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_has(C_.kroot[rk])))) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
     if (BK_TID == 0) {
-        h->root = S->ccomp; h->pass = (uint32_t)C_.pass;
+        h->root = S->ccomp; h->pass = C_.want;
         h->next = 0; h->hits_off = 0; h->seq_len = len; h->counts_len = nlen; h->n_kmers = nk; h->n_reads = nr; h->total_reads = total; h->n_hits = 0;
         h->o_seq = o_seq; h->o_io = o_io; h->o_ot = o_ot; h->o_klocs = o_kl; h->o_kmers = o_km; h->o_reads = o_rd; h->n_sec = 0; h->size = size;
         if (C_.split) {       // the units of a region emit side by side: (order key, record) pairs, ordered and linked by bk_link_kernel
@@ -1541,6 +1566,151 @@ __device__ inline void bk_setup_contigs(int rank)
     BK_ACC(8); BK_CTX(0);
 }
 
+// The seed ranks of this unit's components, ascending: the seed scan and the look-ahead into the next seeds walk this list
+// (a sixteenth of the ranks; looking each rank's owner up costs two dependent loads, and the owner words must be read past
+// the caches once other units change them).  fresh: read the owner words with device-scope loads (after this unit lost a
+// component to unit 0; otherwise the words are as the labelling / the resolve kernel wrote them).  A wavefront per block of
+// ranks: count, prefix over the wavefronts, write in place.
+BK_COLD void bk_build_myseeds(int fresh)
+{
+    BkAsmShared *S = S_;
+    const int wv = BK_TID >> 6, lane = BK_TID & 63, M2 = (int)C_.M2;
+    const int B = (((M2 + BK_WAVES - 1) / BK_WAVES) + 63) / 64 * 64, lo = wv * B, hi = min(M2, lo + B);
+    auto mine = [&](int j) -> bool {
+        if (j >= hi || C_.kstate[j] == BK_K_REMOVED) return false;
+        const uint32_t root = C_.kroot[j];
+        if (root == BK_EMPTY32) return false;
+        const uint32_t ci = fresh ? __hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : C_.cinfo[root];
+        return (ci & (0xFFFFu | BK_CI_ABORT)) == C_.want;
+    };
+    int cnt = 0;
+    for (int b = lo; b < hi; b += 64) cnt += __popcll(__ballot(mine(b + lane)));
+    BK_SYNC();
+    if (lane == 0) S->scan[wv] = (uint32_t)cnt;
+    BK_SYNC();
+    int base = 0, tot = 0;
+    for (int i = 0; i < BK_WAVES; i++) { const int t = (int)S->scan[i]; if (i < wv) base += t; tot += t; }
+    BK_SYNC();
+    int off = base;
+    const int end = base + cnt;
+    for (int b = lo; b < hi; b += 64) {
+        const bool m = mine(b + lane);
+        const unsigned long long bal = __ballot(m);
+        const int at = off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (m && at < end) C_.myseeds[at] = b + lane;
+        off += __popcll(bal);
+    }
+    for (int i = min(off, end) + lane; i < end; i += 64) C_.myseeds[i] = -1;          // (owner words changed between the two sweeps: fewer than counted)
+    __threadfence_block();
+    BK_SYNC();
+    if (BK_TID == 0) { C_.n_my = tot; S->head = 0; }
+    BK_SYNC();
+}
+
+// unit 0, after the serial prefix (the seeds with a count >= BK_SPLIT_HI, run alone and in order): the connected components of what
+// is LEFT of the read / k-mer graph -- the k-mers that are still live -- dealt to the units (bk_comp.hip.h).  The read flags of
+// this moment are kept: a component that runs again starts from here.
+BK_COLD void bk_label_live()
+{
+    BkAsmShared *S = S_;
+    uint32_t *rroot = (uint32_t *)((uint8_t *)C_.cinfo - bk_align_up((uint64_t)C_.U * 4, 256));
+    uint32_t *kroot = const_cast<uint32_t *>(C_.kroot), *cinfo = C_.cinfo, *csz = C_.readl;      // readl: U + 1 words, free between two contigs
+    uint8_t *ufl0 = BK_UFL0;
+    const uint32_t U = C_.U, M = C_.M, M2 = C_.M2;
+    BK_SYNC();
+    if (BK_TID == 0) { const int now = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull); C_.wk->dbg_us[0] = (uint32_t)((now - S->t0) & 0x7FFFFFFF) / 100u; S->t0 = now; }
+    for (uint32_t u = BK_TID; u < U; u += BK_AT) { rroot[u] = u; csz[u] = 0; ufl0[u] = C_.ufl[u]; }
+    __threadfence(); BK_SYNC();
+    for (uint32_t j = BK_TID; j < M; j += BK_AT) {
+        if (C_.kstate[j] != BK_K_LIVE) continue;
+        const uint32_t b = C_.poff[j], e = C_.poff[j + 1];
+        uint32_t first = BK_EMPTY32, last = BK_EMPTY32;
+        for (uint32_t i = b; i < e; i++) {
+            const uint32_t v = C_.post[i] >> 10;
+            if (v == last) continue;                 // (deleted reads stay nodes: every live k-mer then has a component, and only one unit ever touches its state)
+            if (first == BK_EMPTY32) first = v; else bk_uf_union(rroot, first, v);
+            last = v;
+        }
+    }
+    __threadfence(); BK_SYNC();
+    for (uint32_t u = BK_TID; u < U; u += BK_AT) atomicMin(&rroot[u], bk_uf_find(rroot, u));
+    __threadfence(); BK_SYNC();
+    uint32_t seeds = 0;
+    for (uint32_t j = BK_TID; j < M; j += BK_AT) {
+        uint32_t r = BK_EMPTY32;
+        if (C_.kstate[j] == BK_K_LIVE && C_.poff[j + 1] > C_.poff[j]) r = bk_ld_agent(&rroot[C_.post[C_.poff[j]] >> 10]);
+        kroot[j] = r;
+        if (j < M2 && r != BK_EMPTY32 && C_.kcnt[j] >= 2) { atomicAdd(&csz[r], 1u); seeds++; }
+    }
+    uint32_t total;
+    (void)bk_scan256(seeds, S->scan, &total);
+    __threadfence(); BK_SYNC();
+    int big = 0;
+    for (uint32_t u = BK_TID; u < U; u += BK_AT) big = max(big, (int)bk_ld_agent(&csz[u]));
+    big = bk_max256(big, S->scan);
+    // one component with most of the seeds (the graph has percolated: 1 % noise and beyond): everything stays with unit 0
+    const bool deal = 10ull * (unsigned long long)big <= 7ull * total || (C_.flags & BK_F_SPLIT_ALWAYS);
+    for (uint32_t u = BK_TID; u < U; u += BK_AT) {
+        uint32_t ci = BK_CI_NOUNIT;
+        if (bk_ld_agent(&rroot[u]) == u && bk_ld_agent(&csz[u])) ci = (deal ? (uint32_t)(mix64(0x9E3779B97F4A7C15ull ^ u) % BK_SPLIT_G) : 0u) | BK_CI_ACTIVE;
+        cinfo[u] = ci;
+    }
+    __threadfence(); BK_SYNC();
+    // Dealt by size, largest first to the unit with the least so far (a unit's time follows its seed k-mers; by a hash of the root
+    // the fullest unit had 1.8x the mean).  The components with seeds are listed and ordered in the candidate scratch (LDS);
+    // more of them than fit there keep the hash.
+    if (deal) {
+        unsigned long long *L = L_CAND;
+        if (BK_TID == 0) S->tmp0 = 0;
+        BK_SYNC();
+        for (uint32_t u = BK_TID; u < U; u += BK_AT) {
+            const uint32_t c = bk_ld_agent(&csz[u]);
+            if (bk_ld_agent(&rroot[u]) != u || !c) continue;
+            const int at = atomicAdd(&S->tmp0, 1);
+            if (at < (int)C_.MAXCAND) L[at] = ((unsigned long long)(0xFFFFFFFFu - c) << 32) | u;          // ascending key = size descending, then root ascending: deterministic
+        }
+        BK_SYNC();
+        const int n = S->tmp0;
+        if (n <= (int)C_.MAXCAND) {
+            int npad = 1; while (npad < n) npad <<= 1;
+            for (int i = n + BK_TID; i < npad; i += BK_AT) L[i] = ~0ull;
+            BK_SYNC();
+            for (int sz = 2; sz <= npad; sz <<= 1)
+                for (int st = sz >> 1; st > 0; st >>= 1) {
+                    for (int i = BK_TID; i < npad / 2; i += BK_AT) {
+                        const int lo = (i / st) * (st * 2) + (i % st), hi = lo + st;
+                        const bool up = ((lo & sz) == 0);
+                        const unsigned long long a = L[lo], bb = L[hi];
+                        if ((a > bb) == up) { L[lo] = bb; L[hi] = a; }
+                    }
+                    BK_SYNC();
+                }
+            if (BK_TID == 0) {
+                uint32_t load[BK_SPLIT_G];
+                for (int g = 0; g < BK_SPLIT_G; g++) load[g] = 0;
+                for (int i = 0; i < n; i++) {
+                    const uint32_t root = (uint32_t)L[i], c = 0xFFFFFFFFu - (uint32_t)(L[i] >> 32);
+                    int best = 0;
+                    for (int g = 1; g < BK_SPLIT_G; g++) if (load[g] < load[best]) best = g;
+                    load[best] += c + 4u;                                                             // (+ what an iteration costs whatever its size)
+                    cinfo[root] = (uint32_t)best | BK_CI_ACTIVE;
+                }
+            }
+            __threadfence(); BK_SYNC();
+        }
+    }
+    if (BK_TID == 0) {
+        C_.wk->serial_base = (uint32_t)S->serial_ctr; C_.wk->stamp_base = (uint32_t)S->stamp_ctr;
+        __threadfence();
+        __hip_atomic_store(&C_.wk->phase, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        C_.own = 1;
+        { const int now = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull); C_.wk->dbg_us[1] = (uint32_t)((now - S->t0) & 0x7FFFFFFF) / 100u; S->t0 = now; }
+    }
+    BK_SYNC();
+    bk_build_myseeds(0);
+    if (BK_TID == 0) { const int now = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull); C_.wk->dbg_us[2] = (uint32_t)((now - S->t0) & 0x7FFFFFFF) / 100u; S->t0 = now; }
+}
+
 __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, const int unit)
 {
     BkAsmShared *S = S_;
@@ -1552,29 +1722,30 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         c.wk = wk; c.out = p.out; c.out_top = p.out_top; c.out_cap = p.out_cap; c.rc_thresh = p.rc_thresh;
         c.n_clist = p.n_clist; c.clist = p.clist; c.clist_cap = p.clist_cap; c.region = r;
         c.read_words = d.read_words; c.max_len = d.max_len;
-        c.flags = p.flags; c.MAXC = p.max_contig; c.MAXR = p.max_read; c.MAXCAND = p.max_cand; c.KCAP = 2 * p.max_contig; c.k = p.k;
+        c.flags = p.flags; c.MAXC = p.max_contig; c.MAXR = (uint16_t)p.max_read; c.MAXCAND = (uint16_t)p.max_cand; c.k = p.k; c.myseeds = nullptr; c.n_my = (int)wk->M2;
         int o = BK_BUF_OFF;
         // 40 KB at the 256-thread size (four workgroups per CU).  The DP tile-boundary scratch directly behind the contig deque
         // doubles as (a) the [read | founder | read] strips of look-ahead seeds, which only live through the DPs of the round
         // that plans them, all of them single-tile (bk_plan_round), and (b) the generic read buffer of bk_load_read, which
         // is never used while a DP runs.
-        c.o_cand = o; o += c.MAXCAND * 8;
-        c.o_candu = o; o += c.MAXCAND * 4;
-        c.o_cseq = o; o += 2 * c.MAXC;
-        c.o_bound = o; o += (BK_AT / 64) * 2 * (c.MAXR + 2) * 4;
-        c.o_rseq = o; o += BK_SPEC * (c.MAXR + 16);
+        // (every block is a multiple of 16 bytes: the caps are multiples of 8, the read buffers of 16)
+        c.o_cand16 = (uint16_t)(o >> 4); o += (c.MAXCAND * 8 + 15) & ~15;
+        c.o_candu16 = (uint16_t)(o >> 4); o += (c.MAXCAND * 4 + 15) & ~15;
+        c.o_cseq16 = (uint16_t)(o >> 4); o += (2 * c.MAXC + 15) & ~15;
+        c.o_bound16 = (uint16_t)(o >> 4); o += ((BK_AT / 64) * 2 * (c.MAXR + 2) * 4 + 15) & ~15;
+        c.o_rseq16 = (uint16_t)(o >> 4); o += BK_SPEC * (c.MAXR + 16);
         c.reads = p.reads + d.reads_word_off; c.rlen = p.read_len + d.read_meta_off;
         c.nlist = p.nlist + d.nlist_off; c.n_nlist = d.n_nlist;
         const uint64_t mo = d.read_meta_off;
         c.urep = p.urep + mo; c.unr = p.unreads + mo; c.ufl = p.uflag + mo; c.ubuf = p.ubuf + mo; c.ureads = p.ureads + mo; c.ufound = p.ufound + mo; c.uminpos = p.uminpos + mo; c.ulen = p.dd_rep + d.dedup_off;
         c.U = wk->U; c.M = wk->M; c.tmask = wk->tcap - 1; c.M2 = wk->M2;
-        c.split = (int)wk->split; c.unit = unit; c.pass = (int)wk->pass; c.want = (uint32_t)unit | ((uint32_t)wk->pass << 8);
+        c.split = (uint8_t)wk->split; c.unit = (uint8_t)unit; c.pass = (uint8_t)wk->pass; c.want = (uint32_t)unit | ((uint32_t)wk->pass << 8);
+        c.own = (wk->split && !(wk->pass == 0 && unit == 0 && wk->phase == 0)) ? 1 : 0;      // unit 0 of the first pass starts with the serial prefix
         if (c.split) {
             c.kroot = (const uint32_t *)(p.arena + wk->o_kroot); c.cinfo = (uint32_t *)(p.arena + wk->o_cinfo);
             c.cidx_key = (unsigned long long *)(p.arena + wk->o_cidx); c.pairs = (uint32_t *)(p.arena + wk->o_pairs);
         }
-        S->ccomp = 0; S->acc_n = 0; S->foreign = 0; S->foreign_root = BK_EMPTY32; S->seed_rank = 0; S->emit_seq = 0;
-        S->t0 = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull);      // diagnostic: when the unit started
+        S->ccomp = 0; S->acc_n = 0; S->foreign = 0; S->foreign_root = BK_EMPTY32; S->seed_rank = 0; S->emit_seq = 0; S->t0 = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull);
         c.tslot = (const uint32_t *)(p.arena + wk->o_tslot);
         c.klo = (const uint64_t *)(p.arena + wk->o_key_lo); c.khi = (const uint64_t *)(p.arena + wk->o_key_hi);
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
@@ -1586,35 +1757,58 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         S->last = __builtin_amdgcn_s_memrealtime();
 #endif
         // per-region scratch from the arena
-        const uint64_t b_cnt = (uint64_t)8 * c.MAXC * 4, b_kl = (uint64_t)c.KCAP * 4, b_pend = (uint64_t)2 * (c.U + 1) * 4, b_alt = (uint64_t)c.MAXCAND * 4,
+        const uint64_t b_cnt = (uint64_t)8 * c.MAXC * 4, b_kl = (uint64_t)2 * c.MAXC * 4, b_pend = (uint64_t)2 * (c.U + 1) * 4, b_alt = (uint64_t)c.MAXCAND * 4,
                        b_rd = (uint64_t)(c.U + 1) * 4, b_used = (uint64_t)(c.M + 1) * 4;
-        uint64_t need = bk_align_up(b_cnt + 2 * b_kl + b_pend + b_alt + b_rd + b_used + 64 + BK_ACC_MAX * 4, 256);
+        uint64_t need = bk_align_up(b_cnt + 2 * b_kl + b_pend + b_alt + b_rd + b_used + 64 + BK_ACC_MAX * 4 + (wk->split ? ((uint64_t)wk->M2 + 64) * 4 : 0), 256);
         uint64_t off = atomicAdd(p.arena_top, (unsigned long long)need);
         if (off + need > p.arena_cap) S->status = BK_ST_ARENA;
         else {
             uint8_t *sp = p.arena + off;
             c.cnt = (int32_t *)sp; sp += b_cnt; c.klist = (uint32_t *)sp; sp += b_kl; c.nklist = (uint32_t *)sp; sp += b_kl;
             c.pend = (uint32_t *)sp; sp += b_pend; c.altl = (uint32_t *)sp; sp += b_alt; c.readl = (uint32_t *)sp; sp += b_rd; c.usedl = (uint32_t *)sp; sp += b_used; c.acc_root = (uint32_t *)sp;
+            c.myseeds = (int32_t *)(sp + BK_ACC_MAX * 4);
         }
     }
     BK_SYNC();
+    if (C_.split && C_.own) {
+        // the other units start once unit 0 has run the serial prefix and labelled the graph (unit 0 holds a workgroup by then: its
+        // queue entry comes first); contig serials and stamps go on beyond unit 0's, so nothing it left behind looks current
+        if (BK_TID == 0) {
+            int ok = 0;
+            for (int spin = 0; spin < 4000000; spin++) {
+                if (__hip_atomic_load(&wk->phase, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; break; }
+                if (__hip_atomic_load(&wk->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BK_ST_OK) break;
+                __builtin_amdgcn_s_sleep(100);
+            }
+            if (!ok && !S->status) S->status = BK_ST_UNSPLIT;
+            S->serial_ctr = (int)wk->serial_base; S->stamp_ctr = (int)wk->stamp_base;
+        }
+        BK_SYNC();
+        if (BK_TID == 0) S->t0 = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull);
+        if (!S->status) bk_build_myseeds(0);
+    }
     if (C_.M == 0 && !C_.split) { if (BK_TID == 0) wk->n_contigs = 0; return; }                 // init_assembly :33-34
     if (S->status && !C_.split) { if (BK_TID == 0) wk->status = S->status; return; }
     // ---- init_assembly main loop (:43-62) --------------------------------------------------------------
     while (!S->status) {
         // first k-mer still in akmers.mers in (count, mer) descending order; has_mers (:318-322) <=> its count > 1
         // (the seed-capable k-mers are ranks 0 .. M2-1; a unit of a split region takes those of its own components)
-        int head = S->head, found = -1;
-        while (head < (int)C_.M2) {
-            int cand_rk = head + BK_TID;
-            int mine = (cand_rk < (int)C_.M2 && C_.kstate[cand_rk] != BK_K_REMOVED && bk_mine(cand_rk)) ? cand_rk : 0x7FFFFFFF;
+        int head = S->head, found = -1, fidx = -1;
+        while (head < C_.n_my) {
+            const int ci_ = head + BK_TID;
+            const int cand_rk = ci_ < C_.n_my ? bk_seed_at(ci_) : -1;
+            int mine = (cand_rk >= 0 && C_.kstate[cand_rk] != BK_K_REMOVED) ? ci_ : 0x7FFFFFFF;
             int mn = -bk_max256(-mine, S->scan);
-            if (mn != 0x7FFFFFFF) { found = mn; break; }
+            if (mn != 0x7FFFFFFF) { fidx = mn; found = bk_seed_at(mn); break; }
             head += BK_AT;
         }
+        if (C_.split && !C_.own && (found < 0 || C_.kcnt[found] < BK_SPLIT_HI)) { bk_label_live(); continue; }      // the serial prefix is over: label what is left, the other units start
         if (found < 0 || C_.kcnt[found] < 2) break;
         BK_SYNC();
-        if (BK_TID == 0) { S->head = found; S->seed_rank = found; S->emit_seq = 0; S->acc_n = 0; S->ccomp = C_.split ? C_.kroot[found] : 0u; if (C_.split) C_.wk->unit_iters[C_.unit]++; }
+        if (BK_TID == 0) {
+            S->head = fidx; S->seed_rank = found; S->emit_seq = 0; S->acc_n = 0; S->ccomp = C_.own ? C_.kroot[found] : BK_EMPTY32;
+            if (C_.split) C_.wk->unit_iters[C_.unit]++;
+        }
         BK_SYNC();
         BK_ACC(11);
         bk_setup_contigs(found);
@@ -1640,6 +1834,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
                 S->status = 0; S->phead = S->ptail; S->nused = 0; S->nalt = 0; S->plan_ok = 0;
             }
             BK_SYNC();
+            bk_build_myseeds(1);                                 // (what was given up leaves the unit's seed list)
             continue;
         }
         if (S->status) break;
@@ -1659,7 +1854,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
             // a unit reports in; the last one of the region decides what the host sees: a failed unit fails the region (the library
             // runs it again as one unit under larger caps), components that met across units mean another pass
             atomicAdd((unsigned long long *)&C_.wk->nw_cells, S->cells); atomicAdd((unsigned long long *)&C_.wk->nw_calls, S->calls);
-            C_.wk->unit_us[C_.unit] = (uint32_t)((((__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull) - (unsigned long long)(uint32_t)S->t0) & 0x7FFFFFFFull) / 100ull);
+            C_.wk->unit_us[C_.unit] = (uint32_t)((((int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull)) - S->t0) & 0x7FFFFFFF) / 100u;
             if (S->status) atomicCAS((int *)&C_.wk->status, BK_ST_OK, S->status);
             __threadfence();
             const uint32_t done = atomicAdd(&C_.wk->units_done, 1u) + 1u;
@@ -1673,7 +1868,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         }
     }
 #ifdef BK_PHASE_STAMPS
-    if (BK_TID == 0) for (int i = 0; i < 20; i++) C_.wk->stamps[i] = S->acc[i];
+    if (BK_TID == 0) for (int i = 0; i < 20; i++) { if (C_.split) atomicAdd((unsigned long long *)&C_.wk->stamps[i], (unsigned long long)S->acc[i]); else C_.wk->stamps[i] = S->acc[i]; }      // split regions: summed over the units (and passes)
 #ifdef BK_SNAP_COUNT      // one-off: snapshots taken by one wavefront / by the workgroup, entries they looked at (in place of slots / retired / rounds / look-ahead counters)
     if (BK_TID == 0) for (int i = 0; i < 4; i++) C_.wk->stamps[16 + i] = S->acc[20 + i];
 #endif

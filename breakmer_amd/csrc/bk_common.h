@@ -142,6 +142,8 @@ struct BkRegionWork {
     // split regions (bk_comp.hip.h): the read / k-mer graph of a noisy region falls into components that never meet; G units
     // (workgroups) assemble disjoint sets of them side by side.  split = G (0: the region is one unit)
     uint32_t split, pass;        // pass: 0 = first execution; k = k-th repair pass (components that met across units, merged, run again)
+    uint32_t dbg_us[4];          // diagnostic (BK_DEBUG_SPLIT): unit 0's serial prefix, labelling, seed list (microseconds)
+    uint32_t phase, serial_base, stamp_base, pad2_;      // phase 1: unit 0 has run the high-count seeds (the SV's own k-mers) alone and labelled what is left; the other units start then, their contig serials / stamps beyond unit 0's
     uint32_t units_done, n_cidx, n_pairs, n_conf, cidx_cap, pairs_cap;
     uint64_t o_rroot;            // uint32[U]  component root (a read index) of every unique read
     uint64_t o_kroot;            // uint32[M]  component root of every sample k-mer (BK_EMPTY32: homopolymer, never in the graph)
@@ -202,6 +204,7 @@ enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 
 #define BK_CI_ACTIVE 0x10000u         // has seed k-mers (count >= 2)
 #define BK_CI_REDO 0x20000u           // resolve kernel: merged with a component it met across units; runs again in the next pass
 #define BK_CI_ABORT 0x40000u          // its unit gave it up in this pass (it met another unit's component)
+#define BK_SPLIT_HI 8                 // seeds with a count of at least this are run by unit 0 alone, in order, before the graph is labelled (bk_comp.hip.h)
 #define BK_QUEUE_UNIT_SHIFT 24
 
 __device__ inline uint64_t bk_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }

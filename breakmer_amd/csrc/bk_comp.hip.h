@@ -11,17 +11,23 @@
 // percolates), so BK_SPLIT_G units take disjoint sets of components and each walks its seeds in rank order -- exactly the
 // serial order restricted to what it owns.
 //
-// What the static graph does not know: a contig is built from PIECES of reads, and a k-mer across the seam of two pieces
-// may belong to a read of another component (measured with the oracle at 0.5 %: ~35 such meetings per region).  So the
-// assembler checks every contig k-mer (bk_kmers_ordered): a k-mer of
-//   * a component of the same unit          -> fine (the unit IS the serial order over everything it owns); noted as a merge;
-//   * a component without seeds (no unit)   -> claimed by this unit (atomic), then as above;
-//   * a component of another unit           -> CONFLICT: the unit gives the current component up (nothing of the other
-//                                              unit's state has been touched), notes the pair and goes on with its others.
-// After the pass, bk_resolve_kernel merges the components that met, resets the state of every merged set that holds a
-// conflict (reads, k-mers; its contigs are dropped) and they run again in the next pass -- a few per cent of the work,
-// itself spread over the units.  Passes repeat until none is left (components only ever merge).  bk_link_kernel finally
-// orders the surviving contigs by (seed rank, emission order) = the order init_assembly returns them in.
+// Two things the static graph of the k-mer stage does not show:
+//  * The SV's own component is a third of all seed iterations, and it would have to run on one unit.  But its k-mers are the
+//    ones with the high counts: unit 0 first runs the seeds with a count >= BK_SPLIT_HI alone and in order (a handful of
+//    iterations: the SV's contigs), and the graph is labelled AFTERWARDS, inside the assembler, on what is still live
+//    (bk_label_live) -- with its junction k-mers used up the SV's component falls apart into error clusters like everything
+//    else (largest component 8 % of the seed k-mers before, 1 % after).  The components are dealt to the units by size.
+//  * A contig is built from PIECES of reads, and a k-mer across the seam of two pieces may belong to a read of another component
+//    (measured with the oracle at 0.5 %: ~35 such meetings per region).  So the assembler checks every contig k-mer
+//    (bk_kmers_ordered) whatever its state says (the other unit may be ahead in seed order): a k-mer of
+//      - a component of the same unit          -> fine (the unit IS the serial order over everything it owns); noted as a merge;
+//      - a component without seeds (no unit)   -> claimed by this unit (atomic), then as above;
+//      - a component of another unit           -> CONFLICT: the unit gives the current component up (nothing of the other
+//                                                 unit's state has been touched), notes the pair and goes on with its others.
+//    After the pass, bk_resolve_kernel merges the components that met, resets every merged set that holds a conflict to the
+//    state of the labelling (reads, k-mers; its contigs are dropped) and they run again in the next pass -- a few per cent of
+//    the work, itself spread over the units.  Passes repeat until none is left (components only ever merge).
+// bk_link_kernel finally orders the surviving contigs by (seed rank, emission order) = the order init_assembly returns them in.
 // Results are bit-identical to the one-unit run (tests: every noisy fixture with BK_F_NO_SPLIT on and off).
 #pragma once
 #include "bk_common.h"
@@ -51,70 +57,36 @@ __device__ inline void bk_uf_union(uint32_t *par, uint32_t a, uint32_t b)
     }
 }
 
-// Called by every thread of the k-mer workgroup at the end of bk_kmer_body.  Decides whether the region is split and, if so,
-// labels the components and deals them to the units.  M2 = number of seed-capable k-mers (ranks 0 .. M2-1, count >= 2).
-// Needs block-wide helpers of bk_kmer.hip.h (bk_arena_alloc, bk_block_sum).  Returns with wk->split set (thread 0).
-__device__ inline void bk_label_components(const BkParams &p, BkRegionWork *wk, uint32_t U, uint32_t M, uint32_t M2,
-                                           const uint32_t *poff, const uint32_t *post, const uint8_t *kstate, uint32_t *scr)
+// Called by every thread of the k-mer workgroup at the end of bk_kmer_body: decides whether the region is split and allocates what
+// the split needs.  The components themselves are labelled later, inside the assembler (bk_label_live), AFTER unit 0 has run
+// the seeds with a count >= BK_SPLIT_HI alone and in order: those are the SV's own k-mers, and the component that holds them
+// is a third of all seed iterations -- once its junction k-mers are used up, what is left of it falls apart into error clusters
+// like everything else (largest component 8 % of the seed k-mers before, 1 % after).
+// M2 = number of seed-capable k-mers (ranks 0 .. M2-1, count >= 2).
+__device__ inline void bk_split_prepare(const BkParams &p, BkRegionWork *wk, uint32_t U, uint32_t M, uint32_t M2, const uint32_t *kcnt, uint32_t *scr)
 {
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    if (tid == 0) { wk->split = 0; wk->pass = 0; wk->units_done = 0; wk->n_cidx = 0; wk->n_pairs = 0; wk->n_conf = 0; }
+    if (tid == 0) { wk->split = 0; wk->pass = 0; wk->phase = 0; wk->serial_base = 0; wk->stamp_base = 0; wk->units_done = 0; wk->n_cidx = 0; wk->n_pairs = 0; wk->n_conf = 0; }
     if (tid < BK_SPLIT_G) { wk->unit_us[tid] = 0; wk->unit_iters[tid] = 0; }
+    if (tid < 20) wk->stamps[tid] = 0;
     if ((p.flags & BK_F_NO_SPLIT) || p.rmap || U < 4 || (M2 < BK_SPLIT_MIN_SEEDS && !(p.flags & BK_F_SPLIT_ALWAYS)) || M2 < 2) return;      // uniform
+    // the serial prefix must be short: the seeds are ordered by count, so the first rank below BK_SPLIT_HI says how many it has (a
+    // deep noisy region -- 2,000x at 5 %: most error k-mers are seen eight times -- would run serially anyway while fifteen
+    // workgroups wait for it)
+    { uint32_t lo = 0, hi = M2; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (kcnt[mid] >= BK_SPLIT_HI) lo = mid + 1; else hi = mid; }
+      if (20ull * lo > M2 && !(p.flags & BK_F_SPLIT_ALWAYS)) return; }                 // uniform: every thread does the same search
     uint32_t cidx_cap = 64; while (cidx_cap < 2 * U + 64) cidx_cap <<= 1;              // power of two: sorted in place by bk_link_kernel
     const uint32_t pairs_cap = 4096;
-    const uint64_t b_r = bk_align_up((uint64_t)U * 4, 256), b_k = bk_align_up((uint64_t)M * 4, 256), b_x = (uint64_t)cidx_cap * 16, b_p = bk_align_up((uint64_t)pairs_cap * 12, 256);
-    const uint64_t a0 = bk_arena_alloc(p, 2 * b_r + b_k + b_x + b_p, scr + 20);
+    const uint64_t b_r = bk_align_up((uint64_t)U * 4, 256), b_k = bk_align_up((uint64_t)M * 4, 256), b_x = (uint64_t)cidx_cap * 16, b_p = bk_align_up((uint64_t)pairs_cap * 12, 256), b_f = bk_align_up((uint64_t)U, 256);
+    const uint64_t a0 = bk_arena_alloc(p, 2 * b_r + b_k + b_x + b_p + b_f, scr + 20);
     if (a0 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
-    uint32_t *rroot = (uint32_t *)(p.arena + a0), *cinfo = (uint32_t *)(p.arena + a0 + b_r), *kroot = (uint32_t *)(p.arena + a0 + 2 * b_r);
-    uint32_t *csz = (uint32_t *)(p.arena + a0 + 2 * b_r + b_k);                        // seed k-mers per component: the contig index area, free until the assembler runs
-    for (uint32_t u = tid; u < U; u += nt) { rroot[u] = u; csz[u] = 0; }
-    __threadfence(); __syncthreads();
-    // edges: every read of a k-mer's posting list with the list's first read
-    for (uint32_t j = tid; j < M; j += nt) {
-        if (kstate[j] == BK_K_REMOVED) continue;                                       // homopolymer k-mers: dropped at the start, never used (sv_assembly.py:277)
-        const uint32_t b = poff[j], e = poff[j + 1];
-        if (e - b < 2) continue;
-        const uint32_t a = post[b] >> 10;
-        uint32_t last = a;
-        for (uint32_t i = b + 1; i < e; i++) { const uint32_t v = post[i] >> 10; if (v != last) { bk_uf_union(rroot, a, v); last = v; } }
-    }
-    __threadfence(); __syncthreads();
-    for (uint32_t u = tid; u < U; u += nt) { const uint32_t r = bk_uf_find(rroot, u); atomicMin(&rroot[u], r); }
-    __threadfence(); __syncthreads();
-    uint32_t seeds = 0;
-    for (uint32_t j = tid; j < M; j += nt) {
-        uint32_t r = BK_EMPTY32;
-        if (kstate[j] != BK_K_REMOVED && poff[j + 1] > poff[j]) r = bk_ld_agent(&rroot[post[poff[j]] >> 10]);
-        kroot[j] = r;
-        if (j < M2 && r != BK_EMPTY32) { atomicAdd(&csz[r], 1u); seeds++; }
-    }
-    const uint32_t total = bk_block_sum(seeds, scr);
-    __threadfence(); __syncthreads();
-    // the largest component gets a unit of its own (unit 0), the others are dealt by a hash of their root
-    unsigned long long best = 0;
-    for (uint32_t u = tid; u < U; u += nt) { const uint32_t c = bk_ld_agent(&csz[u]); if (c) { const unsigned long long key = ((unsigned long long)c << 32) | (0xFFFFFFFFu - u); if (key > best) best = key; } }
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long ok = __shfl_xor(best, o); if (ok > best) best = ok; }
-    __syncthreads();
-    if ((tid & 63) == 0) { scr[2 * (tid >> 6)] = (uint32_t)best; scr[2 * (tid >> 6) + 1] = (uint32_t)(best >> 32); }
-    __syncthreads();
-    for (uint32_t w = 0; w < (nt >> 6); w++) { const unsigned long long ok = ((unsigned long long)scr[2 * w + 1] << 32) | scr[2 * w]; if (ok > best) best = ok; }
-    __syncthreads();
-    const uint32_t big_root = 0xFFFFFFFFu - (uint32_t)best, big_n = (uint32_t)(best >> 32);
-    // not worth it when one component holds most of the seeds (the graph has percolated: 1 % noise and beyond)
-    const bool split = total >= 2 && (10ull * big_n <= 7ull * total || (p.flags & BK_F_SPLIT_ALWAYS));
-    if (!split) return;                                                                 // uniform; the arena block is simply left unused
-    for (uint32_t u = tid; u < U; u += nt) {
-        uint32_t ci = BK_CI_NOUNIT;
-        if (bk_ld_agent(&csz[u])) ci = (u == big_root ? 0u : 1u + (uint32_t)(mix64(0x9E3779B97F4A7C15ull ^ u) % (BK_SPLIT_G - 1))) | BK_CI_ACTIVE;
-        cinfo[u] = ci;
-    }
-    __threadfence(); __syncthreads();
     if (tid == 0) {
         wk->o_rroot = a0; wk->o_cinfo = a0 + b_r; wk->o_kroot = a0 + 2 * b_r; wk->o_cidx = a0 + 2 * b_r + b_k; wk->o_pairs = a0 + 2 * b_r + b_k + b_x;
         wk->cidx_cap = cidx_cap; wk->pairs_cap = pairs_cap; wk->split = BK_SPLIT_G;
     }
 }
+// the snapshot of the read flags at the moment the graph was labelled (behind the pairs and the inbox): what a component is reset to
+__device__ inline uint8_t *bk_ufl0(const BkParams &p, const BkRegionWork *wk) { return p.arena + wk->o_pairs + bk_align_up((uint64_t)wk->pairs_cap * 12, 256); }
 
 // ---- after a pass in which components met across units: merge what met, reset and re-deal the sets that hold a conflict ----
 // One workgroup per entry of `list` (regions with status BK_ST_REDO).
@@ -132,8 +104,9 @@ extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkP
     // 1. everything that met becomes one component (merges inside a unit included: their contigs mixed their reads)
     for (uint32_t i = tid; i < np; i += nt) bk_uf_union(rroot, pairs[3 * i], pairs[3 * i + 1]);
     __threadfence(); __syncthreads();
-    // 2. a merged set that holds a conflict runs again (a component its unit gave up is always in one: the pair that made it give up)
+    // 2. a merged set that holds a conflict runs again (so does a component its unit gave up: it is always in one)
     for (uint32_t i = tid; i < np; i += nt) if (pairs[3 * i + 2]) atomicOr(&cinfo[bk_uf_find(rroot, pairs[3 * i])], BK_CI_REDO);
+    for (uint32_t u = tid; u < U; u += nt) if (bk_ld_agent(&cinfo[u]) & BK_CI_ABORT) atomicOr(&cinfo[bk_uf_find(rroot, u)], BK_CI_REDO);
     __threadfence(); __syncthreads();
     for (uint32_t u = tid; u < U; u += nt) atomicMin(&rroot[u], bk_uf_find(rroot, u));
     __threadfence(); __syncthreads();
@@ -142,9 +115,10 @@ extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkP
     // 3. reset the state the assembler keeps per read and per k-mer (as the k-mer stage left it) for what runs again
     uint8_t *ufl = p.uflag + d.read_meta_off; int32_t *ubuf = p.ubuf + d.read_meta_off, *ureads = p.ureads + d.read_meta_off, *ufound = p.ufound + d.read_meta_off, *uminpos = p.uminpos + d.read_meta_off;
     uint8_t *kstate = p.arena + wk->o_kstate; int32_t *kstamp = (int32_t *)(p.arena + wk->o_kstamp);
+    const uint8_t *ufl0 = bk_ufl0(p, wk);
     for (uint32_t u = tid; u < U; u += nt) {
         if (!(bk_ld_agent(&cinfo[bk_ld_agent(&rroot[u])]) & BK_CI_REDO)) continue;
-        ufl[u] &= (uint8_t)(BK_R_INDEL | BK_R_HASN); ubuf[u] = 0; ureads[u] = 0; ufound[u] = -1; uminpos[u] = 0x7FFFFFFF;
+        ufl[u] = ufl0[u]; ubuf[u] = 0; ureads[u] = 0; ufound[u] = -1; uminpos[u] = 0x7FFFFFFF;          // as unit 0 left them when it labelled the graph
     }
     for (uint32_t j = tid; j < M; j += nt) {
         const uint32_t k0 = kroot[j];
@@ -154,7 +128,7 @@ extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkP
     __threadfence(); __syncthreads();
     // 4. deal them to the units of the next pass
     for (uint32_t u = tid; u < U; u += nt) {
-        if (bk_ld_agent(&rroot[u]) != u) continue;
+        if (bk_ld_agent(&rroot[u]) != u) { cinfo[u] = BK_CI_NOUNIT; continue; }            // no longer a root: its word means nothing (and must not look given up next time)
         const uint32_t ci = bk_ld_agent(&cinfo[u]);
         if (ci & BK_CI_REDO) cinfo[u] = (uint32_t)(mix64(0xD1B54A32D192ED03ull * (pass + 1) ^ u) % BK_SPLIT_G) | (pass << 8) | BK_CI_ACTIVE;
     }
@@ -179,9 +153,9 @@ extern "C" __global__ void __launch_bounds__(BK_LINK_T) bk_link_kernel(BkParams 
         uint32_t npad = 1; while (npad < n) npad <<= 1;
         // dead contigs sort last
         for (uint32_t i = tid; i < npad; i += nt) {
-            if (i >= n) { key[i] = ~0ull; continue; }
+            if (i >= n || key[i] == ~0ull) { key[i] = ~0ull; continue; }      // padding, or dead since an earlier pass (the sort of that pass mixed both behind the live ones: such an entry may hold no record offset at all)
             const BkContigRec *c = (const BkContigRec *)(p.out + off[i]);
-            if (((cinfo[rroot[c->root]] >> 8) & 0xFFu) != c->pass) key[i] = ~0ull;
+            if (c->root != BK_EMPTY32 && (cinfo[rroot[c->root]] & 0xFFFFu) != c->pass) key[i] = ~0ull;            // made by the unit and pass that hold the component now (no component: unit 0's serial prefix)
         }
         __threadfence(); __syncthreads();
         for (uint32_t sz = 2; sz <= npad; sz <<= 1)

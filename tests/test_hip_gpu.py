@@ -180,8 +180,9 @@ def test_both_workgroup_sizes_gpu(hb, golden_dir):
 
 
 def test_split_regions_are_bit_identical_gpu(hb, golden_dir):
-    """Noisy regions are split over up to 16 assembler workgroups along the components of their read / k-mer graph
-    (bk_comp.hip.h); components that meet across units are merged and run again.  The result must be the serial one:
+    """Noisy regions are split over up to 16 assembler workgroups (bk_comp.hip.h): unit 0 runs the high-count seeds (the SV's own
+    k-mers) alone and in order, then the components of what is left of the read / k-mer graph are dealt to the units;
+    components that meet across units are merged and run again.  The result must be the serial one:
     (a) every reference fixture (G3) with the split FORCED on its small graph (flag 256), both workgroup sizes;
     (b) a mixed batch with mid-size noisy regions against the oracle, split forced;
     (c) full-size regions at 0.2 % / 0.5 % / 1 % substitutions, split (the default) against one unit (flag 128): the same
