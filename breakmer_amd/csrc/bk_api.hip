@@ -533,12 +533,15 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
             HIPCHK(h, hipGetLastError());
         }
     }
+    const bool dbg = getenv("BK_DEBUG_SPLIT") != nullptr;
+    if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] k-mer stage done (%d regions%s, arena %.1f MB)\n", n_launch, subset ? ", subset" : "", h->arena_cap / 1048576.0); }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if (mask & BK_STAGE_ASSEMBLE) {
         // regions ordered by estimated cost, heaviest first (part of the assembler's measured time: ev[1]..ev[2])
         if (!subset) {
             hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad);
             HIPCHK(h, hipGetLastError());
+            if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] sched done\n"); }
         }
         // Workgroup size: 512 threads (8 wavefronts, 8 look-ahead slots, 2 per CU) finish ONE batch soonest; 256 threads (4
         // wavefronts, 4 slots, 4 per CU) give more regions per CU whose serial phases overlap: +14 % regions/s once the
@@ -557,9 +560,11 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
         else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
         HIPCHK(h, hipGetLastError());
+        if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] assembler done (grid %d)\n", grid); }
         if (may_split) {          // contigs of split regions in the reference's order (idle for the others)
             hipLaunchKernelGGL(bk_link_kernel, dim3(std::min(h->n_regions, h->n_cu)), dim3(BK_LINK_T), 0, h->stream, h->params, h->n_regions);
             HIPCHK(h, hipGetLastError());
+            if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] link done\n"); }
         }
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));

@@ -1686,7 +1686,10 @@ BK_COLD void bk_label_live()
                     BK_SYNC();
                 }
             if (BK_TID == 0) {
-                uint32_t load[BK_SPLIT_G];
+                // (the units' loads in LDS -- the candidate list is free between two seeds.  NOT a local array: indexed at run time it
+                //  lives in scratch memory, and that made this out-of-line function fault at random, 3 runs in 20 of a 32-region
+                //  batch -- the second lesson of this kind after the out-of-line return values of round 2)
+                uint32_t *load = L_CANDU;
                 for (int g = 0; g < BK_SPLIT_G; g++) load[g] = 0;
                 for (int i = 0; i < n; i++) {
                     const uint32_t root = (uint32_t)L[i], c = 0xFFFFFFFFu - (uint32_t)(L[i] >> 32);
@@ -1880,10 +1883,15 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
 // than workgroups fit on the chip.
 extern "C" __global__ void __launch_bounds__(BK_AT, 4) BK_ASM_KERNEL(BkParams p)
 {
+    bool first = true;
     for (;;) {
         BK_SYNC();                                       // the previous region's LDS state is dead
-        if (BK_TID == 0) S_->qslot = (int)atomicAdd(p.asm_head, 1ull);
+        // The first entry a workgroup takes is the one of its own index: the grid is sized for the most units the batch can have
+        // (a noisy region is split into up to BK_SPLIT_G on the device), and with one unit per region the workgroups that find
+        // work must be the FIRST ones launched -- one per CU -- not whichever of two on a CU wins a race for the queue head.
+        if (BK_TID == 0) S_->qslot = first ? (int)blockIdx.x : (int)gridDim.x + (int)atomicAdd(p.asm_head, 1ull);
         BK_SYNC();
+        first = false;
         const int q = S_->qslot;
         if (q >= (int)*p.n_queue) break;
         const uint32_t e = p.order[q];

@@ -781,7 +781,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         o_tslot = o_tab2; out_tcap = tcap2;
     }
     BK_STAMP(7);
-    __threadfence(); __syncthreads();
+    __syncthreads();
     bk_split_prepare(p, wk, U, M, M2, kcnt, scr);      // noisy regions: several assembler workgroups per region (bk_comp.hip.h)
     if (tid == 0) {
         wk->U = U; wk->T = T; wk->M = M; wk->M2 = M2; wk->tcap = out_tcap;
