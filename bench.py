@@ -191,12 +191,14 @@ def time_runner(synth, regions, kmer, cycles=1):
     from breakmer_amd import sv_processor as sp
     d = tempfile.mkdtemp()
     bed, genes, data = [], ["header"], {}
+    from breakmer_amd import hip_backend as hb_
+    packed = {id(r): hb_.pack_reads(r.reads, r.read_lens) for r in regions}      # what a read extraction that packs as it goes hands over (BK_SUBMIT_PACKED); outside the clock like the extraction itself
     for c in range(cycles):
         for r in regions:
             name = r.name + ("C%d" % c if c else "")
             bed.append("\t".join([r.chrom, str(r.start), str(r.end), name, "exon"]))
             genes.append("\t".join(["0", name, "chr" + r.chrom, "+", str(r.start), str(r.end)] + ["x"] * 6 + [name]))
-            data[name.upper()] = sp.RegionData(r.read_ids, None, None, None, r.window_str, [], r.disc_reads, read_codes=r.reads, read_lens=r.read_lens)
+            data[name.upper()] = sp.RegionData(r.read_ids, None, None, None, r.window_str, [], r.disc_reads, read_codes=r.reads, read_lens=r.read_lens, read_packed=packed[id(r)])
     def config(tag, nb):
         open(os.path.join(d, tag + ".bed"), "w").write("\n".join(bed[:nb]) + "\n")
         open(os.path.join(d, tag + ".txt"), "w").write("\n".join(genes[:nb + 1]) + "\n")
@@ -210,7 +212,7 @@ def time_runner(synth, regions, kmer, cycles=1):
     dt = time.perf_counter() - t0
     return {"value": round(len(data) / dt, 1), "unit": "regions/s", "regions": len(data), "rows": len(rows), "seconds": round(dt, 3),
             "batches": (len(data) + 255) // 256,
-            "note": "runner.run() wall time: host packing + H2D + GPU stages + native call tail + per-target Python objects (no output files), "
+            "note": "runner.run() wall time: submit of 2-bit packed reads (BK_SUBMIT_PACKED: row copies + H2D) + GPU stages + native call tail + per-target Python objects (no output files), "
                     "after one untimed warm-up run of 3 batches (the process keeps its handles between runs); 2 x 256 distinct regions cycled under 16 sets of target names; "
                     "the timed `value` above excludes submit (inputs resident, SURVEY 8d)"}
 
@@ -400,6 +402,44 @@ def main():
             f.write(gstate["last"])
         with open(a.dump_collated + ".rank0", "wb") as f:
             f.write(last_rows.get("raw", b""))
+    # ---- the same loop with every batch SUBMITTED again (the drop-in's sustained rate: PCIe-inclusive).  The reads go over 2-bit
+    #      packed (BK_SUBMIT_PACKED: 96 MB per 256-region batch; one byte per base would be 384 MB), the submit of step s + inflight
+    #      runs on the library's thread (BK_SUBMIT_ASYNC) while the host collects the steps before it.
+    with_submit = None
+    if not dist:
+        pins = [hb.RegionInput(None, r.window, packed=hb.pack_reads(r.reads, r.read_lens)) for r in regions]
+        def run_steps_submit(k):
+            """step s: collect the results of engine s % n (fetch + call tail) and hand it its next batch (asynchronous submit on the
+            library's thread); the engine half a turn ahead, whose submit was started n/2 steps ago, gets its context and is
+            launched.  So n/2 submits and n/2 runs are in flight at any time."""
+            n = len(engs); half = max(1, n // 2)
+            state = ["idle"] * n                            # idle -> submitted -> running
+            raw = b""
+            done = started = 0
+            t = 0
+            while done < k:
+                i = t % n; e = engs[i]
+                if state[i] == "running":
+                    e.fetch(); raw = e.call_blob(); done += 1; state[i] = "idle"
+                if state[i] == "idle" and started < k:
+                    e.submit(pins, wait=False); state[i] = "submitted"; started += 1
+                j = (t + half) % n; f = engs[j]
+                if state[j] == "submitted":
+                    f.set_call_context(ctx_text); f.run(stages, sync=False); state[j] = "running"
+                t += 1
+            return raw
+        run_steps_submit(len(engs))
+        barrier()
+        tws = time.perf_counter()
+        ksub = max(len(engs), min(a.steps, 48))
+        raw_ws = run_steps_submit(ksub)
+        barrier()
+        wdt = time.perf_counter() - tws
+        with_submit = {"value": round(n_regions * ksub / wdt, 1), "unit": "regions/s", "steps": ksub, "ms_per_step": round(wdt / ksub * 1e3, 3),
+                       "bytes_per_step": int(sum(p_.reads.nbytes for p_ in pins)), "same_rows_as_resident": raw_ws == last_rows.get("raw"),
+                       "note": "every step submits its batch again (BK_SUBMIT_PACKED | BK_SUBMIT_ASYNC: 2-bit packed rows copied + H2D on the library's thread), context set again, then the same stages + call tail"}
+        for e in engs:                                      # back to the resident inputs for what follows
+            e.submit(ins); e.set_call_context(ctx_text)
     # ---- the same steps strictly one after the other (one handle, nothing in flight): the kernel durations of THIS pass
     #      are exclusive (no co-running batches stretch them) and are what the roofline figures use
     ks = max(2, min(a.steps, 8))
@@ -487,6 +527,7 @@ def main():
             "submit_ms": round(sum(submit_ms) / len(submit_ms), 2), "submit_pack_ms": round(pack_ms, 2), "h2d_ms": round(h2d_ms, 2),
             "submit_note": "bk_submit_regions of one %d-region batch (host 2-bit packing + H2D), outside the timed region" % n_regions,
             "one_step_at_a_time": serial,
+            "value_with_submit": with_submit,
         }
         if world == 1 and a.other_configs:
             try:

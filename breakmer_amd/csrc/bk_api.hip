@@ -269,7 +269,7 @@ extern "C" int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int3
 static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags)
 {
     if (!h || !regions || n_regions <= 0) return fail(h, BK_E_ARG, "bk_submit_regions: bad argument");
-    const bool read_codes = (flags & BK_SUBMIT_READ_CODES) != 0;
+    const bool read_codes = (flags & BK_SUBMIT_READ_CODES) != 0, packed = (flags & BK_SUBMIT_PACKED) != 0;
     HIPCHK(h, hipSetDevice(h->dev));
     const int k = h->cfg.kmer_size;
     // a failed submit leaves the handle without a batch (never the old device results paired with new host mirrors):
@@ -288,6 +288,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r];
         if (g.n_reads < 0 || !g.window || g.window_len <= 0 || (g.n_reads > 0 && (!g.reads || !g.read_lens))) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": missing reads/window");
+        if (packed && read_codes) return fail(h, BK_E_ARG, "bk_submit_regions: BK_SUBMIT_PACKED and BK_SUBMIT_READ_CODES exclude each other");
         if (g.n_reads >= (1 << 22)) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 4M reads in one region");
     }
     // per region: longest read, number of bases (one pass over the lengths, regions in parallel)
@@ -372,11 +373,29 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
                 if (r >= n_regions) break;
                 const bk_region &g = regions[r]; const BkRegionDesc &d = n_desc[r];
                 for (int i = 0; i < g.n_reads; i++) { rlen[d.read_meta_off + i] = g.read_lens[i]; rflag[d.read_meta_off + i] = g.indel_only && g.indel_only[i] ? BK_RF_INDEL : 0; }
+                if (packed) {        // rows are 2 bit/base already: copied into the library's row stride, the tail zeroed
+                    for (int i = 0; i < g.n_reads; i++) {
+                        const uint32_t nw = ((uint32_t)g.read_lens[i] + 15u) / 16u; uint32_t *dst = reads + d.reads_word_off + (size_t)i * d.read_words;
+                        memcpy(dst, g.reads + (size_t)i * g.read_stride, (size_t)nw * 4);
+                        if (g.read_lens[i] & 15) dst[nw - 1] &= 0xFFFFFFFFu << (2 * (16 - (g.read_lens[i] & 15)));      // bases beyond the length must read as A (the kernels compare whole words)
+                        for (uint32_t w = nw; w < d.read_words; w++) dst[w] = 0;
+                    }
+                    if (g.read_n && g.n_read_n > 0) {
+                        region_nl[r].assign(g.read_n, g.read_n + g.n_read_n);
+                        for (int e = 0; e < g.n_read_n; e++) {
+                            const uint32_t v = g.read_n[e], ri = v >> 10, pos = v & 1023u;
+                            if ((int)ri >= g.n_reads || pos >= g.read_lens[ri] || (e && g.read_n[e - 1] >= v)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = (int)ri; break; }
+                            uint32_t *dst = reads + d.reads_word_off + (size_t)ri * d.read_words;
+                            dst[pos >> 4] &= ~(3u << (30 - 2 * (pos & 15)));                              // an N is packed as A
+                        }
+                    }
+                    continue;
+                }
                 for (int i = 0; i < g.n_reads; i++)
                     if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i, read_codes)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
             }
         });
-        if (bad_region >= 0) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_region.load()) + " read " + std::to_string(bad_read.load()) + ": base other than A/C/G/T/N");
+        if (bad_region >= 0) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_region.load()) + " read " + std::to_string(bad_read.load()) + (packed ? ": N list not ascending or out of range" : ": base other than A/C/G/T/N"));
     }
     // N calls: one sorted list per region (reads are packed in order, positions ascending), flag on the reads that have any
     std::vector<uint32_t> nlist;

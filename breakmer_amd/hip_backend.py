@@ -37,7 +37,7 @@ class BkRegion(C.Structure):
                 ("n_reads", C.c_int32), ("read_stride", C.c_int32),
                 ("sc_seqs", C.c_void_p), ("sc_lens", C.c_void_p), ("n_sc", C.c_int32), ("sc_stride", C.c_int32),
                 ("window", C.c_char_p), ("window_len", C.c_int32), ("n_partners", C.c_int32),
-                ("partners", C.POINTER(C.c_char_p)), ("partner_lens", C.c_void_p)]
+                ("partners", C.POINTER(C.c_char_p)), ("partner_lens", C.c_void_p), ("read_n", C.c_void_p), ("n_read_n", C.c_int32)]
 
 
 class BkContigInfo(C.Structure):
@@ -146,9 +146,18 @@ def _as_c(a, dtype):
 class RegionInput(object):
     """Host-side view of one target region, kept alive until submit returns."""
 
-    def __init__(self, reads, window, *, read_lens=None, indel_only=None, sc_seqs=None, partners=()):
-        self.codes = isinstance(reads, np.ndarray)          # uint8 codes 0..3 (4 = N), [N, L]: handed over as they are (bk_submit_regions_ex)
-        if self.codes:
+    def __init__(self, reads, window, *, read_lens=None, indel_only=None, sc_seqs=None, partners=(), packed=None):
+        """packed: (words uint32 [N, W], read_lens, n_list uint32) as pack_reads() makes them -- handed over as they are
+        (BK_SUBMIT_PACKED): a quarter of the bytes of a code matrix and no packing on the submit path"""
+        self.packed = packed is not None
+        self.read_n = None
+        self.codes = (not self.packed) and isinstance(reads, np.ndarray)          # uint8 codes 0..3 (4 = N), [N, L]: handed over as they are (bk_submit_regions_ex)
+        if self.packed:
+            words, plens, nl = packed
+            self.reads = _as_c(words, np.uint32)
+            self.lens = _as_c(plens, np.uint16)
+            self.read_n = _as_c(nl, np.uint32) if nl is not None and len(nl) else None
+        elif self.codes:
             self.reads = _as_c(reads, np.uint8) if reads.size else np.zeros((0, 1), dtype=np.uint8)
             self.lens = (_as_c(read_lens, np.uint16) if read_lens is not None
                          else np.full(reads.shape[0], reads.shape[1], dtype=np.uint16))
@@ -179,6 +188,10 @@ class RegionInput(object):
         g.read_lens = self.lens.ctypes.data
         g.indel_only = self.indel_only.ctypes.data if self.indel_only is not None else None
         g.n_reads, g.read_stride = reads.shape
+        if self.packed:
+            g.read_stride = reads.shape[1] * 4                  # bytes between rows
+            g.read_n = self.read_n.ctypes.data if self.read_n is not None else None
+            g.n_read_n = 0 if self.read_n is None else len(self.read_n)
         if self.sc is None:
             g.sc_seqs, g.sc_lens, g.n_sc, g.sc_stride = None, None, -1, 0
         else:
@@ -277,6 +290,15 @@ class Engine(object):
         arr = (BkRegion * len(regions))()
         for g, r in zip(arr, regions):
             r.fill(g)
+        pk = {bool(r.packed) for r in regions if r.reads.shape[0]}
+        if pk == {True}:
+            self._chk(self.L.bk_submit_regions_ex(self.h, arr, len(regions), 4 | (0 if wait else 2)), "bk_submit_regions")
+            self._inputs = None if wait else (arr, regions)
+            self.n_regions = len(regions)
+            self.batch_serial += 1
+            return
+        if True in pk:
+            raise BreakmerHipError("a batch is either all packed reads (RegionInput(packed=...)) or none")
         kinds = {bool(r.codes) for r in regions if r.reads.shape[0]}
         if len(kinds) > 1:                                  # mixed batch: the code matrices become ASCII (one C-speed byte translation each)
             for g, r in zip(arr, regions):
@@ -502,6 +524,27 @@ def close_pool():
 
 import atexit  # noqa: E402
 atexit.register(close_pool)
+
+
+def pack_reads(codes, lens=None):
+    """uint8 code matrix [N, L] (0..3, 4 = N) -> (uint32 words [N, ceil(L/16)], uint16 lens, uint32 N list) in the layout
+    bk_submit_regions_ex(BK_SUBMIT_PACKED) takes: 16 bases per word, the first in the most significant bits, an N packed as A,
+    bases beyond a read's length zero.  Vectorised numpy (what a read extraction that packs as it goes would hand over)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n, L = codes.shape
+    lens = np.full(n, L, dtype=np.uint16) if lens is None else np.ascontiguousarray(lens, dtype=np.uint16)
+    W = (L + 15) // 16
+    pad = np.zeros((n, W * 16), dtype=np.uint8)
+    pad[:, :L] = codes
+    pad[np.arange(W * 16)[None, :] >= lens[:, None]] = 0
+    isn = pad == 4
+    rr, pp = np.nonzero(isn)
+    nl = ((rr.astype(np.uint32) << np.uint32(10)) | pp.astype(np.uint32)).astype(np.uint32)      # row-major: ascending
+    pad[isn] = 0
+    v = pad.reshape(n, W, 16).astype(np.uint32)
+    sh = (30 - 2 * np.arange(16, dtype=np.uint32))[None, None, :]
+    words = np.bitwise_or.reduce(v << sh, axis=2).astype(np.uint32)
+    return words, lens, nl
 
 
 def pack_sequence(seq, codes=False):

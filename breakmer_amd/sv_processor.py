@@ -34,10 +34,12 @@ class RegionData(object):
     the forward window, extra windows with genome coordinates, discordant-pair evidence."""
 
     def __init__(self, read_ids, read_seqs, indel_only=None, sc_seqs=None, window="", partners=(), disc_reads=None, quals=None,
-                 read_codes=None, read_lens=None):
+                 read_codes=None, read_lens=None, read_packed=None):
         # read_codes / read_lens: optional uint8 code matrix [N, L] (0..3 = ACGT, 4 = N) + lengths of the same reads: handed to
         # the library as is (no per-read Python work); read_seqs may then be a lazy sequence of the strings
-        self.read_codes, self.read_lens = read_codes, read_lens
+        # read_packed: optional (words, lens, N list) of the SAME reads as hip_backend.pack_reads makes them (2 bit/base): what goes to
+        # the library then (BK_SUBMIT_PACKED: a quarter of the bytes, no packing on the submit path)
+        self.read_codes, self.read_lens, self.read_packed = read_codes, read_lens, read_packed
         self.read_ids = read_ids if read_codes is not None else list(read_ids)
         self.read_seqs = read_seqs if read_codes is not None else list(read_seqs)
         self.indel_only = (indel_only if read_codes is not None else list(indel_only)) if indel_only is not None else ([False] * len(self.read_ids) if read_codes is None else _np.zeros(len(read_ids), dtype=_np.uint8))
@@ -50,18 +52,21 @@ class RegionData(object):
         self._refcheck = None                   # (window, number of partners, verdict of target.unsupported_reference)
         self._maxlen = None                     # (read_lens, its maximum)
 
-    def device_view(self):
+    def device_view(self, use_packed=True):
         """the hip_backend.RegionInput of these inputs.  Made once per state of the inputs and kept with them: a driver that
         runs the same RegionData again (several analyses over one set of extracted reads) does not rebuild it per run.  The
         objects it was made from are kept and compared by identity, so any replacement of an input makes a new view."""
         from . import hip_backend
         reads = self.read_codes if self.read_codes is not None else self.read_seqs
+        packed = self.read_packed if use_packed else None
         v = self._view
+        if v is not None and v[8].packed != (packed is not None):
+            v = None
         if v is not None and v[0] is reads and v[1] is self.read_lens and v[2] is self.indel_only and v[3] is self.sc_seqs and v[4] is self.window and v[5] is self.partners and v[6] == len(self.partners) \
                 and (self.read_codes is not None or v[7] == len(reads)):
             return v[8]
         io = self.indel_only if type(self.indel_only) is _np.ndarray else _np.asarray(self.indel_only, dtype=_np.uint8)
-        ri = hip_backend.RegionInput(reads, self.window, read_lens=self.read_lens, indel_only=io, sc_seqs=self.sc_seqs, partners=[p[4] for p in self.partners])
+        ri = hip_backend.RegionInput(reads, self.window, read_lens=self.read_lens, indel_only=io, sc_seqs=self.sc_seqs, partners=[p[4] for p in self.partners], packed=packed)
         self._view = (reads, self.read_lens, self.indel_only, self.sc_seqs, self.window, self.partners, len(self.partners), len(reads), ri)
         return ri
 
@@ -712,9 +717,10 @@ class runner(object):                                               # sv_process
         own thread (BK_SUBMIT_ASYNC) while this thread goes on with the previous batch"""
         from . import hip_backend
         ins = []
+        allp = all(t.data.read_packed is not None for t in live)          # a batch goes over packed (BK_SUBMIT_PACKED) or not at all
         for i, t in enumerate(live):
             t.region_index, t.engine = i, eng
-            ins.append(t.data.device_view())
+            ins.append(t.data.device_view(allp))
         try:
             eng.submit(ins, wait=False)
         except TypeError:

@@ -89,6 +89,8 @@ typedef struct bk_region {
     int32_t n_partners;         /* extra windows for realignment (whole-genome fallback stand-in, sv_processor.py:829-831) */
     const char *const *partners;   /* n_partners sequences (ASCII) and their lengths; both may be NULL when n_partners == 0 */
     const int32_t *partner_lens;
+    const uint32_t *read_n;     /* BK_SUBMIT_PACKED only: the N calls of the reads, (read index << 10 | position), ascending; may be NULL */
+    int32_t n_read_n;
 } bk_region;
 
 /* Lifetime (replaces: process start + params(), sv_processor.py:99-105). Fails with BK_E_NOGPU when
@@ -114,6 +116,11 @@ int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions)
  * next call on this handle has returned.  Every later call on the handle first waits for the submit and, if it failed,
  * returns its error code (bk_last_error has the text) instead of doing its own work. */
 #define BK_SUBMIT_ASYNC 2u
+/* BK_SUBMIT_PACKED: the `reads` rows are ALREADY 2 bit/base as bk_pack_sequence makes them (16 bases per 32-bit word, first base in
+ * the most significant bits, an N packed as A), ceil(len / 16) words per row, rows read_stride BYTES apart; the N calls come as
+ * bk_region.read_n.  A quarter of the bytes of BK_SUBMIT_READ_CODES (96 MB instead of 384 MB per 256-region batch of the headline
+ * shape) and no packing on the submit path: for callers whose read extraction packs as it goes. */
+#define BK_SUBMIT_PACKED 4u
 int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags);
 
 /* Run the selected stages on everything submitted (replaces, per region:
