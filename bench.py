@@ -439,7 +439,7 @@ def main():
                        "bytes_per_step": int(sum(p_.reads.nbytes for p_ in pins)), "same_rows_as_resident": raw_ws == last_rows.get("raw"),
                        "note": "every step submits its batch again (BK_SUBMIT_PACKED | BK_SUBMIT_ASYNC: 2-bit packed rows copied + H2D on the library's thread), context set again, then the same stages + call tail"}
         for e in engs:                                      # back to the resident inputs for what follows
-            e.submit(ins); e.set_call_context(ctx_text)
+            e.submit(ins); e.set_call_context(ctx_text); e.run(stages)
     # ---- the same steps strictly one after the other (one handle, nothing in flight): the kernel durations of THIS pass
     #      are exclusive (no co-running batches stretch them) and are what the roofline figures use
     ks = max(2, min(a.steps, 8))

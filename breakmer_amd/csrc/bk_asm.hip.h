@@ -1881,7 +1881,10 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
 // Persistent workgroups: each pulls the next region of the cost-ordered queue (bk_sched.hip.h) until it is empty, so a
 // batch is not bound by whichever heavy region happened to be launched last, and a batch may hold many more regions
 // than workgroups fit on the chip.
-extern "C" __global__ void __launch_bounds__(BK_AT, 4) BK_ASM_KERNEL(BkParams p)
+#ifndef BK_ASM_MINB
+#define BK_ASM_MINB 4
+#endif
+extern "C" __global__ void __launch_bounds__(BK_AT, BK_ASM_MINB) BK_ASM_KERNEL(BkParams p)
 {
     bool first = true;
     for (;;) {

@@ -83,3 +83,18 @@ def test_pack_sequence_simd_equals_table_path():
             hb.pack_sequence(bad)
     with pytest.raises(hb.BreakmerHipError):
         hb.pack_sequence(bytes([0, 1, 2, 3, 7]), codes=True)
+
+
+def test_pack_reads_matches_the_library_packing():
+    """hip_backend.pack_reads (numpy; what BK_SUBMIT_PACKED takes) == bk_pack_sequence (the library's own packing) word for word, N
+    positions included, for ragged reads with N calls."""
+    import numpy as np
+    from breakmer_amd import hip_backend as hb, synth
+    r = synth.make_region(5, depth=30, W=900, n_frac=0.2, var_len=0.5)
+    w, l, nl = hb.pack_reads(r.reads, r.read_lens)
+    assert w.dtype == np.uint32 and l.tolist() == r.read_lens.tolist() and len(nl) > 10 and (np.diff(nl.astype(np.int64)) > 0).all()
+    for i in range(r.reads.shape[0]):
+        ww, npos = hb.pack_sequence(bytes(r.reads[i, :r.read_lens[i]]), codes=True)
+        nw = (int(r.read_lens[i]) + 15) // 16
+        assert (ww[:nw] == w[i, :nw]).all() and (w[i, nw:] == 0).all(), i
+        assert [int(x & 1023) for x in nl if (x >> 10) == i] == npos, i

@@ -1113,3 +1113,34 @@ def test_assembler_occupancy_of_the_headline_shape_gpu(hb):
         eng = _run_regions(hb, regions, 31, stages=7, wg_threads=wg)
         assert eng.stat(25) == wg and eng.stat(23) == want, (wg, eng.stat(23))
         eng.close()
+
+
+def test_packed_submit_gpu(hb):
+    """BK_SUBMIT_PACKED: reads handed over 2 bit/base (hip_backend.pack_reads) -- ragged lengths, reads with N calls, duplicates --
+    give the same k-mers, contigs and realign records as the same reads handed over as base codes or as strings; a batch is all
+    packed or not at all; a broken N list is refused."""
+    import numpy as np
+    regions = [synth.make_region(3, depth=60, W=1500), synth.make_region(31, depth=80, W=1200, var_len=0.6, noise=0.004),
+               synth.make_region(32, depth=80, W=1200, sv_type="ins", n_frac=0.15), synth.make_region(33, depth=60, W=1500, sv_type="inv", var_len=0.3, n_frac=0.05)]
+    a = hb.Engine(kmer_size=31)
+    a.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
+    a.run(hb.BK_STAGE_ALL)
+    b = hb.Engine(kmer_size=31)
+    b.submit([hb.RegionInput(None, r.window, packed=hb.pack_reads(r.reads, r.read_lens)) for r in regions])
+    b.run(hb.BK_STAGE_ALL)
+    c = hb.Engine(kmer_size=31)
+    c.submit([hb.RegionInput(None, r.window, packed=hb.pack_reads(r.reads, r.read_lens)) for r in regions], wait=False)      # through the library's submit thread
+    c.run(hb.BK_STAGE_ALL)
+    for i in range(len(regions)):
+        ka, kb = a.kmers(i), b.kmers(i)
+        assert ka[0] == kb[0] and ka[1].tolist() == kb[1].tolist() and ka[2] == kb[2], i
+        ca = a.contigs(i)
+        assert ca and ca == b.contigs(i) == c.contigs(i), i
+        for ci in range(len(ca)):
+            assert a.hits(i, ci) == b.hits(i, ci), (i, ci)
+    with pytest.raises(hb.BreakmerHipError):
+        hb.Engine(kmer_size=31).submit([hb.RegionInput(regions[0].reads, regions[0].window), hb.RegionInput(None, regions[1].window, packed=hb.pack_reads(regions[1].reads, regions[1].read_lens))])
+    w, l, nl = hb.pack_reads(regions[2].reads, regions[2].read_lens)
+    assert len(nl) > 2
+    with pytest.raises(hb.BreakmerHipError):
+        hb.Engine(kmer_size=31).submit([hb.RegionInput(None, regions[2].window, packed=(w, l, nl[::-1].copy()))])        # not ascending
