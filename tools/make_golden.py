@@ -215,11 +215,13 @@ def g5():
     cases = []
 
     def add(tag, r, sv_rows_fn=None, opts=None, genes_extra=None, drop_partner_gene=False, disc=None, trm=None, arm=None,
-            features='exon', indel_mode=None, noise_seed=None):
+            features='exon', indel_mode=None, noise_seed=None, soft=None):
         reads = r.read_strs()
         mers = rh.ref_kmer_select(reads, [r.window_str], 31)
         cdicts, cobjs = rh.ref_init_assembly(r.read_ids, reads, mers, 31, 2, r.indel_only)
         targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+        if soft:                 # a soft-masked (lower-case) stretch of the target window: BLAT -repeats=lower reports matches on it as repMatches (sv_processor.py:843)
+            targets[0] = targets[0][:soft[0]] + targets[0][soft[0]:soft[1]].lower() + targets[0][soft[1]:]
         tinfo = [(r.chrom, r.start - 200)] + [(p[0], p[1]) for p in r.partners]
         qr = (r.chrom, r.start, r.end, r.name, [(r.chrom, r.start, r.end, r.name, features)])
         genes = {r.name: ['chr' + r.chrom, r.start, r.end]}
@@ -238,7 +240,7 @@ def g5():
                 rows = [my.psl_fields(x, 'contig1', r.name, 0) for x in recs if x['t_index'] == 0]
                 offset, tname = r.start - 200, r.chrom
             else:                # whole-genome style rows: genome coordinates and chr names (Q14)
-                rows = [my.psl_fields(x, 'contig1', 'chr' + tinfo[x['t_index']][0], tinfo[x['t_index']][1]) for x in recs]
+                rows = [my.psl_fields(x, 'contig1', 'chr' + tinfo[x['t_index']][0], tinfo[x['t_index']][1], repeats_lower=False) for x in recs]      # the genome-wide gfClient call has no -repeats=lower
                 offset, tname = None, None
             if sv_rows_fn:
                 rows = sv_rows_fn(rows)
@@ -292,6 +294,17 @@ def g5():
         return out
     add("del_minus_strand_rows", mk(3, "del"), sv_rows_fn=flip)
     add("no_rows", mk(3, "del"), sv_rows_fn=lambda rows: [])
+    # soft-masked windows: rows with repMatches > 0 (sv_caller.py:913; :975-986: such a record is in_repeat and SKIPS the repeat-mask overlap)
+    r = mk(3, "del")
+    c_ = 750
+    g0 = r.start - 200
+    simple_r = [(r.chrom, g0 + 640, g0 + 660, "(CA)n")]
+    add("del_soft_left_flank_indelmode", r, indel_mode=True, soft=(c_ - 160, c_ - 100))
+    add("del_soft_left_flank_rmask_indelmode", r, indel_mode=True, soft=(c_ - 160, c_ - 100), trm=simple_r, arm={r.chrom: simple_r})
+    add("del_rmask_indelmode", r, indel_mode=True, trm=simple_r, arm={r.chrom: simple_r})
+    add("del_soft_whole_window_indelmode", r, indel_mode=True, soft=(0, 1500))
+    add("del_soft_left_flank_genome_rows", r, soft=(c_ - 160, c_ - 100))
+    add("ins_soft_at_brkpt_indelmode", mk(5, "ins"), indel_mode=True, soft=(c_ - 20, c_ + 20))
     add("single_partial_hit", mk(3, "del"), sv_rows_fn=lambda rows: [[str(x) for x in ["120", "0", "0", "0", "0", "0", "0", "0", "+", "contig1", "297", "0", "120", "chr4", "1500", "100502", "100622", "1", "120,", "0,", "100502,"]]])
     dump("caller.json", {"cases": cases})
 
