@@ -1310,3 +1310,63 @@ extern "C" int bk_get_calls(bk_handle *h, char *buf, size_t cap, size_t *needed)
     if (buf && cap >= h->calls_blob.size() + 1) memcpy(buf, h->calls_blob.c_str(), h->calls_blob.size() + 1);
     return BK_OK;
 }
+
+
+// ---- genome-wide seed lookup: sorted sampled k-mer codes in HBM, one binary search pair per query k-mer (N4; include/breakmer_hip.h)
+struct bk_index { int dev = 0; hipStream_t stream = nullptr; DevBuf d_codes, d_q, d_lo, d_hi; uint64_t n = 0; hipEvent_t ev[2] = {}; };
+// A thread per query: lower and upper bound in the sorted codes.  The first ~12 levels of every search touch the same few
+// hundred lines (L2-resident); the rest are one dependent HBM access each -- bound by the latency of ~2 x 16 of them per query,
+// hidden by the other queries in flight.
+extern "C" __global__ void __launch_bounds__(256) bk_index_probe_kernel(const uint32_t *codes, uint64_t n, const uint32_t *q, uint64_t nq, uint32_t *lo, uint32_t *hi)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    const uint32_t key = q[i];
+    uint64_t a = 0, b = n;
+    while (a < b) { const uint64_t m = (a + b) >> 1; if (codes[m] < key) a = m + 1; else b = m; }
+    const uint64_t l = a;
+    b = n;
+    while (a < b) { const uint64_t m = (a + b) >> 1; if (codes[m] <= key) a = m + 1; else b = m; }
+    lo[i] = (uint32_t)l; hi[i] = (uint32_t)a;
+}
+extern "C" int bk_index_create(int device_id, const uint32_t *sorted_codes, uint64_t n, bk_index **out)
+{
+    if (!out || (n && !sorted_codes) || n >= (1ull << 32)) return fail(nullptr, BK_E_ARG, "bk_index_create: bad argument (at most 2^32 - 1 entries)");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return fail(nullptr, BK_E_NOGPU, "bk_index_create: no HIP device visible (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= nd) return fail(nullptr, BK_E_ARG, "bk_index_create: bad device id");
+    bk_index *ix = new bk_index(); ix->dev = device_id; ix->n = n;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ix->ev[0]) != hipSuccess || hipEventCreate(&ix->ev[1]) != hipSuccess ||
+        ix->d_codes.ensure(std::max<uint64_t>(n, 1) * 4) != hipSuccess || (n && hipMemcpy(ix->d_codes.p, sorted_codes, n * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+        (void)bk_index_destroy(ix); return fail(nullptr, BK_E_HIP, "bk_index_create: device allocation / copy failed");
+    }
+    *out = ix;
+    return BK_OK;
+}
+extern "C" int bk_index_probe(bk_index *ix, const uint32_t *queries, uint64_t nq, uint32_t *lo, uint32_t *hi, float *kernel_ms)
+{
+    if (!ix || (nq && (!queries || !lo || !hi))) return BK_E_ARG;
+    if (!nq) return BK_OK;
+    if (hipSetDevice(ix->dev) != hipSuccess) return BK_E_HIP;
+    if (ix->d_q.ensure(nq * 4) != hipSuccess || ix->d_lo.ensure(nq * 4) != hipSuccess || ix->d_hi.ensure(nq * 4) != hipSuccess) return BK_E_NOMEM;
+    if (hipMemcpyAsync(ix->d_q.p, queries, nq * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) return BK_E_HIP;
+    (void)hipEventRecord(ix->ev[0], ix->stream);
+    hipLaunchKernelGGL(bk_index_probe_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ix->stream, (const uint32_t *)ix->d_codes.p, ix->n, (const uint32_t *)ix->d_q.p, nq, (uint32_t *)ix->d_lo.p, (uint32_t *)ix->d_hi.p);
+    if (hipGetLastError() != hipSuccess) return BK_E_HIP;
+    (void)hipEventRecord(ix->ev[1], ix->stream);
+    if (hipMemcpyAsync(lo, ix->d_lo.p, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess || hipMemcpyAsync(hi, ix->d_hi.p, nq * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) return BK_E_HIP;
+    if (hipStreamSynchronize(ix->stream) != hipSuccess) return BK_E_HIP;
+    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ix->ev[0], ix->ev[1]);
+    return BK_OK;
+}
+extern "C" int bk_index_destroy(bk_index *ix)
+{
+    if (!ix) return BK_OK;
+    (void)hipSetDevice(ix->dev);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    ix->d_codes.release(); ix->d_q.release(); ix->d_lo.release(); ix->d_hi.release();
+    for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+    return BK_OK;
+}

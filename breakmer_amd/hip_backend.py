@@ -69,7 +69,7 @@ def call_text(text):
 EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_submit_regions_ex", "bk_run", "bk_sync", "bk_fetch",
            "bk_last_kernel_ms", "bk_get_region_status", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
            "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_get_calls",
-           "bk_nw_batch", "bk_pack_sequence", "bk_trim", "bk_get_hits_flat"]
+           "bk_nw_batch", "bk_pack_sequence", "bk_trim", "bk_get_hits_flat", "bk_index_create", "bk_index_probe", "bk_index_destroy"]
 
 _lib = None
 
@@ -106,6 +106,9 @@ def load_library():
     L.bk_get_hits.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BkPsl), C.c_int32]
     L.bk_get_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     L.bk_get_hits_flat.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.bk_index_create.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.bk_index_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    L.bk_index_destroy.argtypes = [C.c_void_p]
     L.bk_call_text.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
     L.bk_pack_sequence.argtypes = [C.c_char_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.bk_trim.argtypes = [C.c_void_p, C.c_uint64]
@@ -524,6 +527,43 @@ def close_pool():
 
 import atexit  # noqa: E402
 atexit.register(close_pool)
+
+
+class DeviceIndex(object):
+    """sorted sampled k-mer codes of a genome resident in HBM; probe(queries) -> (lo, hi) index ranges by binary search on the
+    device (bk_index_*; the host's numpy.searchsorted over the same array is what it is pinned against)"""
+
+    def __init__(self, sorted_codes, device=0):
+        self.L = load_library()
+        codes = _as_c(sorted_codes, np.uint32)
+        self.h = C.c_void_p()
+        self.n = len(codes)
+        rc = self.L.bk_index_create(int(device), codes.ctypes.data, len(codes), C.byref(self.h))
+        if rc != 0:
+            raise BreakmerHipError("bk_index_create failed (%d): %s" % (rc, self.L.bk_last_error(None).decode()))
+        self.kernel_ms = 0.0
+
+    def probe(self, queries):
+        q = _as_c(queries, np.uint32)
+        lo = np.zeros(len(q), dtype=np.uint32)
+        hi = np.zeros(len(q), dtype=np.uint32)
+        ms = C.c_float()
+        rc = self.L.bk_index_probe(self.h, q.ctypes.data, len(q), lo.ctypes.data, hi.ctypes.data, C.byref(ms))
+        if rc != 0:
+            raise BreakmerHipError("bk_index_probe failed (%d)" % rc)
+        self.kernel_ms = ms.value
+        return lo, hi
+
+    def close(self):
+        if self.h:
+            self.L.bk_index_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def pack_reads(codes, lens=None):

@@ -90,10 +90,28 @@ class GenomeIndex(object):
     every sequence, N-free, sorted by code with (sequence number, position).  Built once per run, on first use (a 3 Gb genome
     at step 8: ~375 M entries, ~3.4 GB, about a minute of numpy); tests use kilobase genomes."""
 
-    def __init__(self, fasta, k=16, step=8, max_occ=64):
+    def __init__(self, fasta, k=16, step=8, max_occ=64, cache=True, device=None):
+        """cache: keep the sorted index next to the FASTA (<fasta>.bkidx.k<k>s<step>.npz, valid while size and mtime of the FASTA
+        stay) -- a 3 Gb genome takes minutes to index and every rank of a run needs the same one.  device: GPU number for the
+        look-ups (hip_backend.DeviceIndex: the sorted codes in HBM, binary search per query k-mer on the device); None = host
+        numpy.searchsorted (the same ranges: tests/test_hip_gpu.py pins one against the other)."""
         import numpy as np
         self.k, self.step, self.max_occ, self.fasta = int(k), int(step), int(max_occ), fasta
         self.names = list(fasta.index.keys())
+        self._dev, self._dev_no = None, device
+        self.probe_ms = 0.0
+        cfn = None
+        if cache and getattr(fasta, "path", None):
+            st = os.stat(fasta.path)
+            cfn = "%s.bkidx.k%ds%d.npz" % (fasta.path, self.k, self.step)
+            if os.path.isfile(cfn):
+                try:
+                    z = np.load(cfn)
+                    if int(z["size"]) == st.st_size and int(z["mtime_ns"]) == st.st_mtime_ns and list(z["names"]) == self.names:
+                        self.code, self.seqno, self.pos = z["code"], z["seqno"], z["pos"]
+                        return
+                except Exception:
+                    pass
         codes, seqno, pos = [], [], []
         lut = np.full(256, 4, dtype=np.uint8)
         for i, ch in enumerate(b"ACGT"):
@@ -125,6 +143,25 @@ class GenomeIndex(object):
             self.code, self.seqno, self.pos = code[order], np.concatenate(seqno)[order], np.concatenate(pos)[order]
         else:
             self.code = np.zeros(0, dtype=np.uint32); self.seqno = np.zeros(0, dtype=np.uint16); self.pos = np.zeros(0, dtype=np.uint32)
+        if cfn:
+            try:
+                tmp = cfn + ".%d.tmp.npz" % os.getpid()
+                np.savez(tmp, code=self.code, seqno=self.seqno, pos=self.pos, size=st.st_size, mtime_ns=st.st_mtime_ns, names=np.array(self.names))
+                os.replace(tmp, cfn)                      # several ranks may build at once: whoever finishes last wins, every file is complete
+            except OSError:
+                pass
+
+    def _ranges(self, code):
+        """index ranges [lo, hi) of the entries equal to each query code"""
+        import numpy as np
+        if self._dev_no is not None:
+            if self._dev is None:
+                from . import hip_backend
+                self._dev = hip_backend.DeviceIndex(self.code, self._dev_no)
+            lo, hi = self._dev.probe(code)
+            self.probe_ms += self._dev.kernel_ms
+            return lo.astype(np.int64), hi.astype(np.int64)
+        return np.searchsorted(self.code, code, side="left"), np.searchsorted(self.code, code, side="right")
 
     def _codes(self, seq):
         import numpy as np
@@ -152,21 +189,21 @@ class GenomeIndex(object):
             code, ok = self._codes(q)
             if not len(code):
                 continue
-            lo = np.searchsorted(self.code, code, side="left"); hi = np.searchsorted(self.code, code, side="right")
-            hits = []
-            for qp in np.nonzero(ok & (hi > lo) & (hi - lo <= self.max_occ))[0]:
-                for e in range(int(lo[qp]), int(hi[qp])):
-                    hits.append((int(self.seqno[e]), int(self.pos[e]) - int(qp), int(self.pos[e])))
-            hits.sort()
-            i = 0
-            while i < len(hits):
-                j = i
-                while j + 1 < len(hits) and hits[j + 1][0] == hits[i][0] and hits[j + 1][1] - hits[j][1] <= band:
-                    j += 1
-                if j - i + 1 >= min_hits:
-                    ps = [h[2] for h in hits[i:j + 1]]
-                    out.append((j - i + 1, self.names[hits[i][0]], strand, min(ps), max(ps) + self.k))
-                i = j + 1
+            lo, hi = self._ranges(code)
+            use = np.nonzero(ok & (hi > lo) & (hi - lo <= self.max_occ))[0]
+            if not len(use):
+                continue
+            cnt = (hi[use] - lo[use]).astype(np.int64)
+            qp = np.repeat(use, cnt)                                                  # query position of every hit
+            e = np.repeat(lo[use], cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))      # its index entry
+            sq = self.seqno[e].astype(np.int64); ps = self.pos[e].astype(np.int64); dg = ps - qp
+            order = np.lexsort((ps, dg, sq))                                          # by (sequence, diagonal, position): as sorted tuples
+            sq, dg, ps = sq[order], dg[order], ps[order]
+            brk = np.nonzero((sq[1:] != sq[:-1]) | (dg[1:] - dg[:-1] > band))[0] + 1  # a locus ends where the sequence changes or the diagonal jumps
+            starts = np.concatenate(([0], brk)); ends = np.concatenate((brk, [len(sq)]))
+            for a, b in zip(starts.tolist(), ends.tolist()):
+                if b - a >= min_hits:
+                    out.append((b - a, self.names[int(sq[a])], strand, int(ps[a:b].min()), int(ps[a:b].max()) + self.k))
         out.sort(key=lambda x: (-x[0], x[1], x[3]))
         return out
 

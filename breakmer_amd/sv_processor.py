@@ -267,15 +267,16 @@ class params(object):                                               # utils.py:5
             self._fasta = refseq.FastaIndex(fn)
         return self._fasta
 
-    def genome_index(self):
-        """sampled k-mer index of the whole `reference_fasta` (refseq.GenomeIndex), built on first use: the genome-wide part of
-        the realignment (N4) for contigs that neither the target window nor a discordant pair explains"""
+    def genome_index(self, device=None):
+        """sampled k-mer index of the whole `reference_fasta` (refseq.GenomeIndex), built on first use (or read from its cache file
+        next to the FASTA): the genome-wide part of the realignment (N4) for contigs that neither the target window nor a
+        discordant pair explains.  device: the GPU whose HBM holds the sorted codes for the look-ups (None: host numpy)"""
         if getattr(self, '_gindex', None) is None:
             fa = self.open_fasta()
             if fa is None:
                 return None
             self.logger.info('indexing %s for the genome-wide realignment of unexplained contigs' % self.opts.get('reference_fasta'))
-            self._gindex = refseq.GenomeIndex(fa)
+            self._gindex = refseq.GenomeIndex(fa, device=device)
         return self._gindex
 
     def open_bam(self, fn):                                          # one parse per alignment file, shared by all targets
@@ -810,7 +811,8 @@ class runner(object):                                               # sv_process
         """partner windows for the contig segments of target t that no record covers (>= trl_minseg_len bases): every k-mer of
         such a segment is looked up in the genome index; loci with >= 2 index hits in one diagonal band, outside the target's
         own window, become windows of +-1,500 bases (at most 4, best supported first)"""
-        gi = self.params.genome_index()
+        # (the look-ups run on the device the engine runs on when it is the HIP engine; the test engines use the host path)
+        gi = self.params.genome_index(device=getattr(eng, 'device', None) if hasattr(eng, 'h') else None)
         if gi is None or not hasattr(eng, 'hits'):
             return []
         minseg = max(20, self.params.get_min_segment_length('trl'))

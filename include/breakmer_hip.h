@@ -212,6 +212,17 @@ int bk_call(bk_handle *h);                                      /* after bk_run:
 int bk_get_calls(bk_handle *h, char *buf, size_t cap, size_t *needed);   /* "<region>\t<contig>\t<13 fields>\n" ... */
 int bk_call_text(const char *text, char *out, size_t cap, int *target_hit);   /* one fully described contig; no GPU needed */
 
+/* ---- genome-wide seed lookup (the step behind the reference's whole-genome fallback: a contig its target window does not explain
+ * is handed to a gfServer over the whole genome, sv_processor.py:829-831, utils.py:620-657; BLAT finds its candidate loci through an
+ * index of the genome's tiles).  Here: the caller samples the genome's k-mers (k <= 16, 2 bit/base in a uint32, every `step`-th
+ * position) and sorts them once (breakmer_amd/refseq.GenomeIndex); the sorted codes live in HBM (1.5 GB for a 3 Gb genome at
+ * step 8) and every query k-mer is looked up by binary search on the device: lo[i], hi[i] = the range of index entries equal to
+ * queries[i] (lo == hi: absent).  The caller turns ranges into loci (>= 2 hits in one diagonal band = BLAT's -minMatch=2). */
+typedef struct bk_index bk_index;
+int bk_index_create(int device_id, const uint32_t *sorted_codes, uint64_t n, bk_index **out);
+int bk_index_probe(bk_index *ix, const uint32_t *queries, uint64_t n_queries, uint32_t *lo, uint32_t *hi, float *kernel_ms);
+int bk_index_destroy(bk_index *ix);
+
 /* The 2-bit packing bk_submit_regions applies to every sequence (16 bases per word, first base in the most significant
  * bits; replaces the FASTA/FASTQ text the reference writes for Jellyfish and the assembler, utils.py:355-381), on one
  * sequence: `words` receives n_words words (zero padded), an 'N' is packed as A and its position appended to n_pos

@@ -1144,3 +1144,43 @@ def test_packed_submit_gpu(hb):
     assert len(nl) > 2
     with pytest.raises(hb.BreakmerHipError):
         hb.Engine(kmer_size=31).submit([hb.RegionInput(None, regions[2].window, packed=(w, l, nl[::-1].copy()))])        # not ascending
+
+
+def test_genome_index_device_probe_gpu(hb, tmp_path):
+    """N4: the genome-wide seed look-up on the device (bk_index_probe_kernel: sorted sampled 16-mers in HBM, binary search per query
+    k-mer) returns the ranges numpy.searchsorted returns on the host, and refseq.GenomeIndex.find gives the same loci through
+    either -- on a 4 Mb genome with an assembly gap and a repeated segment, for planted segments of both strands, absent k-mers
+    and k-mers beyond the occurrence cap."""
+    import numpy as np
+    from breakmer_amd import refseq
+    rng = np.random.default_rng(3)
+    chroms = []
+    for c in range(4):
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 1000000, dtype=np.uint8)].copy()
+        s[300000:300400] = ord("N")
+        s[500000:500300] = s[100000:100300]                       # a duplicated segment: two loci
+        chroms.append(s.tobytes().decode())
+    fn = tmp_path / "g.fa"
+    fn.write_text("".join(">chr%d\n%s\n" % (i + 1, "\n".join(s[j:j + 80] for j in range(0, len(s), 80))) for i, s in enumerate(chroms)))
+    fa = refseq.FastaIndex(str(fn))
+    host = refseq.GenomeIndex(fa, cache=False)
+    dev = refseq.GenomeIndex(fa, cache=True, device=0)
+    assert (tmp_path / "g.fa.bkidx.k16s8.npz").is_file()
+    again = refseq.GenomeIndex(fa, cache=True, device=0)          # from the cache file
+    assert (again.code == host.code).all() and (again.pos == host.pos).all() and (again.seqno == host.seqno).all()
+    q = np.concatenate([host.code[::1000], np.array([0, 0xFFFFFFFF, 12345], dtype=np.uint32), host.code[:5] + np.uint32(1)])
+    di = hb.DeviceIndex(host.code)
+    lo, hi = di.probe(q)
+    assert (lo == np.searchsorted(host.code, q, side="left")).all() and (hi == np.searchsorted(host.code, q, side="right")).all()
+    nloc = 0
+    for i in range(60):
+        c = int(rng.integers(0, 4)); p = int(rng.integers(1000, 990000)) if i % 5 else 100000 + 20 * i
+        seg = chroms[c][p:p + 90]
+        if "N" in seg:
+            continue
+        seg = seg if i % 2 == 0 else refseq.revcomp(seg)
+        a, b = host.find(seg), dev.find(seg)
+        assert a == b, (i, a[:2], b[:2])
+        nloc += len(a)
+        assert a and any(x[1] == "chr%d" % (c + 1) and x[3] >= p and x[4] <= p + 90 for x in a), (i, a[:3])
+    assert nloc > 60 and dev.probe_ms > 0
