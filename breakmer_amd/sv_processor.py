@@ -811,18 +811,17 @@ class runner(object):                                               # sv_process
         """partner windows for the contig segments of target t that no record covers (>= trl_minseg_len bases): every k-mer of
         such a segment is looked up in the genome index; loci with >= 2 index hits in one diagonal band, outside the target's
         own window, become windows of +-1,500 bases (at most 4, best supported first)"""
-        # (the look-ups run on the device the engine runs on when it is the HIP engine; the test engines use the host path)
-        gi = self.params.genome_index(device=getattr(eng, 'device', None) if hasattr(eng, 'h') else None)
-        if gi is None or not hasattr(eng, 'hits'):
+        if not hasattr(eng, 'hits') or self.params.open_fasta() is None:
             return []
         minseg = max(20, self.params.get_min_segment_length('trl'))
-        loci = {}
+        # the contig segments no record covers -- only if there is one is the genome index needed at all (building it, or reading
+        # its cache file, is the expensive part: most targets without a call have contigs their window explains completely)
+        segs = []
         for ci, c in enumerate(eng.contigs(t.region_index)):
             seq = c["seq"]
             cov = bytearray(len(seq))
             for h in eng.hits(t.region_index, ci):
-                for x in range(h["q_start"], h["q_end"]):
-                    cov[x] = 1
+                cov[h["q_start"]:h["q_end"]] = b"\x01" * max(0, h["q_end"] - h["q_start"])
             a = 0
             while a < len(seq):
                 if cov[a]:
@@ -832,14 +831,23 @@ class runner(object):                                               # sv_process
                 while b < len(seq) and not cov[b]:
                     b += 1
                 if b - a >= minseg:
-                    for nh, name, _strand, s0, e0 in gi.find(seq[a:b])[:4]:
-                        c_ = name.replace("chr", "")
-                        if c_ == str(t.chrom).replace("chr", "") and e0 >= t.start - 200 and s0 <= t.end + 200:
-                            continue
-                        key = (c_, s0 // 1000)
-                        if key not in loci or loci[key][0] < nh:
-                            loci[key] = (nh, c_, s0, e0)
+                    segs.append(seq[a:b])
                 a = b
+        if not segs:
+            return []
+        # (the look-ups run on the device the engine runs on when it is the HIP engine; the test engines use the host path)
+        gi = self.params.genome_index(device=getattr(eng, 'device', None) if hasattr(eng, 'h') else None)
+        if gi is None:
+            return []
+        loci = {}
+        for sg in segs:
+            for nh, name, _strand, s0, e0 in gi.find(sg)[:4]:
+                c_ = name.replace("chr", "")
+                if c_ == str(t.chrom).replace("chr", "") and e0 >= t.start - 200 and s0 <= t.end + 200:
+                    continue
+                key = (c_, s0 // 1000)
+                if key not in loci or loci[key][0] < nh:
+                    loci[key] = (nh, c_, s0, e0)
         fa = self.params.open_fasta()
         out = []
         for nh, c_, s0, e0 in sorted(loci.values(), key=lambda x: (-x[0], x[1], x[2]))[:4]:
