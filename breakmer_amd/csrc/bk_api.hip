@@ -712,6 +712,10 @@ static int sync_impl(bk_handle *h)
                         h->n_repair_passes, redo.size(), unsplit.size(), ns_, np_, nc_, nx_, ms[1], ms[2], ms[3]);
                 for (int r = 0; r < h->n_regions && r < 4; r++) { const BkRegionWork &w = h->h_work[r]; if (!w.split) continue;
                     fprintf(stderr, "   region %d  U %u M %u M2 %u  open conflicts %u; unit 0: prefix %u us, labelling %u us, seed list %u us; unit us/iterations:", r, w.U, w.M, w.M2, w.n_conf, w.dbg_us[0], w.dbg_us[1], w.dbg_us[2]); for (int g = 0; g < BK_SPLIT_G; g++) fprintf(stderr, " %u/%u", w.unit_us[g], w.unit_iters[g]); fprintf(stderr, "\n"); }
+                fprintf(stderr, "   all split regions, prefix+labelling+slowest unit (ms):");
+                for (int r = 0; r < h->n_regions; r++) { const BkRegionWork &w = h->h_work[r]; if (!w.split) continue; uint32_t mx = 0; for (int g = 0; g < BK_SPLIT_G; g++) mx = std::max(mx, w.unit_us[g]);
+                    fprintf(stderr, " %.1f+%.1f+%.1f", w.dbg_us[0] / 1000.0, (w.dbg_us[1] + w.dbg_us[2]) / 1000.0, mx / 1000.0); }
+                fprintf(stderr, "\n");
             }
             if (!redo.empty() || !unsplit.empty()) {
                 // split regions (bk_comp.hip.h): components that met across units are merged and run again (a few per cent of the
