@@ -476,7 +476,8 @@ static void fill_params(bk_handle *h)
     p.arena = (uint8_t *)h->d_arena.p; p.arena_top = (unsigned long long *)h->d_tops.p; p.arena_cap = h->arena_cap;
     p.out = (uint8_t *)h->d_out.p; p.out_top = (unsigned long long *)h->d_tops.p + 1; p.out_cap = h->out_cap;
     p.n_clist = (unsigned long long *)h->d_tops.p + 2; p.asm_head = (unsigned long long *)h->d_tops.p + 3; p.sw_head = (unsigned long long *)h->d_tops.p + 4; p.n_queue = (unsigned long long *)h->d_tops.p + 5;
-    p.order = (uint32_t *)h->d_order.p; p.clist = (unsigned long long *)h->d_clist.p; p.clist_cap = h->d_clist.bytes / 8;
+    p.order = (uint32_t *)h->d_order.p; p.clist = (unsigned long long *)h->d_clist.p; p.clist_cap = h->d_clist.bytes / 16;      // first half: the contig list; second half: the realigner's long-contig list
+    p.sw_long = p.clist + p.clist_cap; p.n_sw_long = (unsigned long long *)h->d_tops.p + 6; p.sw_long_head = (unsigned long long *)h->d_tops.p + 7;
     p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->eff_max_read;
     p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions; p.flags = h->cfg.reserved[0];
     p.rmap = nullptr;
@@ -489,12 +490,43 @@ static size_t asm_lds_bytes(const bk_handle *h, int threads, int max_cand, int m
     o += (size_t)max_cand * 8 + waves * 2 * (h->eff_max_read + 2) * 4 + (size_t)max_cand * 4 + (size_t)2 * max_contig + slots * (h->eff_max_read + 16);
     return (o + 15) / 16 * 16;
 }
-// LDS of the realign kernel for a contig cap and a target staging capacity (bases)
-static size_t sw_lds_bytes(int max_contig, uint32_t tw_cap)
+// The realign stage (bk_sw.hip.h), two tiers: SHORT -- contigs up to BK_SW_SHORT bases on small workgroups with a small LDS block
+// (many per CU) --, LONG -- whatever is longer, on 512-thread workgroups with the block sized for max_contig (its list is
+// filled by the SHORT tier; idle as a rule).  One tier of 512 threads when the contig cap is short anyway.
+#define BK_SW_SHORT 1024
+static BkSwTier sw_tier(const bk_handle *h, int contig_cap, int max_contig_for_window, bool small)
 {
-    const size_t mh = (size_t)bk_sw_max_hits(max_contig);
-    return ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)max_contig + 15) / 16) * 16 + 4 * (4 * ((size_t)max_contig / 16 + 2) + 2 * (tw_cap / 16 + 8))      // staged target words + their N mask
-           + mh * sizeof(BkHit) + 2 * (2 * mh + 4) * sizeof(int);                                                                                                     // step-1 hits + interval stack
+    BkSwTier T; T.contig_cap = contig_cap; T.mode = 0;
+    T.sec_lds = small ? 64 : 256; T.n_flags = small ? 256 : 1024;
+    // target staging buffer (packed, 4 bases per byte): the whole window when it fits, else chunks of diagonals
+    uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)contig_cap + 16, small ? 16384u : std::max<uint32_t>(131072, 4 * (uint32_t)contig_cap));
+    while (bk_sw_layout(contig_cap, tw_cap, T.sec_lds, T.n_flags).total > BK_LDS_MAX && tw_cap > 2 * (uint32_t)contig_cap + 4096) tw_cap -= 4096;      // long contig caps: shorter chunks of a long window
+    T.tw_cap = tw_cap; (void)max_contig_for_window;
+    return T;
+}
+static int launch_sw(bk_handle *h, int max_contig, bool note_occupancy)
+{
+    static const int env_t = getenv("BK_SW_T") ? atoi(getenv("BK_SW_T")) : 0;              // diagnostic: workgroup size of the SHORT tier (64 .. 512); 1 = one tier as before round 4
+    const bool two = max_contig > BK_SW_SHORT && env_t != 1;
+    const int threads = !two ? BK_ST_TMAX : (env_t >= 64 && env_t <= 512 ? env_t : 128);
+    BkSwTier T = sw_tier(h, two ? BK_SW_SHORT : max_contig, max_contig, two);
+    HIPCHK(h, hipMemsetAsync((unsigned long long *)h->d_tops.p + 6, 0, 16, h->stream));
+    size_t lds = bk_sw_layout(T.contig_cap, T.tw_cap, T.sec_lds, T.n_flags).total;
+    HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BK_LDS_MAX));
+    // one workgroup per contig, pulled from the list the assembler appended to; the number of contigs is only known
+    // on the device, so a resident-sized grid of persistent workgroups is launched (idle ones exit at once)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bk_sw_kernel, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (note_occupancy) h->sw_wg_per_cu = per_cu;
+    hipLaunchKernelGGL(bk_sw_kernel, dim3(per_cu * h->n_cu), dim3(threads), lds, h->stream, h->params, T);
+    HIPCHK(h, hipGetLastError());
+    if (two) {
+        BkSwTier TL = sw_tier(h, max_contig, max_contig, false); TL.mode = 1;
+        lds = bk_sw_layout(TL.contig_cap, TL.tw_cap, TL.sec_lds, TL.n_flags).total;
+        hipLaunchKernelGGL(bk_sw_kernel, dim3(h->n_cu), dim3(BK_ST_TMAX), lds, h->stream, h->params, TL);
+        HIPCHK(h, hipGetLastError());
+    }
+    return BK_OK;
 }
 // The caps of the re-run of regions that overflowed one (bk_get_region_status): 4x the configured ones as far as one 512-thread
 // workgroup's LDS (the whole CU's) holds them.  false: nothing larger fits (very long reads), the regions fail as they are.
@@ -512,7 +544,7 @@ static bool escalated_caps(const bk_handle *h, int &max_cand, int &max_contig)
 static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subset = nullptr, bool escalate = true)
 {
     // every contig record takes >= 256 B of the result arena, so out_cap / 256 list entries can never overflow
-    HIPCHK(h, h->d_clist.ensure(std::max<uint64_t>(h->out_cap / 256, 1024) * 8));
+    HIPCHK(h, h->d_clist.ensure(std::max<uint64_t>(h->out_cap / 256, 1024) * 16));
     uint32_t npad = 1; while ((int)npad < h->n_regions) npad <<= 1;
     HIPCHK(h, h->d_order.ensure((size_t)h->n_regions * 4 * BK_SPLIT_G)); HIPCHK(h, h->d_skeys.ensure((size_t)npad * 8));      // queue: up to BK_SPLIT_G units per region
     fill_params(h);
@@ -525,7 +557,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         HIPCHK(h, hipMemcpy(h->d_order.p, subset->data(), subset->size() * 4, hipMemcpyHostToDevice));      // the assembler's queue: these regions, in index order
         unsigned long long tops[6];
         HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
-        tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 8); tops[5] = (unsigned long long)n_launch;      // unit queue from its start; the realigner goes on behind the contigs it has seen
+        tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 16); tops[5] = (unsigned long long)n_launch;      // unit queue from its start; the realigner goes on behind the contigs it has seen
         HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
         h->params.rmap = (const uint32_t *)h->d_rmap.p; h->params.n_regions = n_launch; h->params.max_cand = max_cand; h->params.max_contig = max_contig;
     } else {
@@ -587,20 +619,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         }
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    if (mask & BK_STAGE_REALIGN) {
-        // target staging buffer (packed, 4 bases per byte): the whole window when it fits, else chunks of diagonals
-        uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)max_contig + 16, std::max<uint32_t>(131072, 4 * (uint32_t)max_contig));      // words + N mask: 2 x 32 KB
-        while (sw_lds_bytes(max_contig, tw_cap) > BK_LDS_MAX && tw_cap > 2 * (uint32_t)max_contig + 4096) tw_cap -= 4096;      // long contig caps: shorter chunks of a long window
-        const size_t lds = sw_lds_bytes(max_contig, tw_cap);
-        HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // one workgroup per contig, pulled from the list the assembler appended to; the number of contigs is only known
-        // on the device, so a resident-sized grid of persistent workgroups is launched (idle ones exit at once)
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bk_sw_kernel, BK_ST_T, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (!subset) h->sw_wg_per_cu = per_cu;
-        hipLaunchKernelGGL(bk_sw_kernel, dim3(per_cu * h->n_cu), dim3(BK_ST_T), lds, h->stream, h->params, tw_cap);
-        HIPCHK(h, hipGetLastError());
-    }
+    if (mask & BK_STAGE_REALIGN) { const int rc = launch_sw(h, max_contig, !subset); if (rc != BK_OK) return rc; }
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     return BK_OK;
 }
@@ -619,7 +638,7 @@ static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t
     HIPCHK(h, hipMemcpy(h->d_order.p, q.data(), q.size() * 4, hipMemcpyHostToDevice));
     unsigned long long tops[6];
     HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
-    tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 8); tops[5] = (unsigned long long)q.size();
+    tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 16); tops[5] = (unsigned long long)q.size();
     HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
@@ -639,14 +658,7 @@ static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t
     HIPCHK(h, hipGetLastError());
     if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk split]   link done\n"); }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    if (mask & BK_STAGE_REALIGN) {
-        const int max_contig = h->cfg.max_contig_len;
-        uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)max_contig + 16, std::max<uint32_t>(131072, 4 * (uint32_t)max_contig));
-        while (sw_lds_bytes(max_contig, tw_cap) > BK_LDS_MAX && tw_cap > 2 * (uint32_t)max_contig + 4096) tw_cap -= 4096;
-        const size_t slds = sw_lds_bytes(max_contig, tw_cap);
-        hipLaunchKernelGGL(bk_sw_kernel, dim3(std::max(1, h->sw_wg_per_cu) * h->n_cu), dim3(BK_ST_T), slds, h->stream, h->params, tw_cap);
-        HIPCHK(h, hipGetLastError());
-    }
+    if (mask & BK_STAGE_REALIGN) { const int rc = launch_sw(h, h->cfg.max_contig_len, false); if (rc != BK_OK) return rc; }
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     return BK_OK;
 }

@@ -24,7 +24,8 @@
 #pragma once
 #include "bk_common.h"
 
-#define BK_ST_T 512
+#define BK_ST_TMAX 512                 // largest workgroup (the LONG tier and batches of few contigs); the SHORT tier runs smaller ones
+#define BK_ST_T ((int)blockDim.x)
 #define BK_SW_MIN_SEG 20
 #define BK_SW_FLAGS 1024
 
@@ -38,9 +39,9 @@ __host__ __device__ inline int bk_sw_max_hits(int max_contig) { return max_conti
 struct BkSwShared {
     int nseg;
     int nhits;
-    int nsec; BkHit sec[BK_SEC_LDS];             // secondary alignments (step 5), in no particular order
-    int nflag; int flag_off[BK_SW_FLAGS]; int flag_ts[BK_SW_FLAGS];   // diagonals of the whole query on which H can reach min_score (found by the first pass): (offset, target << 1 | strand)
-    unsigned long long red[BK_ST_T / 64]; int red_run[BK_ST_T / 64];
+    int nsec;                                    // secondary alignments (step 5) collected in the LDS list `sec` (dynamic block), in no particular order
+    int nflag;                                   // diagonals of the whole query on which H can reach min_score (found by the first pass): flag_off / flag_ts (dynamic block): (offset, target << 1 | strand)
+    unsigned long long red[BK_ST_TMAX / 64]; int red_run[BK_ST_TMAX / 64];
     unsigned long long best_key; int best_run;
     unsigned long long cells;
     int L, umax;                 // lower bound on the pass maximum (an achieved score); block maximum of U
@@ -49,6 +50,30 @@ struct BkSwShared {
     int status;
     unsigned long long qidx; int skip;
 };
+
+// Two tiers (round 4).  SHORT: contigs of up to `contig_cap` bases on small workgroups with an LDS block sized for THAT (about
+// 12 KB instead of 40: a dozen contigs per CU in flight, and the block fits next to the assembler's workgroups of the other
+// batches in flight); a longer contig is appended to `sw_long` and taken by the LONG tier, a second launch of 512-thread
+// workgroups with the block sized for max_contig (idle when that list is empty, the rule).  Both run the same code.
+struct BkSwTier { uint32_t tw_cap; int contig_cap, sec_lds, n_flags, mode; };      // mode 0: the contig list, longer ones deferred; 1: the deferred ones
+struct BkSwLayout { uint32_t qf, qpk, tp, tnb, hits, seg, sec, foff, fts, total; int qpw, max_hits; };
+__host__ __device__ inline BkSwLayout bk_sw_layout(int contig_cap, uint32_t tw_cap, int sec_lds, int n_flags)
+{
+    BkSwLayout L;
+    L.qpw = contig_cap / 16 + 2; L.max_hits = bk_sw_max_hits(contig_cap);
+    uint32_t o = (uint32_t)((sizeof(BkSwShared) + 15) / 16) * 16;
+    L.qf = o; o += 2 * (uint32_t)contig_cap; o = (o + 15) / 16 * 16;            // contig, forward and reverse complement (codes)
+    L.qpk = o; o += 4 * 4 * (uint32_t)L.qpw;                                   // packed query interval + N masks, both strands
+    L.tp = o; o += 4 * (tw_cap / 16 + 8);                                      // staged target chunk, packed words
+    L.tnb = o; o += 4 * (tw_cap / 16 + 8);                                     // its N mask
+    L.hits = o; o += (uint32_t)L.max_hits * (uint32_t)sizeof(BkHit);           // step-1 hits
+    L.seg = o; o += 2 * (2 * (uint32_t)L.max_hits + 4) * 4;                    // stack of query intervals still to be aligned
+    o = (o + 15) / 16 * 16;
+    L.sec = o; o += (uint32_t)sec_lds * (uint32_t)sizeof(BkHit);               // secondary alignments collected in the LDS
+    L.foff = o; o += 4 * (uint32_t)n_flags; L.fts = o; o += 4 * (uint32_t)n_flags;
+    L.total = (o + 15) / 16 * 16;
+    return L;
+}
 
 __device__ inline unsigned long long bk_sw_key(int score, int tidx, int strand, int a, long long b)
 {   // larger key wins: score desc, target index asc, '+' first, smallest query end, smallest target end
@@ -68,24 +93,10 @@ __device__ inline uint32_t bk_sw_tn(const uint32_t *tn, int i0, int tpn, int sh)
 // matching positions on diagonal `off` (target b = query a + off) of a packed query interval (n bases, qp) against the
 // staged packed target words tp[0..tpn) = target words tpw0.. (16 bases per word, MSB first)
 // qn: N mask of the packed query (bit 2*(15-t) set where base t of the word is an N: an N matches nothing here)
+__device__ inline int bk_sw_diag_count_fwd(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off);
 __device__ inline int bk_sw_diag_matches(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off)
 {
-    const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
-    if (a1 <= a0) return 0;
-    int u = 0;
-    for (int wq = a0 >> 4; wq <= (a1 - 1) >> 4; wq++) {
-        const int aw = wq << 4, pb = aw + off;                      // target position of the word's first base (may be < 0)
-        const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
-        const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
-        const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
-        const uint32_t x = (qp[wq] ^ tb) | bk_sw_tn(tn, i0, tpn, sh);        // an N of the window matches nothing
-        const uint32_t eq = ~(x | (x >> 1) | qn[wq]) & 0x55555555u;
-        const int lo = max(a0 - aw, 0), hi = min(a1 - aw, 16);
-        uint32_t vm = 0xFFFFFFFFu >> (2 * lo);
-        if (hi < 16) vm &= ~(0xFFFFFFFFu >> (2 * hi));
-        u += __popc(eq & vm);
-    }
-    return u;
+    return bk_sw_diag_count_fwd(qp, qn, tp, tn, tpw0, tpn, n, m, off);
 }
 // walk one diagonal on the packed words: best positive run (strict '>': smallest query end among equal scores).  Inside
 // a run of matches the score rises strictly, so only the end of each run can become the new best: the loop advances
@@ -142,15 +153,20 @@ __device__ inline bool bk_sw_diag_maybe(const uint32_t *qp, const uint32_t *qn, 
     }
     return false;
 }
-// match count of a diagonal (as bk_sw_diag_matches) and, in the same pass over its words, the word-granular upper bound of
+// match count of a diagonal (as bk_sw_diag_matches) and -- SCAN -- in the same pass over its words, the word-granular upper bound of
 // bk_sw_diag_maybe: `maybe` = H can reach thresh somewhere on it.  Branch-free (the loads of the next words are not held up).
-__device__ inline int bk_sw_diag_scan(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off, int thresh, bool &maybe)
+// The sweeps of the realigner spend their time here (a contig of Q bases against a window of W: 2 (Q + W) diagonals of Q / 16 words
+// per pass), so the words BETWEEN a diagonal's first and last one take a short path: all 16 bases lie inside the diagonal, both
+// target words are staged (the staged range covers every diagonal of the chunk), the shift is the same for every word of the
+// diagonal ((16 wq + off) & 15 = off & 15), and the second target word of one step is the first of the next.
+template <bool SCAN>
+__device__ inline int bk_sw_diag_count(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off, int thresh, bool &maybe)
 {
     const int a0 = off < 0 ? -off : 0, a1 = min(n, m - off);
     maybe = false;
     if (a1 <= a0) return 0;
     int u = 0, hub = 0, top = 0;
-    for (int wq = a0 >> 4; wq <= (a1 - 1) >> 4; wq++) {
+    auto edge = [&](int wq) {
         const int aw = wq << 4, pb = aw + off;
         const int i0 = (pb >> 4) - tpw0, sh = 2 * (pb & 15);
         const uint32_t w0 = (unsigned)i0 < (unsigned)tpn ? tp[i0] : 0u, w1 = (unsigned)(i0 + 1) < (unsigned)tpn ? tp[i0 + 1] : 0u;
@@ -162,11 +178,38 @@ __device__ inline int bk_sw_diag_scan(const uint32_t *qp, const uint32_t *qn, co
         if (hi < 16) vm &= ~(0xFFFFFFFFu >> (2 * hi));
         const int mm = __popc(eq & vm);
         u += mm;
-        top = max(top, hub + mm);
-        hub = max(hub + 3 * mm - 2 * (hi - lo), mm);
+        if (SCAN) { top = max(top, hub + mm); hub = max(hub + 3 * mm - 2 * (hi - lo), mm); }
+    };
+    const int wlo = a0 >> 4, whi = (a1 - 1) >> 4;
+    if (tn) { for (int wq = wlo; wq <= whi; wq++) edge(wq); }               // a window that holds an N (rare): every word the general way
+    else {
+        edge(wlo);
+        if (whi - wlo >= 2) {
+            const int pb = ((wlo + 1) << 4) + off, sh = 2 * (pb & 15);
+            int i0 = (pb >> 4) - tpw0;
+            uint32_t w0 = tp[i0];
+            for (int wq = wlo + 1; wq < whi; wq++, i0++) {
+                const uint32_t w1 = tp[i0 + 1];                              // (sh == 0 at the end of the staged range: one of the buffer's 8 slack words, not used)
+                const uint32_t tb = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
+                const uint32_t x = qp[wq] ^ tb;
+                const int mm = __popc(~(x | (x >> 1) | qn[wq]) & 0x55555555u);
+                u += mm;
+                if (SCAN) { top = max(top, hub + mm); hub = max(hub + 3 * mm - 32, mm); }
+                w0 = w1;
+            }
+        }
+        if (whi > wlo) edge(whi);
     }
     maybe = top >= thresh;
     return u;
+}
+__device__ inline int bk_sw_diag_count_fwd(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off)
+{
+    bool mb; return bk_sw_diag_count<false>(qp, qn, tp, tn, tpw0, tpn, n, m, off, 0, mb);
+}
+__device__ inline int bk_sw_diag_scan(const uint32_t *qp, const uint32_t *qn, const uint32_t *tp, const uint32_t *tn, int tpw0, int tpn, int n, int m, int off, int thresh, bool &maybe)
+{
+    return bk_sw_diag_count<true>(qp, qn, tp, tn, tpw0, tpn, n, m, off, thresh, maybe);
 }
 // walk one diagonal over the whole query and report every positive excursion (reset to reset / end of the diagonal) whose
 // peak is >= thresh: emit(peak, query end of the first position of the peak, length of the segment from the excursion's start)
@@ -211,39 +254,50 @@ __device__ inline void bk_sw_pack_query(const uint8_t *qf, const uint8_t *qr, in
     }
 }
 
-extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, uint32_t tw_cap)
+extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p, BkSwTier T)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sl[];
     const int tid = threadIdx.x;
+    const uint32_t tw_cap = T.tw_cap;
+    const BkSwLayout LY = bk_sw_layout(T.contig_cap, T.tw_cap, T.sec_lds, T.n_flags);
     BkSwShared *S = (BkSwShared *)sl;
-    uint8_t *qf = sl + ((sizeof(BkSwShared) + 15) / 16) * 16;          // contig forward (codes)
-    uint8_t *qr = qf + p.max_contig;                                   // contig reverse complement
-    uint32_t *qpk = (uint32_t *)(sl + ((((sizeof(BkSwShared) + 15) / 16) * 16 + 2 * (size_t)p.max_contig + 15) / 16) * 16);   // packed query interval, both strands
-    const int qpw = p.max_contig / 16 + 2;
+    uint8_t *qf = sl + LY.qf;                                          // contig forward (codes)
+    uint8_t *qr = qf + T.contig_cap;                                   // contig reverse complement
+    uint32_t *qpk = (uint32_t *)(sl + LY.qpk);                         // packed query interval, both strands
+    const int qpw = LY.qpw;
     uint32_t *qnm = qpk + 2 * qpw;                                     // N masks of the packed query interval, both strands
-    uint32_t *tp = qnm + 2 * qpw;                                      // staged target chunk, packed words (kept across passes and contigs)
-    uint32_t *tnb = tp + (tw_cap / 16 + 8);                            // its N mask, filled (and used) only for windows that hold an N
-    const int max_hits = bk_sw_max_hits(p.max_contig);
-    BkHit *hits = (BkHit *)(tnb + (tw_cap / 16 + 8));                  // step-1 hits of the contig (cannot overflow: see BkSwShared)
-    int *seg = (int *)(hits + max_hits);                               // stack of query intervals still to be aligned: 2 * (2 * max_hits + 4) ints
+    uint32_t *tp = (uint32_t *)(sl + LY.tp);                           // staged target chunk, packed words (kept across passes and contigs)
+    uint32_t *tnb = (uint32_t *)(sl + LY.tnb);                         // its N mask, filled (and used) only for windows that hold an N
+    const int max_hits = LY.max_hits;
+    BkHit *hits = (BkHit *)(sl + LY.hits);                             // step-1 hits of the contig (cannot overflow: see BkSwShared)
+    int *seg = (int *)(sl + LY.seg);                                   // stack of query intervals still to be aligned: 2 * (2 * max_hits + 4) ints
+    BkHit *sec = (BkHit *)(sl + LY.sec);
+    int *flag_off = (int *)(sl + LY.foff), *flag_ts = (int *)(sl + LY.fts);
     if (tid == 0) { S->staged_ti = -1; S->staged_t0 = 0; S->staged_t1 = 0; S->staged_region = -1; }
-    const unsigned long long n_list = min(*p.n_clist, (unsigned long long)p.clist_cap);
+    const unsigned long long n_list = T.mode == 0 ? min(*p.n_clist, (unsigned long long)p.clist_cap) : min(*p.n_sw_long, (unsigned long long)p.clist_cap);
+    const unsigned long long *list = T.mode == 0 ? p.clist : p.sw_long;
     for (;;) {
         __syncthreads();
         if (tid == 0) {
-            const unsigned long long qi = atomicAdd(p.sw_head, 1ull);
+            const unsigned long long qi = atomicAdd(T.mode == 0 ? p.sw_head : p.sw_long_head, 1ull);
             S->qidx = qi; S->cells = 0; S->status = 0; S->skip = 0;
             if (qi < n_list) {                                          // one reader of the (concurrently written) region status
-                const int rr = (int)(p.clist[qi] >> 40);
+                const unsigned long long e0 = list[qi];
+                const int rr = (int)(e0 >> 40);
                 const int rst = p.work[rr].status;
                 S->skip = rst != BK_ST_OK && rst != BK_ST_REDO;          // (a split region that awaits a repair pass: most of its contigs stay, and this launch is the one that sees them)
-                if (S->staged_region != rr) { S->staged_ti = -1; S->staged_region = rr; }
+                if (!S->skip && T.mode == 0 && ((const BkContigRec *)(p.out + (e0 & ((1ull << 40) - 1ull))))->seq_len > T.contig_cap) {
+                    const unsigned long long li = atomicAdd(p.n_sw_long, 1ull);        // too long for this tier's LDS block: the LONG tier takes it
+                    if (li < p.clist_cap) p.sw_long[li] = e0;
+                    S->skip = 1;
+                }
+                if (!S->skip && S->staged_region != rr) { S->staged_ti = -1; S->staged_region = rr; }
             }
         }
         __syncthreads();
         if (S->qidx >= n_list) break;
         if (S->skip) continue;
-        const unsigned long long ent = p.clist[S->qidx];
+        const unsigned long long ent = list[S->qidx];
         const int r = (int)(ent >> 40);
         const unsigned long long roff = ent & ((1ull << 40) - 1ull);
         BkRegionWork *wk = &p.work[r];
@@ -295,7 +349,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                         int u;
                         if (first) {
                             bool maybe; u = bk_sw_diag_scan(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off, p.sw_min_score, maybe);
-                            if (maybe) { const int fi = atomicAdd(&S->nflag, 1); if (fi < BK_SW_FLAGS) { S->flag_off[fi] = off; S->flag_ts[fi] = (ti << 1) | st; } }
+                            if (maybe) { const int fi = atomicAdd(&S->nflag, 1); if (fi < T.n_flags) { flag_off[fi] = off; flag_ts[fi] = (ti << 1) | st; } }
                         } else u = bk_sw_diag_matches(qpk + st * qpw, qnm + st * qpw, tp, tnp, tpw0, tpn, n, m, off);
                         if (u > myu) { myu3 = myu2; myu2 = myu; myD2 = myD; myu = u; myD = D; }
                         else if (u > myu2) { myu3 = myu2; myu2 = u; myD2 = D; }
@@ -340,7 +394,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
             if ((tid & 63) == 0) { S->red[tid >> 6] = bkey; S->red_run[tid >> 6] = brun; }
             __syncthreads();
             if (tid == 0) {
-                for (int w = 0; w < BK_ST_T / 64; w++) if (S->red[w] > S->best_key) { S->best_key = S->red[w]; S->best_run = S->red_run[w]; }
+                for (int w = 0; w < (BK_ST_T + 63) / 64; w++) if (S->red[w] > S->best_key) { S->best_key = S->red[w]; S->best_run = S->red_run[w]; }
                 const unsigned long long key = S->best_key; const int score = (int)(key >> 49);
                 if (score >= p.sw_min_score) {
                     const int tidx = 15 - (int)((key >> 45) & 15), st = 1 - (int)((key >> 44) & 1), a1 = 0x7FFF - (int)((key >> 29) & 0x7FFF), b1 = (int)(0x1FFFFFFFll - (long long)(key & 0x1FFFFFFFull)), run = S->best_run;
@@ -385,11 +439,11 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                         __syncthreads();
                     }
                     const int nd = o1 - o0;
-                    const int nfl = S->nflag, nwork = nfl <= BK_SW_FLAGS ? nfl : 2 * nd;      // the diagonals the first pass flagged; all of them if that list overflowed
+                    const int nfl = S->nflag, nwork = nfl <= T.n_flags ? nfl : 2 * nd;      // the diagonals the first pass flagged; all of them if that list overflowed
                     for (int W = tid; W < nwork; W += BK_ST_T) {
                         int st, off;
-                        if (nfl <= BK_SW_FLAGS) {
-                            const int ts = S->flag_ts[W]; off = S->flag_off[W]; st = ts & 1;
+                        if (nfl <= T.n_flags) {
+                            const int ts = flag_ts[W]; off = flag_off[W]; st = ts & 1;
                             if ((ts >> 1) != ti || off < o0 || off >= o1) continue;
                         } else {
                             st = W >= nd; off = o0 + (st ? W - nd : W);
@@ -410,11 +464,11 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                 __syncthreads();
             }
             };
-            sweep(S->sec, BK_SEC_LDS, true);
+            sweep(sec, T.sec_lds, true);
             __syncthreads();
             const int total = S->nsec;                                       // every thread reads it before it is reset
             __syncthreads();
-            if (total > BK_SEC_LDS) {
+            if (total > T.sec_lds) {
                 // more than the LDS list holds: room for all of them (behind the step-1 hits) in the result arena, same sweep again
                 if (tid == 0) {
                     const uint64_t need = bk_align_up((uint64_t)(nh1 + total) * sizeof(BkHit), 256);
@@ -441,7 +495,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_T) bk_sw_kernel(BkParams p, u
                 uint64_t need = bk_align_up((uint64_t)(nh + ns) * sizeof(BkHit), 256);
                 uint64_t off = atomicAdd(p.out_top, (unsigned long long)need);
                 if (off + need > p.out_cap) { S->status = BK_ST_OUT; rec->n_hits = 0; rec->n_sec = 0; }
-                else { BkHit *o = (BkHit *)(p.out + off); for (int i = 0; i < nh; i++) o[i] = hits[i]; for (int i = 0; i < ns; i++) o[nh + i] = S->sec[i]; rec->hits_off = off; }
+                else { BkHit *o = (BkHit *)(p.out + off); for (int i = 0; i < nh; i++) o[i] = hits[i]; for (int i = 0; i < ns; i++) o[nh + i] = sec[i]; rec->hits_off = off; }
             }
             atomicAdd((unsigned long long *)&wk->sw_cells, S->cells);
             if (S->status) wk->status = S->status;
