@@ -205,7 +205,7 @@ def time_runner(synth, regions, kmer, cycles=1):
         return {"analysis_name": tag, "targets_bed_file": os.path.join(d, tag + ".bed"), "gene_annotation_file": os.path.join(d, tag + ".txt"),
                 "kmer_size": str(kmer), "keep_repeat_regions": True, "batch_regions": 256}
     if cycles > 1:                                      # untimed: creates the handles the process keeps between runs
-        sp.runner(config("warmup", min(768, len(bed))), region_data=data).run()
+        sp.runner(config("warmup", min(1536, len(bed))), region_data=data).run()
     cfg = config("bench", len(bed))
     t0 = time.perf_counter()
     rows = sp.runner(cfg, region_data=data).run()
@@ -213,7 +213,7 @@ def time_runner(synth, regions, kmer, cycles=1):
     return {"value": round(len(data) / dt, 1), "unit": "regions/s", "regions": len(data), "rows": len(rows), "seconds": round(dt, 3),
             "batches": (len(data) + 255) // 256,
             "note": "runner.run() wall time: submit of 2-bit packed reads (BK_SUBMIT_PACKED: row copies + H2D) + GPU stages + native call tail + per-target Python objects (no output files), "
-                    "after one untimed warm-up run of 3 batches (the process keeps its handles between runs); 2 x 256 distinct regions cycled under 16 sets of target names; "
+                    "after one untimed warm-up run of 6 batches (the process keeps its handles between runs); 2 x 256 distinct regions cycled under 16 sets of target names; "
                     "the timed `value` above excludes submit (inputs resident, SURVEY 8d)"}
 
 

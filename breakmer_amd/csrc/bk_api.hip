@@ -100,6 +100,7 @@ struct bk_handle {
     DevBuf d_rmap;                                   // their indices (k-mer kernels of the re-run)
     BkParams params{};
     bkcall::Context call_ctx; bool have_ctx = false, have_tables = false; std::string calls_blob;
+    bool calls_valid = false;        // calls_blob holds the calls of the last run under the current context (bk_call_async made them already)
     // BK_SUBMIT_ASYNC: the submit runs on this thread; every later call on the handle joins it first (and reports its error)
     std::thread worker; bool has_worker = false; int worker_rc = 0; std::vector<bk_region> worker_regions;
 };
@@ -107,6 +108,7 @@ struct bk_handle {
 static int join_pending(bk_handle *h)
 {
     if (!h || !h->has_worker) return 0;
+    if (h->worker.get_id() == std::this_thread::get_id()) return 0;      // the worker itself (bk_call_async: its sync / fetch are entry points too)
     h->worker.join(); h->has_worker = false;
     return h->worker_rc;
 }
@@ -260,7 +262,7 @@ extern "C" int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int3
     if (!h || !regions || n_regions <= 0) return fail(h, BK_E_ARG, "bk_submit_regions: bad argument");
     // the bk_region array is copied; the sequences it points to stay with the caller until the next call on this handle returns
     h->worker_regions.assign(regions, regions + n_regions);
-    h->submitted = false; h->ran = false; h->fetched = false; h->synced = false;
+    h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->calls_valid = false;
     h->worker_rc = BK_OK; h->has_worker = true;
     h->worker = std::thread([h, n_regions, flags]() { h->worker_rc = submit_regions(h, h->worker_regions.data(), n_regions, flags & ~(uint32_t)BK_SUBMIT_ASYNC); });
     return BK_OK;
@@ -459,7 +461,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     { const auto t1 = std::chrono::steady_clock::now();
       h->submit_pack_ms = std::chrono::duration<double, std::milli>(t_h2d0 - t_pack0).count(); h->submit_h2d_ms = std::chrono::duration<double, std::milli>(t1 - t_h2d0).count(); }
     h->h_desc.swap(n_desc); h->h_part.swap(n_part); h->h_targets.swap(n_targets); h->max_win = n_max_win; h->alg_bytes = n_alg_bytes;
-    h->submitted = true; h->ran = false; h->fetched = false;
+    h->submitted = true; h->ran = false; h->fetched = false; h->calls_valid = false;
     return BK_OK;
 }
 
@@ -671,7 +673,7 @@ extern "C" int bk_run(bk_handle *h, uint32_t stage_mask)
     if ((stage_mask & BK_STAGE_ASSEMBLE) && !(stage_mask & BK_STAGE_KMER)) return fail(h, BK_E_ARG, "bk_run: BK_STAGE_ASSEMBLE needs BK_STAGE_KMER in the same run");
     if ((stage_mask & BK_STAGE_REALIGN) && !(stage_mask & BK_STAGE_ASSEMBLE)) return fail(h, BK_E_ARG, "bk_run: BK_STAGE_REALIGN needs BK_STAGE_ASSEMBLE in the same run");
     HIPCHK(h, hipSetDevice(h->dev));
-    h->ran_mask = stage_mask; h->fetched = false; h->synced = false;
+    h->ran_mask = stage_mask; h->fetched = false; h->synced = false; h->calls_valid = false;
     int rc = launch(h, stage_mask);
     if (rc == BK_OK) h->ran = true;
     return rc;
@@ -862,6 +864,16 @@ extern "C" int bk_get_contig_count(bk_handle *h, int32_t region, int32_t *n)
     if (!h || !n || region < 0 || region >= h->n_regions) return BK_E_ARG;
     int rc = sync_impl(h); if (rc != BK_OK) return rc;
     *n = (int32_t)h->h_work[region].n_contigs; return BK_OK;
+}
+
+// the contig counts of all regions of the batch in one call (a driver that only needs the counts: one call per batch, not per target)
+extern "C" int bk_get_contig_counts(bk_handle *h, int32_t *n, int32_t cap)
+{
+    BK_JOIN(h);
+    if (!h || !n || cap < h->n_regions) return BK_E_ARG;
+    int rc = sync_impl(h); if (rc != BK_OK) return rc;
+    for (int r = 0; r < h->n_regions; r++) n[r] = (int32_t)h->h_work[r].n_contigs;
+    return BK_OK;
 }
 
 extern "C" int bk_get_contig_info(bk_handle *h, int32_t region, int32_t contig, bk_contig_info *info)
@@ -1229,7 +1241,7 @@ extern "C" int bk_set_call_context(bk_handle *h, const char *text)
     BK_JOIN(h);
     if (!h || !text) return BK_E_ARG;
     bkcall::Tables prev = std::move(h->call_ctx.tables); const bool had = h->have_tables;
-    h->call_ctx = bkcall::Context(); h->have_ctx = false; h->have_tables = false; std::string err;
+    h->call_ctx = bkcall::Context(); h->have_ctx = false; h->have_tables = false; h->calls_valid = false; std::string err;
     if (!bkcall::parse_context(text, h->call_ctx, err)) return fail(h, BK_E_ARG, "bk_set_call_context: " + err);
     if (h->call_ctx.keep_tables) {
         if (!had) return fail(h, BK_E_STATE, "bk_set_call_context: keep_tables without an earlier context on this handle");
@@ -1243,11 +1255,8 @@ extern "C" int bk_set_call_context(bk_handle *h, const char *text)
 
 // replaces, per contig: contig.query_ref + check_target_blat + make_calls (sv_processor.py:823-866).  Result: text,
 // one line per called contig: "<region>\t<contig index>\t<13 tab-separated fields>".
-extern "C" int bk_call(bk_handle *h)
+static int call_impl(bk_handle *h)
 {
-    BK_JOIN(h);
-    if (!h) return BK_E_ARG;
-    if (!h->have_ctx) return fail(h, BK_E_STATE, "bk_call: bk_set_call_context first");
     int rc = fetch(h); if (rc != BK_OK) return rc;
     h->calls_blob.clear();
     const bkcall::Context &cx = h->call_ctx;
@@ -1297,6 +1306,28 @@ extern "C" int bk_call(bk_handle *h)
     else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
     for (auto &s2 : parts) h->calls_blob += s2;
     h->hold_snapshot = false;                       // the next getter refers to the newest run again
+    h->calls_valid = true;
+    return BK_OK;
+}
+extern "C" int bk_call(bk_handle *h)
+{
+    BK_JOIN(h);
+    if (!h) return BK_E_ARG;
+    if (!h->have_ctx) return fail(h, BK_E_STATE, "bk_call: bk_set_call_context first");
+    if (h->calls_valid && !h->hold_snapshot) return BK_OK;      // bk_call_async has made them
+    return call_impl(h);
+}
+// The same on the handle's own thread: returns at once; the wait for the run, the copy of its records and the call tail happen
+// while the caller prepares its next batch.  Every later call on the handle joins that thread first (and reports its error);
+// bk_call() / bk_get_calls() then find the calls made.
+extern "C" int bk_call_async(bk_handle *h)
+{
+    BK_JOIN(h);
+    if (!h) return BK_E_ARG;
+    if (!h->have_ctx) return fail(h, BK_E_STATE, "bk_call_async: bk_set_call_context first");
+    if (!h->ran) return fail(h, BK_E_STATE, "bk_call_async: nothing was run");
+    h->worker_rc = BK_OK; h->has_worker = true;
+    h->worker = std::thread([h]() { h->worker_rc = call_impl(h); });
     return BK_OK;
 }
 

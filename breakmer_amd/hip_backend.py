@@ -7,6 +7,7 @@ library or without a gfx950 GPU raises.  The library is built in-tree by
 from __future__ import annotations
 
 import ctypes as C
+import struct
 import os
 
 import numpy as np
@@ -68,7 +69,7 @@ def call_text(text):
 
 EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_submit_regions_ex", "bk_run", "bk_sync", "bk_fetch",
            "bk_last_kernel_ms", "bk_get_region_status", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
-           "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_get_calls",
+           "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_call_async", "bk_get_calls", "bk_get_contig_counts",
            "bk_nw_batch", "bk_pack_sequence", "bk_trim", "bk_get_hits_flat", "bk_index_create", "bk_index_probe", "bk_index_destroy"]
 
 _lib = None
@@ -101,6 +102,7 @@ def load_library():
     L.bk_get_kmer_count.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.bk_get_kmers.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
     L.bk_get_contig_count.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.bk_get_contig_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.bk_get_contig_info.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BkContigInfo)]
     L.bk_get_contig.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6
     L.bk_get_hits.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(BkPsl), C.c_int32]
@@ -114,6 +116,7 @@ def load_library():
     L.bk_trim.argtypes = [C.c_void_p, C.c_uint64]
     L.bk_set_call_context.argtypes = [C.c_void_p, C.c_char_p]
     L.bk_call.argtypes = [C.c_void_p]
+    L.bk_call_async.argtypes = [C.c_void_p]
     L.bk_get_calls.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.bk_nw_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
@@ -319,6 +322,21 @@ class Engine(object):
         self.n_regions = len(regions)
         self.batch_serial += 1                               # lazily read results (sv_assembly.LazyContigs) belong to one batch
 
+    def submit_packed(self, items, wait=False):
+        """a batch of (PackedReads, window bytes, indel_only uint8 array or None) -- see region_array_packed; otherwise like
+        submit(..., wait) of RegionInput(packed=...) objects"""
+        arr, wbuf = region_array_packed(items)
+        self._chk(self.L.bk_submit_regions_ex(self.h, arr, len(items), 4 | (0 if wait else 2)), "bk_submit_regions")
+        self._inputs = None if wait else (arr, wbuf, items)
+        self.n_regions = len(items)
+        self.batch_serial += 1
+
+    def contig_counts(self):
+        """the number of contigs of every region of the batch (one library call)"""
+        n = np.zeros(max(self.n_regions, 1), dtype=np.int32)
+        self._chk(self.L.bk_get_contig_counts(self.h, n.ctypes.data, len(n)), "bk_get_contig_counts")
+        return n[:self.n_regions].tolist()
+
     def run(self, stages=BK_STAGE_KMER | BK_STAGE_ASSEMBLE, sync=True):
         self._chk(self.L.bk_run(self.h, stages), "bk_run")
         if sync:
@@ -398,6 +416,10 @@ class Engine(object):
 
     def set_call_context(self, text):
         self._chk(self.L.bk_set_call_context(self.h, text.encode()), "bk_set_call_context")
+
+    def call_async(self):
+        """start the wait for the run + the native SV-call tail on the library's thread; call() / call_blob() pick the result up"""
+        self._chk(self.L.bk_call_async(self.h), "bk_call_async")
 
     def call_blob(self):
         """Native SV-call tail over every contig of the batch -> the serialised records (bytes; one line per call:
@@ -484,11 +506,11 @@ class Engine(object):
 
 # ---- handles kept between driver runs of one process ---------------------------------------------------------------------
 # Creating and destroying a handle costs ~35 ms (stream, pinned staging, device buffers sized by the first batch); a process
-# that runs the driver repeatedly (one sample after the other) keeps up to three per (device, k, rc_thresh) -- of ONE such
+# that runs the driver repeatedly (one sample after the other) keeps up to four per (device, k, rc_thresh) -- of ONE such
 # key at a time (a run with another k closes the others), and no pooled handle keeps a buffer above _POOL_KEEP_BYTES (the
 # scratch arena of a heavy batch can reach tens of GB: it is given back and re-sized by the next batch).
 _POOL = {}
-_POOL_MAX = 3
+_POOL_MAX = 4                                   # the driver has up to four batches on their way (sv_processor.runner: two submitted, one launched, one being read)
 _POOL_KEEP_BYTES = 2 << 30
 
 
@@ -566,6 +588,38 @@ class DeviceIndex(object):
             pass
 
 
+class PackedReads(tuple):
+    """(words, lens, N list) as pack_reads makes them, with what a submit needs of them looked up ONCE (buffer addresses, sizes, the
+    longest read): a driver hands thousands of these over per second, and asking numpy for an address costs more than the struct"""
+
+    def __new__(cls, words, lens, nl):
+        words, lens = _as_c(words, np.uint32), _as_c(lens, np.uint16)
+        nl = _as_c(nl, np.uint32) if nl is not None and len(nl) else None
+        self = tuple.__new__(cls, (words, lens, nl))
+        self.n_reads, self.stride = int(words.shape[0]), int(words.shape[1]) * 4
+        self.p_words, self.p_lens = words.ctypes.data, lens.ctypes.data
+        self.p_n, self.n_n = (nl.ctypes.data, len(nl)) if nl is not None else (0, 0)
+        self.maxlen = int(lens.max()) if len(lens) else 0
+        return self
+
+
+# bk_region as bytes (the ctypes structure above, field for field; C.sizeof(BkRegion) with its tail padding)
+_REGION_PACK = struct.Struct("@PPPiiPPiiPiiPPPi%dx" % (C.sizeof(BkRegion) - struct.calcsize("@PPPiiPPiiPiiPPPi"))).pack
+
+
+def region_array_packed(items):
+    """BkRegion array + what it points to, for a batch of (PackedReads, window bytes, indel_only uint8 array or None): one
+    struct.pack per target instead of a ctypes structure filled field by field (no soft-clip sequences, no partner windows:
+    targets that have those go through RegionInput)"""
+    wbuf = b"".join(w for _p, w, _io in items)
+    base = C.cast(C.c_char_p(wbuf), C.c_void_p).value or 0
+    parts, off, pack = [], 0, _REGION_PACK
+    for pr, w, io in items:
+        parts.append(pack(pr.p_words, pr.p_lens, io.ctypes.data if io is not None else 0, pr.n_reads, pr.stride, 0, 0, -1, 0, base + off, len(w), 0, 0, 0, pr.p_n, pr.n_n))
+        off += len(w)
+    return (BkRegion * len(items)).from_buffer_copy(b"".join(parts)), wbuf
+
+
 def pack_reads(codes, lens=None):
     """uint8 code matrix [N, L] (0..3, 4 = N) -> (uint32 words [N, ceil(L/16)], uint16 lens, uint32 N list) in the layout
     bk_submit_regions_ex(BK_SUBMIT_PACKED) takes: 16 bases per word, the first in the most significant bits, an N packed as A,
@@ -584,7 +638,7 @@ def pack_reads(codes, lens=None):
     v = pad.reshape(n, W, 16).astype(np.uint32)
     sh = (30 - 2 * np.arange(16, dtype=np.uint32))[None, None, :]
     words = np.bitwise_or.reduce(v << sh, axis=2).astype(np.uint32)
-    return words, lens, nl
+    return PackedReads(words, lens, nl)
 
 
 def pack_sequence(seq, codes=False):

@@ -108,10 +108,10 @@ class LazyContigs(object):
     when one is looked at -- the driver with the native call tail and no per-contig files never does.  The records live in
     the engine's host copy of the batch, so they must be read before the engine takes its next batch."""
 
-    def __init__(self, engine, region, reads, kmer_len):
+    def __init__(self, engine, region, reads, kmer_len, n=None):
         self._eng, self._region, self._reads, self._k = engine, region, reads, kmer_len
         self._serial = engine.batch_serial
-        self._n = engine.contig_count(region)
+        self._n = engine.contig_count(region) if n is None else n
         self._items = None
 
     def _get(self):

@@ -21,7 +21,7 @@ import os
 import shutil
 from collections import OrderedDict
 
-from . import read_extraction, refseq, samio, sv_assembly, sv_caller
+from . import call_context as cc, hip_backend, read_extraction, refseq, samio, sv_assembly, sv_caller      # (hip_backend: importing is harmless without the built library)
 
 HEADER_FIELDS = ['genes', 'target_breakpoints', 'align_cigar', 'mismatches', 'strands', 'rep_overlap_segment_len', 'sv_type',
                  'split_read_count', 'nkmers', 'disc_read_count', 'breakpoint_coverages', 'contig_id', 'contig_seq']
@@ -42,7 +42,8 @@ class RegionData(object):
         self.read_codes, self.read_lens, self.read_packed = read_codes, read_lens, read_packed
         self.read_ids = read_ids if read_codes is not None else list(read_ids)
         self.read_seqs = read_seqs if read_codes is not None else list(read_seqs)
-        self.indel_only = (indel_only if read_codes is not None else list(indel_only)) if indel_only is not None else ([False] * len(self.read_ids) if read_codes is None else _np.zeros(len(read_ids), dtype=_np.uint8))
+        self._no_indel_only = indel_only is None and read_codes is not None     # (no read is indel-only: the zero flags are only made when someone looks at them)
+        self._indel_only = (indel_only if read_codes is not None else list(indel_only)) if indel_only is not None else ([False] * len(self.read_ids) if read_codes is None else None)
         self.quals = list(quals) if quals is not None else None
         self.sc_seqs = sc_seqs
         self.window = window
@@ -51,12 +52,42 @@ class RegionData(object):
         self._view = None                       # (the objects the view was made from ..., hip_backend.RegionInput)
         self._refcheck = None                   # (window, number of partners, verdict of target.unsupported_reference)
         self._maxlen = None                     # (read_lens, its maximum)
+        self._wbytes = None                     # (window, its bytes)
+
+    @property
+    def indel_only(self):
+        if self._indel_only is None:
+            self._indel_only = _np.zeros(len(self.read_ids), dtype=_np.uint8)
+        return self._indel_only
+
+    @indel_only.setter
+    def indel_only(self, v):
+        self._indel_only, self._no_indel_only = v, False
+
+    def window_bytes(self):
+        c = self._wbytes
+        if c is None or c[0] is not self.window:
+            c = self._wbytes = (self.window, self.window.encode())
+        return c[1]
+
+    def checked_at_submit(self):
+        """True: the characters of this target's window are checked with the whole batch's (runner._submit_batch: one C-speed scan
+        over the concatenated windows) instead of per target -- the targets that go to the library as packed_item()s"""
+        return type(self.read_packed) is hip_backend.PackedReads and self.sc_seqs is None and not self.partners and type(self.window) is str
+
+    def packed_item(self):
+        """(PackedReads, window bytes, indel_only array or None) for hip_backend.Engine.submit_packed, or None when this target
+        needs the general path (no packed reads, soft-clip sequences, partner windows, a window that is not text)"""
+        pr = self.read_packed
+        if type(pr) is not hip_backend.PackedReads or self.sc_seqs is not None or self.partners or type(self.window) is not str:
+            return None
+        io = None if self._no_indel_only else hip_backend._as_c(self.indel_only, _np.uint8)
+        return (pr, self.window_bytes(), io)
 
     def device_view(self, use_packed=True):
         """the hip_backend.RegionInput of these inputs.  Made once per state of the inputs and kept with them: a driver that
         runs the same RegionData again (several analyses over one set of extracted reads) does not rebuild it per run.  The
         objects it was made from are kept and compared by identity, so any replacement of an input makes a new view."""
-        from . import hip_backend
         reads = self.read_codes if self.read_codes is not None else self.read_seqs
         packed = self.read_packed if use_packed else None
         v = self._view
@@ -71,6 +102,9 @@ class RegionData(object):
         return ri
 
     def max_read_len(self):
+        pr = self.read_packed
+        if pr is not None and hasattr(pr, "maxlen") and pr[1] is self.read_lens:
+            return pr.maxlen
         m = self._maxlen
         if m is None or m[0] is not self.read_lens:
             m = self._maxlen = (self.read_lens, int(_np.asarray(self.read_lens).max()) if len(self.read_lens) else 0)
@@ -404,28 +438,32 @@ class contig(object):
 
 # ------------------------------------------------------------------------------------------------ target
 class target(object):                                               # sv_processor.py:244-722
+    # defaults of the per-target state that starts out immutable (instances overwrite them; a driver makes tens of thousands of
+    # targets per second, and every assignment in __init__ is paid per target)
+    name = chrom = start = end = None
+    disc_reads = None
+    cleaned_read_recs = None
+    read_len = 0
+    repeat_mask = None
+    coverage_fn = None
+    region_index = None                         # slot in the batched GPU call
+    native_rows = None
+    engine = None
+    failed = None                               # text of the device cap this target's region hit (it is skipped then)
+    n_contigs = None                            # number of contigs of the region when the runner asked for all counts of the batch at once
+    logger = logging.getLogger('root')
+
     def __init__(self, intervals, prm, data=None, write_files=True):
         self.params = prm
-        self.name = self.chrom = self.start = self.end = None
         self.paths, self.files = {}, {}
-        self.disc_reads = None
-        self.cleaned_read_recs = None
-        self.read_len = 0
         self.kmers = {}
         self.results = []
         self.svs = {'trl': [0, '-'], 'indel': [0, ''], 'rearrangement': [0, '']}
-        self.logger = logging.getLogger('root')
         self.target_intervals = intervals
-        self.repeat_mask = None
         self.data = data
         self.partner_windows = []
-        self.coverage_fn = None
         self.write_files = write_files and 'targets' in prm.paths
-        self.region_index = None                # slot in the batched GPU call
-        self.native_rows = None
-        self.engine = None
         self.reads = []
-        self.failed = None                      # text of the device cap this target's region hit (it is skipped then)
         self.setup()
 
     def setup(self):                                                 # :267-294
@@ -559,7 +597,7 @@ class target(object):                                               # sv_process
     def _unsupported_reference(d):
         if not d.window:
             return "empty reference window"
-        if isinstance(d.window, str) and d.window.encode().translate(None, b"ACGTNacgtn"):      # C-speed scan (str.strip walks the characters one by one); lower case = soft-masked
+        if isinstance(d.window, str) and d.window_bytes().translate(None, b"ACGTNacgtn"):      # C-speed scan (str.strip walks the characters one by one); lower case = soft-masked
             return "reference window holds characters other than A/C/G/T/N (%s)" % ",".join(sorted(set(d.window.strip("ACGTNacgtn")))[:5])
         for p_ in d.partners:
             if isinstance(p_[4], str) and p_[4].encode().translate(None, b"ACGTNacgtn"):
@@ -624,7 +662,7 @@ class target(object):                                               # sv_process
                     f.write("\t".join([m, str(c)]) + "\n")
         if self.native_rows is not None and not self.write_files and hasattr(eng, 'contig_count') and hasattr(eng, 'batch_serial'):
             # rows come from the native tail and no per-contig file is written: only the number of contigs is needed now
-            self.kmers['clusters'] = sv_assembly.LazyContigs(eng, ri, self.reads, self.params.get_kmer_size())
+            self.kmers['clusters'] = sv_assembly.LazyContigs(eng, ri, self.reads, self.params.get_kmer_size(), self.n_contigs)
         else:
             self.kmers['clusters'] = sv_assembly.contigs_from_engine(eng, ri, self.reads, self.params.get_kmer_size())
         self.cleaned_read_recs = None
@@ -674,14 +712,20 @@ class target(object):                                               # sv_process
         return total
 
     def get_summary(self):                                           # :708-721
-        total = self.get_sv_counts()
-        keys = sorted(self.svs.keys())
+        total = self.get_sv_counts() if self.results else 0
+        svs = self.svs
+        if len(svs) == 3:                                            # the keys the class starts with, sorted: indel, rearrangement, trl
+            return _SUMMARY_HEADER, "%s\t%d\t%d\t%s\t%s\t%s\t-" % (self.name, len(self.kmers['clusters']), total, svs['indel'][0], svs['rearrangement'][0], svs['trl'][0])
+        keys = sorted(svs.keys())
         header = ['Target', 'N_contigs', 'Total_variants'] + ['N_' + str(x) for x in keys] + ['Rearrangements']
         out = self.name + '\t' + str(len(self.kmers['clusters'])) + '\t' + str(total) + '\t'
         for t in keys:
-            out += str(self.svs[t][0]) + '\t'
+            out += str(svs[t][0]) + '\t'
         out += '-'
         return "\t".join(header), out
+
+
+_SUMMARY_HEADER = "\t".join(['Target', 'N_contigs', 'Total_variants', 'N_indel', 'N_rearrangement', 'N_trl', 'Rearrangements'])
 
 
 # ------------------------------------------------------------------------------------------------ runner
@@ -716,7 +760,26 @@ class runner(object):                                               # sv_process
     def _submit_batch(self, eng, live):
         """hand one batch of targets to the library; with a HIP engine the 2-bit packing and the copies run on the library's
         own thread (BK_SUBMIT_ASYNC) while this thread goes on with the previous batch"""
-        from . import hip_backend
+        # (targets whose window was not looked at yet -- RegionData.checked_at_submit -- are checked here: all windows of the batch in
+        # one scan; only if that finds a foreign character are they looked at one by one, and the offenders skipped ALONE as ever)
+        late = [t for t in live if t.data.checked_at_submit()]
+        if late and b"".join(t.data.window_bytes() for t in late).translate(None, b"ACGTNacgtn") or any(not t.data.window for t in late):
+            for t in late:
+                why = t.unsupported_reference()
+                if why:
+                    self.logger.error('target %s: skipped: %s' % (t.name, why))
+                    self.failed_targets[t.name] = why
+                    t.rm_output_dir()
+                    live.remove(t)
+            if not live:
+                return False
+        if hasattr(eng, 'submit_packed'):
+            items = [t.data.packed_item() for t in live]
+            if None not in items:                                     # the common case of a packing read extraction: one struct.pack per target
+                for i, t in enumerate(live):
+                    t.region_index, t.engine = i, eng
+                eng.submit_packed(items, wait=False)
+                return
         ins = []
         allp = all(t.data.read_packed is not None for t in live)          # a batch goes over packed (BK_SUBMIT_PACKED) or not at all
         for i, t in enumerate(live):
@@ -730,13 +793,11 @@ class runner(object):                                               # sv_process
     def _launch_batch(self, eng, live):
         """start the GPU stages of a submitted batch (asynchronous where the engine supports it) and give the library the
         call context of its regions"""
-        from . import hip_backend
         try:
             eng.run(hip_backend.BK_STAGE_ALL, sync=False)
         except TypeError:
             eng.run(hip_backend.BK_STAGE_ALL)
         if self.native_calls and hasattr(eng, 'set_call_context'):
-            from . import call_context as cc
             if self._ctx_head is None:                               # options + annotation tables: the same text for every batch
                 self._ctx_opts = cc.opts_line(self.params.opts)
                 self._ctx_head = "\n".join([self._ctx_opts] + cc.tables_lines(self.params.gene_annotations.genes, self.params.repeat_mask))
@@ -749,6 +810,8 @@ class runner(object):                                               # sv_process
             for i, t in enumerate(live):
                 lines += cc.region_lines(i, t.get_values(), t.repeat_mask, t.disc_reads, t.partner_windows, t.data.read_ids)
             eng.set_call_context("\n".join(lines) + "\n")
+            if hasattr(eng, 'call_async'):                             # the wait for the GPU, the copy back and the call tail run on the library's thread
+                eng.call_async()
 
     def _start_batch(self, eng, live):
         self._submit_batch(eng, live)
@@ -769,8 +832,11 @@ class runner(object):                                               # sv_process
                     self.failed_targets[t.name] = text
         if self.native_calls and hasattr(eng, 'set_call_context'):
             rows = eng.call()
+            counts = eng.contig_counts() if hasattr(eng, 'contig_counts') else None      # one library call per batch instead of one per target
             for i, t in enumerate(live):
                 t.native_rows = rows.get(i, [])
+                if counts is not None:
+                    t.n_contigs = counts[i]
         for t in live:
             if t.failed:
                 t.rm_output_dir()
@@ -863,7 +929,6 @@ class runner(object):                                               # sv_process
     def _make_engine(self):
         if self.engine_factory:
             return self.engine_factory(self.params)
-        from . import hip_backend
         dev = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0                # one process per GPU
         eng = hip_backend.acquire_engine(self.params.get_kmer_size(), self.params.get_sr_thresh('min'), dev)      # kept between runs of one process
         self._pooled.append(eng)
@@ -910,6 +975,9 @@ class runner(object):                                               # sv_process
         # thread picks up the batch launched one iteration earlier (call tail, per-target objects, files), so the GPU is never
         # waited for.  Batches finish in the order they were started.
         bsz = max(1, int(self.params.opts.get('batch_regions', 256)))
+        # submits in flight before a batch's kernels are launched: with one, the launch of a batch of packed reads still waited ~1 ms for
+        # the library's thread (row copies + H2D of 100 MB take longer than this thread needs for a batch); a handle per batch in flight
+        depth = max(1, int(self.params.opts.get('submit_depth', 2)))
         free, pending, running = [], [], []                         # handles; submitted batches; the launched batch
 
         def advance():
@@ -932,7 +1000,7 @@ class runner(object):                                               # sv_process
                     if not t.clean_reads():
                         t.rm_output_dir()
                         continue
-                    why = t.unsupported_reference()
+                    why = None if t.data.checked_at_submit() else t.unsupported_reference()
                     if why:                                           # this target only; the run goes on (summary + exit code report it)
                         self.logger.error('target %s: skipped: %s' % (t.name, why))
                         self.failed_targets[t.name] = why
@@ -943,9 +1011,11 @@ class runner(object):                                               # sv_process
                     continue
                 eng = free.pop() if free else self._make_engine()
                 self.engine = eng
-                self._submit_batch(eng, live)
+                if self._submit_batch(eng, live) is False:            # every target of the batch was skipped at the submit-time window check
+                    free.append(eng)
+                    continue
                 pending.append((eng, live))
-                if len(pending) > 1:
+                if len(pending) > depth:
                     advance()
             while pending:
                 advance()
@@ -967,7 +1037,6 @@ class runner(object):                                               # sv_process
             failure = ex
             self.logger.error('rank %d failed: %s: %s' % (self.rank, type(ex).__name__, ex))
         finally:
-            from . import hip_backend
             for eng in self._pooled:                                    # back to the pool after a clean run, closed otherwise
                 if ok:
                     hip_backend.release_engine(eng)

@@ -163,6 +163,7 @@ typedef struct bk_contig_info {
     int32_t n_hits;         /* realign stage: PSL-equivalent records     */
 } bk_contig_info;
 int bk_get_contig_count(bk_handle *h, int32_t region, int32_t *n_contigs);
+int bk_get_contig_counts(bk_handle *h, int32_t *n_contigs, int32_t cap);   /* all regions of the batch at once (cap >= number of regions) */
 int bk_get_contig_info(bk_handle *h, int32_t region, int32_t contig, bk_contig_info *info);
 /* any pointer may be NULL; sizes from bk_contig_info.
  *   seq        seq_len ASCII bytes            (contig.get_contig_seq(), sv_assembly.py:443)
@@ -209,6 +210,8 @@ int bk_get_hits_flat(bk_handle *h, int32_t region, int32_t contig, int32_t *buf,
  * gene / repeat lines keeps the tables of the handle's previous context (they are the same for every batch of a run). */
 int bk_set_call_context(bk_handle *h, const char *text);
 int bk_call(bk_handle *h);                                      /* after bk_run: calls for every contig of the batch */
+int bk_call_async(bk_handle *h);                                /* the same on the handle's own thread (returns at once; every later call on the handle
+                                                                 * waits for it first and reports its error; bk_call / bk_get_calls then find the calls made) */
 int bk_get_calls(bk_handle *h, char *buf, size_t cap, size_t *needed);   /* "<region>\t<contig>\t<13 fields>\n" ... */
 int bk_call_text(const char *text, char *out, size_t cap, int *target_hit);   /* one fully described contig; no GPU needed */
 

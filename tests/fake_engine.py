@@ -15,7 +15,14 @@ class FakeEngine(object):
     def submit(self, ins):
         self.regions = []
         for g in ins:
-            asc = np.frombuffer(b"ACGTN", dtype=np.uint8)[g.reads] if getattr(g, "codes", False) and g.reads.size else g.reads
+            if getattr(g, "packed", False):                    # 2-bit rows + N list (hip_backend.pack_reads) back to a code matrix
+                w = g.reads
+                codes = ((w[:, :, None] >> (30 - 2 * np.arange(16, dtype=np.uint32))[None, None, :]) & 3).astype(np.uint8).reshape(w.shape[0], -1)
+                for e in (g.read_n if g.read_n is not None else []):
+                    codes[int(e) >> 10, int(e) & 1023] = 4
+                asc = np.frombuffer(b"ACGTN", dtype=np.uint8)[codes]
+            else:
+                asc = np.frombuffer(b"ACGTN", dtype=np.uint8)[g.reads] if getattr(g, "codes", False) and g.reads.size else g.reads
             reads = [bytes(asc[i, :g.lens[i]]).decode() for i in range(g.reads.shape[0])]
             io = g.indel_only if g.indel_only is not None else np.zeros(len(reads), dtype=np.uint8)
             sc = None if g.sc is None else [bytes(g.sc[i, :g.sc_lens[i]]).decode() for i in range(g.sc.shape[0])]

@@ -98,3 +98,29 @@ def test_pack_reads_matches_the_library_packing():
         nw = (int(r.read_lens[i]) + 15) // 16
         assert (ww[:nw] == w[i, :nw]).all() and (w[i, nw:] == 0).all(), i
         assert [int(x & 1023) for x in nl if (x >> 10) == i] == npos, i
+
+
+def test_struct_packed_region_array_equals_the_ctypes_one():
+    """hip_backend.region_array_packed (one struct.pack per target) describes a batch exactly as RegionInput.fill does: same
+    bk_region bytes apart from the window pointer, which points to the same characters"""
+    import ctypes as C
+    import numpy as np
+    from breakmer_amd import hip_backend as hb, synth
+    regs = [synth.make_region(60 + i, depth=20, W=700 + 50 * i, n_frac=(0.1 if i % 2 else 0.0), var_len=0.3) for i in range(5)]
+    packed = [hb.pack_reads(r.reads, r.read_lens) for r in regs]
+    assert all(type(p_) is hb.PackedReads and p_.maxlen == int(r.read_lens.max()) for p_, r in zip(packed, regs))
+    io = [None, np.zeros(regs[1].reads.shape[0], dtype=np.uint8), None, np.ones(regs[3].reads.shape[0], dtype=np.uint8), None]
+    arr, wbuf = hb.region_array_packed([(p_, r.window_str.encode(), i_) for p_, r, i_ in zip(packed, regs, io)])
+    assert C.sizeof(arr) == len(regs) * C.sizeof(hb.BkRegion)
+    ref = (hb.BkRegion * len(regs))()
+    views = [hb.RegionInput(r.reads, r.window_str, read_lens=r.read_lens, indel_only=i_, packed=p_) for p_, r, i_ in zip(packed, regs, io)]
+    for g, v in zip(ref, views):
+        v.fill(g)
+    for a, b, r in zip(arr, ref, regs):
+        for name, _t in hb.BkRegion._fields_:
+            if name == "window":
+                assert C.string_at(C.cast(a.window, C.c_void_p).value, a.window_len) == r.window_str.encode() == C.string_at(C.cast(b.window, C.c_void_p).value, b.window_len)
+            elif name == "partners":
+                assert not a.partners and not b.partners
+            else:
+                assert getattr(a, name) == getattr(b, name), name

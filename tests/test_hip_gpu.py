@@ -726,6 +726,44 @@ def test_fetch_then_rerun_then_call_gpu(hb):
         assert all(row[11] in ids for row in want.get(i, [])), i
 
 
+def test_call_async_makes_the_same_calls_gpu(hb):
+    """bk_call_async: the wait for the run, the copy back and the call tail on the handle's thread; bk_call afterwards finds the
+    calls made (same text as the synchronous tail); a new run invalidates them; an error of the tail is reported by the next call."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from breakmer_amd.sv_processor import params as bk_params
+    regions = [synth.make_region(140 + i, depth=80, W=1500, sv_type=synth.SV_TYPES[i % 3]) for i in range(9)]
+    opts = dict(bk_params.DEFAULTS); opts["var_filter"] = ["indel", "rearrangement", "trl"]
+    ins = [hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions]
+    eng = hb.Engine(kmer_size=31)
+    eng.submit(ins)
+    eng.set_call_context(bench.call_context_text(regions, opts))
+    eng.run(hb.BK_STAGE_ALL)
+    want = eng.call_blob()
+    assert want.count(b"\n") >= 6
+    for _ in range(3):
+        eng.run(hb.BK_STAGE_ALL, sync=False)
+        eng.call_async()                                   # returns at once
+        assert eng.sync() == 0                             # joins the thread
+        assert eng.call_blob() == want
+    # a batch of other regions on the same handle: nothing of the earlier calls is left
+    eng.submit(ins[:4])
+    eng.set_call_context(bench.call_context_text(regions[:4], opts))
+    eng.run(hb.BK_STAGE_ALL, sync=False)
+    eng.call_async()
+    got = eng.call()
+    assert sorted(got) == sorted(k for k in range(4) if k in got) and all(k < 4 for k in got)
+    fresh = hb.Engine(kmer_size=31)
+    fresh.submit(ins[:4]); fresh.set_call_context(bench.call_context_text(regions[:4], opts)); fresh.run(hb.BK_STAGE_ALL)
+    assert fresh.call() == got
+    # without a context the call is refused where it is made
+    other = hb.Engine(kmer_size=31)
+    other.submit(ins[:2]); other.run(hb.BK_STAGE_ALL)
+    with pytest.raises(hb.BreakmerHipError):
+        other.call_async()
+
+
 def test_arena_growth_and_rerun_gpu(hb):
     """A deliberately tiny scratch arena: the library must notice the overflow, grow the arena and rerun --
     results identical to a run with the default arena; repeated bk_run on one handle is idempotent."""

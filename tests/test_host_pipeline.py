@@ -459,6 +459,36 @@ def test_window_with_n_is_processed_and_other_characters_skip_that_target_only(t
     assert [x for x in rows if x[0] == rows2[-1][0]] == [rows2[-1]]                  # the untouched target: the same row
 
 
+def test_packed_targets_are_checked_at_submit_and_give_the_same_rows(tmp_path):
+    """Targets that come with packed reads (hip_backend.pack_reads) have their windows checked once per batch at submit; a window
+    with a foreign character still skips that target ALONE, and the rows of the others equal those of the string inputs."""
+    from breakmer_amd import hip_backend as hb
+    spec = [(3, "del"), (4, "del"), (5, "ins"), (6, "del")]
+    cfg, data = make_inputs(tmp_path, spec)
+    r0 = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+    rows0 = r0.run()
+    d2 = tmp_path / "packed"
+    d2.mkdir()
+    cfg2, _ = make_inputs(d2, spec)
+    data2 = {}
+    for rid, sv in spec:
+        r = synth.make_region(rid, sv_type=sv, depth=60, W=1500)
+        pk = hb.pack_reads(r.reads, r.read_lens)
+        assert type(pk) is hb.PackedReads
+        data2[r.name.upper()] = sp.RegionData(r.read_ids, None, None, None, r.window_str, [], r.disc_reads, read_codes=r.reads, read_lens=r.read_lens, read_packed=pk)
+        assert data2[r.name.upper()].checked_at_submit() and data2[r.name.upper()].max_read_len() == int(r.read_lens.max())
+    names = sorted(data2)
+    r1 = sp.runner(cfg2, region_data=data2, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+    rows1 = r1.run()
+    assert rows1 == rows0 and not r1.failed_targets and len(rows1) >= 3
+    bad = data2[names[2]]
+    bad.window = bad.window[:300] + "Y" + bad.window[301:]
+    r2 = sp.runner(cfg2, region_data=data2, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')))
+    rows2 = r2.run()
+    assert [t.upper() for t in r2.failed_targets] == [names[2]] and "A/C/G/T/N" in list(r2.failed_targets.values())[0]
+    assert rows2 == [x for x in rows0 if not x[11].upper().startswith(names[2])] and len(rows2) == len(rows0) - 1
+
+
 def test_soft_masked_refseq_file_keeps_its_case(tmp_path):
     """A <name>_forward_refseq.fa written by the reference tool from a soft-masked genome keeps lower case
     (utils.py:366-371: str(seq)); refseq.extract_refseq_fa writes the bytes of the genome file as the reference does, and the
