@@ -451,6 +451,7 @@ class target(object):                                               # sv_process
     engine = None
     failed = None                               # text of the device cap this target's region hit (it is skipped then)
     n_contigs = None                            # number of contigs of the region when the runner asked for all counts of the batch at once
+    check_at_submit = False                     # the window's characters are checked with the whole batch's (runner._submit_batch)
     logger = logging.getLogger('root')
 
     def __init__(self, intervals, prm, data=None, write_files=True):
@@ -762,7 +763,7 @@ class runner(object):                                               # sv_process
         own thread (BK_SUBMIT_ASYNC) while this thread goes on with the previous batch"""
         # (targets whose window was not looked at yet -- RegionData.checked_at_submit -- are checked here: all windows of the batch in
         # one scan; only if that finds a foreign character are they looked at one by one, and the offenders skipped ALONE as ever)
-        late = [t for t in live if t.data.checked_at_submit()]
+        late = [t for t in live if t.check_at_submit]
         if late and b"".join(t.data.window_bytes() for t in late).translate(None, b"ACGTNacgtn") or any(not t.data.window for t in late):
             for t in late:
                 why = t.unsupported_reference()
@@ -1000,7 +1001,8 @@ class runner(object):                                               # sv_process
                     if not t.clean_reads():
                         t.rm_output_dir()
                         continue
-                    why = None if t.data.checked_at_submit() else t.unsupported_reference()
+                    t.check_at_submit = t.data.checked_at_submit()
+                    why = None if t.check_at_submit else t.unsupported_reference()
                     if why:                                           # this target only; the run goes on (summary + exit code report it)
                         self.logger.error('target %s: skipped: %s' % (t.name, why))
                         self.failed_targets[t.name] = why

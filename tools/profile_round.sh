@@ -1,13 +1,13 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the GPU box through gpurun, from the repo root):
-#   bash tools/profile_round.sh r03
+#   bash tools/profile_round.sh r04
 # The PMC passes run one launch at a time (--inflight 1: counter collection serialises kernels anyway); the timed loop then
 # launches the 256-thread assembler (bk_asm_kernel_w4, the kernel of the default bench line), the one-step-at-a-time pass the
 # 512-thread one, so every pass has per-launch figures of both.
 # Separate passes (kernel stats; FETCH_SIZE; WRITE_SIZE; SQ instruction counters): PMC collection is never combined with
 # other tracing, and the profiled program is python3 itself (no launcher in between).
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/prof_$tag
 export TMPDIR=/tmp
 mkdir -p "$out"
