@@ -48,6 +48,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=24, help="regions timed through the CPU oracle on ONE core (0 = skip the CPU baseline)")
     ap.add_argument("--inflight", type=int, default=6, help="steps in flight (independent batches on separate HIP streams)")
     ap.add_argument("--max-candidates", type=int, default=0, help="diagnostic: device cap on one k-mer's candidate reads (0 = library default 2048); sizes the assembler's LDS and so its workgroups per CU")
+    ap.add_argument("--max-contig", type=int, default=0, help="diagnostic: device cap on the contig length (0 = library default 4096); sizes the assembler's and the realigner's LDS")
     ap.add_argument("--wg", type=int, default=256, help="assembler workgroup size of the batches in flight (256: 4 per CU; 512: 2 per CU); the one-step-at-a-time pass always uses 512")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (testing)")
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
@@ -284,7 +285,7 @@ def main():
     engs = []
     submit_ms = []
     for _ in range(max(1, a.inflight)):                # one handle (= one HIP stream + its own buffers) per step in flight
-        e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local, flags=a.flags, wg_threads=a.wg, max_candidates=a.max_candidates)
+        e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local, flags=a.flags, wg_threads=a.wg, max_candidates=a.max_candidates, max_contig_len=a.max_contig)
         t0 = time.perf_counter()
         e.submit(ins)
         submit_ms.append((time.perf_counter() - t0) * 1e3)
