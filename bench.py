@@ -505,6 +505,7 @@ def main():
                        "stages": "group reads + k-mer select + assemble (olc.nw) + realign on the GPU, SV-call tail in host C++, rows collated",
                        "regions_per_gpu_per_step": n_regions, "regions_total_per_step": n_regions * world,
                        "sv_calls_per_step": last_rows.get("n", 0),
+                       "sv_calls_parity": "k-mer selection, assembly and the caller are pinned by vectors generated from the reference itself; the realign records the calls are made from follow the contract of oracle/bk_oracle.c (BLAT is absent: that stage is parity-unpinned, DESIGN 4.3)",
                        "steps_in_flight": len(engs),
                        "asm_workgroup_threads": int(eng.stat(25)), "asm_workgroups_per_cu": int(eng.stat(23)),
                        "one_step_at_a_time_workgroup_threads": 512,
