@@ -295,20 +295,35 @@ def main():
     pack_ms, h2d_ms = eng.stat(20) / 1e3, eng.stat(21) / 1e3
     last_rows = {}
 
+    def take_rows(raw):
+        last_rows["n"] = raw.count(b"\n") + (1 if raw and not raw.endswith(b"\n") else 0)
+        last_rows["raw"] = raw
+        if dist:                                       # collate the variable-length records of all ranks (RCCL all-gather)
+            gather(np.frombuffer(raw, dtype=np.uint8))
+
     def finish_step(e, relaunch):
         """consume one step of handle e: wait + copy its records to the host, start the handle's next step at once (its
-        device buffers are free again), then run the SV-call tail on the host copy while those kernels execute"""
+        device buffers are free again), and have the SV-call tail made on the host copy while those kernels execute -- on the
+        library's own thread (bk_call_async), so this thread goes on to the next handle; the calls of a step are picked up when
+        its handle comes round again (or by collect_tails() at the end of the run: every step's tail is inside the timed region)"""
+        if tails.get(id(e)):
+            take_rows(e.call_blob())                   # the tail of this handle's previous step: made meanwhile
         e.fetch()
         ms = [e.kernel_ms(j + 1) for j in range(3)]
         if relaunch:
             e.run(stages, sync=False)                  # group + k-mer select + assemble + realign on the GPU (async)
-        raw = e.call_blob()                            # SV-call tail (host C++): one tab-separated record per call, region order
-        last_rows["n"] = raw.count(b"\n") + (1 if raw and not raw.endswith(b"\n") else 0)
-        last_rows["raw"] = raw
-        blob = np.frombuffer(raw, dtype=np.uint8)
-        if dist:                                       # collate the variable-length records of all ranks (RCCL all-gather)
-            gather(blob)
+        e.call_async()                                 # SV-call tail (host C++) over the fetched copy: one tab-separated record per call, region order
+        tails[id(e)] = True
         return ms
+
+    tails = {}
+
+    def collect_tails(k):
+        for j in range(len(engs)):                     # in step order: the oldest outstanding step is on handle k % inflight
+            e = engs[(k + j) % len(engs)]
+            if tails.get(id(e)):
+                take_rows(e.call_blob())
+                tails[id(e)] = False
 
     # Collation: the records of GATHER_EVERY steps go out in one all-gather, framed per step ([n_steps | (length, records)*]
     # per rank, fixed capacity), two slots so that a gather overlaps the kernels of the following steps (the records are only
@@ -379,6 +394,7 @@ def main():
             launched += 1 if relaunch else 0
             for j in range(3):
                 acc[j] += ms[j]
+        collect_tails(k)
         drain()
         return acc
 

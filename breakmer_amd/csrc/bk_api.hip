@@ -37,6 +37,9 @@ using at512::bk_nw_batch_kernel;
 #include <atomic>
 #include <chrono>
 #include <functional>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <thread>
 #include <vector>
 
@@ -116,6 +119,33 @@ static int join_pending(bk_handle *h)
 
 #define HIPCHK(h, call)                                                                              \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BK_E_HIP; } } while (0)
+
+// Launch-time queries that do not change between launches of the same shape (a driver launches thousands of batches per second;
+// each of these calls costs the host thread microseconds): the occupancy of (kernel, workgroup size, LDS bytes) per device, and
+// the dynamic-LDS attribute a kernel was last given.
+static int cached_occupancy(int dev, const void *fn, int threads, size_t lds)
+{
+    static std::mutex mu; static std::map<std::tuple<int, const void *, int, size_t>, int> memo;
+    std::lock_guard<std::mutex> g(mu);
+    auto key = std::make_tuple(dev, fn, threads, lds);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    memo[key] = per_cu;
+    return per_cu;
+}
+static hipError_t set_max_dyn_lds(int dev, const void *fn, int bytes)
+{
+    static std::mutex mu; static std::map<std::pair<int, const void *>, int> last;
+    std::lock_guard<std::mutex> g(mu);
+    auto key = std::make_pair(dev, fn);
+    auto it = last.find(key);
+    if (it != last.end() && it->second >= bytes) return hipSuccess;          // (the attribute is a maximum: a smaller request is covered)
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) last[key] = bytes;
+    return e;
+}
 
 static int fail(bk_handle *h, int code, const std::string &msg) { if (h) h->err = msg; else g_create_err = msg; return code; }
 
@@ -514,11 +544,10 @@ static int launch_sw(bk_handle *h, int max_contig, bool note_occupancy)
     BkSwTier T = sw_tier(h, two ? BK_SW_SHORT : max_contig, max_contig, two);
     HIPCHK(h, hipMemsetAsync((unsigned long long *)h->d_tops.p + 6, 0, 16, h->stream));
     size_t lds = bk_sw_layout(T.contig_cap, T.tw_cap, T.sec_lds, T.n_flags).total;
-    HIPCHK(h, hipFuncSetAttribute((const void *)bk_sw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BK_LDS_MAX));
+    HIPCHK(h, set_max_dyn_lds(h->dev, (const void *)bk_sw_kernel, (int)BK_LDS_MAX));
     // one workgroup per contig, pulled from the list the assembler appended to; the number of contigs is only known
     // on the device, so a resident-sized grid of persistent workgroups is launched (idle ones exit at once)
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bk_sw_kernel, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int per_cu = cached_occupancy(h->dev, (const void *)bk_sw_kernel, threads, lds);
     if (note_occupancy) h->sw_wg_per_cu = per_cu;
     hipLaunchKernelGGL(bk_sw_kernel, dim3(per_cu * h->n_cu), dim3(threads), lds, h->stream, h->params, T);
     HIPCHK(h, hipGetLastError());
@@ -575,13 +604,13 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
             // the LDS first holds the read-grouping table (one word per slot, when it fits), then the reference k-mer set
             const uint32_t lds_words = std::max<uint32_t>(32 + 256 + 2 * h->win_words_cap + h->ref_cap, h->group_words);
             const size_t lds = (size_t)lds_words * 4;
-            HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(h, set_max_dyn_lds(h->dev, (const void *)bk_kmer_kernel, (int)lds));
             hipLaunchKernelGGL(bk_kmer_kernel, dim3(n_launch), dim3(kmer_threads), lds, h->stream, h->params, h->ref_cap, h->win_words_cap, lds_words);
             HIPCHK(h, hipGetLastError());
         }
         if (h->n_big > 0) {
             const size_t lds = (32 + 256 + (size_t)BK_K_PERM_G) * 4;
-            HIPCHK(h, hipFuncSetAttribute((const void *)bk_kmer_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(h, set_max_dyn_lds(h->dev, (const void *)bk_kmer_kernel_g, (int)lds));
             hipLaunchKernelGGL(bk_kmer_kernel_g, dim3(n_launch), dim3(kmer_threads), lds, h->stream, h->params);
             HIPCHK(h, hipGetLastError());
         }
@@ -602,10 +631,9 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         const int threads = asm_threads;
         const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
         const size_t lds = asm_lds_bytes(h, threads, max_cand, max_contig);
-        HIPCHK(h, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(h, set_max_dyn_lds(h->dev, kfn, (int)lds));
         // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        const int per_cu = cached_occupancy(h->dev, kfn, threads, lds);
         if (!subset) { h->asm_wg_per_cu = per_cu; h->asm_threads = threads; }
         // (a noisy region is split into up to BK_SPLIT_G units on the device, bk_comp.hip.h: the host only knows the bound)
         const bool may_split = !subset && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
