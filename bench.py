@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
     ap.add_argument("--cfg3-regions", type=int, default=4096, help="batch size of the configs[3] side measurement (heavy regions: the chip fills at a few thousand)")
     ap.add_argument("--cfg4-regions", type=int, default=768, help="batch size of the configs[4] side measurement: a region's chain of ~19,000 dependent rounds takes ~3 s whatever runs beside it, so regions in flight ARE the throughput (256: 69 regions/s, 512: 101, 768: 121) until the scratch arena (~270 MB per region) fills the HBM (896 no longer fit)")
+    ap.add_argument("--split-experimental", type=int, default=0, help="also time the noisy side configuration with the experimental component split (off by default: intermittent device faults, DESIGN 4.5)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic library flags (bk_config.reserved[0]); 0 in every reported number")
     ap.add_argument("--lib", default=None, help="diagnostic: path of an alternative build of the library (A/B runs on one box)")
     ap.add_argument("--dump-collated", default=None, help="write the bytes collated in the last step to this file (testing)")
@@ -126,9 +127,9 @@ def make_regions_parallel(kind, n):
         return pool.map(_gen_region, [(kind, i) for i in range(n)], chunksize=4)
 
 
-def time_other_config(hb, regions, k, opts, reps, device):
+def time_other_config(hb, regions, k, opts, reps, device, flags=0):
     """whole path (GPU stages + native call tail) over one batch, inputs resident; returns regions/s and details"""
-    eng = hb.Engine(kmer_size=k, rc_thresh=2, device=device)
+    eng = hb.Engine(kmer_size=k, rc_thresh=2, device=device, flags=flags)
     eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, partners=[p[4] for p in r.partners]) for r in regions])
     eng.set_call_context(call_context_text(regions, opts))
     eng.run(hb.BK_STAGE_ALL)
@@ -568,6 +569,8 @@ def main():
                 regsn = [synth.make_region(50000 + i, depth=a.depth, L=a.read_len, sv_type="del", noise=0.005) for i in range(64)]
                 oc["noise_0.5pct_64_regions"] = time_other_config(hb, regsn, a.kmer, opts, 2, local)
                 oc["noise_0.5pct_64_regions"]["workload"] = "64 regions of the configs[1] shape with 0.5 % substitution noise per base, one launch (seconds per launch = ms_per_batch / 1000)"
+                if a.split_experimental:                 # opt-in: the component split (bk_config.reserved[0] bit 1024) -- it can fault the device
+                    oc["noise_0.5pct_64_regions_split_experimental"] = time_other_config(hb, regsn, a.kmer, opts, 2, local, flags=1024)
                 del regsn
             except Exception as ex:                      # never lose the headline line to a side measurement
                 oc["error"] = repr(ex)

@@ -166,6 +166,7 @@ extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
     if (cfg->kmer_size < 2 || cfg->kmer_size > 64) return fail(nullptr, BK_E_ARG, "bk_create: kmer_size must be in [2, 64]");
     bk_handle *h = new bk_handle();
     h->dev = device_id; h->cfg = *cfg; h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    { const char *e = getenv("BK_SPLIT"); if (e && atoi(e) > 0) h->cfg.reserved[0] |= BK_F_SPLIT; }      // diagnostic: the experimental component split for every handle of the process
     if (h->cfg.max_contig_len <= 0) h->cfg.max_contig_len = 4096;
     if (h->cfg.max_read_len <= 0) h->cfg.max_read_len = 1024;
     if (h->cfg.max_candidates <= 0) h->cfg.max_candidates = 2048;
@@ -616,6 +617,14 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         }
     }
     const bool dbg = getenv("BK_DEBUG_SPLIT") != nullptr;
+    if (dbg) {
+        const std::pair<const char *, const DevBuf *> bufs[] = {{"desc", &h->d_desc}, {"work", &h->d_work}, {"part", &h->d_part}, {"reads", &h->d_reads}, {"rlen", &h->d_rlen}, {"rflag", &h->d_rflag}, {"sc", &h->d_sc}, {"sclen", &h->d_sclen}, {"win", &h->d_win},
+            {"ddslot", &h->d_ddslot}, {"ddrep", &h->d_ddrep}, {"ddcnt", &h->d_ddcnt}, {"grp", &h->d_grp}, {"urep", &h->d_urep}, {"unr", &h->d_unr}, {"ufl", &h->d_ufl}, {"ubuf", &h->d_ubuf}, {"ureads", &h->d_ureads}, {"ufound", &h->d_ufound}, {"uminpos", &h->d_uminpos},
+            {"arena", &h->d_arena}, {"out", &h->d_out}, {"tops", &h->d_tops}, {"order", &h->d_order}, {"skeys", &h->d_skeys}, {"clist", &h->d_clist}, {"nlist", &h->d_nlist}, {"wnlist", &h->d_wnlist}, {"rmap", &h->d_rmap}};
+        fprintf(stderr, "[bk launch] buffers:");
+        for (const auto &b : bufs) fprintf(stderr, " %s %p+%zu", b.first, b.second->p, b.second->bytes);
+        fprintf(stderr, "\n");
+    }
     if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] k-mer stage done (%d regions%s, arena %.1f MB)\n", n_launch, subset ? ", subset" : "", h->arena_cap / 1048576.0); }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if (mask & BK_STAGE_ASSEMBLE) {
@@ -636,7 +645,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         const int per_cu = cached_occupancy(h->dev, kfn, threads, lds);
         if (!subset) { h->asm_wg_per_cu = per_cu; h->asm_threads = threads; }
         // (a noisy region is split into up to BK_SPLIT_G units on the device, bk_comp.hip.h: the host only knows the bound)
-        const bool may_split = !subset && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
+        const bool may_split = !subset && (h->cfg.reserved[0] & (BK_F_SPLIT | BK_F_SPLIT_ALWAYS)) && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
         const int grid = std::min<long long>((long long)n_launch * (may_split ? BK_SPLIT_G : 1), (long long)per_cu * h->n_cu);
         if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
         else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
@@ -754,6 +763,7 @@ static int sync_impl(bk_handle *h)
                         h->n_repair_passes, redo.size(), unsplit.size(), ns_, np_, nc_, nx_, ms[1], ms[2], ms[3]);
                 for (int r = 0; r < h->n_regions && r < 4; r++) { const BkRegionWork &w = h->h_work[r]; if (!w.split) continue;
                     fprintf(stderr, "   region %d  U %u M %u M2 %u  open conflicts %u; unit 0: prefix %u us, labelling %u us, seed list %u us; unit us/iterations:", r, w.U, w.M, w.M2, w.n_conf, w.dbg_us[0], w.dbg_us[1], w.dbg_us[2]); for (int g = 0; g < BK_SPLIT_G; g++) fprintf(stderr, " %u/%u", w.unit_us[g], w.unit_iters[g]); fprintf(stderr, "\n"); }
+                for (int r = 0; r < h->n_regions; r++) { const BkRegionWork &w = h->h_work[r]; if (w.split && w.stamps[10]) fprintf(stderr, "   CHECK region %d: code %llu value 0x%llx unit/pass 0x%llx serial/seed 0x%llx (U %u M %u M2 %u)\n", r, (unsigned long long)w.stamps[10], (unsigned long long)w.stamps[11], (unsigned long long)w.stamps[12], (unsigned long long)w.stamps[13], w.U, w.M, w.M2); }
                 fprintf(stderr, "   all split regions, prefix+labelling+slowest unit (ms):");
                 for (int r = 0; r < h->n_regions; r++) { const BkRegionWork &w = h->h_work[r]; if (!w.split) continue; uint32_t mx = 0; for (int g = 0; g < BK_SPLIT_G; g++) mx = std::max(mx, w.unit_us[g]);
                     fprintf(stderr, " %.1f+%.1f+%.1f", w.dbg_us[0] / 1000.0, (w.dbg_us[1] + w.dbg_us[2]) / 1000.0, mx / 1000.0); }
@@ -1302,6 +1312,15 @@ static int call_impl(bk_handle *h)
             for (; off; ci++) {
                 const BkContigRec *c = (const BkContigRec *)(h->h_out.data() + off); off = c->next;
                 const uint8_t *b = (const uint8_t *)c;
+                // The bulk of a noisy region's contigs are a few reads that share a sequencing error: ONE gap-free alignment over the
+                // whole contig on the target window, nothing else.  Its single record spans the query and has no gap bases, so
+                // check_blat_indel (sv_caller.py:621-651) keeps no indel (ngap_total() = 0 < indel_size), has no other hit to make
+                // an event from, and the contig has no row -- (or BLAT's seeding rule drops the hit and there is no record at all):
+                // no call either way, decided from the raw hit without building the records.
+                if (c->n_hits == 1 && c->n_sec == 0 && c->hits_off && cx.opts.indel_size > 0) {
+                    const BkHit *h1 = (const BkHit *)(h->h_out.data() + c->hits_off);
+                    if (h1->tidx == 0 && h1->qs == 0 && h1->qe == c->seq_len) continue;
+                }
                 bkcall::Contig ct; ct.seq.assign((const char *)b + c->o_seq, c->seq_len); ct.id = "contig" + std::to_string(ci + 1);
                 ct.io = (const int *)(b + c->o_io); ct.ot = (const int *)(b + c->o_ot); ct.clen = c->counts_len; ct.klocs = (const int *)(b + c->o_klocs); ct.nkmers = c->n_kmers;
                 { const uint32_t *rd = (const uint32_t *)(b + c->o_reads); const std::string &tg = cx.rtags[r]; bool same = true; char first = 0;

@@ -186,6 +186,16 @@ __device__ inline void bk_patch_n(uint32_t i, uint8_t *dst, int from, int count)
     for (uint32_t e = lo; e < hi; e++) { const int q = (int)(C_.nlist[e] & 1023u) - from; if (q >= 0 && q < count) dst[q] = BK_CODE_N; }
 }
 
+#ifdef BK_CHECK      // diagnostic build: indices that must hold, recorded (first one wins) in wk->stamps[10..13] instead of being followed
+#define BK_CHK(cond, code, val) ((cond) ? true : (bk_chk_fail((code), (unsigned long long)(val)), false))
+__device__ __noinline__ void bk_chk_fail(int code, unsigned long long val)
+{
+    unsigned long long *st = (unsigned long long *)C_.wk->stamps;
+    if (atomicCAS(&st[10], 0ull, (unsigned long long)code) == 0ull) { st[11] = val; st[12] = ((unsigned long long)C_.unit << 32) | C_.pass; st[13] = ((unsigned long long)S_->serial << 32) | (uint32_t)S_->seed_rank; }
+}
+#else
+#define BK_CHK(cond, code, val) true
+#endif
 // split regions: does k-mer `rk` belong to a component this unit owns in this pass (always true for an unsplit region)
 __device__ inline bool bk_mine(int rk)
 {
@@ -195,7 +205,7 @@ __device__ inline bool bk_mine(int rk)
     return (__hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (0xFFFFu | BK_CI_ABORT)) == C_.want;
 }
 #define BK_UFL0 ((uint8_t *)C_.pairs + bk_align_up((uint64_t)C_.wk->pairs_cap * 12, 256))      // the read flags as they were when the graph was labelled (bk_comp.hip.h: bk_ufl0)
-__device__ inline int bk_seed_at(int i) { return C_.own ? C_.myseeds[i] : i; }      // the i-th seed candidate of this unit (rank; -1: none)
+__device__ inline int bk_seed_at(int i) { if (C_.own && !BK_CHK((uint32_t)i < C_.M2 + 64u, 8, i)) return -1; return C_.own ? C_.myseeds[i] : i; }      // the i-th seed candidate of this unit (rank; -1: none)
 __device__ inline bool bk_acc_has(uint32_t root) { BkAsmShared *S = S_; if (root == S->ccomp) return true; for (uint32_t i = 0; i < S->acc_n; i++) if (C_.acc_root[i] == root) return true; return false; }
 
 // sample k-mer table lookup -> rank or -1 (any state)
@@ -258,6 +268,7 @@ __device__ inline int bk_max256(int v, uint32_t *scr)
 // ---- unpack unique read u into rseq (LDS bytes) ----------------------------------------------------
 __device__ inline void bk_load_read(int u)
 {
+    if (!BK_CHK((uint32_t)u < C_.U, 14, u)) u = 0;
     const uint32_t i = C_.urep[u];
     const int len = C_.rlen[i];
     const uint32_t *w = C_.reads + (uint64_t)i * C_.read_words;
@@ -332,6 +343,7 @@ __device__ inline void bk_note_pair(uint32_t a, uint32_t b, uint32_t kind)
 __device__ inline void bk_meet(uint32_t root)
 {
     BkAsmShared *S = S_;
+    if (!BK_CHK(root < C_.U, 1, root)) { S->status = BK_ST_CONFLICT; S->foreign = 0; S->foreign_root = BK_EMPTY32; return; }
     uint32_t ci = __hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((ci & BK_CI_UNIT) == BK_CI_NOUNIT) { const uint32_t old = atomicCAS(&C_.cinfo[root], ci, C_.want); ci = old == ci ? C_.want : old; }
     if ((ci & (0xFFFFu | BK_CI_ABORT)) == C_.want && S->acc_n < BK_ACC_MAX) {
@@ -654,7 +666,7 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
         if (match) {
             C_.ufl[u] = (uint8_t)(pre_fl | BK_R_USED);
             if (pre_ureads != S->serial) { C_.ureads[u] = S->serial; C_.readl[S->nr++] = (uint32_t)u; }
-            if (grow && pre_found >= 0) { C_.pend[2 * pre_found] = BK_EMPTY32; C_.ufound[u] = -1; }       // buff.remove_contig :638-639
+            if (grow && pre_found >= 0 && BK_CHK((uint32_t)pre_found <= C_.U, 10, pre_found)) { C_.pend[2 * pre_found] = BK_EMPTY32; C_.ufound[u] = -1; }       // buff.remove_contig :638-639
         } else if (pre_kc > 2 && !(pre_fl & BK_R_USED)) {
             if (S->nalt < C_.MAXCAND) C_.altl[S->nalt++] = (uint32_t)u; else S->status = BK_ST_CAND;
         } else C_.ufl[u] = (uint8_t)(pre_fl | BK_R_DELETED);                       // rb.delete -> rb.clean :390
@@ -976,7 +988,7 @@ __device__ __forceinline__ void bk_retire_run(int sl, int s1, bool grow)
             if (match) {
                 C_.ufl[u] = (uint8_t)(my_fl | BK_R_USED);
                 if (to_list) { C_.ureads[u] = S->serial; C_.readl[S->nr + __popcll(lm & below)] = (uint32_t)u; }
-                if (grow && my_found >= 0) { C_.pend[2 * my_found] = BK_EMPTY32; C_.ufound[u] = -1; }
+                if (grow && my_found >= 0 && BK_CHK((uint32_t)my_found <= C_.U, 11, my_found)) { C_.pend[2 * my_found] = BK_EMPTY32; C_.ufound[u] = -1; }
             } else if (to_alt) {
                 const int at = S->nalt + __popcll(am & below);
                 if (at < C_.MAXCAND) C_.altl[at] = (uint32_t)u; else S->status = BK_ST_CAND;
@@ -1178,7 +1190,11 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         const int cap = ((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) || S->clen > BK_NW_DUAL_COLS) ? BK_SPEC_WIDE : BK_SPEC;
         const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
         // look into the following visits when this one leaves slots free (needs the scratch for BK_AT/64 lists of 64 reads)
-        const bool la_on = n - q < cap && !(C_.flags & (vt >= 0 ? BK_F_NO_XVISIT : BK_F_NO_XSEED)) && 2 * C_.MAXCAND >= 4 * BK_AT;
+        // (split regions, bk_comp.hip.h: no look-ahead.  With it the assembler faulted about once in 25 runs of a 64-region noisy batch
+        //  -- wild indices, sometimes a hang -- with either kind of look-ahead switched off never in 120 (tools/probes/soak_flags.sh);
+        //  an iteration that is given up at a meeting leaves in the middle of a round, which no path of the unsplit assembler does
+        //  and the plans were not written for.  The units more than make up for it.)
+        const bool la_on = n - q < cap && !(C_.flags & (vt >= 0 ? BK_F_NO_XVISIT : BK_F_NO_XSEED)) && 2 * C_.MAXCAND >= 4 * BK_AT && (!C_.split || (C_.flags & BK_F_SPLIT_LOOKAHEAD));
         const bool la = la_on && S->la_pause == 0;
         // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
         BK_SYNC();
@@ -1419,7 +1435,8 @@ __device__ __forceinline__ void bk_grow()
             if (C_.ureads[fu] != S->serial) { C_.ureads[fu] = S->serial; C_.readl[S->nr++] = (uint32_t)fu; }
         }
         for (uint32_t t = BK_TID; t < T; t += BK_AT) {
-            const uint32_t en = C_.nklist[t]; const int rank = (int)(en & 0x3FFFFFFFu);
+            const uint32_t en = C_.nklist[t]; int rank = (int)(en & 0x3FFFFFFFu);
+            if (!BK_CHK((uint32_t)rank < C_.M, 7, ((unsigned long long)t << 32) | en)) rank = 0;
             const uint32_t pb = C_.poff[rank], pe = C_.poff[rank + 1];
             bool has = pe - pb > 16u;                                             // long lists take the ordinary visit
             for (uint32_t i = pb; !has && i < pe; i++) { const uint32_t u = C_.post[i] >> 10; has = !(C_.ufl[u] & BK_R_DELETED) && C_.ubuf[u] != S->serial; }
@@ -1432,7 +1449,8 @@ __device__ __forceinline__ void bk_grow()
         uint32_t t = 0, en_next = C_.nklist[0];
         while (t < T) {
             if (S->status) return;
-            const uint32_t en = en_next; const int rank = (int)(en & 0x3FFFFFFFu); const bool rev = (en >> 31) != 0;
+            const uint32_t en = en_next; int rank = (int)(en & 0x3FFFFFFFu); const bool rev = (en >> 31) != 0;
+            if (!BK_CHK((uint32_t)rank < C_.M, 6, ((unsigned long long)t << 32) | en)) { S->status = S->status ? S->status : BK_ST_UNSPLIT; BK_SYNC(); return; }
             if (en & 0x40000000u) {
                 // a run of candidate-less visits, in order: used_mers.add(mer) for each k-mer not yet in it
                 if ((BK_TID >> 6) == 0) {
@@ -1507,7 +1525,7 @@ BK_COLD void bk_emit_contig()
     const int32_t *io = bk_cnt_io(S->cbuf) + S->nbase, *ot = bk_cnt_ot(S->cbuf) + S->nbase;
     for (int t = BK_TID; t < len; t += BK_AT) { oseq[t] = "ACGTN"[cs[t]]; okl[t] = 0; }
     for (int t = BK_TID; t < nlen; t += BK_AT) { oio[t] = io[t]; oot[t] = ot[t]; }
-    for (int t = BK_TID; t < nk; t += BK_AT) { uint32_t rk = C_.klist[t] & 0x7FFFFFFFu; okm[2 * t] = C_.klo[rk]; okm[2 * t + 1] = C_.khi[rk]; }
+    for (int t = BK_TID; t < nk; t += BK_AT) { uint32_t rk = C_.klist[t] & 0x7FFFFFFFu; if (!BK_CHK(rk < C_.M, 4, ((unsigned long long)t << 32) | C_.klist[t])) rk = 0; okm[2 * t] = C_.klo[rk]; okm[2 * t + 1] = C_.khi[rk]; }
     for (int t = BK_TID; t < nr; t += BK_AT) ord_[t] = C_.urep[C_.readl[t]];
     // first occurrence of every sample k-mer in the contig (str.find over all len-k+1 positions)
     // (split regions: the stamps of other units' k-mers are left alone -- only the contig's own k-mers are read back below, and
@@ -1515,6 +1533,7 @@ BK_COLD void bk_emit_contig()
     for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.own || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_has(C_.kroot[rk])))) atomicMin(&C_.kstamp[3 * rk + 2], x); }
     BK_SYNC();
     for (int t = BK_TID; t < nk; t += BK_AT) {
+        if (!BK_CHK((C_.klist[t] & 0x7FFFFFFFu) < C_.M, 5, C_.klist[t])) continue;
         int pos = C_.kstamp[3 * (C_.klist[t] & 0x7FFFFFFFu) + 2];
         if (pos == 0x7FFFFFFF) continue;                 // find() == -1: the python slice [-1:k-1] is empty for len >= k
         for (int q = pos; q < min(pos + k, len); q++) atomicAdd(&okl[q], 1);
@@ -1806,6 +1825,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
             head += BK_AT;
         }
         if (C_.split && !C_.own && (found < 0 || C_.kcnt[found] < BK_SPLIT_HI)) { bk_label_live(); continue; }      // the serial prefix is over: label what is left, the other units start
+        if (found >= 0 && !BK_CHK((uint32_t)found < C_.M, 9, found)) break;
         if (found < 0 || C_.kcnt[found] < 2) break;
         BK_SYNC();
         if (BK_TID == 0) {
@@ -1817,7 +1837,8 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         bk_setup_contigs(found);
         while (!S->status && S->phead < S->ptail) {                                // :50-59
             const int ph = S->phead;
-            const uint32_t prk = C_.pend[2 * ph], pu = C_.pend[2 * ph + 1];
+            uint32_t prk = C_.pend[2 * ph], pu = C_.pend[2 * ph + 1];
+            if (prk != BK_EMPTY32 && !(BK_CHK(prk < C_.M, 12, prk) && BK_CHK(pu < C_.U, 13, pu))) prk = BK_EMPTY32;
             BK_SYNC();
             if (BK_TID == 0) { S->phead = ph + 1; if (prk != BK_EMPTY32) C_.ufound[pu] = -1; }
             BK_SYNC();
@@ -1832,8 +1853,8 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
             // they run again); the unit goes on with its other components.
             BK_SYNC();
             if (BK_TID == 0) {
-                atomicOr(&C_.cinfo[S->ccomp], BK_CI_ABORT);
-                for (uint32_t i = 0; i < S->acc_n; i++) atomicOr(&C_.cinfo[C_.acc_root[i]], BK_CI_ABORT);
+                if (BK_CHK(S->ccomp < C_.U, 2, S->ccomp)) atomicOr(&C_.cinfo[S->ccomp], BK_CI_ABORT);
+                for (uint32_t i = 0; i < S->acc_n; i++) if (BK_CHK(C_.acc_root[i] < C_.U, 3, C_.acc_root[i])) atomicOr(&C_.cinfo[C_.acc_root[i]], BK_CI_ABORT);
                 S->status = 0; S->phead = S->ptail; S->nused = 0; S->nalt = 0; S->plan_ok = 0;
             }
             BK_SYNC();

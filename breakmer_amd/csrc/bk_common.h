@@ -36,7 +36,9 @@ enum {
     BK_ST_CONFLICT = 22       // assembler-internal: the current seed iteration reached a k-mer of another unit's component
 };
 
+#ifndef BK_SPLIT_G
 #define BK_SPLIT_G 16                 // units of a split region (bk_comp.hip.h)
+#endif
 struct BkKey { uint64_t hi, lo; };
 
 __host__ __device__ inline bool key_eq(const BkKey &a, const BkKey &b) { return a.lo == b.lo && a.hi == b.hi; }
@@ -197,7 +199,7 @@ struct BkParams {
     int32_t flags;               // BK_F_*
     const uint32_t *rmap;        // launch over a subset of the batch (re-run of regions that overflowed a cap): workgroup b of the k-mer kernels takes region rmap[b]; nullptr = region b
 };
-enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64, BK_F_NO_SPLIT = 128, BK_F_SPLIT_ALWAYS = 256 };   // 128: every region is one unit (no component split); 256: split whatever the size (diagnostic: the split path on small fixtures)   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
+enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64, BK_F_NO_SPLIT = 128, BK_F_SPLIT_ALWAYS = 256, BK_F_SPLIT_LOOKAHEAD = 512, BK_F_SPLIT = 1024 };   // 1024: noisy regions are split into units (bk_comp.hip.h) -- EXPERIMENTAL, off by default: intermittent device faults under load   // 512: diagnostic -- split regions keep the look-ahead (bk_asm.hip.h: intermittent faults)   // 128: every region is one unit (no component split); 256: split whatever the size (diagnostic: the split path on small fixtures)   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
 
 // component info word (BkRegionWork.o_cinfo, at the component's root read)
 #define BK_CI_UNIT 0xFFu

@@ -39,6 +39,7 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
             }
             __syncthreads();
         }
+#ifdef BK_QUEUE_REGION_MAJOR      // diagnostic: the queue order of the first version (the units of a region behind each other)
     // the queue: one entry per unit -- (region | unit << 24); the units of a split region (bk_comp.hip.h) follow each other, so the
     // heaviest region's components are all in flight at once
     __shared__ uint32_t wsum[BK_SCHED_T / 64], base_s;
@@ -60,5 +61,31 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
         if (tid == 0) base_s += tot;
         __syncthreads();
     }
+#else
+    // the queue: one entry per unit -- (region | unit << 24).  First every region once (unit 0 of a split region, bk_comp.hip.h: it
+    // runs the serial prefix the other units wait for, so all prefixes of a batch start at once however few workgroups are
+    // resident -- with the units of a region behind each other, 64 split regions on 512 resident workgroups ran their prefixes in
+    // two waves), then the other units of the split regions, region by region in the same order.
+    __shared__ uint32_t wsum[BK_SCHED_T / 64], base_s;
+    for (int i = tid; i < n; i += BK_SCHED_T) p.order[i] = (uint32_t)keys[i];
+    if (tid == 0) base_s = (uint32_t)n;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += BK_SCHED_T) {
+        const int i = c0 + tid;
+        uint32_t rid = 0, g = 0;                                             // g: units beyond the first
+        if (i < n) { rid = (uint32_t)keys[i]; const uint32_t sp = p.work[rid].split; g = sp ? sp - 1u : 0u; }
+        uint32_t inc = g;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((tid & 63) >= o) inc += t; }
+        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t pre = base_s, tot = 0;
+        for (int w = 0; w < BK_SCHED_T / 64; w++) { const uint32_t t = wsum[w]; if (w < (tid >> 6)) pre += t; tot += t; }
+        const uint32_t at = pre + inc - g;
+        for (uint32_t u = 0; u < g; u++) p.order[at + u] = rid | ((u + 1u) << BK_QUEUE_UNIT_SHIFT);
+        __syncthreads();
+        if (tid == 0) base_s += tot;
+        __syncthreads();
+    }
+#endif
     if (tid == 0) *p.n_queue = base_s;
 }

@@ -60,6 +60,10 @@ typedef struct bk_config {
                                  *      8 = no look-ahead across k-mer visits, 16 = no look-ahead into the next seeds: same results, more DP rounds;
                                  *      32 = bucket sort of the seed k-mers whatever their number (the path of very large noisy regions),
                                  *      64 = every read retired on its own (no run retire): same results)
+                                 *      1024 = EXPERIMENTAL, off by default: noisy regions (>= 1,024 seed k-mers) are split into up to 16 units that run on
+                                 *      16 workgroups (same results, 2-6x faster on such regions) -- under load the device faults intermittently on
+                                 *      this path (about one run in 25 of a 64-region batch; not understood: DESIGN 4.5), so it is opt-in;
+                                 *      256 = with it, split whatever the size (tests); 128 = never split)
                                  * [1]: assembler workgroup size: 512 = 8 wavefronts / 8 look-ahead slots / 2 per CU (one batch finishes soonest),
                                  *      256 = 4 wavefronts / 4 slots / 4 per CU (most regions/s when batches are in flight), 0 = library chooses
                                  * [2]: 1 = do NOT re-run regions that overflow an assembler cap with larger caps (they fail at once: bk_get_region_status) */

@@ -4,7 +4,7 @@
 tag=${1:-r04}; out=gpurun_out/evidence_$tag; mkdir -p $out
 BK_FUZZ_WG=256 timeout 1500 python3 tools/fuzz_parity.py ${FUZZ_N:-400} 401 > $out/fuzz_parity_wg256.log 2>&1
 BK_FUZZ_WG=512 timeout 1500 python3 tools/fuzz_parity.py ${FUZZ_N:-400} 402 > $out/fuzz_parity_wg512.log 2>&1
-BK_FUZZ_FLAGS=256 timeout 1500 python3 tools/fuzz_parity.py ${FUZZ_N:-400} 403 > $out/fuzz_parity_split_forced.log 2>&1
+BK_FUZZ_FLAGS=1280 timeout 1500 python3 tools/fuzz_parity.py ${FUZZ_N:-400} 403 > $out/fuzz_parity_split_forced.log 2>&1
 timeout 900 python3 tools/stress_batch.py 0 1500 4 > $out/stress_batch.log 2>&1
-timeout 900 python3 tools/stress_batch.py 256 600 3 > $out/stress_batch_split_forced.log 2>&1
+timeout 900 python3 tools/stress_batch.py 1280 600 3 > $out/stress_batch_split_forced.log 2>&1
 tail -n 2 $out/*.log

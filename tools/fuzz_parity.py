@@ -34,7 +34,7 @@ while done < n:
         if r.region_id % 5 == 0:
             fl = synth.rand_bases(synth.stream_key(seed, r.region_id, 9), 2 * 15000)
             r.window = np.concatenate([fl[:15000], r.window, fl[15000:]]).astype(np.uint8)
-    eng = hb.Engine(kmer_size=k, rc_thresh=rc, wg_threads=int(os.environ.get("BK_FUZZ_WG", "0")), flags=int(os.environ.get("BK_FUZZ_FLAGS", "0")))      # BK_FUZZ_FLAGS=256: every region split into units (bk_comp.hip.h)
+    eng = hb.Engine(kmer_size=k, rc_thresh=rc, wg_threads=int(os.environ.get("BK_FUZZ_WG", "0")), flags=int(os.environ.get("BK_FUZZ_FLAGS", "0")))      # BK_FUZZ_FLAGS=1280: every region split into units (experimental, bk_comp.hip.h)
     eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only, partners=[p[4] for p in r.partners]) for r in regs])
     eng.run(hb.BK_STAGE_ALL)
     for i, (r, (rid, kw)) in enumerate(zip(regs, batch)):
