@@ -596,6 +596,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         static const unsigned long long tops[6] = {256, 256, 0, 0, 0, 0};      // arena top, out top, contigs listed, unit queue head, contig queue head, units queued (bk_sched_kernel)
         HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
     }
+    { const char *e = getenv("BK_POISON_ARENA"); if (e && h->d_arena.p) HIPCHK(h, hipMemsetAsync(h->d_arena.p, atoi(e) & 0xFF, h->d_arena.bytes, h->stream)); }      // diagnostic: what an uninitialised read of the scratch arena sees
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     // workgroup sizes: latency mode (one batch at a time) or throughput mode (batches in flight / a batch that fills the chip)
     const int asm_threads = subset ? 512 : h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions > 2 * h->n_cu ? 256 : 512);      // more regions than 512-thread workgroups can be resident at once (2 per CU): the smaller ones keep them all in flight
@@ -640,6 +641,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         const int threads = asm_threads;
         const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
         const size_t lds = asm_lds_bytes(h, threads, max_cand, max_contig);
+        { const char *e = getenv("BK_POISON_LDS"); h->params.asm_lds_bytes = (uint32_t)lds; h->params.poison = e ? (0x100u | (uint32_t)(atoi(e) & 0xFF)) : 0u; }
         HIPCHK(h, set_max_dyn_lds(h->dev, kfn, (int)lds));
         // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)
         const int per_cu = cached_occupancy(h->dev, kfn, threads, lds);

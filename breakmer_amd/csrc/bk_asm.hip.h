@@ -70,7 +70,7 @@ struct BkAsmShared {
     // split regions (bk_comp.hip.h): the component of the current seed, the components its contigs have taken in (same unit or
     // claimed), what bk_kmers_ordered found beyond them
     int seed_rank, emit_seq, t0;
-    uint32_t ccomp, acc_n, foreign, foreign_root;
+    uint32_t ccomp, acc_n, foreign, foreign_root, dirty;
     uint32_t scan[10];
 #ifdef BK_PHASE_STAMPS
     unsigned long long acc[24], last; int ctx;
@@ -206,7 +206,12 @@ __device__ inline bool bk_mine(int rk)
 }
 #define BK_UFL0 ((uint8_t *)C_.pairs + bk_align_up((uint64_t)C_.wk->pairs_cap * 12, 256))      // the read flags as they were when the graph was labelled (bk_comp.hip.h: bk_ufl0)
 __device__ inline int bk_seed_at(int i) { if (C_.own && !BK_CHK((uint32_t)i < C_.M2 + 64u, 8, i)) return -1; return C_.own ? C_.myseeds[i] : i; }      // the i-th seed candidate of this unit (rank; -1: none)
-__device__ inline bool bk_acc_has(uint32_t root) { BkAsmShared *S = S_; if (root == S->ccomp) return true; for (uint32_t i = 0; i < S->acc_n; i++) if (C_.acc_root[i] == root) return true; return false; }
+// the components of the running seed iteration: the seed's own, those taken in (entries of acc_root), and -- bit 31 set -- those of
+// OTHER units it met: their k-mers are left out of the contig's k-mer list and the iteration runs on to its normal end (its component
+// is given up and runs again after the merge; nothing of the other unit's state is touched).  bk_acc_has: known either way;
+// bk_acc_mine: held by this iteration.
+__device__ inline bool bk_acc_has(uint32_t root) { BkAsmShared *S = S_; if (root == S->ccomp) return true; for (uint32_t i = 0; i < S->acc_n; i++) if ((C_.acc_root[i] & 0x7FFFFFFFu) == root) return true; return false; }
+__device__ inline bool bk_acc_mine(uint32_t root) { BkAsmShared *S = S_; if (root == S->ccomp) return true; for (uint32_t i = 0; i < S->acc_n; i++) if (C_.acc_root[i] == root) return true; return false; }
 
 // sample k-mer table lookup -> rank or -1 (any state)
 __device__ inline int bk_lookup(const BkKey &key)
@@ -349,7 +354,11 @@ __device__ inline void bk_meet(uint32_t root)
     if ((ci & (0xFFFFu | BK_CI_ABORT)) == C_.want && S->acc_n < BK_ACC_MAX) {
         bk_note_pair(S->ccomp, root, 0u);
         C_.acc_root[S->acc_n] = root; __threadfence_block(); S->acc_n++;
-    } else { bk_note_pair(S->ccomp, root, 1u); S->status = BK_ST_CONFLICT; }
+    } else {
+        bk_note_pair(S->ccomp, root, 1u);
+        if (S->acc_n < BK_ACC_MAX) { C_.acc_root[S->acc_n] = root | 0x80000000u; __threadfence_block(); S->acc_n++; S->dirty = 1; }      // met, not taken in: the iteration goes on without its k-mers
+        else S->status = BK_ST_CONFLICT;                                    // (no room to remember it: the iteration is left here, as in the first version)
+    }
     S->foreign = 0; S->foreign_root = BK_EMPTY32;
 }
 
@@ -389,7 +398,16 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
             if (!S->foreign) break;
         }
     }
-    if (C_.own) { for (int x = BK_TID; x < np; x += BK_AT) if (tmp[x] >= 0 && (tmp[x] & 0x40000000)) tmp[x] = -1; BK_SYNC(); }
+    if (C_.own) {
+        const bool dirty = S->dirty != 0;                    // (uniform) the iteration has met a component of another unit
+        for (int x = BK_TID; x < np; x += BK_AT) {
+            const int rk = tmp[x];
+            if (rk < 0) continue;
+            if (rk & 0x40000000) { tmp[x] = -1; continue; }
+            if (dirty) { const uint32_t root = C_.kroot[rk]; if (root != BK_EMPTY32 && !bk_acc_mine(root)) tmp[x] = -1; }
+        }
+        BK_SYNC();
+    }
     const int chunk = (max(np, 0) + BK_AT - 1) / BK_AT, b = BK_TID * chunk, e = min(np, b + chunk);
     uint32_t cnt = 0, T;
     for (int x = b; x < e; x++) cnt += tmp[x] >= 0;
@@ -1530,7 +1548,7 @@ BK_COLD void bk_emit_contig()
     // first occurrence of every sample k-mer in the contig (str.find over all len-k+1 positions)
     // (split regions: the stamps of other units' k-mers are left alone -- only the contig's own k-mers are read back below, and
     // those all belong to components this unit holds)
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.own || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_has(C_.kroot[rk])))) atomicMin(&C_.kstamp[3 * rk + 2], x); }
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.own || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_mine(C_.kroot[rk])))) atomicMin(&C_.kstamp[3 * rk + 2], x); }
     BK_SYNC();
     for (int t = BK_TID; t < nk; t += BK_AT) {
         if (!BK_CHK((C_.klist[t] & 0x7FFFFFFFu) < C_.M, 5, C_.klist[t])) continue;
@@ -1539,7 +1557,7 @@ BK_COLD void bk_emit_contig()
         for (int q = pos; q < min(pos + k, len); q++) atomicAdd(&okl[q], 1);
     }
     BK_SYNC();
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.own || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_has(C_.kroot[rk])))) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
+    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.own || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_mine(C_.kroot[rk])))) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
     if (BK_TID == 0) {
         h->root = S->ccomp; h->pass = C_.want;
         h->next = 0; h->hits_off = 0; h->seq_len = len; h->counts_len = nlen; h->n_kmers = nk; h->n_reads = nr; h->total_reads = total; h->n_hits = 0;
@@ -1737,6 +1755,15 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
 {
     BkAsmShared *S = S_;
     BkRegionWork *wk = &p.work[r];
+    if (p.poison) {      // diagnostic: everything but the queue slot word of the shared state
+        const int keep = S->qslot;
+        BK_SYNC();
+        const uint32_t v = (p.poison & 0xFFu) * 0x01010101u;
+        for (uint32_t i = BK_TID; i < p.asm_lds_bytes / 4; i += BK_AT) ((uint32_t *)bk_lds)[i] = v;
+        BK_SYNC();
+        if (BK_TID == 0) S->qslot = keep;
+        BK_SYNC();
+    }
     if (__hip_atomic_load(&wk->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BK_ST_OK && !wk->split) return;              // k-mer stage failed for this region (a split region: another unit may have failed meanwhile; this one still reports in below)
     if (BK_TID == 0) {
         const BkRegionDesc d = p.desc[r];
@@ -1767,7 +1794,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
             c.kroot = (const uint32_t *)(p.arena + wk->o_kroot); c.cinfo = (uint32_t *)(p.arena + wk->o_cinfo);
             c.cidx_key = (unsigned long long *)(p.arena + wk->o_cidx); c.pairs = (uint32_t *)(p.arena + wk->o_pairs);
         }
-        S->ccomp = 0; S->acc_n = 0; S->foreign = 0; S->foreign_root = BK_EMPTY32; S->seed_rank = 0; S->emit_seq = 0; S->t0 = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull);
+        S->ccomp = 0; S->acc_n = 0; S->dirty = 0; S->foreign = 0; S->foreign_root = BK_EMPTY32; S->seed_rank = 0; S->emit_seq = 0; S->t0 = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull);
         c.tslot = (const uint32_t *)(p.arena + wk->o_tslot);
         c.klo = (const uint64_t *)(p.arena + wk->o_key_lo); c.khi = (const uint64_t *)(p.arena + wk->o_key_hi);
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
@@ -1829,7 +1856,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         if (found < 0 || C_.kcnt[found] < 2) break;
         BK_SYNC();
         if (BK_TID == 0) {
-            S->head = fidx; S->seed_rank = found; S->emit_seq = 0; S->acc_n = 0; S->ccomp = C_.own ? C_.kroot[found] : BK_EMPTY32;
+            S->head = fidx; S->seed_rank = found; S->emit_seq = 0; S->acc_n = 0; S->dirty = 0; S->ccomp = C_.own ? C_.kroot[found] : BK_EMPTY32;
             if (C_.split) C_.wk->unit_iters[C_.unit]++;
         }
         BK_SYNC();
@@ -1847,15 +1874,15 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
             bk_grow();
             if (!S->status) bk_emit_contig();
         }
-        if (S->status == BK_ST_CONFLICT) {
+        if (S->status == BK_ST_CONFLICT || (S->dirty && !S->status)) {
             // The iteration met a component of another unit: nothing of that unit's state was touched.  The seed's component and
             // what its contigs had taken in are given up for this pass (bk_resolve_kernel merges them with what they met and
             // they run again); the unit goes on with its other components.
             BK_SYNC();
             if (BK_TID == 0) {
                 if (BK_CHK(S->ccomp < C_.U, 2, S->ccomp)) atomicOr(&C_.cinfo[S->ccomp], BK_CI_ABORT);
-                for (uint32_t i = 0; i < S->acc_n; i++) if (BK_CHK(C_.acc_root[i] < C_.U, 3, C_.acc_root[i])) atomicOr(&C_.cinfo[C_.acc_root[i]], BK_CI_ABORT);
-                S->status = 0; S->phead = S->ptail; S->nused = 0; S->nalt = 0; S->plan_ok = 0;
+                for (uint32_t i = 0; i < S->acc_n; i++) if (!(C_.acc_root[i] & 0x80000000u) && BK_CHK(C_.acc_root[i] < C_.U, 3, C_.acc_root[i])) atomicOr(&C_.cinfo[C_.acc_root[i]], BK_CI_ABORT);      // (not the other units' components it met)
+                S->status = 0; S->dirty = 0; S->phead = S->ptail; S->nused = 0; S->nalt = 0; S->plan_ok = 0;
             }
             BK_SYNC();
             bk_build_myseeds(1);                                 // (what was given up leaves the unit's seed list)
