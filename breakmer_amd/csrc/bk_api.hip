@@ -640,7 +640,8 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         // chip is full.  bk_config.reserved[1] = 256 / 512 chooses; 0 = 512 unless the batch alone fills the chip twice.
         const int threads = asm_threads;
         const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
-        const size_t lds = asm_lds_bytes(h, threads, max_cand, max_contig);
+        const size_t lds = asm_lds_bytes(h, threads, max_cand, max_contig) + (getenv("BK_LDS_PAD") ? (size_t)(atoi(getenv("BK_LDS_PAD")) & ~15) : 0);
+        { const char *e = getenv("BK_LDS_PAD"); h->params.asm_lds_pad = e ? (uint32_t)(atoi(e) & ~15) : 0u; }
         { const char *e = getenv("BK_POISON_LDS"); h->params.asm_lds_bytes = (uint32_t)lds; h->params.poison = e ? (0x100u | (uint32_t)(atoi(e) & 0xFF)) : 0u; }
         HIPCHK(h, set_max_dyn_lds(h->dev, kfn, (int)lds));
         // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)
@@ -765,6 +766,7 @@ static int sync_impl(bk_handle *h)
                         h->n_repair_passes, redo.size(), unsplit.size(), ns_, np_, nc_, nx_, ms[1], ms[2], ms[3]);
                 for (int r = 0; r < h->n_regions && r < 4; r++) { const BkRegionWork &w = h->h_work[r]; if (!w.split) continue;
                     fprintf(stderr, "   region %d  U %u M %u M2 %u  open conflicts %u; unit 0: prefix %u us, labelling %u us, seed list %u us; unit us/iterations:", r, w.U, w.M, w.M2, w.n_conf, w.dbg_us[0], w.dbg_us[1], w.dbg_us[2]); for (int g = 0; g < BK_SPLIT_G; g++) fprintf(stderr, " %u/%u", w.unit_us[g], w.unit_iters[g]); fprintf(stderr, "\n"); }
+                for (int r = 0; r < h->n_regions; r++) { const BkRegionWork &w = h->h_work[r]; if (w.stamps[14]) fprintf(stderr, "   LDS GUARD region %d: first byte written behind the block at +%llu (value 0x%llx)\n", r, (unsigned long long)w.stamps[14] - 1, (unsigned long long)w.stamps[15]); }
                 for (int r = 0; r < h->n_regions; r++) { const BkRegionWork &w = h->h_work[r]; if (w.split && w.stamps[10]) fprintf(stderr, "   CHECK region %d: code %llu value 0x%llx unit/pass 0x%llx serial/seed 0x%llx (U %u M %u M2 %u)\n", r, (unsigned long long)w.stamps[10], (unsigned long long)w.stamps[11], (unsigned long long)w.stamps[12], (unsigned long long)w.stamps[13], w.U, w.M, w.M2); }
                 fprintf(stderr, "   all split regions, prefix+labelling+slowest unit (ms):");
                 for (int r = 0; r < h->n_regions; r++) { const BkRegionWork &w = h->h_work[r]; if (!w.split) continue; uint32_t mx = 0; for (int g = 0; g < BK_SPLIT_G; g++) mx = std::max(mx, w.unit_us[g]);

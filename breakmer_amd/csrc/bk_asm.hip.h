@@ -1764,6 +1764,11 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         if (BK_TID == 0) S->qslot = keep;
         BK_SYNC();
     }
+    if (p.asm_lds_pad) {      // diagnostic: the guard band behind the block
+        BK_SYNC();
+        for (uint32_t i = BK_TID; i < p.asm_lds_pad / 4; i += BK_AT) ((uint32_t *)(bk_lds + p.asm_lds_bytes - p.asm_lds_pad))[i] = 0xA5A5A5A5u;
+        BK_SYNC();
+    }
     if (__hip_atomic_load(&wk->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BK_ST_OK && !wk->split) return;              // k-mer stage failed for this region (a split region: another unit may have failed meanwhile; this one still reports in below)
     if (BK_TID == 0) {
         const BkRegionDesc d = p.desc[r];
@@ -1917,6 +1922,14 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
                 else if (nc_ > 0) atomicCAS((int *)&C_.wk->status, BK_ST_OK, BK_ST_REDO);
             }
         }
+    }
+    if (p.asm_lds_pad) {
+        BK_SYNC();
+        for (uint32_t i = BK_TID; i < p.asm_lds_pad / 4; i += BK_AT) {
+            const uint32_t v = ((uint32_t *)(bk_lds + p.asm_lds_bytes - p.asm_lds_pad))[i];
+            if (v != 0xA5A5A5A5u) { unsigned long long *st = (unsigned long long *)wk->stamps; if (atomicCAS(&st[14], 0ull, (unsigned long long)(4 * i + 1)) == 0ull) st[15] = v; }
+        }
+        BK_SYNC();
     }
 #ifdef BK_PHASE_STAMPS
     if (BK_TID == 0) for (int i = 0; i < 20; i++) { if (C_.split) atomicAdd((unsigned long long *)&C_.wk->stamps[i], (unsigned long long)S->acc[i]); else C_.wk->stamps[i] = S->acc[i]; }      // split regions: summed over the units (and passes)
