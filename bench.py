@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
     ap.add_argument("--cfg3-regions", type=int, default=4096, help="batch size of the configs[3] side measurement (heavy regions: the chip fills at a few thousand)")
     ap.add_argument("--cfg4-regions", type=int, default=768, help="batch size of the configs[4] side measurement: a region's chain of ~19,000 dependent rounds takes ~3 s whatever runs beside it, so regions in flight ARE the throughput (256: 69 regions/s, 512: 101, 768: 121) until the scratch arena (~270 MB per region) fills the HBM (896 no longer fit)")
+    ap.add_argument("--side-configs-only", type=int, default=0, help="internal: print the side measurements (configs[3], configs[4], noisy batch) as one JSON object and exit")
     ap.add_argument("--split-experimental", type=int, default=0, help="also time the noisy side configuration with the experimental component split (off by default: intermittent device faults, DESIGN 4.5)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic library flags (bk_config.reserved[0]); 0 in every reported number")
     ap.add_argument("--lib", default=None, help="diagnostic: path of an alternative build of the library (A/B runs on one box)")
@@ -125,6 +126,30 @@ def make_regions_parallel(kind, n):
         return [_gen_region((kind, i)) for i in range(n)]
     with mp.get_context("spawn").Pool(min(cores, 16)) as pool:
         return pool.map(_gen_region, [(kind, i) for i in range(n)], chunksize=4)
+
+
+def side_configs(a, hb, synth, opts, local):
+    """BASELINE configs[3] / configs[4] and the noisy 64-region batch on one GPU (whole path incl. call tail, inputs resident)"""
+    oc = {}
+    try:
+        regs3 = [cfg3_region(synth, i) for i in range(a.cfg3_regions)]
+        oc["configs[3]"] = time_other_config(hb, regs3, 31, opts, 2, local)
+        oc["configs[3]"]["workload"] = "mixed SV set (indel/inv/dup/trl + partner window), 1,000x 150 bp, k=31"
+        del regs3
+        regs4 = make_regions_parallel("cfg4", a.cfg4_regions)
+        oc["configs[4]"] = time_other_config(hb, regs4, 41, opts, 1, local)
+        oc["configs[4]"]["workload"] = "250 bp reads at 2,000x, k=41, 5 % substitution noise"
+        del regs4
+        # the standing round-1 bar: one launch of 64 configs[1]-shaped regions at 0.5 % substitution noise (< 0.1 s asked for)
+        regsn = [synth.make_region(50000 + i, depth=a.depth, L=a.read_len, sv_type="del", noise=0.005) for i in range(64)]
+        oc["noise_0.5pct_64_regions"] = time_other_config(hb, regsn, a.kmer, opts, 2, local)
+        oc["noise_0.5pct_64_regions"]["workload"] = "64 regions of the configs[1] shape with 0.5 % substitution noise per base, one launch (seconds per launch = ms_per_batch / 1000)"
+        if a.split_experimental:                 # opt-in: the component split (bk_config.reserved[0] bit 1024) -- it can fault the device (DESIGN 4.5)
+            oc["noise_0.5pct_64_regions_split_experimental"] = time_other_config(hb, regsn, a.kmer, opts, 2, local, flags=1024)
+        del regsn
+    except Exception as ex:                      # never lose what was measured to a later side measurement
+        oc["error"] = repr(ex)
+    return oc
 
 
 def time_other_config(hb, regions, k, opts, reps, device, flags=0):
@@ -234,6 +259,11 @@ def _cpu_region(args):
 
 def main():
     a = parse()
+    if a.side_configs_only:                                  # child of the default run: the side measurements in a process of their own
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        from breakmer_amd import hip_backend as hb, synth
+        print(json.dumps(side_configs(a, hb, synth, default_opts(), int(os.environ.get("LOCAL_RANK", "0")))), flush=True)
+        return
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(a))
     # ---- CPU baseline on ALL host cores (process pool over regions through the C oracle).  Runs first, before anything
@@ -555,25 +585,17 @@ def main():
                 out["runner_end_to_end"] = {"error": repr(ex)}
         # ---- other BASELINE configs on one GPU (not the headline; whole path incl. call tail, inputs resident) -----
         if world == 1 and a.other_configs:
-            oc = {}
+            # In a process of their own: a device fault in one of these side measurements ("known defect": noisy regions under
+            # load) must not take the headline line with it.  The child prints one JSON object; anything else becomes an "error" entry.
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--side-configs-only", "1", "--kmer", str(a.kmer), "--depth", str(a.depth), "--read-len", str(a.read_len),
+                   "--cfg3-regions", str(a.cfg3_regions), "--cfg4-regions", str(a.cfg4_regions), "--split-experimental", str(a.split_experimental)]
             try:
-                regs3 = [cfg3_region(synth, i) for i in range(a.cfg3_regions)]
-                oc["configs[3]"] = time_other_config(hb, regs3, 31, opts, 2, local)
-                oc["configs[3]"]["workload"] = "mixed SV set (indel/inv/dup/trl + partner window), 1,000x 150 bp, k=31"
-                del regs3
-                regs4 = make_regions_parallel("cfg4", a.cfg4_regions)
-                oc["configs[4]"] = time_other_config(hb, regs4, 41, opts, 1, local)
-                oc["configs[4]"]["workload"] = "250 bp reads at 2,000x, k=41, 5 % substitution noise"
-                del regs4
-                # the standing round-1 bar: one launch of 64 configs[1]-shaped regions at 0.5 % substitution noise (< 0.1 s asked for)
-                regsn = [synth.make_region(50000 + i, depth=a.depth, L=a.read_len, sv_type="del", noise=0.005) for i in range(64)]
-                oc["noise_0.5pct_64_regions"] = time_other_config(hb, regsn, a.kmer, opts, 2, local)
-                oc["noise_0.5pct_64_regions"]["workload"] = "64 regions of the configs[1] shape with 0.5 % substitution noise per base, one launch (seconds per launch = ms_per_batch / 1000)"
-                if a.split_experimental:                 # opt-in: the component split (bk_config.reserved[0] bit 1024) -- it can fault the device
-                    oc["noise_0.5pct_64_regions_split_experimental"] = time_other_config(hb, regsn, a.kmer, opts, 2, local, flags=1024)
-                del regsn
-            except Exception as ex:                      # never lose the headline line to a side measurement
-                oc["error"] = repr(ex)
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+                lines = [ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")]
+                oc = json.loads(lines[-1]) if (pr.returncode == 0 and lines) else {"error": "side measurements ended with code %d" % pr.returncode, "stderr_tail": pr.stderr[-400:]}
+            except Exception as ex:
+                oc = {"error": repr(ex)}
             out["other_configs"] = oc
         # ---- CPU baseline: the oracle (C port of the reference algorithm) on the host cores, bounded sample -------
         if world == 1 and a.cpu_sample > 0:
