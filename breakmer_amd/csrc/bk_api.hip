@@ -642,6 +642,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
         const size_t lds = asm_lds_bytes(h, threads, max_cand, max_contig) + (getenv("BK_LDS_PAD") ? (size_t)(atoi(getenv("BK_LDS_PAD")) & ~15) : 0);
         { const char *e = getenv("BK_LDS_PAD"); h->params.asm_lds_pad = e ? (uint32_t)(atoi(e) & ~15) : 0u; }
+        { const char *e = getenv("BK_DBG_ITERS"); h->params.dbg_iters = e ? (uint32_t)atoi(e) : 0u; }
         { const char *e = getenv("BK_POISON_LDS"); h->params.asm_lds_bytes = (uint32_t)lds; h->params.poison = e ? (0x100u | (uint32_t)(atoi(e) & 0xFF)) : 0u; }
         HIPCHK(h, set_max_dyn_lds(h->dev, kfn, (int)lds));
         // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)

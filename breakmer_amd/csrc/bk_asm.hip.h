@@ -117,7 +117,16 @@ struct BkAsmCtx {
 #define BK_COLD __device__ inline
 #endif
 #define BK_TID ((int)threadIdx.x)
+#ifdef BK_JITTER      // diagnostic build: after every workgroup barrier ONE wavefront (which one depends on the source line) sleeps a few microseconds --
+                      // code that silently relies on the wavefronts staying in step after a barrier (a missing second barrier) then goes wrong at any load
+#ifndef BK_JIT_LO
+#define BK_JIT_LO 0
+#define BK_JIT_HI 1000000
+#endif
+#define BK_SYNC() do { __syncthreads(); if (__LINE__ >= BK_JIT_LO && __LINE__ < BK_JIT_HI && (((int)(BK_TID >> 6)) + __LINE__ * BK_JITTER) % (BK_AT / 64) == 0) __builtin_amdgcn_s_sleep(100); } while (0)
+#else
 #define BK_SYNC() __syncthreads()
+#endif
 #ifdef BK_PHASE_STAMPS      // diagnostic build only: where does a region's time go (s_memrealtime, 100 MHz)
 #define BK_ACC(i) do { if (BK_TID == 0) { unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); S_->acc[i] += now_ - S_->last; S_->last = now_; } } while (0)
 #else
@@ -613,8 +622,10 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
     if (BK_TID == 0) { pre_fl = C_.ufl[u]; pre_ureads = C_.ureads[u]; pre_kc = C_.kcnt[rank]; if (grow) pre_found = C_.ufound[u]; }
     int ds = 0, de = 0;                             // uniform: computed identically by every thread
     bool tie = false;
+    bool synced = false;                            // (uniform) a barrier has been passed since this function was entered
     int dec = bk_decide(v1, v2, clen, rl, ds, de, tie);
     if (tie) {
+        synced = true;
         // k-mer position tie-break: x.replace('-','') of the aligned strings are the plain slices
         if (wv == 0) {
             BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank];
@@ -638,6 +649,7 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
     const bool match = dec != BK_DEC_NONE;
     bool ext = false;                                   // contig was extended (POST / PRE): new k-mers in grow mode
     if (dec == BK_DEC_SUPER) {                                                    // aseq.set_superseq :232-236 (rare: separate phases)
+        synced = true;
         bk_counts_superseq(rl, nreads, indel, ds, de);
         const int base = C_.MAXC - rl;
         for (int t = BK_TID; t < rl; t += BK_AT) L_CSEQ[base + t] = rseq[t];
@@ -667,6 +679,7 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
             // this barrier a wavefront that is late into this function (starved by co-resident workgroups) reads the
             // NEW base and updates a range shifted by the prepended length.
             BK_SYNC();
+            synced = true;
             if (BK_TID == 0 && dec != BK_DEC_SUB) {
                 if (dec == BK_DEC_PRE) { S->cbase = cbase - pl; S->nbase = nbase - pl; S->pc += pl; }
                 S->clen = clen + pl; S->nlen = nlen + pl;
@@ -674,7 +687,13 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
             ext = dec != BK_DEC_SUB;
         }
     }
-    // check_read bookkeeping (:552-565)
+    // check_read bookkeeping (:552-565).  It replaces words the CALLER's control flow reads right before this call, on every wavefront
+    // for itself (S->last_dec in bk_retire_checked, the acceptance counters in bk_expect_reject: which retire path is taken, whether the
+    // prediction held): a wavefront that is late into this call must have read them before thread 0 writes -- a read that changes
+    // nothing (dec NONE / SAME) passes no barrier on its way here, and a late wavefront then took another path than the others,
+    // with other barriers (found with a sleeping wavefront behind every barrier, -DBK_JITTER: wrong fixtures at any load; in the
+    // field: faults and hangs once several noisy workgroups share a CU).
+    if (!synced) BK_SYNC();
     if (BK_TID == 0) {
         S->last_dec = dec; S->hit = match ? 1 : 0;
         if (match) S->n_acc++; else S->n_rej++;
@@ -1844,6 +1863,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
     if (C_.M == 0 && !C_.split) { if (BK_TID == 0) wk->n_contigs = 0; return; }                 // init_assembly :33-34
     if (S->status && !C_.split) { if (BK_TID == 0) wk->status = S->status; return; }
     // ---- init_assembly main loop (:43-62) --------------------------------------------------------------
+    uint32_t iters_done = 0;
     while (!S->status) {
         // first k-mer still in akmers.mers in (count, mer) descending order; has_mers (:318-322) <=> its count > 1
         // (the seed-capable k-mers are ranks 0 .. M2-1; a unit of a split region takes those of its own components)
@@ -1859,6 +1879,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         if (C_.split && !C_.own && (found < 0 || C_.kcnt[found] < BK_SPLIT_HI)) { bk_label_live(); continue; }      // the serial prefix is over: label what is left, the other units start
         if (found >= 0 && !BK_CHK((uint32_t)found < C_.M, 9, found)) break;
         if (found < 0 || C_.kcnt[found] < 2) break;
+        if (p.dbg_iters && iters_done++ >= p.dbg_iters) break;      // diagnostic (uniform)
         BK_SYNC();
         if (BK_TID == 0) {
             S->head = fidx; S->seed_rank = found; S->emit_seq = 0; S->acc_n = 0; S->dirty = 0; S->ccomp = C_.own ? C_.kroot[found] : BK_EMPTY32;

@@ -193,7 +193,8 @@ struct BkParams {
     // scheduling (bk_sched.hip.h): regions in descending order of estimated assembler cost, pulled by persistent
     // workgroups; every emitted contig is appended to `clist` (its `out` offset | region << 40), pulled by the realigner
     uint32_t *order; unsigned long long *asm_head, *sw_head, *n_clist, *n_queue; unsigned long long *clist; uint64_t clist_cap;
-    uint32_t asm_lds_pad, asm_lds_pad2_;      // diagnostic (BK_LDS_PAD=<bytes>): a guard band behind the assembler's LDS block, filled before and checked after every region (BkRegionWork.stamps[14..15])
+    uint32_t asm_lds_pad, dbg_iters;      // dbg_iters (BK_DBG_ITERS=k): diagnostic -- every region stops after k seed iterations (0: no limit)
+    //      // diagnostic (BK_LDS_PAD=<bytes>): a guard band behind the assembler's LDS block, filled before and checked after every region (BkRegionWork.stamps[14..15])
     uint32_t asm_lds_bytes, poison;      // diagnostic (BK_POISON_LDS=<byte>): the assembler's LDS block is filled with this byte before every region (an uninitialised read then behaves the same whatever ran on the CU before)
     unsigned long long *sw_long, *n_sw_long, *sw_long_head;      // contigs too long for the realigner's SHORT tier (bk_sw.hip.h): same entries as clist, same capacity      // order: (region | unit << 24) entries, *n_queue of them
     int32_t k, rc_thresh, max_contig, max_read, max_cand, sw_min_score;

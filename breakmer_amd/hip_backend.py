@@ -84,10 +84,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.isfile(LIB_PATH):
+    if not os.path.isfile(os.environ.get("BK_LIB") or LIB_PATH):
         raise BreakmerHipError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(os.environ.get("BK_LIB") or LIB_PATH)      # (BK_LIB: diagnostic -- another build of the library)
     L.bk_last_error.restype = C.c_char_p
     L.bk_last_error.argtypes = [C.c_void_p]
     L.bk_create.argtypes = [C.c_int, C.POINTER(BkConfig), C.POINTER(C.c_void_p)]
