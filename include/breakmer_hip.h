@@ -61,8 +61,8 @@ typedef struct bk_config {
                                  *      32 = bucket sort of the seed k-mers whatever their number (the path of very large noisy regions),
                                  *      64 = every read retired on its own (no run retire): same results)
                                  *      1024 = EXPERIMENTAL, off by default: noisy regions (>= 1,024 seed k-mers) are split into up to 16 units that run on
-                                 *      16 workgroups (same results, 2-6x faster on such regions) -- under load the device faults intermittently on
-                                 *      this path (about one run in 25 of a 64-region batch; not understood: DESIGN 4.5), so it is opt-in;
+                                 *      16 workgroups (same results, 2-6x faster on such regions); opt-in for this round (the evidence
+                                 *      has not been repeated with it switched on since the barrier fix of DESIGN 7);
                                  *      256 = with it, split whatever the size (tests); 128 = never split)
                                  * [1]: assembler workgroup size: 512 = 8 wavefronts / 8 look-ahead slots / 2 per CU (one batch finishes soonest),
                                  *      256 = 4 wavefronts / 4 slots / 4 per CU (most regions/s when batches are in flight), 0 = library chooses
