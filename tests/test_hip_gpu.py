@@ -231,6 +231,25 @@ def test_split_regions_are_bit_identical_gpu(hb, golden_dir):
             assert one.hits(i, ci) == many.hits(i, ci), (i, ci)
 
 
+def test_assembler_does_not_depend_on_wavefront_timing_gpu(tmp_path):
+    """A build of the library in which ONE wavefront sleeps behind every workgroup barrier of the assembler (-DBK_JITTER: legal at any
+    time, so anything that goes wrong with it is a race) must give the reference fixtures like the product build.  This is how the
+    missing barrier of bk_retire was found in round 4: without it a wavefront that was late into the call took another
+    path than its workgroup -- faults and hangs once several noisy workgroups shared a CU.  Runs in a process of its own."""
+    import shutil, subprocess, sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.isfile(hipcc) and not shutil.which(hipcc):
+        pytest.skip("no hipcc on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = str(tmp_path / "libbreakmer_hip_jitter.so")
+    for k in (3,):
+        b = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result", "-DBK_JITTER=%d" % k, "-o", lib, "bk_api.hip"],
+                           cwd=os.path.join(root, "breakmer_amd", "csrc"), capture_output=True, text=True, timeout=600)
+        assert b.returncode == 0, b.stderr[-2000:]
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "g3_check.py")], env=dict(os.environ, BK_LIB=lib), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "wrong: 0" in r.stdout, (k, r.returncode, r.stdout[-500:], r.stderr[-500:])
+
+
 def test_batch_vs_oracle_gpu(hb):
     """A mixed batch (config-2-like regions at reduced depth) against the C oracle."""
     from oracle import bk_oracle as bo
