@@ -144,8 +144,6 @@ def side_configs(a, hb, synth, opts, local):
         regsn = [synth.make_region(50000 + i, depth=a.depth, L=a.read_len, sv_type="del", noise=0.005) for i in range(64)]
         oc["noise_0.5pct_64_regions"] = time_other_config(hb, regsn, a.kmer, opts, 2, local)
         oc["noise_0.5pct_64_regions"]["workload"] = "64 regions of the configs[1] shape with 0.5 % substitution noise per base, one launch (seconds per launch = ms_per_batch / 1000)"
-        if a.split_experimental:                 # opt-in: the component split (bk_config.reserved[0] bit 1024) -- it can fault the device
-            oc["noise_0.5pct_64_regions_split_experimental"] = time_other_config(hb, regsn, a.kmer, opts, 2, local, flags=1024)
         del regsn
     except Exception as ex:                      # never lose what was measured to a later side measurement
         oc["error"] = repr(ex)
@@ -262,6 +260,12 @@ def main():
     if a.side_configs_only:                                  # child of the default run: the side measurements in a process of their own
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         from breakmer_amd import hip_backend as hb, synth
+        if a.side_configs_only == 2:                         # the experimental component split alone (it has faulted the device before the fix of DESIGN 7: its own process)
+            regsn = [synth.make_region(50000 + i, depth=a.depth, L=a.read_len, sv_type="del", noise=0.005) for i in range(64)]
+            oc = {"noise_0.5pct_64_regions_split_experimental": time_other_config(hb, regsn, a.kmer, default_opts(), 2, int(os.environ.get("LOCAL_RANK", "0")), flags=1024)}
+            oc["noise_0.5pct_64_regions_split_experimental"]["workload"] = "the same 64 noisy regions with bk_config.reserved[0] bit 1024: every region split into up to 16 units (opt-in this round, DESIGN 4.5)"
+            print(json.dumps(oc), flush=True)
+            return
         print(json.dumps(side_configs(a, hb, synth, default_opts(), int(os.environ.get("LOCAL_RANK", "0")))), flush=True)
         return
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -596,6 +600,13 @@ def main():
                 oc = json.loads(lines[-1]) if (pr.returncode == 0 and lines) else {"error": "side measurements ended with code %d" % pr.returncode, "stderr_tail": pr.stderr[-400:]}
             except Exception as ex:
                 oc = {"error": repr(ex)}
+            try:                                             # ... and the experimental split in a process of ITS own, so that it cannot cost the others
+                cmd2 = [sys.executable, os.path.abspath(__file__), "--side-configs-only", "2", "--kmer", str(a.kmer), "--depth", str(a.depth), "--read-len", str(a.read_len)]
+                pr2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=300)
+                lines2 = [ln for ln in pr2.stdout.strip().splitlines() if ln.startswith("{")]
+                oc.update(json.loads(lines2[-1]) if (pr2.returncode == 0 and lines2) else {"noise_0.5pct_64_regions_split_experimental": {"error": "ended with code %d" % pr2.returncode}})
+            except Exception as ex:
+                oc["noise_0.5pct_64_regions_split_experimental"] = {"error": repr(ex)}
             out["other_configs"] = oc
         # ---- CPU baseline: the oracle (C port of the reference algorithm) on the host cores, bounded sample -------
         if world == 1 and a.cpu_sample > 0:
