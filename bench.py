@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument("--cfg3-regions", type=int, default=4096, help="batch size of the configs[3] side measurement (heavy regions: the chip fills at a few thousand)")
     ap.add_argument("--cfg4-regions", type=int, default=768, help="batch size of the configs[4] side measurement: a region's chain of ~19,000 dependent rounds takes ~3 s whatever runs beside it, so regions in flight ARE the throughput (256: 69 regions/s, 512: 101, 768: 121) until the scratch arena (~270 MB per region) fills the HBM (896 no longer fit)")
     ap.add_argument("--side-configs-only", type=int, default=0, help="internal: print the side measurements (configs[3], configs[4], noisy batch) as one JSON object and exit")
-    ap.add_argument("--split-experimental", type=int, default=0, help="also time the noisy side configuration with the experimental component split (off by default: intermittent device faults, DESIGN 4.5)")
+    ap.add_argument("--split-experimental", type=int, default=0, help="(ignored: the component split of noisy regions is the default since round 5)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic library flags (bk_config.reserved[0]); 0 in every reported number")
     ap.add_argument("--lib", default=None, help="diagnostic: path of an alternative build of the library (A/B runs on one box)")
     ap.add_argument("--dump-collated", default=None, help="write the bytes collated in the last step to this file (testing)")
@@ -260,10 +260,10 @@ def main():
     if a.side_configs_only:                                  # child of the default run: the side measurements in a process of their own
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         from breakmer_amd import hip_backend as hb, synth
-        if a.side_configs_only == 2:                         # the experimental component split alone (it has faulted the device before the fix of DESIGN 7: its own process)
+        if a.side_configs_only == 2:                         # the same noisy batch with one unit per region (how every region ran until round 4): the comparison figure
             regsn = [synth.make_region(50000 + i, depth=a.depth, L=a.read_len, sv_type="del", noise=0.005) for i in range(64)]
-            oc = {"noise_0.5pct_64_regions_split_experimental": time_other_config(hb, regsn, a.kmer, default_opts(), 2, int(os.environ.get("LOCAL_RANK", "0")), flags=1024)}
-            oc["noise_0.5pct_64_regions_split_experimental"]["workload"] = "the same 64 noisy regions with bk_config.reserved[0] bit 1024: every region split into up to 16 units (opt-in this round, DESIGN 4.5)"
+            oc = {"noise_0.5pct_64_regions_one_unit": time_other_config(hb, regsn, a.kmer, default_opts(), 2, int(os.environ.get("LOCAL_RANK", "0")), flags=128)}
+            oc["noise_0.5pct_64_regions_one_unit"]["workload"] = "the same 64 noisy regions with bk_config.reserved[0] bit 128: no component split, one assembler workgroup per region (the default until round 4)"
             print(json.dumps(oc), flush=True)
             return
         print(json.dumps(side_configs(a, hb, synth, default_opts(), int(os.environ.get("LOCAL_RANK", "0")))), flush=True)
@@ -304,7 +304,7 @@ def main():
             td.init_process_group("nccl", device_id=torch.device("cuda", local))
     from breakmer_amd import hip_backend as hb, synth, collate
     if a.lib:
-        hb.LIB_PATH = os.path.abspath(a.lib)
+        hb.load_library(os.path.abspath(a.lib))
     # The SAME batch per GPU per step at every N (weak scaling: the 1 -> 8 GPU curve compares like with like; a larger batch
     # raises per-GPU throughput by itself on this latency-bound path).  256 = configs[1] on each GPU; at N = 8 configs[2]'s
     # 4,096 regions are two consecutive steps of 8 x 256 (with 6 steps in flight 1,536 regions per GPU are resident anyway).
@@ -449,6 +449,16 @@ def main():
     total_regions = n_regions * world * a.steps
     value = total_regions / dt
     collated = gstate["collated"]
+    # The same loop over >= 100 steps: with K = 20 the timed region is 22 ms and holds the fill and drain of the 6-deep pipeline
+    # (about a step's worth each); `value` keeps the contract (EXACTLY K steps), this leg says what the loop sustains.
+    long_run = None
+    if a.steps < 100:
+        barrier()
+        tl = time.perf_counter()
+        run_steps(100)
+        barrier()
+        ldt = allmax(time.perf_counter() - tl)
+        long_run = {"value": round(n_regions * world * 100 / ldt, 1), "unit": "regions/s", "steps": 100, "ms_per_step": round(ldt / 100 * 1e3, 3)}
     if a.dump_collated and rank == 0:
         with open(a.dump_collated, "wb") as f:
             f.write(gstate["last"])
@@ -565,7 +575,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": prof.get("traffic_source"),
                          "kernel": kname, "kernel_ms": round(k_ms, 3),
-                         "kernel_ms_note": "average launch duration of this kernel over the timed steps (HIP events on its stream; %d batches in flight stretch each other)" % len(engs),
+                         "kernel_ms_note": "average duration of ONE launch of this kernel over the timed steps (HIP events on its stream), not chip time per step: %d batches are in flight and their launches overlap (the durations of the three kernels sum to more than ms_per_step x steps in flight)" % len(engs),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "exclusive": {"kernel": "bk_asm_kernel", "kernel_ms": round(s_a / ks, 3), "achieved": round(alg_bytes / asm_excl_s / 1e9, 3),
                                        "traffic": prof.get("bk_asm_kernel_bytes_per_launch"),
@@ -580,6 +590,7 @@ def main():
             "submit_ms": round(sum(submit_ms) / len(submit_ms), 2), "submit_pack_ms": round(pack_ms, 2), "h2d_ms": round(h2d_ms, 2),
             "submit_note": "bk_submit_regions of one %d-region batch (host 2-bit packing + H2D), outside the timed region" % n_regions,
             "one_step_at_a_time": serial,
+            "value_100_steps": long_run if long_run else {"value": round(value, 1), "unit": "regions/s", "steps": a.steps, "ms_per_step": round(step_s * 1e3, 3)},
             "value_with_submit": with_submit,
         }
         if world == 1 and a.other_configs:
@@ -600,13 +611,13 @@ def main():
                 oc = json.loads(lines[-1]) if (pr.returncode == 0 and lines) else {"error": "side measurements ended with code %d" % pr.returncode, "stderr_tail": pr.stderr[-400:]}
             except Exception as ex:
                 oc = {"error": repr(ex)}
-            try:                                             # ... and the experimental split in a process of ITS own, so that it cannot cost the others
+            try:                                             # ... and the one-unit comparison run of the noisy batch
                 cmd2 = [sys.executable, os.path.abspath(__file__), "--side-configs-only", "2", "--kmer", str(a.kmer), "--depth", str(a.depth), "--read-len", str(a.read_len)]
                 pr2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=300)
                 lines2 = [ln for ln in pr2.stdout.strip().splitlines() if ln.startswith("{")]
-                oc.update(json.loads(lines2[-1]) if (pr2.returncode == 0 and lines2) else {"noise_0.5pct_64_regions_split_experimental": {"error": "ended with code %d" % pr2.returncode}})
+                oc.update(json.loads(lines2[-1]) if (pr2.returncode == 0 and lines2) else {"noise_0.5pct_64_regions_one_unit": {"error": "ended with code %d" % pr2.returncode}})
             except Exception as ex:
-                oc["noise_0.5pct_64_regions_split_experimental"] = {"error": repr(ex)}
+                oc["noise_0.5pct_64_regions_one_unit"] = {"error": repr(ex)}
             out["other_configs"] = oc
         # ---- CPU baseline: the oracle (C port of the reference algorithm) on the host cores, bounded sample -------
         if world == 1 and a.cpu_sample > 0:

@@ -17,13 +17,35 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=False):
+# Diagnostic variants of the library (never loaded by the product: tests and tools name them through
+# hip_backend.load_library(path)).  The product build has no -D at all and reads nothing from the environment.
+VARIANTS = {
+    "": [],
+    "diag": ["-DBK_DIAG"],                                   # the environment switches of bk_api.hip (BK_DEBUG_SPLIT, BK_POISON_*, ...)
+    "jitter": ["-DBK_JITTER"],                               # a pseudo-random subset of the wavefronts sleeps behind every barrier (bk_common.h)
+    "check": ["-DBK_SYNC_CHECK"],                            # every barrier verifies that all wavefronts stand at the same site
+    "checkjit": ["-DBK_SYNC_CHECK", "-DBK_JITTER"],
+    "stamps": ["-DBK_DIAG", "-DBK_PHASE_STAMPS"],            # per-phase times (tools/phase_probe_*.py)
+}
+
+
+def lib_path(variant=""):
+    return HIP_LIB if not variant else os.path.join(_HERE, "libbreakmer_hip_%s.so" % variant)
+
+
+def build_hip(force=False, verbose=False, variant="", extra=()):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "breakmer_hip.h")]
-    if force or _stale(HIP_LIB, deps):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result",
-               "-o", HIP_LIB, HIP_SRC]
+    out = lib_path(variant)
+    if force or _stale(out, deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result"] + VARIANTS[variant] + list(extra) + ["-o", out, HIP_SRC]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
-    return HIP_LIB
+    return out
+
+
+if __name__ == "__main__":
+    import sys
+    for v in (sys.argv[1:] or [""]):
+        print(build_hip(verbose=True, variant=v))

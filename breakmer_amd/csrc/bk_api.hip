@@ -1,5 +1,13 @@
 // bk_api.hip -- host side of libbreakmer_hip.so: the C-ABI of include/breakmer_hip.h.
 // gfx950 only; there is no CPU fallback anywhere in this library.
+//
+// Builds.  The PRODUCT build (breakmer_amd/build.py, no -D) reads nothing from the environment: its behaviour is a function of
+// its arguments.  Every diagnostic switch lives behind -DBK_DIAG (build.py variant "diag"; implied by the barrier-check and
+// jitter builds, bk_common.h): environment variables BK_SPLIT_OFF, BK_SW_T, BK_POISON_ARENA, BK_POISON_LDS, BK_LDS_PAD, BK_DBG_ITERS,
+// BK_DEBUG_SPLIT, BK_JITTER_SEED -- read through bk_diag_env(), which is a constant nullptr in the product build.
+#if (defined(BK_SYNC_CHECK) || defined(BK_JITTER)) && !defined(BK_DIAG)
+#define BK_DIAG 1
+#endif
 #include "../../include/breakmer_hip.h"
 #include "bk_common.h"
 #include "bk_kmer.hip.h"
@@ -30,6 +38,7 @@ using at512::bk_nw_batch_kernel;
 #include "bk_call.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -44,8 +53,17 @@ using at512::bk_nw_batch_kernel;
 #include <vector>
 
 static std::string g_create_err;
+#ifdef BK_DIAG
+static inline const char *bk_diag_env(const char *name) { return getenv(name); }
+#else
+static inline constexpr const char *bk_diag_env(const char *) { return nullptr; }
+#endif
 #define BK_MAX_CONTIG_ABS 32704      // the realign kernel's 64-bit hit key holds 15 bits of query position
+#ifdef BK_SYNC_CHECK
+#define BK_LDS_MAX (160 * 1024 - 256)      // (barrier-check build: the site table of bk_sync_diag is static LDS of every kernel)
+#else
 #define BK_LDS_MAX (160 * 1024)      // LDS of a gfx950 CU = the most one workgroup can have
+#endif
 
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
@@ -108,10 +126,14 @@ struct bk_handle {
     std::thread worker; bool has_worker = false; int worker_rc = 0; std::vector<bk_region> worker_regions;
 };
 
+// A handle's worker thread runs call_impl / submit_regions, which pass through entry-point code that joins the worker: the
+// worker recognises ITSELF by a thread-local flag it sets first thing (not through h->worker, which the launching thread may
+// still be move-assigning when the new thread gets here: get_id() of a half-assigned std::thread, then join() on a
+// non-joinable one -> std::terminate.  ADVICE round 4).
+static thread_local bool tl_is_worker = false;
 static int join_pending(bk_handle *h)
 {
-    if (!h || !h->has_worker) return 0;
-    if (h->worker.get_id() == std::this_thread::get_id()) return 0;      // the worker itself (bk_call_async: its sync / fetch are entry points too)
+    if (!h || tl_is_worker || !h->has_worker) return 0;
     h->worker.join(); h->has_worker = false;
     return h->worker_rc;
 }
@@ -152,6 +174,7 @@ static int fail(bk_handle *h, int code, const std::string &msg) { if (h) h->err 
 extern "C" int bk_abi_version(void) { return BK_ABI_VERSION; }
 extern "C" const char *bk_last_error(const bk_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+static size_t asm_lds_bytes(const bk_handle *h, int threads, int max_cand, int max_contig);
 extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
 {
     if (!cfg || !out) return fail(nullptr, BK_E_ARG, "bk_create: null argument");
@@ -166,7 +189,7 @@ extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
     if (cfg->kmer_size < 2 || cfg->kmer_size > 64) return fail(nullptr, BK_E_ARG, "bk_create: kmer_size must be in [2, 64]");
     bk_handle *h = new bk_handle();
     h->dev = device_id; h->cfg = *cfg; h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    { const char *e = getenv("BK_SPLIT"); if (e && atoi(e) > 0) h->cfg.reserved[0] |= BK_F_SPLIT; }      // diagnostic: the experimental component split for every handle of the process
+    { const char *e = bk_diag_env("BK_SPLIT_OFF"); if (e && atoi(e) > 0) h->cfg.reserved[0] |= BK_F_NO_SPLIT; }      // diagnostic build: every region one unit, for every handle of the process
     if (h->cfg.max_contig_len <= 0) h->cfg.max_contig_len = 4096;
     if (h->cfg.max_read_len <= 0) h->cfg.max_read_len = 1024;
     if (h->cfg.max_candidates <= 0) h->cfg.max_candidates = 2048;
@@ -175,8 +198,21 @@ extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
     if (h->cfg.max_read_len > 1024 || h->cfg.max_contig_len > BK_MAX_CONTIG_ABS || h->cfg.max_contig_len > 2 * h->cfg.max_candidates) {
         delete h; return fail(nullptr, BK_E_ARG, "bk_create: limits: max_read_len <= 1024, max_contig_len <= 32,704 and <= 2*max_candidates");
     }
+    {   // what the caps cost in LDS: the assembler's block at the 512-thread size with the shortest read buffers, the realigner's LONG tier
+        h->eff_max_read = 64;
+        const size_t a = asm_lds_bytes(h, 512, h->cfg.max_candidates, h->cfg.max_contig_len);
+        const size_t w = bk_sw_layout(h->cfg.max_contig_len, 2 * (uint32_t)h->cfg.max_contig_len + 4096, 256, 1024, h->cfg.sw_min_score).total;
+        if (a > BK_LDS_MAX || w > BK_LDS_MAX) {
+            const std::string msg = "bk_create: max_contig_len " + std::to_string(h->cfg.max_contig_len) + " / max_candidates " + std::to_string(h->cfg.max_candidates) + " need " + std::to_string(a) + " B (assembler) and " + std::to_string(w) +
+                                    " B (realigner) of LDS per workgroup; a CU has " + std::to_string(BK_LDS_MAX) + " (the library raises working caps by itself for regions that overflow them)";
+            delete h; return fail(nullptr, BK_E_ARG, msg);
+        }
+    }
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, BK_E_HIP, "stream creation failed"); }
     for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { (void)bk_destroy(h); return fail(nullptr, BK_E_HIP, "event creation failed"); }
+#if defined(BK_JITTER)
+    { const char *e = bk_diag_env("BK_JITTER_SEED"); const uint32_t seed = e ? (uint32_t)strtoul(e, nullptr, 0) : 1u; (void)hipMemcpyToSymbol(HIP_SYMBOL(bk_jitter_seed), &seed, sizeof(seed)); }
+#endif
     *out = h;
     return BK_OK;
 }
@@ -295,7 +331,7 @@ extern "C" int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int3
     h->worker_regions.assign(regions, regions + n_regions);
     h->submitted = false; h->ran = false; h->fetched = false; h->synced = false; h->calls_valid = false;
     h->worker_rc = BK_OK; h->has_worker = true;
-    h->worker = std::thread([h, n_regions, flags]() { h->worker_rc = submit_regions(h, h->worker_regions.data(), n_regions, flags & ~(uint32_t)BK_SUBMIT_ASYNC); });
+    h->worker = std::thread([h, n_regions, flags]() { tl_is_worker = true; h->worker_rc = submit_regions(h, h->worker_regions.data(), n_regions, flags & ~(uint32_t)BK_SUBMIT_ASYNC); });
     return BK_OK;
 }
 
@@ -452,7 +488,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     uint32_t max_small = 0; h->n_big = 0; uint64_t big_bytes = 0;
     for (auto &d : n_desc) {
         uint32_t cap, words;
-        d.big = lds_need(d.win_len, cap, words) > 160 * 1024 ? 1u : 0u;
+        d.big = lds_need(d.win_len, cap, words) > BK_LDS_MAX ? 1u : 0u;
         if (d.big) { h->n_big++; uint64_t gc = 1024; while (gc < 4ull * d.win_len) gc <<= 1; big_bytes += gc * 8 + d.win_len / 4 + 4096; if (d.win_len >= (1u << 28)) return fail(h, BK_E_LIMIT, "bk_submit_regions: reference window longer than 256 Mb"); }
         else max_small = std::max(max_small, d.win_len);
     }
@@ -533,18 +569,18 @@ static BkSwTier sw_tier(const bk_handle *h, int contig_cap, int max_contig_for_w
     T.sec_lds = small ? 64 : 256; T.n_flags = small ? 256 : 1024;
     // target staging buffer (packed, 4 bases per byte): the whole window when it fits, else chunks of diagonals
     uint32_t tw_cap = std::min<uint32_t>(h->max_win + 2 * (uint32_t)contig_cap + 16, small ? 16384u : std::max<uint32_t>(131072, 4 * (uint32_t)contig_cap));
-    while (bk_sw_layout(contig_cap, tw_cap, T.sec_lds, T.n_flags).total > BK_LDS_MAX && tw_cap > 2 * (uint32_t)contig_cap + 4096) tw_cap -= 4096;      // long contig caps: shorter chunks of a long window
+    while (bk_sw_layout(contig_cap, tw_cap, T.sec_lds, T.n_flags, h->cfg.sw_min_score).total > BK_LDS_MAX && tw_cap > 2 * (uint32_t)contig_cap + 4096) tw_cap -= 4096;      // long contig caps: shorter chunks of a long window
     T.tw_cap = tw_cap; (void)max_contig_for_window;
     return T;
 }
 static int launch_sw(bk_handle *h, int max_contig, bool note_occupancy)
 {
-    static const int env_t = getenv("BK_SW_T") ? atoi(getenv("BK_SW_T")) : 0;              // diagnostic: workgroup size of the SHORT tier (64 .. 512); 1 = one tier as before round 4
+    static const int env_t = [] { const char *e = bk_diag_env("BK_SW_T"); return e ? atoi(e) : 0; }();              // diagnostic build: workgroup size of the SHORT tier (64 .. 512); 1 = one tier as before round 4
     const bool two = max_contig > BK_SW_SHORT && env_t != 1;
     const int threads = !two ? BK_ST_TMAX : (env_t >= 64 && env_t <= 512 ? env_t : 128);
     BkSwTier T = sw_tier(h, two ? BK_SW_SHORT : max_contig, max_contig, two);
     HIPCHK(h, hipMemsetAsync((unsigned long long *)h->d_tops.p + 6, 0, 16, h->stream));
-    size_t lds = bk_sw_layout(T.contig_cap, T.tw_cap, T.sec_lds, T.n_flags).total;
+    size_t lds = bk_sw_layout(T.contig_cap, T.tw_cap, T.sec_lds, T.n_flags, h->cfg.sw_min_score).total;
     HIPCHK(h, set_max_dyn_lds(h->dev, (const void *)bk_sw_kernel, (int)BK_LDS_MAX));
     // one workgroup per contig, pulled from the list the assembler appended to; the number of contigs is only known
     // on the device, so a resident-sized grid of persistent workgroups is launched (idle ones exit at once)
@@ -554,7 +590,7 @@ static int launch_sw(bk_handle *h, int max_contig, bool note_occupancy)
     HIPCHK(h, hipGetLastError());
     if (two) {
         BkSwTier TL = sw_tier(h, max_contig, max_contig, false); TL.mode = 1;
-        lds = bk_sw_layout(TL.contig_cap, TL.tw_cap, TL.sec_lds, TL.n_flags).total;
+        lds = bk_sw_layout(TL.contig_cap, TL.tw_cap, TL.sec_lds, TL.n_flags, h->cfg.sw_min_score).total;
         hipLaunchKernelGGL(bk_sw_kernel, dim3(h->n_cu), dim3(BK_ST_TMAX), lds, h->stream, h->params, TL);
         HIPCHK(h, hipGetLastError());
     }
@@ -568,6 +604,29 @@ static bool escalated_caps(const bk_handle *h, int &max_cand, int &max_contig)
     while (max_cand > h->cfg.max_candidates && asm_lds_bytes(h, 512, max_cand, std::min(max_contig, 2 * max_cand)) > BK_LDS_MAX) max_cand /= 2;
     max_contig = std::min(max_contig, 2 * max_cand);
     return max_cand > h->cfg.max_candidates || max_contig > h->cfg.max_contig_len;
+}
+
+// The assembler launch of a batch, of a re-run subset and of a repair pass: LDS size, kernel attribute, diagnostic parameters and
+// grid in ONE place (they used to be recomputed, differently, by launch_repair).  `units`: entries in the queue at most.
+static int launch_asm(bk_handle *h, int threads, int max_cand, int max_contig, long long units, bool note)
+{
+    const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
+    size_t lds = asm_lds_bytes(h, threads, max_cand, max_contig);
+    h->params.asm_lds_pad = 0; h->params.dbg_iters = 0; h->params.poison = 0;
+    { const char *e = bk_diag_env("BK_LDS_PAD"); if (e) { h->params.asm_lds_pad = (uint32_t)(atoi(e) & ~15); lds += h->params.asm_lds_pad; } }      // diagnostic build: guard band behind the block
+    { const char *e = bk_diag_env("BK_DBG_ITERS"); if (e) h->params.dbg_iters = (uint32_t)atoi(e); }
+    { const char *e = bk_diag_env("BK_POISON_LDS"); if (e) h->params.poison = 0x100u | (uint32_t)(atoi(e) & 0xFF); }
+    h->params.asm_lds_bytes = (uint32_t)lds;
+    if (lds > BK_LDS_MAX) return fail(h, BK_E_LIMIT, "assembler: max_candidates / max_contig_len / read length of this batch need " + std::to_string(lds) + " B of LDS per workgroup, a CU has " + std::to_string(BK_LDS_MAX));
+    HIPCHK(h, set_max_dyn_lds(h->dev, kfn, (int)lds));
+    // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)
+    const int per_cu = cached_occupancy(h->dev, kfn, threads, lds);
+    if (note) { h->asm_wg_per_cu = per_cu; h->asm_threads = threads; }
+    const int grid = (int)std::max<long long>(1, std::min<long long>(units, (long long)per_cu * h->n_cu));
+    if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
+    else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
+    HIPCHK(h, hipGetLastError());
+    return BK_OK;
 }
 
 // subset == nullptr: the whole batch.  Else: only these regions, from the k-mer stage on (it resets their state), each as ONE unit
@@ -596,7 +655,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         static const unsigned long long tops[6] = {256, 256, 0, 0, 0, 0};      // arena top, out top, contigs listed, unit queue head, contig queue head, units queued (bk_sched_kernel)
         HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
     }
-    { const char *e = getenv("BK_POISON_ARENA"); if (e && h->d_arena.p) HIPCHK(h, hipMemsetAsync(h->d_arena.p, atoi(e) & 0xFF, h->d_arena.bytes, h->stream)); }      // diagnostic: what an uninitialised read of the scratch arena sees
+    { const char *e = bk_diag_env("BK_POISON_ARENA"); if (e && h->d_arena.p) HIPCHK(h, hipMemsetAsync(h->d_arena.p, atoi(e) & 0xFF, h->d_arena.bytes, h->stream)); }      // diagnostic: what an uninitialised read of the scratch arena sees
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     // workgroup sizes: latency mode (one batch at a time) or throughput mode (batches in flight / a batch that fills the chip)
     const int asm_threads = subset ? 512 : h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions > 2 * h->n_cu ? 256 : 512);      // more regions than 512-thread workgroups can be resident at once (2 per CU): the smaller ones keep them all in flight
@@ -617,7 +676,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
             HIPCHK(h, hipGetLastError());
         }
     }
-    const bool dbg = getenv("BK_DEBUG_SPLIT") != nullptr;
+    const bool dbg = bk_diag_env("BK_DEBUG_SPLIT") != nullptr;
     if (dbg) {
         const std::pair<const char *, const DevBuf *> bufs[] = {{"desc", &h->d_desc}, {"work", &h->d_work}, {"part", &h->d_part}, {"reads", &h->d_reads}, {"rlen", &h->d_rlen}, {"rflag", &h->d_rflag}, {"sc", &h->d_sc}, {"sclen", &h->d_sclen}, {"win", &h->d_win},
             {"ddslot", &h->d_ddslot}, {"ddrep", &h->d_ddrep}, {"ddcnt", &h->d_ddcnt}, {"grp", &h->d_grp}, {"urep", &h->d_urep}, {"unr", &h->d_unr}, {"ufl", &h->d_ufl}, {"ubuf", &h->d_ubuf}, {"ureads", &h->d_ureads}, {"ufound", &h->d_ufound}, {"uminpos", &h->d_uminpos},
@@ -636,25 +695,12 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
             if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] sched done\n"); }
         }
         // Workgroup size: 512 threads (8 wavefronts, 8 look-ahead slots, 2 per CU) finish ONE batch soonest; 256 threads (4
-        // wavefronts, 4 slots, 4 per CU) give more regions per CU whose serial phases overlap: +14 % regions/s once the
+        // wavefronts, 8 slots, 4 per CU) give more regions per CU whose serial phases overlap: +14 % regions/s once the
         // chip is full.  bk_config.reserved[1] = 256 / 512 chooses; 0 = 512 unless the batch alone fills the chip twice.
-        const int threads = asm_threads;
-        const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
-        const size_t lds = asm_lds_bytes(h, threads, max_cand, max_contig) + (getenv("BK_LDS_PAD") ? (size_t)(atoi(getenv("BK_LDS_PAD")) & ~15) : 0);
-        { const char *e = getenv("BK_LDS_PAD"); h->params.asm_lds_pad = e ? (uint32_t)(atoi(e) & ~15) : 0u; }
-        { const char *e = getenv("BK_DBG_ITERS"); h->params.dbg_iters = e ? (uint32_t)atoi(e) : 0u; }
-        { const char *e = getenv("BK_POISON_LDS"); h->params.asm_lds_bytes = (uint32_t)lds; h->params.poison = e ? (0x100u | (uint32_t)(atoi(e) & 0xFF)) : 0u; }
-        HIPCHK(h, set_max_dyn_lds(h->dev, kfn, (int)lds));
-        // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)
-        const int per_cu = cached_occupancy(h->dev, kfn, threads, lds);
-        if (!subset) { h->asm_wg_per_cu = per_cu; h->asm_threads = threads; }
         // (a noisy region is split into up to BK_SPLIT_G units on the device, bk_comp.hip.h: the host only knows the bound)
-        const bool may_split = !subset && (h->cfg.reserved[0] & (BK_F_SPLIT | BK_F_SPLIT_ALWAYS)) && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
-        const int grid = std::min<long long>((long long)n_launch * (may_split ? BK_SPLIT_G : 1), (long long)per_cu * h->n_cu);
-        if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
-        else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
-        HIPCHK(h, hipGetLastError());
-        if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] assembler done (grid %d)\n", grid); }
+        const bool may_split = !subset && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
+        { const int rc = launch_asm(h, asm_threads, max_cand, max_contig, (long long)n_launch * (may_split ? BK_SPLIT_G : 1), !subset); if (rc != BK_OK) return rc; }
+        if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] assembler done\n"); }
         if (may_split) {          // contigs of split regions in the reference's order (idle for the others)
             hipLaunchKernelGGL(bk_link_kernel, dim3(std::min(h->n_regions, h->n_cu)), dim3(BK_LINK_T), 0, h->stream, h->params, h->n_regions);
             HIPCHK(h, hipGetLastError());
@@ -685,17 +731,11 @@ static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t
     HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    const bool dbg = getenv("BK_DEBUG_SPLIT") != nullptr;
+    const bool dbg = bk_diag_env("BK_DEBUG_SPLIT") != nullptr;
     hipLaunchKernelGGL(bk_resolve_kernel, dim3(n), dim3(BK_RESOLVE_T), 0, h->stream, h->params, (const uint32_t *)h->d_rmap.p);
     HIPCHK(h, hipGetLastError());
     if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk split]   resolve done\n"); }
-    const int threads = h->asm_threads;
-    const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
-    const size_t lds = asm_lds_bytes(h, threads, h->cfg.max_candidates, h->cfg.max_contig_len);
-    const int grid = std::min<long long>((long long)q.size(), (long long)std::max(1, h->asm_wg_per_cu) * h->n_cu);
-    if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
-    else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
-    HIPCHK(h, hipGetLastError());
+    { const int rc = launch_asm(h, h->asm_threads, h->cfg.max_candidates, h->cfg.max_contig_len, (long long)q.size(), false); if (rc != BK_OK) return rc; }
     if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk split]   assembler pass done\n"); }
     hipLaunchKernelGGL(bk_link_kernel, dim3(std::min(h->n_regions, h->n_cu)), dim3(BK_LINK_T), 0, h->stream, h->params, h->n_regions);
     HIPCHK(h, hipGetLastError());
@@ -726,7 +766,7 @@ static const char *st_name(int s)
     case BK_ST_ARENA: return "device scratch arena exhausted"; case BK_ST_WINDOW: return "reference window too long";
     case BK_ST_CONTIG: return "contig longer than max_contig_len"; case BK_ST_CAND: return "more candidate reads for one k-mer than max_candidates";
     case BK_ST_KLIST: return "contig k-mer list overflow"; case BK_ST_READLEN: return "read longer than max_read_len";
-    case BK_ST_OUT: return "output arena exhausted"; default: return "unknown";
+    case BK_ST_OUT: return "output arena exhausted"; case BK_ST_HITS: return "realign stage: step-1 hit list overflow"; default: return "unknown";
     }
 }
 
@@ -743,6 +783,18 @@ static int sync_impl(bk_handle *h)
     h->n_escalated = 0; h->n_repair_passes = 0;
     for (int attempt = 0; attempt < 16; attempt++) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
+#if defined(BK_SYNC_CHECK)
+        {   // barrier-check build (bk_common.h): did any workgroup's wavefronts meet at different barrier sites?
+            unsigned long long rep_[4] = {0, 0, 0, 0};
+            HIPCHK(h, hipMemcpyFromSymbol(rep_, HIP_SYMBOL(bk_sync_report), sizeof(rep_)));
+            if (rep_[0]) {
+                const unsigned long long zero[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(bk_sync_report), zero, sizeof(zero));
+                const unsigned a = (unsigned)(rep_[0] - 1), b = (unsigned)rep_[1];
+                return fail(h, BK_E_HIP, "BARRIER DIVERGENCE: wavefront " + std::to_string(rep_[3]) + " of workgroup " + std::to_string(rep_[2]) + " stood at barrier site file " + std::to_string(a >> 16) + " line " + std::to_string(a & 0xFFFF) +
+                            " while another wavefront of the workgroup stood at file " + std::to_string(b >> 16) + " line " + std::to_string(b & 0xFFFF) + " (file ids: bk_common.h BK_SRC_ID)");
+            }
+        }
+#endif
         h->h_work.resize(h->n_regions);
         HIPCHK(h, hipMemcpy(h->h_work.data(), h->d_work.p, sizeof(BkRegionWork) * h->n_regions, hipMemcpyDeviceToHost));
         // A region that overflowed an assembler cap (candidates per k-mer visit, contig length, k-mer list) is run again, with
@@ -761,7 +813,7 @@ static int sync_impl(bk_handle *h)
             float ms[4];
             for (int i = 0; i < 3; i++) { ms[i + 1] = 0; (void)hipEventElapsedTime(&ms[i + 1], h->ev[i], h->ev[i + 1]); }
             ms[0] = 0; (void)hipEventElapsedTime(&ms[0], h->ev[0], h->ev[3]);
-            if (getenv("BK_DEBUG_SPLIT")) {
+            if (bk_diag_env("BK_DEBUG_SPLIT")) {
                 unsigned long long np_ = 0, nc_ = 0, nx_ = 0, ns_ = 0; for (int r = 0; r < h->n_regions; r++) { const BkRegionWork &w = h->h_work[r]; if (w.split) { ns_++; np_ += w.n_pairs; nc_ += w.n_conf; nx_ += w.n_cidx; } }
                 fprintf(stderr, "[bk split] pass %d: %zu region(s) to repair, %zu to unsplit; split regions %llu, meetings noted %llu (conflicts %llu), contigs emitted so far %llu; kernels %.2f / %.2f / %.2f ms\n",
                         h->n_repair_passes, redo.size(), unsplit.size(), ns_, np_, nc_, nx_, ms[1], ms[2], ms[3]);
@@ -989,7 +1041,21 @@ struct BkPslV {
     int strand = '+', q_size = 0, q_start = 0, q_end = 0, t_index = 0, t_size = 0, t_start = 0, t_end = 0, score = 0;
     std::vector<int> block_sizes, q_starts, t_starts;
 };
-static void chain_hits(const char *contig, int Q, const std::vector<BkTarget> &targets, std::vector<BkHit> hits, std::vector<BkHit> sec, std::vector<BkPslV> &out)
+// Realign contract step 8 (oracle/bk_oracle.h: bko_psl_passes): BLAT's documented output filters -- -minScore ("matches minus the
+// mismatches minus some sort of gap penalty", sv_processor.py:840, 843: 20) and -minIdentity (default 90 for nucleotide searches),
+// the identity from the milliBad the reference's caller computes for a record (sv_caller.py:954-968).  Integer exact.
+#define BK_MIN_IDENTITY 90
+static bool psl_passes(const BkPslV &r, int min_score)
+{
+    const long total = (long)r.matches + r.rep_matches + r.mismatches;
+    if ((long)r.matches + r.rep_matches - r.mismatches - r.q_num_insert - r.t_num_insert < (long)min_score) return false;
+    const int qali = r.q_end - r.q_start, tali = r.t_end - r.t_start;
+    if (std::min(qali, tali) <= 0 || total == 0) return true;
+    const int dif = std::max(0, qali - tali);
+    const long bad = (long)r.mismatches + r.q_num_insert + lround(3.0 * log(1.0 + (double)dif));
+    return 100L * bad <= (long)(100 - BK_MIN_IDENTITY) * total;
+}
+static void chain_hits(const char *contig, int Q, const std::vector<BkTarget> &targets, std::vector<BkHit> hits, std::vector<BkHit> sec, std::vector<BkPslV> &out, int min_score)
 {
     out.clear();
     std::string rc(Q, 'N');
@@ -1111,6 +1177,7 @@ static void chain_hits(const char *contig, int Q, const std::vector<BkTarget> &t
             r->block_sizes.push_back(bs); r->q_starts.push_back(c.qs); r->t_starts.push_back(c.ts);
             pq = c.qe; pt = c.te;
         }
+        if (!psl_passes(*r, min_score)) out.pop_back();                      // step 8: BLAT would not print it
     }
     for (const BkHit &e : sec) {
         out.emplace_back(); BkPslV *r = &out.back();
@@ -1119,6 +1186,7 @@ static void chain_hits(const char *contig, int Q, const std::vector<BkTarget> &t
         r->t_start = e.ts; r->t_end = e.te; r->q_start = e.strand == 0 ? e.qs : Q - e.qe; r->q_end = e.strand == 0 ? e.qe : Q - e.qs;
         for (int z = 0; z < e.qe - e.qs; z++) { if (qstr[e.qs + z] == t[e.ts + z] && qstr[e.qs + z] != 'N') { if (t.masked(e.ts + z)) r->rep_matches++; else r->matches++; } else r->mismatches++; }
         r->block_sizes.push_back(e.qe - e.qs); r->q_starts.push_back(e.qs); r->t_starts.push_back(e.ts); r->score = e.score;
+        if (!psl_passes(*r, min_score)) out.pop_back();                      // step 8
     }
 }
 static BkTarget make_target(const char *s, int len)
@@ -1146,7 +1214,7 @@ extern "C" int bk_get_hits(bk_handle *h, int32_t region, int32_t contig, bk_psl 
     const char *seq = (const char *)c + c->o_seq;
     std::string s(seq, c->seq_len);
     std::vector<BkPslV> recs;
-    chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, sec, recs);
+    chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, sec, recs, h->cfg.sw_min_score);
     for (const BkPslV &x : recs) if (x.block_sizes.size() > (size_t)BK_MAX_BLOCKS) return fail(h, BK_E_LIMIT, "bk_get_hits: a chained record of this contig has more than BK_MAX_BLOCKS blocks (bk_psl cannot hold it; bk_call has no such limit)");
     for (size_t i = 0; i < recs.size() && (int32_t)i < cap; i++) {
         const BkPslV &x = recs[i]; bk_psl *r = &hits[i]; memset(r, 0, sizeof(*r));
@@ -1171,7 +1239,7 @@ extern "C" int bk_get_hits_flat(bk_handle *h, int32_t region, int32_t contig, in
     std::vector<BkHit> raw, sec; raw_hits_of(h, c, raw, sec);
     std::string s((const char *)c + c->o_seq, c->seq_len);
     std::vector<BkPslV> recs;
-    chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, sec, recs);
+    chain_hits(s.c_str(), c->seq_len, h->h_targets[region], raw, sec, recs, h->cfg.sw_min_score);
     size_t need = 0; for (const BkPslV &x : recs) need += BK_PSL_FLAT_HEAD + 3 * x.block_sizes.size();
     *needed = need;
     if (need <= cap) {
@@ -1322,7 +1390,7 @@ static int call_impl(bk_handle *h)
                 // check_blat_indel (sv_caller.py:621-651) keeps no indel (ngap_total() = 0 < indel_size), has no other hit to make
                 // an event from, and the contig has no row -- (or BLAT's seeding rule drops the hit and there is no record at all):
                 // no call either way, decided from the raw hit without building the records.
-                if (c->n_hits == 1 && c->n_sec == 0 && c->hits_off && cx.opts.indel_size > 0) {
+                if (c->n_hits == 1 && c->n_sec == 0 && c->hits_off && cx.opts.indel_size > 0 && !(h->cfg.reserved[0] & BK_F_NO_CALL_SHORTCUT)) {
                     const BkHit *h1 = (const BkHit *)(h->h_out.data() + c->hits_off);
                     if (h1->tidx == 0 && h1->qs == 0 && h1->qe == c->seq_len) continue;
                 }
@@ -1332,7 +1400,7 @@ static int call_impl(bk_handle *h)
                   for (int i = 0; i < c->n_reads; i++) { char tch = rd[i] < tg.size() ? tg[rd[i]] : '0'; if (i == 0) first = tch; else if (tch != first) same = false; } ct.same_read_tag = same && c->n_reads > 0; }
                 std::vector<BkHit> raw, sec; raw_hits_of(h, c, raw, sec);
                 std::vector<BkPslV> recs;
-                chain_hits(ct.seq.c_str(), c->seq_len, h->h_targets[r], raw, sec, recs);
+                chain_hits(ct.seq.c_str(), c->seq_len, h->h_targets[r], raw, sec, recs, h->cfg.sw_min_score);
                 const int n = (int)recs.size();
                 // repeats_lower: the BLAT call against the target window has -repeats=lower (sv_processor.py:843), the genome-wide gfClient
                 // call (:840) has not -- there a match on a soft-masked base is a plain match
@@ -1379,7 +1447,7 @@ extern "C" int bk_call_async(bk_handle *h)
     if (!h->have_ctx) return fail(h, BK_E_STATE, "bk_call_async: bk_set_call_context first");
     if (!h->ran) return fail(h, BK_E_STATE, "bk_call_async: nothing was run");
     h->worker_rc = BK_OK; h->has_worker = true;
-    h->worker = std::thread([h]() { h->worker_rc = call_impl(h); });
+    h->worker = std::thread([h]() { tl_is_worker = true; h->worker_rc = call_impl(h); });
     return BK_OK;
 }
 

@@ -117,16 +117,8 @@ struct BkAsmCtx {
 #define BK_COLD __device__ inline
 #endif
 #define BK_TID ((int)threadIdx.x)
-#ifdef BK_JITTER      // diagnostic build: after every workgroup barrier ONE wavefront (which one depends on the source line) sleeps a few microseconds --
-                      // code that silently relies on the wavefronts staying in step after a barrier (a missing second barrier) then goes wrong at any load
-#ifndef BK_JIT_LO
-#define BK_JIT_LO 0
-#define BK_JIT_HI 1000000
-#endif
-#define BK_SYNC() do { __syncthreads(); if (__LINE__ >= BK_JIT_LO && __LINE__ < BK_JIT_HI && (((int)(BK_TID >> 6)) + __LINE__ * BK_JITTER) % (BK_AT / 64) == 0) __builtin_amdgcn_s_sleep(100); } while (0)
-#else
-#define BK_SYNC() __syncthreads()
-#endif
+#undef BK_SRC_ID
+#define BK_SRC_ID 5      // barrier sites of this file (bk_common.h: BK_SYNC; the two instances of this header share the site ids)
 #ifdef BK_PHASE_STAMPS      // diagnostic build only: where does a region's time go (s_memrealtime, 100 MHz)
 #define BK_ACC(i) do { if (BK_TID == 0) { unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); S_->acc[i] += now_ - S_->last; S_->last = now_; } } while (0)
 #else
@@ -394,17 +386,22 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
         tmp[x] = rk;
     }
     BK_SYNC();
-    if (C_.own && S->foreign) {
+    if (C_.own) {
         // The contig holds k-mers of components other than the seed's (a k-mer across the seam of two read pieces).  One new
         // component per turn, smallest root first: same unit -> taken in; no unit (it has no seeds) -> claimed, taken in;
         // another unit's -> the current component is given up (bk_comp.hip.h).  Rare: thread 0 decides, everyone re-checks.
-        for (;;) {
+        // S->foreign steers the loop and bk_meet (thread 0) resets it: every wavefront reads it, THEN a barrier, then the reset
+        // (round 5: without that barrier a late wavefront read the reset word, skipped the loop and its barriers -- the wild
+        // indices and hangs of the split path under load).
+        bool more = S->foreign != 0;
+        while (more) {
+            BK_SYNC();
             if (BK_TID == 0) bk_meet(S->foreign_root);
             BK_SYNC();
             if (S->status) return;
             for (int x = BK_TID; x < np; x += BK_AT) { const int rk = tmp[x]; if (rk >= 0) { const uint32_t root = C_.kroot[rk & 0x3FFFFFFF]; if (root != BK_EMPTY32 && root != S->ccomp && !bk_acc_has(root)) { S->foreign = 1; atomicMin(&S->foreign_root, root); } } }
             BK_SYNC();
-            if (!S->foreign) break;
+            more = S->foreign != 0;
         }
     }
     if (C_.own) {
@@ -1227,11 +1224,10 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         const int cap = ((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) || S->clen > BK_NW_DUAL_COLS) ? BK_SPEC_WIDE : BK_SPEC;
         const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
         // look into the following visits when this one leaves slots free (needs the scratch for BK_AT/64 lists of 64 reads)
-        // (split regions, bk_comp.hip.h: no look-ahead.  With it the assembler faulted about once in 25 runs of a 64-region noisy batch
-        //  -- wild indices, sometimes a hang -- with either kind of look-ahead switched off never in 120 (tools/probes/soak_flags.sh);
-        //  an iteration that is given up at a meeting leaves in the middle of a round, which no path of the unsplit assembler does
-        //  and the plans were not written for.  The units more than make up for it.)
-        const bool la_on = n - q < cap && !(C_.flags & (vt >= 0 ? BK_F_NO_XVISIT : BK_F_NO_XSEED)) && 2 * C_.MAXCAND >= 4 * BK_AT && (!C_.split || (C_.flags & BK_F_SPLIT_LOOKAHEAD));
+        // (split regions, bk_comp.hip.h: until round 4 the look-ahead was off inside them -- with it the assembler faulted about once
+        //  in 25 runs of a 64-region noisy batch.  The causes were two missing barriers (bk_retire's bookkeeping, round 4; the
+        //  S->foreign loop of bk_kmers_ordered, round 5), not the plans; BK_F_SPLIT_NO_LOOKAHEAD is the round-4 setting.)
+        const bool la_on = n - q < cap && !(C_.flags & (vt >= 0 ? BK_F_NO_XVISIT : BK_F_NO_XSEED)) && 2 * C_.MAXCAND >= 4 * BK_AT && !(C_.split && (C_.flags & BK_F_SPLIT_NO_LOOKAHEAD));
         const bool la = la_on && S->la_pause == 0;
         // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
         BK_SYNC();
@@ -1774,6 +1770,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
 {
     BkAsmShared *S = S_;
     BkRegionWork *wk = &p.work[r];
+#ifdef BK_DIAG
     if (p.poison) {      // diagnostic: everything but the queue slot word of the shared state
         const int keep = S->qslot;
         BK_SYNC();
@@ -1788,6 +1785,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         for (uint32_t i = BK_TID; i < p.asm_lds_pad / 4; i += BK_AT) ((uint32_t *)(bk_lds + p.asm_lds_bytes - p.asm_lds_pad))[i] = 0xA5A5A5A5u;
         BK_SYNC();
     }
+#endif
     if (__hip_atomic_load(&wk->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BK_ST_OK && !wk->split) return;              // k-mer stage failed for this region (a split region: another unit may have failed meanwhile; this one still reports in below)
     if (BK_TID == 0) {
         const BkRegionDesc d = p.desc[r];
@@ -1863,7 +1861,9 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
     if (C_.M == 0 && !C_.split) { if (BK_TID == 0) wk->n_contigs = 0; return; }                 // init_assembly :33-34
     if (S->status && !C_.split) { if (BK_TID == 0) wk->status = S->status; return; }
     // ---- init_assembly main loop (:43-62) --------------------------------------------------------------
+#ifdef BK_DIAG
     uint32_t iters_done = 0;
+#endif
     while (!S->status) {
         // first k-mer still in akmers.mers in (count, mer) descending order; has_mers (:318-322) <=> its count > 1
         // (the seed-capable k-mers are ranks 0 .. M2-1; a unit of a split region takes those of its own components)
@@ -1879,7 +1879,9 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         if (C_.split && !C_.own && (found < 0 || C_.kcnt[found] < BK_SPLIT_HI)) { bk_label_live(); continue; }      // the serial prefix is over: label what is left, the other units start
         if (found >= 0 && !BK_CHK((uint32_t)found < C_.M, 9, found)) break;
         if (found < 0 || C_.kcnt[found] < 2) break;
-        if (p.dbg_iters && iters_done++ >= p.dbg_iters) break;      // diagnostic (uniform)
+#ifdef BK_DIAG
+        if (p.dbg_iters && iters_done++ >= p.dbg_iters) break;      // diagnostic build (uniform): stop after BK_DBG_ITERS seed iterations
+#endif
         BK_SYNC();
         if (BK_TID == 0) {
             S->head = fidx; S->seed_rank = found; S->emit_seq = 0; S->acc_n = 0; S->dirty = 0; S->ccomp = C_.own ? C_.kroot[found] : BK_EMPTY32;
@@ -1944,6 +1946,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
             }
         }
     }
+#ifdef BK_DIAG
     if (p.asm_lds_pad) {
         BK_SYNC();
         for (uint32_t i = BK_TID; i < p.asm_lds_pad / 4; i += BK_AT) {
@@ -1952,6 +1955,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         }
         BK_SYNC();
     }
+#endif
 #ifdef BK_PHASE_STAMPS
     if (BK_TID == 0) for (int i = 0; i < 20; i++) { if (C_.split) atomicAdd((unsigned long long *)&C_.wk->stamps[i], (unsigned long long)S->acc[i]); else C_.wk->stamps[i] = S->acc[i]; }      // split regions: summed over the units (and passes)
 #ifdef BK_SNAP_COUNT      // one-off: snapshots taken by one wavefront / by the workgroup, entries they looked at (in place of slots / retired / rounds / look-ahead counters)
@@ -1995,7 +1999,7 @@ extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_
     int *bound = (int *)(l + ((m + 15) & ~15) + ((n + 15) & ~15));   // 2*(max(m,n)+2) ints
     for (int t = threadIdx.x; t < m; t += 64) s1[t] = codes[off1[b] + t];
     for (int t = threadIdx.x; t < n; t += 64) s2[t] = codes[off2[b] + t];
-    __syncthreads();
+    BK_SYNC();
     if (transposed >= 5) {                             // bk_nw_pair: half A = pair b, half B = pair b+1 (cyclic); 5 / 6 -> A's nw(seq1, seq2) / nw(seq2, seq1), 7 / 8 -> B's
         const int b2 = (b + 1) % (int)gridDim.x, m2 = (int)len1[b2], n2 = (int)len2[b2];
         const int mp = (int)((m + 15) & ~15), np_ = (int)((n + 15) & ~15), mp2 = (int)((m2 + 15) & ~15), np2 = (int)((n2 + 15) & ~15);
@@ -2006,7 +2010,7 @@ extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_
         BkPairArgs A, B;
         A.contig = 0; A.clen = m; A.read = mp; A.n = n; A.res = (int)((uint8_t *)res - l);
         B.contig = mp + np_; B.clen = m2; B.read = mp + np_ + mp2; B.n = n2; B.res = (int)((uint8_t *)(res + 8) - l);
-        __syncthreads();
+        BK_SYNC();
         if (m <= BK_NW_DUAL_COLS && m2 <= BK_NW_DUAL_COLS) {
             for (int i = 0; i < reps; i++) bk_nw_pair(A, B);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();

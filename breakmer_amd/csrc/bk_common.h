@@ -18,6 +18,56 @@
 #define BK_EMPTY32 0xFFFFFFFFu
 #define BK_EMPTY64 0xFFFFFFFFFFFFFFFFull
 
+// ---- BK_SYNC(): THE workgroup barrier of all device code of this library (no kernel calls __syncthreads() directly) ----------
+// Every kernel here runs its control flow redundantly on all threads over state in LDS that one thread commits between barriers.
+// The discipline that keeps that correct: a word that steers control flow is read by every wavefront BEFORE a barrier and
+// written only AFTER it.  Three defects of that class (a late wavefront reads the new value, takes another branch, and meets
+// its workgroup at a different barrier: wild indices, hangs) were found by accident under load in rounds 2-4.  Two diagnostic
+// builds make the discipline testable on every kernel:
+//   -DBK_SYNC_CHECK   every barrier verifies that ALL wavefronts of the workgroup arrived at the SAME barrier site: the site id
+//                     (source file << 16 | line) is published per wavefront, compared after the barrier; the first disagreement
+//                     is recorded in bk_sync_report[] (read and reported by bk_sync as BK_E_HIP) and the workgroup ends cleanly
+//                     -- a divergence is a deterministic red test instead of a rare fault or hang;
+//   -DBK_JITTER       behind every barrier a pseudo-random subset of the wavefronts (hash of site, wavefront, workgroup and
+//                     the run-time seed bk_jitter_seed: BK_JITTER_SEED in the environment of a -DBK_DIAG build) sleeps for a
+//                     few microseconds, so a wavefront that is "late after the barrier" happens at every site at any load.
+// The product build defines neither: BK_SYNC() is __syncthreads().
+#ifndef BK_SRC_ID
+#define BK_SRC_ID 0
+#endif
+#if defined(BK_SYNC_CHECK) || defined(BK_JITTER)
+__device__ unsigned long long bk_sync_report[4];      // [0] site of the reporting wavefront + 1 (0: none), [1] the other site, [2] workgroup, [3] wavefront
+__device__ uint32_t bk_jitter_seed;
+__device__ __forceinline__ void bk_sync_diag(const uint32_t site)
+{
+    const uint32_t wv = threadIdx.x >> 6;
+#ifdef BK_SYNC_CHECK
+    __shared__ uint32_t bk_sync_site[16];
+    if ((threadIdx.x & 63u) == 0) bk_sync_site[wv] = site;
+    __syncthreads();
+    const uint32_t nw = (blockDim.x + 63u) >> 6;
+    uint32_t other = site;
+    for (uint32_t w = 0; w < nw; w++) { const uint32_t s = bk_sync_site[w]; if (s != site) other = s; }
+    __syncthreads();                                   // every wavefront has compared before the next barrier's sites are written
+    if (other != site) {                               // (all wavefronts see the same table: the whole workgroup leaves here)
+        if ((threadIdx.x & 63u) == 0 && atomicCAS(&bk_sync_report[0], 0ull, (unsigned long long)site + 1ull) == 0ull) { bk_sync_report[1] = other; bk_sync_report[2] = blockIdx.x; bk_sync_report[3] = wv; }
+        __threadfence();
+        __builtin_amdgcn_endpgm();
+    }
+#else
+    __syncthreads();
+#endif
+#ifdef BK_JITTER
+    uint32_t x = site * 0x9E3779B1u ^ (wv + 1u) * 0x85EBCA77u ^ bk_jitter_seed * 0xC2B2AE3Du ^ blockIdx.x * 0x27D4EB2Fu;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    if ((x & 3u) == 0u) __builtin_amdgcn_s_sleep(100);             // ~64 x 100 cycles: a few microseconds
+#endif
+}
+#define BK_SYNC() bk_sync_diag(((uint32_t)BK_SRC_ID << 16) | (uint32_t)__LINE__)
+#else
+#define BK_SYNC() __syncthreads()
+#endif
+
 // per-region status codes written by the kernels (0 = ok)
 enum {
     BK_ST_OK = 0,
@@ -202,7 +252,7 @@ struct BkParams {
     int32_t flags;               // BK_F_*
     const uint32_t *rmap;        // launch over a subset of the batch (re-run of regions that overflowed a cap): workgroup b of the k-mer kernels takes region rmap[b]; nullptr = region b
 };
-enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64, BK_F_NO_SPLIT = 128, BK_F_SPLIT_ALWAYS = 256, BK_F_SPLIT_LOOKAHEAD = 512, BK_F_SPLIT = 1024 };   // 1024: noisy regions are split into units (bk_comp.hip.h) -- EXPERIMENTAL, off by default: intermittent device faults under load   // 512: diagnostic -- split regions keep the look-ahead (bk_asm.hip.h: intermittent faults)   // 128: every region is one unit (no component split); 256: split whatever the size (diagnostic: the split path on small fixtures)   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
+enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64, BK_F_NO_SPLIT = 128, BK_F_SPLIT_ALWAYS = 256, BK_F_SPLIT_NO_LOOKAHEAD = 512, BK_F_SPLIT = 1024, BK_F_NO_CALL_SHORTCUT = 2048 };   // noisy regions are split into units (bk_comp.hip.h) by DEFAULT since round 5; 1024: accepted, no effect (it switched the split on while it was experimental)   // 512: diagnostic -- no look-ahead inside split regions (the round-4 setting)   // 128: every region is one unit (no component split); 256: split whatever the size (diagnostic: the split path on small fixtures)   // 2048: bk_call takes every contig through the full caller (no shortcut for single full-span hits; tests)   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
 
 // component info word (BkRegionWork.o_cinfo, at the component's root read)
 #define BK_CI_UNIT 0xFFu

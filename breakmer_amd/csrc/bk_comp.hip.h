@@ -31,6 +31,8 @@
 // Results are bit-identical to the one-unit run (tests: every noisy fixture with BK_F_NO_SPLIT on and off).
 #pragma once
 #include "bk_common.h"
+#undef BK_SRC_ID
+#define BK_SRC_ID 4      // barrier sites of this file (bk_common.h: BK_SYNC)
 
 #define BK_SPLIT_MIN_SEEDS 1024        // regions with fewer seed k-mers stay one unit (a clean SV has 30)
 
@@ -69,7 +71,7 @@ __device__ inline void bk_split_prepare(const BkParams &p, BkRegionWork *wk, uin
     if (tid == 0) { wk->split = 0; wk->pass = 0; wk->phase = 0; wk->serial_base = 0; wk->stamp_base = 0; wk->units_done = 0; wk->n_cidx = 0; wk->n_pairs = 0; wk->n_conf = 0; }
     if (tid < BK_SPLIT_G) { wk->unit_us[tid] = 0; wk->unit_iters[tid] = 0; }
     if (tid < 20) wk->stamps[tid] = 0;
-    if (!(p.flags & (BK_F_SPLIT | BK_F_SPLIT_ALWAYS)) || (p.flags & BK_F_NO_SPLIT) || p.rmap || U < 4 || (M2 < BK_SPLIT_MIN_SEEDS && !(p.flags & BK_F_SPLIT_ALWAYS)) || M2 < 2) return;      // uniform
+    if ((p.flags & BK_F_NO_SPLIT) || p.rmap || U < 4 || (M2 < BK_SPLIT_MIN_SEEDS && !(p.flags & BK_F_SPLIT_ALWAYS)) || M2 < 2) return;      // uniform
     // the serial prefix must be short: the seeds are ordered by count, so the first rank below BK_SPLIT_HI says how many it has (a
     // deep noisy region -- 2,000x at 5 %: most error k-mers are seen eight times -- would run serially anyway while fifteen
     // workgroups wait for it)
@@ -103,15 +105,15 @@ extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkP
     const uint32_t np = min(wk->n_pairs, wk->pairs_cap), pass = wk->pass + 1;
     // 1. everything that met becomes one component (merges inside a unit included: their contigs mixed their reads)
     for (uint32_t i = tid; i < np; i += nt) bk_uf_union(rroot, pairs[3 * i], pairs[3 * i + 1]);
-    __threadfence(); __syncthreads();
+    __threadfence(); BK_SYNC();
     // 2. a merged set that holds a conflict runs again (so does a component its unit gave up: it is always in one)
     for (uint32_t i = tid; i < np; i += nt) if (pairs[3 * i + 2]) atomicOr(&cinfo[bk_uf_find(rroot, pairs[3 * i])], BK_CI_REDO);
     for (uint32_t u = tid; u < U; u += nt) if (bk_ld_agent(&cinfo[u]) & BK_CI_ABORT) atomicOr(&cinfo[bk_uf_find(rroot, u)], BK_CI_REDO);
-    __threadfence(); __syncthreads();
+    __threadfence(); BK_SYNC();
     for (uint32_t u = tid; u < U; u += nt) atomicMin(&rroot[u], bk_uf_find(rroot, u));
-    __threadfence(); __syncthreads();
+    __threadfence(); BK_SYNC();
     for (uint32_t j = tid; j < M; j += nt) { const uint32_t k0 = kroot[j]; if (k0 != BK_EMPTY32) kroot[j] = bk_ld_agent(&rroot[k0]); }
-    __threadfence(); __syncthreads();
+    __threadfence(); BK_SYNC();
     // 3. reset the state the assembler keeps per read and per k-mer (as the k-mer stage left it) for what runs again
     uint8_t *ufl = p.uflag + d.read_meta_off; int32_t *ubuf = p.ubuf + d.read_meta_off, *ureads = p.ureads + d.read_meta_off, *ufound = p.ufound + d.read_meta_off, *uminpos = p.uminpos + d.read_meta_off;
     uint8_t *kstate = p.arena + wk->o_kstate; int32_t *kstamp = (int32_t *)(p.arena + wk->o_kstamp);
@@ -125,14 +127,14 @@ extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkP
         if (k0 == BK_EMPTY32 || !(bk_ld_agent(&cinfo[k0]) & BK_CI_REDO)) continue;
         kstate[j] = BK_K_LIVE; kstamp[3 * j] = 0; kstamp[3 * j + 1] = 0; kstamp[3 * j + 2] = 0x7FFFFFFF;
     }
-    __threadfence(); __syncthreads();
+    __threadfence(); BK_SYNC();
     // 4. deal them to the units of the next pass
     for (uint32_t u = tid; u < U; u += nt) {
         if (bk_ld_agent(&rroot[u]) != u) { cinfo[u] = BK_CI_NOUNIT; continue; }            // no longer a root: its word means nothing (and must not look given up next time)
         const uint32_t ci = bk_ld_agent(&cinfo[u]);
         if (ci & BK_CI_REDO) cinfo[u] = (uint32_t)(mix64(0xD1B54A32D192ED03ull * (pass + 1) ^ u) % BK_SPLIT_G) | (pass << 8) | BK_CI_ACTIVE;
     }
-    __threadfence(); __syncthreads();
+    __threadfence(); BK_SYNC();
     if (tid < BK_SPLIT_G) { wk->unit_us[tid] = 0; wk->unit_iters[tid] = 0; }
     if (tid == 0) { wk->pass = pass; wk->n_pairs = 0; wk->n_conf = 0; wk->units_done = 0; wk->status = pass >= 200 ? BK_ST_UNSPLIT : BK_ST_OK; }
 }
@@ -157,7 +159,7 @@ extern "C" __global__ void __launch_bounds__(BK_LINK_T) bk_link_kernel(BkParams 
             const BkContigRec *c = (const BkContigRec *)(p.out + off[i]);
             if (c->root != BK_EMPTY32 && (cinfo[rroot[c->root]] & 0xFFFFu) != c->pass) key[i] = ~0ull;            // made by the unit and pass that hold the component now (no component: unit 0's serial prefix)
         }
-        __threadfence(); __syncthreads();
+        __threadfence(); BK_SYNC();
         for (uint32_t sz = 2; sz <= npad; sz <<= 1)
             for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
                 for (uint32_t i = tid; i < npad / 2; i += nt) {
@@ -166,7 +168,7 @@ extern "C" __global__ void __launch_bounds__(BK_LINK_T) bk_link_kernel(BkParams 
                     const unsigned long long a = key[lo], b = key[hi];
                     if ((a > b) == up) { key[lo] = b; key[hi] = a; const unsigned long long oa = off[lo]; off[lo] = off[hi]; off[hi] = oa; }
                 }
-                __threadfence(); __syncthreads();
+                __threadfence(); BK_SYNC();
             }
         uint32_t live = 0;
         for (uint32_t i = tid; i < n; i += nt) {
@@ -177,13 +179,13 @@ extern "C" __global__ void __launch_bounds__(BK_LINK_T) bk_link_kernel(BkParams 
         }
         for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
         __shared__ uint32_t red[BK_LINK_T / 64];
-        __syncthreads();
+        BK_SYNC();
         if ((tid & 63) == 0) red[tid >> 6] = live;
-        __syncthreads();
+        BK_SYNC();
         if (tid == 0) {
             uint32_t tot = 0; for (uint32_t w = 0; w < nt / 64; w++) tot += red[w];
             wk->n_contigs = tot; wk->o_first_contig = tot ? off[0] : 0ull; wk->o_last_contig = tot ? off[tot - 1] : 0ull;
         }
-        __syncthreads();
+        BK_SYNC();
     }
 }

@@ -12,6 +12,8 @@
 #pragma once
 #include <type_traits>
 #include "bk_common.h"
+#undef BK_SRC_ID
+#define BK_SRC_ID 1      // barrier sites of this file (bk_common.h: BK_SYNC)
 
 #define BK_KT 512             // threads per workgroup when batches are in flight (8 waves: co-resides with the assembler workgroups of other batches)
 #define BK_KT_MAX 1024        // ... when one batch runs at a time (every phase is a chain of dependent accesses of ONE workgroup: 0.30 -> 0.21 ms per launch)
@@ -175,11 +177,11 @@ __device__ inline uint32_t bk_block_sum(uint32_t v, uint32_t *scratch /* >= 17 w
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();
+    BK_SYNC();
     if ((threadIdx.x & 63) == 0) scratch[wv] = v;
-    __syncthreads();
+    BK_SYNC();
     if (threadIdx.x == 0) { uint32_t s = 0; for (int i = 0; i < nw; i++) s += scratch[i]; scratch[16] = s; }
-    __syncthreads();
+    BK_SYNC();
     return scratch[16];
 }
 // exclusive scan of one value per thread across the block; returns (prefix, total via *total)
@@ -188,25 +190,25 @@ __device__ inline uint32_t bk_block_excl_scan(uint32_t v, uint32_t *scratch /* >
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     uint32_t inc = v;
     for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    __syncthreads();
+    BK_SYNC();
     if (lane == 63) scratch[wv] = inc;
-    __syncthreads();
+    BK_SYNC();
     if (threadIdx.x == 0) { uint32_t s = 0; for (int i = 0; i < nw; i++) { uint32_t t = scratch[i]; scratch[i] = s; s += t; } scratch[17] = s; }
-    __syncthreads();
+    BK_SYNC();
     *total = scratch[17];
     return scratch[wv] + inc - v;
 }
 
 __device__ inline uint64_t bk_arena_alloc(const BkParams &p, uint64_t bytes, uint32_t *bcast /* LDS 2 words */)
 {
-    __syncthreads();
+    BK_SYNC();
     if (threadIdx.x == 0) {
         uint64_t need = bk_align_up(bytes, 256);
         uint64_t off = atomicAdd(p.arena_top, (unsigned long long)need);
         if (off + need > p.arena_cap) off = ~0ull;
         bcast[0] = (uint32_t)off; bcast[1] = (uint32_t)(off >> 32);
     }
-    __syncthreads();
+    BK_SYNC();
     return ((uint64_t)bcast[1] << 32) | bcast[0];
 }
 
@@ -238,9 +240,9 @@ __device__ inline bool bk_bucket_sort(uint32_t *perm, uint32_t M2, const uint64_
     if (LC < 1024 + 1536) return false;
     uint32_t *hc = L, *sb = L + 256, *bb = L + 512;            // per count class: size, split bits, first bucket
     for (uint32_t c = tid; c < 256; c += nt) hc[c] = 0;
-    __syncthreads();
+    BK_SYNC();
     for (uint32_t j = tid; j < M2; j += nt) atomicAdd(&hc[min(kcnt[j], 255u)], 1u);
-    __syncthreads();
+    BK_SYNC();
     if (tid == 0) {
         uint32_t nbk = 0;
         for (int c = 255; c >= 0; c--) {                         // descending count
@@ -250,11 +252,11 @@ __device__ inline bool bk_bucket_sort(uint32_t *perm, uint32_t M2, const uint64_
         }
         scr[26] = nbk;
     }
-    __syncthreads();
+    BK_SYNC();
     const uint32_t NB = scr[26];
     if (NB + 1 > bcap) return false;
     for (uint32_t b = tid; b <= NB; b += nt) bst[b] = 0;
-    __syncthreads();
+    BK_SYNC();
     auto bucket_of = [&](uint32_t j) -> uint32_t {
         const uint32_t c = min(kcnt[j], 255u), s = sb[c];
         const BkKey key{khi[j], klo[j]};
@@ -262,7 +264,7 @@ __device__ inline bool bk_bucket_sort(uint32_t *perm, uint32_t M2, const uint64_
         return bb[c] + ((1u << s) - 1u - top);                   // mer descending inside the class
     };
     for (uint32_t j = tid; j < M2; j += nt) atomicAdd(&bst[bucket_of(j)], 1u);
-    __syncthreads();
+    BK_SYNC();
     {   // exclusive prefix over the buckets -> first position of each; a copy serves as the scatter cursor
         const uint32_t chunk = (NB + nt - 1) / nt, b0 = tid * chunk, b1 = min(NB, b0 + chunk);
         uint32_t c = 0, tot = 0, big = 0;
@@ -270,13 +272,13 @@ __device__ inline bool bk_bucket_sort(uint32_t *perm, uint32_t M2, const uint64_
         uint32_t pre = bk_block_excl_scan(c, scr, &tot);
         for (uint32_t b = b0; b < b1; b++) { const uint32_t n = bst[b]; bst[b] = pre; bcur[b] = pre; pre += n; }
         if (tid == 0) { bst[NB] = tot; scr[27] = 0; }
-        __syncthreads();
+        BK_SYNC();
         if (big) scr[27] = 1;
-        __syncthreads();
+        BK_SYNC();
         if (scr[27]) return false;                               // some bucket is larger than a wavefront sorts
     }
     for (uint32_t j = tid; j < M2; j += nt) perm[atomicAdd(&bcur[bucket_of(j)], 1u)] = j;
-    __syncthreads();
+    BK_SYNC();
     // one wavefront per bucket; (proxy, index) pairs in LDS
     const uint32_t stride = BK_BS_CAP * 3, nwv = min(nt >> 6, LC / stride);
     if (wv < nwv) {
@@ -310,12 +312,12 @@ __device__ inline bool bk_bucket_sort(uint32_t *perm, uint32_t M2, const uint64_
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
     }
-    __syncthreads();
+    BK_SYNC();
     return true;
 }
 
 #ifdef BK_PHASE_STAMPS
-#define BK_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) wk->stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define BK_STAMP(i) do { BK_SYNC(); if (threadIdx.x == 0) wk->stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define BK_STAMP(i) do { } while (0)
 #endif
@@ -339,7 +341,7 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
     uint32_t *gslot = p.grp_slot + d.read_meta_off;
     if constexpr (LG) { for (uint32_t i = tid; i < d.dedup_cap; i += nt) lslot[i] = BK_EMPTY32; }
     else for (uint32_t i = tid; i < d.dedup_cap; i += nt) { dslot[i] = BK_EMPTY64; dcnt[i] = 0; }
-    __syncthreads();
+    BK_SYNC();
     const uint32_t dmask = d.dedup_cap - 1;
     const uint8_t *rfl = p.read_flag + d.read_meta_off;
     const uint32_t *nl = p.nlist + d.nlist_off; const uint32_t nnl = d.n_nlist;
@@ -392,7 +394,7 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
         gslot[i] = s;
         if constexpr (!LG) atomicAdd(&dcnt[s], 1u);
     }
-    __syncthreads();
+    BK_SYNC();
 #ifdef BK_PHASE_STAMPS
     if (threadIdx.x == 0) p.work[p.rmap ? p.rmap[blockIdx.x] : blockIdx.x].stamps[2] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -414,12 +416,12 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
         for (int t = 0; t < 32; t++) if (b + t < e && rep_of(g[t]) == b + t) isrep |= 1u << t;
         c = __popc(isrep);
         if constexpr (LG) {                                     // copy counts: the slot words become a histogram over grp_slot
-            __syncthreads();
+            BK_SYNC();
             for (uint32_t i = tid; i < d.dedup_cap; i += nt) lslot[i] = 0;
-            __syncthreads();
+            BK_SYNC();
 #pragma unroll
             for (int t = 0; t < 32; t++) if (b + t < e) atomicAdd(&lslot[g[t]], 1u);
-            __syncthreads();
+            BK_SYNC();
         }
         uint32_t pre = bk_block_excl_scan(c, scr, &U);
 #pragma unroll
@@ -431,7 +433,7 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
         uint32_t pre = bk_block_excl_scan(c, scr, &U);
         for (uint32_t i = b; i < e; i++) if (rep_of(gslot[i]) == i) urep[pre++] = i;
     }
-    __syncthreads();
+    BK_SYNC();
     // only the representative list is written from the per-thread chunks (scattered); the other per-unique-read arrays
     // are filled by index so that a wave writes whole lines
     for (uint32_t j = tid; j < U; j += nt) {
@@ -439,11 +441,13 @@ __device__ inline uint32_t bk_group_reads(const BkParams &p, const BkRegionDesc 
         unr[j] = cnt_of(sl); ufl[j] = ((f & BK_RF_INDEL) ? BK_R_INDEL : 0) | ((f & BK_RF_HASN) ? BK_R_HASN : 0); ulen[j] = rlen[i];
         p.ubuf[d.read_meta_off + j] = 0; p.ureads[d.read_meta_off + j] = 0; p.ufound[d.read_meta_off + j] = -1; p.uminpos[d.read_meta_off + j] = 0x7FFFFFFF;
     }
-    __syncthreads();
+    BK_SYNC();
     return U;
 }
 
 #include "bk_comp.hip.h"
+#undef BK_SRC_ID
+#define BK_SRC_ID 1
 
 #define BK_K_PERM_G 16384      // words of LDS sort permutation in the global-table variant
 
@@ -501,7 +505,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         rt.win_f = gw; rt.win_r = win_r; rt.tab = tab; rt.cap_mask = gcap - 1; rt.nww = ww + 2;     // the host pads every packed window with 2 zero words
         perm_lds = lds + 32 + 16 * 16; perm_cap = BK_K_PERM_G;
     }
-    __syncthreads();
+    BK_SYNC();
     // reverse complement, packed: base j of rc = 3 - base (W-1-j) of forward
     {
         uint32_t *win_r = const_cast<uint32_t *>(rt.win_r);
@@ -511,14 +515,14 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
             win_r[wi] = x;
         }
     }
-    __syncthreads();
+    BK_SYNC();
     if (d.n_win_n) {                                         // a window with N (rare): which window k-mers do not exist
         const uint32_t nbw = (uint32_t)(2 * WK + 31) / 32 + 1;
         const uint64_t o_nb = bk_arena_alloc(p, (uint64_t)nbw * 4, scr + 20);
         if (o_nb == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
         uint32_t *nb = (uint32_t *)(p.arena + o_nb);
         for (uint32_t i = tid; i < nbw; i += nt) nb[i] = 0;
-        __syncthreads();
+        BK_SYNC();
         const uint32_t *wn = p.wnlist + d.win_n_off;
         for (uint32_t e = tid; e < d.n_win_n; e += nt) {
             const int pf = (int)wn[e], pr = W - 1 - pf;      // position in the forward / in the reverse-complement window
@@ -526,11 +530,11 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
             for (int x = max(pr - k + 1, 0); x <= min(pr, WK - 1); x++) atomicOr(&nb[(WK + x) >> 5], 1u << ((WK + x) & 31));
         }
         __threadfence();
-        __syncthreads();
+        BK_SYNC();
         rt.nbits = nb;
     }
     for (int i = tid; i < 2 * WK; i += nt) if (!rt.dead(i)) rt.insert((uint32_t)i);
-    __syncthreads();
+    BK_SYNC();
 
     BK_STAMP(3);
     // ---- P3a: which unique reads have non-reference k-mers at all -------------------------------------
@@ -538,7 +542,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     // errors, SV junctions) go on a list (grp_slot is free after P2) and get the full scan
     uint32_t *slow = gslot;
     if (tid == 0) scr[25] = 0;
-    __syncthreads();
+    BK_SYNC();
     uint32_t myk = 0;                                            // k-mer positions of the listed reads: upper bound of T
     for (uint32_t u = tid; u < U; u += nt) {
         const uint32_t i = urep[u]; const int len = rlen[i];
@@ -546,7 +550,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         if (len <= 16 * BK_RW_MAX && !(p.uflag[d.read_meta_off + u] & BK_R_HASN)) { uint32_t wb[BK_RW_MAX]; bk_load_words(reads + (uint64_t)i * RW, (len + 15) / 16, wb); clean = bk_read_is_clean(wb, len, rt); }
         if (!clean) { slow[atomicAdd(&scr[25], 1u)] = u; myk += (uint32_t)max(len - k + 1, 0); }
     }
-    __syncthreads();
+    BK_SYNC();
     const uint32_t nslow = scr[25];
     BK_STAMP(8);
     const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
@@ -565,7 +569,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     const uint64_t o_ent = a0, o_tsl = bk_align_up(o_ent + (uint64_t)Tmax * 4, 256);
     uint32_t *t_ent = (uint32_t *)(p.arena + o_ent), *t_sl = (uint32_t *)(p.arena + o_tsl);
     if (tid == 0) scr[24] = 0;
-    __syncthreads();
+    BK_SYNC();
     // Each wavefront takes the listed reads wv, wv + 8, ...: the metadata of up to 64 of them is fetched by the 64 lanes
     // at once and the packed words of read j+1 are requested before read j is scanned, so the scan of a read does not
     // wait for three dependent global accesses of its own (they were 3 of the 4 us a read took).
@@ -607,7 +611,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
             } else if (lane == 0) bk_scan_nonref(reads + (uint64_t)i * RW, len, rt, rec);
         }
     }
-    __syncthreads();
+    BK_SYNC();
     const uint32_t T = scr[24];
     // sized by the OCCURRENCES (their number is all that is known here), of which the distinct k-mers are a part (3/4 at 5 % noise):
     // 1.5 T slots keep the load below 2/3 even if every occurrence were distinct; a power of two >= 2 T (round 2) doubled the
@@ -630,7 +634,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     }
     uint32_t *wslot = tslot, *wcnt = tcnt;
     for (uint32_t i = tid; i < tcap; i += nt) { wslot[i] = BK_EMPTY32; wcnt[i] = 0; }
-    __syncthreads();
+    BK_SYNC();
     BK_STAMP(11);
     const uint32_t tmask = tcap - 1;
     for (uint32_t idx = tid; idx < T; idx += nt) {
@@ -646,7 +650,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         }
         t_sl[idx] = s; atomicAdd(&wcnt[s], unr[u]);          // case[mer] counts every read (duplicates included)
     }
-    __syncthreads();
+    BK_SYNC();
     // soft-clip set: keep only k-mers also present in case_sc (sv_processor.py:619-621)
     if (d.n_sc >= 0) {
         const uint32_t *sc = p.sc + d.sc_word_off; const uint16_t *sl = p.sc_len + d.sc_meta_off;
@@ -662,9 +666,9 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
                 }
             });
         }
-        __syncthreads();
+        BK_SYNC();
         for (uint32_t i = tid; i < tcap; i += nt) { if (tslot[i] != BK_EMPTY32 && !(tcnt[i] & 0x80000000u)) tslot[i] = BK_EMPTY32 - 1; tcnt[i] &= 0x7FFFFFFFu; }   // tombstone: probe chains stay intact
-        __syncthreads();
+        BK_SYNC();
     }
     BK_STAMP(5);
     // ---- P4: compact -> M sample-only k-mers.  Those that can seed a contig (count >= 2, init_assembly :46) come
@@ -705,12 +709,12 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         const uint32_t j = tcnt[i] >= 2 ? pre2++ : M2 + pre1++;
         klo[j] = key.lo; khi[j] = key.hi; kcnt[j] = tcnt[i]; ptmp[j] = i;
     }
-    __syncthreads();
+    BK_SYNC();
     bool sorted = false;
     if (use_bucket) sorted = bk_bucket_sort(perm, M2, klo, khi, kcnt, k, perm_lds, perm_cap, (uint32_t *)(p.arena + o_bst), (uint32_t *)(p.arena + o_bst) + bcap, bcap, scr);
     if (!sorted) {
         for (uint32_t i = tid; i < npad; i += nt) perm[i] = i < M2 ? i : BK_EMPTY32;
-        __syncthreads();
+        BK_SYNC();
         for (uint32_t sz = 2; sz <= npad; sz <<= 1)
             for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
                 for (uint32_t i = tid; i < npad / 2; i += nt) {
@@ -722,7 +726,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
                     else { BkKey ka{khi[a], klo[a]}, kb{khi[b], klo[b]}; a_first = bk_kmer_before(kcnt[a], ka, kcnt[b], kb); }
                     if (a_first != up) { perm[lo] = b; perm[hi2] = a; }
                 }
-                __syncthreads();
+                BK_SYNC();
             }
     }
     // apply the permutation: arrays indexed by compaction index -> arrays indexed by rank, staged through the
@@ -731,29 +735,29 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         uint64_t *s64 = (uint64_t *)kstamp;                     // M*8 of the M*12 stamp bytes
         uint32_t *s32 = poff;                                   // (M+1)*4
         for (uint32_t j = tid; j < M; j += nt) { uint32_t a = j < M2 ? perm[j] : j; s64[j] = klo[a]; s32[j] = kcnt[a]; }
-        __syncthreads();
+        BK_SYNC();
         for (uint32_t j = tid; j < M; j += nt) { klo[j] = s64[j]; kcnt[j] = s32[j]; }
-        __syncthreads();
+        BK_SYNC();
         for (uint32_t j = tid; j < M; j += nt) { uint32_t a = j < M2 ? perm[j] : j; s64[j] = khi[a]; s32[j] = ptmp[a]; }
-        __syncthreads();
+        BK_SYNC();
         // the assembler's lookups go table slot -> rank -> key: the slot itself now holds the rank (the claimant is not needed any more)
         for (uint32_t j = tid; j < M; j += nt) { khi[j] = s64[j]; tslot[s32[j]] = j; ptmp[j] = 0; }
-        __syncthreads();
+        BK_SYNC();
     }
     for (uint32_t j = tid; j < M; j += nt) {
         BkKey key{khi[j], klo[j]};
         kstate[j] = key_homopolymer(key, k) ? BK_K_REMOVED : BK_K_LIVE;      // kmers.add_kmer (sv_assembly.py:277)
         kstamp[3 * j] = 0; kstamp[3 * j + 1] = 0; kstamp[3 * j + 2] = 0x7FFFFFFF;
     }
-    __syncthreads();
+    BK_SYNC();
     BK_STAMP(6);
     // ---- P5: posting lists k-mer rank -> (u, pos) -------------------------------------------------
     // list lengths and fill cursors in LDS when they fit (the LDS holds nothing that is still needed), else in ptmp
     // (LDS table: in the count words, which are free by now; else the start of the LDS, which holds nothing that is still needed)
     uint32_t *pcur = lds_tab ? tcnt : (M + 32u + 16u * 16u <= lds_words ? lds + 32 + 16 * 16 : ptmp);
-    if (pcur != ptmp) { for (uint32_t j = tid; j < M; j += nt) pcur[j] = 0; __syncthreads(); }
+    if (pcur != ptmp) { for (uint32_t j = tid; j < M; j += nt) pcur[j] = 0; BK_SYNC(); }
     for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = tslot[t_sl[idx]]; if (rk < BK_EMPTY32 - 1) atomicAdd(&pcur[rk], 1u); }
-    __syncthreads();
+    BK_SYNC();
     {
         const uint32_t chunk = (M + nt - 1) / nt, b = tid * chunk, e = min(M, b + chunk);
         uint32_t c = 0, tot;
@@ -762,26 +766,26 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         for (uint32_t j = b; j < e; j++) { uint32_t n = pcur[j]; poff[j] = pre; pcur[j] = pre; pre += n; }
         if (tid == 0) poff[M] = tot;
     }
-    __syncthreads();
+    BK_SYNC();
     for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = tslot[t_sl[idx]]; if (rk < BK_EMPTY32 - 1) post[atomicAdd(&pcur[rk], 1u)] = t_ent[idx]; }
-    __syncthreads();
+    BK_SYNC();
     uint32_t out_tcap = tcap;
     if (lds_tab) {
         // compact table slot -> rank for the assembler's lookups (bk_lookup): tcap2 >= 2 M slots, built in the count words, copied out once
         uint32_t *tab2 = tcnt, *gtab2 = (uint32_t *)(p.arena + o_tab2);
         for (uint32_t i = tid; i < tcap2; i += nt) tab2[i] = BK_EMPTY32;
-        __syncthreads();
+        BK_SYNC();
         for (uint32_t j = tid; j < M; j += nt) {
             const BkKey key{khi[j], klo[j]};
             uint32_t s2 = key_hash(key) & (tcap2 - 1);
             while (atomicCAS(&tab2[s2], BK_EMPTY32, j) != BK_EMPTY32) s2 = (s2 + 1) & (tcap2 - 1);
         }
-        __syncthreads();
+        BK_SYNC();
         for (uint32_t i = tid; i < tcap2; i += nt) gtab2[i] = tab2[i];
         o_tslot = o_tab2; out_tcap = tcap2;
     }
     BK_STAMP(7);
-    __syncthreads();
+    BK_SYNC();
     bk_split_prepare(p, wk, U, M, M2, kcnt, scr);      // noisy regions: several assembler workgroups per region (bk_comp.hip.h)
     if (tid == 0) {
         wk->U = U; wk->T = T; wk->M = M; wk->M2 = M2; wk->tcap = out_tcap;

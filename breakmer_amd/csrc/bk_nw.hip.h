@@ -28,6 +28,8 @@
 // Integer VALU + DPP only (no MFMA: a max-plus recurrence is not a dense contraction).
 #pragma once
 #include "bk_common.h"
+#undef BK_SRC_ID
+#define BK_SRC_ID 3      // barrier sites of this file (bk_common.h: BK_SYNC)
 
 #define BK_NW_PRIO_MASK 0x00030000
 #define BK_NW_MATCH ((1 << 18) + (2 << 16))

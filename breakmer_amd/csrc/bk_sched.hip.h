@@ -9,6 +9,8 @@
 // persistent: each pulls the next region of that order from a device-side queue head until the queue is empty.
 #pragma once
 #include "bk_common.h"
+#undef BK_SRC_ID
+#define BK_SRC_ID 2      // barrier sites of this file (bk_common.h: BK_SYNC)
 
 #define BK_SCHED_T 1024
 
@@ -28,7 +30,7 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
         }
         keys[i] = key;
     }
-    __syncthreads();
+    BK_SYNC();
     for (uint32_t sz = 2; sz <= npad; sz <<= 1)
         for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
             for (uint32_t i = tid; i < npad / 2; i += BK_SCHED_T) {
@@ -37,14 +39,14 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
                 const unsigned long long a = keys[lo], b = keys[hi];
                 if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
             }
-            __syncthreads();
+            BK_SYNC();
         }
 #ifdef BK_QUEUE_REGION_MAJOR      // diagnostic: the queue order of the first version (the units of a region behind each other)
     // the queue: one entry per unit -- (region | unit << 24); the units of a split region (bk_comp.hip.h) follow each other, so the
     // heaviest region's components are all in flight at once
     __shared__ uint32_t wsum[BK_SCHED_T / 64], base_s;
     if (tid == 0) base_s = 0;
-    __syncthreads();
+    BK_SYNC();
     for (int c0 = 0; c0 < n; c0 += BK_SCHED_T) {
         const int i = c0 + tid;
         uint32_t rid = 0, g = 0;
@@ -52,14 +54,14 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
         uint32_t inc = g;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((tid & 63) >= o) inc += t; }
         if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-        __syncthreads();
+        BK_SYNC();
         uint32_t pre = base_s, tot = 0;
         for (int w = 0; w < BK_SCHED_T / 64; w++) { const uint32_t t = wsum[w]; if (w < (tid >> 6)) pre += t; tot += t; }
         const uint32_t at = pre + inc - g;
         for (uint32_t u = 0; u < g; u++) p.order[at + u] = rid | (u << BK_QUEUE_UNIT_SHIFT);
-        __syncthreads();
+        BK_SYNC();
         if (tid == 0) base_s += tot;
-        __syncthreads();
+        BK_SYNC();
     }
 #else
     // the queue: one entry per unit -- (region | unit << 24).  First every region once (unit 0 of a split region, bk_comp.hip.h: it
@@ -69,7 +71,7 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
     __shared__ uint32_t wsum[BK_SCHED_T / 64], base_s;
     for (int i = tid; i < n; i += BK_SCHED_T) p.order[i] = (uint32_t)keys[i];
     if (tid == 0) base_s = (uint32_t)n;
-    __syncthreads();
+    BK_SYNC();
     for (int c0 = 0; c0 < n; c0 += BK_SCHED_T) {
         const int i = c0 + tid;
         uint32_t rid = 0, g = 0;                                             // g: units beyond the first
@@ -77,14 +79,14 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
         uint32_t inc = g;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((tid & 63) >= o) inc += t; }
         if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-        __syncthreads();
+        BK_SYNC();
         uint32_t pre = base_s, tot = 0;
         for (int w = 0; w < BK_SCHED_T / 64; w++) { const uint32_t t = wsum[w]; if (w < (tid >> 6)) pre += t; tot += t; }
         const uint32_t at = pre + inc - g;
         for (uint32_t u = 0; u < g; u++) p.order[at + u] = rid | ((u + 1u) << BK_QUEUE_UNIT_SHIFT);
-        __syncthreads();
+        BK_SYNC();
         if (tid == 0) base_s += tot;
-        __syncthreads();
+        BK_SYNC();
     }
 #endif
     if (tid == 0) *p.n_queue = base_s;

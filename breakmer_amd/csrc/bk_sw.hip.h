@@ -23,19 +23,22 @@
 // Chaining of collinear hits into PSL records is host code (bk_api.hip), restated in the oracle.
 #pragma once
 #include "bk_common.h"
+#undef BK_SRC_ID
+#define BK_SRC_ID 6      // barrier sites of this file (bk_common.h: BK_SYNC)
 
 #define BK_ST_TMAX 512                 // largest workgroup (the LONG tier and batches of few contigs); the SHORT tier runs smaller ones
 #define BK_ST_T ((int)blockDim.x)
 #define BK_SW_MIN_SEG 20
 #define BK_SW_FLAGS 1024
 
-// Step-1 hits tile the query with >= BK_SW_MIN_SEG bases each (a hit scores >= min_score >= its length's worth of matches), so a
-// contig of at most max_contig bases has at most max_contig / BK_SW_MIN_SEG of them: the hit list and the interval stack are
-// sized for that in the dynamic LDS block and cannot overflow.  Secondary alignments have no such bound (a microsatellite in
+// Step-1 hits tile the query; a hit holds at least min_score bases (it scores >= min_score, +1 per match) and is only looked for
+// in intervals of >= BK_SW_MIN_SEG bases, so a contig of at most max_contig bases has at most max_contig / min(BK_SW_MIN_SEG,
+// min_score) of them: the hit list and the interval stack are sized for that in the dynamic LDS block and cannot overflow
+// (should they ever, the region fails with BK_ST_HITS: never a silent drop).  Secondary alignments have no such bound (a microsatellite in
 // the window: hundreds per contig): BK_SEC_LDS of them are collected in LDS; when there are more the sweep is repeated
 // writing straight into the result arena (their number is known by then).  Neither is a cap.
 #define BK_SEC_LDS 256
-__host__ __device__ inline int bk_sw_max_hits(int max_contig) { return max_contig / BK_SW_MIN_SEG + 2; }
+__host__ __device__ inline int bk_sw_max_hits(int max_contig, int min_score) { const int ms = min_score < 1 ? 1 : min_score; return max_contig / (ms < BK_SW_MIN_SEG ? ms : BK_SW_MIN_SEG) + 2; }
 struct BkSwShared {
     int nseg;
     int nhits;
@@ -57,10 +60,10 @@ struct BkSwShared {
 // workgroups with the block sized for max_contig (idle when that list is empty, the rule).  Both run the same code.
 struct BkSwTier { uint32_t tw_cap; int contig_cap, sec_lds, n_flags, mode; };      // mode 0: the contig list, longer ones deferred; 1: the deferred ones
 struct BkSwLayout { uint32_t qf, qpk, tp, tnb, hits, seg, sec, foff, fts, total; int qpw, max_hits; };
-__host__ __device__ inline BkSwLayout bk_sw_layout(int contig_cap, uint32_t tw_cap, int sec_lds, int n_flags)
+__host__ __device__ inline BkSwLayout bk_sw_layout(int contig_cap, uint32_t tw_cap, int sec_lds, int n_flags, int min_score)
 {
     BkSwLayout L;
-    L.qpw = contig_cap / 16 + 2; L.max_hits = bk_sw_max_hits(contig_cap);
+    L.qpw = contig_cap / 16 + 2; L.max_hits = bk_sw_max_hits(contig_cap, min_score);
     uint32_t o = (uint32_t)((sizeof(BkSwShared) + 15) / 16) * 16;
     L.qf = o; o += 2 * (uint32_t)contig_cap; o = (o + 15) / 16 * 16;            // contig, forward and reverse complement (codes)
     L.qpk = o; o += 4 * 4 * (uint32_t)L.qpw;                                   // packed query interval + N masks, both strands
@@ -259,7 +262,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
     extern __shared__ __attribute__((aligned(16))) uint8_t sl[];
     const int tid = threadIdx.x;
     const uint32_t tw_cap = T.tw_cap;
-    const BkSwLayout LY = bk_sw_layout(T.contig_cap, T.tw_cap, T.sec_lds, T.n_flags);
+    const BkSwLayout LY = bk_sw_layout(T.contig_cap, T.tw_cap, T.sec_lds, T.n_flags, p.sw_min_score);
     BkSwShared *S = (BkSwShared *)sl;
     uint8_t *qf = sl + LY.qf;                                          // contig forward (codes)
     uint8_t *qr = qf + T.contig_cap;                                   // contig reverse complement
@@ -277,7 +280,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
     const unsigned long long n_list = T.mode == 0 ? min(*p.n_clist, (unsigned long long)p.clist_cap) : min(*p.n_sw_long, (unsigned long long)p.clist_cap);
     const unsigned long long *list = T.mode == 0 ? p.clist : p.sw_long;
     for (;;) {
-        __syncthreads();
+        BK_SYNC();
         if (tid == 0) {
             const unsigned long long qi = atomicAdd(T.mode == 0 ? p.sw_head : p.sw_long_head, 1ull);
             S->qidx = qi; S->cells = 0; S->status = 0; S->skip = 0;
@@ -294,7 +297,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                 if (!S->skip && S->staged_region != rr) { S->staged_ti = -1; S->staged_region = rr; }
             }
         }
-        __syncthreads();
+        BK_SYNC();
         if (S->qidx >= n_list) break;
         if (S->skip) continue;
         const unsigned long long ent = list[S->qidx];
@@ -307,12 +310,12 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
         const char *seq = (const char *)(p.out + roff + rec->o_seq);
         for (int i = tid; i < Q; i += BK_ST_T) { char ch = seq[i]; uint8_t c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : BK_CODE_N; qf[i] = c; qr[Q - 1 - i] = c == BK_CODE_N ? (uint8_t)BK_CODE_N : (uint8_t)(3 - c); }
         if (tid == 0) { S->nseg = 1; seg[0] = 0; seg[1] = Q; S->nhits = 0; S->nsec = 0; S->nflag = 0; }
-        __syncthreads();
+        BK_SYNC();
         while (S->nseg > 0 && S->status == 0) {
             const int qs = seg[2 * (S->nseg - 1)], qe = seg[2 * (S->nseg - 1) + 1], n = qe - qs;
-            __syncthreads();
+            BK_SYNC();
             if (tid == 0) { S->nseg--; S->best_key = 0; S->best_run = 0; S->L = 0; }
-            __syncthreads();
+            BK_SYNC();
             if (n < BK_SW_MIN_SEG) continue;
             const bool first = qs == 0 && qe == Q && S->nhits == 0;              // the first pass: the whole query
             // packed copies of the query interval (both strands) for the match counts
@@ -330,15 +333,15 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                 for (int o0 = -(n - 1); o0 < m; o0 += CH) {
                     const int o1 = min(o0 + CH, m), t0 = max(o0, 0), t1 = min(m, o1 - 1 + n);
                     const int tpw0 = t0 >> 4, tpn = ((t1 + 15) >> 4) - tpw0;
-                    __syncthreads();
+                    BK_SYNC();
                     const bool staged = S->staged_ti == ti && S->staged_t0 == t0 && S->staged_t1 == t1;   // e.g. one short window: staged once per region
-                    __syncthreads();
+                    BK_SYNC();
                     if (!staged) for (int i = tid; i < tpn; i += BK_ST_T) { tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u; if (nn) tnb[i] = 0u; }
                     if (tid == 0) { S->umax = 0; S->staged_ti = ti; S->staged_t0 = t0; S->staged_t1 = t1; }
-                    __syncthreads();
+                    BK_SYNC();
                     if (!staged && nn) {
                         for (int e = tid; e < nn; e += BK_ST_T) { const int pn = (int)wn[e], wi = (pn >> 4) - tpw0; if ((unsigned)wi < (unsigned)tpn) atomicOr(&tnb[wi], 1u << (2 * (15 - (pn & 15)))); }
-                        __syncthreads();
+                        BK_SYNC();
                     }
                     const int nd = o1 - o0;
                     // (1) match counts; this thread's two best diagonals and the largest count among its others.  The first pass
@@ -356,7 +359,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                         else if (u > myu3) myu3 = u;
                     }
                     if (myu > 0) atomicMax(&S->umax, myu);
-                    __syncthreads();
+                    BK_SYNC();
                     // (2) the diagonals with the largest count raise the lower bound
                     int walked = -1;
                     if (myu == S->umax && myu >= S->L && myu > 0) {
@@ -365,7 +368,7 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                         if (bh > 0) { const unsigned long long key = bk_sw_key(bh, ti, st, ba, (long long)ba + off); if (key > bkey) { bkey = key; brun = br; } atomicMax(&S->L, bh); }
                         walked = myD;
                     }
-                    __syncthreads();
+                    BK_SYNC();
                     // (3) every diagonal that can still hold the maximum (count >= L; ties are walked): this thread's best one if (2)
                     // did not take it, its second best, and -- only if even the largest of its other counts reaches L -- a
                     // rescan of all its diagonals (rare: the counts of unrelated diagonals are far below an achieved score)
@@ -387,12 +390,12 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                     }
                 }
                 if (tid == 0) S->cells += 2ull * (unsigned long long)n * (unsigned long long)m;
-                __syncthreads();
+                BK_SYNC();
             }
             // block reduction of the best key (unique: (target, strand, a, b) identify a cell)
             for (int o = 32; o > 0; o >>= 1) { unsigned long long ok = __shfl_xor(bkey, o); int orun = __shfl_xor(brun, o); if (ok > bkey) { bkey = ok; brun = orun; } }
             if ((tid & 63) == 0) { S->red[tid >> 6] = bkey; S->red_run[tid >> 6] = brun; }
-            __syncthreads();
+            BK_SYNC();
             if (tid == 0) {
                 for (int w = 0; w < (BK_ST_T + 63) / 64; w++) if (S->red[w] > S->best_key) { S->best_key = S->red[w]; S->best_run = S->red_run[w]; }
                 const unsigned long long key = S->best_key; const int score = (int)(key >> 49);
@@ -406,13 +409,13 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                         hits[S->nhits++] = hgt;
                         seg[2 * S->nseg] = fe; seg[2 * S->nseg + 1] = qe; S->nseg++;            // right remainder (after the left one)
                         seg[2 * S->nseg] = qs; seg[2 * S->nseg + 1] = fs; S->nseg++;
-                    }
+                    } else S->status = BK_ST_HITS;                                            // (unreachable by the sizing above; loud if it ever is)
                 }
             }
-            __syncthreads();
+            BK_SYNC();
         }
         // ---- step 5: secondary alignments (a contig without a step-1 hit has none: the first pass saw every diagonal) ----
-        __syncthreads();
+        BK_SYNC();
         if (S->nhits > 0 && S->status == 0) {
             const int n = Q, nh1 = S->nhits;
             bk_sw_pack_query(qf, qr, Q, 0, Q, qpk, qnm, qpw, tid);
@@ -428,15 +431,15 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                 for (int o0 = -(n - 1); o0 < m; o0 += CH) {
                     const int o1 = min(o0 + CH, m), t0 = max(o0, 0), t1 = min(m, o1 - 1 + n);
                     const int tpw0 = t0 >> 4, tpn = ((t1 + 15) >> 4) - tpw0;
-                    __syncthreads();
+                    BK_SYNC();
                     const bool staged = S->staged_ti == ti && S->staged_t0 == t0 && S->staged_t1 == t1;
-                    __syncthreads();
+                    BK_SYNC();
                     if (!staged) for (int i = tid; i < tpn; i += BK_ST_T) { tp[i] = tpw0 + i < mw ? gw[tpw0 + i] : 0u; if (nn) tnb[i] = 0u; }
                     if (tid == 0) { S->staged_ti = ti; S->staged_t0 = t0; S->staged_t1 = t1; }
-                    __syncthreads();
+                    BK_SYNC();
                     if (!staged && nn) {
                         for (int e = tid; e < nn; e += BK_ST_T) { const int pn = (int)wn[e], wi = (pn >> 4) - tpw0; if ((unsigned)wi < (unsigned)tpn) atomicOr(&tnb[wi], 1u << (2 * (15 - (pn & 15)))); }
-                        __syncthreads();
+                        BK_SYNC();
                     }
                     const int nd = o1 - o0;
                     const int nfl = S->nflag, nwork = nfl <= T.n_flags ? nfl : 2 * nd;      // the diagonals the first pass flagged; all of them if that list overflowed
@@ -461,13 +464,13 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                     }
                 }
                 if (tid == 0 && count_cells) S->cells += 2ull * (unsigned long long)n * (unsigned long long)m;
-                __syncthreads();
+                BK_SYNC();
             }
             };
             sweep(sec, T.sec_lds, true);
-            __syncthreads();
+            BK_SYNC();
             const int total = S->nsec;                                       // every thread reads it before it is reset
-            __syncthreads();
+            BK_SYNC();
             if (total > T.sec_lds) {
                 // more than the LDS list holds: room for all of them (behind the step-1 hits) in the result arena, same sweep again
                 if (tid == 0) {
@@ -477,14 +480,14 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                     if (!S->rec_off) S->status = BK_ST_OUT;
                     S->nsec = 0;
                 }
-                __syncthreads();
+                BK_SYNC();
                 if (S->rec_off) sweep((BkHit *)(p.out + S->rec_off) + nh1, total, false);
-                __syncthreads();
+                BK_SYNC();
                 if (tid == 0) S->nsec = S->rec_off ? -total : 0;             // negative: already in the arena
             }
         }
         // write the raw hits next to the contig record
-        __syncthreads();
+        BK_SYNC();
         if (tid == 0) {
             const int nh = S->nhits; int ns = S->nsec;
             rec->n_hits = nh; rec->n_sec = (uint32_t)(ns < 0 ? -ns : ns); rec->hits_off = 0;

@@ -18,7 +18,7 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("BREAKMER_HIP_LIB") or os.path.join(_HERE, "libbreakmer_hip.so")     # the override is for A/B builds (tools/)
+LIB_PATH = os.path.join(_HERE, "libbreakmer_hip.so")      # the product build; diagnostic builds (build.VARIANTS) are named explicitly: load_library(path)
 
 BK_STAGE_KMER, BK_STAGE_ASSEMBLE, BK_STAGE_REALIGN, BK_STAGE_ALL = 1, 2, 4, 7
 BK_MAX_BLOCKS = 32
@@ -79,15 +79,20 @@ class BreakmerHipError(RuntimeError):
     pass
 
 
-def load_library():
-    """dlopen the in-tree library; raises if it has not been built (no fallback)."""
+def load_library(path=None):
+    """dlopen the in-tree library; raises if it has not been built (no fallback).  `path`: another build of the library
+    (a diagnostic variant of build.VARIANTS) -- named by tests / tools BEFORE the first engine is made; the product never passes it
+    and reads no environment variable to choose one."""
     global _lib
     if _lib is not None:
+        if path is not None and os.path.abspath(path) != _lib._name:
+            raise BreakmerHipError("load_library(%s): %s is loaded already" % (path, _lib._name))
         return _lib
-    if not os.path.isfile(os.environ.get("BK_LIB") or LIB_PATH):
+    lp = os.path.abspath(path) if path else LIB_PATH
+    if not os.path.isfile(lp):
         raise BreakmerHipError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
-    L = C.CDLL(os.environ.get("BK_LIB") or LIB_PATH)      # (BK_LIB: diagnostic -- another build of the library)
+                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % lp)
+    L = C.CDLL(lp)
     L.bk_last_error.restype = C.c_char_p
     L.bk_last_error.argtypes = [C.c_void_p]
     L.bk_create.argtypes = [C.c_int, C.POINTER(BkConfig), C.POINTER(C.c_void_p)]

@@ -125,12 +125,15 @@ class Region(object):
 def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int = 150, depth: int = 500,
                 sv_type: str = "del", sv_size: int | None = None, noise: float = 0.0,
                 n_reads: int | None = None, var_len: float = 0.0, indel_only_frac: float = 0.0, n_frac: float = 0.0,
-                flank_dups: int = 0, trl_repeat_copies: int = 0, microsat: int = 0) -> Region:
+                flank_dups: int = 0, trl_repeat_copies: int = 0, microsat: int = 0, flank_div: int = 0) -> Region:
     """Generate region `region_id` (config 1-3 defaults).
 
     Multi-mapping variants (realign contract step 5; off by default, the default regions are unchanged):
       flank_dups (del only): bit 0 = the L bases left of the deletion also sit at window[20:20+L], bit 1 = the L bases right
         of it also at window[W-20-L:W-20], bit 2 = that right copy is reverse-complemented;
+      flank_div (with flank_dups bit 0): the left copy is DIVERGED -- its last 30 bases (next to where the junction would be) are
+        exact (two of BLAT's index tiles wherever the grid falls), of the bases before them every flank_div-th is substituted:
+        4 -> an ~80 % copy (a +1/-2 segment still runs through it; BLAT's -minIdentity=90 drops it), 12 -> a ~94 % copy;
       trl_repeat_copies (trl only): a second partner window holding that many copies of the partner half of the donor;
       microsat (del only): the `microsat` bases left of the deletion are a (CA)n repeat -- a contig across the junction then
         aligns on every second diagonal of the repeat (tens to hundreds of secondary alignments)."""
@@ -153,7 +156,11 @@ def make_region(region_id: int, *, global_seed: int = 1, W: int = 3000, L: int =
         assert sv_type == "del" and W >= 2 * (h + 2 * L + 40)
         win = win.copy()
         if flank_dups & 1:
-            win[20:20 + L] = win[c - h - L:c - h]
+            cp = win[c - h - L:c - h].copy()
+            if flank_div:
+                at = np.arange(L - 31, -1, -flank_div)
+                cp[at] = (cp[at] + 1) & 3
+            win[20:20 + L] = cp
         if flank_dups & 2:
             cp = win[c + h:c + h + L]
             win[W - 20 - L:W - 20] = revcomp_codes(cp) if flank_dups & 4 else cp

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 static uint64_t g_cells = 0, g_calls = 0;
 uint64_t bko_cells(int reset) { uint64_t v = g_cells; if (reset) g_cells = 0; return v; }
@@ -792,6 +793,28 @@ static int sw_seedable(const char *q, const char *t, int qs, int ts, int len)
     return tiles >= SEED_MIN;
 }
 
+/* ---- R2 step 8 (bk_oracle.h): BLAT's documented output filters, applied to every record before it is reported.
+ * The reference's command lines (sv_processor.py:840, 843) give -minScore=20 and leave -minIdentity at its default; BLAT's usage
+ * text: "-minScore=N sets minimum score.  This is the matches minus the mismatches minus some sort of gap penalty" and
+ * "-minIdentity=N Sets minimum sequence identity (in percent).  Default is 90 for nucleotide searches".
+ *   score    = matches + repMatches - misMatches - qNumInsert - tNumInsert          >= min_score
+ *   identity = 100 - milliBad / 10 with the milliBad of the PSL record exactly as the reference's caller computes it
+ *              (sv_caller.py:954-968, blat_res.calcMilliBad: UCSC's pslCalcMilliBad for DNA)  >= 90
+ *            <=> 10 * (misMatches + qNumInsert + round(3 ln(1 + max(0, qAliSize - tAliSize)))) <= matches + repMatches + misMatches
+ * (integer exact: every term is an integer; 3 ln n is never a half-integer, so the rounding mode does not matter). */
+#define BKO_MIN_IDENTITY 90
+int bko_psl_passes(const bko_psl *r, int min_score)
+{
+    const long total = (long)r->matches + r->rep_matches + r->mismatches;
+    if ((long)r->matches + r->rep_matches - r->mismatches - r->q_num_insert - r->t_num_insert < (long)min_score) return 0;
+    const int qali = r->q_end - r->q_start, tali = r->t_end - r->t_start;
+    const int ali = qali < tali ? qali : tali;
+    if (ali <= 0 || total == 0) return 1;                                  /* calcMilliBad returns 0: identity 100 */
+    const int dif = qali - tali > 0 ? qali - tali : 0;
+    const long bad = (long)r->mismatches + r->q_num_insert + lround(3.0 * log(1.0 + (double)dif));
+    return 100L * bad <= (long)(100 - BKO_MIN_IDENTITY) * total;           /* 100 - 100 bad / total >= BKO_MIN_IDENTITY */
+}
+
 int bko_realign(const char *contig, int Q, const char *const *targets_in, const int *tlens, int ntargets,
                 int min_score, int min_seg, bko_psl *out, int cap)
 {
@@ -969,8 +992,8 @@ int bko_realign(const char *contig, int Q, const char *const *targets_in, const 
             if (h.strand == 0) chain[tail++] = h; else chain[--head] = h;
             taken[j] = 1;
         }
-        if (nrec < cap) {
-            bko_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
+        {
+            static bko_psl tmpc_; bko_psl *r = nrec < cap ? &out[nrec] : &tmpc_; memset(r, 0, sizeof(*r));      /* (beyond cap: built all the same, the filter needs it; the caller comes back with a larger cap) */
             const swhit *f = &chain[head], *l = &chain[tail - 1];
             const char *qstr = f->strand == 0 ? contig : rc; const char *tstr = targets[f->tidx];
             r->strand = f->strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = f->tidx; r->t_size = tlens[f->tidx];
@@ -1002,18 +1025,19 @@ int bko_realign(const char *contig, int Q, const char *const *targets_in, const 
                 pq = bq + bs; pt = bt + bs;
             }
             r->block_count = nb;
+            if (!bko_psl_passes(r, min_score)) continue;                   /* step 8: BLAT would not print it */
         }
         nrec++;
     }
-    for (int x = 0; x < nsec; x++, nrec++) {
-        if (nrec >= cap) continue;
-        bko_psl *r = &out[nrec]; memset(r, 0, sizeof(*r));
+    for (int x = 0; x < nsec; x++) {
+        static bko_psl tmp_; bko_psl *r = nrec < cap ? &out[nrec] : &tmp_; memset(r, 0, sizeof(*r));
         const swsec *e = &sec[x]; const char *qstr = e->strand == 0 ? contig : rc; const char *tstr = targets[e->tidx];
         r->strand = e->strand == 0 ? '+' : '-'; r->q_size = Q; r->t_index = e->tidx; r->t_size = tlens[e->tidx];
         r->t_start = e->ts; r->t_end = e->te;
         r->q_start = e->strand == 0 ? e->qs : Q - e->qe; r->q_end = e->strand == 0 ? e->qe : Q - e->qs;
         for (int z = 0; z < e->qe - e->qs; z++) { if (SW_EQ(qstr[e->qs + z], tstr[e->ts + z])) { if (soft[e->tidx][e->ts + z]) r->rep_matches++; else r->matches++; } else r->mismatches++; }
         r->block_count = 1; r->block_sizes[0] = e->qe - e->qs; r->q_starts[0] = e->qs; r->t_starts[0] = e->ts; r->score = e->score;
+        if (bko_psl_passes(r, min_score)) nrec++;                          /* step 8 */
     }
     free(sec);
     free(rc); free(hits); free(stk); free(taken); free(chain); free(blocks); free(anch);

@@ -102,6 +102,23 @@ void bko_asm_free(bko_asm *a);
  *      breaks between consecutive hits, then the sum of |diagonal shift| between chained neighbours, is smallest (ties:
  *      the earlier candidate).  A chosen alternative becomes the hit, restricted to the hit's query interval; the hit it
  *      replaces is listed with the secondary alignments, the secondary it came from is dropped.
+ *   7. soft-masked windows: see below (rep_matches).
+ *   8. BLAT's documented OUTPUT FILTERS (round 5), applied to every record -- chained or secondary -- before it is reported
+ *      (bko_psl_passes).  The reference's command lines are `blat -t=dna -q=dna -out=psl -minScore=20 -stepSize=10 -minMatch=2
+ *      -repeats=lower` (sv_processor.py:843) and `gfClient -t=dna -q=dna -out=psl -minScore=20` (:840); BLAT's usage text says
+ *      "-minScore=N sets minimum score.  This is the matches minus the mismatches minus some sort of gap penalty" and
+ *      "-minIdentity=N Sets minimum sequence identity (in percent).  Default is 90 for nucleotide searches" (the reference
+ *      passes none, so 90 applies).  Here:
+ *          matches + repMatches - misMatches - qNumInsert - tNumInsert >= min_score, and
+ *          100 - milliBad / 10 >= 90 with the milliBad the reference's caller computes for a record (sv_caller.py:954-968,
+ *          UCSC's pslCalcMilliBad for DNA): 10 * (misMatches + qNumInsert + round(3 ln(1 + max(0, qAli - tAli)))) <= total.
+ *      What it changes: a low-identity alignment (a diverged copy of a flank: 80 matches / 20 mismatches scores +40 under
+ *      +1/-2 and was reported; BLAT drops it at 80 %) no longer counts in hit_freq / mean_cov / check_uniqueness
+ *      (sv_caller.py:593-594, 631, 430-432).  What it cannot change: the step-1 acceptance score.  A segment BLAT can SEED
+ *      (step 2b: two perfect 11-base tiles) that passes both filters always scores >= min_score under +1/-2 as well: with s =
+ *      m - 2x, identity >= 90 % means 9x <= m; two adjacent tiles are a perfect run of 21 (s >= 21 on its own), two separated
+ *      tiles enclose >= 9 bases of which at most x mismatch, so m >= 29 - x + ... and s < 20 would need x <= 2, m <= 23: impossible.
+ *      So "+1/-2 score >= 20" is implied for everything BLAT would print, and lowering it would add nothing.
  * An N (in the contig or in a window) matches nothing.  A lower-case (soft-masked) window base is the same base; a match on
  * one is counted in rep_matches instead of matches (BLAT's -repeats=lower, sv_processor.py:843).
  * Output: PSL-equivalent records (fields consumed by sv_caller.py:911-936).  Returns the number of records (may exceed
@@ -119,6 +136,7 @@ typedef struct bko_psl {
 } bko_psl;
 int bko_realign(const char *contig, int qlen, const char *const *targets, const int *tlens, int ntargets,
                 int min_score, int min_seg, bko_psl *out, int cap);
+int bko_psl_passes(const bko_psl *r, int min_score);      /* step 8: would BLAT print this record (-minScore, -minIdentity default 90) */
 uint64_t bko_sw_cells(int reset);
 
 #ifdef __cplusplus

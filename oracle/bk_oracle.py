@@ -17,7 +17,7 @@ def build(force=False):
     src = os.path.join(_HERE, "bk_oracle.c")
     hdr = os.path.join(_HERE, "bk_oracle.h")
     if force or not os.path.isfile(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src], cwd=_HERE)
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src, "-lm"], cwd=_HERE)
     return so
 
 

@@ -50,6 +50,31 @@ def test_product_never_imports_the_oracle():
                 assert "bk_oracle" not in txt.replace("oracle/bk_oracle", ""), fn
 
 
+def test_product_library_reads_no_environment(lib):
+    """A drop-in's behaviour is a function of its arguments: the product build of the library imports no getenv at all (every
+    diagnostic switch sits behind -DBK_DIAG: breakmer_amd/build.py VARIANTS), every workgroup barrier of the device code is
+    BK_SYNC() (bk_common.h: the barrier-check and jitter builds then cover every kernel), and the Python layer names a diagnostic
+    build explicitly (load_library(path)) instead of reading a variable."""
+    import subprocess
+    from breakmer_amd import build
+    syms = subprocess.run(["nm", "-D", "--undefined-only", build.HIP_LIB], capture_output=True, text=True).stdout
+    assert "getenv" not in syms and "hipLaunchKernel" in syms
+    csrc = os.path.join(ROOT, "breakmer_amd", "csrc")
+    for fn in os.listdir(csrc):
+        txt = open(os.path.join(csrc, fn)).read()
+        if fn != "bk_common.h":
+            assert "__syncthreads" not in txt, fn
+        if fn == "bk_api.hip":
+            assert txt.count("getenv(") == 1 and "static inline const char *bk_diag_env(const char *name) { return getenv(name); }" in txt
+        else:
+            assert "getenv(" not in txt, fn
+    for fn in os.listdir(os.path.join(ROOT, "breakmer_amd")):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(ROOT, "breakmer_amd", fn)).read()
+            for m in re.finditer(r"environ(?:\.get|\.setdefault|\[)\(?\s*[\"']([A-Z_0-9]+)", txt):
+                assert m.group(1) in ("GPU_MAX_HW_QUEUES", "HIPCC", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"), (fn, m.group(1))
+
+
 def test_pack_sequence_simd_equals_table_path():
     """bk_pack_sequence (host code of the library, no GPU): the SSSE3 path of the 2-bit packing -- whole 16-base blocks of
     plain A/C/G/T -- and the table path -- blocks with an N, tails -- against a Python restatement; other characters fail."""

@@ -148,6 +148,13 @@ def test_g8m_multi_mapping_contigs(golden_dir):
     assert tags["trl_partner_repeat_nodisc"]["contract"]["expected"] is None and tags["trl_unique_nodisc"]["contract"]["expected"] is not None
     assert tags["trl_partner_repeat_disc"]["contract"]["expected"][5].endswith(":6.0")
     assert tags["trl_partner_half_also_in_target"]["contract"]["expected"] is None
+    # contract step 8 (BLAT's -minIdentity default of 90 %, -minScore): a diverged copy of the left flank at ~80 % identity -- a
+    # +1/-2 segment runs through it -- is not a record (BLAT would not print it: hit_freq stays 1), at ~93 % it is, with its mismatches
+    lo, hi = tags["del_left_flank_diverged_copy_80pct"], tags["del_left_flank_diverged_copy_93pct"]
+    assert len(lo["contract"]["records"]) == 1 and lo["contract"]["max_hit_freq"] == 1 and "AC" not in lo["tag"]
+    assert len(hi["contract"]["records"]) == 2 and hi["contract"]["max_hit_freq"] == 2
+    sec = hi["contract"]["records"][1]
+    assert sec["mismatches"] >= 8 and 100 * sec["matches"] >= 90 * (sec["matches"] + sec["mismatches"])
     for c in d["cases"]:
         assert bo.realign(c["contig"]["seq"], c["targets"]) == c["contract"]["records"], c["tag"]
         assert c["contract"]["max_hit_freq"] == c["blat_style"]["max_hit_freq"], c["tag"]

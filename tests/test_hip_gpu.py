@@ -15,8 +15,26 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def hb():
     from breakmer_amd import hip_backend
+    # BK_TEST_VARIANT (test infrastructure, e.g. "checkjit"): the whole suite through a diagnostic build of the library
+    # (breakmer_amd/build.py VARIANTS: barrier-site check, sleeping wavefronts); unset = the product build
+    v = os.environ.get("BK_TEST_VARIANT", "")
+    if v:
+        from breakmer_amd import build
+        hip_backend.load_library(build.lib_path(v))
     hip_backend.load_library()          # fails loudly if the extension is missing
     return hip_backend
+
+
+def _race_check(args, timeout=1500):
+    """tools/race_check.py in a child process (a device fault or a hang is then a red test, not a dead suite)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "race_check.py")] + args, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("race_check %s hung (killed after %d s): %s" % (args, timeout, (e.stdout or b"")[-1500:]))
+    assert r.returncode == 0 and "RACE CHECK RESULT: ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-1500:])
+    return r.stdout
 
 
 def _load(golden_dir, name):
@@ -179,16 +197,14 @@ def test_both_workgroup_sizes_gpu(hb, golden_dir):
             assert _strip(eng.contigs(len(cases) + j)) == want and len(want) >= 1, (wg, j)
 
 
-@pytest.mark.skipif(os.environ.get("BK_TEST_SPLIT", "0") != "1", reason="the component split is experimental and off by default: under load it faults "
-                    "intermittently on the device (DESIGN 4.5), which would take the whole test process down; BK_TEST_SPLIT=1 runs it")
 def test_split_regions_are_bit_identical_gpu(hb, golden_dir):
-    """EXPERIMENTAL path (bk_config.reserved[0] bit 1024; off by default).
+    """The shipped path of noisy regions (default since round 5; flag 128 = one unit per region, as everything ran until round 4).
     Noisy regions are split over up to 16 assembler workgroups (bk_comp.hip.h): unit 0 runs the high-count seeds (the SV's own
     k-mers) alone and in order, then the components of what is left of the read / k-mer graph are dealt to the units;
     components that meet across units are merged and run again.  The result must be the serial one:
     (a) every reference fixture (G3) with the split FORCED on its small graph (flag 256), both workgroup sizes;
     (b) a mixed batch with mid-size noisy regions against the oracle, split forced;
-    (c) full-size regions at 0.2 % / 0.5 % / 1 % substitutions, split (flag 1024) against one unit (the default): the same
+    (c) full-size regions at 0.2 % / 0.5 % / 1 % substitutions, split (the default) against one unit (flag 128): the same
         contigs in the same order, the same realign records -- and the split really happened, with repair passes."""
     from oracle import bk_oracle as bo
     d = _load(golden_dir, "assembly.json")
@@ -218,8 +234,8 @@ def test_split_regions_are_bit_identical_gpu(hb, golden_dir):
             assert eng.hits(i, ci) == bo.realign(got[ci]["seq"], targets), (i, ci)
     eng.close()
     full = [synth.make_region(50000 + i, depth=500, L=150, sv_type=("del", "ins", "inv")[i % 3], noise=nz) for i, nz in enumerate((0.002, 0.005, 0.005, 0.005, 0.01, 0.0))]
-    one = _run_regions(hb, full, 31, stages=7)
-    many = _run_regions(hb, full, 31, stages=7, flags=1024)
+    one = _run_regions(hb, full, 31, stages=7, flags=128)
+    many = _run_regions(hb, full, 31, stages=7)
     assert one.sync() == 0 and many.sync() == 0
     assert one.stat(28) == 0 and many.stat(28) >= 4, many.stat(28)          # the clean region and the percolated one (1 %) stay one unit
     assert many.stat(27) >= 1                                                # components met across units: at least one repair pass
@@ -231,23 +247,31 @@ def test_split_regions_are_bit_identical_gpu(hb, golden_dir):
             assert one.hits(i, ci) == many.hits(i, ci), (i, ci)
 
 
-def test_assembler_does_not_depend_on_wavefront_timing_gpu(tmp_path):
-    """A build of the library in which ONE wavefront sleeps behind every workgroup barrier of the assembler (-DBK_JITTER: legal at any
-    time, so anything that goes wrong with it is a race) must give the reference fixtures like the product build.  This is how the
-    missing barrier of bk_retire was found in round 4: without it a wavefront that was late into the call took another
-    path than its workgroup -- faults and hangs once several noisy workgroups shared a CU.  Runs in a process of its own."""
-    import shutil, subprocess, sys
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.isfile(hipcc) and not shutil.which(hipcc):
-        pytest.skip("no hipcc on this machine")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = str(tmp_path / "libbreakmer_hip_jitter.so")
-    for k in (3,):
-        b = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result", "-DBK_JITTER=%d" % k, "-o", lib, "bk_api.hip"],
-                           cwd=os.path.join(root, "breakmer_amd", "csrc"), capture_output=True, text=True, timeout=600)
-        assert b.returncode == 0, b.stderr[-2000:]
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "g3_check.py")], env=dict(os.environ, BK_LIB=lib), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "wrong: 0" in r.stdout, (k, r.returncode, r.stdout[-500:], r.stderr[-500:])
+def test_barrier_discipline_of_every_kernel_gpu():
+    """Every workgroup barrier of the library is BK_SYNC() (bk_common.h).  The `checkjit` build verifies at EVERY barrier that all
+    wavefronts of the workgroup stand at the same barrier site (a divergence is reported by bk_sync with both sites) while a
+    pseudo-random subset of the wavefronts sleeps behind each barrier -- legal at any time, so whatever goes wrong with it is a
+    race.  Three seeds (which wavefront sleeps where): the reference fixtures on both workgroup sizes, as shipped and with the
+    component split forced; a mixed batch of small regions against the oracle incl. the realign records.  This is the class of
+    defect found by accident in rounds 2, 3 and 4 (bk_retire twice, bk_find_reads) and once more in round 5 (the S->foreign loop of
+    bk_kmers_ordered: found by reading, confirmed by this build)."""
+    from breakmer_amd import build
+    if not os.path.isfile(build.lib_path("checkjit")):
+        import shutil
+        if not os.path.isfile(build.HIPCC) and not shutil.which(build.HIPCC):
+            pytest.skip("libbreakmer_hip_checkjit.so was not built and there is no hipcc on this machine")
+        build.build_hip(variant="checkjit")
+    out = _race_check(["--variant", "checkjit", "--seeds", "1,2,3", "g3", "mixed"])
+    assert out.count("ok    ") >= 3 * (2 + 4)
+
+
+def test_batches_that_faulted_in_round_4_gpu():
+    """The shape that faulted or hung until the barrier fixes (profiles/r04/split_fault/README.md; no test had it): several workgroups
+    of small NOISY regions per CU.  720 and 1,024 regions at 1 % noise, six runs each on both workgroup sizes: every run gives the
+    records of the first, eight sampled regions equal the oracle; and full-size noisy regions split over 16 workgroups each
+    against the one-unit run.  Product build, in a child process."""
+    out = _race_check(["shape:720", "shape:1024", "noisy:12"])
+    assert out.count("ok    ") == 6
 
 
 def test_batch_vs_oracle_gpu(hb):
@@ -320,7 +344,9 @@ def test_g8m_multi_mapping_rows_gpu(hb, golden_dir):
     mk = lambda **kw: synth.make_region(3, depth=60, W=1500, **kw)
     cases = [("del_unique", mk(sv_type="del")), ("del_left_flank_dup", mk(sv_type="del", flank_dups=1)), ("del_both_flanks_dup", mk(sv_type="del", flank_dups=3)),
              ("del_right_flank_dup_rc", mk(sv_type="del", flank_dups=6)), ("del_right_flank_dup", mk(sv_type="del", flank_dups=2)),
-             ("trl_partner_repeat_disc", mk(sv_type="trl", trl_repeat_copies=5))]
+             ("trl_partner_repeat_disc", mk(sv_type="trl", trl_repeat_copies=5)),
+             # contract step 8 (BLAT's -minIdentity default 90): the ~80 % copy of the flank is no record, the ~93 % copy is
+             ("del_left_flank_diverged_copy_80pct", mk(sv_type="del", flank_dups=1, flank_div=4)), ("del_left_flank_diverged_copy_93pct", mk(sv_type="del", flank_dups=1, flank_div=12))]
     regions = [r for _t, r in cases]
     opts = dict(bk_params.DEFAULTS); opts["var_filter"] = ["indel", "rearrangement", "trl"]
     eng = hb.Engine(kmer_size=31)
@@ -773,6 +799,30 @@ def test_native_tail_equals_python_tail_on_noisy_regions_gpu(hb, tmp_path):
     r2 = sp.runner(cfg2, region_data=data2, native_calls=False)
     assert r2.run() == rows and len(rows) >= 3
     assert r1.summary == r2.summary and sum(int(v.split("\t")[1]) for v in r1.summary.values()) > 300       # N_contigs: the noise made hundreds
+
+
+def test_call_shortcut_equals_full_caller_gpu(hb, golden_dir):
+    """bk_call decides a contig whose only alignment is ONE gap-free hit over its whole length on the target window from the raw
+    hit (no records, no target_hit / get_result: bk_api.hip call_impl).  With the shortcut switched off (bk_config.reserved[0] bit
+    2048) every contig goes through the full caller: the call records must be byte-identical -- on noisy regions (hundreds of
+    such contigs), on clean ones of every SV type, and on the regions of the reference-made surface fixtures."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    regions = [synth.make_region(900 + i, sv_type=sv, depth=150, W=1500, noise=noise)
+               for i, (sv, noise) in enumerate([("del", 0.01), ("ins", 0.006), ("inv", 0.01), ("dup", 0.004), ("del", 0.0), ("trl", 0.0), ("trl", 0.008), ("ins", 0.0)])]
+    regions += [synth.make_region(**c["gen"]) for c in _load(golden_dir, "assembly.json")["cases"] if c["k"] == 31 and c["rc_thresh"] == 2]
+    opts = bench.default_opts()
+    blobs = []
+    for flags in (0, 2048):
+        eng = hb.Engine(kmer_size=31, rc_thresh=2, flags=flags)
+        eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only, partners=[p[4] for p in r.partners]) for r in regions])
+        eng.set_call_context(bench.call_context_text(regions, opts))
+        eng.run(hb.BK_STAGE_ALL)
+        blobs.append(eng.call_blob())
+        ncontigs = eng.stat(6)
+        eng.close()
+    assert blobs[0] == blobs[1] and blobs[0].count(b"\n") >= 6 and ncontigs > 300
 
 
 def test_call_async_makes_the_same_calls_gpu(hb):

@@ -5,6 +5,9 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variant  # noqa: E402
+_variant.use()                       # BK_VARIANT / BK_LIB: the build of the library to check (default: the product)
 import numpy as np  # noqa: E402
 from breakmer_amd import hip_backend as hb, synth  # noqa: E402
 from oracle import bk_oracle as bo  # noqa: E402
@@ -34,7 +37,7 @@ while done < n:
         if r.region_id % 5 == 0:
             fl = synth.rand_bases(synth.stream_key(seed, r.region_id, 9), 2 * 15000)
             r.window = np.concatenate([fl[:15000], r.window, fl[15000:]]).astype(np.uint8)
-    eng = hb.Engine(kmer_size=k, rc_thresh=rc, wg_threads=int(os.environ.get("BK_FUZZ_WG", "0")), flags=int(os.environ.get("BK_FUZZ_FLAGS", "0")))      # BK_FUZZ_FLAGS=1280: every region split into units (experimental, bk_comp.hip.h)
+    eng = hb.Engine(kmer_size=k, rc_thresh=rc, wg_threads=int(os.environ.get("BK_FUZZ_WG", "0")), flags=int(os.environ.get("BK_FUZZ_FLAGS", "0")))      # BK_FUZZ_FLAGS=256: every region split into units whatever its size; 128: never
     eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only, partners=[p[4] for p in r.partners]) for r in regs])
     eng.run(hb.BK_STAGE_ALL)
     for i, (r, (rid, kw)) in enumerate(zip(regs, batch)):

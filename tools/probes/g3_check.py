@@ -3,6 +3,9 @@ both workgroup sizes; prints how many cases come out as the fixtures say (no pyt
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, "tools"))
+import _variant
+_variant.use()                       # BK_VARIANT / BK_LIB: the build of the library to check (default: the product)
 from breakmer_amd import hip_backend as hb, synth
 d = json.load(open(os.path.join(root, "tests", "golden", "assembly.json")))
 by = {}

@@ -1,0 +1,168 @@
+"""Barrier-discipline evidence on the GPU box (not imported by the product; tests/test_hip_gpu.py runs it in a child process so
+that a device fault is a red test, not a dead suite).
+
+    python tools/race_check.py [--variant checkjit|jitter|check|''] [--seeds 1,2,3] what [what ...]
+
+what:
+  g3            the reference-made assembly fixtures (tests/golden/assembly.json), both workgroup sizes, as shipped and with the
+                component split forced on their small graphs
+  mixed         40 small regions (every SV type, 0-1.5 % noise) against the C oracle, as shipped and split forced, realign included
+  shape:N[:R]   the batches that faulted in round 4 (profiles/r04/split_fault): N small regions at 1 % noise, R runs (default 6)
+                on both workgroup sizes -- records identical between runs, 8 sampled regions equal to the oracle
+  noisy:N       N full-size regions (500x, 150 bp) at 0.5 % noise: split (default) against one unit per region, bit for bit
+
+With a jitter variant every `what` is repeated for every seed (BK_JITTER_SEED: which wavefronts sleep behind which barrier).
+With a check variant a barrier divergence surfaces as an error of bk_sync naming both sites.  Last line: RACE CHECK RESULT: ok | FAILED."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from breakmer_amd import build, hip_backend as hb, synth  # noqa: E402
+from oracle import bk_oracle as bo  # noqa: E402
+
+STRIP = ("total_reads", "n_hits")
+bad = 0
+
+
+def note(ok, text):
+    global bad
+    if not ok:
+        bad += 1
+    print(("ok    " if ok else "FAILED"), text, flush=True)
+
+
+def strip(cs):
+    return [{k: v for k, v in c.items() if k not in STRIP} for c in cs]
+
+
+def engine(k, rc=2, **kw):
+    return hb.Engine(kmer_size=k, rc_thresh=rc, **kw)
+
+
+def submit(eng, regions):
+    eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, indel_only=r.indel_only, partners=[p[4] for p in r.partners]) for r in regions])
+
+
+def g3(tag):
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "assembly.json")))
+    by = {}
+    for c in d["cases"]:
+        by.setdefault((c["k"], c["rc_thresh"]), []).append(c)
+    for flags in (0, 256):
+        wrong = tot = 0
+        for (k, rc), cases in by.items():
+            regions = [synth.make_region(**c["gen"]) for c in cases]
+            for wg in (512, 256):
+                eng = engine(k, rc, wg_threads=wg, flags=flags)
+                submit(eng, regions)
+                eng.run(3)
+                for i, c in enumerate(cases):
+                    tot += 1
+                    wrong += strip(eng.contigs(i)) != c["contigs"]
+                eng.close()
+        note(wrong == 0, "%s g3 fixtures x workgroup sizes, flags %d: %d cases, %d wrong" % (tag, flags, tot, wrong))
+
+
+def mixed(tag):
+    regions = [synth.make_region(7000 + i, sv_type=synth.SV_TYPES[i % 5], depth=(60, 120, 200)[i % 3], W=(900, 1200)[i % 2], L=(100, 150)[i % 2],
+                                 noise=(0.0, 0.004, 0.008, 0.015)[i % 4], n_frac=(0.0, 0.0, 0.1)[i % 3]) for i in range(40)]
+    want = [bo.assemble_region(r.read_strs(), [r.window_str], 31, 2, indel_only=r.indel_only.tolist())[0] for r in regions]
+    for flags in (0, 256):
+        for wg in (256, 512):
+            eng = engine(31, wg_threads=wg, flags=flags)
+            submit(eng, regions)
+            eng.run(hb.BK_STAGE_ALL)
+            wrong = sum(strip(eng.contigs(i)) != want[i] for i in range(len(regions)))
+            hw = 0
+            for i in range(0, len(regions), 5):
+                r = regions[i]
+                targets = [r.window_str] + [synth.codes_to_str(p[4]) for p in r.partners]
+                for ci, c in enumerate(want[i][:3]):
+                    hw += eng.hits(i, ci) != bo.realign(c["seq"], targets)
+            note(wrong == 0 and hw == 0, "%s mixed batch vs oracle, flags %d wg %d: %d regions wrong, %d realign mismatches, split regions %d, repair passes %d"
+                 % (tag, flags, wg, wrong, hw, eng.stat(28), eng.stat(27)))
+            eng.close()
+
+
+def shape(tag, n, runs):
+    base = [synth.make_region(50000 + i, depth=60, L=150, sv_type="del", noise=0.01) for i in range(min(n, 256))]
+    regions = [base[i % len(base)] for i in range(n)]
+    sample = list(range(0, min(n, 256), 32))[:8]
+    want = {i: bo.assemble_region(regions[i].read_strs(), [regions[i].window_str], 31, 2)[0] for i in sample}
+    for wg in (256, 512):
+        eng = engine(31, wg_threads=wg)
+        submit(eng, regions)
+        ref = None
+        diff = 0
+        t0 = time.time()
+        for rep in range(runs):
+            eng.run(hb.BK_STAGE_ALL)
+            cur = [[(c["seq"], tuple(c["others"]), tuple(c["indel_only"]), tuple(c["reads"])) for c in eng.contigs(i)] for i in range(n)]
+            if ref is None:
+                ref = cur
+            else:
+                diff += sum(cur[i] != ref[i] for i in range(n))
+        vs = sum(strip(eng.contigs(i)) != want[i] for i in sample)
+        note(diff == 0 and vs == 0, "%s %d small regions at 1 %% noise, wg %d, %d runs (%.1f s): %d region-runs differ from run 0, %d of %d sampled regions differ from the oracle"
+             % (tag, n, wg, runs, time.time() - t0, diff, vs, len(sample)))
+        eng.close()
+
+
+def noisy(tag, n):
+    regions = [synth.make_region(50000 + i, depth=500, L=150, sv_type=("del", "ins", "inv")[i % 3], noise=0.005) for i in range(n)]
+    for wg in (256, 512):
+        one = engine(31, wg_threads=wg, flags=128)
+        many = engine(31, wg_threads=wg)
+        for e in (one, many):
+            submit(e, regions)
+            e.run(hb.BK_STAGE_ALL)
+        wrong = 0
+        for i in range(n):
+            a, b = one.contigs(i), many.contigs(i)
+            wrong += a != b
+            if a == b:
+                wrong += any(one.hits(i, ci) != many.hits(i, ci) for ci in range(0, len(a), 97))
+        note(wrong == 0 and many.stat(28) > 0, "%s %d full-size regions at 0.5 %% noise, wg %d: %d differ between split and one unit; split regions %d, repair passes %d, assembler %.1f vs %.1f ms"
+             % (tag, n, wg, wrong, many.stat(28), many.stat(27), many.kernel_ms(2), one.kernel_ms(2)))
+        one.close(); many.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", default="")
+    ap.add_argument("--seeds", default="1")
+    ap.add_argument("what", nargs="+")
+    a = ap.parse_args()
+    if a.variant:
+        hb.load_library(build.lib_path(a.variant))
+    seeds = [int(s) for s in a.seeds.split(",")] if "jit" in a.variant else [0]
+    for seed in seeds:
+        os.environ["BK_JITTER_SEED"] = str(seed)               # read by bk_create of a jitter build (a diagnostic build: the product reads no environment)
+        tag = "[%s seed %d]" % (a.variant or "product", seed)
+        for w in a.what:
+            try:
+                if w == "g3":
+                    g3(tag)
+                elif w == "mixed":
+                    mixed(tag)
+                elif w.startswith("shape:"):
+                    f = w.split(":")
+                    shape(tag, int(f[1]), int(f[2]) if len(f) > 2 else 6)
+                elif w.startswith("noisy:"):
+                    noisy(tag, int(w.split(":")[1]))
+                else:
+                    raise SystemExit("unknown check " + w)
+            except hb.BreakmerHipError as e:
+                note(False, "%s %s: %s" % (tag, w, e))
+                print("RACE CHECK RESULT: FAILED", flush=True)       # the device context may be gone: stop here
+                sys.exit(1)
+    print("RACE CHECK RESULT: %s" % ("ok" if bad == 0 else "FAILED"), flush=True)
+    sys.exit(0 if bad == 0 else 1)
+
+
+if __name__ == "__main__":
+    main()

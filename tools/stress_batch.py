@@ -2,6 +2,9 @@
 runs and equal to the oracle.  python tools/stress_batch.py [flags] [n_regions] [reps]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variant
+_variant.use()
 from breakmer_amd import hip_backend as hb, synth
 from oracle import bk_oracle as bo
 flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
