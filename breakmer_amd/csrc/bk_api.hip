@@ -547,6 +547,8 @@ static void fill_params(bk_handle *h)
     p.n_clist = (unsigned long long *)h->d_tops.p + 2; p.asm_head = (unsigned long long *)h->d_tops.p + 3; p.sw_head = (unsigned long long *)h->d_tops.p + 4; p.n_queue = (unsigned long long *)h->d_tops.p + 5;
     p.order = (uint32_t *)h->d_order.p; p.clist = (unsigned long long *)h->d_clist.p; p.clist_cap = h->d_clist.bytes / 16;      // first half: the contig list; second half: the realigner's long-contig list
     p.sw_long = p.clist + p.clist_cap; p.n_sw_long = (unsigned long long *)h->d_tops.p + 6; p.sw_long_head = (unsigned long long *)h->d_tops.p + 7;
+    p.n_queue0 = (unsigned long long *)h->d_tops.p + 8; p.pending = (unsigned long long *)h->d_tops.p + 9; p.queue_cap = (unsigned long long *)h->d_tops.p + 10;      // the dynamic unit queue (bk_asm.hip.h)
+    p.order_cap = (uint32_t)std::min<uint64_t>(h->d_order.bytes / 4, 0xFFFFFFF0u); p.pad_q = 0;
     p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->eff_max_read;
     p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions; p.flags = h->cfg.reserved[0];
     p.rmap = nullptr;
@@ -608,21 +610,29 @@ static bool escalated_caps(const bk_handle *h, int &max_cand, int &max_contig)
 
 // The assembler launch of a batch, of a re-run subset and of a repair pass: LDS size, kernel attribute, diagnostic parameters and
 // grid in ONE place (they used to be recomputed, differently, by launch_repair).  `units`: entries in the queue at most.
-static int launch_asm(bk_handle *h, int threads, int max_cand, int max_contig, long long units, bool note)
+struct BkAsmShape { size_t lds; int per_cu, grid; };
+static int asm_shape(bk_handle *h, int threads, int max_cand, int max_contig, long long units, BkAsmShape &sh)
 {
     const void *kfn = threads == 512 ? (const void *)at512::bk_asm_kernel : (const void *)at256::bk_asm_kernel_w4;
     size_t lds = asm_lds_bytes(h, threads, max_cand, max_contig);
-    h->params.asm_lds_pad = 0; h->params.dbg_iters = 0; h->params.poison = 0;
-    { const char *e = bk_diag_env("BK_LDS_PAD"); if (e) { h->params.asm_lds_pad = (uint32_t)(atoi(e) & ~15); lds += h->params.asm_lds_pad; } }      // diagnostic build: guard band behind the block
-    { const char *e = bk_diag_env("BK_DBG_ITERS"); if (e) h->params.dbg_iters = (uint32_t)atoi(e); }
-    { const char *e = bk_diag_env("BK_POISON_LDS"); if (e) h->params.poison = 0x100u | (uint32_t)(atoi(e) & 0xFF); }
-    h->params.asm_lds_bytes = (uint32_t)lds;
+    { const char *e = bk_diag_env("BK_LDS_PAD"); if (e) lds += (size_t)(atoi(e) & ~15); }      // diagnostic build: guard band behind the block
     if (lds > BK_LDS_MAX) return fail(h, BK_E_LIMIT, "assembler: max_candidates / max_contig_len / read length of this batch need " + std::to_string(lds) + " B of LDS per workgroup, a CU has " + std::to_string(BK_LDS_MAX));
     HIPCHK(h, set_max_dyn_lds(h->dev, kfn, (int)lds));
     // persistent workgroups: as many as are resident at once (a surplus one would only find the queue empty)
-    const int per_cu = cached_occupancy(h->dev, kfn, threads, lds);
-    if (note) { h->asm_wg_per_cu = per_cu; h->asm_threads = threads; }
-    const int grid = (int)std::max<long long>(1, std::min<long long>(units, (long long)per_cu * h->n_cu));
+    sh.lds = lds; sh.per_cu = cached_occupancy(h->dev, kfn, threads, lds);
+    sh.grid = (int)std::max<long long>(1, std::min<long long>(units, (long long)sh.per_cu * h->n_cu));
+    return BK_OK;
+}
+static int launch_asm(bk_handle *h, int threads, int max_cand, int max_contig, long long units, bool note)
+{
+    BkAsmShape sh; { const int rc = asm_shape(h, threads, max_cand, max_contig, units, sh); if (rc != BK_OK) return rc; }
+    const size_t lds = sh.lds; const int grid = sh.grid;
+    h->params.asm_lds_pad = 0; h->params.dbg_iters = 0; h->params.poison = 0;
+    { const char *e = bk_diag_env("BK_LDS_PAD"); if (e) h->params.asm_lds_pad = (uint32_t)(atoi(e) & ~15); }
+    { const char *e = bk_diag_env("BK_DBG_ITERS"); if (e) h->params.dbg_iters = (uint32_t)atoi(e); }
+    { const char *e = bk_diag_env("BK_POISON_LDS"); if (e) h->params.poison = 0x100u | (uint32_t)(atoi(e) & 0xFF); }
+    h->params.asm_lds_bytes = (uint32_t)lds;
+    if (note) { h->asm_wg_per_cu = sh.per_cu; h->asm_threads = threads; }
     if (threads == 512) hipLaunchKernelGGL(at512::bk_asm_kernel, dim3(grid), dim3(512), lds, h->stream, h->params);
     else hipLaunchKernelGGL(at256::bk_asm_kernel_w4, dim3(grid), dim3(256), lds, h->stream, h->params);
     HIPCHK(h, hipGetLastError());
@@ -637,7 +647,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
     // every contig record takes >= 256 B of the result arena, so out_cap / 256 list entries can never overflow
     HIPCHK(h, h->d_clist.ensure(std::max<uint64_t>(h->out_cap / 256, 1024) * 16));
     uint32_t npad = 1; while ((int)npad < h->n_regions) npad <<= 1;
-    HIPCHK(h, h->d_order.ensure((size_t)h->n_regions * 4 * BK_SPLIT_G)); HIPCHK(h, h->d_skeys.ensure((size_t)npad * 8));      // queue: up to BK_SPLIT_G units per region
+    HIPCHK(h, h->d_order.ensure((size_t)h->n_regions * 4 * BK_SPLIT_G * (1 + BK_REQUEUE_PASSES))); HIPCHK(h, h->d_skeys.ensure((size_t)npad * 8));      // queue: up to BK_SPLIT_G units per region, and room for the passes split regions append themselves
     fill_params(h);
     const int n_launch = subset ? (int)subset->size() : h->n_regions;
     int max_cand = h->cfg.max_candidates, max_contig = h->cfg.max_contig_len;
@@ -646,13 +656,16 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         HIPCHK(h, h->d_rmap.ensure(subset->size() * 4));
         HIPCHK(h, hipMemcpy(h->d_rmap.p, subset->data(), subset->size() * 4, hipMemcpyHostToDevice));       // (the stream is idle: bk_sync has just waited for it)
         HIPCHK(h, hipMemcpy(h->d_order.p, subset->data(), subset->size() * 4, hipMemcpyHostToDevice));      // the assembler's queue: these regions, in index order
-        unsigned long long tops[6];
+        unsigned long long tops[11];
         HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
-        tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 16); tops[5] = (unsigned long long)n_launch;      // unit queue from its start; the realigner goes on behind the contigs it has seen
-        HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        BkAsmShape sh; { const int rc = asm_shape(h, 512, max_cand, max_contig, n_launch, sh); if (rc != BK_OK) return rc; }
+        // unit queue: these regions, one unit each (no split: nothing is appended); the realigner goes on behind the contigs it has seen
+        tops[3] = (unsigned long long)std::min(sh.grid, n_launch); tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 16); tops[5] = (unsigned long long)n_launch;
+        tops[8] = (unsigned long long)n_launch; tops[9] = 0; tops[10] = (unsigned long long)n_launch;
+        HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice));
         h->params.rmap = (const uint32_t *)h->d_rmap.p; h->params.n_regions = n_launch; h->params.max_cand = max_cand; h->params.max_contig = max_contig;
     } else {
-        static const unsigned long long tops[6] = {256, 256, 0, 0, 0, 0};      // arena top, out top, contigs listed, unit queue head, contig queue head, units queued (bk_sched_kernel)
+        static const unsigned long long tops[11] = {256, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // arena top, out top, contigs listed, unit queue head, contig queue head, units queued, (realigner's long list: 2), initial units, split regions pending, queue capacity (bk_sched_kernel)
         HIPCHK(h, hipMemcpyAsync(h->d_tops.p, tops, sizeof(tops), hipMemcpyHostToDevice, h->stream));
     }
     { const char *e = bk_diag_env("BK_POISON_ARENA"); if (e && h->d_arena.p) HIPCHK(h, hipMemsetAsync(h->d_arena.p, atoi(e) & 0xFF, h->d_arena.bytes, h->stream)); }      // diagnostic: what an uninitialised read of the scratch arena sees
@@ -689,8 +702,10 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if (mask & BK_STAGE_ASSEMBLE) {
         // regions ordered by estimated cost, heaviest first (part of the assembler's measured time: ev[1]..ev[2])
+        const bool may_split = !subset && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
         if (!subset) {
-            hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad);
+            BkAsmShape sh; { const int rc = asm_shape(h, asm_threads, max_cand, max_contig, (long long)n_launch * (may_split ? BK_SPLIT_G : 1), sh); if (rc != BK_OK) return rc; }
+            hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad, (uint32_t)sh.grid);
             HIPCHK(h, hipGetLastError());
             if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] sched done\n"); }
         }
@@ -698,14 +713,9 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         // wavefronts, 8 slots, 4 per CU) give more regions per CU whose serial phases overlap: +14 % regions/s once the
         // chip is full.  bk_config.reserved[1] = 256 / 512 chooses; 0 = 512 unless the batch alone fills the chip twice.
         // (a noisy region is split into up to BK_SPLIT_G units on the device, bk_comp.hip.h: the host only knows the bound)
-        const bool may_split = !subset && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
+        // (split regions settle inside the assembler: merge + re-queue when components met, link when none did -- no link kernel here)
         { const int rc = launch_asm(h, asm_threads, max_cand, max_contig, (long long)n_launch * (may_split ? BK_SPLIT_G : 1), !subset); if (rc != BK_OK) return rc; }
         if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] assembler done\n"); }
-        if (may_split) {          // contigs of split regions in the reference's order (idle for the others)
-            hipLaunchKernelGGL(bk_link_kernel, dim3(std::min(h->n_regions, h->n_cu)), dim3(BK_LINK_T), 0, h->stream, h->params, h->n_regions);
-            HIPCHK(h, hipGetLastError());
-            if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] link done\n"); }
-        }
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if (mask & BK_STAGE_REALIGN) { const int rc = launch_sw(h, max_contig, !subset); if (rc != BK_OK) return rc; }
@@ -725,10 +735,14 @@ static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t
     std::vector<uint32_t> q; q.reserve((size_t)n * BK_SPLIT_G);
     for (uint32_t r : redo) for (uint32_t g = 0; g < BK_SPLIT_G; g++) q.push_back(r | (g << BK_QUEUE_UNIT_SHIFT));
     HIPCHK(h, hipMemcpy(h->d_order.p, q.data(), q.size() * 4, hipMemcpyHostToDevice));
-    unsigned long long tops[6];
+    unsigned long long tops[11];
     HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
-    tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 16); tops[5] = (unsigned long long)q.size();
-    HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    BkAsmShape sh; { const int rc = asm_shape(h, h->asm_threads, h->cfg.max_candidates, h->cfg.max_contig_len, (long long)q.size(), sh); if (rc != BK_OK) return rc; }
+    // (a host-driven pass: the queue holds exactly the units of this pass -- queue_cap leaves no room to append, so a region whose
+    //  components meet again comes back with BK_ST_REDO; every region of the pass is pending until its last unit has reported in)
+    tops[3] = (unsigned long long)std::min<size_t>((size_t)sh.grid, q.size()); tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 16); tops[5] = (unsigned long long)q.size();
+    tops[8] = (unsigned long long)q.size(); tops[9] = (unsigned long long)n; tops[10] = (unsigned long long)q.size();
+    HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     const bool dbg = bk_diag_env("BK_DEBUG_SPLIT") != nullptr;
@@ -1270,7 +1284,8 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     if (which == 21) v = (uint64_t)(h->submit_h2d_ms * 1000.0);
     if (which == 22) v = (uint64_t)h->n_failed;
     if (which == 26) v = (uint64_t)h->n_escalated;
-    if (which == 27) v = (uint64_t)h->n_repair_passes;
+    if (which == 27) { v = 0; for (int r = 0; r < h->n_regions; r++) v = std::max<uint64_t>(v, h->h_work[r].pass); }      // repair passes of split regions (the most any region needed; in-kernel and host-driven ones)
+    if (which == 29) v = (uint64_t)h->n_repair_passes;                                                                          // ... of which the host drove
     if (which == 28) { v = 0; for (int r = 0; r < h->n_regions; r++) v += h->h_work[r].split ? 1 : 0; }          // regions that were split into units
     if (which == 23) v = (uint64_t)h->asm_wg_per_cu;                        // resident assembler / realign workgroups per CU (occupancy query)
     if (which == 24) v = (uint64_t)h->sw_wg_per_cu;

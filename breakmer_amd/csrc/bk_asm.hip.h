@@ -1928,6 +1928,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
     BK_SYNC();
     BK_ACC(S_->ctx);
     if (BK_TID == 0) {
+        int action = 0;                                  // split regions, the last unit to report in: 1 merge + re-queue, 2 link, 3 leave it to the host
         if (!C_.split) { C_.wk->n_contigs = (uint32_t)S->n_contigs; C_.wk->nw_cells = S->cells; C_.wk->nw_calls = S->calls; if (S->status) C_.wk->status = S->status; }
         else {
             // a unit reports in; the last one of the region decides what the host sees: a failed unit fails the region (the library
@@ -1938,12 +1939,46 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
             __threadfence();
             const uint32_t done = atomicAdd(&C_.wk->units_done, 1u) + 1u;
             if (done == (uint32_t)C_.split) {
+                // The last unit of the region to report in settles it, here and now (round 5; until round 4 the host did, after the
+                // LAST region of the batch had finished its pass): nothing met across units -> the contigs are put into the
+                // reference's order (bk_link_region); components met -> they are merged, reset and dealt again (bk_resolve_region)
+                // and the units of the next pass appended to the queue, where the workgroups that have run out of work pick them up
+                // while the stragglers of the batch still run.  No room in the queue / bookkeeping overflow / a failed unit: the
+                // host takes over as before (BK_ST_REDO / BK_ST_UNSPLIT / the unit's status).
                 __threadfence();
                 const uint32_t np_ = __hip_atomic_load(&C_.wk->n_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nc_ = __hip_atomic_load(&C_.wk->n_conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                                nx_ = __hip_atomic_load(&C_.wk->n_cidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (np_ > C_.wk->pairs_cap || nx_ > C_.wk->cidx_cap) atomicCAS((int *)&C_.wk->status, BK_ST_OK, BK_ST_UNSPLIT);
-                else if (nc_ > 0) atomicCAS((int *)&C_.wk->status, BK_ST_OK, BK_ST_REDO);
+                const int st_ = __hip_atomic_load(&C_.wk->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (st_ != BK_ST_OK) action = 3;
+                else if (np_ > C_.wk->pairs_cap || nx_ > C_.wk->cidx_cap) { atomicCAS((int *)&C_.wk->status, BK_ST_OK, BK_ST_UNSPLIT); action = 3; }
+                else if (nc_ > 0) {
+                    const unsigned long long cap_ = __hip_atomic_load(p.queue_cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {
+                        const unsigned long long old = __hip_atomic_load(p.n_queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old + (unsigned long long)C_.split > cap_) { atomicCAS((int *)&C_.wk->status, BK_ST_OK, BK_ST_REDO); action = 3; break; }
+                        if (atomicCAS(p.n_queue, old, old + (unsigned long long)C_.split) == old) { S->tmp1 = (int)old; action = 1; break; }
+                    }
+                } else action = 2;
             }
+        }
+        S->tmp0 = action;
+    }
+    BK_SYNC();
+    {
+        const int action = S->tmp0, qat = S->tmp1, nunits = (int)C_.split;
+        BK_SYNC();                                       // (every wavefront has read the two words)
+        if (action == 1) {
+            bk_resolve_region(p, (uint32_t)r, (uint32_t)BK_TID, (uint32_t)BK_AT);
+            if (BK_TID < nunits) {
+                const bool ok = __hip_atomic_load(&wk->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == BK_ST_OK;          // (too many passes: the host runs the region again as one unit)
+                __hip_atomic_store(&p.order[qat + BK_TID], ok ? ((uint32_t)r | ((uint32_t)BK_TID << BK_QUEUE_UNIT_SHIFT)) : BK_QUEUE_NOP, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (!ok && BK_TID == 0) { __threadfence(); atomicSub(p.pending, 1ull); }
+            }
+        } else if (action == 2) {
+            bk_link_region(p, (uint32_t)r, (uint32_t)BK_TID, (uint32_t)BK_AT, S->scan);
+            if (BK_TID == 0) { __threadfence(); atomicSub(p.pending, 1ull); }
+        } else if (action == 3) {
+            if (BK_TID == 0) { __threadfence(); atomicSub(p.pending, 1ull); }
         }
     }
 #ifdef BK_DIAG
@@ -1978,12 +2013,30 @@ extern "C" __global__ void __launch_bounds__(BK_AT, BK_ASM_MINB) BK_ASM_KERNEL(B
         // The first entry a workgroup takes is the one of its own index: the grid is sized for the most units the batch can have
         // (a noisy region is split into up to BK_SPLIT_G on the device), and with one unit per region the workgroups that find
         // work must be the FIRST ones launched -- one per CU -- not whichever of two on a CU wins a race for the queue head.
-        if (BK_TID == 0) S_->qslot = first ? (int)blockIdx.x : (int)gridDim.x + (int)atomicAdd(p.asm_head, 1ull);
+        // After that the queue is dynamic: *asm_head is the next entry to hand out, *n_queue the entries allocated (split regions
+        // whose components met append the units of their next pass, bk_asm_region), an entry is valid once written; a workgroup
+        // that finds the queue empty leaves only when no split region can append any more (*pending == 0: at once for a batch
+        // without split regions).
+        if (BK_TID == 0) {
+            int q = -1; uint32_t e = BK_QUEUE_NOP;
+            if (first && (unsigned long long)blockIdx.x < __hip_atomic_load(p.n_queue0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) q = (int)blockIdx.x;
+            else for (;;) {
+                const unsigned long long n = __hip_atomic_load(p.n_queue, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hd = __hip_atomic_load(p.asm_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (hd < n) { if (atomicCAS(p.asm_head, hd, hd + 1ull) == hd) { q = (int)hd; break; } continue; }
+                if (__hip_atomic_load(p.pending, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0ull) break;      // (what was appended before the last region settled has been handed out: it could not settle otherwise)
+                __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+            }
+            if (q >= 0) {
+                while ((e = __hip_atomic_load(&p.order[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == BK_EMPTY32) __builtin_amdgcn_s_sleep(20);      // allocated, not yet written
+            }
+            S_->qslot = q; S_->tmp2 = (int)e;
+        }
         BK_SYNC();
         first = false;
-        const int q = S_->qslot;
-        if (q >= (int)*p.n_queue) break;
-        const uint32_t e = p.order[q];
+        const int q = S_->qslot; const uint32_t e = (uint32_t)S_->tmp2;
+        if (q < 0) break;
+        if (e == BK_QUEUE_NOP) continue;
         bk_asm_region(p, (int)(e & ((1u << BK_QUEUE_UNIT_SHIFT) - 1u)), (int)(e >> BK_QUEUE_UNIT_SHIFT));
     }
 }

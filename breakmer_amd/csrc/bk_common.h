@@ -243,6 +243,11 @@ struct BkParams {
     // scheduling (bk_sched.hip.h): regions in descending order of estimated assembler cost, pulled by persistent
     // workgroups; every emitted contig is appended to `clist` (its `out` offset | region << 40), pulled by the realigner
     uint32_t *order; unsigned long long *asm_head, *sw_head, *n_clist, *n_queue; unsigned long long *clist; uint64_t clist_cap;
+    // the unit queue is DYNAMIC since round 5 (bk_asm.hip.h): order[0 .. *n_queue0) are the entries of the launch (bk_sched_kernel / the
+    // host), a split region whose components met across units appends the units of its next pass itself (entries up to order_cap; *n_queue
+    // = entries allocated, an entry is valid once its word is not BK_EMPTY32), *asm_head = next entry to hand out, *pending = split
+    // regions that may still append (persistent workgroups that find the queue empty wait for it to reach 0)
+    unsigned long long *n_queue0, *pending, *queue_cap; uint32_t order_cap, pad_q;      // *queue_cap: entries of `order` that may be used by this launch (marked empty beyond *n_queue0)
     uint32_t asm_lds_pad, dbg_iters;      // dbg_iters (BK_DBG_ITERS=k): diagnostic -- every region stops after k seed iterations (0: no limit)
     //      // diagnostic (BK_LDS_PAD=<bytes>): a guard band behind the assembler's LDS block, filled before and checked after every region (BkRegionWork.stamps[14..15])
     uint32_t asm_lds_bytes, poison;      // diagnostic (BK_POISON_LDS=<byte>): the assembler's LDS block is filled with this byte before every region (an uninitialised read then behaves the same whatever ran on the CU before)
@@ -252,7 +257,7 @@ struct BkParams {
     int32_t flags;               // BK_F_*
     const uint32_t *rmap;        // launch over a subset of the batch (re-run of regions that overflowed a cap): workgroup b of the k-mer kernels takes region rmap[b]; nullptr = region b
 };
-enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64, BK_F_NO_SPLIT = 128, BK_F_SPLIT_ALWAYS = 256, BK_F_SPLIT_NO_LOOKAHEAD = 512, BK_F_SPLIT = 1024, BK_F_NO_CALL_SHORTCUT = 2048 };   // noisy regions are split into units (bk_comp.hip.h) by DEFAULT since round 5; 1024: accepted, no effect (it switched the split on while it was experimental)   // 512: diagnostic -- no look-ahead inside split regions (the round-4 setting)   // 128: every region is one unit (no component split); 256: split whatever the size (diagnostic: the split path on small fixtures)   // 2048: bk_call takes every contig through the full caller (no shortcut for single full-span hits; tests)   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
+enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64, BK_F_NO_SPLIT = 128, BK_F_SPLIT_ALWAYS = 256, BK_F_SPLIT_NO_LOOKAHEAD = 512, BK_F_SPLIT = 1024, BK_F_NO_CALL_SHORTCUT = 2048, BK_F_HOST_REPAIR = 4096 };   // 4096: split regions whose components met are repaired by host-driven passes (the round-4 way: the fallback of the in-kernel repair, kept testable)   // noisy regions are split into units (bk_comp.hip.h) by DEFAULT since round 5; 1024: accepted, no effect (it switched the split on while it was experimental)   // 512: diagnostic -- no look-ahead inside split regions (the round-4 setting)   // 128: every region is one unit (no component split); 256: split whatever the size (diagnostic: the split path on small fixtures)   // 2048: bk_call takes every contig through the full caller (no shortcut for single full-span hits; tests)   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
 
 // component info word (BkRegionWork.o_cinfo, at the component's root read)
 #define BK_CI_UNIT 0xFFu
@@ -262,6 +267,8 @@ enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 
 #define BK_CI_ABORT 0x40000u          // its unit gave it up in this pass (it met another unit's component)
 #define BK_SPLIT_HI 8                 // seeds with a count of at least this are run by unit 0 alone, in order, before the graph is labelled (bk_comp.hip.h)
 #define BK_QUEUE_UNIT_SHIFT 24
+#define BK_QUEUE_NOP 0xFFFFFFFEu      // a reserved queue entry that turned out to have no work (its region failed while the entries were reserved)
+#define BK_REQUEUE_PASSES 12          // room in the unit queue for this many in-kernel repair passes of every split region (beyond it: the host drives the pass)
 
 __device__ inline uint64_t bk_align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 

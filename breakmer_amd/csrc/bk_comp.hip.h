@@ -91,18 +91,17 @@ __device__ inline void bk_split_prepare(const BkParams &p, BkRegionWork *wk, uin
 __device__ inline uint8_t *bk_ufl0(const BkParams &p, const BkRegionWork *wk) { return p.arena + wk->o_pairs + bk_align_up((uint64_t)wk->pairs_cap * 12, 256); }
 
 // ---- after a pass in which components met across units: merge what met, reset and re-deal the sets that hold a conflict ----
-// One workgroup per entry of `list` (regions with status BK_ST_REDO).
-#define BK_RESOLVE_T 512
-extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkParams p, const uint32_t *list)
+// Executed by ONE workgroup of nt threads (every thread calls it) for region r: by the last unit of the region to report in, inside
+// the assembler (round 5: a region repairs itself while the stragglers of the batch still run), or by bk_resolve_kernel (the
+// host-driven fallback when the unit queue has no room for another pass).
+__device__ inline void bk_resolve_region(const BkParams &p, const uint32_t r, const uint32_t tid, const uint32_t nt)
 {
-    const uint32_t tid = threadIdx.x, nt = BK_RESOLVE_T;
-    const uint32_t r = list[blockIdx.x];
     BkRegionWork *wk = &p.work[r];
     const BkRegionDesc d = p.desc[r];
     const uint32_t U = wk->U, M = wk->M;
     uint32_t *rroot = (uint32_t *)(p.arena + wk->o_rroot), *cinfo = (uint32_t *)(p.arena + wk->o_cinfo), *kroot = (uint32_t *)(p.arena + wk->o_kroot);
     const uint32_t *pairs = (const uint32_t *)(p.arena + wk->o_pairs);
-    const uint32_t np = min(wk->n_pairs, wk->pairs_cap), pass = wk->pass + 1;
+    const uint32_t np = min(bk_ld_agent(&wk->n_pairs), wk->pairs_cap), pass = wk->pass + 1;
     // 1. everything that met becomes one component (merges inside a unit included: their contigs mixed their reads)
     for (uint32_t i = tid; i < np; i += nt) bk_uf_union(rroot, pairs[3 * i], pairs[3 * i + 1]);
     __threadfence(); BK_SYNC();
@@ -137,55 +136,66 @@ extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkP
     __threadfence(); BK_SYNC();
     if (tid < BK_SPLIT_G) { wk->unit_us[tid] = 0; wk->unit_iters[tid] = 0; }
     if (tid == 0) { wk->pass = pass; wk->n_pairs = 0; wk->n_conf = 0; wk->units_done = 0; wk->status = pass >= 200 ? BK_ST_UNSPLIT : BK_ST_OK; }
+    __threadfence(); BK_SYNC();
+}
+#define BK_RESOLVE_T 512
+extern "C" __global__ void __launch_bounds__(BK_RESOLVE_T) bk_resolve_kernel(BkParams p, const uint32_t *list)
+{
+    bk_resolve_region(p, list[blockIdx.x], threadIdx.x, BK_RESOLVE_T);
 }
 
 // ---- the contigs of a split region in the order init_assembly returns them: by (seed rank, emission order); contigs of
-//      components that ran again are dropped (their pass is not the component's last) ----
+//      components that ran again are dropped (their pass is not the component's last).  One workgroup of nt threads; red: >= 16 words
+//      of LDS.  Called by the last unit of a region that settles inside the assembler, or by bk_link_kernel (host-driven passes).
+__device__ inline void bk_link_region(const BkParams &p, const uint32_t r, const uint32_t tid, const uint32_t nt, uint32_t *red)
+{
+    BkRegionWork *wk = &p.work[r];
+    const uint32_t *rroot = (const uint32_t *)(p.arena + wk->o_rroot), *cinfo = (const uint32_t *)(p.arena + wk->o_cinfo);
+    unsigned long long *key = (unsigned long long *)(p.arena + wk->o_cidx), *off = key + wk->cidx_cap;
+    const uint32_t n = bk_ld_agent(&wk->n_cidx);
+    if (n > wk->cidx_cap) { if (tid == 0) wk->status = BK_ST_UNSPLIT; return; }             // uniform
+    uint32_t npad = 1; while (npad < n) npad <<= 1;
+    // dead contigs sort last
+    for (uint32_t i = tid; i < npad; i += nt) {
+        if (i >= n || key[i] == ~0ull) { key[i] = ~0ull; continue; }      // padding, or dead since an earlier pass (the sort of that pass mixed both behind the live ones: such an entry may hold no record offset at all)
+        const BkContigRec *c = (const BkContigRec *)(p.out + off[i]);
+        if (c->root != BK_EMPTY32 && (cinfo[rroot[c->root]] & 0xFFFFu) != c->pass) key[i] = ~0ull;            // made by the unit and pass that hold the component now (no component: unit 0's serial prefix)
+    }
+    __threadfence(); BK_SYNC();
+    for (uint32_t sz = 2; sz <= npad; sz <<= 1)
+        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+            for (uint32_t i = tid; i < npad / 2; i += nt) {
+                const uint32_t lo = (i / st) * (st * 2) + (i % st), hi = lo + st;
+                const bool up = (lo & sz) == 0;
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; const unsigned long long oa = off[lo]; off[lo] = off[hi]; off[hi] = oa; }
+            }
+            __threadfence(); BK_SYNC();
+        }
+    uint32_t live = 0;
+    for (uint32_t i = tid; i < n; i += nt) {
+        if (key[i] == ~0ull) continue;
+        live++;
+        BkContigRec *c = (BkContigRec *)(p.out + off[i]);
+        c->next = (i + 1 < n && key[i + 1] != ~0ull) ? off[i + 1] : 0ull;
+    }
+    for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
+    BK_SYNC();
+    if ((tid & 63) == 0) red[tid >> 6] = live;
+    BK_SYNC();
+    if (tid == 0) {
+        uint32_t tot = 0; for (uint32_t w = 0; w < (nt + 63) / 64; w++) tot += red[w];
+        wk->n_contigs = tot; wk->o_first_contig = tot ? off[0] : 0ull; wk->o_last_contig = tot ? off[tot - 1] : 0ull;
+    }
+    BK_SYNC();
+}
 #define BK_LINK_T 256
 extern "C" __global__ void __launch_bounds__(BK_LINK_T) bk_link_kernel(BkParams p, int n_regions)
 {
-    const uint32_t tid = threadIdx.x, nt = BK_LINK_T;
+    __shared__ uint32_t red[BK_LINK_T / 64];
     for (int r = blockIdx.x; r < n_regions; r += gridDim.x) {
-        BkRegionWork *wk = &p.work[r];
+        const BkRegionWork *wk = &p.work[r];
         if (!wk->split || wk->status != BK_ST_OK) continue;                            // uniform
-        const uint32_t *rroot = (const uint32_t *)(p.arena + wk->o_rroot), *cinfo = (const uint32_t *)(p.arena + wk->o_cinfo);
-        unsigned long long *key = (unsigned long long *)(p.arena + wk->o_cidx), *off = key + wk->cidx_cap;
-        const uint32_t n = wk->n_cidx;
-        if (n > wk->cidx_cap) { if (tid == 0) wk->status = BK_ST_UNSPLIT; continue; }
-        uint32_t npad = 1; while (npad < n) npad <<= 1;
-        // dead contigs sort last
-        for (uint32_t i = tid; i < npad; i += nt) {
-            if (i >= n || key[i] == ~0ull) { key[i] = ~0ull; continue; }      // padding, or dead since an earlier pass (the sort of that pass mixed both behind the live ones: such an entry may hold no record offset at all)
-            const BkContigRec *c = (const BkContigRec *)(p.out + off[i]);
-            if (c->root != BK_EMPTY32 && (cinfo[rroot[c->root]] & 0xFFFFu) != c->pass) key[i] = ~0ull;            // made by the unit and pass that hold the component now (no component: unit 0's serial prefix)
-        }
-        __threadfence(); BK_SYNC();
-        for (uint32_t sz = 2; sz <= npad; sz <<= 1)
-            for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
-                for (uint32_t i = tid; i < npad / 2; i += nt) {
-                    const uint32_t lo = (i / st) * (st * 2) + (i % st), hi = lo + st;
-                    const bool up = (lo & sz) == 0;
-                    const unsigned long long a = key[lo], b = key[hi];
-                    if ((a > b) == up) { key[lo] = b; key[hi] = a; const unsigned long long oa = off[lo]; off[lo] = off[hi]; off[hi] = oa; }
-                }
-                __threadfence(); BK_SYNC();
-            }
-        uint32_t live = 0;
-        for (uint32_t i = tid; i < n; i += nt) {
-            if (key[i] == ~0ull) continue;
-            live++;
-            BkContigRec *c = (BkContigRec *)(p.out + off[i]);
-            c->next = (i + 1 < n && key[i + 1] != ~0ull) ? off[i + 1] : 0ull;
-        }
-        for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
-        __shared__ uint32_t red[BK_LINK_T / 64];
-        BK_SYNC();
-        if ((tid & 63) == 0) red[tid >> 6] = live;
-        BK_SYNC();
-        if (tid == 0) {
-            uint32_t tot = 0; for (uint32_t w = 0; w < nt / 64; w++) tot += red[w];
-            wk->n_contigs = tot; wk->o_first_contig = tot ? off[0] : 0ull; wk->o_last_contig = tot ? off[tot - 1] : 0ull;
-        }
-        BK_SYNC();
+        bk_link_region(p, (uint32_t)r, threadIdx.x, BK_LINK_T, red);
     }
 }

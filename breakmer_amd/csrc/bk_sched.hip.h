@@ -15,9 +15,11 @@
 #define BK_SCHED_T 1024
 
 // one workgroup: order[] = region ids by (cost descending, id ascending) -- deterministic
-extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParams p, unsigned long long *keys /* npad words of scratch */, uint32_t npad)
+extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParams p, unsigned long long *keys /* npad words of scratch */, uint32_t npad, uint32_t asm_grid /* workgroups of the assembler launch that follows */)
 {
     const int tid = threadIdx.x, n = p.n_regions;
+    __shared__ uint32_t nsplit_s;
+    if (tid == 0) nsplit_s = 0;
     for (uint32_t i = tid; i < npad; i += BK_SCHED_T) {
         unsigned long long key = ~0ull;                                   // padding sorts last
         if ((int)i < n) {
@@ -41,29 +43,6 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
             }
             BK_SYNC();
         }
-#ifdef BK_QUEUE_REGION_MAJOR      // diagnostic: the queue order of the first version (the units of a region behind each other)
-    // the queue: one entry per unit -- (region | unit << 24); the units of a split region (bk_comp.hip.h) follow each other, so the
-    // heaviest region's components are all in flight at once
-    __shared__ uint32_t wsum[BK_SCHED_T / 64], base_s;
-    if (tid == 0) base_s = 0;
-    BK_SYNC();
-    for (int c0 = 0; c0 < n; c0 += BK_SCHED_T) {
-        const int i = c0 + tid;
-        uint32_t rid = 0, g = 0;
-        if (i < n) { rid = (uint32_t)keys[i]; const uint32_t sp = p.work[rid].split; g = sp ? sp : 1u; }
-        uint32_t inc = g;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((tid & 63) >= o) inc += t; }
-        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-        BK_SYNC();
-        uint32_t pre = base_s, tot = 0;
-        for (int w = 0; w < BK_SCHED_T / 64; w++) { const uint32_t t = wsum[w]; if (w < (tid >> 6)) pre += t; tot += t; }
-        const uint32_t at = pre + inc - g;
-        for (uint32_t u = 0; u < g; u++) p.order[at + u] = rid | (u << BK_QUEUE_UNIT_SHIFT);
-        BK_SYNC();
-        if (tid == 0) base_s += tot;
-        BK_SYNC();
-    }
-#else
     // the queue: one entry per unit -- (region | unit << 24).  First every region once (unit 0 of a split region, bk_comp.hip.h: it
     // runs the serial prefix the other units wait for, so all prefixes of a batch start at once however few workgroups are
     // resident -- with the units of a region behind each other, 64 split regions on 512 resident workgroups ran their prefixes in
@@ -75,7 +54,7 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
     for (int c0 = 0; c0 < n; c0 += BK_SCHED_T) {
         const int i = c0 + tid;
         uint32_t rid = 0, g = 0;                                             // g: units beyond the first
-        if (i < n) { rid = (uint32_t)keys[i]; const uint32_t sp = p.work[rid].split; g = sp ? sp - 1u : 0u; }
+        if (i < n) { rid = (uint32_t)keys[i]; const uint32_t sp = p.work[rid].split; g = sp ? sp - 1u : 0u; if (sp) atomicAdd(&nsplit_s, 1u); }
         uint32_t inc = g;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((tid & 63) >= o) inc += t; }
         if ((tid & 63) == 63) wsum[tid >> 6] = inc;
@@ -88,6 +67,11 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
         if (tid == 0) base_s += tot;
         BK_SYNC();
     }
-#endif
-    if (tid == 0) *p.n_queue = base_s;
+    // the queue is dynamic (bk_asm.hip.h): room behind the launch's entries for the units that split regions append when their
+    // components met across units (marked empty: an entry is valid once written); the first asm_grid entries are taken by block index
+    BK_SYNC();
+    const uint32_t nq = base_s, nsp = nsplit_s;
+    const uint32_t ext_end = (p.flags & BK_F_HOST_REPAIR) ? nq : (uint32_t)min((unsigned long long)p.order_cap, (unsigned long long)nq + (unsigned long long)nsp * BK_SPLIT_G * BK_REQUEUE_PASSES);
+    for (uint32_t i = nq + tid; i < ext_end; i += BK_SCHED_T) p.order[i] = BK_EMPTY32;
+    if (tid == 0) { *p.n_queue = nq; *p.n_queue0 = nq; *p.asm_head = min(asm_grid, nq); *p.pending = nsp; *p.queue_cap = ext_end; }
 }

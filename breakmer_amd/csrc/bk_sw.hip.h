@@ -294,6 +294,13 @@ extern "C" __global__ void __launch_bounds__(BK_ST_TMAX) bk_sw_kernel(BkParams p
                     if (li < p.clist_cap) p.sw_long[li] = e0;
                     S->skip = 1;
                 }
+                if (!S->skip && p.work[rr].split) {                       // a contig of a component that ran again in a later pass (bk_comp.hip.h) is dead: not in the region's list, nobody reads its hits
+                    const BkContigRec *c0 = (const BkContigRec *)(p.out + (e0 & ((1ull << 40) - 1ull)));
+                    if (c0->root != BK_EMPTY32) {
+                        const uint32_t *rroot = (const uint32_t *)(p.arena + p.work[rr].o_rroot), *cinfo = (const uint32_t *)(p.arena + p.work[rr].o_cinfo);
+                        if ((cinfo[rroot[c0->root]] & 0xFFFFu) != c0->pass) S->skip = 1;
+                    }
+                }
                 if (!S->skip && S->staged_region != rr) { S->staged_ti = -1; S->staged_region = rr; }
             }
         }

@@ -205,7 +205,9 @@ def test_split_regions_are_bit_identical_gpu(hb, golden_dir):
     (a) every reference fixture (G3) with the split FORCED on its small graph (flag 256), both workgroup sizes;
     (b) a mixed batch with mid-size noisy regions against the oracle, split forced;
     (c) full-size regions at 0.2 % / 0.5 % / 1 % substitutions, split (the default) against one unit (flag 128): the same
-        contigs in the same order, the same realign records -- and the split really happened, with repair passes."""
+        contigs in the same order, the same realign records -- and the split really happened, with repair passes: inside the
+        assembler kernel (the last unit of a region merges, re-deals and re-queues: the default) and driven by the host (flag 4096:
+        the fallback when the unit queue has no room)."""
     from oracle import bk_oracle as bo
     d = _load(golden_dir, "assembly.json")
     by_cfg = {}
@@ -238,13 +240,15 @@ def test_split_regions_are_bit_identical_gpu(hb, golden_dir):
     many = _run_regions(hb, full, 31, stages=7)
     assert one.sync() == 0 and many.sync() == 0
     assert one.stat(28) == 0 and many.stat(28) >= 4, many.stat(28)          # the clean region and the percolated one (1 %) stay one unit
-    assert many.stat(27) >= 1                                                # components met across units: at least one repair pass
+    assert many.stat(27) >= 1 and many.stat(29) == 0                         # components met across units: at least one repair pass, all of them inside the assembler kernel
     assert many.stat(1) >= one.stat(1)                                       # (the DPs of components that ran again are counted too)
+    host = _run_regions(hb, full, 31, stages=7, flags=4096)                  # the fallback: repair passes driven by the host (no room in the unit queue)
+    assert host.sync() == 0 and host.stat(28) >= 4 and host.stat(29) >= 1
     for i in range(len(full)):
-        a, b = one.contigs(i), many.contigs(i)
-        assert len(a) == len(b) and a == b, (i, len(a), len(b))
+        a, b, c = one.contigs(i), many.contigs(i), host.contigs(i)
+        assert len(a) == len(b) and a == b and c == a, (i, len(a), len(b), len(c))
         for ci in range(0, len(a), 50):
-            assert one.hits(i, ci) == many.hits(i, ci), (i, ci)
+            assert one.hits(i, ci) == many.hits(i, ci) == host.hits(i, ci), (i, ci)
 
 
 def test_barrier_discipline_of_every_kernel_gpu():
