@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libbreakmer_hip.so")      # the product build; d
 
 BK_STAGE_KMER, BK_STAGE_ASSEMBLE, BK_STAGE_REALIGN, BK_STAGE_ALL = 1, 2, 4, 7
 BK_MAX_BLOCKS = 32
-BK_ABI_VERSION = 3
+BK_ABI_VERSION = 4
 BK_PSL_FLAT_HEAD = 18
 BK_W_REGIONS_FAILED = 1
 
@@ -70,7 +70,7 @@ def call_text(text):
 EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_submit_regions_ex", "bk_run", "bk_sync", "bk_fetch",
            "bk_last_kernel_ms", "bk_get_region_status", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
            "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_call_async", "bk_get_calls", "bk_get_contig_counts",
-           "bk_nw_batch", "bk_pack_sequence", "bk_trim", "bk_get_hits_flat", "bk_index_create", "bk_index_probe", "bk_index_destroy"]
+           "bk_nw_batch", "bk_pack_sequence", "bk_trim", "bk_get_hits_flat", "bk_index_create", "bk_index_probe", "bk_index_destroy", "bk_index_set_loci", "bk_index_find"]
 
 _lib = None
 
@@ -116,6 +116,8 @@ def load_library(path=None):
     L.bk_index_create.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
     L.bk_index_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     L.bk_index_destroy.argtypes = [C.c_void_p]
+    L.bk_index_set_loci.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bk_index_find.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
     L.bk_call_text.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
     L.bk_pack_sequence.argtypes = [C.c_char_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.bk_trim.argtypes = [C.c_void_p, C.c_uint64]
@@ -580,6 +582,32 @@ class DeviceIndex(object):
             raise BreakmerHipError("bk_index_probe failed (%d)" % rc)
         self.kernel_ms = ms.value
         return lo, hi
+
+    def set_loci(self, seqno, pos):
+        """sequence number (uint16) and position (uint32) of every index entry, parallel to the sorted codes: what find() needs"""
+        sq, ps = _as_c(seqno, np.uint16), _as_c(pos, np.uint32)
+        if len(sq) != self.n or len(ps) != self.n:
+            raise BreakmerHipError("DeviceIndex.set_loci: arrays must be parallel to the codes")
+        rc = self.L.bk_index_set_loci(self.h, sq.ctypes.data, ps.ctypes.data)
+        if rc != 0:
+            raise BreakmerHipError("bk_index_set_loci failed (%d)" % rc)
+
+    def find(self, codes, ok, max_occ=64, band=32, min_hits=2):
+        """loci of one strand of a query on the device: [(hits, sequence number, first index position, last index position)] in
+        (sequence, diagonal, position) order (bk_index_find)"""
+        q = _as_c(codes, np.uint32)
+        okb = _as_c(np.asarray(ok).astype(np.uint8), np.uint8)
+        cap = 256
+        while True:
+            out = np.zeros((cap, 4), dtype=np.uint32)
+            n, ms = C.c_uint32(), C.c_float()
+            rc = self.L.bk_index_find(self.h, q.ctypes.data, okb.ctypes.data, len(q), int(max_occ), int(band), int(min_hits), out.ctypes.data, cap, C.byref(n), C.byref(ms))
+            if rc != 0:
+                raise BreakmerHipError("bk_index_find failed (%d)" % rc)
+            self.kernel_ms = ms.value
+            if n.value <= cap:
+                return [tuple(int(v) for v in row) for row in out[:n.value]]
+            cap = int(n.value)
 
     def close(self):
         if self.h:

@@ -98,7 +98,7 @@ class GenomeIndex(object):
         import numpy as np
         self.k, self.step, self.max_occ, self.fasta = int(k), int(step), int(max_occ), fasta
         self.names = list(fasta.index.keys())
-        self._dev, self._dev_no = None, device
+        self._dev, self._dev_no, self._dev_loci = None, device, False
         self.probe_ms = 0.0
         cfn = None
         if cache and getattr(fasta, "path", None):
@@ -155,13 +155,17 @@ class GenomeIndex(object):
         """index ranges [lo, hi) of the entries equal to each query code"""
         import numpy as np
         if self._dev_no is not None:
-            if self._dev is None:
-                from . import hip_backend
-                self._dev = hip_backend.DeviceIndex(self.code, self._dev_no)
+            self._device()
             lo, hi = self._dev.probe(code)
             self.probe_ms += self._dev.kernel_ms
             return lo.astype(np.int64), hi.astype(np.int64)
         return np.searchsorted(self.code, code, side="left"), np.searchsorted(self.code, code, side="right")
+
+    def _device(self):
+        if self._dev is None:
+            from . import hip_backend
+            self._dev = hip_backend.DeviceIndex(self.code, self._dev_no)
+        return self._dev
 
     def _codes(self, seq):
         import numpy as np
@@ -188,6 +192,17 @@ class GenomeIndex(object):
         for strand, q in (("+", seq), ("-", revcomp(seq))):
             code, ok = self._codes(q)
             if not len(code):
+                continue
+            if self._dev_no is not None and len(code) <= 32768:
+                # the whole look-up on the device (bk_index_find: ranges, hits sorted by (sequence, diagonal, position), loci cut at
+                # sequence changes / diagonal jumps, >= min_hits): the same loci in the same order as the numpy path below
+                self._device()
+                if not self._dev_loci:
+                    self._dev.set_loci(self.seqno, self.pos)
+                    self._dev_loci = True
+                for nh, sq_, p0, p1 in self._dev.find(code, ok, self.max_occ, band, min_hits):
+                    out.append((nh, self.names[sq_], strand, p0, p1 + self.k))
+                self.probe_ms += self._dev.kernel_ms
                 continue
             lo, hi = self._ranges(code)
             use = np.nonzero(ok & (hi > lo) & (hi - lo <= self.max_occ))[0]

@@ -18,10 +18,13 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 3       /* 2: bk_psl holds 32 blocks; bk_get_hits also returns secondary alignments; bk_sync reports regions that hit a cap (BK_W_REGIONS_FAILED)
+#define BK_ABI_VERSION 4       /* 2: bk_psl holds 32 blocks; bk_get_hits also returns secondary alignments; bk_sync reports regions that hit a cap (BK_W_REGIONS_FAILED)
                                 * 3: the realign stage has no hit / block caps any more (bk_get_hits_flat returns records of any size, bk_call uses them);
                                 *    reference / partner windows may be soft-masked (lower case => rep_matches); regions that overflow an assembler cap are
-                                *    re-run by the library with larger ones (bk_config.reserved[2]); BK_SUBMIT_PACKED */
+                                *    re-run by the library with larger ones (bk_config.reserved[2]); BK_SUBMIT_PACKED
+                                * 4: noisy regions are split over up to 16 assembler workgroups by default (same results; reserved[0] bit 128 = never);
+                                *    the realign records pass BLAT's documented output filters (-minScore, -minIdentity default 90: oracle/bk_oracle.h
+                                *    step 8); bk_index_set_loci / bk_index_find; the product build reads no environment variable (diagnostics: -DBK_DIAG) */
 
 enum {
     BK_OK = 0,
@@ -60,10 +63,12 @@ typedef struct bk_config {
                                  *      8 = no look-ahead across k-mer visits, 16 = no look-ahead into the next seeds: same results, more DP rounds;
                                  *      32 = bucket sort of the seed k-mers whatever their number (the path of very large noisy regions),
                                  *      64 = every read retired on its own (no run retire): same results)
-                                 *      1024 = EXPERIMENTAL, off by default: noisy regions (>= 1,024 seed k-mers) are split into up to 16 units that run on
-                                 *      16 workgroups (same results, 2-6x faster on such regions); opt-in for this round (the evidence
-                                 *      has not been repeated with it switched on since the barrier fix of DESIGN 7);
-                                 *      256 = with it, split whatever the size (tests); 128 = never split)
+                                 *      noisy regions (>= 1,024 seed k-mers) are split into up to 16 units that run on 16 workgroups and repair
+                                 *      themselves inside the kernel where components meet (same results, 2-6x faster on such regions; the default
+                                 *      since ABI 4): 128 = never split (one workgroup per region), 256 = split whatever the size (tests),
+                                 *      512 = no look-ahead inside split regions, 4096 = repair passes driven by the host (the fallback path),
+                                 *      1024 = accepted, no effect (it switched the split on while it was opt-in);
+                                 *      2048 = bk_call takes every contig through the full caller (no shortcut for single full-span hits))
                                  * [1]: assembler workgroup size: 512 = 8 wavefronts / 8 look-ahead slots / 2 per CU (one batch finishes soonest),
                                  *      256 = 4 wavefronts / 4 slots / 4 per CU (most regions/s when batches are in flight), 0 = library chooses
                                  * [2]: 1 = do NOT re-run regions that overflow an assembler cap with larger caps (they fail at once: bk_get_region_status) */
@@ -228,6 +233,17 @@ int bk_call_text(const char *text, char *out, size_t cap, int *target_hit);   /*
 typedef struct bk_index bk_index;
 int bk_index_create(int device_id, const uint32_t *sorted_codes, uint64_t n, bk_index **out);
 int bk_index_probe(bk_index *ix, const uint32_t *queries, uint64_t n_queries, uint32_t *lo, uint32_t *hi, float *kernel_ms);
+/* The whole look-up on the device (round 5): with the sequence number and position of every index entry resident as well
+ * (bk_index_set_loci: arrays parallel to sorted_codes), bk_index_find returns the LOCI of one query sequence -- the k-mers of one
+ * strand of a contig segment (queries[i] = k-mer at query position i, ok[i] = 0 where it holds an N; at most 32,768) --: index hits
+ * of k-mers that occur at most max_occ times, sorted by (sequence, diagonal, position), cut where the sequence changes or the
+ * diagonal jumps by more than `band`, kept with >= min_hits hits (2 = BLAT's -minMatch=2), in that order; start / end = first and
+ * last index position of the locus.  *n_loci may exceed cap.  Replaces the numpy clustering of refseq.GenomeIndex.find, which
+ * stays as the host path it is tested against. */
+typedef struct bk_locus { uint32_t hits, seqno, start, end; } bk_locus;
+int bk_index_set_loci(bk_index *ix, const uint16_t *seqno, const uint32_t *pos);
+int bk_index_find(bk_index *ix, const uint32_t *queries, const uint8_t *ok, uint32_t n_queries, uint32_t max_occ, uint32_t band, uint32_t min_hits,
+                  bk_locus *loci, uint32_t cap, uint32_t *n_loci, float *kernel_ms);
 int bk_index_destroy(bk_index *ix);
 
 /* The 2-bit packing bk_submit_regions applies to every sequence (16 bases per word, first base in the most significant

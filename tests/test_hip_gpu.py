@@ -1152,6 +1152,49 @@ def test_translocation_partner_discovery_gpu(hb, tmp_path):
     assert sp.runner(cfg2, native_calls=False).run() == rows
 
 
+def test_translocation_without_discordant_pairs_genome_search_gpu(hb, tmp_path, monkeypatch):
+    """N4, the genome-wide second pass as a GPU path: a translocation that only split reads speak of (every pair with its ends on two
+    chromosomes removed from the alignment file) -- the first pass leaves the partner half of the contig unaligned, the driver looks
+    that segment up in the genome index ON THE DEVICE (bk_index_find: ranges, hits sorted by (sequence, diagonal, position), loci with
+    >= 2 hits in a diagonal band), runs the target again with the window found, and the contig is explained.  The same run with the
+    look-ups on the host (numpy) must find the same window and give the same rows.  (A stand-in for the reference's whole-genome
+    gfServer, sv_processor.py:829-831: unpinned)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_pipeline import make_trl_inputs
+    from breakmer_amd import refseq, sv_processor as sp
+
+    def run_once(d, on_device):
+        d.mkdir()
+        cfg, r = make_trl_inputs(d)
+        sam = (d / "sample.sam").read_text().splitlines()
+        kept = [ln for ln in sam if ln.startswith("@") or ln.split("\t")[6] == "="]
+        assert 0 < len(kept) < len(sam)
+        (d / "sample.sam").write_text("\n".join(kept) + "\n")
+        made = []
+        orig = refseq.GenomeIndex.__init__
+
+        def init(self, fasta, *a, **kw):
+            if not on_device:
+                kw["device"] = None
+            kw["cache"] = False
+            orig(self, fasta, *a, **kw)
+            made.append(self)
+        monkeypatch.setattr(refseq.GenomeIndex, "__init__", init)
+        run = sp.runner(cfg)
+        rows = run.run()
+        monkeypatch.setattr(refseq.GenomeIndex, "__init__", orig)
+        t = run.targets[r.name.upper()]
+        assert t.genome_searched and len(made) == 1 and (made[0]._dev_no is not None) == on_device
+        assert made[0]._dev_loci == on_device and (made[0].probe_ms > 0) == on_device          # the loci came from bk_index_find / from numpy
+        return rows, [(w[0], w[1], w[2], w[3]) for w in t.partner_windows], t
+    rows_d, wins_d, t = run_once(tmp_path / "dev", True)
+    rows_h, wins_h, _t = run_once(tmp_path / "host", False)
+    assert wins_d == wins_h and len(wins_d) == 1 and rows_d == rows_h
+    pc, ps, pe, pn = wins_d[0]
+    assert pc == "2" and pn == "PARTNERX" and ps < 5000 + 600 < pe
+
+
 @pytest.mark.gpu
 def test_async_submit_gpu(hb):
     """BK_SUBMIT_ASYNC (the driver's overlap of packing + H2D with the previous batch): same results as the blocking submit;

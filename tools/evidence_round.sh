@@ -1,14 +1,24 @@
 #!/bin/bash
-# parity evidence of a round on the GPU box (randomised sweep vs the oracle + run-to-run identity of a large batch):
-#   bash tools/evidence_round.sh r04
-# The last two steps exercise the EXPERIMENTAL component split (flags 1280 = on + whatever the size); that path can fault the device
-# (DESIGN 4.5), so they come last and each runs in its own process.
-tag=${1:-r04}; out=gpurun_out/evidence_$tag; mkdir -p $out
-BK_FUZZ_WG=256 timeout 1500 python3 tools/fuzz_parity.py ${FUZZ_N:-400} 411 > $out/fuzz_parity_wg256.log 2>&1
-BK_FUZZ_WG=512 timeout 1500 python3 tools/fuzz_parity.py ${FUZZ_N:-400} 412 > $out/fuzz_parity_wg512.log 2>&1
-timeout 900 python3 tools/stress_batch.py 0 1500 4 > $out/stress_batch.log 2>&1
-timeout 600 python3 tools/probes/split_probe.py soak 64 40 256 0 > $out/soak_default_wg256.log 2>&1
-timeout 600 python3 tools/probes/split_probe.py soak 64 40 512 0 > $out/soak_default_wg512.log 2>&1
-BK_FUZZ_FLAGS=1280 timeout 1500 python3 tools/fuzz_parity.py ${FUZZ_N:-400} 413 > $out/fuzz_parity_split_forced.log 2>&1
-timeout 900 python3 tools/stress_batch.py 1280 600 3 > $out/stress_batch_split_forced.log 2>&1
+# Parity evidence of a round on the GPU box: the randomised sweep against the oracle (tools/fuzz_parity.py) through the barrier-check +
+# jitter build of the library (five seeds: which wavefronts sleep behind which barrier; both workgroup sizes; split as shipped,
+# forced on small graphs, switched off) and through the product build, then run-to-run identity of large batches (stress_batch.py).
+#   bash tools/evidence_round.sh r05
+# The sweeps spend their time in the CPU oracle, so they run side by side (one process each; the GPU is shared).
+tag=${1:-r05}; out=gpurun_out/evidence_$tag; mkdir -p $out
+N=${FUZZ_N:-240}
+run() { # name variant jitter_seed wg flags n fuzz_seed
+  BK_VARIANT=$2 BK_JITTER_SEED=$3 BK_FUZZ_WG=$4 BK_FUZZ_FLAGS=$5 timeout 1700 python3 tools/fuzz_parity.py $6 $7 > $out/fuzz_$1.log 2>&1 &
+}
+run checkjit_seed1_wg256_default   checkjit 1 256 0   $N 511
+run checkjit_seed2_wg512_default   checkjit 2 512 0   $N 512
+run checkjit_seed3_wg256_splitall  checkjit 3 256 256 $N 513
+run checkjit_seed4_wg512_splitall  checkjit 4 512 256 $N 514
+run checkjit_seed5_auto_nosplit    checkjit 5 0   128 $N 515
+run product_wg256_default          ""       0 256 0   300 516
+run product_auto_splitall          ""       0 0   256 300 517
+wait
+timeout 900 python3 tools/stress_batch.py 0 1500 4 > $out/stress_batch.log 2>&1 &
+timeout 900 python3 tools/stress_batch.py 256 600 3 > $out/stress_batch_split_forced.log 2>&1 &
+BK_VARIANT=checkjit BK_JITTER_SEED=7 timeout 900 python3 tools/stress_batch.py 0 1500 3 > $out/stress_batch_checkjit.log 2>&1 &
+wait
 tail -n 2 $out/*.log

@@ -3,7 +3,7 @@ build tools/probes/libbk_stamps_probe.  argv: [noise [depth [L [k]]]]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from breakmer_amd import hip_backend as hb, synth
-hb.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libbk_stamps_probe")
+from breakmer_amd import build as _bk_build; hb.load_library(_bk_build.lib_path("stamps"))      # the diagnostic build with phase stamps (python breakmer_amd/build.py stamps)
 noise = float(sys.argv[1]) if len(sys.argv) > 1 else 0.05
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 250

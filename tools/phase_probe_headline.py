@@ -3,7 +3,7 @@ tools/probes/libbk_stamps_probe (see tools/README.md).  BK_WG=256|512 selects th
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from breakmer_amd import hip_backend as hb, synth
-hb.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libbk_stamps_probe")
+from breakmer_amd import build as _bk_build; hb.load_library(_bk_build.lib_path("stamps"))      # the diagnostic build with phase stamps (python breakmer_amd/build.py stamps)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 regions = [synth.make_region(i, depth=500, L=150, sv_type="del") for i in range(n)]           # bench.py's default batch
 eng = hb.Engine(kmer_size=31, wg_threads=int(os.environ.get("BK_WG", "0")))

@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from breakmer_amd import hip_backend as hb, synth
-hb.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libbk_stamps_probe")
+from breakmer_amd import build as _bk_build; hb.load_library(_bk_build.lib_path("stamps"))      # the diagnostic build with phase stamps (python breakmer_amd/build.py stamps)
 regions = [bench.cfg4_region(synth, 0)]
 eng = hb.Engine(kmer_size=41)
 eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])

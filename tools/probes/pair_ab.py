@@ -3,7 +3,7 @@ import sys, os, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from breakmer_amd import hip_backend as hb
 if os.environ.get("BK_LIB"):
-    hb.LIB_PATH = os.environ["BK_LIB"]
+    hb.load_library(os.environ["BK_LIB"])
 rnd = random.Random(1)
 eng = hb.Engine(kmer_size=31)
 base = "".join(rnd.choice("ACGT") for _ in range(600))
