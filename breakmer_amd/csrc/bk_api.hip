@@ -705,7 +705,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         const bool may_split = !subset && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
         if (!subset) {
             BkAsmShape sh; { const int rc = asm_shape(h, asm_threads, max_cand, max_contig, (long long)n_launch * (may_split ? BK_SPLIT_G : 1), sh); if (rc != BK_OK) return rc; }
-            hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad, (uint32_t)sh.grid);
+            hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad, (uint32_t)sh.grid, (uint32_t)(sh.per_cu * h->n_cu));
             HIPCHK(h, hipGetLastError());
             if (dbg) { HIPCHK(h, hipStreamSynchronize(h->stream)); fprintf(stderr, "[bk launch] sched done\n"); }
         }
@@ -733,7 +733,7 @@ static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t
     HIPCHK(h, h->d_rmap.ensure(redo.size() * 4));
     HIPCHK(h, hipMemcpy(h->d_rmap.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));             // (the stream is idle: bk_sync has just waited for it)
     std::vector<uint32_t> q; q.reserve((size_t)n * BK_SPLIT_G);
-    for (uint32_t r : redo) for (uint32_t g = 0; g < BK_SPLIT_G; g++) q.push_back(r | (g << BK_QUEUE_UNIT_SHIFT));
+    for (uint32_t r : redo) for (uint32_t g = 0; g < h->h_work[r].split; g++) q.push_back(r | (g << BK_QUEUE_UNIT_SHIFT));
     HIPCHK(h, hipMemcpy(h->d_order.p, q.data(), q.size() * 4, hipMemcpyHostToDevice));
     unsigned long long tops[11];
     HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));

@@ -1704,7 +1704,7 @@ BK_COLD void bk_label_live()
     const bool deal = 10ull * (unsigned long long)big <= 7ull * total || (C_.flags & BK_F_SPLIT_ALWAYS);
     for (uint32_t u = BK_TID; u < U; u += BK_AT) {
         uint32_t ci = BK_CI_NOUNIT;
-        if (bk_ld_agent(&rroot[u]) == u && bk_ld_agent(&csz[u])) ci = (deal ? (uint32_t)(mix64(0x9E3779B97F4A7C15ull ^ u) % BK_SPLIT_G) : 0u) | BK_CI_ACTIVE;
+        if (bk_ld_agent(&rroot[u]) == u && bk_ld_agent(&csz[u])) ci = (deal ? (uint32_t)(mix64(0x9E3779B97F4A7C15ull ^ u) % (uint32_t)C_.split) : 0u) | BK_CI_ACTIVE;
         cinfo[u] = ci;
     }
     __threadfence(); BK_SYNC();
@@ -1742,11 +1742,12 @@ BK_COLD void bk_label_live()
                 //  lives in scratch memory, and that made this out-of-line function fault at random, 3 runs in 20 of a 32-region
                 //  batch -- the second lesson of this kind after the out-of-line return values of round 2)
                 uint32_t *load = L_CANDU;
-                for (int g = 0; g < BK_SPLIT_G; g++) load[g] = 0;
+                const int G_ = (int)C_.split;                                                      // units of this region (bk_sched_kernel: 2 .. BK_SPLIT_G)
+                for (int g = 0; g < G_; g++) load[g] = 0;
                 for (int i = 0; i < n; i++) {
                     const uint32_t root = (uint32_t)L[i], c = 0xFFFFFFFFu - (uint32_t)(L[i] >> 32);
                     int best = 0;
-                    for (int g = 1; g < BK_SPLIT_G; g++) if (load[g] < load[best]) best = g;
+                    for (int g = 1; g < G_; g++) if (load[g] < load[best]) best = g;
                     load[best] += c + 4u;                                                             // (+ what an iteration costs whatever its size)
                     cinfo[root] = (uint32_t)best | BK_CI_ACTIVE;
                 }

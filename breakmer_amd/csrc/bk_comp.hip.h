@@ -84,7 +84,7 @@ __device__ inline void bk_split_prepare(const BkParams &p, BkRegionWork *wk, uin
     if (a0 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
     if (tid == 0) {
         wk->o_rroot = a0; wk->o_cinfo = a0 + b_r; wk->o_kroot = a0 + 2 * b_r; wk->o_cidx = a0 + 2 * b_r + b_k; wk->o_pairs = a0 + 2 * b_r + b_k + b_x;
-        wk->cidx_cap = cidx_cap; wk->pairs_cap = pairs_cap; wk->split = BK_SPLIT_G;
+        wk->cidx_cap = cidx_cap; wk->pairs_cap = pairs_cap; wk->split = BK_SPLIT_G;      // "may be split": bk_sched_kernel sets the number of units (2 .. BK_SPLIT_G) or 0 (the batch fills the chip as it is)
     }
 }
 // the snapshot of the read flags at the moment the graph was labelled (behind the pairs and the inbox): what a component is reset to
@@ -131,7 +131,7 @@ __device__ inline void bk_resolve_region(const BkParams &p, const uint32_t r, co
     for (uint32_t u = tid; u < U; u += nt) {
         if (bk_ld_agent(&rroot[u]) != u) { cinfo[u] = BK_CI_NOUNIT; continue; }            // no longer a root: its word means nothing (and must not look given up next time)
         const uint32_t ci = bk_ld_agent(&cinfo[u]);
-        if (ci & BK_CI_REDO) cinfo[u] = (uint32_t)(mix64(0xD1B54A32D192ED03ull * (pass + 1) ^ u) % BK_SPLIT_G) | (pass << 8) | BK_CI_ACTIVE;
+        if (ci & BK_CI_REDO) cinfo[u] = (uint32_t)(mix64(0xD1B54A32D192ED03ull * (pass + 1) ^ u) % wk->split) | (pass << 8) | BK_CI_ACTIVE;
     }
     __threadfence(); BK_SYNC();
     if (tid < BK_SPLIT_G) { wk->unit_us[tid] = 0; wk->unit_iters[tid] = 0; }

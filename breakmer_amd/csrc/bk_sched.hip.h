@@ -15,7 +15,7 @@
 #define BK_SCHED_T 1024
 
 // one workgroup: order[] = region ids by (cost descending, id ascending) -- deterministic
-extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParams p, unsigned long long *keys /* npad words of scratch */, uint32_t npad, uint32_t asm_grid /* workgroups of the assembler launch that follows */)
+extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParams p, unsigned long long *keys /* npad words of scratch */, uint32_t npad, uint32_t asm_grid /* workgroups of the assembler launch that follows */, uint32_t resident /* assembler workgroups the chip holds at once */)
 {
     const int tid = threadIdx.x, n = p.n_regions;
     __shared__ uint32_t nsplit_s;
@@ -47,14 +47,26 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
     // runs the serial prefix the other units wait for, so all prefixes of a batch start at once however few workgroups are
     // resident -- with the units of a region behind each other, 64 split regions on 512 resident workgroups ran their prefixes in
     // two waves), then the other units of the split regions, region by region in the same order.
+    // How many units a split region gets: BK_SPLIT_G, whatever the batch.  Measured in round 5 (profiles/r05/noisy_units_per_region.txt,
+    // regions of the configs[1] shape at 0.5 % noise, 512 resident workgroups): giving a region only as many units as the batch leaves
+    // workgroup slots empty (8 / 4 / 2 units for 64 / 128 / 256 noisy regions) was SLOWER than 16 units each with the queue
+    // oversubscribed (108 vs 90 ms, 163 vs 134 ms, 420 vs 324 ms per launch; one unit per region: 438 ms for 256): what bounds a
+    // noisy batch is the critical path of its slowest regions and the balance of the dealing, not the workgroup time summed up.
+    // (`resident` is what the measurement used; the units of a region are a per-region number all the same: wk->split.)
     __shared__ uint32_t wsum[BK_SCHED_T / 64], base_s;
-    for (int i = tid; i < n; i += BK_SCHED_T) p.order[i] = (uint32_t)keys[i];
+    for (int i = tid; i < n; i += BK_SCHED_T) { p.order[i] = (uint32_t)keys[i]; if (p.work[i].split) atomicAdd(&nsplit_s, 1u); }
     if (tid == 0) base_s = (uint32_t)n;
+    BK_SYNC();
+    const uint32_t nwant = nsplit_s;
+    const uint32_t G = nwant ? (uint32_t)BK_SPLIT_G : 0u; (void)resident;
+    for (int i = tid; i < n; i += BK_SCHED_T) if (p.work[i].split) p.work[i].split = G;
+    __threadfence(); BK_SYNC();
+    if (tid == 0) nsplit_s = G ? nwant : 0u;
     BK_SYNC();
     for (int c0 = 0; c0 < n; c0 += BK_SCHED_T) {
         const int i = c0 + tid;
         uint32_t rid = 0, g = 0;                                             // g: units beyond the first
-        if (i < n) { rid = (uint32_t)keys[i]; const uint32_t sp = p.work[rid].split; g = sp ? sp - 1u : 0u; if (sp) atomicAdd(&nsplit_s, 1u); }
+        if (i < n) { rid = (uint32_t)keys[i]; const uint32_t sp = p.work[rid].split; g = sp ? sp - 1u : 0u; }
         uint32_t inc = g;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((tid & 63) >= o) inc += t; }
         if ((tid & 63) == 63) wsum[tid >> 6] = inc;
