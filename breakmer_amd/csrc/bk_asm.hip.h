@@ -57,6 +57,9 @@ struct BkAsmShared {
     // look-ahead slots (see bk_run_candidates): read q+s aligned against the PREDICTED contig after reads q..q+s-1
     struct Slot { int u, rl, rn, rindel, pos, pb, plen, kind, amt, hasn, vt, rank, fu, first, dec, ds, de; BkNwResult v1, v2; } slot[BK_SPEC];
     int nb, pc, last_dec, dual;
+    // the score sweep (bk_nw.hip.h: bk_nw_score_c) runs first while few of its reads need the full sweep after all: reads swept /
+    // reads that had to be swept again, in a window that is halved at 64; fast = the plan of the current round uses it
+    int dp_n, dp_redo, fast;
     // look-ahead across k-mer visits of grow (bk_run_candidates): slots [plan_r, nb) hold reads of LATER visits, already aligned
     // against the predicted contig; plan_upto = last visit (index into the snapshot) whose candidate list the plan knows
     int ncur, plan_r, plan_upto, plan_ok, hit;
@@ -739,10 +742,31 @@ __device__ __noinline__ void bk_dp_round()
             A.contig = BK_O_CSEQ + S->slot[a].pb; A.clen = S->slot[a].plen; A.read = BK_O_RSEQ + a * (C_.MAXR + 16); A.n = S->slot[a].rl; A.res = (int)((uint8_t *)&S->slot[a].v1 - bk_lds);
             if (b < nb) { B.contig = BK_O_CSEQ + S->slot[b].pb; B.clen = S->slot[b].plen; B.read = BK_O_RSEQ + b * (C_.MAXR + 16); B.n = S->slot[b].rl; B.res = (int)((uint8_t *)&S->slot[b].v1 - bk_lds); }
             else { B.contig = 0; B.clen = 0; B.read = 0; B.n = 0; B.res = 0; }
-            bk_nw_pair(A, B);
+            if (S->fast) {
+                // the score sweep first: end cells and scores of both calls; the border cells follow without a traceback for overlaps
+                // without a mismatch or an indel (bk_nw.hip.h).  A read it cannot settle is swept again in full -- with its partner
+                const int nrd = b < nb ? 2 : 1;
+                bk_nw_score_pair(A, B);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                bool redo = S->slot[a].v1.j_start == BK_NW_NEEDS_DP || S->slot[a].v2.j_start == BK_NW_NEEDS_DP;
+                if (b < nb) redo = redo || S->slot[b].v1.j_start == BK_NW_NEEDS_DP || S->slot[b].v2.j_start == BK_NW_NEEDS_DP;
+                redo = __builtin_amdgcn_readfirstlane((int)redo) != 0;
+                if ((BK_TID & 63) == 0) { atomicAdd(&S->dp_n, nrd); if (redo) atomicAdd(&S->dp_redo, nrd); }
+                if (redo) bk_nw_pair(A, B);
+            } else bk_nw_pair(A, B);
         }
     } else if (S->dual) {                                // both DPs of slot wv on this wavefront
-        if (wv < nb) bk_nw_dual(BK_O_CSEQ + S->slot[wv].pb, S->slot[wv].plen, BK_O_RSEQ + wv * (C_.MAXR + 16), S->slot[wv].rl, (int)((uint8_t *)&S->slot[wv].v1 - bk_lds));
+        if (wv < nb) {
+            const int contig = BK_O_CSEQ + S->slot[wv].pb, clen = S->slot[wv].plen, rd = BK_O_RSEQ + wv * (C_.MAXR + 16), rl = S->slot[wv].rl, res = (int)((uint8_t *)&S->slot[wv].v1 - bk_lds);
+            if (S->fast) {
+                BkPairArgs A; A.contig = contig; A.clen = clen; A.read = rd; A.n = rl; A.res = res;
+                bk_nw_score_one(A);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const bool redo = __builtin_amdgcn_readfirstlane((int)(S->slot[wv].v1.j_start == BK_NW_NEEDS_DP || S->slot[wv].v2.j_start == BK_NW_NEEDS_DP)) != 0;
+                if ((BK_TID & 63) == 0) { atomicAdd(&S->dp_n, 1); if (redo) atomicAdd(&S->dp_redo, 1); }
+                if (redo) bk_nw_dual(contig, clen, rd, rl, res);
+            } else bk_nw_dual(contig, clen, rd, rl, res);
+        }
     } else {                                             // two wavefronts per slot, both with the contig on the tile columns
         const int sl = wv >> 1;
         if (sl < nb) {
@@ -1158,6 +1182,8 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
     // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
     S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
+    if (S->dp_n >= 64) { S->dp_n >>= 1; S->dp_redo >>= 1; }
+    S->fast = !(C_.flags & BK_F_NO_SCORE_SWEEP) && 4 * S->dp_redo <= S->dp_n + 8;      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays)
     int nc = ncur;
     if (!S->dual && nb > BK_SPEC_WIDE) { nc = min(nc, BK_SPEC_WIDE); nb = nc; upto = vt; }      // two wavefronts per slot: this visit's reads only
     S->nb = nb; S->ncur = nc;
@@ -1823,7 +1849,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
         c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
-        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32; S->n_rej = 0; S->n_acc = 0;
+        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32; S->n_rej = 0; S->n_acc = 0; S->dp_n = 0; S->dp_redo = 0; S->fast = 0;
 #ifdef BK_PHASE_STAMPS
         for (int i = 0; i < 24; i++) S->acc[i] = 0; S->ctx = 0;
         S->last = __builtin_amdgcn_s_memrealtime();
@@ -2065,6 +2091,25 @@ extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_
         A.contig = 0; A.clen = m; A.read = mp; A.n = n; A.res = (int)((uint8_t *)res - l);
         B.contig = mp + np_; B.clen = m2; B.read = mp + np_ + mp2; B.n = n2; B.res = (int)((uint8_t *)(res + 8) - l);
         BK_SYNC();
+        if (transposed >= 9) {
+            // the score sweep (bk_nw_score_c).  9..12: two reads per wavefront, every origin wanted, flagged reads swept again by
+            // bk_nw_pair -- A's nw(seq1, seq2) / nw(seq2, seq1), B's two; 13 / 14: one read per wavefront + bk_nw_dual;
+            // 15: the score sweep ALONE as the assembler calls it (origins only where check_align can look at them): A's
+            // (v1.j_start or -1 = needs the full sweep, v1.score, v2.j_start or -1, v2.score); 16 / 17: timing of the sweep alone
+            if (m > BK_NW_DUAL_COLS || m2 > BK_NW_DUAL_COLS) { if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[4 * b + q] = -1; return; }
+            const bool one = transposed == 13 || transposed == 14 || transposed == 17, timing = transposed >= 16;
+            for (int i = 0; i < reps; i++) { if (one) bk_nw_score_one(A, timing || transposed == 15 ? 0 : 1); else bk_nw_score_pair(A, B, timing || transposed == 15 ? 0 : 1); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (transposed == 15 || timing) { if (threadIdx.x == 0) { out[4 * b] = res[0]; out[4 * b + 1] = res[3]; out[4 * b + 2] = res[4]; out[4 * b + 3] = res[7]; } return; }
+            const bool fa = res[0] == BK_NW_NEEDS_DP || res[4] == BK_NW_NEEDS_DP, fb = !one && (res[8] == BK_NW_NEEDS_DP || res[12] == BK_NW_NEEDS_DP);
+            if (__builtin_amdgcn_readfirstlane((int)(fa || fb))) {
+                if (one) bk_nw_dual(A.contig, m, A.read, n, A.res); else bk_nw_pair(A, B);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            }
+            const int sel = transposed <= 12 ? (transposed - 9) * 4 : (transposed - 13) * 4;
+            if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[4 * b + q] = res[sel + q];
+            return;
+        }
         if (m <= BK_NW_DUAL_COLS && m2 <= BK_NW_DUAL_COLS) {
             for (int i = 0; i < reps; i++) bk_nw_pair(A, B);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();

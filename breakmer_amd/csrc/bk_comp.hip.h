@@ -70,7 +70,7 @@ __device__ inline void bk_split_prepare(const BkParams &p, BkRegionWork *wk, uin
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) { wk->split = 0; wk->pass = 0; wk->phase = 0; wk->serial_base = 0; wk->stamp_base = 0; wk->units_done = 0; wk->n_cidx = 0; wk->n_pairs = 0; wk->n_conf = 0; }
     if (tid < BK_SPLIT_G) { wk->unit_us[tid] = 0; wk->unit_iters[tid] = 0; }
-    if (tid < 20) wk->stamps[tid] = 0;
+    if (tid >= 12 && tid < 20) wk->stamps[tid] = 0;      // (check / guard-band words of the diagnostic builds; [0..11] hold the k-mer kernel's phase stamps in a stamps build)
     if ((p.flags & BK_F_NO_SPLIT) || p.rmap || U < 4 || (M2 < BK_SPLIT_MIN_SEEDS && !(p.flags & BK_F_SPLIT_ALWAYS)) || M2 < 2) return;      // uniform
     // the serial prefix must be short: the seeds are ordered by count, so the first rank below BK_SPLIT_HI says how many it has (a
     // deep noisy region -- 2,000x at 5 %: most error k-mers are seen eight times -- would run serially anyway while fifteen

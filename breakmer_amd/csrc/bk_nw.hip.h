@@ -514,6 +514,120 @@ __device__ inline void bk_nw_pair_call(int c, const BkPairArgs &A, const BkPairA
 // both contigs <= BK_NW_DUAL_COLS; registers per lane = ceil(longer contig / 32)
 __device__ inline void bk_nw_pair(const BkPairArgs &A, const BkPairArgs &B) { bk_nw_pair_call<3>((max(A.clen, B.n ? B.clen : 0) + 31) / 32, A, B); }
 
+// ---- round 5: the SCORE sweep -- one plain score matrix per read, no pointers, no origins ---------------------------------------
+// What check_align consumes of an overlap DP is (j_start, i_end, i_start, score): the END CELL of the traceback (largest row among the
+// maxima of the last column, olc.py:79-83) and the border cell the traceback reaches.  The end cells of BOTH calls -- nw(contig, read):
+// last column; nw(read, contig): last row of the same matrix, largest column among the maxima -- need the scores only: 6 instructions
+// per cell (compare, select, three adds, one max3) instead of the 12 of bk_nw_pair_c.  The border cell then follows WITHOUT a
+// traceback in the case clean data consists of:
+//   Let the end cell be (i, m) with score s, d = min(i, m) the most diagonal steps any path into it can have.  A path with a matches,
+//   x mismatches and g gaps scores a - 2x - 2g <= d - 2g.  s == d  =>  a = d, x = g = 0: the ONLY path that reaches the score is the
+//   pure diagonal of d matches from the border -- and along it the diagonal candidate wins every cell strictly (a gap candidate would
+//   need a neighbour scoring 2 more than the cell, which exceeds that neighbour's own bound min(i, j)), so the reference's pointer
+//   walk follows it whatever the tie-break order: origin = (0, m - i) if i <= m, else (i - m, 0).
+// Otherwise the origin is only needed when the score can pass check_align's first test (4 * score >= min(len(contig), len(read)),
+// sv_assembly.py:459-461): else the decision never looks at it (bk_decide: ok_k false; a call whose partner wins is only read for
+// its score).  What is left -- an overlap with a mismatch or an indel in it -- is FLAGGED (j_start = -1) and the caller runs the full
+// sweep (bk_nw_pair_c / bk_nw_dual_c) for that read: bit-identical by construction, since every value reported here IS the
+// reference's.  LPR = lanes per read: 64 (one read per wavefront, the latency build) or 32 (two reads per wavefront).
+#define BK_NW_NEEDS_DP (-1)
+template <int C, int LPR>
+__device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int force_)
+{
+    const int lane = threadIdx.x & 63, hl = lane & (LPR - 1), half = LPR == 32 ? lane >> 5 : 0;
+    const int a0 = __builtin_amdgcn_readfirstlane(A_.contig), a1 = __builtin_amdgcn_readfirstlane(A_.clen), a2 = __builtin_amdgcn_readfirstlane(A_.read), a3 = __builtin_amdgcn_readfirstlane(A_.n), a4 = __builtin_amdgcn_readfirstlane(A_.res);
+    const int b0_ = __builtin_amdgcn_readfirstlane(B_.contig), b1 = __builtin_amdgcn_readfirstlane(B_.clen), b2 = __builtin_amdgcn_readfirstlane(B_.read), b3 = __builtin_amdgcn_readfirstlane(B_.n), b4 = __builtin_amdgcn_readfirstlane(B_.res);
+    const int force = __builtin_amdgcn_readfirstlane(force_);          // (tests: every origin is wanted, whatever the score)
+    const uint8_t *cols = bk_dyn_lds + (half ? b0_ : a0), *rows = bk_dyn_lds + (half ? b2 : a2);
+    const int mt = half ? b1 : a1, n = half ? b3 : a3;
+    int *res = (int *)(bk_dyn_lds + (half ? b4 : a4));
+    const int nmax = LPR == 32 ? max(a3, b3) : a3;
+    const int nl = (mt + C - 1) / C, lm = nl - 1, pad = nl * C - mt;
+    const int lm_max = (LPR == 32 ? max((a1 + C - 1) / C, (b1 + C - 1) / C) : (a1 + C - 1) / C) - 1;
+    int H[C], cb[C], gh[C];
+#pragma unroll
+    for (int x = 0; x < C; x++) {
+        const int jj = hl * C + x - pad;                                            // 0-based column, < 0: padding (right-aligned columns: the last one is register C-1 of lane lm)
+        const bool real = jj >= 0 && jj < mt && hl <= lm;
+        H[x] = 0;                                                                   // row 0: score 0
+        cb[x] = real ? (int)cols[jj] : 8;                                           // 8 matches nothing
+        gh[x] = jj >= 0 ? -2 : 0;                                                   // the border column's score (0) travels through the padding unchanged
+    }
+    int dprev = 0, rb = 0, im1 = -hl;
+    int best = 0, best_im1 = -1;                                                    // the border cell (0, m): score 0 (olc.py:79-83)
+    const bool inl = hl <= lm && n > 0;
+    const int steps = nmax + lm_max;
+    for (int t0 = 0; t0 < steps; t0 += LPR) {
+        const int rblk = (t0 + hl < n) ? (int)rows[t0 + hl] : 0;
+        const int te = min(LPR, steps - t0);
+        for (int tl = 0; tl < te; tl++) {
+            const int recv = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);
+            rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
+            if constexpr (LPR == 32) { const int ra = __builtin_amdgcn_readlane(rblk, tl), rbb = __builtin_amdgcn_readlane(rblk, 32 + tl); if (hl == 0) rb = half ? rbb : ra; }
+            else { const int ra = __builtin_amdgcn_readlane(rblk, tl); if (hl == 0) rb = ra; }
+            if (inl && (unsigned)im1 < (unsigned)n) {
+                const int left = hl == 0 ? 0 : recv;                                // border column (i, 0): score 0
+                int u_in = left, hprev = dprev;
+#pragma unroll
+                for (int x = 0; x < C; x++) {
+                    const int hold = H[x];
+                    const int nv = max(max(hprev + (cb[x] == rb ? 1 : -2), u_in + gh[x]), hold - 2);
+                    H[x] = nv; u_in = nv; hprev = hold;
+                }
+                dprev = left;
+                const int v = H[C - 1];                                            // lane lm: the last column (olc.py:81 '>=': last row wins)
+                const bool take = v >= best;
+                best = take ? v : best; best_im1 = take ? im1 : best_im1;
+            }
+            im1++;
+        }
+    }
+    const int s1 = __shfl(best, (half * LPR) + lm), i1 = __shfl(best_im1, (half * LPR) + lm) + 1;
+    // nw(read, contig): the last row, columns ascending ('>=' keeps the largest index), reduced over the read's lanes
+    int s2 = 0, i2 = 0;
+#pragma unroll
+    for (int x = 0; x < C; x++) {
+        const int jj = hl * C + x - pad;
+        if (jj >= 0 && jj < mt && inl && H[x] >= s2) { s2 = H[x]; i2 = jj + 1; }
+    }
+    for (int o = 1; o < LPR; o <<= 1) {
+        const int os = __shfl_xor(s2, o), oi = __shfl_xor(i2, o);
+        if (os > s2 || (os == s2 && oi > i2)) { s2 = os; i2 = oi; }
+    }
+    if (hl == 0 && n > 0) {
+        const int minlen = min(mt, n);
+        // v1 = nw(contig, read): m_ref = mt, end cell (i1, mt); v2 = nw(read, contig): m_ref = n, end cell (contig position i2, read column n)
+        int j1 = 0, r1 = 0, j2 = 0, r2 = 0; bool k1 = false, k2 = false;             // border cells (j_start, i_start); known without a traceback?
+        if (i1 == 0) { j1 = mt - 1; k1 = true; }                                     // Q5: one forced traceback step from (0, m), score 0
+        else if (s1 == min(i1, mt)) { j1 = i1 <= mt ? mt - i1 : 0; r1 = i1 <= mt ? 0 : i1 - mt; k1 = true; }
+        if (i2 == 0) { j2 = n - 1; k2 = true; }
+        else if (s2 == min(i2, n)) { j2 = i2 <= n ? n - i2 : 0; r2 = i2 <= n ? 0 : i2 - n; k2 = true; }
+        // Which border cells does check_align look at (bk_decide, sv_assembly.py:459-503)?  ok_k = 4 s_k >= minlen and 200 s_k >= 179 *
+        // overlap_k (needs j_start_k); both false: no match, nothing else is read.  Else the call with the larger score decides, alone;
+        // equal scores: both are read.  So: nothing if neither passes the first test; the winner's always; the loser's only while the
+        // winner's own ok is not known to be true (it then decides between "no match" and the winner's move).
+        const bool p1 = i1 > 0 && 4 * s1 >= minlen, p2 = i2 > 0 && 4 * s2 >= minlen;
+        bool n1 = false, n2 = false;
+        if (force) { n1 = true; n2 = true; }
+        else if (p1 || p2) {
+            if (s1 == s2) { n1 = true; n2 = true; }
+            else if (s1 > s2) { n1 = true; n2 = p2 && !(k1 && p1 && 200 * s1 >= 179 * (mt - j1)); }
+            else { n2 = true; n1 = p1 && !(k2 && p2 && 200 * s2 >= 179 * (n - j2)); }
+        }
+        res[0] = (n1 && !k1) ? BK_NW_NEEDS_DP : j1; res[1] = i1; res[2] = r1; res[3] = i1 == 0 ? 0 : s1;
+        res[4] = (n2 && !k2) ? BK_NW_NEEDS_DP : j2; res[5] = i2; res[6] = r2; res[7] = i2 == 0 ? 0 : s2;
+    }
+}
+template <int C, int LPR>
+__device__ inline void bk_nw_score_call(int c, const BkPairArgs &A, const BkPairArgs &B, int force)
+{
+    if (c <= C) { bk_nw_score_c<C, LPR>(A, B, force); return; }
+    if constexpr (C < BK_NW_DUAL_C) bk_nw_score_call<C + 1, LPR>(c, A, B, force);
+}
+// two reads per wavefront (both contigs <= BK_NW_DUAL_COLS) / one read per wavefront (contig <= BK_NW_DUAL_COLS: C <= 5)
+__device__ inline void bk_nw_score_pair(const BkPairArgs &A, const BkPairArgs &B, int force = 0) { bk_nw_score_call<3, 32>((max(A.clen, B.n ? B.clen : 0) + 31) / 32, A, B, force); }
+__device__ inline void bk_nw_score_one(const BkPairArgs &A, int force = 0) { BkPairArgs B; B.contig = 0; B.clen = 0; B.read = 0; B.n = 0; B.res = 0; bk_nw_score_call<2, 64>((A.clen + 63) / 64, A, B, force); }
+
 // Tried in round 3 and not kept, second attempt (profiles/r03/pair_two_word_ab.txt): bk_nw_pair_c with the second order carried as a
 // second WORD [score | priority | origin] through its own v_max3 (12 instructions per cell, no compares against the score, no
 // register copies, no hazard nops) instead of the origin register with its two compares and selects (14 + nops).  Bit-exact,

@@ -258,7 +258,11 @@ int bk_pack_sequence(const char *seq, int32_t len, uint32_t flags, uint32_t *wor
  * (j_start, i_end, i_start, score); transposed = 1 uses the sweep the assembler uses for nw(read, contig), 2 the
  * suffix-restricted direct sweep it uses for nw(contig, read); 3 / 4: both DPs on one wavefront (bk_nw_dual), result of nw(seq1, seq2) /
  * nw(seq2, seq1); 5..8: one score matrix with both tie-break orders, two pairs per wavefront (bk_nw_pair): pair i in one half (5: nw(seq1,
- * seq2), 6: nw(seq2, seq1)), pair i+1 in the other (7, 8: ITS two results are returned in out[i]).  Same results by construction; the tests compare them all */
+ * seq2), 6: nw(seq2, seq1)), pair i+1 in the other (7, 8: ITS two results are returned in out[i]).  9..14: the score sweep of ABI 4
+ * (bk_nw_score_c: one plain score matrix per read, the border cell without a traceback where the end cell's score equals its
+ * diagonal, the full sweep for the rest) -- 9..12 like 5..8 with two reads per wavefront, 13 / 14 like 3 / 4 with one; 15: the
+ * score sweep alone as the assembler calls it: out = (v1.j_start or -1 = needs the full sweep, v1.score, v2.j_start or -1, v2.score);
+ * 16 / 17: the score sweep alone (two reads / one read per wavefront) for timing.  Same results by construction; the tests compare them all */
 int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, const uint32_t *off1, const uint32_t *len1,
                 const uint32_t *off2, const uint32_t *len2, int32_t n_pairs, int32_t reps, int32_t transposed, int32_t *out, float *ms);
 

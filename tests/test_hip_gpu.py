@@ -58,6 +58,10 @@ def test_g1_nw_kats_gpu(hb, golden_dir):
     rot = lambda x: x[1:] + x[:1]
     assert eng.nw_batch(small, transposed=5)[0].tolist() == o3 and eng.nw_batch(small, transposed=6)[0].tolist() == o4
     assert eng.nw_batch(small, transposed=7)[0].tolist() == rot(o3) and eng.nw_batch(small, transposed=8)[0].tolist() == rot(o4)
+    # the score sweep (+ the full sweep for what it flags): two reads per wavefront, one read per wavefront
+    assert eng.nw_batch(small, transposed=9)[0].tolist() == o3 and eng.nw_batch(small, transposed=10)[0].tolist() == o4
+    assert eng.nw_batch(small, transposed=11)[0].tolist() == rot(o3) and eng.nw_batch(small, transposed=12)[0].tolist() == rot(o4)
+    assert eng.nw_batch(small, transposed=13)[0].tolist() == o3 and eng.nw_batch(small, transposed=14)[0].tolist() == o4
     for c, o in zip(d["cases"], out.tolist()):
         exp = c["out"]
         assert o == [exp[3], exp[4], exp[5], exp[6]], c["tag"]
@@ -136,13 +140,59 @@ def test_nw_random_vs_oracle_gpu(hb):
             ov = min(m, n, rnd2.randint(1, 150))
             dual.append((a, (a[:ov][::-1][::-1] if (m + n) % 3 == 0 else a[m - ov:]) + "".join(rnd2.choice("ACGT") for _ in range(n - ov))))
     want = [(bo.nw(a, b), bo.nw(b, a)) for a, b in dual]
-    for mode1, mode2, shift, tag in ((3, 4, 0, "dual"), (5, 6, 0, "pair, half A"), (7, 8, 1, "pair, half B")):
+    # 9..14: the score sweep of round 5 (one plain score matrix per read; the border cell without a traceback where the end
+    # cell's score equals its diagonal; everything else swept again in full): two reads per wavefront (9..12), one (13, 14)
+    for mode1, mode2, shift, tag in ((3, 4, 0, "dual"), (5, 6, 0, "pair, half A"), (7, 8, 1, "pair, half B"),
+                                     (9, 10, 0, "score sweep, two reads per wavefront, half A"), (11, 12, 1, "score sweep, half B"), (13, 14, 0, "score sweep, one read per wavefront")):
         d1, _ = eng.nw_batch(dual, transposed=mode1)
         d2, _ = eng.nw_batch(dual, transposed=mode2)
         for q, (x1, x2) in enumerate(zip(d1.tolist(), d2.tolist())):
             (a, b), (e1, e2) = dual[(q + shift) % len(dual)], want[(q + shift) % len(dual)]
             assert x1 == [e1[3], e1[4], e1[5], e1[6]], (len(a), len(b), "v1", tag)
             assert x2 == [e2[3], e2[4], e2[5], e2[6]], (len(a), len(b), "v2", tag)
+    # 15: the score sweep alone, as the assembler calls it: scores and end cells always the reference's; a border cell that
+    # check_align can look at (bk_decide: the winner's; the loser's unless the winner's ok test is true; both at equal scores;
+    # none when neither score passes the first test) is either the reference's or flagged -1 (the full sweep follows); and the
+    # sweep settles the exact overlaps by itself (the case clean data consists of)
+    raw, _ = eng.nw_batch(dual, transposed=15)
+    settled = flagged = 0
+    for (a, b), (e1, e2), x in zip(dual, want, raw.tolist()):
+        j1, s1, j2, s2 = x
+        assert s1 == e1[6] and s2 == e2[6], (len(a), len(b))
+        minlen = min(len(a), len(b))
+        p1, p2 = e1[4] > 0 and 4 * s1 >= minlen, e2[4] > 0 and 4 * s2 >= minlen
+        ok1 = p1 and 200 * s1 >= 179 * (len(a) - e1[3])
+        ok2 = p2 and 200 * s2 >= 179 * (len(b) - e2[3])
+        if not (p1 or p2):
+            need = (False, False)
+        elif s1 == s2:
+            need = (True, True)
+        elif s1 > s2:
+            need = (True, p2 and not ok1)
+        else:
+            need = (p1 and not ok2, True)
+        for j, e, nd in ((j1, e1, need[0]), (j2, e2, need[1])):
+            if j == -1:
+                flagged += 1
+            elif nd:
+                settled += 1
+                assert j == e[3], (len(a), len(b), j, e, need)
+    assert settled > 300 and flagged > 50
+    exact = [(a, b) for (a, b), (e1, e2) in zip(dual, want) if e1[6] == min(e1[4], len(a)) and e1[4] > 0]
+    r2, _ = eng.nw_batch(exact, transposed=15)
+    assert len(exact) > 100 and all(x[0] != -1 for x in r2.tolist())
+    # the headline's reads: the read hangs over the contig end by one base (or starts one base before it): nw(read, contig) then
+    # ends in a gap and loses -- nothing is flagged
+    rnd3 = random.Random(13)
+    ext = []
+    for t in range(60):
+        m = rnd3.randint(150, 320)
+        a = "".join(rnd3.choice("ACGT") for _ in range(m))
+        k_ = rnd3.randint(1, 3)
+        ext.append((a, a[m - (150 - k_):] + "".join(rnd3.choice("ACGT") for _ in range(k_))))
+        ext.append((a, "".join(rnd3.choice("ACGT") for _ in range(k_)) + a[:150 - k_]))
+    r3, _ = eng.nw_batch(ext, transposed=15)
+    assert all(x[0] != -1 and x[2] != -1 for x in r3.tolist()), [x for x in r3.tolist() if -1 in (x[0], x[2])][:3]
 
 
 def _run_regions(hb, regions, k, rc_thresh=2, stages=3, **limits):

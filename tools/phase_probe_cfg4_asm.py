@@ -1,5 +1,5 @@
 """Per-phase times of the assembler kernel on ONE configs[4] region (24,000 x 250 bp, k = 41, 5 % noise); needs the diagnostic
-build tools/probes/libbk_stamps_probe.  argv: [noise [depth [L [k]]]]"""
+build `python breakmer_amd/build.py stamps`.  argv: [noise [depth [L [k]]]]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from breakmer_amd import hip_backend as hb, synth

@@ -1,5 +1,5 @@
 """Per-phase time shares of the assembler kernel on the headline batch (256 regions of configs[1]); needs the diagnostic build
-tools/probes/libbk_stamps_probe (see tools/README.md).  BK_WG=256|512 selects the workgroup size."""
+the build `python breakmer_amd/build.py stamps`.  BK_WG=256|512 selects the workgroup size."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from breakmer_amd import hip_backend as hb, synth
