@@ -133,16 +133,16 @@ def side_configs(a, hb, synth, opts, local):
     oc = {}
     try:
         regs3 = [cfg3_region(synth, i) for i in range(a.cfg3_regions)]
-        oc["configs[3]"] = time_other_config(hb, regs3, 31, opts, 2, local)
+        oc["configs[3]"] = time_other_config(hb, regs3, 31, opts, 2, local, flags=a.flags)
         oc["configs[3]"]["workload"] = "mixed SV set (indel/inv/dup/trl + partner window), 1,000x 150 bp, k=31"
         del regs3
         regs4 = make_regions_parallel("cfg4", a.cfg4_regions)
-        oc["configs[4]"] = time_other_config(hb, regs4, 41, opts, 1, local)
+        oc["configs[4]"] = time_other_config(hb, regs4, 41, opts, 1, local, flags=a.flags)
         oc["configs[4]"]["workload"] = "250 bp reads at 2,000x, k=41, 5 % substitution noise"
         del regs4
         # the standing round-1 bar: one launch of 64 configs[1]-shaped regions at 0.5 % substitution noise (< 0.1 s asked for)
         regsn = [synth.make_region(50000 + i, depth=a.depth, L=a.read_len, sv_type="del", noise=0.005) for i in range(64)]
-        oc["noise_0.5pct_64_regions"] = time_other_config(hb, regsn, a.kmer, opts, 2, local)
+        oc["noise_0.5pct_64_regions"] = time_other_config(hb, regsn, a.kmer, opts, 2, local, flags=a.flags)
         oc["noise_0.5pct_64_regions"]["workload"] = "64 regions of the configs[1] shape with 0.5 % substitution noise per base, one launch (seconds per launch = ms_per_batch / 1000)"
         del regsn
     except Exception as ex:                      # never lose what was measured to a later side measurement
@@ -266,7 +266,7 @@ def main():
             oc["noise_0.5pct_64_regions_one_unit"]["workload"] = "the same 64 noisy regions with bk_config.reserved[0] bit 128: no component split, one assembler workgroup per region (the default until round 4)"
             print(json.dumps(oc), flush=True)
             return
-        print(json.dumps(side_configs(a, hb, synth, default_opts(), int(os.environ.get("LOCAL_RANK", "0")))), flush=True)
+        print(json.dumps(side_configs(a, hb, synth, default_opts(), int(os.environ.get("LOCAL_RANK", "0")))), flush=True)      # (--flags applies: diagnostic A/B runs)
         return
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(a))

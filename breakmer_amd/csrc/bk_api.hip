@@ -1314,8 +1314,8 @@ extern "C" int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, con
     HIPCHK(h, hipMemcpy(dc.p, codes.data(), seq_bytes, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d1.p, off1, nb, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(d2.p, len1, nb, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d3.p, off2, nb, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(d4.p, len2, nb, hipMemcpyHostToDevice));
-    const size_t lds = transposed >= 5 ? (size_t)2 * (((maxm + 15) & ~15u) + ((maxn + 15) & ~15u)) + 256      // bk_nw_pair: two pairs of sequences, parameters, results
-                                       : ((maxm + 15) & ~15u) + ((maxn + 15) & ~15u) + (size_t)2 * (std::max(maxm, maxn) + 2) * 4;
+    const size_t lds = (transposed >= 5 && transposed <= 17) ? (size_t)2 * (((maxm + 15) & ~15u) + ((maxn + 15) & ~15u)) + 256      // bk_nw_pair / the score sweep on pairs: two pairs of sequences, parameters, results
+                                       : ((maxm + 15) & ~15u) + ((maxn + 15) & ~15u) + (size_t)2 * (std::max(maxm, maxn) + 2) * 4 + 64;      // (+ 8 result ints of modes 18-20)
     HIPCHK(h, hipFuncSetAttribute((const void *)bk_nw_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
     hipLaunchKernelGGL(bk_nw_batch_kernel, dim3(n_pairs), dim3(64), lds, h->stream, (const uint8_t *)dc.p, (const uint32_t *)d1.p, (const uint32_t *)d2.p,

@@ -770,11 +770,32 @@ __device__ __noinline__ void bk_dp_round()
     } else {                                             // two wavefronts per slot, both with the contig on the tile columns
         const int sl = wv >> 1;
         if (sl < nb) {
-            const uint8_t *cs = L_CSEQ + S->slot[sl].pb; const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
-            // waves w and w+4 land on the same SIMD: give it one direct (heavier) and one transposed sweep
-            if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
-            else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
+            const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
+            if (S->fast) {
+                // the score sweep of the whole matrix on ONE of the slot's two wavefronts (any contig length: column tiles); what it
+                // cannot settle is swept in full after the round's barrier (bk_dp_redo)
+                if ((wv & 1) == 0) {
+                    bk_nw_score_long(BK_O_CSEQ + S->slot[sl].pb, cl, BK_O_RSEQ + sl * (C_.MAXR + 16), rl, (int)((uint8_t *)&S->slot[sl].v1 - bk_lds), L_BOUND_W(wv));
+                    if ((BK_TID & 63) == 0) atomicAdd(&S->dp_n, 1);
+                }
+            } else {
+                const uint8_t *cs = L_CSEQ + S->slot[sl].pb;
+                // waves w and w+4 land on the same SIMD: give it one direct (heavier) and one transposed sweep
+                if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
+                else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
+            }
         }
+    }
+}
+// the slots of a two-wavefronts-per-slot round whose score sweep left a border cell open: both overlap DPs in full
+__device__ __noinline__ void bk_dp_redo()
+{
+    BkAsmShared *S = S_;
+    const int wv = BK_TID >> 6, sl = wv >> 1;
+    if (sl < S->nb && S->slot[sl].dec) {                 // (Slot::dec is free between the staging of a round and its retirement: here it says "sweep again")
+        const uint8_t *cs = L_CSEQ + S->slot[sl].pb; const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
+        if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
+        else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
     }
 }
 // noisy reads: check_align has lately rejected three reads out of four (prediction then is "nothing changes", bk_predict)
@@ -1317,6 +1338,21 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         // 2. the overlap DPs (:451-452) of every slot of this round
         bk_dp_round();
         BK_SYNC();
+        if (!S->dual && S->fast) {                      // (uniform) two wavefronts per slot: did the score sweep leave a border cell open?
+            bool any = false;
+            for (int sl = 0; sl < nb; sl++) any = any || S->slot[sl].v1.j_start == BK_NW_NEEDS_DP || S->slot[sl].v2.j_start == BK_NW_NEEDS_DP;
+            if (any) {
+                BK_SYNC();                              // every wavefront has looked at the result words before they change
+                if (BK_TID < nb) {
+                    const int f = (S->slot[BK_TID].v1.j_start == BK_NW_NEEDS_DP || S->slot[BK_TID].v2.j_start == BK_NW_NEEDS_DP) ? 1 : 0;
+                    S->slot[BK_TID].dec = f;
+                    if (f) atomicAdd(&S->dp_redo, 1);
+                }
+                BK_SYNC();
+                bk_dp_redo();
+                BK_SYNC();
+            }
+        }
         BK_ACC(2);
         s0 = 0; s1 = ncur;
         }
@@ -2080,6 +2116,20 @@ extern "C" __global__ void __launch_bounds__(64) bk_nw_batch_kernel(const uint8_
     for (int t = threadIdx.x; t < m; t += 64) s1[t] = codes[off1[b] + t];
     for (int t = threadIdx.x; t < n; t += 64) s2[t] = codes[off2[b] + t];
     BK_SYNC();
+    if (transposed == 18 || transposed == 19 || transposed == 20) {      // the score sweep for any contig length (column tiles) + the full sweeps for what it flags: 18 -> nw(seq1, seq2), 19 -> nw(seq2, seq1); 20: the sweep alone (timing)
+        int *res = bound + 2 * (max(m, n) + 2);          // (8 ints behind the scratch: bk_nw_batch allocates them)
+        for (int i = 0; i < reps; i++) bk_nw_score_long((int)(s1 - l), m, (int)(s2 - l), n, (int)((uint8_t *)res - l), bound, transposed == 20 ? 0 : 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        int o[4];
+        const int sel = transposed == 19 ? 4 : 0;
+        for (int q = 0; q < 4; q++) o[q] = res[sel + q];
+        if (transposed != 20 && __builtin_amdgcn_readfirstlane((int)(o[0] == BK_NW_NEEDS_DP))) {
+            const BkNwResult r2 = transposed == 18 ? bk_nw_suffix(s1, m, s2, n, bound) : bk_nw_wave<true>(s1, m, s2, n, bound);
+            o[0] = r2.j_start; o[1] = r2.i_end; o[2] = r2.i_start; o[3] = r2.score;
+        }
+        if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[4 * b + q] = o[q];
+        return;
+    }
     if (transposed >= 5) {                             // bk_nw_pair: half A = pair b, half B = pair b+1 (cyclic); 5 / 6 -> A's nw(seq1, seq2) / nw(seq2, seq1), 7 / 8 -> B's
         const int b2 = (b + 1) % (int)gridDim.x, m2 = (int)len1[b2], n2 = (int)len2[b2];
         const int mp = (int)((m + 15) & ~15), np_ = (int)((n + 15) & ~15), mp2 = (int)((m2 + 15) & ~15), np2 = (int)((n2 + 15) & ~15);

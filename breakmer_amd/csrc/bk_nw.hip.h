@@ -531,6 +531,7 @@ __device__ inline void bk_nw_pair(const BkPairArgs &A, const BkPairArgs &B) { bk
 // sweep (bk_nw_pair_c / bk_nw_dual_c) for that read: bit-identical by construction, since every value reported here IS the
 // reference's.  LPR = lanes per read: 64 (one read per wavefront, the latency build) or 32 (two reads per wavefront).
 #define BK_NW_NEEDS_DP (-1)
+__device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int i1, int s2, int i2, int force);
 template <int C, int LPR>
 __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int force_)
 {
@@ -594,29 +595,7 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
         const int os = __shfl_xor(s2, o), oi = __shfl_xor(i2, o);
         if (os > s2 || (os == s2 && oi > i2)) { s2 = os; i2 = oi; }
     }
-    if (hl == 0 && n > 0) {
-        const int minlen = min(mt, n);
-        // v1 = nw(contig, read): m_ref = mt, end cell (i1, mt); v2 = nw(read, contig): m_ref = n, end cell (contig position i2, read column n)
-        int j1 = 0, r1 = 0, j2 = 0, r2 = 0; bool k1 = false, k2 = false;             // border cells (j_start, i_start); known without a traceback?
-        if (i1 == 0) { j1 = mt - 1; k1 = true; }                                     // Q5: one forced traceback step from (0, m), score 0
-        else if (s1 == min(i1, mt)) { j1 = i1 <= mt ? mt - i1 : 0; r1 = i1 <= mt ? 0 : i1 - mt; k1 = true; }
-        if (i2 == 0) { j2 = n - 1; k2 = true; }
-        else if (s2 == min(i2, n)) { j2 = i2 <= n ? n - i2 : 0; r2 = i2 <= n ? 0 : i2 - n; k2 = true; }
-        // Which border cells does check_align look at (bk_decide, sv_assembly.py:459-503)?  ok_k = 4 s_k >= minlen and 200 s_k >= 179 *
-        // overlap_k (needs j_start_k); both false: no match, nothing else is read.  Else the call with the larger score decides, alone;
-        // equal scores: both are read.  So: nothing if neither passes the first test; the winner's always; the loser's only while the
-        // winner's own ok is not known to be true (it then decides between "no match" and the winner's move).
-        const bool p1 = i1 > 0 && 4 * s1 >= minlen, p2 = i2 > 0 && 4 * s2 >= minlen;
-        bool n1 = false, n2 = false;
-        if (force) { n1 = true; n2 = true; }
-        else if (p1 || p2) {
-            if (s1 == s2) { n1 = true; n2 = true; }
-            else if (s1 > s2) { n1 = true; n2 = p2 && !(k1 && p1 && 200 * s1 >= 179 * (mt - j1)); }
-            else { n2 = true; n1 = p1 && !(k2 && p2 && 200 * s2 >= 179 * (n - j2)); }
-        }
-        res[0] = (n1 && !k1) ? BK_NW_NEEDS_DP : j1; res[1] = i1; res[2] = r1; res[3] = i1 == 0 ? 0 : s1;
-        res[4] = (n2 && !k2) ? BK_NW_NEEDS_DP : j2; res[5] = i2; res[6] = r2; res[7] = i2 == 0 ? 0 : s2;
-    }
+    if (hl == 0 && n > 0) bk_nw_score_results(res, mt, n, s1, i1, s2, i2, force);
 }
 template <int C, int LPR>
 __device__ inline void bk_nw_score_call(int c, const BkPairArgs &A, const BkPairArgs &B, int force)
@@ -627,6 +606,125 @@ __device__ inline void bk_nw_score_call(int c, const BkPairArgs &A, const BkPair
 // two reads per wavefront (both contigs <= BK_NW_DUAL_COLS) / one read per wavefront (contig <= BK_NW_DUAL_COLS: C <= 5)
 __device__ inline void bk_nw_score_pair(const BkPairArgs &A, const BkPairArgs &B, int force = 0) { bk_nw_score_call<3, 32>((max(A.clen, B.n ? B.clen : 0) + 31) / 32, A, B, force); }
 __device__ inline void bk_nw_score_one(const BkPairArgs &A, int force = 0) { BkPairArgs B; B.contig = 0; B.clen = 0; B.read = 0; B.n = 0; B.res = 0; bk_nw_score_call<2, 64>((A.clen + 63) / 64, A, B, force); }
+
+// ---- the score sweep for contigs of any length: column tiles of 64 x C columns, one wavefront, the tile's edge column staged in LDS --
+// Same recurrence, end cells and rules as bk_nw_score_c; the columns of a tile are right-aligned in the lanes (the last column is
+// register C-1 of the last lane: a full tile has no padding, the last tile's padding passes the edge column through).  bound_in /
+// bound_out: n ints each in LDS (the scores of the column left of the tile / of its last column); the edge values and the row
+// symbols of 64 steps are fetched as a block, so the loop itself has no LDS read.  s2 / i2 (the last row: largest column among the
+// maxima) are carried from tile to tile in ascending column order; best / best_im1 (the last column) come from the last tile.
+struct BkScoreCarry { int s2, i2, best, best_im1; };
+template <int C>
+__device__ __noinline__ BkScoreCarry bk_nw_score_tile_c(const uint8_t *cols, const uint8_t *rows, int n_, int j0_, int mt_, const int *bound_in, int *bound_out, int last_, int s2_, int i2_)
+{
+    const int n = __builtin_amdgcn_readfirstlane(n_), j0 = __builtin_amdgcn_readfirstlane(j0_), mt = __builtin_amdgcn_readfirstlane(mt_);
+    const bool last = __builtin_amdgcn_readfirstlane(last_) != 0;
+    const int lane = threadIdx.x & 63;
+    const int nl = (mt + C - 1) / C, lm = nl - 1, pad = nl * C - mt;
+    int H[C], cb[C], gh[C];
+#pragma unroll
+    for (int x = 0; x < C; x++) {
+        const int jj = lane * C + x - pad;
+        const bool real = jj >= 0 && jj < mt && lane <= lm;
+        H[x] = 0;
+        cb[x] = real ? (int)cols[j0 + jj] : 8;
+        gh[x] = jj >= 0 ? -2 : 0;
+    }
+    int dprev = 0, rb = 0, im1 = -lane;
+    int best = 0, best_im1 = -1;
+    const bool inl = lane <= lm;
+    const int steps = n + lm;
+    for (int t0 = 0; t0 < steps; t0 += 64) {
+        const int rblk = (t0 + lane < n) ? (int)rows[t0 + lane] : 0;
+        const int bblk = (j0 > 0 && t0 + lane < n) ? bound_in[t0 + lane] : 0;      // S[i][j0] for the rows lane 0 handles in this block (the border column: 0)
+        const int te = min(64, steps - t0);
+        for (int tl = 0; tl < te; tl++) {
+            const int recv = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);
+            rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
+            const int ra = __builtin_amdgcn_readlane(rblk, tl), bi = __builtin_amdgcn_readlane(bblk, tl);
+            if (lane == 0) rb = ra;
+            if (inl && (unsigned)im1 < (unsigned)n) {
+                const int left = lane == 0 ? bi : recv;                             // lane 0 handles row t0 + tl at this step: its edge value is entry tl of the block
+                int u_in = left, hprev = dprev;
+#pragma unroll
+                for (int x = 0; x < C; x++) {
+                    const int hold = H[x];
+                    const int nv = max(max(hprev + (cb[x] == rb ? 1 : -2), u_in + gh[x]), hold - 2);
+                    H[x] = nv; u_in = nv; hprev = hold;
+                }
+                dprev = left;
+                const int v = H[C - 1];
+                if (last) { const bool take = v >= best; best = take ? v : best; best_im1 = take ? im1 : best_im1; }
+                else if (lane == lm) bound_out[im1] = v;
+            }
+            im1++;
+        }
+    }
+    int s2 = s2_, i2 = i2_;                                                         // carried: compared with '>=' in ascending column order
+    int ms = -0x40000000, mi = 0;
+#pragma unroll
+    for (int x = 0; x < C; x++) {
+        const int jj = lane * C + x - pad;
+        if (jj >= 0 && jj < mt && inl && H[x] >= ms) { ms = H[x]; mi = j0 + jj + 1; }
+    }
+    for (int o = 1; o < 64; o <<= 1) {
+        const int os = __shfl_xor(ms, o), oi = __shfl_xor(mi, o);
+        if (os > ms || (os == ms && oi > mi)) { ms = os; mi = oi; }
+    }
+    if (ms >= s2) { s2 = ms; i2 = mi; }
+    BkScoreCarry c; c.s2 = s2; c.i2 = i2; c.best = __shfl(best, lm); c.best_im1 = __shfl(best_im1, lm);
+    return c;
+}
+template <int C>
+__device__ inline BkScoreCarry bk_nw_score_tile_call(int c, const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt, const int *bi, int *bo, int last, int s2, int i2)
+{
+    if (c <= C) return bk_nw_score_tile_c<C>(cols, rows, n, j0, mt, bi, bo, last, s2, i2);
+    if constexpr (C < BK_NW_TILE_C) return bk_nw_score_tile_call<C + 1>(c, cols, rows, n, j0, mt, bi, bo, last, s2, i2);
+    BkScoreCarry z; z.s2 = s2; z.i2 = i2; z.best = 0; z.best_im1 = -1; return z;
+}
+// the epilogue of bk_nw_score_c as a function of the end cells (lane 0 writes the 8 result ints)
+__device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int i1, int s2, int i2, int force)
+{
+    // v1 = nw(contig, read): m_ref = mt, end cell (i1, mt); v2 = nw(read, contig): m_ref = n, end cell (contig position i2, read column n)
+    const int minlen = min(mt, n);
+    int j1 = 0, r1 = 0, j2 = 0, r2 = 0; bool k1 = false, k2 = false;             // border cells (j_start, i_start); known without a traceback?
+    // Which border cells does check_align look at (bk_decide, sv_assembly.py:459-503)?  ok_k = 4 s_k >= minlen and 200 s_k >= 179 *
+    // overlap_k (needs j_start_k); both false: no match, nothing else is read.  Else the call with the larger score decides, alone;
+    // equal scores: both are read.  So: nothing if neither passes the first test; the winner's always; the loser's only while the
+    // winner's own ok is not known to be true (it then decides between "no match" and the winner's move).
+    if (i1 == 0) { j1 = mt - 1; k1 = true; }                                     // Q5: one forced traceback step from (0, m), score 0
+    else if (s1 == min(i1, mt)) { j1 = i1 <= mt ? mt - i1 : 0; r1 = i1 <= mt ? 0 : i1 - mt; k1 = true; }
+    if (i2 == 0) { j2 = n - 1; k2 = true; }
+    else if (s2 == min(i2, n)) { j2 = i2 <= n ? n - i2 : 0; r2 = i2 <= n ? 0 : i2 - n; k2 = true; }
+    const bool p1 = i1 > 0 && 4 * s1 >= minlen, p2 = i2 > 0 && 4 * s2 >= minlen;
+    bool n1 = false, n2 = false;
+    if (force) { n1 = true; n2 = true; }
+    else if (p1 || p2) {
+        if (s1 == s2) { n1 = true; n2 = true; }
+        else if (s1 > s2) { n1 = true; n2 = p2 && !(k1 && p1 && 200 * s1 >= 179 * (mt - j1)); }
+        else { n2 = true; n1 = p1 && !(k2 && p2 && 200 * s2 >= 179 * (n - j2)); }
+    }
+    res[0] = (n1 && !k1) ? BK_NW_NEEDS_DP : j1; res[1] = i1; res[2] = r1; res[3] = i1 == 0 ? 0 : s1;
+    res[4] = (n2 && !k2) ? BK_NW_NEEDS_DP : j2; res[5] = i2; res[6] = r2; res[7] = i2 == 0 ? 0 : s2;
+}
+// One read against a contig of any length, executed by the calling wavefront: up to 640 columns in registers (bk_nw_score_c), beyond
+// that in column tiles.  contig / read / res: offsets into the dynamic LDS block; bound: 2 * n ints of LDS scratch (tiles only).
+__device__ inline void bk_nw_score_long(int contig, int clen, int read, int n, int res, int *bound, int force = 0)
+{
+    if (clen <= 64 * BK_NW_DUAL_C) { BkPairArgs A; A.contig = contig; A.clen = clen; A.read = read; A.n = n; A.res = res; bk_nw_score_one(A, force); return; }
+    const uint8_t *cols = bk_dyn_lds + contig, *rows = bk_dyn_lds + read;
+    int *bi = bound, *bo = bound + n;
+    BkScoreCarry c; c.s2 = 0; c.i2 = 0; c.best = 0; c.best_im1 = -1;
+    for (int j0 = 0; j0 < clen; j0 += BK_NW_TILE_COLS) {
+        const int mt = min(clen - j0, BK_NW_TILE_COLS);
+        const bool last = j0 + mt >= clen;
+        c = bk_nw_score_tile_call<1>((mt + 63) / 64, cols, rows, n, j0, mt, bi, bo, last ? 1 : 0, c.s2, c.i2);
+        int *t = bi; bi = bo; bo = t;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if ((threadIdx.x & 63) == 0) bk_nw_score_results((int *)(bk_dyn_lds + res), clen, n, c.best, c.best_im1 + 1, c.s2, c.i2, force);
+}
 
 // Tried in round 3 and not kept, second attempt (profiles/r03/pair_two_word_ab.txt): bk_nw_pair_c with the second order carried as a
 // second WORD [score | priority | origin] through its own v_max3 (12 instructions per cell, no compares against the score, no

@@ -109,11 +109,18 @@ def test_nw_random_vs_oracle_gpu(hb):
     out, _ = eng.nw_batch(pairs)
     out_t, _ = eng.nw_batch(pairs, transposed=True)
     out_s, _ = eng.nw_batch(pairs, transposed=2)
-    for (a, b), o, ot, os_ in zip(pairs, out.tolist(), out_t.tolist(), out_s.tolist()):
+    # 18 / 19: the score sweep for contigs of any length (column tiles beyond 640 columns) + the full sweep for what it flags
+    out_l, _ = eng.nw_batch(pairs, transposed=18)
+    out_l2, _ = eng.nw_batch(pairs, transposed=19)
+    for (a, b), o, ot, os_, ol, ol2 in zip(pairs, out.tolist(), out_t.tolist(), out_s.tolist(), out_l.tolist(), out_l2.tolist()):
         e = bo.nw(a, b)
         assert o == [e[3], e[4], e[5], e[6]], (len(a), len(b))
         assert ot == o, (len(a), len(b), "transposed")
         assert os_ == o, (len(a), len(b), "suffix")
+        assert ol == o, (len(a), len(b), "score sweep, any length")
+        if len(b) <= 1024:
+            e2 = bo.nw(b, a)
+            assert ol2 == [e2[3], e2[4], e2[5], e2[6]], (len(a), len(b), "score sweep, any length, nw(seq2, seq1)")
     # both overlap DPs of check_align on one wavefront: (contig, read) -> nw(contig, read) and nw(read, contig)
     rnd2 = random.Random(12)
     dual = [(a, b) for a, b in pairs if len(a) <= 320 and len(b) <= 400]
