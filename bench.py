@@ -168,7 +168,8 @@ def time_other_config(hb, regions, k, opts, reps, device, flags=0):
     out = {"regions": len(regions), "reads_per_region": int(regions[0].reads.shape[0]), "k": k, "value": round(len(regions) / dt, 1), "unit": "regions/s",
            "ms_per_batch": round(dt * 1e3, 2), "kernels_ms": {"kmer": round(eng.kernel_ms(1), 2), "asm": round(eng.kernel_ms(2), 2), "sw": round(eng.kernel_ms(3), 2)},
            "contigs": int(eng.stat(6)), "sv_calls": int(ncalls), "nw_cells": int(eng.stat(0)), "failed_regions": int(eng.stat(22)),
-           "dp_tcups": round(eng.stat(0) / dt / 1e12, 3)}
+           "dp_tcups": round(eng.stat(0) / dt / 1e12, 3),
+           "dp_reads_through_score_sweep": int(eng.stat(30)), "dp_reads_swept_again_in_full": int(eng.stat(31))}
     eng.close()
     return out
 

@@ -1277,7 +1277,7 @@ extern "C" int bk_get_stat(bk_handle *h, int which, uint64_t *value)
     uint64_t v = 0;
     for (int r = 0; r < h->n_regions; r++) {
         const BkRegionWork &w = h->h_work[r];
-        switch (which) { case 0: v += w.nw_cells; break; case 1: v += w.nw_calls; break; case 2: v += w.sw_cells; break; case 4: v += w.U; break; case 5: v += w.M; break; case 6: v += w.n_contigs; break; case 7: v += w.T; break; case 8: v += w.tcap; break; default: break; }
+        switch (which) { case 0: v += w.nw_cells; break; case 1: v += w.nw_calls; break; case 2: v += w.sw_cells; break; case 4: v += w.U; break; case 5: v += w.M; break; case 6: v += w.n_contigs; break; case 7: v += w.T; break; case 8: v += w.tcap; break; case 30: v += w.dp_sweeps; break; case 31: v += w.dp_redos; break; default: break; }
     }
     if (which == 3) v = h->alg_bytes;
     if (which == 20) v = (uint64_t)(h->submit_pack_ms * 1000.0);              // microseconds

@@ -60,6 +60,7 @@ struct BkAsmShared {
     // the score sweep (bk_nw.hip.h: bk_nw_score_c) runs first while few of its reads need the full sweep after all: reads swept /
     // reads that had to be swept again, in a window that is halved at 64; fast = the plan of the current round uses it
     int dp_n, dp_redo, fast;
+    int dp_tot, dp_rtot;             // the same counts over the whole region (reported: BkRegionWork.dp_sweeps / dp_redos)
     // look-ahead across k-mer visits of grow (bk_run_candidates): slots [plan_r, nb) hold reads of LATER visits, already aligned
     // against the predicted contig; plan_upto = last visit (index into the snapshot) whose candidate list the plan knows
     int ncur, plan_r, plan_upto, plan_ok, hit;
@@ -1203,7 +1204,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
     // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
     S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
-    if (S->dp_n >= 64) { S->dp_n >>= 1; S->dp_redo >>= 1; }
+    if (S->dp_n >= 64) { S->dp_tot += S->dp_n - (S->dp_n >> 1); S->dp_rtot += S->dp_redo - (S->dp_redo >> 1); S->dp_n >>= 1; S->dp_redo >>= 1; }
     S->fast = !(C_.flags & BK_F_NO_SCORE_SWEEP) && 4 * S->dp_redo <= S->dp_n + 8;      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays)
     int nc = ncur;
     if (!S->dual && nb > BK_SPEC_WIDE) { nc = min(nc, BK_SPEC_WIDE); nb = nc; upto = vt; }      // two wavefronts per slot: this visit's reads only
@@ -1885,7 +1886,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
         c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
-        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32; S->n_rej = 0; S->n_acc = 0; S->dp_n = 0; S->dp_redo = 0; S->fast = 0;
+        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32; S->n_rej = 0; S->n_acc = 0; S->dp_n = 0; S->dp_redo = 0; S->fast = 0; S->dp_tot = 0; S->dp_rtot = 0;
 #ifdef BK_PHASE_STAMPS
         for (int i = 0; i < 24; i++) S->acc[i] = 0; S->ctx = 0;
         S->last = __builtin_amdgcn_s_memrealtime();
@@ -1992,6 +1993,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
     BK_ACC(S_->ctx);
     if (BK_TID == 0) {
         int action = 0;                                  // split regions, the last unit to report in: 1 merge + re-queue, 2 link, 3 leave it to the host
+        atomicAdd((unsigned long long *)&C_.wk->dp_sweeps, (unsigned long long)(S->dp_tot + S->dp_n)); atomicAdd((unsigned long long *)&C_.wk->dp_redos, (unsigned long long)(S->dp_rtot + S->dp_redo));
         if (!C_.split) { C_.wk->n_contigs = (uint32_t)S->n_contigs; C_.wk->nw_cells = S->cells; C_.wk->nw_calls = S->calls; if (S->status) C_.wk->status = S->status; }
         else {
             // a unit reports in; the last one of the region decides what the host sees: a failed unit fails the region (the library

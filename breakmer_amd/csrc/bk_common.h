@@ -176,6 +176,7 @@ struct BkRegionWork {
     uint32_t tcap;               // k-mer table capacity (power of two)
     uint32_t n_contigs;
     uint64_t nw_cells, nw_calls; // algorithmic DP work
+    uint64_t dp_sweeps, dp_redos;   // reads whose overlap DPs went through the score sweep / of those, swept again in full (bk_nw.hip.h; bk_get_stat 30, 31)
     uint64_t sw_cells;
     // arena offsets (bytes)
     uint64_t o_trip_ent;         // uint32[T]   (u << 10 | pos)

@@ -464,7 +464,7 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     uint32_t *scr = lds;                       // 32 words scratch
     uint32_t *stage = lds + 32;                // 16 words per wavefront: the read a wavefront scans cooperatively
 
-    if (tid == 0) { wk->status = BK_ST_OK; wk->U = 0; wk->T = 0; wk->M = 0; wk->M2 = 0; wk->split = 0; wk->pass = 0; wk->phase = 0; wk->units_done = 0; wk->n_cidx = 0; wk->n_pairs = 0; wk->n_conf = 0; wk->tcap = 0; wk->n_contigs = 0; wk->nw_cells = 0; wk->nw_calls = 0; wk->sw_cells = 0; wk->o_first_contig = 0; wk->o_last_contig = 0; for (int q = 0; q < 4; q++) wk->stamps[q] = 0; }
+    if (tid == 0) { wk->status = BK_ST_OK; wk->U = 0; wk->T = 0; wk->M = 0; wk->M2 = 0; wk->split = 0; wk->pass = 0; wk->phase = 0; wk->units_done = 0; wk->n_cidx = 0; wk->n_pairs = 0; wk->n_conf = 0; wk->tcap = 0; wk->n_contigs = 0; wk->nw_cells = 0; wk->nw_calls = 0; wk->sw_cells = 0; wk->dp_sweeps = 0; wk->dp_redos = 0; wk->o_first_contig = 0; wk->o_last_contig = 0; for (int q = 0; q < 4; q++) wk->stamps[q] = 0; }
     const int W = (int)d.win_len, WK = W >= k ? W - k + 1 : 0;
     const uint32_t *gw = p.windows + d.win_word_off;
     const int ww = (W + 15) / 16;

@@ -525,13 +525,28 @@ __device__ inline void bk_nw_pair(const BkPairArgs &A, const BkPairArgs &B) { bk
 //   pure diagonal of d matches from the border -- and along it the diagonal candidate wins every cell strictly (a gap candidate would
 //   need a neighbour scoring 2 more than the cell, which exceeds that neighbour's own bound min(i, j)), so the reference's pointer
 //   walk follows it whatever the tie-break order: origin = (0, m - i) if i <= m, else (i - m, 0).
+// The same holds with substitutions on that diagonal: if the pure diagonal from the border to the end cell, with its x mismatches, scores
+// d - 3x == s, it is an optimal path, so every prefix of it is optimal for the cell it ends in (a better prefix would make a better
+// path), i.e. at every cell on it the diagonal candidate reaches the cell's score -- and the diagonal has the highest priority in both
+// tie-break orders (olc.py:69-74): the pointer walk follows it to the border.  x is counted on the sequences (d comparisons, the
+// lanes of the read in parallel); this settles the overlaps of reads with sequencing errors, whose alignments have no gaps.
 // Otherwise the origin is only needed when the score can pass check_align's first test (4 * score >= min(len(contig), len(read)),
 // sv_assembly.py:459-461): else the decision never looks at it (bk_decide: ok_k false; a call whose partner wins is only read for
 // its score).  What is left -- an overlap with a mismatch or an indel in it -- is FLAGGED (j_start = -1) and the caller runs the full
 // sweep (bk_nw_pair_c / bk_nw_dual_c) for that read: bit-identical by construction, since every value reported here IS the
 // reference's.  LPR = lanes per read: 64 (one read per wavefront, the latency build) or 32 (two reads per wavefront).
 #define BK_NW_NEEDS_DP (-1)
-__device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int i1, int s2, int i2, int force);
+// mismatches on the d cells of the diagonal that ends in matrix cell (row ie, column je): read symbol rows[ie - 1 - t] against contig
+// symbol cols[je - 1 - t]; executed by the LPR lanes that hold the read (hl = lane within them), result in all of them
+template <int LPR>
+__device__ inline int bk_nw_diag_mismatches(const uint8_t *cols, const uint8_t *rows, int ie, int je, int d, int hl)
+{
+    int c = 0;
+    for (int t = hl; t < d; t += LPR) c += rows[ie - 1 - t] != cols[je - 1 - t] ? 1 : 0;
+    for (int o = 1; o < LPR; o <<= 1) c += __shfl_xor(c, o);
+    return c;
+}
+__device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int i1, int s2, int i2, int x1, int x2, int force);
 template <int C, int LPR>
 __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int force_)
 {
@@ -595,7 +610,11 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
         const int os = __shfl_xor(s2, o), oi = __shfl_xor(i2, o);
         if (os > s2 || (os == s2 && oi > i2)) { s2 = os; i2 = oi; }
     }
-    if (hl == 0 && n > 0) bk_nw_score_results(res, mt, n, s1, i1, s2, i2, force);
+    // the end cells' diagonals (uniform per read: s, i are): v1 ends in (row i1, column mt), v2 in (row n, column i2)
+    int x1 = 0, x2 = 0;
+    if (n > 0 && i1 > 0 && s1 != min(i1, mt)) x1 = bk_nw_diag_mismatches<LPR>(cols, rows, i1, mt, min(i1, mt), hl);
+    if (n > 0 && i2 > 0 && s2 != min(i2, n)) x2 = bk_nw_diag_mismatches<LPR>(cols, rows, n, i2, min(i2, n), hl);
+    if (hl == 0 && n > 0) bk_nw_score_results(res, mt, n, s1, i1, s2, i2, x1, x2, force);
 }
 template <int C, int LPR>
 __device__ inline void bk_nw_score_call(int c, const BkPairArgs &A, const BkPairArgs &B, int force)
@@ -683,8 +702,9 @@ __device__ inline BkScoreCarry bk_nw_score_tile_call(int c, const uint8_t *cols,
     BkScoreCarry z; z.s2 = s2; z.i2 = i2; z.best = 0; z.best_im1 = -1; return z;
 }
 // the epilogue of bk_nw_score_c as a function of the end cells (lane 0 writes the 8 result ints)
-__device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int i1, int s2, int i2, int force)
+__device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int i1, int s2, int i2, int x1, int x2, int force)
 {
+    // x1 / x2: mismatches on the pure diagonal from the border to the end cell of v1 / v2 (bk_nw_diag_mismatches; 0 where it was not counted)
     // v1 = nw(contig, read): m_ref = mt, end cell (i1, mt); v2 = nw(read, contig): m_ref = n, end cell (contig position i2, read column n)
     const int minlen = min(mt, n);
     int j1 = 0, r1 = 0, j2 = 0, r2 = 0; bool k1 = false, k2 = false;             // border cells (j_start, i_start); known without a traceback?
@@ -693,9 +713,9 @@ __device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int 
     // equal scores: both are read.  So: nothing if neither passes the first test; the winner's always; the loser's only while the
     // winner's own ok is not known to be true (it then decides between "no match" and the winner's move).
     if (i1 == 0) { j1 = mt - 1; k1 = true; }                                     // Q5: one forced traceback step from (0, m), score 0
-    else if (s1 == min(i1, mt)) { j1 = i1 <= mt ? mt - i1 : 0; r1 = i1 <= mt ? 0 : i1 - mt; k1 = true; }
+    else if (s1 == min(i1, mt) - 3 * x1) { j1 = i1 <= mt ? mt - i1 : 0; r1 = i1 <= mt ? 0 : i1 - mt; k1 = true; }
     if (i2 == 0) { j2 = n - 1; k2 = true; }
-    else if (s2 == min(i2, n)) { j2 = i2 <= n ? n - i2 : 0; r2 = i2 <= n ? 0 : i2 - n; k2 = true; }
+    else if (s2 == min(i2, n) - 3 * x2) { j2 = i2 <= n ? n - i2 : 0; r2 = i2 <= n ? 0 : i2 - n; k2 = true; }
     const bool p1 = i1 > 0 && 4 * s1 >= minlen, p2 = i2 > 0 && 4 * s2 >= minlen;
     bool n1 = false, n2 = false;
     if (force) { n1 = true; n2 = true; }
@@ -723,7 +743,11 @@ __device__ inline void bk_nw_score_long(int contig, int clen, int read, int n, i
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if ((threadIdx.x & 63) == 0) bk_nw_score_results((int *)(bk_dyn_lds + res), clen, n, c.best, c.best_im1 + 1, c.s2, c.i2, force);
+    const int s1 = c.best, i1 = c.best_im1 + 1, s2 = c.s2, i2 = c.i2, hl = threadIdx.x & 63;
+    int x1 = 0, x2 = 0;
+    if (i1 > 0 && s1 != min(i1, clen)) x1 = bk_nw_diag_mismatches<64>(cols, rows, i1, clen, min(i1, clen), hl);
+    if (i2 > 0 && s2 != min(i2, n)) x2 = bk_nw_diag_mismatches<64>(cols, rows, n, i2, min(i2, n), hl);
+    if (hl == 0) bk_nw_score_results((int *)(bk_dyn_lds + res), clen, n, s1, i1, s2, i2, x1, x2, force);
 }
 
 // Tried in round 3 and not kept, second attempt (profiles/r03/pair_two_word_ab.txt): bk_nw_pair_c with the second order carried as a
