@@ -156,7 +156,13 @@ extern __shared__ __attribute__((aligned(16))) uint8_t bk_lds[];
 __device__ inline int32_t *bk_cnt_io(int buf) { return C_.cnt + (size_t)buf * 4 * C_.MAXC; }
 __device__ inline int32_t *bk_cnt_ot(int buf) { return C_.cnt + (size_t)buf * 4 * C_.MAXC + 2 * C_.MAXC; }
 
-__device__ inline void bk_fail(int st) { if (BK_TID == 0 && S_->status == 0) S_->status = st; }
+// A region gives up (a working cap overflowed: the library runs it again under larger ones).  S->status steers every loop of the
+// state machine (`if (S->status) return;`), so the write is bracketed by barriers HERE: every wavefront has finished the reads that
+// came before, and none reads the word again before the second barrier.  Every call site is uniform.  (Round 5: bk_retire called the
+// bare write of rounds 1-4 with no barrier behind the loop-top test of the retire loop -- a late wavefront saw the status, left
+// bk_run_candidates and stood in bk_finalize's barrier while its workgroup stood in bk_retire's.  Only on the contig-overflow path;
+// found by running the whole GPU suite through the barrier-check build, tests/test_hip_gpu.py with BK_TEST_VARIANT=checkjit.)
+__device__ inline void bk_fail(int st) { BK_SYNC(); if (BK_TID == 0 && S_->status == 0) S_->status = st; BK_SYNC(); }
 
 // k-mer key of LDS bytes s[0..k); false when the window holds an N (code 4): no such k-mer exists (Jellyfish skips them)
 // Four bases per step: aligned LDS words funnelled to the byte offset of s (v_alignbyte), the four 2-bit codes of a word
@@ -303,7 +309,7 @@ __device__ inline void bk_extend_counts(int l, int nreads, int indel, bool post)
     BkAsmShared *S = S_;
     int32_t *io = bk_cnt_io(S->cbuf), *ot = bk_cnt_ot(S->cbuf);
     const int at = post ? S->nbase + S->nlen : S->nbase - l;
-    if (at < 0 || at + l > 2 * C_.MAXC) { bk_fail(BK_ST_CONTIG); BK_SYNC(); return; }
+    if (at < 0 || at + l > 2 * C_.MAXC) { bk_fail(BK_ST_CONTIG); return; }
     for (int t = BK_TID; t < l; t += BK_AT) { io[at + t] = indel ? nreads : 0; ot[at + t] = indel ? 0 : nreads; }
     BK_SYNC();
     if (BK_TID == 0) { if (!post) S->nbase -= l; S->nlen += l; }
@@ -377,7 +383,7 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
     const int k = C_.k, np = L - k;                      // number of positions
     int *tmp = (int *)L_CAND;                           // rank per position (or -1)
     const int m = L / 2;
-    if (np > 2 * C_.MAXCAND) { bk_fail(BK_ST_KLIST); BK_SYNC(); return; }
+    if (np > 2 * C_.MAXCAND) { bk_fail(BK_ST_KLIST); return; }
     if (np <= 0 && order != BK_ORD_MID) return;         // a one-base extension has no new k-mer (Q1: range(0, L-k) of a window of k bases): nothing to append, six barriers saved
     if (S->status) return;                              // (uniform) a conflict is being unwound
     // Split regions: a k-mer of a component this unit does not hold counts as a meeting WHATEVER its state says -- the other unit
@@ -431,7 +437,7 @@ BK_COLD void bk_kmers_ordered(int s0, int L, int order)
     }
     const int pre_m = S->tmp0;
     const int base = (order == BK_ORD_MID) ? 0 : S->nk;
-    if (base + (int)T > (2 * C_.MAXC)) { bk_fail(BK_ST_KLIST); BK_SYNC(); return; }
+    if (base + (int)T > (2 * C_.MAXC)) { bk_fail(BK_ST_KLIST); return; }
     uint32_t q = pre;
     for (int x = b; x < e; x++) {
         int rk = tmp[x];
@@ -487,7 +493,7 @@ BK_COLD void bk_find_reads(int rank, bool rev, bool filter)
         // every thread reads ncand BEFORE thread 0 may reset it (the extra barrier is only taken on the failing path; the
         // condition is uniform, so the workgroup's barriers stay aligned -- a late wavefront must not see the reset value)
         const int nc_ = S->ncand;
-        if (nc_ > C_.MAXCAND) { BK_SYNC(); bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); }
+        if (nc_ > C_.MAXCAND) { bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); }      // (bk_fail starts with a barrier: every thread has read ncand)
         BK_ACC(4);
         return;
     }
@@ -511,7 +517,7 @@ BK_COLD void bk_find_reads(int rank, bool rev, bool filter)
     BK_SYNC();
     for (uint32_t i = b + BK_TID; i < e; i += BK_AT) C_.uminpos[C_.post[i] >> 10] = 0x7FFFFFFF;
     const int n = S->ncand;
-    if (n > C_.MAXCAND) { BK_SYNC(); bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); return; }      // barrier first: every thread has read ncand
+    if (n > C_.MAXCAND) { bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); return; }      // (bk_fail starts with a barrier: every thread has read ncand)
     int npad = 1; while (npad < n) npad <<= 1;
     for (int i = n + BK_TID; i < npad; i += BK_AT) L_CAND[i] = ~0ull;
     BK_SYNC();
@@ -554,7 +560,7 @@ __device__ inline void bk_contig_new(int rank, int u, bool in_fifo)             
     BkAsmShared *S = S_;
     bk_load_read(u);
     const int len = S->rlen, nreads = S->rn, indel = S->rindel;
-    if (len > C_.MAXC) { bk_fail(BK_ST_CONTIG); BK_SYNC(); return; }
+    if (len > C_.MAXC) { bk_fail(BK_ST_CONTIG); return; }
     const int base = C_.MAXC - len;
     for (int t = BK_TID; t < len; t += BK_AT) L_CSEQ[base + t] = L_RSEQ[t];
     int32_t *io = bk_cnt_io(0) + base, *ot = bk_cnt_ot(0) + base;
@@ -672,7 +678,7 @@ __device__ inline bool bk_retire(int rank, int sl, bool grow)
             fail = cbase - pl < 0 || clen + pl > C_.MAXC || at < 0;
             if (!fail) for (int t = BK_TID; t < pl; t += BK_AT) L_CSEQ[cbase - pl + t] = rseq[t];
         }
-        if (fail) bk_fail(BK_ST_CONTIG);
+        if (fail) { bk_fail(BK_ST_CONTIG); synced = true; }
         else {
             for (int t = s0 + BK_TID; t < min(s1, nlen); t += BK_AT) cv[t] += nreads;          // set_counts :195-199 (old coordinates)
             for (int t = BK_TID; t < pl; t += BK_AT) { io[at + t] = indel ? nreads : 0; ot[at + t] = indel ? 0 : nreads; }   // extend_counts :201-221
@@ -775,6 +781,9 @@ __device__ __noinline__ void bk_dp_round()
             if (S->fast) {
                 // the score sweep of the whole matrix on ONE of the slot's two wavefronts (any contig length: column tiles); what it
                 // cannot settle is swept in full after the round's barrier (bk_dp_redo)
+                // (a tile pipeline over BOTH wavefronts of the slot -- alternate column tiles, the second ~128 steps behind on the edge
+                //  column in LDS -- was built and measured in round 5: bit-exact, and no faster where long contigs occur: configs[4]
+                //  6,367 -> 6,394 ms per batch, configs[3] 945 -> 953; not kept: profiles/r05/score_sweep_ab.txt)
                 if ((wv & 1) == 0) {
                     bk_nw_score_long(BK_O_CSEQ + S->slot[sl].pb, cl, BK_O_RSEQ + sl * (C_.MAXR + 16), rl, (int)((uint8_t *)&S->slot[sl].v1 - bk_lds), L_BOUND_W(wv));
                     if ((BK_TID & 63) == 0) atomicAdd(&S->dp_n, 1);

@@ -710,20 +710,25 @@ __device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int 
     int j1 = 0, r1 = 0, j2 = 0, r2 = 0; bool k1 = false, k2 = false;             // border cells (j_start, i_start); known without a traceback?
     // Which border cells does check_align look at (bk_decide, sv_assembly.py:459-503)?  ok_k = 4 s_k >= minlen and 200 s_k >= 179 *
     // overlap_k (needs j_start_k); both false: no match, nothing else is read.  Else the call with the larger score decides, alone;
-    // equal scores: both are read.  So: nothing if neither passes the first test; the winner's always; the loser's only while the
-    // winner's own ok is not known to be true (it then decides between "no match" and the winner's move).
+    // equal scores: both are read.  So the sweep first establishes what it can of ok_1 / ok_2 (below), then: a match is certain -> the
+    // winner's border cell; no match is certain -> none; else the border cells of the calls whose ok is still open.
     if (i1 == 0) { j1 = mt - 1; k1 = true; }                                     // Q5: one forced traceback step from (0, m), score 0
     else if (s1 == min(i1, mt) - 3 * x1) { j1 = i1 <= mt ? mt - i1 : 0; r1 = i1 <= mt ? 0 : i1 - mt; k1 = true; }
     if (i2 == 0) { j2 = n - 1; k2 = true; }
     else if (s2 == min(i2, n) - 3 * x2) { j2 = i2 <= n ? n - i2 : 0; r2 = i2 <= n ? 0 : i2 - n; k2 = true; }
+    // ok_k as far as it is known here: 1 true, 0 false, -1 open.  False without the border cell where the score cannot pass the ratio
+    // test whatever the path: a path into end cell (i, .) that starts on the top border consumes i rows = a diagonal steps + gr row gaps
+    // and scores s <= a - 2 gr = i - 3 gr, so gr <= (i - s) / 3 and it spans >= a = i - gr >= (2 i + s) / 3 columns (its overlap); one
+    // that starts on the left border spans all m_ref columns.  200 s < 179 * overlap for both => ok_k is false (the reads of a noisy
+    // region that check_align rejects: ~10 % mismatches in an overlap score 0.7 per base against the 0.895 it asks for).
     const bool p1 = i1 > 0 && 4 * s1 >= minlen, p2 = i2 > 0 && 4 * s2 >= minlen;
+    int o1 = !p1 ? 0 : k1 ? (200 * s1 >= 179 * (mt - j1) ? 1 : 0) : ((600 * s1 < 179 * (2 * i1 + s1) && 200 * s1 < 179 * mt) ? 0 : -1);
+    int o2 = !p2 ? 0 : k2 ? (200 * s2 >= 179 * (n - j2) ? 1 : 0) : ((600 * s2 < 179 * (2 * i2 + s2) && 200 * s2 < 179 * n) ? 0 : -1);
     bool n1 = false, n2 = false;
     if (force) { n1 = true; n2 = true; }
-    else if (p1 || p2) {
-        if (s1 == s2) { n1 = true; n2 = true; }
-        else if (s1 > s2) { n1 = true; n2 = p2 && !(k1 && p1 && 200 * s1 >= 179 * (mt - j1)); }
-        else { n2 = true; n1 = p1 && !(k2 && p2 && 200 * s2 >= 179 * (n - j2)); }
-    }
+    else if (o1 == 1 || o2 == 1) { n1 = s1 >= s2; n2 = s2 >= s1; }                // a match: the call with the larger score decides (both at equal scores)
+    else if (o1 == 0 && o2 == 0) { }                                             // no match: nothing else is read
+    else { n1 = o1 < 0; n2 = o2 < 0; }                                           // open: the border cell of the call(s) whose ok is not known
     res[0] = (n1 && !k1) ? BK_NW_NEEDS_DP : j1; res[1] = i1; res[2] = r1; res[3] = i1 == 0 ? 0 : s1;
     res[4] = (n2 && !k2) ? BK_NW_NEEDS_DP : j2; res[5] = i2; res[6] = r2; res[7] = i2 == 0 ? 0 : s2;
 }

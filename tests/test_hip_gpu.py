@@ -167,9 +167,8 @@ def test_nw_random_vs_oracle_gpu(hb):
             assert x1 == [e1[3], e1[4], e1[5], e1[6]], (len(a), len(b), "v1", tag)
             assert x2 == [e2[3], e2[4], e2[5], e2[6]], (len(a), len(b), "v2", tag)
     # 15: the score sweep alone, as the assembler calls it: scores and end cells always the reference's; a border cell that
-    # check_align can look at (bk_decide: the winner's; the loser's unless the winner's ok test is true; both at equal scores;
-    # none when neither score passes the first test) is either the reference's or flagged -1 (the full sweep follows); and the
-    # sweep settles the exact overlaps by itself (the case clean data consists of)
+    # check_align looks at (bk_decide: none when both ok tests fail; else the winner's, both at equal scores) is either the
+    # reference's or flagged -1 (the full sweep follows); and the sweep settles the exact overlaps by itself
     raw, _ = eng.nw_batch(dual, transposed=15)
     settled = flagged = 0
     for (a, b), (e1, e2), x in zip(dual, want, raw.tolist()):
@@ -179,14 +178,10 @@ def test_nw_random_vs_oracle_gpu(hb):
         p1, p2 = e1[4] > 0 and 4 * s1 >= minlen, e2[4] > 0 and 4 * s2 >= minlen
         ok1 = p1 and 200 * s1 >= 179 * (len(a) - e1[3])
         ok2 = p2 and 200 * s2 >= 179 * (len(b) - e2[3])
-        if not (p1 or p2):
-            need = (False, False)
-        elif s1 == s2:
-            need = (True, True)
-        elif s1 > s2:
-            need = (True, p2 and not ok1)
+        if not (ok1 or ok2):
+            need = (False, False)                            # no match: check_align reads nothing else
         else:
-            need = (p1 and not ok2, True)
+            need = (s1 >= s2, s2 >= s1)                      # the call with the larger score decides (both at equal scores)
         for j, e, nd in ((j1, e1, need[0]), (j2, e2, need[1])):
             if j == -1:
                 flagged += 1
@@ -341,17 +336,19 @@ def test_barrier_discipline_of_every_kernel_gpu():
     wavefronts of the workgroup stand at the same barrier site (a divergence is reported by bk_sync with both sites) while a
     pseudo-random subset of the wavefronts sleeps behind each barrier -- legal at any time, so whatever goes wrong with it is a
     race.  Three seeds (which wavefront sleeps where): the reference fixtures on both workgroup sizes, as shipped and with the
-    component split forced; a mixed batch of small regions against the oracle incl. the realign records.  This is the class of
-    defect found by accident in rounds 2, 3 and 4 (bk_retire twice, bk_find_reads) and once more in round 5 (the S->foreign loop of
-    bk_kmers_ordered: found by reading, confirmed by this build)."""
+    component split forced; a mixed batch of small regions against the oracle incl. the realign records; regions that overflow a
+    working cap (the give-up paths).  This is the class of defect found by accident in rounds 2, 3 and 4 (bk_retire twice,
+    bk_find_reads) and twice more in round 5: the S->foreign loop of bk_kmers_ordered (found by reading FOR the rule) and bk_fail's
+    bare write of S->status on the contig-overflow path of bk_retire (found by this build: BK_TEST_VARIANT=checkjit runs the WHOLE
+    suite through it)."""
     from breakmer_amd import build
     if not os.path.isfile(build.lib_path("checkjit")):
         import shutil
         if not os.path.isfile(build.HIPCC) and not shutil.which(build.HIPCC):
             pytest.skip("libbreakmer_hip_checkjit.so was not built and there is no hipcc on this machine")
         build.build_hip(variant="checkjit")
-    out = _race_check(["--variant", "checkjit", "--seeds", "1,2,3", "g3", "mixed"])
-    assert out.count("ok    ") >= 3 * (2 + 4)
+    out = _race_check(["--variant", "checkjit", "--seeds", "1,2,3", "g3", "mixed", "caps"])
+    assert out.count("ok    ") >= 3 * (2 + 4 + 4)
 
 
 def test_batches_that_faulted_in_round_4_gpu():
@@ -1380,6 +1377,8 @@ def test_assembler_occupancy_of_the_headline_shape_gpu(hb):
     regions = [synth.make_region(7900 + i, sv_type="del", depth=60, W=1500, L=150) for i in range(8)]
     for wg, want in ((256, 4), (512, 2)):
         eng = _run_regions(hb, regions, 31, stages=7, wg_threads=wg)
+        if "check" in os.environ.get("BK_TEST_VARIANT", "") and wg == 256:
+            want -= 1                                        # (the barrier-check build keeps its site table in static LDS: 3 instead of 4 per CU)
         assert eng.stat(25) == wg and eng.stat(23) == want, (wg, eng.stat(23))
         eng.close()
 

@@ -10,6 +10,9 @@ what:
   shape:N[:R]   the batches that faulted in round 4 (profiles/r04/split_fault): N small regions at 1 % noise, R runs (default 6)
                 on both workgroup sizes -- records identical between runs, 8 sampled regions equal to the oracle
   noisy:N       N full-size regions (500x, 150 bp) at 0.5 % noise: split (default) against one unit per region, bit for bit
+  caps          regions that overflow a working cap of the assembler (4,700 candidate reads on one k-mer; a contig of 5,300 bases):
+                the give-up paths (bk_fail) and the re-run under larger caps, against the oracle -- the path on which the whole-suite
+                run through the check build found a missing barrier in round 5
 
 With a jitter variant every `what` is repeated for every seed (BK_JITTER_SEED: which wavefronts sleep behind which barrier).
 With a check variant a barrier divergence surfaces as an error of bk_sync naming both sites.  Last line: RACE CHECK RESULT: ok | FAILED."""
@@ -112,6 +115,29 @@ def shape(tag, n, runs):
         eng.close()
 
 
+def caps(tag):
+    deep = synth.make_region(21, depth=6000, W=800, var_len=1.0)
+    longc = synth.make_region(22, sv_type="ins", sv_size=5000, W=1200, n_reads=1600)
+    plain = synth.make_region(3, depth=60, W=1500)
+    regions = [deep, plain, longc]
+    want = [bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)[0] for r in regions]
+    for wg in (256, 512):
+        eng = engine(31, wg_threads=wg)
+        submit(eng, regions)
+        eng.run(hb.BK_STAGE_ALL, sync=False)
+        nf = eng.sync()
+        wrong = sum(strip(eng.contigs(i)) != want[i] for i in range(3))
+        note(nf == 0 and wrong == 0 and eng.stat(26) == 2, "%s cap overflows, wg %d: %d failed, %d of 3 regions differ from the oracle, %d re-run under larger caps" % (tag, wg, nf, wrong, eng.stat(26)))
+        eng.close()
+        off = engine(31, wg_threads=wg, no_escalation=1)
+        submit(off, regions)
+        off.run(hb.BK_STAGE_ALL, sync=False)
+        nf = off.sync()
+        note(nf == 2 and off.region_status(0)[0] == 4 and off.region_status(2)[0] == 3 and strip(off.contigs(1)) == want[1],
+             "%s cap overflows without the re-run, wg %d: %d regions fail with their own status, the neighbour is untouched" % (tag, wg, nf))
+        off.close()
+
+
 def noisy(tag, n):
     regions = [synth.make_region(50000 + i, depth=500, L=150, sv_type=("del", "ins", "inv")[i % 3], noise=0.005) for i in range(n)]
     for wg in (256, 512):
@@ -154,6 +180,8 @@ def main():
                     shape(tag, int(f[1]), int(f[2]) if len(f) > 2 else 6)
                 elif w.startswith("noisy:"):
                     noisy(tag, int(w.split(":")[1]))
+                elif w == "caps":
+                    caps(tag)
                 else:
                     raise SystemExit("unknown check " + w)
             except hb.BreakmerHipError as e:
