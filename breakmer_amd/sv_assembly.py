@@ -114,6 +114,15 @@ class LazyContigs(object):
         self._n = engine.contig_count(region) if n is None else n
         self._items = None
 
+    @classmethod
+    def counted(cls, n):
+        """the contigs of a target whose engine has moved on: their number, nothing to look at any more"""
+        self = cls.__new__(cls)
+        self._eng = self._reads = self._items = None
+        self._region = self._k = self._serial = None
+        self._n = n
+        return self
+
     def _get(self):
         if self._items is None:
             if self._eng is None or self._eng.batch_serial != self._serial:

@@ -730,11 +730,51 @@ _SUMMARY_HEADER = "\t".join(['Target', 'N_contigs', 'Total_variants', 'N_indel',
 
 
 # ------------------------------------------------------------------------------------------------ runner
+class _Targets(object):
+    """runner.targets (sv_processor.py:165-170: name -> target, every target of the run): the same mapping, its objects made when
+    someone asks for one.  The batch lane of runner.run never does -- it keeps a target's outcome as (rows, number of contigs)
+    -- so a run over tens of thousands of plain targets does not pay for tens of thousands of objects nobody looks at; a target
+    looked at afterwards is the object the per-target sequence would have left behind (runner._make_target)."""
+
+    def __init__(self, run):
+        self._run, self._made = run, {}
+
+    def __getitem__(self, key):
+        t = self._made.get(key)
+        if t is None:
+            t = self._made[key] = self._run._make_target(key)       # KeyError for a name the run does not have
+        return t
+
+    def __setitem__(self, key, t):
+        self._made[key] = t
+
+    def __contains__(self, key): return key in self._run.params.targets
+    def __len__(self): return len(self._run.params.targets)
+    def __iter__(self): return iter(sorted(self._run.params.targets))
+    def keys(self): return sorted(self._run.params.targets)
+    def values(self): return [self[k] for k in self]
+    def items(self): return [(k, self[k]) for k in self]
+    def get(self, key, default=None): return self[key] if key in self else default
+
+
+class _LaneBatch(object):
+    """one batch of PLAIN targets (runner._lane_batch) on its way through the library: parallel lists instead of target objects"""
+    __slots__ = ("keys", "names", "regions", "data")
+
+    def __init__(self):
+        self.keys, self.names, self.regions, self.data = [], [], [], []
+
+    def __len__(self):
+        return len(self.keys)
+
+
 class runner(object):                                               # sv_processor.py:98-235
-    def __init__(self, config_d, region_data=None, engine_factory=None, rank=0, world=1, collate=None, native_calls=True, status_exchange=None):
+    def __init__(self, config_d, region_data=None, engine_factory=None, rank=0, world=1, collate=None, native_calls=True, status_exchange=None, batch_lane=True):
         self.params = params(config_d)
         self.results = []
-        self.targets = {}
+        self.targets = _Targets(self)
+        self.batch_lane = batch_lane            # plain targets go through the library as rows of a batch table (_lane_batch); False: every target as an object
+        self._lane_done = {}                    # key -> (rows, number of contigs, why it failed or None) of the targets the batch lane ran
         self.summary = {}
         self.summary_header = ''
         self.logger = logging.getLogger('root')
@@ -753,16 +793,107 @@ class runner(object):                                               # sv_process
                                                 # its window): logged as errors, listed at the end of the run, exit code 3 of breakmer.py
 
     def create_targets(self):                                        # :165-170
-        names = sorted(self.params.targets.keys())
-        for n in names:
-            self.targets[n] = target(self.params.targets[n], self.params, self.region_data.get(n))
-        return names
+        """the sorted target names; the objects themselves are made by self.targets when asked for"""
+        return sorted(self.params.targets.keys())
+
+    def _make_target(self, key):
+        """the target object of one name: before its batch has run, the object the per-target sequence starts from; after the
+        batch lane ran it, the object that sequence would have left behind (results, contig count, SV counts, inputs released)"""
+        done = self._lane_done.get(key)
+        t = target(self.params.targets[key], self.params, self.region_data.get(key) if done is None else None)
+        if done is not None:
+            rows, n_contigs, why = done
+            d = self.region_data.get(key)
+            t.failed = why
+            t.disc_reads, t.partner_windows, t.read_len = d.disc_reads, d.partners, d.max_read_len()
+            if why is None:
+                t.native_rows = t.results = rows
+                t.n_contigs = n_contigs
+                t.kmers['clusters'] = sv_assembly.LazyContigs.counted(n_contigs)
+                t.kmers['case_only'] = {}
+                t.get_sv_counts()
+        return t
+
+    # ---- the batch lane: plain targets as rows of a table (no per-target objects, one pass per batch for each step)
+    def _lane_ok(self):
+        """whether this run may use the batch lane at all: rows from the native call tail, no per-target files, nothing that needs
+        a per-target look at the genome or a repeat mask (those runs spend their time elsewhere anyway)"""
+        prm = self.params
+        return bool(self.batch_lane and self.native_calls and not prm.paths and prm.repeat_mask is None and prm.open_fasta() is None
+                    and not (prm.opts.get('sample_bam_file') and os.path.isfile(prm.opts['sample_bam_file'])))
+
+    def _lane_batch(self, eng, keys):
+        """the _LaneBatch of these targets if EVERY one of them is plain -- in-memory inputs with 2-bit packed reads
+        (hip_backend.PackedReads) as a read extraction that packs as it goes hands them over, a text window, no soft-clip
+        sequences, no partner windows, no object made for it yet -- and the engine takes packed batches; else None (the batch
+        goes the general way, target by target).  Targets without reads are left out as the general way leaves them out."""
+        if not (hasattr(eng, 'submit_packed') and hasattr(eng, 'set_call_context') and hasattr(eng, 'contig_counts')):
+            return None
+        lb = _LaneBatch()
+        rd, tg, made, PR = self.region_data, self.params.targets, self.targets._made, hip_backend.PackedReads
+        for key in keys:
+            d = rd.get(key)
+            if d is None or key in made or type(d.read_packed) is not PR or d.sc_seqs is not None or d.partners or type(d.window) is not str or d.read_codes is None:
+                return None
+            if not len(d.read_ids):
+                continue
+            ivs = tg[key]
+            v = ivs[0]
+            if len(ivs) == 1:
+                region = (v[0], v[1], v[2], v[3], ivs)
+            else:                                                      # target.setup (:267-294): first name and chromosome, the hull of the intervals
+                region = (v[0], min(x[1] for x in ivs), max(x[2] for x in ivs), v[3], ivs)
+            lb.keys.append(key); lb.names.append(v[3]); lb.regions.append(region); lb.data.append(d)
+        return lb
+
+    def _lane_submit(self, eng, lb):
+        """False: a window of the batch is empty -- the batch goes the per-target way, which skips the offender alone.  (The
+        CHARACTERS of the windows are not looked at here: the library does when it packs them, on its own thread; a foreign one
+        makes its submit fail, which _launch_batch hears of and then sends the batch the per-target way too.)"""
+        wins = [d.window_bytes() for d in lb.data]
+        if not all(wins):
+            return False
+        as_c, u8 = hip_backend._as_c, _np.uint8
+        eng.submit_packed([(d.read_packed, w, None if d._no_indel_only else as_c(d.indel_only, u8)) for d, w in zip(lb.data, wins)], wait=False)
+        return True
+
+    def _lane_finish(self, eng, lb, order):
+        rows = eng.call()
+        counts = eng.contig_counts()
+        failed = {}
+        if hasattr(eng, 'region_status') and not (hasattr(eng, 'stat') and eng.stat(22) == 0):
+            for i, name in enumerate(lb.names):
+                st, text = eng.region_status(i)
+                if st != 0:
+                    self.logger.error('target %s: not assembled on the device: %s' % (name, text))
+                    failed[i] = self.failed_targets[name] = text
+        done, summary, results, none = self._lane_done, self.summary, self.results, []
+        for i, key in enumerate(lb.keys):
+            if failed and i in failed:
+                done[key] = (none, 0, failed[i])
+                continue
+            r = rows.get(i, none)
+            ni = nr = nt = 0
+            if r:
+                oi = order[key]
+                for x in r:                                            # get_sv_counts (:686-705)
+                    tag = x[6]
+                    if tag == 'indel': ni += 1
+                    elif tag == 'trl': nt += 1
+                    elif tag.find('rearrangement') > -1: nr += 1
+                    else: raise KeyError(tag)
+                    results.append([oi, x])
+            summary[lb.names[i]] = "%s\t%d\t%d\t%d\t%d\t%d\t-" % (lb.names[i], counts[i], len(r), ni, nr, nt)
+            done[key] = (r, counts[i], None)
+        self.summary_header = _SUMMARY_HEADER
 
     def _submit_batch(self, eng, live):
         """hand one batch of targets to the library; with a HIP engine the 2-bit packing and the copies run on the library's
         own thread (BK_SUBMIT_ASYNC) while this thread goes on with the previous batch"""
         # (targets whose window was not looked at yet -- RegionData.checked_at_submit -- are checked here: all windows of the batch in
         # one scan; only if that finds a foreign character are they looked at one by one, and the offenders skipped ALONE as ever)
+        if type(live) is _LaneBatch:
+            return self._lane_submit(eng, live)
         late = [t for t in live if t.check_at_submit]
         if late and b"".join(t.data.window_bytes() for t in late).translate(None, b"ACGTNacgtn") or any(not t.data.window for t in late):
             for t in late:
@@ -798,6 +929,16 @@ class runner(object):                                               # sv_process
             eng.run(hip_backend.BK_STAGE_ALL, sync=False)
         except TypeError:
             eng.run(hip_backend.BK_STAGE_ALL)
+        except hip_backend.BreakmerHipError as ex:
+            # the (asynchronous) submit of a lane batch found a character other than A/C/G/T/N in a window: the per-target way names
+            # the target, skips it ALONE and hands the others over again
+            if type(live) is not _LaneBatch or "in the reference window" not in str(ex):
+                raise
+            live = self._prepare(live.keys)
+            if not live or self._submit_batch(eng, live) is False:
+                return []
+            self._launch_batch(eng, live)
+            return live
         if self.native_calls and hasattr(eng, 'set_call_context'):
             if self._ctx_head is None:                               # options + annotation tables: the same text for every batch
                 self._ctx_opts = cc.opts_line(self.params.opts)
@@ -808,11 +949,42 @@ class runner(object):                                               # sv_process
             else:
                 lines = [self._ctx_head]
                 eng._ctx_tables_of = self._ctx_token
-            for i, t in enumerate(live):
-                lines += cc.region_lines(i, t.get_values(), t.repeat_mask, t.disc_reads, t.partner_windows, t.data.read_ids)
+            if type(live) is _LaneBatch:
+                rl, add = cc.region_lines, lines.append
+                for i, d in enumerate(live.data):
+                    rg, dr = live.regions[i], d.disc_reads
+                    ivs = rg[4]
+                    if len(ivs) == 1 and getattr(d.read_ids, "uniform_tag", None) is not None and not (dr.get("inv") or dr.get("td") or dr.get("other") or dr.get("disc")):
+                        # the common shape -- one interval, one class of read ids, no discordant pairs -- in one piece (the lines region_lines makes)
+                        add("region %d %s %d %d %s\niv %d %d %d\nrtags 0" % (i, rg[0], rg[1], rg[2], rg[3], rg[1], rg[2], 1 if ivs[0][4] == 'exon' else 0))
+                    else:
+                        lines += rl(i, rg, None, dr, (), d.read_ids)
+            else:
+                for i, t in enumerate(live):
+                    lines += cc.region_lines(i, t.get_values(), t.repeat_mask, t.disc_reads, t.partner_windows, t.data.read_ids)
             eng.set_call_context("\n".join(lines) + "\n")
             if hasattr(eng, 'call_async'):                             # the wait for the GPU, the copy back and the call tail run on the library's thread
                 eng.call_async()
+
+    def _prepare(self, keys):
+        """the reference's per-target steps before the hot path (sv_processor.py:183-192) for the targets of one batch -> those that go on"""
+        live = []
+        for n in keys:
+            t = self.targets[n]
+            t.set_ref_data()
+            t.extract_bam_reads()
+            if not t.clean_reads():
+                t.rm_output_dir()
+                continue
+            t.check_at_submit = t.data.checked_at_submit()
+            why = None if t.check_at_submit else t.unsupported_reference()
+            if why:                                           # this target only; the run goes on (summary + exit code report it)
+                self.logger.error('target %s: skipped: %s' % (t.name, why))
+                self.failed_targets[t.name] = why
+                t.rm_output_dir()
+                continue
+            live.append(t)
+        return live
 
     def _start_batch(self, eng, live):
         self._submit_batch(eng, live)
@@ -822,6 +994,8 @@ class runner(object):                                               # sv_process
         """wait for a batch, then the reference's per-target sequence compare_kmers -> resolve_sv -> summary -> files"""
         if hasattr(eng, 'sync'):
             eng.sync()
+        if type(live) is _LaneBatch:
+            return self._lane_finish(eng, live, order)
         # a region that hit a device cap fails alone (bk_get_region_status): the target is logged and skipped like a
         # target without reads (sv_processor.py:190-192); the rank still takes part in the collation
         if hasattr(eng, 'region_status') and not (hasattr(eng, 'stat') and eng.stat(22) == 0):      # stat 22: regions that failed in the last run
@@ -858,7 +1032,7 @@ class runner(object):                                               # sv_process
             if t.has_results():
                 if 'output' in t.paths:
                     t.write_results()
-                self.results.extend([order[t.name], r] for r in t.results)
+                self.results.extend([order[t.name.upper()], r] for r in t.results)      # (the names of the run are the upper-cased BED names, utils.py:545-572)
             else:
                 t.rm_output_dir()
             t.release()
@@ -958,7 +1132,7 @@ class runner(object):                                               # sv_process
         # target order after the collation.
         order = {n: i for i, n in enumerate(names)}
         if self.world > 1:
-            cost = {n: int(self.targets[n].cost_estimate()) for n in names}
+            cost = {n: (len(self.region_data[n].read_ids) if n in self.region_data else int(self.targets[n].cost_estimate())) for n in names}
             load = [0] * self.world
             owner = {}
             for n in sorted(names, key=lambda x: (-cost[x], x)):
@@ -983,35 +1157,42 @@ class runner(object):                                               # sv_process
 
         def advance():
             eng, live = pending.pop(0)
-            self._launch_batch(eng, live)                            # the GPU starts on this batch ...
+            again = self._launch_batch(eng, live)                    # the GPU starts on this batch ...
+            if again is not None:                                     # (a lane batch that had to go the per-target way after all)
+                live = again
             if running:                                               # ... while the one before it (long finished) is picked up
                 done = running.pop()
                 self._finish_batch(done[0], done[1], order)
                 free.append(done[0])
-            running.append((eng, live))
+            if live:
+                running.append((eng, live))
+            else:
+                free.append(eng)
 
         ok, failure = False, None
         try:
+            lane = self._lane_ok()
             for b0 in range(0, len(mine), bsz):
-                live = []
-                for n in mine[b0:b0 + bsz]:
-                    t = self.targets[n]
-                    t.set_ref_data()
-                    t.extract_bam_reads()
-                    if not t.clean_reads():
-                        t.rm_output_dir()
+                eng = None
+                if lane:                                               # a batch of plain targets goes through as a table
+                    eng = free.pop() if free else self._make_engine()
+                    self.engine = eng
+                    lb = self._lane_batch(eng, mine[b0:b0 + bsz])
+                    if lb is not None and not len(lb):                 # nothing but targets without reads
+                        free.append(eng)
                         continue
-                    t.check_at_submit = t.data.checked_at_submit()
-                    why = None if t.check_at_submit else t.unsupported_reference()
-                    if why:                                           # this target only; the run goes on (summary + exit code report it)
-                        self.logger.error('target %s: skipped: %s' % (t.name, why))
-                        self.failed_targets[t.name] = why
-                        t.rm_output_dir()
+                    if lb is not None and self._submit_batch(eng, lb) is not False:
+                        pending.append((eng, lb))
+                        if len(pending) > depth:
+                            advance()
                         continue
-                    live.append(t)
+                live = self._prepare(mine[b0:b0 + bsz])
                 if not live:
+                    if eng is not None:
+                        free.append(eng)
                     continue
-                eng = free.pop() if free else self._make_engine()
+                if eng is None:
+                    eng = free.pop() if free else self._make_engine()
                 self.engine = eng
                 if self._submit_batch(eng, live) is False:            # every target of the batch was skipped at the submit-time window check
                     free.append(eng)

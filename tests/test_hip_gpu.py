@@ -1234,6 +1234,49 @@ def test_translocation_partner_discovery_gpu(hb, tmp_path):
     assert sp.runner(cfg2, native_calls=False).run() == rows
 
 
+def test_batch_lane_of_the_driver_gpu(hb, tmp_path):
+    """runner.run over 160 targets with packed reads (every SV type, a third with noise, one without reads; three translocation
+    targets with a partner window, which are not plain: their batch goes per target) in batches of 48 on several handles: the batch
+    lane (no target objects, the batch as a table) gives the rows, summary lines and target objects of the per-target way
+    (batch_lane=False), and the rows of the per-target way over the C oracle with the Python call tail."""
+    import numpy as np
+    from breakmer_amd import sv_processor as sp
+    from fake_engine import FakeEngine
+    n = 160
+    regions = [synth.make_region(900 + i, depth=(60, 100)[i % 2], W=1500, sv_type="trl" if i in (100, 110, 120) else synth.SV_TYPES[i % 4], noise=(0.0, 0.0, 0.004)[i % 3]) for i in range(n)]
+    bed, genes = [], ["header"]
+    for r in regions:
+        bed.append("\t".join([r.chrom, str(r.start), str(r.end), r.name, "exon"]))
+        genes.append("\t".join(["0", r.name, "chr" + r.chrom, "+", str(r.start), str(r.end)] + ["x"] * 6 + [r.name]))
+        for p_ in r.partners:
+            genes.append("\t".join(["0", p_[3], "chr" + p_[0], "+", str(p_[1]), str(p_[2])] + ["x"] * 6 + [p_[3]]))
+    (tmp_path / "t.bed").write_text("\n".join(bed) + "\n")
+    (tmp_path / "g.txt").write_text("\n".join(genes) + "\n")
+    cfg = {"analysis_name": "lane", "targets_bed_file": str(tmp_path / "t.bed"), "gene_annotation_file": str(tmp_path / "g.txt"), "kmer_size": "31",
+           "keep_repeat_regions": True, "batch_regions": 48}
+
+    def inputs(packed):
+        data = {}
+        for i, r in enumerate(regions):
+            reads, lens, ids = (r.reads, r.read_lens, r.read_ids) if i != 17 else (r.reads[:0], r.read_lens[:0], r.read_ids[:0])
+            pk = None if not packed else hb.pack_reads(reads, lens) if len(lens) else hb.PackedReads(np.zeros((0, 10), np.uint32), lens, None)
+            data[r.name.upper()] = sp.RegionData(ids, None, None, None, r.window_str, [(p_[0], p_[1], p_[2], p_[3], synth.codes_to_str(p_[4])) for p_ in r.partners],
+                                                 r.disc_reads, read_codes=reads, read_lens=lens, read_packed=pk)
+        return data
+    out = {}
+    for way in (True, False):
+        run = sp.runner(cfg, region_data=inputs(True), batch_lane=way)
+        rows = run.run()
+        assert set(run.targets._made) == {r.name.upper() for r in (regions[96:144] if way else regions)}      # objects only where a batch went per target
+        objs = {k: (t.name, t.chrom, t.start, t.end, t.results, len(t.kmers.get('clusters', [])), t.svs, t.failed) for k, t in run.targets.items()}
+        out[way] = (rows, run.summary, run.summary_header, run.failed_targets, objs)
+    assert out[True] == out[False]
+    rows = out[True][0]
+    assert len(rows) >= n - 10 and not out[True][3]
+    want = sp.runner(cfg, region_data=inputs(False), engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min')), native_calls=False).run()
+    assert [[str(x) for x in w] for w in want] == rows
+
+
 def test_translocation_without_discordant_pairs_genome_search_gpu(hb, tmp_path, monkeypatch):
     """N4, the genome-wide second pass as a GPU path: a translocation that only split reads speak of (every pair with its ends on two
     chromosomes removed from the alignment file) -- the first pass leaves the partner half of the contig unaligned, the driver looks

@@ -550,3 +550,105 @@ def test_framed_step_buffers_of_two_ranks_deframe_in_rank_order_gloo():
     from breakmer_amd import collate
     with pytest.raises(RuntimeError):
         collate.frame_steps([b"x" * 100], 64)
+
+
+class ScriptedEngine(object):
+    """an engine that answers from a script {window bytes: (rows, number of contigs, why the region failed or None)} through both
+    ways runner.run hands batches over (objects: submit; the batch lane: submit_packed): what the two ways make of the SAME answers
+    must be the same"""
+    batch_serial = 0
+
+    def __init__(self, script, log):
+        self.script, self.log, self.wins = script, log, []
+
+    def submit(self, ins, wait=True):
+        self.wins = [bytes(g.window) for g in ins]
+        self.batch_serial += 1
+        self.log.append(("submit", len(ins)))
+
+    def submit_packed(self, items, wait=False):
+        self.wins = [w for _p, w, _io in items]
+        self.batch_serial += 1
+        self.log.append(("submit", len(items)))
+
+    def run(self, stages, sync=True):
+        from breakmer_amd import hip_backend as hb
+        for i, w in enumerate(self.wins):                  # as the library: the (asynchronous) submit fails, the next call on the handle says so
+            if w.translate(None, b"ACGTNacgtn"):
+                raise hb.BreakmerHipError("bk_run: bk_submit_regions: region %d: character other than A/C/G/T/N in the reference window" % i)
+    def sync(self): pass
+    def close(self): pass
+    def contigs(self, r): return []
+    def hits(self, r, c): return []
+
+    def set_call_context(self, text):
+        self.log.append(("ctx", [ln for ln in text.split("\n") if ln.split(" ")[0] in ("region", "iv", "inv", "td", "other", "disc", "partner", "rtags")]))
+
+    def call(self):
+        return {i: [list(r) for r in self.script[w][0]] for i, w in enumerate(self.wins) if self.script[w][0]}
+
+    def contig_counts(self): return [self.script[w][1] for w in self.wins]
+    def contig_count(self, r): return self.script[self.wins[r]][1]
+    def stat(self, i): return sum(1 for w in self.wins if self.script[w][2]) if i == 22 else 0
+
+    def region_status(self, r):
+        why = self.script[self.wins[r]][2]
+        return (0, "ok") if why is None else (3, why)
+
+
+def test_batch_lane_equals_the_per_target_way(tmp_path):
+    """runner.run takes batches of plain targets (packed reads, text window, nothing else) through as rows of a table without
+    making a target object for each (the batch lane); rows, summary lines, skipped and failed targets, the call context handed to
+    the library and the target objects looked at AFTERWARDS are those of the per-target way (batch_lane=False).  Covered: targets
+    of several intervals, a lower-case BED name, a target without reads, without rows, with two rows, a region that failed on the
+    device, a window with a foreign character (the library refuses the batch, which then goes the per-target way and skips it alone), a target with soft-clip
+    sequences (not plain: its batch goes the per-target way), batches of 3."""
+    import numpy as np
+    from breakmer_amd import hip_backend as hb
+    ids = [(3, "del"), (4, "ins"), (5, "del"), (6, "inv"), (7, "del"), (8, "dup"), (9, "del"), (10, "del"), (11, "ins"), (12, "del"), (13, "del")]
+    regs = [synth.make_region(rid, sv_type=sv, depth=20, W=600) for rid, sv in ids]
+    bed, genes = [], ["header"]
+    for n, r in enumerate(regs):
+        name = r.name.lower() if n == 2 else r.name
+        bed.append("\t".join([r.chrom, str(r.start), str(r.end), name, "exon"]))
+        if n == 1:                                                       # a second interval of the same target
+            bed.append("\t".join([r.chrom, str(r.end + 500), str(r.end + 900), name, "intron"]))
+        genes.append("\t".join(["0", r.name, "chr" + r.chrom, "+", str(r.start), str(r.end)] + ["x"] * 6 + [r.name]))
+    (tmp_path / "t.bed").write_text("\n".join(bed) + "\n")
+    (tmp_path / "g.txt").write_text("\n".join(genes) + "\n")
+    cfg = {"analysis_name": "lane", "targets_bed_file": str(tmp_path / "t.bed"), "gene_annotation_file": str(tmp_path / "g.txt"), "kmer_size": "31",
+           "keep_repeat_regions": True, "batch_regions": 3}
+
+    def inputs():
+        data = {}
+        for n, r in enumerate(regs):
+            reads, lens, ids_ = (r.reads, r.read_lens, r.read_ids) if n != 4 else (r.reads[:0], r.read_lens[:0], r.read_ids[:0])      # target 4: no reads
+            w = r.window_str if n != 7 else r.window_str[:50] + "R" + r.window_str[51:]                                                # target 7: a foreign character
+            data[r.name.upper()] = sp.RegionData(ids_, None, None, ["ACGT" * 12] if n == 9 else None, w, [], r.disc_reads, read_codes=reads, read_lens=lens,
+                                                 read_packed=hb.pack_reads(reads, lens) if len(lens) else hb.PackedReads(np.zeros((0, 10), np.uint32), lens, None))
+        return data
+    row = lambda r, c, tag: [r.name, "%s:%d" % (r.chrom, r.start + 100 * c), "D10", "0", "+", "0", tag, "7", "30", "0", "40", "%s_contig%d" % (r.name, c), "ACGT"]
+    script = {}
+    for n, r in enumerate(regs):
+        rows = [] if n == 3 else [row(r, 1, "indel"), row(r, 2, "rearrangement_inversion")] if n == 5 else [row(r, 1, "trl" if n == 6 else "indel")]
+        w = inputs()[r.name.upper()].window.encode()
+        script[w] = ([], 0, "contig longer than max_contig_len") if n == 8 else (rows, len(rows) + (n % 2), None)
+    out = {}
+    for way in (False, True):
+        log = []
+        run = sp.runner(cfg, region_data=inputs(), engine_factory=lambda prm: ScriptedEngine(script, log), batch_lane=way)
+        rows = run.run()
+        # batches 1, 2 and 4 of the lane run are plain (no object made); 3 holds the bad window, 4 the soft-clip target: per target
+        assert set(run.targets._made) == ({r.name.upper() for r in regs[6:]} if way else {r.name.upper() for r in regs})
+        assert [n for k, n in log if k != "ctx"] == ([3, 2, 3, 2, 2] if way else [3, 2, 2, 2])
+        objs = {}
+        for k in run.targets:
+            t = run.targets[k]
+            objs[k] = (t.name, t.chrom, t.start, t.end, t.results, t.has_results(), len(t.kmers.get('clusters', [])), t.svs, t.failed, t.data is None or len(t.data.read_ids) == 0)
+        out[way] = (rows, run.summary, run.summary_header, run.failed_targets, objs, [x for x in log if x[0] == "ctx"])
+    assert out[True] == out[False]
+    rows, summary, header, failed, objs, _ctx = out[True]
+    assert len(rows) == 8 and [r[11] for r in rows] == sorted(r[11] for r in rows)
+    assert set(failed) == {regs[7].name, regs[8].name} and "A/C/G/T/N" in failed[regs[7].name] and "max_contig_len" in failed[regs[8].name]
+    assert regs[2].name.lower() in summary and regs[4].name not in summary and regs[8].name not in summary
+    assert summary[regs[5].name].split("\t")[2:6] == ["2", "1", "1", "0"] and objs[regs[1].name][3] == regs[1].end + 900
