@@ -76,15 +76,16 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
-def call_context_text(regions, opts):
-    """query_region / annotation / discordant-pair context of the batch for the native call tail."""
+def call_context_text(regions, opts, keep_tables=False):
+    """query_region / annotation / discordant-pair context of the batch for the native call tail.  keep_tables: the handle keeps the
+    gene table of its previous context (the same for every batch of a run: sv_processor.runner sends it once per handle too)"""
     from breakmer_amd import call_context as cc
     genes = {}
     for r in regions:
         genes[r.name] = ["chr" + r.chrom, r.start, r.end]
         for p in r.partners:
             genes[p[3]] = ["chr" + p[0], p[1], p[2]]
-    lines = [cc.opts_line(opts)] + cc.tables_lines(genes, None)
+    lines = [cc.opts_line(opts)] + (["keep_tables"] if keep_tables else cc.tables_lines(genes, None))
     for i, r in enumerate(regions):
         qr = (r.chrom, r.start, r.end, r.name, [(r.chrom, r.start, r.end, r.name, "exon")])
         lines += cc.region_lines(i, qr, None, r.disc_reads, [(p[0], p[1]) for p in r.partners], r.read_ids)
@@ -471,10 +472,12 @@ def main():
     with_submit = None
     if not dist:
         pins = [hb.RegionInput(None, r.window, packed=hb.pack_reads(r.reads, r.read_lens)) for r in regions]
+        ctx_keep = call_context_text(regions, opts, keep_tables=True)      # (every handle got the tables with ctx_text above)
         def run_steps_submit(k):
-            """step s: collect the results of engine s % n (fetch + call tail) and hand it its next batch (asynchronous submit on the
-            library's thread); the engine half a turn ahead, whose submit was started n/2 steps ago, gets its context and is
-            launched.  So n/2 submits and n/2 runs are in flight at any time."""
+            """step s: pick up the calls of engine s % n and hand it its next batch (asynchronous submit on the library's thread);
+            the engine half a turn ahead, whose submit was started n/2 steps ago, gets its context and is launched, and the
+            library's thread of that handle waits for its kernels, takes the records and makes the calls (bk_call_async) -- the way
+            sv_processor.runner drives the library.  So n/2 submits and n/2 runs are in flight at any time."""
             n = len(engs); half = max(1, n // 2)
             state = ["idle"] * n                            # idle -> submitted -> running
             raw = b""
@@ -483,12 +486,12 @@ def main():
             while done < k:
                 i = t % n; e = engs[i]
                 if state[i] == "running":
-                    e.fetch(); raw = e.call_blob(); done += 1; state[i] = "idle"
+                    raw = e.call_blob(); done += 1; state[i] = "idle"
                 if state[i] == "idle" and started < k:
                     e.submit(pins, wait=False); state[i] = "submitted"; started += 1
                 j = (t + half) % n; f = engs[j]
                 if state[j] == "submitted":
-                    f.set_call_context(ctx_text); f.run(stages, sync=False); state[j] = "running"
+                    f.set_call_context(ctx_keep); f.run(stages, sync=False); f.call_async(); state[j] = "running"
                 t += 1
             return raw
         run_steps_submit(len(engs))
@@ -500,7 +503,7 @@ def main():
         wdt = time.perf_counter() - tws
         with_submit = {"value": round(n_regions * ksub / wdt, 1), "unit": "regions/s", "steps": ksub, "ms_per_step": round(wdt / ksub * 1e3, 3),
                        "bytes_per_step": int(sum(p_.reads.nbytes for p_ in pins)), "same_rows_as_resident": raw_ws == last_rows.get("raw"),
-                       "note": "every step submits its batch again (BK_SUBMIT_PACKED | BK_SUBMIT_ASYNC: 2-bit packed rows copied + H2D on the library's thread), context set again, then the same stages + call tail"}
+                       "note": "every step submits its batch again (BK_SUBMIT_PACKED | BK_SUBMIT_ASYNC: 2-bit packed rows copied + H2D on the library's thread), context set again, then the same stages + call tail (bk_call_async, as sv_processor.runner drives it)"}
         for e in engs:                                      # back to the resident inputs for what follows
             e.submit(ins); e.set_call_context(ctx_text); e.run(stages)
     # ---- the same steps strictly one after the other (one handle, nothing in flight): the kernel durations of THIS pass

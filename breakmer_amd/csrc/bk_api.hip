@@ -45,6 +45,8 @@ using at512::bk_nw_batch_kernel;
 #include <cstdlib>
 #include <atomic>
 #include <chrono>
+#include <climits>
+#include <condition_variable>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -106,6 +108,11 @@ struct bk_handle {
     uint32_t group_words = 0;                   // LDS words wanted by the in-LDS read-grouping table (largest region that qualifies)
     // host mirrors
     std::vector<BkRegionDesc> h_desc; std::vector<BkRegionWork> h_work; HostVec h_out;
+    // What the host reads of EVERY batch -- the work records, the bump pointers, the contig records -- is written into pinned host
+    // memory by the batch's last kernel (bk_mirror_kernel) instead of being fetched by small copies after it: a copy engine that is
+    // in the middle of another handle's 100 MB submit made each of those wait its turn (1.3-1.5 ms per batch with submits in flight).
+    // m_out and h_out swap roles at bk_fetch (a run in flight never writes into the copy bk_call is still reading).
+    HostVec m_work, m_tops, m_out; bool mirror_fresh = false; uint64_t m_out_cap = 0;
     HostVec hs_reads, hs_rlen, hs_rflag;        // pinned staging of a submit (packed reads, lengths, flags): kept and reused, so a
                                                 // submit neither page-faults a fresh 100 MB vector nor copies from pageable memory
     std::vector<BkPartnerDesc> h_part;
@@ -226,7 +233,7 @@ extern "C" int bk_destroy(bk_handle *h)
     DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
                       &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist, &h->d_nlist, &h->d_wnlist, &h->d_rmap};
     for (auto b : bufs) b->release();
-    h->h_out.release(); h->hs_reads.release(); h->hs_rlen.release(); h->hs_rflag.release();
+    h->h_out.release(); h->hs_reads.release(); h->hs_rlen.release(); h->hs_rflag.release(); h->m_work.release(); h->m_tops.release(); h->m_out.release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -320,6 +327,30 @@ static hipError_t upload_raw(bk_handle *h, DevBuf &b, const void *src, size_t by
     return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream);
 }
 
+// The helper threads of one submit: spawned once, then handed one job after the other (spawning sixteen threads per phase cost as
+// much as a phase).  run(): the helpers and the caller execute the job; start() / wait(): the helpers alone, the caller does
+// something else meanwhile (issues the copies of the chunks they finish).
+class BkTeam {
+    std::vector<std::thread> th_; std::mutex m_; std::condition_variable cv_, done_cv_;
+    const std::function<void()> *job_ = nullptr; uint64_t serial_ = 0; int busy_ = 0; bool stop_ = false;
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void()> *job;
+            { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return stop_ || serial_ != seen; }); if (stop_) return; seen = serial_; job = job_; }
+            (*job)();
+            { std::lock_guard<std::mutex> lk(m_); if (--busy_ == 0) done_cv_.notify_all(); }
+        }
+    }
+public:
+    explicit BkTeam(int helpers) { for (int i = 0; i < helpers; i++) th_.emplace_back([this] { loop(); }); }
+    ~BkTeam() { { std::lock_guard<std::mutex> lk(m_); stop_ = true; } cv_.notify_all(); for (auto &t : th_) t.join(); }
+    void start(const std::function<void()> &fn) { if (th_.empty()) return; { std::lock_guard<std::mutex> lk(m_); job_ = &fn; busy_ = (int)th_.size(); serial_++; } cv_.notify_all(); }
+    void wait() { if (th_.empty()) return; std::unique_lock<std::mutex> lk(m_); done_cv_.wait(lk, [&] { return busy_ == 0; }); }
+    void run(const std::function<void()> &fn) { start(fn); fn(); wait(); }
+};
+
+static hipError_t ensure_mirrors(bk_handle *h);
 static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags);
 extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions) { (void)join_pending(h); return submit_regions(h, regions, n_regions, 0); }
 extern "C" int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags)
@@ -350,21 +381,19 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     uint64_t dd_total = 0; uint32_t max_w = 0;
     size_t tot_reads = 0, tot_words = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;
     const int nth = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), n_regions}));
-    auto run_parallel = [&](const std::function<void()> &fn) {
-        if (nth == 1) { fn(); return; }
-        std::vector<std::thread> th; for (int t = 0; t < nth; t++) th.emplace_back(fn); for (auto &x : th) x.join();
-    };
+    BkTeam team(nth - 1);                                // the helper threads of this submit, spawned once (this thread is the nth)
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r];
         if (g.n_reads < 0 || !g.window || g.window_len <= 0 || (g.n_reads > 0 && (!g.reads || !g.read_lens))) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": missing reads/window");
         if (packed && read_codes) return fail(h, BK_E_ARG, "bk_submit_regions: BK_SUBMIT_PACKED and BK_SUBMIT_READ_CODES exclude each other");
         if (g.n_reads >= (1 << 22)) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 4M reads in one region");
+        if (g.n_partners > 15) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 15 partner windows");
     }
     // per region: longest read, number of bases (one pass over the lengths, regions in parallel)
     std::vector<uint32_t> r_maxl(n_regions, 0); std::vector<uint64_t> r_bases(n_regions, 0);
     {
         std::atomic<int> next{0};
-        run_parallel([&]() {
+        team.run([&]() {
             for (;;) {
                 const int r = next.fetch_add(1);
                 if (r >= n_regions) break;
@@ -387,14 +416,15 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     uint32_t *reads = (uint32_t *)h->hs_reads.data(); uint16_t *rlen = (uint16_t *)h->hs_rlen.data(); uint8_t *rflag = h->hs_rflag.data();
     if (!tot_words) reads[0] = 0;
     if (!tot_reads) { rlen[0] = 0; rflag[0] = 0; }
-    sc.reserve(tot_scw); sclen.reserve(tot_sc); win.reserve(tot_win);
-    size_t reads_top = 0, meta_top = 0;
+    sc.reserve(tot_scw); sclen.reserve(tot_sc); win.assign(tot_win, 0);
+    // Layout of the batch (offsets only; the sequences are packed below, regions in parallel)
+    size_t reads_top = 0, meta_top = 0, win_top = 0;
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r]; BkRegionDesc &d = n_desc[r];
         const uint32_t maxl = r_maxl[r];
         d.n_reads = g.n_reads; d.read_words = (maxl + 15) / 16 + 1;          // +1: k-mer extraction may touch one word past the end
         d.max_len = maxl;
-        d.reads_word_off = reads_top; d.read_meta_off = meta_top;            // reads, lengths and flags are filled below, regions in parallel
+        d.reads_word_off = reads_top; d.read_meta_off = meta_top;
         reads_top += (size_t)d.n_reads * d.read_words; meta_top += d.n_reads;
         d.n_sc = g.n_sc < 0 ? -1 : g.n_sc; d.sc_word_off = sc.size(); d.sc_meta_off = sclen.size(); d.sc_words = 1;
         if (g.n_sc > 0) {
@@ -405,74 +435,108 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
                 sclen.push_back(g.sc_lens[i]);
             }
         }
-        d.win_len = g.window_len; d.win_word_off = win.size();
-        {   // an N of the window (an assembly gap near the target) is packed as code 0 and listed: its k-mers do not exist, it matches nothing
-            size_t nw = (g.window_len + 15) / 16 + 2; win.resize(win.size() + nw);
-            std::vector<uint32_t> wn;
-            if (!pack_seq(g.window, g.window_len, win.data() + d.win_word_off, (int)nw, &wn, 0, false, true)) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": character other than A/C/G/T/N in the reference window");
-            d.win_n_off = wnlist.size(); d.n_win_n = (uint32_t)wn.size(); wnlist.insert(wnlist.end(), wn.begin(), wn.end());
-        }
+        d.win_len = g.window_len; d.win_word_off = win_top; win_top += (g.window_len + 15) / 16 + 2;
         max_w = std::max<uint32_t>(max_w, g.window_len);
         n_max_win = std::max<uint32_t>(n_max_win, g.window_len);
-        n_targets[r].push_back(make_target(g.window, g.window_len));
-        if (g.n_partners > 15) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 15 partner windows");
         d.n_partners = g.n_partners; d.part_desc_off = n_part.size();
         for (int q = 0; q < g.n_partners; q++) {
-            BkPartnerDesc pd; pd.word_off = win.size(); pd.len = g.partner_lens[q];
-            size_t nw = (pd.len + 15) / 16 + 2; win.resize(win.size() + nw);
-            std::vector<uint32_t> wn;
-            if (!pack_seq(g.partners[q], pd.len, win.data() + pd.word_off, (int)nw, &wn, 0, false, true)) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": character other than A/C/G/T/N in a partner window");
-            pd.n_off = wnlist.size(); pd.n_n = (uint32_t)wn.size(); wnlist.insert(wnlist.end(), wn.begin(), wn.end());
+            BkPartnerDesc pd; pd.word_off = win_top; pd.len = g.partner_lens[q]; pd.n_n = 0; pd.n_off = 0;
+            win_top += (pd.len + 15) / 16 + 2;
             n_part.push_back(pd);
-            n_targets[r].push_back(make_target(g.partners[q], (int)pd.len)); n_max_win = std::max<uint32_t>(n_max_win, pd.len);
+            n_max_win = std::max<uint32_t>(n_max_win, pd.len);
         }
+        n_targets[r].resize(1 + (size_t)std::max(g.n_partners, 0));
         uint32_t cap = 64; while ((uint64_t)cap * 7 < (uint64_t)std::max(g.n_reads, 1) * 10) cap <<= 1;      // load factor <= 0.7 even if every read is unique
         d.dedup_cap = cap; d.dedup_off = dd_total; dd_total += cap;
         // algorithmic HBM bytes per region: 2-bit reads + 4 B/read offsets + window fwd+rc + ~2 KB of output
         n_alg_bytes += (r_bases[r] + 3) / 4 + 4ull * g.n_reads + 2ull * ((g.window_len + 3) / 4) + 2048;
     }
     const auto t_pack0 = std::chrono::steady_clock::now();
-    std::vector<std::vector<uint32_t>> region_nl;
-    {   // 2-bit packing of the reads: the bulk of the host work of a submit (0.4 GB of ASCII for 256 regions), regions are independent
-        std::atomic<int> next{0}, bad_region{-1}, bad_read{-1};
-        region_nl.assign(n_regions, {});
-        run_parallel([&]() {
-            for (;;) {
-                const int r = next.fetch_add(1);
-                if (r >= n_regions) break;
-                const bk_region &g = regions[r]; const BkRegionDesc &d = n_desc[r];
-                for (int i = 0; i < g.n_reads; i++) { rlen[d.read_meta_off + i] = g.read_lens[i]; rflag[d.read_meta_off + i] = g.indel_only && g.indel_only[i] ? BK_RF_INDEL : 0; }
-                if (packed) {        // rows are 2 bit/base already: copied into the library's row stride, the tail zeroed
-                    for (int i = 0; i < g.n_reads; i++) {
-                        const uint32_t nw = ((uint32_t)g.read_lens[i] + 15u) / 16u; uint32_t *dst = reads + d.reads_word_off + (size_t)i * d.read_words;
-                        memcpy(dst, g.reads + (size_t)i * g.read_stride, (size_t)nw * 4);
-                        if (g.read_lens[i] & 15) dst[nw - 1] &= 0xFFFFFFFFu << (2 * (16 - (g.read_lens[i] & 15)));      // bases beyond the length must read as A (the kernels compare whole words)
-                        for (uint32_t w = nw; w < d.read_words; w++) dst[w] = 0;
-                    }
-                    if (g.read_n && g.n_read_n > 0) {
-                        region_nl[r].assign(g.read_n, g.read_n + g.n_read_n);
-                        for (int e = 0; e < g.n_read_n; e++) {
-                            const uint32_t v = g.read_n[e], ri = v >> 10, pos = v & 1023u;
-                            if ((int)ri >= g.n_reads || pos >= g.read_lens[ri] || (e && g.read_n[e - 1] >= v)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = (int)ri; break; }
-                            uint32_t *dst = reads + d.reads_word_off + (size_t)ri * d.read_words;
-                            dst[pos >> 4] &= ~(3u << (30 - 2 * (pos & 15)));                              // an N is packed as A
-                        }
-                    }
-                    continue;
+    // The bulk of a submit: the reads into the pinned staging buffer (2-bit packing of 0.4 GB of ASCII, or row copies of 0.1 GB of
+    // packed rows, per 256 regions), the windows packed, the host's copies of the windows made -- regions are independent and go
+    // over the helper threads in index order.  The staging buffer goes to the device in CHUNKS of regions as they are finished
+    // (this thread issues the copies), so the transfer of the first chunk runs while the last ones are still being filled.
+    HIPCHK(h, h->d_reads.ensure(std::max<size_t>(tot_words * 4, 256)));
+    std::vector<std::vector<uint32_t>> region_nl(n_regions), region_wn(n_regions);
+    std::vector<std::vector<uint32_t>> region_wn_cnt(n_regions);          // N positions per window of the region (window, then its partners): lengths of the pieces of region_wn
+    const int n_chunks = std::max(1, std::min(8, n_regions / 8));
+    std::vector<int> chunk_end(n_chunks, n_regions);
+    { size_t acc = 0; int c = 0; for (int r = 0; r < n_regions && c < n_chunks - 1; r++) { acc += (size_t)n_desc[r].n_reads * n_desc[r].read_words; if (acc * n_chunks >= tot_words * (size_t)(c + 1)) chunk_end[c++] = r + 1; } }
+    std::vector<std::atomic<int>> chunk_done(n_chunks);
+    for (auto &c : chunk_done) c.store(0);
+    std::vector<int> chunk_of(n_regions, 0);
+    { int c = 0; for (int r = 0; r < n_regions; r++) { while (r >= chunk_end[c]) c++; chunk_of[r] = c; } }
+    // the first (smallest region index) offender of each kind: region << 32 | read, region << 1 | (partner window)
+    std::atomic<int> next{0}; std::atomic<uint64_t> bad_read{UINT64_MAX}, bad_window{UINT64_MAX};
+    auto note_min = [](std::atomic<uint64_t> &a, uint64_t v) { uint64_t cur = a.load(); while (v < cur && !a.compare_exchange_weak(cur, v)) {} };
+    const std::function<void()> pack_region = [&]() {
+        for (;;) {
+            const int r = next.fetch_add(1);
+            if (r >= n_regions) break;
+            const bk_region &g = regions[r]; const BkRegionDesc &d = n_desc[r];
+            for (int i = 0; i < g.n_reads; i++) { rlen[d.read_meta_off + i] = g.read_lens[i]; rflag[d.read_meta_off + i] = g.indel_only && g.indel_only[i] ? BK_RF_INDEL : 0; }
+            if (packed) {        // rows are 2 bit/base already: copied into the library's row stride, the tail zeroed
+                for (int i = 0; i < g.n_reads; i++) {
+                    const uint32_t nw = ((uint32_t)g.read_lens[i] + 15u) / 16u; uint32_t *dst = reads + d.reads_word_off + (size_t)i * d.read_words;
+                    memcpy(dst, g.reads + (size_t)i * g.read_stride, (size_t)nw * 4);
+                    if (g.read_lens[i] & 15) dst[nw - 1] &= 0xFFFFFFFFu << (2 * (16 - (g.read_lens[i] & 15)));      // bases beyond the length must read as A (the kernels compare whole words)
+                    for (uint32_t w = nw; w < d.read_words; w++) dst[w] = 0;
                 }
+                if (g.read_n && g.n_read_n > 0) {
+                    region_nl[r].assign(g.read_n, g.read_n + g.n_read_n);
+                    for (int e = 0; e < g.n_read_n; e++) {
+                        const uint32_t v = g.read_n[e], ri = v >> 10, pos = v & 1023u;
+                        if ((int)ri >= g.n_reads || pos >= g.read_lens[ri] || (e && g.read_n[e - 1] >= v)) { note_min(bad_read, ((uint64_t)r << 32) | ri); break; }
+                        uint32_t *dst = reads + d.reads_word_off + (size_t)ri * d.read_words;
+                        dst[pos >> 4] &= ~(3u << (30 - 2 * (pos & 15)));                              // an N is packed as A
+                    }
+                }
+            } else {
                 for (int i = 0; i < g.n_reads; i++)
-                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i, read_codes)) { int exp = -1; if (bad_region.compare_exchange_strong(exp, r)) bad_read = i; break; }
+                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i, read_codes)) { note_min(bad_read, ((uint64_t)r << 32) | (uint32_t)i); break; }
             }
-        });
-        if (bad_region >= 0) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_region.load()) + " read " + std::to_string(bad_read.load()) + (packed ? ": N list not ascending or out of range" : ": base other than A/C/G/T/N"));
+            chunk_done[chunk_of[r]].fetch_add(1, std::memory_order_release);          // the rows of this region are in the staging buffer
+            // the windows: an N (an assembly gap near the target) is packed as code 0 and listed: its k-mers do not exist, it matches nothing
+            for (int q = -1; q < g.n_partners; q++) {
+                const char *ws = q < 0 ? g.window : g.partners[q]; const int wl = q < 0 ? g.window_len : (int)g.partner_lens[q];
+                const uint64_t off = q < 0 ? d.win_word_off : n_part[d.part_desc_off + (size_t)q].word_off;
+                const size_t before = region_wn[r].size();
+                if (!pack_seq(ws, wl, win.data() + off, (wl + 15) / 16 + 2, &region_wn[r], 0, false, true)) { note_min(bad_window, ((uint64_t)r << 1) | (q < 0 ? 0u : 1u)); break; }
+                region_wn_cnt[r].push_back((uint32_t)(region_wn[r].size() - before));
+                n_targets[r][(size_t)(q + 1)] = make_target(ws, wl);
+            }
+        }
+    };
+    if (nth == 1) {
+        pack_region();
+        if (tot_words) HIPCHK(h, hipMemcpyAsync(h->d_reads.p, reads, tot_words * 4, hipMemcpyHostToDevice, h->stream));
+    } else {
+        team.start(pack_region);
+        hipError_t cerr = hipSuccess; size_t sent = 0;      // words of the staging buffer handed to the copy engine so far
+        for (int c = 0; c < n_chunks; c++) {
+            const int first = c ? chunk_end[c - 1] : 0, want = chunk_end[c] - first;
+            while (chunk_done[c].load(std::memory_order_acquire) < want) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            const size_t upto = chunk_end[c] < n_regions ? (size_t)n_desc[chunk_end[c]].reads_word_off : tot_words;
+            if (cerr == hipSuccess && upto > sent) cerr = hipMemcpyAsync((uint8_t *)h->d_reads.p + sent * 4, reads + sent, (upto - sent) * 4, hipMemcpyHostToDevice, h->stream);
+            sent = upto;
+        }
+        team.wait();
+        HIPCHK(h, cerr);
     }
-    // N calls: one sorted list per region (reads are packed in order, positions ascending), flag on the reads that have any
+    if (bad_window.load() != UINT64_MAX) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_window.load() >> 1) + ((bad_window.load() & 1) ? ": character other than A/C/G/T/N in a partner window" : ": character other than A/C/G/T/N in the reference window"));
+    if (bad_read.load() != UINT64_MAX) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_read.load() >> 32) + " read " + std::to_string(bad_read.load() & 0xFFFFFFFFu) + (packed ? ": N list not ascending or out of range" : ": base other than A/C/G/T/N"));
+    // N calls: one sorted list per region (reads are packed in order, positions ascending), flag on the reads that have any;
+    // the N positions of the windows, window by window
     std::vector<uint32_t> nlist;
     for (int r = 0; r < n_regions; r++) {
         BkRegionDesc &d = n_desc[r];
         d.nlist_off = nlist.size(); d.n_nlist = (uint32_t)region_nl[r].size();
         for (uint32_t e : region_nl[r]) rflag[d.read_meta_off + (e >> 10)] |= BK_RF_HASN;
         nlist.insert(nlist.end(), region_nl[r].begin(), region_nl[r].end());
+        d.win_n_off = wnlist.size(); d.n_win_n = region_wn_cnt[r][0];
+        size_t o = d.n_win_n;
+        for (uint32_t q = 0; q < d.n_partners; q++) { BkPartnerDesc &pd = n_part[d.part_desc_off + q]; pd.n_off = wnlist.size() + o; pd.n_n = region_wn_cnt[r][q + 1]; o += pd.n_n; }
+        wnlist.insert(wnlist.end(), region_wn[r].begin(), region_wn[r].end());
     }
     if (nlist.empty()) nlist.push_back(0);
     h->total_reads = tot_reads; h->n_regions = n_regions;
@@ -505,7 +569,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     if (wnlist.empty()) wnlist.push_back(0);
     const auto t_h2d0 = std::chrono::steady_clock::now();
     HIPCHK(h, upload(h, h->d_desc, n_desc)); HIPCHK(h, upload(h, h->d_part, n_part));
-    HIPCHK(h, upload_raw(h, h->d_reads, reads, std::max<size_t>(tot_words, 1) * 4)); HIPCHK(h, upload_raw(h, h->d_rlen, rlen, std::max<size_t>(tot_reads, 1) * 2));
+    HIPCHK(h, upload_raw(h, h->d_rlen, rlen, std::max<size_t>(tot_reads, 1) * 2));      // (the reads went over in chunks above)
     HIPCHK(h, upload_raw(h, h->d_rflag, rflag, std::max<size_t>(tot_reads, 1)));
     HIPCHK(h, upload(h, h->d_sc, sc)); HIPCHK(h, upload(h, h->d_sclen, sclen)); HIPCHK(h, upload(h, h->d_win, win));
     HIPCHK(h, upload(h, h->d_nlist, nlist)); HIPCHK(h, upload(h, h->d_wnlist, wnlist));
@@ -524,6 +588,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     }
     if (h->out_cap == 0) h->out_cap = h->cfg.out_kbytes > 0 ? (uint64_t)h->cfg.out_kbytes << 10 : std::max<uint64_t>(8ull << 20, (uint64_t)n_regions * (64ull << 10));
     HIPCHK(h, h->d_arena.ensure(h->arena_cap)); HIPCHK(h, h->d_out.ensure(h->out_cap));
+    HIPCHK(h, ensure_mirrors(h));                        // (here, not at the first launch: pinned allocations take milliseconds and wait for the device)
     HIPCHK(h, hipStreamSynchronize(h->stream));          // host staging vectors go out of scope
     { const auto t1 = std::chrono::steady_clock::now();
       h->submit_pack_ms = std::chrono::duration<double, std::milli>(t_h2d0 - t_pack0).count(); h->submit_h2d_ms = std::chrono::duration<double, std::milli>(t1 - t_h2d0).count(); }
@@ -642,8 +707,35 @@ static int launch_asm(bk_handle *h, int threads, int max_cand, int max_contig, l
 // subset == nullptr: the whole batch.  Else: only these regions, from the k-mer stage on (it resets their state), each as ONE unit
 // (no component split), with the escalated caps if `escalate`, on top of what the batch's run left in the arenas (bump
 // pointers and the contig list go on).
+// The pinned host buffers bk_mirror_kernel writes into: the work records, the bump pointers, and BOTH buffers that take turns as
+// the host copy of the contig records (up to 8 MB of them: a batch with more -- tens of thousands of contigs -- is fetched by a copy).
+static hipError_t ensure_mirrors(bk_handle *h)
+{
+    const uint64_t want = std::min<uint64_t>(h->out_cap & ~15ull, 8ull << 20);
+    hipError_t e = hipSuccess;
+    if (h->m_out.cap < want) e = h->m_out.resize(want);
+    if (e == hipSuccess && h->h_out.cap < want) { e = h->h_out.resize(want); h->h_out.n = 0; }
+    if (e == hipSuccess) e = h->m_work.resize(sizeof(BkRegionWork) * (size_t)std::max(h->n_regions, 1));
+    if (e == hipSuccess) e = h->m_tops.resize(11 * sizeof(unsigned long long));
+    h->m_out_cap = std::min<uint64_t>(want, std::min(h->m_out.cap, h->h_out.cap) & ~(size_t)15);
+    return e;
+}
+
+// Last kernel of a batch: the work records, the bump pointers and the contig records (when they fit the host buffer) go to pinned
+// host memory over the fabric, written by the shader -- no copy engine, no host-side wait behind another handle's transfers.
+extern "C" __global__ void __launch_bounds__(256) bk_mirror_kernel(const uint32_t *work, uint32_t work_words, const unsigned long long *tops, const uint4 *out,
+                                                                   uint32_t *m_work, unsigned long long *m_tops, uint4 *m_out, unsigned long long m_out_cap)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < work_words; i += nth) m_work[i] = work[i];
+    if (tid < 11) m_tops[tid] = tops[tid];
+    const unsigned long long nb = tops[1];
+    if (nb <= m_out_cap) for (size_t i = tid; i < (size_t)((nb + 15) / 16); i += nth) m_out[i] = out[i];
+}
+
 static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subset = nullptr, bool escalate = true)
 {
+    h->mirror_fresh = false;
     // every contig record takes >= 256 B of the result arena, so out_cap / 256 list entries can never overflow
     HIPCHK(h, h->d_clist.ensure(std::max<uint64_t>(h->out_cap / 256, 1024) * 16));
     uint32_t npad = 1; while ((int)npad < h->n_regions) npad <<= 1;
@@ -720,6 +812,15 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     if (mask & BK_STAGE_REALIGN) { const int rc = launch_sw(h, max_contig, !subset); if (rc != BK_OK) return rc; }
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    if (!subset) {
+        static_assert(sizeof(BkRegionWork) % 4 == 0, "BkRegionWork is copied word by word");
+        HIPCHK(h, ensure_mirrors(h));                    // (a no-op unless the result arena grew since the submit)
+        const uint32_t words = (uint32_t)(sizeof(BkRegionWork) / 4 * (size_t)h->n_regions);
+        hipLaunchKernelGGL(bk_mirror_kernel, dim3(32), dim3(256), 0, h->stream, (const uint32_t *)h->d_work.p, words, (const unsigned long long *)h->d_tops.p, (const uint4 *)h->d_out.p,
+                           (uint32_t *)h->m_work.data(), (unsigned long long *)h->m_tops.data(), (uint4 *)h->m_out.data(), (unsigned long long)h->m_out_cap);
+        HIPCHK(h, hipGetLastError());
+        h->mirror_fresh = true;
+    }
     return BK_OK;
 }
 
@@ -728,6 +829,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
 // realigned.  Same kernels and caps as the batch's run.
 static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t> &redo)
 {
+    h->mirror_fresh = false;
     fill_params(h);
     const int n = (int)redo.size();
     HIPCHK(h, h->d_rmap.ensure(redo.size() * 4));
@@ -810,7 +912,8 @@ static int sync_impl(bk_handle *h)
         }
 #endif
         h->h_work.resize(h->n_regions);
-        HIPCHK(h, hipMemcpy(h->h_work.data(), h->d_work.p, sizeof(BkRegionWork) * h->n_regions, hipMemcpyDeviceToHost));
+        if (h->mirror_fresh) memcpy((void *)h->h_work.data(), h->m_work.data(), sizeof(BkRegionWork) * (size_t)h->n_regions);      // written by bk_mirror_kernel behind the batch's kernels
+        else HIPCHK(h, hipMemcpy(h->h_work.data(), h->d_work.p, sizeof(BkRegionWork) * h->n_regions, hipMemcpyDeviceToHost));
         // A region that overflowed an assembler cap (candidates per k-mer visit, contig length, k-mer list) is run again, with
         // the others that did, under caps 4x larger (below).  One that overflows those too fails ALONE: its status is kept
         // (bk_get_region_status), it reports no contigs, the other regions of the batch are unaffected.
@@ -895,6 +998,12 @@ static int fetch(bk_handle *h)
     int rc = sync_impl(h);
     if (rc != BK_OK) return rc;
     if (h->fetched) return BK_OK;
+    if (h->mirror_fresh && ((const unsigned long long *)h->m_tops.data())[1] <= h->m_out_cap) {      // the records are on the host already: the buffers change roles
+        std::swap(h->h_out, h->m_out); h->h_out.n = (size_t)((const unsigned long long *)h->m_tops.data())[1];
+        h->mirror_fresh = false;                  // (the work records were taken by sync_impl above; a second fetch of this run finds h->fetched)
+        h->fetched = true;
+        return BK_OK;
+    }
     unsigned long long tops[2];
     HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
     HIPCHK(h, h->h_out.resize(tops[1]));

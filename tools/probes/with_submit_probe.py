@@ -24,7 +24,8 @@ e.close()
 
 for how in ("submit", "submit_packed"):
     engs = [hb.Engine(kmer_size=31) for _ in range(n_eng)]
-    tm = {"fetch": 0.0, "call": 0.0, "submit": 0.0, "ctx": 0.0, "run": 0.0}
+    tm = {"sync": 0.0, "fetch": 0.0, "call": 0.0, "submit": 0.0, "ctx": 0.0, "run": 0.0}
+    kms = [0.0] * 4
 
     def loop(k):
         n = len(engs); half = max(1, n // 2)
@@ -33,8 +34,10 @@ for how in ("submit", "submit_packed"):
         while done < k:
             i = t % n; g = engs[i]
             if state[i] == "running":
-                a = time.perf_counter(); g.fetch(); b = time.perf_counter(); g.call_blob(); c = time.perf_counter()
-                tm["fetch"] += b - a; tm["call"] += c - b
+                a0 = time.perf_counter(); g.sync(); a = time.perf_counter(); g.fetch(); b = time.perf_counter(); g.call_blob(); c = time.perf_counter()
+                tm["sync"] += a - a0; tm["fetch"] += b - a; tm["call"] += c - b
+                for q in range(4):
+                    kms[q] += g.kernel_ms(q)
                 done += 1; state[i] = "idle"
             if state[i] == "idle" and started < k:
                 a = time.perf_counter()
@@ -53,8 +56,10 @@ for how in ("submit", "submit_packed"):
     loop(n_eng)
     for k_ in tm:
         tm[k_] = 0.0
+    kms[:] = [0.0] * 4
     t0 = time.perf_counter(); loop(steps); dt = time.perf_counter() - t0
     print("%s, %d handles, %d steps: %.3f ms per step = %.1f k regions/s; driver thread per step: %s; last submit of handle 0: row copies %.2f ms, H2D + waits %.2f ms"
           % (how, n_eng, steps, dt / steps * 1e3, 256 * steps / dt / 1e3, ", ".join("%s %.3f" % (k_, v / steps * 1e3) for k_, v in tm.items()), engs[0].stat(20) / 1e3, engs[0].stat(21) / 1e3), flush=True)
+    print("   kernels of a batch on the GPU's clock (first to last event / k-mer / assembler / realign): %s ms" % " / ".join("%.2f" % (v / steps) for v in kms), flush=True)
     for g in engs:
         g.close()
