@@ -497,7 +497,7 @@ def main():
         run_steps_submit(len(engs))
         barrier()
         tws = time.perf_counter()
-        ksub = max(len(engs), min(a.steps, 48))
+        ksub = 48 if a.steps >= 8 else max(len(engs), a.steps)      # its own number of steps (a side figure): 20 steps of 3 ms are a 60 ms window
         raw_ws = run_steps_submit(ksub)
         barrier()
         wdt = time.perf_counter() - tws

@@ -274,6 +274,15 @@ __attribute__((target("ssse3"))) static inline bool pack16_ssse3(const unsigned 
 }
 static const bool g_have_ssse3 = __builtin_cpu_supports("ssse3");
 
+// a row of packed words (2.5 million of ~40 bytes per batch: a library memcpy call per row costs more than the copy)
+static inline void copy_words(uint32_t *dst, const uint32_t *src, uint32_t nw)
+{
+    uint32_t w = 0;
+    for (; w + 4 <= nw; w += 4) _mm_storeu_si128((__m128i *)(dst + w), _mm_loadu_si128((const __m128i *)(src + w)));
+    if (w + 2 <= nw) { uint64_t v; memcpy(&v, src + w, 8); memcpy(dst + w, &v, 8); w += 2; }
+    if (w < nw) dst[w] = src[w];
+}
+
 static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vector<uint32_t> *nlist = nullptr, uint32_t tag = 0, bool codes = false, bool window = false)
 {
     const uint8_t *lut = codes ? g_code_lut.v : window ? g_win_lut.v : g_pack_lut.v; const unsigned char *u = (const unsigned char *)s;
@@ -478,7 +487,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
             if (packed) {        // rows are 2 bit/base already: copied into the library's row stride, the tail zeroed
                 for (int i = 0; i < g.n_reads; i++) {
                     const uint32_t nw = ((uint32_t)g.read_lens[i] + 15u) / 16u; uint32_t *dst = reads + d.reads_word_off + (size_t)i * d.read_words;
-                    memcpy(dst, g.reads + (size_t)i * g.read_stride, (size_t)nw * 4);
+                    copy_words(dst, (const uint32_t *)(g.reads + (size_t)i * g.read_stride), nw);
                     if (g.read_lens[i] & 15) dst[nw - 1] &= 0xFFFFFFFFu << (2 * (16 - (g.read_lens[i] & 15)));      // bases beyond the length must read as A (the kernels compare whole words)
                     for (uint32_t w = nw; w < d.read_words; w++) dst[w] = 0;
                 }

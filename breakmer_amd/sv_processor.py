@@ -730,6 +730,25 @@ _SUMMARY_HEADER = "\t".join(['Target', 'N_contigs', 'Total_variants', 'N_indel',
 
 
 # ------------------------------------------------------------------------------------------------ runner
+class _gc_paused(object):
+    """The driver makes tens of thousands of small, short-lived, acyclic objects per second (intervals, targets, views, rows), and
+    every so many allocations the cyclic collector walks EVERYTHING the process keeps alive to find nothing: in a process that has
+    torch imported (bench.py, any torch.distributed launch) that was half of the driver's time -- 15-17 k regions/s with the
+    collector on, 30 k with it off, same box (tools/probes/runner_env_probe.py) -- and a full collection landing in the parse of
+    the target files doubled the time of one run in four (tools/probes/runner_repeat_probe.py).  It is switched off while the
+    target tables are read and for the duration of the run; what they leave behind is reference-counted like everything else."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            import gc
+            gc.enable()
+
+
 class _Targets(object):
     """runner.targets (sv_processor.py:165-170: name -> target, every target of the run): the same mapping, its objects made when
     someone asks for one.  The batch lane of runner.run never does -- it keeps a target's outcome as (rows, number of contigs)
@@ -770,7 +789,8 @@ class _LaneBatch(object):
 
 class runner(object):                                               # sv_processor.py:98-235
     def __init__(self, config_d, region_data=None, engine_factory=None, rank=0, world=1, collate=None, native_calls=True, status_exchange=None, batch_lane=True):
-        self.params = params(config_d)
+        with _gc_paused():
+            self.params = params(config_d)
         self.results = []
         self.targets = _Targets(self)
         self.batch_lane = batch_lane            # plain targets go through the library as rows of a batch table (_lane_batch); False: every target as an object
@@ -1110,19 +1130,8 @@ class runner(object):                                               # sv_process
         return eng
 
     def run(self, start_time=None):                                  # :174-209
-        # The batches make tens of thousands of small, short-lived, acyclic objects per second (targets, views, rows), and
-        # every so many allocations the cyclic collector walks EVERYTHING the process keeps alive to find nothing: in a
-        # process that has torch imported (bench.py, any torch.distributed launch) that was half of the driver's time --
-        # 15-17 k regions/s with the collector on, 30 k with it off, same box (tools/probes/runner_env_probe.py).  It is
-        # switched off for the duration of the run; what the run leaves behind is reference-counted like everything else.
-        import gc
-        gc_was = gc.isenabled()
-        gc.disable()
-        try:
+        with _gc_paused():
             return self._run(start_time)
-        finally:
-            if gc_was:
-                gc.enable()
 
     def _run(self, start_time=None):
         names = self.create_targets()
