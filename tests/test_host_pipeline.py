@@ -112,6 +112,13 @@ def _rank_main(rank, world, port, base, q, mode):
     import pathlib
     d = pathlib.Path(base) / ("rank%d" % rank)
     d.mkdir()
+    if mode == "lane":                                   # plain targets with packed reads through a scripted engine: the batch lane on every rank
+        cfg, data, script = _lane_inputs(d)
+        r = sp.runner(cfg, region_data=data, engine_factory=lambda prm: ScriptedEngine(script, []), rank=rank, world=world, collate=collate_results, status_exchange=exchange_status)
+        rows = r.run()
+        q.put((rank, "ok" if not r.targets._made else "objects were made", rows, sorted(r.summary.items()), r.assigned_cost))
+        td.destroy_process_group()
+        return
     cfg, data = _skew_inputs(d) if mode != "plain" else make_inputs(d, [(3, "del"), (5, "ins"), (7, "inv"), (9, "del")])
 
     class Failing(FakeEngine):
@@ -127,6 +134,24 @@ def _rank_main(rank, world, port, base, q, mode):
     except Exception as ex:
         q.put((rank, "raised", "%s: %s" % (type(ex).__name__, ex), None, r.assigned_cost))
     td.destroy_process_group()
+
+
+def _lane_inputs(d):
+    """seven plain targets of different depth (packed reads, no files) and the script of a ScriptedEngine for them"""
+    import numpy as np
+    from breakmer_amd import hip_backend as hb
+    regs = [synth.make_region(20 + i, sv_type=("del", "ins", "inv")[i % 3], depth=10 + 7 * i, W=600) for i in range(7)]
+    bed, genes, data, script = [], ["header"], {}, {}
+    for n, r in enumerate(regs):
+        bed.append("\t".join([r.chrom, str(r.start), str(r.end), r.name, "exon"]))
+        genes.append("\t".join(["0", r.name, "chr" + r.chrom, "+", str(r.start), str(r.end)] + ["x"] * 6 + [r.name]))
+        data[r.name.upper()] = sp.RegionData(r.read_ids, None, None, None, r.window_str, [], r.disc_reads, read_codes=r.reads, read_lens=r.read_lens, read_packed=hb.pack_reads(r.reads, r.read_lens))
+        rows = [[r.name, "%s:%d" % (r.chrom, r.start + 100 * c), "D10", "0", "+", "0", "indel", "7", "30", "0", "40", "%s_contig%d" % (r.name, c), "ACGT"] for c in range(1, 1 + n % 3)]
+        script[r.window_str.encode()] = (rows, len(rows) + 1, None)
+    (d / "t.bed").write_text("\n".join(bed) + "\n")
+    (d / "g.txt").write_text("\n".join(genes) + "\n")
+    cfg = {"analysis_name": "lane", "targets_bed_file": str(d / "t.bed"), "gene_annotation_file": str(d / "g.txt"), "kmer_size": "31", "keep_repeat_regions": True, "batch_regions": 2}
+    return cfg, data, script
 
 
 def _run_ranks(tmp_path, mode, tag):
@@ -178,6 +203,21 @@ def test_two_rank_cost_skew_and_failed_rank_gloo(tmp_path):
     assert [g[1] for g in got] == ["raised", "raised"], got
     assert "injected device failure" in got[1][2]                     # the failing rank re-raises its own exception
     assert "rank 1" in got[0][2] and "injected device failure" in got[0][2]      # the healthy rank names it
+
+
+def test_two_rank_batch_lane_gloo(tmp_path):
+    """the batch lane under two ranks (gloo): targets dealt by cost without a target object being made, rows and summary lines
+    collated == the single-process run"""
+    single = tmp_path / "single"
+    single.mkdir()
+    cfg, data, script = _lane_inputs(single)
+    one = sp.runner(cfg, region_data=data, engine_factory=lambda prm: ScriptedEngine(script, []))
+    want = one.run()
+    assert len(want) == 6 and not one.targets._made
+    got = _run_ranks(tmp_path, "lane", "lane")
+    for rank, state, rows, summary, _cost in got:
+        assert state == "ok" and rows == want and summary == sorted(one.summary.items()), rank
+    assert sorted(g[4] for g in got) != [0, 0] and sum(g[4] for g in got) == sum(len(d_.read_ids) for d_ in data.values())
 
 
 def make_sam_inputs(tmp_path, rid=3, sv="del", size=120, n_pairs=400):
