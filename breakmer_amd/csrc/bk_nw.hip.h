@@ -560,16 +560,22 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
     const int nmax = LPR == 32 ? max(a3, b3) : a3;
     const int nl = (mt + C - 1) / C, lm = nl - 1, pad = nl * C - mt;
     const int lm_max = (LPR == 32 ? max((a1 + C - 1) / C, (b1 + C - 1) / C) : (a1 + C - 1) / C) - 1;
-    int H[C], cb[C], gh[C];
+    // The cells hold V(i, j) = S(i, j) + 2 (i + j) instead of the score S: a gap move then adds NOTHING (S - 2 one cell further) and
+    // the diagonal adds 4 + (1 | -2) = 2 + 3 [match].  All three candidates of a cell carry the same offset, so the maximum picks the
+    // same one: S = V - 2 (i + j) exactly, taken where a score is read (the last column's running maximum, the last row at the end).
+    // The row's symbol travels as the word 3 << 4 * code, a column keeps 4 * code: one bit-field extract yields 3 [match] or 0, and a
+    // cell is v_bfe_u32, v_add3_u32, v_max3_i32 -- 3 instructions where the first version of the sweep had 6, and no condition code.
+    int H[C], cb[C], ms[C];
 #pragma unroll
     for (int x = 0; x < C; x++) {
         const int jj = hl * C + x - pad;                                            // 0-based column, < 0: padding (right-aligned columns: the last one is register C-1 of lane lm)
         const bool real = jj >= 0 && jj < mt && hl <= lm;
-        H[x] = 0;                                                                   // row 0: score 0
-        cb[x] = real ? (int)cols[jj] : 8;                                           // 8 matches nothing
-        gh[x] = jj >= 0 ? -2 : 0;                                                   // the border column's score (0) travels through the padding unchanged
+        H[x] = jj >= 0 ? 2 * (jj + 1) : 0;                                          // row 0: score 0 in matrix column jj + 1; the padding stands for column 0
+        cb[x] = real ? 4 * (int)cols[jj] : 28;                                      // the column's symbol as a nibble position (28: no symbol sits there, matches nothing)
+        ms[x] = jj >= 0 ? 2 : 0;                                                    // mismatch on the diagonal: -2 + 4; inside the padding (all of it column 0) a "diagonal" step is a step down the border column
     }
-    int dprev = 0, rb = 0, im1 = -hl;
+    int dprev = 2 * max(hl * C - pad, 0), rb = 0, im1 = -hl;                        // V(0, column left of this lane's first)
+    int voff = 2 * (1 - hl + mt);                                                   // 2 (i + m) of the row this lane is on: the last column's score is V - voff
     int best = 0, best_im1 = -1;                                                    // the border cell (0, m): score 0 (olc.py:79-83)
     const bool inl = hl <= lm && n > 0;
     const int steps = nmax + lm_max;
@@ -579,23 +585,27 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
         for (int tl = 0; tl < te; tl++) {
             const int recv = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);
             rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
-            if constexpr (LPR == 32) { const int ra = __builtin_amdgcn_readlane(rblk, tl), rbb = __builtin_amdgcn_readlane(rblk, 32 + tl); if (hl == 0) rb = half ? rbb : ra; }
-            else { const int ra = __builtin_amdgcn_readlane(rblk, tl); if (hl == 0) rb = ra; }
+            if constexpr (LPR == 32) { const int ra = 3 << (4 * __builtin_amdgcn_readlane(rblk, tl)), rbb = 3 << (4 * __builtin_amdgcn_readlane(rblk, 32 + tl)); if (hl == 0) rb = half ? rbb : ra; }
+            else { const int ra = 3 << (4 * __builtin_amdgcn_readlane(rblk, tl)); if (hl == 0) rb = ra; }
             if (inl && (unsigned)im1 < (unsigned)n) {
-                const int left = hl == 0 ? 0 : recv;                                // border column (i, 0): score 0
-                int u_in = left, hprev = dprev;
+                const int left = hl == 0 ? 2 * im1 + 2 : recv;                      // border column (i, 0): score 0, V = 2 i
+                // the diagonal candidates of the whole row first (from the previous row's values), then the chain of max3 IN PLACE: left
+                // to itself the compiler interleaves them and pays a register copy per column to put the new values back where the
+                // loop carries them
+                int dg[C];
+                dg[0] = dprev + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[0], 4u) + ms[0];
 #pragma unroll
-                for (int x = 0; x < C; x++) {
-                    const int hold = H[x];
-                    const int nv = max(max(hprev + (cb[x] == rb ? 1 : -2), u_in + gh[x]), hold - 2);
-                    H[x] = nv; u_in = nv; hprev = hold;
-                }
+                for (int x = 1; x < C; x++) dg[x] = H[x - 1] + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[x], 4u) + ms[x];
+                __builtin_amdgcn_sched_barrier(0);
+                int u_in = left;
+#pragma unroll
+                for (int x = 0; x < C; x++) { H[x] = max(max(dg[x], u_in), H[x]); u_in = H[x]; }
                 dprev = left;
-                const int v = H[C - 1];                                            // lane lm: the last column (olc.py:81 '>=': last row wins)
+                const int v = H[C - 1] - voff;                                     // lane lm: the last column's score (olc.py:81 '>=': last row wins)
                 const bool take = v >= best;
                 best = take ? v : best; best_im1 = take ? im1 : best_im1;
             }
-            im1++;
+            im1++; voff += 2;
         }
     }
     const int s1 = __shfl(best, (half * LPR) + lm), i1 = __shfl(best_im1, (half * LPR) + lm) + 1;
@@ -603,8 +613,8 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
     int s2 = 0, i2 = 0;
 #pragma unroll
     for (int x = 0; x < C; x++) {
-        const int jj = hl * C + x - pad;
-        if (jj >= 0 && jj < mt && inl && H[x] >= s2) { s2 = H[x]; i2 = jj + 1; }
+        const int jj = hl * C + x - pad, sc = H[x] - 2 * (n + jj + 1);             // the score of (n, jj + 1)
+        if (jj >= 0 && jj < mt && inl && sc >= s2) { s2 = sc; i2 = jj + 1; }
     }
     for (int o = 1; o < LPR; o <<= 1) {
         const int os = __shfl_xor(s2, o), oi = __shfl_xor(i2, o);
@@ -640,16 +650,18 @@ __device__ __noinline__ BkScoreCarry bk_nw_score_tile_c(const uint8_t *cols, con
     const bool last = __builtin_amdgcn_readfirstlane(last_) != 0;
     const int lane = threadIdx.x & 63;
     const int nl = (mt + C - 1) / C, lm = nl - 1, pad = nl * C - mt;
-    int H[C], cb[C], gh[C];
+    // (cells hold V = S + 2 (i + column within the tile), as in bk_nw_score_c: 4 instructions per cell; the edge columns in LDS hold scores)
+    int H[C], cb[C], ms[C];
 #pragma unroll
     for (int x = 0; x < C; x++) {
         const int jj = lane * C + x - pad;
         const bool real = jj >= 0 && jj < mt && lane <= lm;
-        H[x] = 0;
-        cb[x] = real ? (int)cols[j0 + jj] : 8;
-        gh[x] = jj >= 0 ? -2 : 0;
+        H[x] = jj >= 0 ? 2 * (jj + 1) : 0;
+        cb[x] = real ? 4 * (int)cols[j0 + jj] : 28;
+        ms[x] = jj >= 0 ? 2 : 0;
     }
-    int dprev = 0, rb = 0, im1 = -lane;
+    int dprev = 2 * max(lane * C - pad, 0), rb = 0, im1 = -lane;
+    int voff = 2 * (1 - lane + mt);
     int best = 0, best_im1 = -1;
     const bool inl = lane <= lm;
     const int steps = n + lm;
@@ -660,37 +672,41 @@ __device__ __noinline__ BkScoreCarry bk_nw_score_tile_c(const uint8_t *cols, con
         for (int tl = 0; tl < te; tl++) {
             const int recv = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);
             rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
-            const int ra = __builtin_amdgcn_readlane(rblk, tl), bi = __builtin_amdgcn_readlane(bblk, tl);
+            const int ra = 3 << (4 * __builtin_amdgcn_readlane(rblk, tl)), bi = __builtin_amdgcn_readlane(bblk, tl);
             if (lane == 0) rb = ra;
             if (inl && (unsigned)im1 < (unsigned)n) {
-                const int left = lane == 0 ? bi : recv;                             // lane 0 handles row t0 + tl at this step: its edge value is entry tl of the block
-                int u_in = left, hprev = dprev;
+                const int left = lane == 0 ? bi + 2 * im1 + 2 : recv;               // lane 0 handles row t0 + tl at this step: its edge value is entry tl of the block
+                // the diagonal candidates of the whole row first (from the previous row's values), then the chain of max3 IN PLACE: left
+                // to itself the compiler interleaves them and pays a register copy per column to put the new values back where the
+                // loop carries them
+                int dg[C];
+                dg[0] = dprev + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[0], 4u) + ms[0];
 #pragma unroll
-                for (int x = 0; x < C; x++) {
-                    const int hold = H[x];
-                    const int nv = max(max(hprev + (cb[x] == rb ? 1 : -2), u_in + gh[x]), hold - 2);
-                    H[x] = nv; u_in = nv; hprev = hold;
-                }
+                for (int x = 1; x < C; x++) dg[x] = H[x - 1] + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[x], 4u) + ms[x];
+                __builtin_amdgcn_sched_barrier(0);
+                int u_in = left;
+#pragma unroll
+                for (int x = 0; x < C; x++) { H[x] = max(max(dg[x], u_in), H[x]); u_in = H[x]; }
                 dprev = left;
-                const int v = H[C - 1];
+                const int v = H[C - 1] - voff;
                 if (last) { const bool take = v >= best; best = take ? v : best; best_im1 = take ? im1 : best_im1; }
                 else if (lane == lm) bound_out[im1] = v;
             }
-            im1++;
+            im1++; voff += 2;
         }
     }
     int s2 = s2_, i2 = i2_;                                                         // carried: compared with '>=' in ascending column order
-    int ms = -0x40000000, mi = 0;
+    int mx = -0x40000000, mi = 0;
 #pragma unroll
     for (int x = 0; x < C; x++) {
-        const int jj = lane * C + x - pad;
-        if (jj >= 0 && jj < mt && inl && H[x] >= ms) { ms = H[x]; mi = j0 + jj + 1; }
+        const int jj = lane * C + x - pad, sc = H[x] - 2 * (n + jj + 1);
+        if (jj >= 0 && jj < mt && inl && sc >= mx) { mx = sc; mi = j0 + jj + 1; }
     }
     for (int o = 1; o < 64; o <<= 1) {
-        const int os = __shfl_xor(ms, o), oi = __shfl_xor(mi, o);
-        if (os > ms || (os == ms && oi > mi)) { ms = os; mi = oi; }
+        const int os = __shfl_xor(mx, o), oi = __shfl_xor(mi, o);
+        if (os > mx || (os == mx && oi > mi)) { mx = os; mi = oi; }
     }
-    if (ms >= s2) { s2 = ms; i2 = mi; }
+    if (mx >= s2) { s2 = mx; i2 = mi; }
     BkScoreCarry c; c.s2 = s2; c.i2 = i2; c.best = __shfl(best, lm); c.best_im1 = __shfl(best_im1, lm);
     return c;
 }
