@@ -5,6 +5,7 @@
 // side to compare with the reference's rows; exit code 0 = every call behaved.
 //   host_driver <dir>      <dir>/ctx_<n>.txt: call context of an n-region batch; <dir>/case_<i>.txt: one described contig
 #include "../../include/breakmer_hip.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,6 +109,66 @@ static void one_handle(const std::string &dir, unsigned seed)
     CHECK(bk_destroy(h) == BK_OK);
 }
 
+// The submit path at the size where it works in chunks (>= 16 regions: the reads go to the device chunk by chunk while the helper
+// threads fill the rest), with ASCII reads and with 2-bit packed rows (BK_SUBMIT_PACKED), waited for and asynchronous; and what it
+// says when a window, a partner window or an N list is bad: the FIRST offending region, by name of the fault.
+static void submit_paths(unsigned seed)
+{
+    bk_config cfg{}; cfg.abi_version = BK_ABI_VERSION; cfg.kmer_size = 31; cfg.rc_thresh = 2;
+    bk_handle *h = nullptr;
+    CHECK(bk_create(0, &cfg, &h) == BK_OK);
+    const int n = 44, L = 150;
+    Batch b; make_batch(b, n, 200, L, seed, false);
+    // packed copy of the same batch: rows of W words, N calls listed (row << 10 | position, ascending)
+    const int W = (L + 15) / 16;
+    std::vector<std::vector<uint32_t>> rows(n), nls(n); std::vector<bk_region> pg = b.g;
+    for (int r = 0; r < n; r++) {
+        const int nr = b.g[r].n_reads;
+        rows[r].assign((size_t)std::max(nr, 1) * W, 0);
+        for (int i = 0; i < nr; i++) {
+            std::vector<uint32_t> w(W + 1), np(L + 1); int32_t nn = 0;
+            CHECK(bk_pack_sequence(b.reads[r].data() + (size_t)i * L, b.lens[r][i], 0, w.data(), (int32_t)w.size(), np.data(), L, &nn) == BK_OK);
+            memcpy(rows[r].data() + (size_t)i * W, w.data(), (size_t)W * 4);
+            for (int e = 0; e < nn; e++) nls[r].push_back(((uint32_t)i << 10) | np[e]);
+        }
+        pg[r].reads = (const char *)rows[r].data(); pg[r].read_stride = W * 4; pg[r].read_n = nls[r].empty() ? nullptr : nls[r].data(); pg[r].n_read_n = (int32_t)nls[r].size();
+        pg[r].sc_seqs = nullptr; pg[r].sc_lens = nullptr; pg[r].n_sc = -1;
+    }
+    for (int round = 0; round < 4; round++) {
+        const bool packed = round & 1, async = round >= 2;
+        CHECK(bk_submit_regions_ex(h, packed ? pg.data() : b.g.data(), n, (packed ? BK_SUBMIT_PACKED : 0u) | (async ? BK_SUBMIT_ASYNC : 0u)) == BK_OK);
+        CHECK(bk_run(h, BK_STAGE_ALL) == BK_OK);
+        CHECK(bk_sync(h) == BK_OK);
+        CHECK(bk_fetch(h) == BK_OK);
+    }
+    auto says = [&](const char *a, const char *c) { const char *e = bk_last_error(h); return e && strstr(e, a) && strstr(e, c); };
+    {   // a foreign character in the windows of regions 30 and 9: region 9 is named
+        std::string w30 = b.win[30], w9 = b.win[9]; w30[5] = 'R'; w9[100] = '-';
+        std::vector<bk_region> g = b.g; g[30].window = w30.c_str(); g[9].window = w9.c_str();
+        CHECK(bk_submit_regions(h, g.data(), n) == BK_E_ARG && says("region 9:", "in the reference window"));
+        CHECK(bk_run(h, BK_STAGE_ALL) == BK_E_STATE);
+        CHECK(bk_submit_regions_ex(h, g.data(), n, BK_SUBMIT_ASYNC) == BK_OK);
+        CHECK(bk_run(h, BK_STAGE_ALL) == BK_E_ARG && says("region 9:", "in the reference window"));
+        // ... and in a partner window (regions 0, 3, 6, ... carry one); a window fault anywhere is reported before a read fault
+        std::string p12 = b.partners[12][0]; p12[7] = 'X'; const char *pp[1] = {p12.c_str()};
+        g = b.g; g[12].partners = pp; std::vector<char> rd = b.reads[2]; rd[3] = 'x'; g[2].reads = rd.data();
+        CHECK(bk_submit_regions(h, g.data(), n) == BK_E_ARG && says("region 12:", "in a partner window"));
+        g[12].partners = b.g[12].partners;
+        CHECK(bk_submit_regions(h, g.data(), n) == BK_E_ARG && says("region 2 read 0", "base other than"));
+    }
+    {   // packed rows: an N list that is not ascending, one that points behind a read
+        std::vector<bk_region> g = pg; std::vector<uint32_t> bad = {(5u << 10) | 7u, (5u << 10) | 7u};
+        g[20].read_n = bad.data(); g[20].n_read_n = 2;
+        CHECK(bk_submit_regions_ex(h, g.data(), n, BK_SUBMIT_PACKED) == BK_E_ARG && says("region 20 read 5", "N list"));
+        bad = {(3u << 10) | 1000u}; g[20].read_n = bad.data(); g[20].n_read_n = 1;
+        CHECK(bk_submit_regions_ex(h, g.data(), n, BK_SUBMIT_PACKED) == BK_E_ARG && says("region 20 read 3", "N list"));
+        CHECK(bk_submit_regions_ex(h, pg.data(), n, BK_SUBMIT_PACKED | BK_SUBMIT_READ_CODES) == BK_E_ARG);
+    }
+    CHECK(bk_submit_regions_ex(h, pg.data(), n, BK_SUBMIT_PACKED) == BK_OK);                 // and the handle takes a good batch again
+    CHECK(bk_run(h, BK_STAGE_ALL) == BK_OK && bk_sync(h) == BK_OK);
+    CHECK(bk_destroy(h) == BK_OK);
+}
+
 int main(int argc, char **argv)
 {
     CHECK(argc == 2);
@@ -137,6 +198,7 @@ int main(int argc, char **argv)
         char small[4]; int hit; CHECK(bk_call_text("garbage", small, sizeof(small), &hit) != BK_OK);
     }
     one_handle(dir, 100);
+    submit_paths(400);
     std::thread t1(one_handle, dir, 200u), t2(one_handle, dir, 300u);        // handles are independent: two threads, one handle each
     t1.join(); t2.join();
     printf("DONE\n");

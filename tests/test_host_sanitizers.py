@@ -2,7 +2,9 @@
 only: GPU-side sanitizers are not available on this pool).  bk_api.hip is compiled `hipcc --cuda-host-only -fsanitize=...` and
 linked with a stand-in for the HIP runtime (tests/sanitize/hip_stub.cpp: device memory = zeroed host memory, launches do
 nothing) and a driver (tests/sanitize/host_driver.cpp) that goes through the C-ABI: 2-bit packing on both paths, synchronous
-and asynchronous submits on reused staging, two handles on two threads, getters on empty results, error paths, bk_trim, and
+and asynchronous submits on reused staging (also at the size where a submit goes to the device in chunks while its helper threads
+fill the rest, with ASCII reads and 2-bit packed rows, and the fault each bad window / partner window / N list is reported with),
+two handles on two threads, getters on empty results, error paths, bk_trim, and
 the native call tail on the G5 / G8m fixture texts -- whose rows must still equal the reference's.  Two synchronisation bugs of
 round 2 sat in code paths like these; this is the guard the host side did not have."""
 import json
