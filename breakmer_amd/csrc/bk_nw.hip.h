@@ -517,9 +517,9 @@ __device__ inline void bk_nw_pair(const BkPairArgs &A, const BkPairArgs &B) { bk
 // ---- round 5: the SCORE sweep -- one plain score matrix per read, no pointers, no origins ---------------------------------------
 // What check_align consumes of an overlap DP is (j_start, i_end, i_start, score): the END CELL of the traceback (largest row among the
 // maxima of the last column, olc.py:79-83) and the border cell the traceback reaches.  The end cells of BOTH calls -- nw(contig, read):
-// last column; nw(read, contig): last row of the same matrix, largest column among the maxima -- need the scores only: 6 instructions
-// per cell (compare, select, three adds, one max3) instead of the 12 of bk_nw_pair_c.  The border cell then follows WITHOUT a
-// traceback in the case clean data consists of:
+// last column; nw(read, contig): last row of the same matrix, largest column among the maxima -- need the scores only: 3 instructions
+// per cell (bit-field extract, add3, max3: see bk_nw_score_c; 6 in the sweep's first version) instead of the 12 of bk_nw_pair_c.
+// The border cell then follows WITHOUT a traceback in the case clean data consists of:
 //   Let the end cell be (i, m) with score s, d = min(i, m) the most diagonal steps any path into it can have.  A path with a matches,
 //   x mismatches and g gaps scores a - 2x - 2g <= d - 2g.  s == d  =>  a = d, x = g = 0: the ONLY path that reaches the score is the
 //   pure diagonal of d matches from the border -- and along it the diagonal candidate wins every cell strictly (a gap candidate would
