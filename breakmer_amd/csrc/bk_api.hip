@@ -336,6 +336,7 @@ static hipError_t upload_raw(bk_handle *h, DevBuf &b, const void *src, size_t by
     return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream);
 }
 
+#define BK_SUBMIT_THREADS 8       // threads filling the staging buffer of one submit unless bk_config.reserved[3] says otherwise (a driver has two or three submits in flight on 16 cores: 16 each measured no faster than 8, tools/probes/with_submit_probe.py)
 // The helper threads of one submit: spawned once, then handed one job after the other (spawning sixteen threads per phase cost as
 // much as a phase).  run(): the helpers and the caller execute the job; start() / wait(): the helpers alone, the caller does
 // something else meanwhile (issues the copies of the chunks they finish).
@@ -389,7 +390,8 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     uint32_t n_max_win = 0; uint64_t n_alg_bytes = 0;
     uint64_t dd_total = 0; uint32_t max_w = 0;
     size_t tot_reads = 0, tot_words = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;
-    const int nth = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), n_regions}));
+    const int want_th = h->cfg.reserved[3] > 0 ? std::min(h->cfg.reserved[3], 64) : BK_SUBMIT_THREADS;
+    const int nth = std::max(1, std::min<int>({want_th, (int)std::thread::hardware_concurrency(), n_regions}));
     BkTeam team(nth - 1);                                // the helper threads of this submit, spawned once (this thread is the nth)
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r];

@@ -270,6 +270,7 @@ class Engine(object):
         cfg.reserved[0] = int(limits.get("flags", 0))
         cfg.reserved[1] = int(limits.get("wg_threads", 0))          # assembler workgroup size: 0 = library default, 256 (throughput) or 512 (latency)
         cfg.reserved[2] = int(limits.get("no_escalation", 0))       # 1: regions that overflow an assembler cap fail at once instead of being re-run under larger caps
+        cfg.reserved[3] = int(limits.get("submit_threads", 0))      # host threads filling the staging buffer of a submit (0: library default)
         self.k = int(kmer_size)
         self.rc_thresh, self.device = int(rc_thresh), int(device)
         self._inputs = None

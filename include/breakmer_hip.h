@@ -71,7 +71,8 @@ typedef struct bk_config {
                                  *      2048 = bk_call takes every contig through the full caller (no shortcut for single full-span hits))
                                  * [1]: assembler workgroup size: 512 = 8 wavefronts / 8 look-ahead slots / 2 per CU (one batch finishes soonest),
                                  *      256 = 4 wavefronts / 4 slots / 4 per CU (most regions/s when batches are in flight), 0 = library chooses
-                                 * [2]: 1 = do NOT re-run regions that overflow an assembler cap with larger caps (they fail at once: bk_get_region_status) */
+                                 * [2]: 1 = do NOT re-run regions that overflow an assembler cap with larger caps (they fail at once: bk_get_region_status)
+                                 * [3]: host threads that fill the staging buffer of one submit (0 = library chooses; 1 .. 64) */
 } bk_config;
 
 /* One target region = what sv_processor.target hands to compare_kmers()/resolve_sv()
