@@ -390,7 +390,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     uint32_t n_max_win = 0; uint64_t n_alg_bytes = 0;
     uint64_t dd_total = 0; uint32_t max_w = 0;
     size_t tot_reads = 0, tot_words = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;
-    const int want_th = h->cfg.reserved[3] > 0 ? std::min(h->cfg.reserved[3], 64) : BK_SUBMIT_THREADS;
+    const int want_th = h->cfg.reserved[3] > 0 ? std::min(h->cfg.reserved[3], 64) : packed ? BK_SUBMIT_THREADS : 2 * BK_SUBMIT_THREADS;      // (2-bit packing of ASCII is four times the bytes and real work per byte)
     const int nth = std::max(1, std::min<int>({want_th, (int)std::thread::hardware_concurrency(), n_regions}));
     BkTeam team(nth - 1);                                // the helper threads of this submit, spawned once (this thread is the nth)
     for (int r = 0; r < n_regions; r++) {
