@@ -99,6 +99,7 @@ struct bk_handle {
     uint32_t ran_mask = 0;
     // device
     DevBuf d_desc, d_work, d_part, d_reads, d_rlen, d_rflag, d_sc, d_sclen, d_win;
+    DevBuf d_reads_in, d_cwoff;      // a submit's reads as they cross the bus (rows without the pad word) and where each region's rows start in them
     DevBuf d_ddslot, d_ddrep, d_ddcnt, d_grp, d_urep, d_unr, d_ufl, d_ubuf, d_ureads, d_ufound, d_uminpos;
     DevBuf d_arena, d_out, d_tops, d_order, d_skeys, d_clist, d_nlist, d_wnlist;
     int n_cu = 256, asm_wg_per_cu = 0, sw_wg_per_cu = 0, asm_threads = 512;
@@ -230,7 +231,7 @@ extern "C" int bk_destroy(bk_handle *h)
     (void)join_pending(h);
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
+    DevBuf *bufs[] = {&h->d_reads_in, &h->d_cwoff, &h->d_desc, &h->d_work, &h->d_part, &h->d_reads, &h->d_rlen, &h->d_rflag, &h->d_sc, &h->d_sclen, &h->d_win, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt,
                       &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos, &h->d_arena, &h->d_out, &h->d_tops, &h->d_order, &h->d_skeys, &h->d_clist, &h->d_nlist, &h->d_wnlist, &h->d_rmap};
     for (auto b : bufs) b->release();
     h->h_out.release(); h->hs_reads.release(); h->hs_rlen.release(); h->hs_rflag.release(); h->m_work.release(); h->m_tops.release(); h->m_out.release();
@@ -361,6 +362,20 @@ public:
 };
 
 static hipError_t ensure_mirrors(bk_handle *h);
+// The rows of a submit cross the bus WITHOUT the pad word the kernels want behind every row (k-mer extraction may touch one word past
+// the end: 11 instead of 10 words per 150-base read, 9 % of the bytes of a batch); this kernel lays them out with it.  One workgroup
+// column per region (blockIdx.x), blockIdx.y strides over its words.
+extern "C" __global__ void __launch_bounds__(256) bk_expand_rows_kernel(const BkRegionDesc *desc, const unsigned long long *cwoff, const uint32_t *in, uint32_t *out)
+{
+    const BkRegionDesc d = desc[blockIdx.x];
+    const uint32_t rw = d.read_words, wc = rw - 1;
+    const uint32_t *src = in + cwoff[blockIdx.x]; uint32_t *dst = out + d.reads_word_off;
+    const uint32_t n = d.n_reads * rw;                       // < 2^22 reads x <= 65 words: fits 32 bits (32-bit divisions below)
+    for (uint32_t o = blockIdx.y * blockDim.x + threadIdx.x; o < n; o += gridDim.y * blockDim.x) {
+        const uint32_t i = o / rw, w = o - i * rw;
+        dst[o] = w < wc ? src[(size_t)i * wc + w] : 0u;
+    }
+}
 static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags);
 extern "C" int bk_submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regions) { (void)join_pending(h); return submit_regions(h, regions, n_regions, 0); }
 extern "C" int bk_submit_regions_ex(bk_handle *h, const bk_region *regions, int32_t n_regions, uint32_t flags)
@@ -389,7 +404,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     std::vector<BkRegionDesc> n_desc(n_regions, BkRegionDesc{}); std::vector<BkPartnerDesc> n_part; std::vector<std::vector<BkTarget>> n_targets(n_regions);
     uint32_t n_max_win = 0; uint64_t n_alg_bytes = 0;
     uint64_t dd_total = 0; uint32_t max_w = 0;
-    size_t tot_reads = 0, tot_words = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;
+    size_t tot_reads = 0, tot_words = 0, tot_cwords = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;      // tot_words: rows with their pad word (device layout); tot_cwords: without (staging, transfer)
     const int want_th = h->cfg.reserved[3] > 0 ? std::min(h->cfg.reserved[3], 64) : packed ? BK_SUBMIT_THREADS : 2 * BK_SUBMIT_THREADS;      // (2-bit packing of ASCII is four times the bytes and real work per byte)
     const int nth = std::max(1, std::min<int>({want_th, (int)std::thread::hardware_concurrency(), n_regions}));
     BkTeam team(nth - 1);                                // the helper threads of this submit, spawned once (this thread is the nth)
@@ -418,25 +433,26 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r];
         if ((int)r_maxl[r] > h->cfg.max_read_len) return fail(h, BK_E_LIMIT, "bk_submit_regions: read longer than max_read_len");
-        tot_reads += g.n_reads; tot_words += (size_t)g.n_reads * ((r_maxl[r] + 15) / 16 + 1);
+        tot_reads += g.n_reads; tot_words += (size_t)g.n_reads * ((r_maxl[r] + 15) / 16 + 1); tot_cwords += (size_t)g.n_reads * ((r_maxl[r] + 15) / 16);
         if (g.n_sc > 0) { uint32_t ms = 0; for (int i = 0; i < g.n_sc; i++) ms = std::max<uint32_t>(ms, g.sc_lens[i]); tot_sc += g.n_sc; tot_scw += (size_t)g.n_sc * ((ms + 15) / 16 + 1); }
         tot_win += (g.window_len + 15) / 16 + 2; for (int q = 0; q < g.n_partners; q++) tot_win += (g.partner_lens[q] + 15) / 16 + 2;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));          // the staging buffers may still feed the copies of the previous submit
-    HIPCHK(h, h->hs_reads.resize(std::max<size_t>(tot_words, 1) * 4)); HIPCHK(h, h->hs_rlen.resize(std::max<size_t>(tot_reads, 1) * 2)); HIPCHK(h, h->hs_rflag.resize(std::max<size_t>(tot_reads, 1)));
+    HIPCHK(h, h->hs_reads.resize(std::max<size_t>(tot_cwords, 1) * 4)); HIPCHK(h, h->hs_rlen.resize(std::max<size_t>(tot_reads, 1) * 2)); HIPCHK(h, h->hs_rflag.resize(std::max<size_t>(tot_reads, 1)));
     uint32_t *reads = (uint32_t *)h->hs_reads.data(); uint16_t *rlen = (uint16_t *)h->hs_rlen.data(); uint8_t *rflag = h->hs_rflag.data();
-    if (!tot_words) reads[0] = 0;
+    if (!tot_cwords) reads[0] = 0;
     if (!tot_reads) { rlen[0] = 0; rflag[0] = 0; }
     sc.reserve(tot_scw); sclen.reserve(tot_sc); win.assign(tot_win, 0);
     // Layout of the batch (offsets only; the sequences are packed below, regions in parallel)
-    size_t reads_top = 0, meta_top = 0, win_top = 0;
+    size_t reads_top = 0, creads_top = 0, meta_top = 0, win_top = 0;
+    std::vector<unsigned long long> cwoff(n_regions, 0);          // where region r's rows start in the staging buffer (words)
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r]; BkRegionDesc &d = n_desc[r];
         const uint32_t maxl = r_maxl[r];
         d.n_reads = g.n_reads; d.read_words = (maxl + 15) / 16 + 1;          // +1: k-mer extraction may touch one word past the end
         d.max_len = maxl;
-        d.reads_word_off = reads_top; d.read_meta_off = meta_top;
-        reads_top += (size_t)d.n_reads * d.read_words; meta_top += d.n_reads;
+        d.reads_word_off = reads_top; d.read_meta_off = meta_top; cwoff[r] = creads_top;
+        reads_top += (size_t)d.n_reads * d.read_words; creads_top += (size_t)d.n_reads * (d.read_words - 1); meta_top += d.n_reads;
         d.n_sc = g.n_sc < 0 ? -1 : g.n_sc; d.sc_word_off = sc.size(); d.sc_meta_off = sclen.size(); d.sc_words = 1;
         if (g.n_sc > 0) {
             uint32_t ms = 0; for (int i = 0; i < g.n_sc; i++) ms = std::max<uint32_t>(ms, g.sc_lens[i]);
@@ -467,12 +483,12 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     // packed rows, per 256 regions), the windows packed, the host's copies of the windows made -- regions are independent and go
     // over the helper threads in index order.  The staging buffer goes to the device in CHUNKS of regions as they are finished
     // (this thread issues the copies), so the transfer of the first chunk runs while the last ones are still being filled.
-    HIPCHK(h, h->d_reads.ensure(std::max<size_t>(tot_words * 4, 256)));
+    HIPCHK(h, h->d_reads.ensure(std::max<size_t>(tot_words * 4, 256))); HIPCHK(h, h->d_reads_in.ensure(std::max<size_t>(tot_cwords * 4, 256)));
     std::vector<std::vector<uint32_t>> region_nl(n_regions), region_wn(n_regions);
     std::vector<std::vector<uint32_t>> region_wn_cnt(n_regions);          // N positions per window of the region (window, then its partners): lengths of the pieces of region_wn
     const int n_chunks = std::max(1, std::min(8, n_regions / 8));
     std::vector<int> chunk_end(n_chunks, n_regions);
-    { size_t acc = 0; int c = 0; for (int r = 0; r < n_regions && c < n_chunks - 1; r++) { acc += (size_t)n_desc[r].n_reads * n_desc[r].read_words; if (acc * n_chunks >= tot_words * (size_t)(c + 1)) chunk_end[c++] = r + 1; } }
+    { size_t acc = 0; int c = 0; for (int r = 0; r < n_regions && c < n_chunks - 1; r++) { acc += (size_t)n_desc[r].n_reads * (n_desc[r].read_words - 1); if (acc * n_chunks >= tot_cwords * (size_t)(c + 1)) chunk_end[c++] = r + 1; } }
     std::vector<std::atomic<int>> chunk_done(n_chunks);
     for (auto &c : chunk_done) c.store(0);
     std::vector<int> chunk_of(n_regions, 0);
@@ -485,26 +501,27 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
             const int r = next.fetch_add(1);
             if (r >= n_regions) break;
             const bk_region &g = regions[r]; const BkRegionDesc &d = n_desc[r];
+            const uint32_t wc = d.read_words - 1;            // words per row in the staging buffer (the device adds the pad word: bk_expand_rows_kernel)
             for (int i = 0; i < g.n_reads; i++) { rlen[d.read_meta_off + i] = g.read_lens[i]; rflag[d.read_meta_off + i] = g.indel_only && g.indel_only[i] ? BK_RF_INDEL : 0; }
             if (packed) {        // rows are 2 bit/base already: copied into the library's row stride, the tail zeroed
                 for (int i = 0; i < g.n_reads; i++) {
-                    const uint32_t nw = ((uint32_t)g.read_lens[i] + 15u) / 16u; uint32_t *dst = reads + d.reads_word_off + (size_t)i * d.read_words;
+                    const uint32_t nw = ((uint32_t)g.read_lens[i] + 15u) / 16u; uint32_t *dst = reads + cwoff[r] + (size_t)i * wc;
                     copy_words(dst, (const uint32_t *)(g.reads + (size_t)i * g.read_stride), nw);
                     if (g.read_lens[i] & 15) dst[nw - 1] &= 0xFFFFFFFFu << (2 * (16 - (g.read_lens[i] & 15)));      // bases beyond the length must read as A (the kernels compare whole words)
-                    for (uint32_t w = nw; w < d.read_words; w++) dst[w] = 0;
+                    for (uint32_t w = nw; w < wc; w++) dst[w] = 0;
                 }
                 if (g.read_n && g.n_read_n > 0) {
                     region_nl[r].assign(g.read_n, g.read_n + g.n_read_n);
                     for (int e = 0; e < g.n_read_n; e++) {
                         const uint32_t v = g.read_n[e], ri = v >> 10, pos = v & 1023u;
                         if ((int)ri >= g.n_reads || pos >= g.read_lens[ri] || (e && g.read_n[e - 1] >= v)) { note_min(bad_read, ((uint64_t)r << 32) | ri); break; }
-                        uint32_t *dst = reads + d.reads_word_off + (size_t)ri * d.read_words;
+                        uint32_t *dst = reads + cwoff[r] + (size_t)ri * wc;
                         dst[pos >> 4] &= ~(3u << (30 - 2 * (pos & 15)));                              // an N is packed as A
                     }
                 }
             } else {
                 for (int i = 0; i < g.n_reads; i++)
-                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads + d.reads_word_off + (size_t)i * d.read_words, d.read_words, &region_nl[r], (uint32_t)i, read_codes)) { note_min(bad_read, ((uint64_t)r << 32) | (uint32_t)i); break; }
+                    if (!pack_seq(g.reads + (size_t)i * g.read_stride, g.read_lens[i], reads + cwoff[r] + (size_t)i * wc, (int)wc, &region_nl[r], (uint32_t)i, read_codes)) { note_min(bad_read, ((uint64_t)r << 32) | (uint32_t)i); break; }
             }
             chunk_done[chunk_of[r]].fetch_add(1, std::memory_order_release);          // the rows of this region are in the staging buffer
             // the windows: an N (an assembly gap near the target) is packed as code 0 and listed: its k-mers do not exist, it matches nothing
@@ -520,15 +537,15 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     };
     if (nth == 1) {
         pack_region();
-        if (tot_words) HIPCHK(h, hipMemcpyAsync(h->d_reads.p, reads, tot_words * 4, hipMemcpyHostToDevice, h->stream));
+        if (tot_cwords) HIPCHK(h, hipMemcpyAsync(h->d_reads_in.p, reads, tot_cwords * 4, hipMemcpyHostToDevice, h->stream));
     } else {
         team.start(pack_region);
         hipError_t cerr = hipSuccess; size_t sent = 0;      // words of the staging buffer handed to the copy engine so far
         for (int c = 0; c < n_chunks; c++) {
             const int first = c ? chunk_end[c - 1] : 0, want = chunk_end[c] - first;
             while (chunk_done[c].load(std::memory_order_acquire) < want) std::this_thread::sleep_for(std::chrono::microseconds(20));
-            const size_t upto = chunk_end[c] < n_regions ? (size_t)n_desc[chunk_end[c]].reads_word_off : tot_words;
-            if (cerr == hipSuccess && upto > sent) cerr = hipMemcpyAsync((uint8_t *)h->d_reads.p + sent * 4, reads + sent, (upto - sent) * 4, hipMemcpyHostToDevice, h->stream);
+            const size_t upto = chunk_end[c] < n_regions ? (size_t)cwoff[chunk_end[c]] : tot_cwords;
+            if (cerr == hipSuccess && upto > sent) cerr = hipMemcpyAsync((uint8_t *)h->d_reads_in.p + sent * 4, reads + sent, (upto - sent) * 4, hipMemcpyHostToDevice, h->stream);
             sent = upto;
         }
         team.wait();
@@ -579,7 +596,10 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     if (n_part.empty()) n_part.push_back(BkPartnerDesc{0, 0, 0, 0});
     if (wnlist.empty()) wnlist.push_back(0);
     const auto t_h2d0 = std::chrono::steady_clock::now();
-    HIPCHK(h, upload(h, h->d_desc, n_desc)); HIPCHK(h, upload(h, h->d_part, n_part));
+    HIPCHK(h, upload(h, h->d_desc, n_desc)); HIPCHK(h, upload(h, h->d_part, n_part)); HIPCHK(h, upload(h, h->d_cwoff, cwoff));
+    // (same stream as the chunks above and the descriptors: the rows are complete and described when this runs)
+    hipLaunchKernelGGL(bk_expand_rows_kernel, dim3(n_regions, 16), dim3(256), 0, h->stream, (const BkRegionDesc *)h->d_desc.p, (const unsigned long long *)h->d_cwoff.p, (const uint32_t *)h->d_reads_in.p, (uint32_t *)h->d_reads.p);
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, upload_raw(h, h->d_rlen, rlen, std::max<size_t>(tot_reads, 1) * 2));      // (the reads went over in chunks above)
     HIPCHK(h, upload_raw(h, h->d_rflag, rflag, std::max<size_t>(tot_reads, 1)));
     HIPCHK(h, upload(h, h->d_sc, sc)); HIPCHK(h, upload(h, h->d_sclen, sclen)); HIPCHK(h, upload(h, h->d_win, win));
@@ -1596,7 +1616,7 @@ extern "C" int bk_trim(bk_handle *h, uint64_t keep_bytes)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->d_arena.bytes > keep_bytes) { h->d_arena.release(); h->arena_cap = 0; }
     if (h->d_out.bytes > keep_bytes) { h->d_out.release(); h->out_cap = 0; h->d_clist.release(); }
-    DevBuf *bufs[] = {&h->d_reads, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt, &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos};
+    DevBuf *bufs[] = {&h->d_reads_in, &h->d_reads, &h->d_ddslot, &h->d_ddrep, &h->d_ddcnt, &h->d_grp, &h->d_urep, &h->d_unr, &h->d_ufl, &h->d_ubuf, &h->d_ureads, &h->d_ufound, &h->d_uminpos};
     for (auto b : bufs) if (b->bytes > keep_bytes) b->release();
     if (h->h_out.cap > keep_bytes) h->h_out.release();
     if (h->hs_reads.cap > keep_bytes) { h->hs_reads.release(); }
