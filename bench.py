@@ -56,7 +56,7 @@ def parse(argv=None):
     ap.add_argument("--cfg4-regions", type=int, default=768, help="batch size of the configs[4] side measurement: a region's chain of ~19,000 dependent rounds takes ~3 s whatever runs beside it, so regions in flight ARE the throughput (256: 69 regions/s, 512: 101, 768: 121) until the scratch arena (~270 MB per region) fills the HBM (896 no longer fit)")
     ap.add_argument("--side-configs-only", type=int, default=0, help="internal: print the side measurements (configs[3], configs[4], noisy batch) as one JSON object and exit")
     ap.add_argument("--split-experimental", type=int, default=0, help="(ignored: the component split of noisy regions is the default since round 5)")
-    ap.add_argument("--flags", type=int, default=0, help="diagnostic library flags (bk_config.reserved[0]); 0 in every reported number")
+    ap.add_argument("--flags", type=int, default=0, help="library flags (bk_config.flags: BK_CFG_*); 0 in every reported number")
     ap.add_argument("--lib", default=None, help="diagnostic: path of an alternative build of the library (A/B runs on one box)")
     ap.add_argument("--dump-collated", default=None, help="write the bytes collated in the last step to this file (testing)")
     return ap.parse_args(argv)
@@ -265,7 +265,7 @@ def main():
         if a.side_configs_only == 2:                         # the same noisy batch with one unit per region (how every region ran until round 4): the comparison figure
             regsn = [synth.make_region(50000 + i, depth=a.depth, L=a.read_len, sv_type="del", noise=0.005) for i in range(64)]
             oc = {"noise_0.5pct_64_regions_one_unit": time_other_config(hb, regsn, a.kmer, default_opts(), 2, int(os.environ.get("LOCAL_RANK", "0")), flags=128)}
-            oc["noise_0.5pct_64_regions_one_unit"]["workload"] = "the same 64 noisy regions with bk_config.reserved[0] bit 128: no component split, one assembler workgroup per region (the default until round 4)"
+            oc["noise_0.5pct_64_regions_one_unit"]["workload"] = "the same 64 noisy regions with bk_config.flags = BK_CFG_NO_SPLIT (128): no component split, one assembler workgroup per region (the default until round 4)"
             print(json.dumps(oc), flush=True)
             return
         print(json.dumps(side_configs(a, hb, synth, default_opts(), int(os.environ.get("LOCAL_RANK", "0")))), flush=True)      # (--flags applies: diagnostic A/B runs)

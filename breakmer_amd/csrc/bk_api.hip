@@ -93,7 +93,7 @@ struct BkTarget { std::string seq; std::string soft; bool masked(int i) const { 
 
 struct bk_handle {
     int dev = 0; hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
-    bk_config cfg{}; std::string err;
+    bk_config cfg{}; std::string err; int32_t err_region = -1;      // err_region: the region the last failed submit names (bk_last_error_region)
     int n_regions = 0; bool submitted = false, ran = false, fetched = false, synced = false;
     bool hold_snapshot = false;      // bk_fetch() done: bk_call() uses the host copy even if a newer run is in flight
     uint32_t ran_mask = 0;
@@ -177,16 +177,29 @@ static hipError_t set_max_dyn_lds(int dev, const void *fn, int bytes)
     return e;
 }
 
-static int fail(bk_handle *h, int code, const std::string &msg) { if (h) h->err = msg; else g_create_err = msg; return code; }
+static int fail(bk_handle *h, int code, const std::string &msg, int32_t region = -1) { if (h) { h->err = msg; h->err_region = region; } else g_create_err = msg; return code; }
 
 extern "C" int bk_abi_version(void) { return BK_ABI_VERSION; }
 extern "C" const char *bk_last_error(const bk_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+extern "C" int32_t bk_last_error_region(const bk_handle *h) { return h ? h->err_region : -1; }
 
 static size_t asm_lds_bytes(const bk_handle *h, int threads, int max_cand, int max_contig);
 extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
 {
     if (!cfg || !out) return fail(nullptr, BK_E_ARG, "bk_create: null argument");
     if (cfg->abi_version != BK_ABI_VERSION) return fail(nullptr, BK_E_ARG, "bk_create: ABI version mismatch");
+    // the arguments first (a bad configuration is BK_E_ARG on any machine), then the device
+    if (cfg->kmer_size < 2 || cfg->kmer_size > 64) return fail(nullptr, BK_E_ARG, "bk_create: kmer_size must be in [2, 64]");
+    // ABI 5: what steers the library has a name; nothing rides in `reserved`
+    static_assert(sizeof(bk_config) == 64 && offsetof(bk_config, flags) == 40 && offsetof(bk_config, asm_wg_threads) == 44 && offsetof(bk_config, no_escalation) == 48 &&
+                  offsetof(bk_config, submit_threads) == 52 && offsetof(bk_config, reserved) == 56, "bk_config layout (include/breakmer_hip.h; hip_backend.py and tests/test_abi_cpu.py mirror it)");
+    if (cfg->reserved[0] || cfg->reserved[1]) return fail(nullptr, BK_E_ARG, "bk_create: bk_config.reserved must be 0 (ABI 5: flags, asm_wg_threads, no_escalation and submit_threads are fields of their own)");
+    if (cfg->flags & ~(uint32_t)BK_CFG_KNOWN_MASK) return fail(nullptr, BK_E_ARG, "bk_create: unknown bit in bk_config.flags");
+#ifndef BK_DIAG
+    if (cfg->flags & (uint32_t)BK_CFG_DIAG_MASK) return fail(nullptr, BK_E_ARG, "bk_create: bk_config.flags holds a diagnostic-only bit (BK_CFG_DIAG_MASK): those are accepted by the -DBK_DIAG builds of the library only");
+#endif
+    if (cfg->asm_wg_threads != 0 && cfg->asm_wg_threads != 256 && cfg->asm_wg_threads != 512) return fail(nullptr, BK_E_ARG, "bk_create: asm_wg_threads must be 0 (the library chooses), 256 or 512");
+    if ((cfg->no_escalation != 0 && cfg->no_escalation != 1) || cfg->submit_threads < 0 || cfg->submit_threads > 64) return fail(nullptr, BK_E_ARG, "bk_create: no_escalation must be 0 or 1, submit_threads in [0, 64]");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, BK_E_NOGPU, "bk_create: no HIP device visible (this library has no CPU fallback)");
     if (device_id < 0 || device_id >= n) return fail(nullptr, BK_E_ARG, "bk_create: bad device id");
@@ -194,10 +207,9 @@ extern "C" int bk_create(int device_id, const bk_config *cfg, bk_handle **out)
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, BK_E_HIP, "hipGetDeviceProperties failed");
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
         return fail(nullptr, BK_E_NOGPU, std::string("bk_create: device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only");
-    if (cfg->kmer_size < 2 || cfg->kmer_size > 64) return fail(nullptr, BK_E_ARG, "bk_create: kmer_size must be in [2, 64]");
     bk_handle *h = new bk_handle();
     h->dev = device_id; h->cfg = *cfg; h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    { const char *e = bk_diag_env("BK_SPLIT_OFF"); if (e && atoi(e) > 0) h->cfg.reserved[0] |= BK_F_NO_SPLIT; }      // diagnostic build: every region one unit, for every handle of the process
+    { const char *e = bk_diag_env("BK_SPLIT_OFF"); if (e && atoi(e) > 0) h->cfg.flags |= BK_F_NO_SPLIT; }      // diagnostic build: every region one unit, for every handle of the process
     if (h->cfg.max_contig_len <= 0) h->cfg.max_contig_len = 4096;
     if (h->cfg.max_read_len <= 0) h->cfg.max_read_len = 1024;
     if (h->cfg.max_candidates <= 0) h->cfg.max_candidates = 2048;
@@ -276,12 +288,13 @@ __attribute__((target("ssse3"))) static inline bool pack16_ssse3(const unsigned 
 static const bool g_have_ssse3 = __builtin_cpu_supports("ssse3");
 
 // a row of packed words (2.5 million of ~40 bytes per batch: a library memcpy call per row costs more than the copy)
-static inline void copy_words(uint32_t *dst, const uint32_t *src, uint32_t nw)
+// (the source is the caller's row: bk_region.read_stride is in BYTES and promises no alignment, so it is read as bytes)
+static inline void copy_words(uint32_t *dst, const unsigned char *src, uint32_t nw)
 {
     uint32_t w = 0;
-    for (; w + 4 <= nw; w += 4) _mm_storeu_si128((__m128i *)(dst + w), _mm_loadu_si128((const __m128i *)(src + w)));
-    if (w + 2 <= nw) { uint64_t v; memcpy(&v, src + w, 8); memcpy(dst + w, &v, 8); w += 2; }
-    if (w < nw) dst[w] = src[w];
+    for (; w + 4 <= nw; w += 4) _mm_storeu_si128((__m128i *)(dst + w), _mm_loadu_si128((const __m128i *)(src + 4 * (size_t)w)));
+    if (w + 2 <= nw) { uint64_t v; memcpy(&v, src + 4 * (size_t)w, 8); memcpy(dst + w, &v, 8); w += 2; }
+    if (w < nw) memcpy(dst + w, src + 4 * (size_t)w, 4);
 }
 
 static bool pack_seq(const char *s, int len, uint32_t *w, int nwords, std::vector<uint32_t> *nlist = nullptr, uint32_t tag = 0, bool codes = false, bool window = false)
@@ -337,7 +350,7 @@ static hipError_t upload_raw(bk_handle *h, DevBuf &b, const void *src, size_t by
     return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream);
 }
 
-#define BK_SUBMIT_THREADS 8       // threads filling the staging buffer of one submit unless bk_config.reserved[3] says otherwise (a driver has two or three submits in flight on 16 cores: 16 each measured no faster than 8, tools/probes/with_submit_probe.py)
+#define BK_SUBMIT_THREADS 8       // threads filling the staging buffer of one submit unless bk_config.submit_threads says otherwise (a driver has two or three submits in flight on 16 cores: 16 each measured no faster than 8, tools/probes/with_submit_probe.py)
 // The helper threads of one submit: spawned once, then handed one job after the other (spawning sixteen threads per phase cost as
 // much as a phase).  run(): the helpers and the caller execute the job; start() / wait(): the helpers alone, the caller does
 // something else meanwhile (issues the copies of the chunks they finish).
@@ -405,12 +418,12 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
     uint32_t n_max_win = 0; uint64_t n_alg_bytes = 0;
     uint64_t dd_total = 0; uint32_t max_w = 0;
     size_t tot_reads = 0, tot_words = 0, tot_cwords = 0, tot_sc = 0, tot_scw = 0, tot_win = 0;      // tot_words: rows with their pad word (device layout); tot_cwords: without (staging, transfer)
-    const int want_th = h->cfg.reserved[3] > 0 ? std::min(h->cfg.reserved[3], 64) : packed ? BK_SUBMIT_THREADS : 2 * BK_SUBMIT_THREADS;      // (2-bit packing of ASCII is four times the bytes and real work per byte)
+    const int want_th = h->cfg.submit_threads > 0 ? std::min(h->cfg.submit_threads, 64) : packed ? BK_SUBMIT_THREADS : 2 * BK_SUBMIT_THREADS;      // (2-bit packing of ASCII is four times the bytes and real work per byte)
     const int nth = std::max(1, std::min<int>({want_th, (int)std::thread::hardware_concurrency(), n_regions}));
     BkTeam team(nth - 1);                                // the helper threads of this submit, spawned once (this thread is the nth)
     for (int r = 0; r < n_regions; r++) {
         const bk_region &g = regions[r];
-        if (g.n_reads < 0 || !g.window || g.window_len <= 0 || (g.n_reads > 0 && (!g.reads || !g.read_lens))) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": missing reads/window");
+        if (g.n_reads < 0 || !g.window || g.window_len <= 0 || (g.n_reads > 0 && (!g.reads || !g.read_lens))) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(r) + ": missing reads/window", r);
         if (packed && read_codes) return fail(h, BK_E_ARG, "bk_submit_regions: BK_SUBMIT_PACKED and BK_SUBMIT_READ_CODES exclude each other");
         if (g.n_reads >= (1 << 22)) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 4M reads in one region");
         if (g.n_partners > 15) return fail(h, BK_E_LIMIT, "bk_submit_regions: more than 15 partner windows");
@@ -506,7 +519,7 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
             if (packed) {        // rows are 2 bit/base already: copied into the library's row stride, the tail zeroed
                 for (int i = 0; i < g.n_reads; i++) {
                     const uint32_t nw = ((uint32_t)g.read_lens[i] + 15u) / 16u; uint32_t *dst = reads + cwoff[r] + (size_t)i * wc;
-                    copy_words(dst, (const uint32_t *)(g.reads + (size_t)i * g.read_stride), nw);
+                    copy_words(dst, (const unsigned char *)g.reads + (size_t)i * g.read_stride, nw);
                     if (g.read_lens[i] & 15) dst[nw - 1] &= 0xFFFFFFFFu << (2 * (16 - (g.read_lens[i] & 15)));      // bases beyond the length must read as A (the kernels compare whole words)
                     for (uint32_t w = nw; w < wc; w++) dst[w] = 0;
                 }
@@ -551,8 +564,8 @@ static int submit_regions(bk_handle *h, const bk_region *regions, int32_t n_regi
         team.wait();
         HIPCHK(h, cerr);
     }
-    if (bad_window.load() != UINT64_MAX) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_window.load() >> 1) + ((bad_window.load() & 1) ? ": character other than A/C/G/T/N in a partner window" : ": character other than A/C/G/T/N in the reference window"));
-    if (bad_read.load() != UINT64_MAX) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_read.load() >> 32) + " read " + std::to_string(bad_read.load() & 0xFFFFFFFFu) + (packed ? ": N list not ascending or out of range" : ": base other than A/C/G/T/N"));
+    if (bad_window.load() != UINT64_MAX) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_window.load() >> 1) + ((bad_window.load() & 1) ? ": character other than A/C/G/T/N in a partner window" : ": character other than A/C/G/T/N in the reference window"), (int32_t)(bad_window.load() >> 1));
+    if (bad_read.load() != UINT64_MAX) return fail(h, BK_E_ARG, "bk_submit_regions: region " + std::to_string(bad_read.load() >> 32) + " read " + std::to_string(bad_read.load() & 0xFFFFFFFFu) + (packed ? ": N list not ascending or out of range" : ": base other than A/C/G/T/N"), (int32_t)(bad_read.load() >> 32));
     // N calls: one sorted list per region (reads are packed in order, positions ascending), flag on the reads that have any;
     // the N positions of the windows, window by window
     std::vector<uint32_t> nlist;
@@ -646,7 +659,7 @@ static void fill_params(bk_handle *h)
     p.n_queue0 = (unsigned long long *)h->d_tops.p + 8; p.pending = (unsigned long long *)h->d_tops.p + 9; p.queue_cap = (unsigned long long *)h->d_tops.p + 10;      // the dynamic unit queue (bk_asm.hip.h)
     p.order_cap = (uint32_t)std::min<uint64_t>(h->d_order.bytes / 4, 0xFFFFFFF0u); p.pad_q = 0;
     p.k = h->cfg.kmer_size; p.rc_thresh = h->cfg.rc_thresh; p.max_contig = h->cfg.max_contig_len; p.max_read = h->eff_max_read;
-    p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions; p.flags = h->cfg.reserved[0];
+    p.max_cand = h->cfg.max_candidates; p.sw_min_score = h->cfg.sw_min_score; p.n_regions = h->n_regions; p.flags = (int32_t)h->cfg.flags;
     p.rmap = nullptr;
 }
 
@@ -794,7 +807,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
     { const char *e = bk_diag_env("BK_POISON_ARENA"); if (e && h->d_arena.p) HIPCHK(h, hipMemsetAsync(h->d_arena.p, atoi(e) & 0xFF, h->d_arena.bytes, h->stream)); }      // diagnostic: what an uninitialised read of the scratch arena sees
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     // workgroup sizes: latency mode (one batch at a time) or throughput mode (batches in flight / a batch that fills the chip)
-    const int asm_threads = subset ? 512 : h->cfg.reserved[1] == 256 ? 256 : h->cfg.reserved[1] == 512 ? 512 : (h->n_regions > 2 * h->n_cu ? 256 : 512);      // more regions than 512-thread workgroups can be resident at once (2 per CU): the smaller ones keep them all in flight
+    const int asm_threads = subset ? 512 : h->cfg.asm_wg_threads == 256 ? 256 : h->cfg.asm_wg_threads == 512 ? 512 : (h->n_regions > 2 * h->n_cu ? 256 : 512);      // more regions than 512-thread workgroups can be resident at once (2 per CU): the smaller ones keep them all in flight
     const int kmer_threads = asm_threads == 512 ? BK_KT_MAX : BK_KT;
     if (mask & BK_STAGE_KMER) {
         if (h->n_big < h->n_regions) {
@@ -825,7 +838,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if (mask & BK_STAGE_ASSEMBLE) {
         // regions ordered by estimated cost, heaviest first (part of the assembler's measured time: ev[1]..ev[2])
-        const bool may_split = !subset && !(h->cfg.reserved[0] & BK_F_NO_SPLIT);
+        const bool may_split = !subset && !(h->cfg.flags & BK_F_NO_SPLIT);
         if (!subset) {
             BkAsmShape sh; { const int rc = asm_shape(h, asm_threads, max_cand, max_contig, (long long)n_launch * (may_split ? BK_SPLIT_G : 1), sh); if (rc != BK_OK) return rc; }
             hipLaunchKernelGGL(bk_sched_kernel, dim3(1), dim3(BK_SCHED_T), 0, h->stream, h->params, (unsigned long long *)h->d_skeys.p, npad, (uint32_t)sh.grid, (uint32_t)(sh.per_cu * h->n_cu));
@@ -834,7 +847,7 @@ static int launch(bk_handle *h, uint32_t mask, const std::vector<uint32_t> *subs
         }
         // Workgroup size: 512 threads (8 wavefronts, 8 look-ahead slots, 2 per CU) finish ONE batch soonest; 256 threads (4
         // wavefronts, 8 slots, 4 per CU) give more regions per CU whose serial phases overlap: +14 % regions/s once the
-        // chip is full.  bk_config.reserved[1] = 256 / 512 chooses; 0 = 512 unless the batch alone fills the chip twice.
+        // chip is full.  bk_config.asm_wg_threads = 256 / 512 chooses; 0 = 512 unless the batch alone fills the chip twice.
         // (a noisy region is split into up to BK_SPLIT_G units on the device, bk_comp.hip.h: the host only knows the bound)
         // (split regions settle inside the assembler: merge + re-queue when components met, link when none did -- no link kernel here)
         { const int rc = launch_asm(h, asm_threads, max_cand, max_contig, (long long)n_launch * (may_split ? BK_SPLIT_G : 1), !subset); if (rc != BK_OK) return rc; }
@@ -873,8 +886,9 @@ static int launch_repair(bk_handle *h, uint32_t mask, const std::vector<uint32_t
     BkAsmShape sh; { const int rc = asm_shape(h, h->asm_threads, h->cfg.max_candidates, h->cfg.max_contig_len, (long long)q.size(), sh); if (rc != BK_OK) return rc; }
     // (a host-driven pass: the queue holds exactly the units of this pass -- queue_cap leaves no room to append, so a region whose
     //  components meet again comes back with BK_ST_REDO; every region of the pass is pending until its last unit has reported in)
-    tops[3] = (unsigned long long)std::min<size_t>((size_t)sh.grid, q.size()); tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 16); tops[5] = (unsigned long long)q.size();
-    tops[8] = (unsigned long long)q.size(); tops[9] = (unsigned long long)n; tops[10] = (unsigned long long)q.size();
+    // (every entry through the queue head, none by block index: the workgroups of this pass wait for *pending, bk_sched.hip.h)
+    tops[3] = 0; tops[4] = std::min<unsigned long long>(tops[2], h->d_clist.bytes / 16); tops[5] = (unsigned long long)q.size();
+    tops[8] = 0; tops[9] = (unsigned long long)n; tops[10] = (unsigned long long)q.size();
     HIPCHK(h, hipMemcpy((unsigned long long *)h->d_tops.p + 3, tops + 3, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
@@ -986,7 +1000,7 @@ static int sync_impl(bk_handle *h)
                 continue;
             }
             int mc, ml;
-            if (!over.empty() && !escalated && h->cfg.reserved[2] != 1 && (h->ran_mask & BK_STAGE_ASSEMBLE) && escalated_caps(h, mc, ml)) {
+            if (!over.empty() && !escalated && !h->cfg.no_escalation && (h->ran_mask & BK_STAGE_ASSEMBLE) && escalated_caps(h, mc, ml)) {
                 for (int i = 0; i < 4; i++) ms_first[i] += ms[i];
                 escalated = true; h->n_escalated = (int)over.size();
                 int rc = launch(h, h->ran_mask, &over);
@@ -1545,7 +1559,7 @@ static int call_impl(bk_handle *h)
                 // check_blat_indel (sv_caller.py:621-651) keeps no indel (ngap_total() = 0 < indel_size), has no other hit to make
                 // an event from, and the contig has no row -- (or BLAT's seeding rule drops the hit and there is no record at all):
                 // no call either way, decided from the raw hit without building the records.
-                if (c->n_hits == 1 && c->n_sec == 0 && c->hits_off && cx.opts.indel_size > 0 && !(h->cfg.reserved[0] & BK_F_NO_CALL_SHORTCUT)) {
+                if (c->n_hits == 1 && c->n_sec == 0 && c->hits_off && cx.opts.indel_size > 0 && !(h->cfg.flags & BK_F_NO_CALL_SHORTCUT)) {
                     const BkHit *h1 = (const BkHit *)(h->h_out.data() + c->hits_off);
                     if (h1->tidx == 0 && h1->qs == 0 && h1->qe == c->seq_len) continue;
                 }
@@ -1758,7 +1772,7 @@ extern "C" int bk_index_find(bk_index *ix, const uint32_t *queries, const uint8_
     uint32_t key_cap = 1; while (key_cap < std::max<uint32_t>(4096u, 4u * n_queries)) key_cap <<= 1;      // a power of two: the sort pads to one
     uint32_t meta[4] = {0, 0, 0, 0};
     for (int attempt = 0; attempt < 3; attempt++) {
-        const uint32_t out_cap = key_cap / 2 + 1;
+        const uint32_t out_cap = min_hits >= 2 ? key_cap / 2 + 1 : key_cap + 1;      // a locus has >= min_hits of the <= key_cap hits (min_hits < 2: every hit may be one)
         if (ix->d_keys.ensure((size_t)key_cap * 8) != hipSuccess || ix->d_runs.ensure(((size_t)key_cap + 1) * 4) != hipSuccess || ix->d_out.ensure((size_t)out_cap * sizeof(BkLocus)) != hipSuccess) return BK_E_NOMEM;
         (void)hipEventRecord(ix->ev[0], ix->stream);
         hipLaunchKernelGGL(bk_index_find_kernel, dim3(1), dim3(BK_FIND_T), 0, ix->stream, (const uint32_t *)ix->d_codes.p, (const uint16_t *)ix->d_seqno.p, (const uint32_t *)ix->d_pos.p, ix->n,

@@ -1915,13 +1915,18 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
     }
     BK_SYNC();
     if (C_.split && C_.own) {
-        // the other units start once unit 0 has run the serial prefix and labelled the graph (unit 0 holds a workgroup by then: its
-        // queue entry comes first); contig serials and stamps go on beyond unit 0's, so nothing it left behind looks current
+        // the other units start once unit 0 has run the serial prefix and labelled the graph: since round 6 it appends their queue
+        // entries at that moment, so the word is set when they get here; with BK_F_PREQUEUE_UNITS (the round-5 queue) they wait for it --
+        // unit 0 holds a workgroup by then, its queue entry was handed out before theirs.  Contig serials and stamps go on beyond unit
+        // 0's, so nothing it left behind looks current
         if (BK_TID == 0) {
             int ok = 0;
             for (int spin = 0; spin < 4000000; spin++) {
                 if (__hip_atomic_load(&wk->phase, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; break; }
                 if (__hip_atomic_load(&wk->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BK_ST_OK) break;
+#ifdef BK_SYNC_CHECK
+                if (__hip_atomic_load(&bk_sync_report[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;      // (unit 0 diverged and ended: bk_common.h)
+#endif
                 __builtin_amdgcn_s_sleep(100);
             }
             if (!ok && !S->status) S->status = BK_ST_UNSPLIT;
@@ -1949,7 +1954,33 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
             if (mn != 0x7FFFFFFF) { fidx = mn; found = bk_seed_at(mn); break; }
             head += BK_AT;
         }
-        if (C_.split && !C_.own && (found < 0 || C_.kcnt[found] < BK_SPLIT_HI)) { bk_label_live(); continue; }      // the serial prefix is over: label what is left, the other units start
+        if (C_.split && !C_.own && (found < 0 || C_.kcnt[found] < BK_SPLIT_HI)) {      // the serial prefix is over: label what is left, the other units start
+            bk_label_live();
+            if (!(p.flags & BK_F_PREQUEUE_UNITS)) {
+                // ... as queue entries this unit appends now (round 6; bk_sched.hip.h): nobody held a workgroup slot waiting for this
+                // prefix.  No room (cannot happen while the host sizes `order` for it): the region reports in for the units that never
+                // started and is run again as one unit by the host.
+                if (BK_TID == 0) {
+                    const unsigned long long cap_ = __hip_atomic_load(p.queue_cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), need = (unsigned long long)C_.split - 1ull;
+                    int ok = 0;
+                    for (;;) {
+                        const unsigned long long old = __hip_atomic_load(p.n_queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old + need > cap_) break;
+                        if (atomicCAS(p.n_queue, old, old + need) == old) {
+                            for (unsigned long long i = 0; i < need; i++) __hip_atomic_store(&p.order[old + i], (uint32_t)r | ((uint32_t)(i + 1ull) << BK_QUEUE_UNIT_SHIFT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = 1; break;
+                        }
+                    }
+                    if (!ok) { __threadfence(); atomicAdd(&wk->units_done, (uint32_t)need); }
+                    S->tmp0 = ok;
+                }
+                BK_SYNC();
+                const int ok = S->tmp0;
+                BK_SYNC();
+                if (!ok) bk_fail(BK_ST_UNSPLIT);
+            }
+            continue;
+        }
         if (found >= 0 && !BK_CHK((uint32_t)found < C_.M, 9, found)) break;
         if (found < 0 || C_.kcnt[found] < 2) break;
 #ifdef BK_DIAG
@@ -2011,6 +2042,11 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
             C_.wk->unit_us[C_.unit] = (uint32_t)((((int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull)) - S->t0) & 0x7FFFFFFF) / 100u;
             if (S->status) atomicCAS((int *)&C_.wk->status, BK_ST_OK, S->status);
             __threadfence();
+            // Unit 0 leaves before it has labelled the graph (the scratch arena was exhausted -- the ordinary first launch of a noisy
+            // batch: the host grows the arena and runs the batch again --, or a cap overflowed in the prefix): the other units were
+            // never appended to the queue, so it reports in for them too.  Without this the region never settles, *pending never
+            // reaches 0 and every workgroup of the launch waits for ever.
+            if (!C_.own && !(p.flags & BK_F_PREQUEUE_UNITS)) atomicAdd(&C_.wk->units_done, (uint32_t)C_.split - 1u);
             const uint32_t done = atomicAdd(&C_.wk->units_done, 1u) + 1u;
             if (done == (uint32_t)C_.split) {
                 // The last unit of the region to report in settles it, here and now (round 5; until round 4 the host did, after the
@@ -2079,15 +2115,18 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
 #ifndef BK_ASM_MINB
 #define BK_ASM_MINB 4
 #endif
+
 extern "C" __global__ void __launch_bounds__(BK_AT, BK_ASM_MINB) BK_ASM_KERNEL(BkParams p)
 {
     bool first = true;
     for (;;) {
         BK_SYNC();                                       // the previous region's LDS state is dead
-        // The first entry a workgroup takes is the one of its own index: the grid is sized for the most units the batch can have
-        // (a noisy region is split into up to BK_SPLIT_G on the device), and with one unit per region the workgroups that find
-        // work must be the FIRST ones launched -- one per CU -- not whichever of two on a CU wins a race for the queue head.
-        // After that the queue is dynamic: *asm_head is the next entry to hand out, *n_queue the entries allocated (split regions
+        // A batch WITHOUT split regions: the first entry a workgroup takes is the one of its own index -- the grid is sized for the most
+        // units the batch can have (a noisy region is split into up to BK_SPLIT_G on the device), and with one unit per region the
+        // workgroups that find work must be the FIRST ones launched -- one per CU -- not whichever of two on a CU wins a race for the
+        // queue head.  A batch WITH split regions has *n_queue0 = 0 (bk_sched.hip.h): every entry is handed out through the head, so no
+        // entry is tied to a workgroup that may not be resident (two handles' kernels could otherwise wait for each other).
+        // The queue is dynamic: *asm_head is the next entry to hand out, *n_queue the entries allocated (split regions
         // whose components met append the units of their next pass, bk_asm_region), an entry is valid once written; a workgroup
         // that finds the queue empty leaves only when no split region can append any more (*pending == 0: at once for a batch
         // without split regions).
@@ -2099,10 +2138,20 @@ extern "C" __global__ void __launch_bounds__(BK_AT, BK_ASM_MINB) BK_ASM_KERNEL(B
                 const unsigned long long hd = __hip_atomic_load(p.asm_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (hd < n) { if (atomicCAS(p.asm_head, hd, hd + 1ull) == hd) { q = (int)hd; break; } continue; }
                 if (__hip_atomic_load(p.pending, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0ull) break;      // (what was appended before the last region settled has been handed out: it could not settle otherwise)
+#ifdef BK_SYNC_CHECK
+                // barrier-check build: a workgroup that diverged has ended without reporting its unit in (bk_common.h) -- *pending will never
+                // reach 0; everybody leaves so that bk_sync can report the divergence instead of hanging
+                if (__hip_atomic_load(&bk_sync_report[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+#endif
                 __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
             }
             if (q >= 0) {
-                while ((e = __hip_atomic_load(&p.order[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == BK_EMPTY32) __builtin_amdgcn_s_sleep(20);      // allocated, not yet written
+                while ((e = __hip_atomic_load(&p.order[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == BK_EMPTY32) {      // allocated, not yet written
+#ifdef BK_SYNC_CHECK
+                    if (__hip_atomic_load(&bk_sync_report[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { e = BK_QUEUE_NOP; break; }
+#endif
+                    __builtin_amdgcn_s_sleep(20);
+                }
             }
             S_->qslot = q; S_->tmp2 = (int)e;
         }

@@ -258,7 +258,24 @@ struct BkParams {
     int32_t flags;               // BK_F_*
     const uint32_t *rmap;        // launch over a subset of the batch (re-run of regions that overflowed a cap): workgroup b of the k-mer kernels takes region rmap[b]; nullptr = region b
 };
-enum { BK_F_NO_DUAL = 1, BK_F_SPEC4 = 2, BK_F_DUAL_ALWAYS = 4, BK_F_NO_XVISIT = 8, BK_F_NO_XSEED = 16, BK_F_BUCKET_SORT = 32, BK_F_NO_RUN_RETIRE = 64, BK_F_NO_SPLIT = 128, BK_F_SPLIT_ALWAYS = 256, BK_F_SPLIT_NO_LOOKAHEAD = 512, BK_F_SPLIT = 1024, BK_F_NO_CALL_SHORTCUT = 2048, BK_F_HOST_REPAIR = 4096, BK_F_NO_SCORE_SWEEP = 8192 };   // 8192: every overlap DP is the full sweep with origins (no score sweep first: the round-4 DP rounds; same results)   // 4096: split regions whose components met are repaired by host-driven passes (the round-4 way: the fallback of the in-kernel repair, kept testable)   // noisy regions are split into units (bk_comp.hip.h) by DEFAULT since round 5; 1024: accepted, no effect (it switched the split on while it was experimental)   // 512: diagnostic -- no look-ahead inside split regions (the round-4 setting)   // 128: every region is one unit (no component split); 256: split whatever the size (diagnostic: the split path on small fixtures)   // 2048: bk_call takes every contig through the full caller (no shortcut for single full-span hits; tests)   // 8: look-ahead within one k-mer visit only; 16: no look-ahead into the next seeds; 32: the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number (diagnostic)   // 2: at most 4 look-ahead slots (diagnostic)      // diagnostic: two wavefronts per look-ahead slot (one DP each) even for short contigs
+// BkParams.flags = bk_config.flags (include/breakmer_hip.h: BK_CFG_*, same values; every bit is another way to the same results)
+enum {
+    BK_F_NO_DUAL = 1,                // diagnostic: one overlap DP per wavefront even for short contigs
+    BK_F_SPEC4 = 2,                  // diagnostic: at most 4 look-ahead slots
+    BK_F_DUAL_ALWAYS = 4,            // diagnostic: both DPs of a slot on one wavefront whatever the round holds
+    BK_F_NO_XVISIT = 8,              // look-ahead within one k-mer visit only
+    BK_F_NO_XSEED = 16,              // no look-ahead into the next seeds
+    BK_F_BUCKET_SORT = 32,           // the k-mer stage orders the seed k-mers with the bucket sort of large regions whatever their number
+    BK_F_NO_RUN_RETIRE = 64,         // every read retired on its own
+    BK_F_NO_SPLIT = 128,             // every region is one unit (no component split)
+    BK_F_SPLIT_ALWAYS = 256,         // split whatever the size (the split path on small fixtures)
+    BK_F_SPLIT_NO_LOOKAHEAD = 512,   // diagnostic: no look-ahead inside split regions (the round-4 setting)
+    BK_F_SPLIT = 1024,               // accepted, no effect (it switched the split on while it was experimental)
+    BK_F_NO_CALL_SHORTCUT = 2048,    // bk_call takes every contig through the full caller
+    BK_F_HOST_REPAIR = 4096,         // split regions whose components met are repaired by host-driven passes (the fallback of the in-kernel repair, kept testable)
+    BK_F_NO_SCORE_SWEEP = 8192,      // every overlap DP is the full sweep with origins (the round-4 DP rounds)
+    BK_F_PREQUEUE_UNITS = 16384      // the units of a split region are queue entries of the launch and wait for unit 0 (the round-5 queue); default since round 6: unit 0 appends them once the graph is labelled
+};
 
 // component info word (BkRegionWork.o_cinfo, at the component's root read)
 #define BK_CI_UNIT 0xFFu

@@ -59,6 +59,11 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
     BK_SYNC();
     const uint32_t nwant = nsplit_s;
     const uint32_t G = nwant ? (uint32_t)BK_SPLIT_G : 0u; (void)resident;
+    // Round 6: the units of a split region beyond the first are NOT entries of the launch any more: unit 0 appends them itself once it
+    // has run the serial prefix and labelled the graph (bk_asm.hip.h).  Queued at launch they took workgroup slots and slept until their
+    // region's prefix was over -- 2.7 to 36 ms at 0.5 % noise -- while the units of regions that were ready waited behind them in the queue
+    // (256 noisy regions: 247 ms of assembler for ~96 ms of work per slot).  BK_F_PREQUEUE_UNITS is the round-5 queue (tests hold both).
+    const bool preq = (p.flags & BK_F_PREQUEUE_UNITS) != 0;
     for (int i = tid; i < n; i += BK_SCHED_T) if (p.work[i].split) p.work[i].split = G;
     __threadfence(); BK_SYNC();
     if (tid == 0) nsplit_s = G ? nwant : 0u;
@@ -66,7 +71,7 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
     for (int c0 = 0; c0 < n; c0 += BK_SCHED_T) {
         const int i = c0 + tid;
         uint32_t rid = 0, g = 0;                                             // g: units beyond the first
-        if (i < n) { rid = (uint32_t)keys[i]; const uint32_t sp = p.work[rid].split; g = sp ? sp - 1u : 0u; }
+        if (i < n) { rid = (uint32_t)keys[i]; const uint32_t sp = p.work[rid].split; g = (sp && preq) ? sp - 1u : 0u; }
         uint32_t inc = g;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((tid & 63) >= o) inc += t; }
         if ((tid & 63) == 63) wsum[tid >> 6] = inc;
@@ -79,11 +84,17 @@ extern "C" __global__ void __launch_bounds__(BK_SCHED_T) bk_sched_kernel(BkParam
         if (tid == 0) base_s += tot;
         BK_SYNC();
     }
-    // the queue is dynamic (bk_asm.hip.h): room behind the launch's entries for the units that split regions append when their
-    // components met across units (marked empty: an entry is valid once written); the first asm_grid entries are taken by block index
+    // the queue is dynamic (bk_asm.hip.h): room behind the launch's entries for the units split regions append -- those of the first pass
+    // once unit 0 has labelled the graph, those of a repair pass when components met across units (marked empty: an entry is valid once
+    // written); a batch without split regions takes its first asm_grid entries by block index
     BK_SYNC();
     const uint32_t nq = base_s, nsp = nsplit_s;
-    const uint32_t ext_end = (p.flags & BK_F_HOST_REPAIR) ? nq : (uint32_t)min((unsigned long long)p.order_cap, (unsigned long long)nq + (unsigned long long)nsp * BK_SPLIT_G * BK_REQUEUE_PASSES);
+    const unsigned long long room = (preq ? 0ull : (unsigned long long)nsp * (BK_SPLIT_G - 1)) + ((p.flags & BK_F_HOST_REPAIR) ? 0ull : (unsigned long long)nsp * BK_SPLIT_G * BK_REQUEUE_PASSES);
+    const uint32_t ext_end = (uint32_t)min((unsigned long long)p.order_cap, (unsigned long long)nq + room);
     for (uint32_t i = nq + tid; i < ext_end; i += BK_SCHED_T) p.order[i] = BK_EMPTY32;
-    if (tid == 0) { *p.n_queue = nq; *p.n_queue0 = nq; *p.asm_head = min(asm_grid, nq); *p.pending = nsp; *p.queue_cap = ext_end; }
+    // A batch WITH split regions hands out every entry through *asm_head, the first one of a workgroup included (n_queue0 = 0): a workgroup
+    // that finds the queue empty waits for *pending, and with entries reserved by block index it could wait for a workgroup that is not
+    // resident yet -- two assembler kernels of two handles, each partly resident, then wait for each other for ever.  Any
+    // resident workgroup can take any entry now; what a taken entry waits for (unit 0's labelling) is held by a workgroup that is running.
+    if (tid == 0) { *p.n_queue = nq; *p.n_queue0 = nsp ? 0u : nq; *p.asm_head = nsp ? 0u : min(asm_grid, nq); *p.pending = nsp; *p.queue_cap = ext_end; }
 }

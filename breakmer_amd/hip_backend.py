@@ -22,7 +22,10 @@ LIB_PATH = os.path.join(_HERE, "libbreakmer_hip.so")      # the product build; d
 
 BK_STAGE_KMER, BK_STAGE_ASSEMBLE, BK_STAGE_REALIGN, BK_STAGE_ALL = 1, 2, 4, 7
 BK_MAX_BLOCKS = 32
-BK_ABI_VERSION = 4
+BK_ABI_VERSION = 5
+BK_E_ARG = -1
+# bk_config.flags (include/breakmer_hip.h: BK_CFG_*); production leaves 0
+BK_CFG_NO_SPLIT, BK_CFG_TEST_SPLIT_ALWAYS, BK_CFG_TEST_FULL_CALLER, BK_CFG_TEST_HOST_REPAIR, BK_CFG_TEST_PREQUEUE_UNITS = 128, 256, 2048, 4096, 16384
 BK_PSL_FLAT_HEAD = 18
 BK_W_REGIONS_FAILED = 1
 
@@ -30,7 +33,8 @@ BK_W_REGIONS_FAILED = 1
 class BkConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("kmer_size", C.c_int32), ("rc_thresh", C.c_int32),
                 ("max_contig_len", C.c_int32), ("max_read_len", C.c_int32), ("max_candidates", C.c_int32),
-                ("arena_bytes", C.c_int64), ("sw_min_score", C.c_int32), ("out_kbytes", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("arena_bytes", C.c_int64), ("sw_min_score", C.c_int32), ("out_kbytes", C.c_int32),
+                ("flags", C.c_uint32), ("asm_wg_threads", C.c_int32), ("no_escalation", C.c_int32), ("submit_threads", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class BkRegion(C.Structure):
@@ -70,13 +74,15 @@ def call_text(text):
 EXPORTS = ["bk_create", "bk_destroy", "bk_last_error", "bk_abi_version", "bk_submit_regions", "bk_submit_regions_ex", "bk_run", "bk_sync", "bk_fetch",
            "bk_last_kernel_ms", "bk_get_region_status", "bk_get_kmer_count", "bk_get_kmers", "bk_get_contig_count", "bk_get_contig_info",
            "bk_get_contig", "bk_get_hits", "bk_get_stat", "bk_call_text", "bk_set_call_context", "bk_call", "bk_call_async", "bk_get_calls", "bk_get_contig_counts",
-           "bk_nw_batch", "bk_pack_sequence", "bk_trim", "bk_get_hits_flat", "bk_index_create", "bk_index_probe", "bk_index_destroy", "bk_index_set_loci", "bk_index_find"]
+           "bk_nw_batch", "bk_pack_sequence", "bk_trim", "bk_get_hits_flat", "bk_index_create", "bk_index_probe", "bk_index_destroy", "bk_index_set_loci", "bk_index_find", "bk_last_error_region"]
 
 _lib = None
 
 
 class BreakmerHipError(RuntimeError):
-    pass
+    """code: the BK_E_* value the library returned; region: the region a failed submit names (bk_last_error_region), else -1"""
+    code = 0
+    region = -1
 
 
 def load_library(path=None):
@@ -95,6 +101,8 @@ def load_library(path=None):
     L = C.CDLL(lp)
     L.bk_last_error.restype = C.c_char_p
     L.bk_last_error.argtypes = [C.c_void_p]
+    L.bk_last_error_region.restype = C.c_int32
+    L.bk_last_error_region.argtypes = [C.c_void_p]
     L.bk_create.argtypes = [C.c_int, C.POINTER(BkConfig), C.POINTER(C.c_void_p)]
     L.bk_destroy.argtypes = [C.c_void_p]
     L.bk_submit_regions.argtypes = [C.c_void_p, C.POINTER(BkRegion), C.c_int32]
@@ -267,10 +275,10 @@ class Engine(object):
         cfg.arena_bytes = int(limits.get("arena_bytes", 0))
         cfg.out_kbytes = int(limits.get("out_kbytes", 0))
         cfg.sw_min_score = int(limits.get("sw_min_score", 0))
-        cfg.reserved[0] = int(limits.get("flags", 0))
-        cfg.reserved[1] = int(limits.get("wg_threads", 0))          # assembler workgroup size: 0 = library default, 256 (throughput) or 512 (latency)
-        cfg.reserved[2] = int(limits.get("no_escalation", 0))       # 1: regions that overflow an assembler cap fail at once instead of being re-run under larger caps
-        cfg.reserved[3] = int(limits.get("submit_threads", 0))      # host threads filling the staging buffer of a submit (0: library default)
+        cfg.flags = int(limits.get("flags", 0))                     # BK_CFG_* (0 in production)
+        cfg.asm_wg_threads = int(limits.get("wg_threads", 0))       # assembler workgroup size: 0 = library default, 256 (throughput) or 512 (latency)
+        cfg.no_escalation = int(limits.get("no_escalation", 0))     # 1: regions that overflow an assembler cap fail at once instead of being re-run under larger caps
+        cfg.submit_threads = int(limits.get("submit_threads", 0))   # host threads filling the staging buffer of a submit (0: library default)
         self.k = int(kmer_size)
         self.rc_thresh, self.device = int(rc_thresh), int(device)
         self._inputs = None
@@ -278,13 +286,17 @@ class Engine(object):
         self.batch_serial = 0
         rc = self.L.bk_create(int(device), C.byref(cfg), C.byref(self.h))
         if rc != 0:
-            raise BreakmerHipError("bk_create failed (%d): %s" % (rc, self.L.bk_last_error(None).decode()))
+            ex = BreakmerHipError("bk_create failed (%d): %s" % (rc, self.L.bk_last_error(None).decode()))
+            ex.code = rc
+            raise ex
         self.n_regions = 0
         self.n_failed = 0
 
     def _chk(self, rc, what):
         if rc != 0:
-            raise BreakmerHipError("%s failed (%d): %s" % (what, rc, self.L.bk_last_error(self.h).decode()))
+            ex = BreakmerHipError("%s failed (%d): %s" % (what, rc, self.L.bk_last_error(self.h).decode()))
+            ex.code, ex.region = rc, int(self.L.bk_last_error_region(self.h))
+            raise ex
 
     def close(self):
         if self.h:

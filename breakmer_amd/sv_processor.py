@@ -950,9 +950,10 @@ class runner(object):                                               # sv_process
         except TypeError:
             eng.run(hip_backend.BK_STAGE_ALL)
         except hip_backend.BreakmerHipError as ex:
-            # the (asynchronous) submit of a lane batch found a character other than A/C/G/T/N in a window: the per-target way names
-            # the target, skips it ALONE and hands the others over again
-            if type(live) is not _LaneBatch or "in the reference window" not in str(ex):
+            # the (asynchronous) submit of a lane batch was refused (BK_E_ARG: a character other than A/C/G/T/N in a window, ...): the
+            # per-target way names the target, skips it ALONE and hands the others over again.  The branch is on the library's error
+            # CODE (hip_backend.BreakmerHipError.code), never on the wording of its message
+            if type(live) is not _LaneBatch or getattr(ex, "code", 0) != hip_backend.BK_E_ARG:
                 raise
             live = self._prepare(live.keys)
             if not live or self._submit_batch(eng, live) is False:

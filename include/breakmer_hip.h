@@ -18,13 +18,16 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 4       /* 2: bk_psl holds 32 blocks; bk_get_hits also returns secondary alignments; bk_sync reports regions that hit a cap (BK_W_REGIONS_FAILED)
+#define BK_ABI_VERSION 5       /* 2: bk_psl holds 32 blocks; bk_get_hits also returns secondary alignments; bk_sync reports regions that hit a cap (BK_W_REGIONS_FAILED)
                                 * 3: the realign stage has no hit / block caps any more (bk_get_hits_flat returns records of any size, bk_call uses them);
                                 *    reference / partner windows may be soft-masked (lower case => rep_matches); regions that overflow an assembler cap are
-                                *    re-run by the library with larger ones (bk_config.reserved[2]); BK_SUBMIT_PACKED
-                                * 4: noisy regions are split over up to 16 assembler workgroups by default (same results; reserved[0] bit 128 = never);
+                                *    re-run by the library with larger ones (bk_config.no_escalation); BK_SUBMIT_PACKED
+                                * 4: noisy regions are split over up to 16 assembler workgroups by default (same results; BK_CFG_NO_SPLIT = never);
                                 *    the realign records pass BLAT's documented output filters (-minScore, -minIdentity default 90: oracle/bk_oracle.h
-                                *    step 8); bk_index_set_loci / bk_index_find; the product build reads no environment variable (diagnostics: -DBK_DIAG) */
+                                *    step 8); bk_index_set_loci / bk_index_find; the product build reads no environment variable (diagnostics: -DBK_DIAG)
+                                * 5: what bk_config.reserved[0..3] carried until ABI 4 has NAMES (flags, asm_wg_threads, no_escalation, submit_threads: same
+                                *    offsets, same values); bk_create rejects a non-zero `reserved` word, an unknown flag bit and -- in the product build --
+                                *    the diagnostic-only bits (BK_CFG_DIAG_MASK); submit errors that name a region carry its index (bk_last_error_region) */
 
 enum {
     BK_OK = 0,
@@ -59,21 +62,39 @@ typedef struct bk_config {
     int64_t arena_bytes;        /* device scratch arena; 0 = choose from the batch; grown and retried on overflow */
     int32_t sw_min_score;       /* BLAT -minScore=20 analogue for the realign stage (sv_processor.py:843) */
     int32_t out_kbytes;         /* initial result arena in KiB; 0 = choose from the batch; grown and retried on overflow */
-    int32_t reserved[6];        /* [0]: diagnostic flags (0 in production; 1 = one overlap DP per wavefront even for short contigs,
-                                 *      8 = no look-ahead across k-mer visits, 16 = no look-ahead into the next seeds: same results, more DP rounds;
-                                 *      32 = bucket sort of the seed k-mers whatever their number (the path of very large noisy regions),
-                                 *      64 = every read retired on its own (no run retire): same results)
-                                 *      noisy regions (>= 1,024 seed k-mers) are split into up to 16 units that run on 16 workgroups and repair
-                                 *      themselves inside the kernel where components meet (same results, 2-6x faster on such regions; the default
-                                 *      since ABI 4): 128 = never split (one workgroup per region), 256 = split whatever the size (tests),
-                                 *      512 = no look-ahead inside split regions, 4096 = repair passes driven by the host (the fallback path),
-                                 *      1024 = accepted, no effect (it switched the split on while it was opt-in);
-                                 *      2048 = bk_call takes every contig through the full caller (no shortcut for single full-span hits))
-                                 * [1]: assembler workgroup size: 512 = 8 wavefronts / 8 look-ahead slots / 2 per CU (one batch finishes soonest),
-                                 *      256 = 4 wavefronts / 4 slots / 4 per CU (most regions/s when batches are in flight), 0 = library chooses
-                                 * [2]: 1 = do NOT re-run regions that overflow an assembler cap with larger caps (they fail at once: bk_get_region_status)
-                                 * [3]: host threads that fill the staging buffer of one submit (0 = library chooses; 1 .. 64) */
+    uint32_t flags;             /* BK_CFG_* bits below; 0 in production */
+    int32_t asm_wg_threads;     /* assembler workgroup size: 512 = 8 wavefronts / 8 look-ahead slots / 2 per CU (one batch finishes soonest),
+                                 * 256 = 4 wavefronts / 8 slots / 4 per CU (most regions/s when batches are in flight), 0 = the library chooses */
+    int32_t no_escalation;      /* 1 = do NOT re-run regions that overflow an assembler cap under larger caps (they fail at once: bk_get_region_status) */
+    int32_t submit_threads;     /* host threads that fill the staging buffer of one submit (0 = the library chooses; 1 .. 64) */
+    int32_t reserved[2];        /* must be 0 (bk_create: BK_E_ARG otherwise) */
 } bk_config;
+
+/* bk_config.flags.  Every bit selects another way to the SAME results (the GPU suite holds them against each other); production leaves 0.
+ *   option        BK_CFG_NO_SPLIT: noisy regions (>= 1,024 seed k-mers) are NOT split into up to 16 units on 16 workgroups (the split is the
+ *                 default since ABI 4: identical results, 2-6x faster on such regions);
+ *   test hooks    accepted by every build -- the parity tests run the product's alternative paths through them;
+ *   diagnostics   BK_CFG_DIAG_MASK: accepted by the -DBK_DIAG builds only (breakmer_amd/build.py: diag / check / jitter / stamps); the product
+ *                 build's bk_create answers BK_E_ARG. */
+enum {
+    BK_CFG_DIAG_NO_DUAL = 1,              /* diagnostic: one overlap DP per wavefront even for short contigs */
+    BK_CFG_DIAG_SPEC4 = 2,                /* diagnostic: at most 4 look-ahead slots */
+    BK_CFG_DIAG_DUAL_ALWAYS = 4,          /* diagnostic: both DPs of a slot on one wavefront whatever the number of reads in the round */
+    BK_CFG_TEST_NO_XVISIT = 8,            /* test hook: no look-ahead across the k-mer visits of grow */
+    BK_CFG_TEST_NO_XSEED = 16,            /* test hook: no look-ahead into the next seeds */
+    BK_CFG_TEST_BUCKET_SORT = 32,         /* test hook: bucket sort of the seed k-mers whatever their number (the path of very large noisy regions) */
+    BK_CFG_TEST_NO_RUN_RETIRE = 64,       /* test hook: every read retired on its own */
+    BK_CFG_NO_SPLIT = 128,                /* option: one assembler workgroup per region, never split */
+    BK_CFG_TEST_SPLIT_ALWAYS = 256,       /* test hook: split whatever the size of the region (the split path on small fixtures) */
+    BK_CFG_DIAG_SPLIT_NO_LOOKAHEAD = 512, /* diagnostic: no look-ahead inside split regions (the round-4 setting) */
+    BK_CFG_DIAG_LEGACY_SPLIT = 1024,      /* diagnostic builds accept it, no effect (it switched the split on while it was opt-in, ABI 3) */
+    BK_CFG_TEST_FULL_CALLER = 2048,       /* test hook: bk_call takes every contig through the full caller (no shortcut for single full-span hits) */
+    BK_CFG_TEST_HOST_REPAIR = 4096,       /* test hook: repair passes of split regions driven by the host (the fallback when the unit queue is full) */
+    BK_CFG_TEST_NO_SCORE_SWEEP = 8192,    /* test hook: every overlap DP is the full sweep with origins (the round-4 DP rounds) */
+    BK_CFG_TEST_PREQUEUE_UNITS = 16384,   /* test hook: the units of a split region are queued at launch and wait for unit 0 (the round-5 queue) instead of being appended by it */
+    BK_CFG_DIAG_MASK = 1 | 2 | 4 | 512 | 1024,
+    BK_CFG_KNOWN_MASK = 32767
+};
 
 /* One target region = what sv_processor.target hands to compare_kmers()/resolve_sv()
  * (sv_processor.py:609-665): the cleaned reads (self.cleaned_read_recs before grouping,
@@ -108,6 +129,10 @@ typedef struct bk_region {
 int bk_create(int device_id, const bk_config *cfg, bk_handle **out);
 int bk_destroy(bk_handle *h);
 const char *bk_last_error(const bk_handle *h);   /* h may be NULL: last error of bk_create */
+/* The region a failed bk_submit_regions[_ex] names in its error text (BK_E_ARG: a character other than A/C/G/T/N in a window or a read,
+ * a read longer than max_read_len, ...), or -1 when the last error names none.  A batching driver branches on THIS, not on the wording:
+ * it hands the other targets over again and skips that one alone (the per-target analogue: sv_processor.py:190-192). */
+int32_t bk_last_error_region(const bk_handle *h);
 /* Free every device / pinned buffer of the handle larger than keep_bytes (the scratch arena grows with the largest batch it
  * has seen and is otherwise only freed by bk_destroy); the submitted batch is dropped, the next bk_submit_regions sizes
  * the buffers anew.  For callers that keep handles between runs (the reference creates everything per run). */
@@ -272,7 +297,7 @@ int bk_nw_batch(bk_handle *h, const char *seqs, size_t seq_bytes, const uint32_t
  *           3: algorithmic HBM bytes (SURVEY 8d formula), 4: unique reads, 5: sample k-mers, 6: contigs,
  *           20/21: host packing / host-to-device copy time of the last bk_submit_regions (microseconds),
  *           22: regions of the last run that failed on a device cap (bk_get_region_status),
- *           26: regions the library re-ran with larger assembler caps (bk_config.reserved[2]) */
+ *           26: regions the library re-ran with larger assembler caps (unless bk_config.no_escalation) */
 int bk_get_stat(bk_handle *h, int which, uint64_t *value);
 
 #ifdef __cplusplus

@@ -149,3 +149,72 @@ def test_struct_packed_region_array_equals_the_ctypes_one():
                 assert not a.partners and not b.partners
             else:
                 assert getattr(a, name) == getattr(b, name), name
+
+
+def test_struct_layouts_of_the_header_equal_the_ctypes_mirrors(tmp_path):
+    """ABI 5: every structure of include/breakmer_hip.h as a C compiler lays it out (gcc on the header itself: sizeof and the offset of
+    every member) against the ctypes mirrors a binding uses (breakmer_amd/hip_backend.py; INTEGRATION.md shows the same declarations)."""
+    import subprocess
+    from breakmer_amd import hip_backend as hb
+    structs = {"bk_config": hb.BkConfig, "bk_region": hb.BkRegion, "bk_contig_info": hb.BkContigInfo, "bk_psl": hb.BkPsl}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "breakmer_hip.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (name, name))
+        for f, _t in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+    lines.append('printf("abi %d known %d diag %d\\n", BK_ABI_VERSION, BK_CFG_KNOWN_MASK, BK_CFG_DIAG_MASK); return 0; }')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    got = {}
+    for ln in out:
+        w = ln.split()
+        if len(w) == 3 and w[0] in structs:
+            got[(w[0], w[1])] = int(w[2])
+    for name, cls in structs.items():
+        assert got[(name, "sizeof")] == C.sizeof(cls), name
+        for f, _t in cls._fields_:
+            assert got[(name, f)] == getattr(cls, f).offset, (name, f)
+    assert ("abi %d " % hb.BK_ABI_VERSION) in out[-2]
+    # the names the Python layer uses for the flag bits are the header's
+    hdr = open(os.path.join(ROOT, "include", "breakmer_hip.h")).read()
+    for nm in ("BK_CFG_NO_SPLIT", "BK_CFG_TEST_SPLIT_ALWAYS", "BK_CFG_TEST_FULL_CALLER", "BK_CFG_TEST_HOST_REPAIR", "BK_CFG_TEST_PREQUEUE_UNITS"):
+        m = re.search(r"\b%s\s*=\s*(\d+)" % nm, hdr)
+        assert m and int(m.group(1)) == getattr(hb, nm), nm
+    # ... and the device code's BK_F_* values are the same bits
+    com = open(os.path.join(ROOT, "breakmer_amd", "csrc", "bk_common.h")).read()
+    cfg_bits = {int(v) for v in re.findall(r"\bBK_CFG_(?:DIAG|TEST)?_?[A-Z0-9_]+\s*=\s*(\d+)\s*,", hdr)}
+    f_bits = {int(v) for v in re.findall(r"\bBK_F_[A-Z0-9_]+\s*=\s*(\d+)", com)}
+    assert f_bits == cfg_bits and len(f_bits) == 15, (sorted(f_bits), sorted(cfg_bits))
+
+
+def test_bk_create_checks_its_configuration_before_it_looks_for_a_device(lib):
+    """ABI 5: a non-zero `reserved` word, an unknown flag bit, a diagnostic-only bit (product build), a workgroup size other than 0 / 256 /
+    512 are BK_E_ARG on any machine; a valid configuration then fails with BK_E_NOGPU here (no CPU fallback) or succeeds on a GPU box."""
+    from breakmer_amd import hip_backend as hb
+
+    def create(**kw):
+        cfg = hb.BkConfig()
+        cfg.abi_version, cfg.kmer_size, cfg.rc_thresh = hb.BK_ABI_VERSION, 31, 2
+        for k, v in kw.items():
+            if k == "reserved":
+                cfg.reserved[v[0]] = v[1]
+            else:
+                setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.bk_create(0, C.byref(cfg), C.byref(h))
+        text = lib.bk_last_error(None).decode() if rc else ""
+        if rc == 0:
+            lib.bk_destroy(h)
+        return rc, text
+
+    for bad, word in ((dict(reserved=(0, 1)), "reserved"), (dict(reserved=(1, 7)), "reserved"), (dict(flags=1 << 20), "unknown bit"), (dict(flags=512), "diagnostic-only"),
+                      (dict(flags=1), "diagnostic-only"), (dict(asm_wg_threads=128), "asm_wg_threads"), (dict(no_escalation=2), "no_escalation"), (dict(submit_threads=65), "submit_threads"),
+                      (dict(abi_version=4), "ABI version")):
+        rc, text = create(**bad)
+        assert rc == hb.BK_E_ARG and word in text, (bad, rc, text)
+    rc, text = create(flags=hb.BK_CFG_NO_SPLIT | hb.BK_CFG_TEST_SPLIT_ALWAYS, asm_wg_threads=256, no_escalation=1, submit_threads=4)
+    assert rc in (0, -3), (rc, text)
+    assert lib.bk_last_error_region(None) == -1

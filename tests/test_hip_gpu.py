@@ -261,7 +261,7 @@ def test_g3_assembly_golden_gpu(hb, golden_dir):
 
 def test_both_workgroup_sizes_gpu(hb, golden_dir):
     """The assembler exists in two workgroup sizes (512 threads / 8 look-ahead slots, 256 threads / 4 slots; bk_config
-    reserved[1]): the reference fixtures, a noisy region and long contigs give the same records through both."""
+    asm_wg_threads): the reference fixtures, a noisy region and long contigs give the same records through both."""
     from oracle import bk_oracle as bo
     d = _load(golden_dir, "assembly.json")
     cases = [c for c in d["cases"] if c["k"] == 31 and c["rc_thresh"] == 2]
@@ -324,11 +324,58 @@ def test_split_regions_are_bit_identical_gpu(hb, golden_dir):
     assert many.stat(1) >= one.stat(1)                                       # (the DPs of components that ran again are counted too)
     host = _run_regions(hb, full, 31, stages=7, flags=4096)                  # the fallback: repair passes driven by the host (no room in the unit queue)
     assert host.sync() == 0 and host.stat(28) >= 4 and host.stat(29) >= 1
+    preq = _run_regions(hb, full, 31, stages=7, flags=hb.BK_CFG_TEST_PREQUEUE_UNITS)      # the round-5 queue: the units of a region are entries of the launch and wait for unit 0
+    assert preq.sync() == 0 and preq.stat(28) >= 4
     for i in range(len(full)):
-        a, b, c = one.contigs(i), many.contigs(i), host.contigs(i)
-        assert len(a) == len(b) and a == b and c == a, (i, len(a), len(b), len(c))
+        a, b, c, e = one.contigs(i), many.contigs(i), host.contigs(i), preq.contigs(i)
+        assert len(a) == len(b) and a == b and c == a and e == a, (i, len(a), len(b), len(c), len(e))
         for ci in range(0, len(a), 50):
-            assert one.hits(i, ci) == many.hits(i, ci) == host.hits(i, ci), (i, ci)
+            assert one.hits(i, ci) == many.hits(i, ci) == host.hits(i, ci) == preq.hits(i, ci), (i, ci)
+    # (d) ... and DIRECTLY against the oracle at full size (round 6: until then full-size noisy regions were only held split-vs-one-unit
+    #     and run-vs-run; the oracle comparison of noisy regions stopped at depth 300): the 0.2 % region and the three 0.5 % regions,
+    #     10,000 reads each, ~1,100-1,200 contigs per region, every field of every contig; realign records of every 40th contig
+    for i in (0, 1, 2, 3):
+        r = full[i]
+        want, _ = bo.assemble_region(synth.BASES[r.reads], [r.window_str], 31, 2, find_index=True)
+        got = many.contigs(i)
+        assert len(got) == len(want) and len(want) > 300, (i, len(got), len(want))
+        assert _strip(got) == want, i
+        for ci in range(0, len(got), 40):
+            assert many.hits(i, ci) == bo.realign(got[ci]["seq"], [r.window_str]), (i, ci)
+
+
+def test_split_batches_on_concurrent_handles_gpu(hb):
+    """with the unit queue of round 5 a workgroup that found the queue empty waited for *pending while the first
+    entries were tied to workgroups by block index -- two assembler kernels of two handles, each only partly resident, could wait for
+    each other for ever.  Since round 6 every entry of a batch with split regions is handed out through the queue head (bk_sched.hip.h).
+    Four handles, each with a batch whose units (64 regions x 16) exceed what the chip holds resident, split forced, launched back to
+    back and waited for together, three times over; a fifth handle runs the same regions with the round-5 queue order
+    (BK_CFG_TEST_PREQUEUE_UNITS) in the same crowd.  Every handle must come back -- the test runs under the suite's timeout -- with the
+    records of a handle that ran alone, and those are the oracle's."""
+    from oracle import bk_oracle as bo
+    regions = [synth.make_region(8800 + i, sv_type=synth.SV_TYPES[i % 5], depth=(120, 200)[i % 2], W=1200, noise=(0.004, 0.008, 0.006)[i % 3]) for i in range(64)]
+    ins = [hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, partners=[p[4] for p in r.partners]) for r in regions]
+    alone = hb.Engine(kmer_size=31, flags=hb.BK_CFG_TEST_SPLIT_ALWAYS)
+    alone.submit(ins); alone.run(7)
+    assert alone.stat(22) == 0 and alone.stat(28) >= 48
+    ref = [alone.contigs(i) for i in range(len(regions))]
+    for i in range(0, len(regions), 9):
+        want, _ = bo.assemble_region(regions[i].read_strs(), [regions[i].window_str], 31, 2)
+        assert _strip(ref[i]) == want, i
+    engs = [hb.Engine(kmer_size=31, flags=hb.BK_CFG_TEST_SPLIT_ALWAYS | (hb.BK_CFG_TEST_PREQUEUE_UNITS if j == 4 else 0), wg_threads=(512, 256)[j % 2]) for j in range(5)]
+    for e in engs:
+        e.submit(ins)
+    for rep in range(3):
+        for e in engs:
+            e.run(7, sync=False)
+        for j, e in enumerate(engs):
+            assert e.sync() == 0, (rep, j)
+            assert e.stat(28) >= 48
+        for j, e in enumerate(engs):
+            for i in range(rep, len(regions), 5):
+                assert e.contigs(i) == ref[i], (rep, j, i)
+    for e in engs + [alone]:
+        e.close()
 
 
 def test_barrier_discipline_of_every_kernel_gpu():
@@ -889,7 +936,7 @@ def test_native_tail_equals_python_tail_on_noisy_regions_gpu(hb, tmp_path):
 
 def test_call_shortcut_equals_full_caller_gpu(hb, golden_dir):
     """bk_call decides a contig whose only alignment is ONE gap-free hit over its whole length on the target window from the raw
-    hit (no records, no target_hit / get_result: bk_api.hip call_impl).  With the shortcut switched off (bk_config.reserved[0] bit
+    hit (no records, no target_hit / get_result: bk_api.hip call_impl).  With the shortcut switched off (bk_config.flags bit
     2048) every contig goes through the full caller: the call records must be byte-identical -- on noisy regions (hundreds of
     such contigs), on clean ones of every SV type, and on the regions of the reference-made surface fixtures."""
     import sys
@@ -1355,7 +1402,7 @@ def test_async_submit_gpu(hb):
 def test_lookahead_across_visits_changes_nothing_gpu(hb):
     """The look-ahead across k-mer visits and into the next seeds only moves DPs to an earlier round: contigs, realign
     records and the DP work counted (the reference's nw calls and cells) are the same with either or both switched off
-    (bk_config.reserved[0] = 8 / 16 / 24), for both workgroup sizes, on clean, noisy and N-carrying regions.  The same for
+    (bk_config.flags = 8 / 16 / 24), for both workgroup sizes, on clean, noisy and N-carrying regions.  The same for
     the run retire (64 = off: every read retired on its own): reads that leave the contig sequence as it is -- rejected,
     identical, contained -- are retired together; on the noisy regions whole runs are rejections (the shape that made the
     first, unguarded version of it crawl: a run without a contained read has an empty count range)."""
@@ -1383,7 +1430,7 @@ def test_lookahead_across_visits_changes_nothing_gpu(hb):
 @pytest.mark.gpu
 def test_bucket_sort_of_seed_kmers_gpu(hb, golden_dir):
     """Regions with millions of seed-capable k-mers order them with a bucket sort (count classes, leading mer bits, one
-    wavefront per bucket) instead of the in-LDS bitonic sort.  bk_config.reserved[0] = 32 forces that path on the small
+    wavefront per bucket) instead of the in-LDS bitonic sort.  bk_config.flags = 32 forces that path on the small
     G3 fixtures: same k-mer order ((count, mer) descending) and same contigs as the reference produced; on a noisy
     region with ~10^5 seed k-mers the order is checked directly."""
     d = _load(golden_dir, "assembly.json")

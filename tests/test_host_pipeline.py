@@ -615,7 +615,9 @@ class ScriptedEngine(object):
         from breakmer_amd import hip_backend as hb
         for i, w in enumerate(self.wins):                  # as the library: the (asynchronous) submit fails, the next call on the handle says so
             if w.translate(None, b"ACGTNacgtn"):
-                raise hb.BreakmerHipError("bk_run: bk_submit_regions: region %d: character other than A/C/G/T/N in the reference window" % i)
+                ex = hb.BreakmerHipError("bk_run failed (-1): the submit was refused for region %d" % i)      # (the driver branches on the CODE, not on this text)
+                ex.code, ex.region = hb.BK_E_ARG, i
+                raise ex
     def sync(self): pass
     def close(self): pass
     def contigs(self, r): return []

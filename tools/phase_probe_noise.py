@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from breakmer_amd import hip_backend as hb, synth
 from breakmer_amd import build as _bk_build; hb.load_library(_bk_build.lib_path("stamps"))      # the diagnostic build with phase stamps (python breakmer_amd/build.py stamps)
 noise = float(sys.argv[1]) if len(sys.argv) > 1 else 0.005
-regions = [synth.make_region(900, sv_type="del", depth=500, W=3000, L=150, noise=noise)]
+regions = [synth.make_region(int(os.environ.get("BK_RID", "900")), sv_type="del", depth=500, W=3000, L=150, noise=noise)]
 eng = hb.Engine(kmer_size=31, wg_threads=int(os.environ.get("BK_WG", "0")), flags=int(os.environ.get("BK_FLAGS", "0")))
 eng.submit([hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions])
 eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)

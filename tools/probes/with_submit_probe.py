@@ -8,7 +8,7 @@ from breakmer_amd import hip_backend as hb, synth  # noqa: E402
 
 n_eng = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 48
-sub_th = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # host threads per submit (bk_config.reserved[3]; 0: library default)
+sub_th = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # host threads per submit (bk_config.submit_threads; 0: library default)
 regions = [synth.make_region(i, depth=500, L=150, sv_type="del") for i in range(256)]
 packs = [hb.pack_reads(r.reads, r.read_lens) for r in regions]
 pins = [hb.RegionInput(None, r.window, packed=p) for r, p in zip(regions, packs)]
