@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--other-configs", type=int, default=1, help="also time configs[3]/[4] of BASELINE.json (one GPU only; 0 = skip)")
     ap.add_argument("--cfg3-regions", type=int, default=4096, help="batch size of the configs[3] side measurement (heavy regions: the chip fills at a few thousand)")
     ap.add_argument("--cfg4-regions", type=int, default=768, help="batch size of the configs[4] side measurement: a region's chain of ~19,000 dependent rounds takes ~3 s whatever runs beside it, so regions in flight ARE the throughput (256: 69 regions/s, 512: 101, 768: 121) until the scratch arena (~270 MB per region) fills the HBM (896 no longer fit)")
+    ap.add_argument("--noisy-inflight", type=int, default=8, help="batches in flight of the noisy 256-region side measurement (other_configs.noise_0.5pct_256_regions.in_flight)")
     ap.add_argument("--side-configs-only", type=int, default=0, help="internal: print the side measurements (configs[3], configs[4], noisy batch) as one JSON object and exit")
     ap.add_argument("--split-experimental", type=int, default=0, help="(ignored: the component split of noisy regions is the default since round 5)")
     ap.add_argument("--flags", type=int, default=0, help="library flags (bk_config.flags: BK_CFG_*); 0 in every reported number")
@@ -112,10 +113,57 @@ def cfg4_region(synth, i, depth=2000):
     return synth.make_region(40000 + i, sv_type="del", depth=depth, W=3000, L=250, noise=0.05)
 
 
+def noisy_region(synth, i, depth=500, L=150, noise=0.005):
+    """a configs[1]-shaped region (10,000 x 150 bp, planted 200 bp deletion) with substitution noise per base: what real reads look like"""
+    return synth.make_region(50000 + i, depth=depth, L=L, sv_type="del", noise=noise)
+
+
+SIDE_K = {"cfg3": 31, "cfg4": 41, "noisy": 31}
+
+
 def _gen_region(spec):
     kind, i = spec
     from breakmer_amd import synth
-    return cfg4_region(synth, i) if kind == "cfg4" else cfg3_region(synth, i)
+    return cfg4_region(synth, i) if kind == "cfg4" else noisy_region(synth, i) if kind == "noisy" else cfg3_region(synth, i)
+
+
+def _cpu_side_region(spec):
+    """one region of a side configuration through the C oracle (worker of cpu_side_baselines): contigs, seconds of THIS region"""
+    kind, i = spec
+    from breakmer_amd import synth
+    from oracle import bk_oracle as bo
+    if i < 0:                                               # start-up (imports, library load) outside the clock
+        r = synth.make_region(3, sv_type="del", depth=40, W=1200)
+        bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)
+        return 0, 0.0
+    r = _gen_region((kind, i))
+    targets = [r.window_str] + [synth.codes_to_str(p_[4]) for p_ in r.partners]
+    t0 = time.perf_counter()
+    want, _ = bo.assemble_region(synth.BASES[r.reads], [r.window_str], SIDE_K[kind], 2, find_index=True)
+    for c in want:
+        bo.realign(c["seq"], targets)
+    return len(want), time.perf_counter() - t0
+
+
+def cpu_side_baselines(samples):
+    """CPU figure beside every side configuration (a GPU figure with nothing beside it cannot be read): the C oracle (oracle/bk_oracle.c,
+    kind "port") over a bounded sample of the SAME regions on all host cores -- one spawned pool, a region per task; `value` = regions /
+    wall time of the pool (cores stated), `value_1core` = 1 / mean seconds of one region inside its worker.  Runs BEFORE this process
+    touches the GPU.  samples: {key: (kind, number of regions)}."""
+    import multiprocessing as mp
+    cores = usable_cores()
+    out = {}
+    with mp.get_context("spawn").Pool(cores) as pool:
+        pool.map(_cpu_side_region, [("noisy", -1)] * cores, chunksize=1)
+        for key, (kind, n) in samples.items():
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_side_region, [(kind, i) for i in range(n)], chunksize=1)
+            wall = time.perf_counter() - t0
+            per = [x[1] for x in res]
+            out[key] = {"value": round(n / wall, 4), "unit": "regions/s", "cores": min(cores, n), "kind": "port", "value_1core": round(len(per) / sum(per), 4),
+                        "sample": "oracle/bk_oracle.c (T1+K1/K2+init_assembly with its k-mer -> reads index for find_reads+realign) on regions 0..%d of this configuration, one region per task over %d worker processes (%.1f s wall); value_1core from the seconds each region took inside its worker" % (n - 1, min(cores, n), wall),
+                        "contigs_in_sample": int(sum(x[0] for x in res))}
+    return out
 
 
 def make_regions_parallel(kind, n):
@@ -129,8 +177,50 @@ def make_regions_parallel(kind, n):
         return pool.map(_gen_region, [(kind, i) for i in range(n)], chunksize=4)
 
 
+def time_inflight(hb, regions, k, opts, device, handles, steps, flags, wg):
+    """sustained rate of one configuration with `handles` batches in flight (one handle = one HIP stream each, the way the headline is
+    timed): a single noisy batch is bound by the serial chain of its slowest region (round 6: one region of 256 takes 224 of the
+    batch's 247 ms), batches in flight fill the chip meanwhile -- and then one workgroup per region (BK_CFG_NO_SPLIT) on 256-thread
+    workgroups is the cheaper way through the same work than 16 units per region"""
+    ins = [hb.RegionInput(r.reads, r.window, read_lens=r.read_lens, partners=[p[4] for p in r.partners]) for r in regions]
+    ctx = call_context_text(regions, opts)
+    engs, ref = [], None
+    for _ in range(handles):
+        e = hb.Engine(kmer_size=k, rc_thresh=2, device=device, flags=flags, wg_threads=wg)
+        e.submit(ins)
+        e.set_call_context(ctx)
+        e.run(hb.BK_STAGE_ALL)
+        raw = e.call_blob()
+        ref = raw if ref is None else ref
+        engs.append(e)
+
+    def run_steps(kk):
+        launched, same = 0, True
+        for j in range(min(handles, kk)):
+            engs[j].run(hb.BK_STAGE_ALL, sync=False)
+            launched += 1
+        for s_ in range(kk):
+            e = engs[s_ % handles]
+            e.fetch()
+            if launched < kk:
+                e.run(hb.BK_STAGE_ALL, sync=False)
+                launched += 1
+            same = (e.call_blob() == ref) and same
+        return same
+    run_steps(handles)
+    t0 = time.perf_counter()
+    same = run_steps(steps)
+    dt = time.perf_counter() - t0
+    out = {"value": round(len(regions) * steps / dt, 1), "unit": "regions/s", "ms_per_batch": round(dt / steps * 1e3, 2), "batches_in_flight": handles, "steps": steps,
+           "flags": flags, "asm_workgroup_threads": int(engs[0].stat(25)), "failed_regions": int(sum(e.stat(22) for e in engs)), "sv_calls": int(ref.count(b"\n")),
+           "rows_identical_across_batches": bool(same)}
+    for e in engs:
+        e.close()
+    return out
+
+
 def side_configs(a, hb, synth, opts, local):
-    """BASELINE configs[3] / configs[4] and the noisy 64-region batch on one GPU (whole path incl. call tail, inputs resident)"""
+    """BASELINE configs[3] / configs[4] and the noisy batches on one GPU (whole path incl. call tail, inputs resident)"""
     oc = {}
     try:
         regs3 = [cfg3_region(synth, i) for i in range(a.cfg3_regions)]
@@ -146,6 +236,14 @@ def side_configs(a, hb, synth, opts, local):
         oc["noise_0.5pct_64_regions"] = time_other_config(hb, regsn, a.kmer, opts, 2, local, flags=a.flags)
         oc["noise_0.5pct_64_regions"]["workload"] = "64 regions of the configs[1] shape with 0.5 % substitution noise per base, one launch (seconds per launch = ms_per_batch / 1000)"
         del regsn
+        # realistic reads at the size of the headline batch: 256 regions at 0.5 %.  One batch alone (as shipped: noisy regions split into
+        # units) is the LATENCY of a batch; `in_flight` is the sustained rate with batches on several handles, as the headline is timed
+        regs256 = make_regions_parallel("noisy", 256)
+        oc["noise_0.5pct_256_regions"] = time_other_config(hb, regs256, a.kmer, opts, 2, local, flags=a.flags)
+        oc["noise_0.5pct_256_regions"]["workload"] = "256 regions of the configs[1] shape with 0.5 % substitution noise per base; value = ONE batch at a time (a batch's latency: bound by the serial chain of its slowest region); in_flight = sustained rate with batches in flight"
+        oc["noise_0.5pct_256_regions"]["in_flight"] = time_inflight(hb, regs256, a.kmer, opts, local, handles=a.noisy_inflight, steps=3 * a.noisy_inflight, flags=128 | a.flags, wg=256)
+        oc["noise_0.5pct_256_regions"]["in_flight"]["note"] = "bk_config.flags = BK_CFG_NO_SPLIT, asm_wg_threads = 256: with the chip full of other batches one workgroup per region costs less than 16 units per region (same rows: rows_identical_across_batches compares every batch with a batch that ran alone)"
+        del regs256
     except Exception as ex:                      # never lose what was measured to a later side measurement
         oc["error"] = repr(ex)
     return oc
@@ -268,7 +366,20 @@ def main():
             oc["noise_0.5pct_64_regions_one_unit"]["workload"] = "the same 64 noisy regions with bk_config.flags = BK_CFG_NO_SPLIT (128): no component split, one assembler workgroup per region (the default until round 4)"
             print(json.dumps(oc), flush=True)
             return
-        print(json.dumps(side_configs(a, hb, synth, default_opts(), int(os.environ.get("LOCAL_RANK", "0")))), flush=True)      # (--flags applies: diagnostic A/B runs)
+        cpu = {}
+        if a.cpu_sample > 0:                                     # the CPU figures first: nothing of this process has touched the GPU yet
+            try:
+                nc = usable_cores()
+                cpu = cpu_side_baselines({"configs[3]": ("cfg3", max(16, nc)), "configs[4]": ("cfg4", min(nc, 16)), "noise": ("noisy", max(16, nc))})
+            except Exception as ex:
+                cpu = {"error": repr(ex)}
+        oc = side_configs(a, hb, synth, default_opts(), int(os.environ.get("LOCAL_RANK", "0")))      # (--flags applies: diagnostic A/B runs)
+        for key, ent in oc.items():
+            if isinstance(ent, dict) and "value" in ent:
+                src = cpu.get("noise" if key.startswith("noise") else key) if "error" not in cpu else {"error": cpu["error"]}
+                if src:
+                    ent["cpu_baseline"] = src
+        print(json.dumps(oc), flush=True)
         return
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(a))
@@ -530,7 +641,7 @@ def main():
         step_s = dt / a.steps
         achieved = alg_bytes / asm_excl_s / 1e9
         prof = {}
-        for name in ("traffic.json", "valu.json"):
+        for name in ("traffic.json", "valu.json", "kernel_ms.json"):
             fn = os.path.join(ROOT, "profiles", name)
             if os.path.isfile(fn):
                 try:
@@ -546,6 +657,12 @@ def main():
         k_ms = asm_ms / a.steps
         achieved = alg_bytes / (k_ms / 1e3) / 1e9
         traffic = prof.get(kname + "_bytes_per_launch")
+        # the same kernel's average launch duration in the committed rocprofv3 --kernel-trace --stats run of this command (profiles/kernel_ms.json,
+        # written by tools/summarize_profile.py from the round's profile run): the live figure and this one differ by what the batches in flight
+        # do to each other in a given run and by what the HIP events bracket (they include the scheduling kernel and the gaps between launches)
+        k_ms_prof = prof.get(kname + "_avg_ms")
+        kmer_excl_s = s_k / ks / 1e3
+        kmer_traffic = prof.get("bk_kmer_kernel_bytes_per_launch")
         # integer-VALU roofline of the assembler.  Algorithmic lane-ops per DP cell of olc.nw (olc.py:62-74): three candidate
         # sums, the match/mismatch compare + select, one three-way max = 6; `peak` = the chip's VALU issue rate / 6.  What the
         # kernel really issues per algorithmic cell (SQ_INSTS_VALU x 64 / cells: the 7-op cell of this encoding, pipeline
@@ -579,6 +696,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": prof.get("traffic_source"),
                          "kernel": kname, "kernel_ms": round(k_ms, 3),
+                         "kernel_ms_profiled": k_ms_prof, "frac_profiled": (round(alg_bytes / (k_ms_prof / 1e3) / 1e9 / HBM_PEAK_GBS, 6) if k_ms_prof else None),
+                         "kernel_ms_profiled_source": prof.get("kernel_ms_source"),
+                         "chip_ms_per_step": round(step_s * 1e3, 3),
+                         "chip_ms_per_step_note": "wall time of the timed region / steps = the time the chip spends per step with %d batches in flight (profiles/<round>/overlap_summary.csv: span of a 100-step window of the kernel trace / 100, the device never idle inside it); algorithmic bytes / chip_ms_per_step is `hbm_path`" % len(engs),
                          "kernel_ms_note": "average duration of ONE launch of this kernel over the timed steps (HIP events on its stream), not chip time per step: %d batches are in flight and their launches overlap (the durations of the three kernels sum to more than ms_per_step x steps in flight)" % len(engs),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "exclusive": {"kernel": "bk_asm_kernel", "kernel_ms": round(s_a / ks, 3), "achieved": round(alg_bytes / asm_excl_s / 1e9, 3),
@@ -586,6 +707,13 @@ def main():
                                        "note": "the one-step-at-a-time pass below (one handle, 512-thread build): nothing co-runs"},
                          "note": "the path is integer-VALU/latency bound, not HBM bound (SURVEY 8d): see roofline_valu"},
             "roofline_valu": valu,
+            # the k-mer kernel is the one stage SURVEY 8d calls HBM-bound (one streaming pass over the packed reads): its own line
+            "roofline_kmer": {"bound": "hbm", "kernel": "bk_kmer_kernel", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                              "kernel_ms": round(s_k / ks, 4), "kernel_ms_note": "exclusive: the one-step-at-a-time pass (one handle, 1,024-thread workgroups, nothing co-runs)",
+                              "kernel_ms_inflight": round(kmer_ms / a.steps, 4),
+                              "algorithmic_bytes_per_launch": alg_bytes, "achieved": round(alg_bytes / kmer_excl_s / 1e9, 2), "frac": round(alg_bytes / kmer_excl_s / 1e9 / HBM_PEAK_GBS, 5),
+                              "traffic": kmer_traffic, "traffic_over_algorithmic": (round(kmer_traffic / alg_bytes, 3) if kmer_traffic else None),
+                              "traffic_rate": (round(kmer_traffic / kmer_excl_s / 1e9, 1) if kmer_traffic else None), "traffic_source": prof.get("traffic_source")},
             "hbm_path": {"achieved": round(alg_bytes / step_s / 1e9, 3), "unit": "GB/s", "frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 6),
                          "note": "algorithmic bytes of one step / ms_per_step (all kernels, batches in flight)"},
             "kernels_ms": serial["kernels_ms"],
@@ -608,20 +736,22 @@ def main():
             # load) must not take the headline line with it.  The child prints one JSON object; anything else becomes an "error" entry.
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--side-configs-only", "1", "--kmer", str(a.kmer), "--depth", str(a.depth), "--read-len", str(a.read_len),
-                   "--cfg3-regions", str(a.cfg3_regions), "--cfg4-regions", str(a.cfg4_regions), "--split-experimental", str(a.split_experimental)]
+                   "--cfg3-regions", str(a.cfg3_regions), "--cfg4-regions", str(a.cfg4_regions), "--noisy-inflight", str(a.noisy_inflight), "--cpu-sample", str(a.cpu_sample)]
             try:
-                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=2400)
                 lines = [ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")]
                 oc = json.loads(lines[-1]) if (pr.returncode == 0 and lines) else {"error": "side measurements ended with code %d" % pr.returncode, "stderr_tail": pr.stderr[-400:]}
             except Exception as ex:
                 oc = {"error": repr(ex)}
             try:                                             # ... and the one-unit comparison run of the noisy batch
-                cmd2 = [sys.executable, os.path.abspath(__file__), "--side-configs-only", "2", "--kmer", str(a.kmer), "--depth", str(a.depth), "--read-len", str(a.read_len)]
+                cmd2 = [sys.executable, os.path.abspath(__file__), "--side-configs-only", "2", "--kmer", str(a.kmer), "--depth", str(a.depth), "--read-len", str(a.read_len), "--cpu-sample", "0"]
                 pr2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=300)
                 lines2 = [ln for ln in pr2.stdout.strip().splitlines() if ln.startswith("{")]
                 oc.update(json.loads(lines2[-1]) if (pr2.returncode == 0 and lines2) else {"noise_0.5pct_64_regions_one_unit": {"error": "ended with code %d" % pr2.returncode}})
             except Exception as ex:
                 oc["noise_0.5pct_64_regions_one_unit"] = {"error": repr(ex)}
+            if isinstance(oc.get("noise_0.5pct_64_regions"), dict) and "cpu_baseline" in oc["noise_0.5pct_64_regions"] and isinstance(oc.get("noise_0.5pct_64_regions_one_unit"), dict):
+                oc["noise_0.5pct_64_regions_one_unit"].setdefault("cpu_baseline", oc["noise_0.5pct_64_regions"]["cpu_baseline"])      # (the same regions)
             out["other_configs"] = oc
         # ---- CPU baseline: the oracle (C port of the reference algorithm) on the host cores, bounded sample -------
         if world == 1 and a.cpu_sample > 0:

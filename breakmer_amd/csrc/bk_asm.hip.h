@@ -16,6 +16,15 @@
 // look-ahead slots, 2 workgroups per CU: shortest time for one batch) and BK_AT = 256 (4 wavefronts, 4 slots, 4 workgroups per
 // CU: highest throughput when batches are in flight); BK_ASM_KERNEL names the kernel.  bk_common.h / bk_nw.hip.h are
 // included by bk_api.hip before, outside the namespaces.
+// The state machine is spread over this header and six it includes (round 6; one file of 2,200 lines until then), in dependency order:
+//   bk_asm.hip.h         shared state (BkAsmShared, BkAsmCtx), LDS layout, table look-ups, count vectors; bk_asm_region (init_assembly's main
+//                        loop, the settling of split regions), the persistent-workgroup kernel, the stand-alone nw batch kernel
+//   bk_asm_kmers.hip.h   meetings of components (split regions), contig k-mer lists, find_reads
+//   bk_asm_apply.hip.h   contig life cycle, check_align's verdict (bk_decide) and its application for one read (bk_retire)
+//   bk_asm_plan.hip.h    the DP dispatch of a round, look-ahead lists of the following visits / seeds, the prediction step
+//   bk_asm_round.hip.h   run retire, the plan of a round, the candidate loop with its speculative look-ahead (bk_run_candidates)
+//   bk_asm_grow.hip.h    check_alt_reads, finalize, grow, the contig record (emit), setup_contigs
+//   bk_asm_units.hip.h   units of a split region: seed lists, unit 0's labelling of the graph
 
 #ifndef BK_AT
 #error "define BK_AT (threads per assembler workgroup: 512 or 256) and BK_ASM_KERNEL before including bk_asm.hip.h"
@@ -344,1500 +353,14 @@ __device__ inline int bk_total_reads()                                          
     return a + b;
 }
 
-// ---- split regions: the contig of the running seed iteration holds a k-mer of component `root`, which is neither the seed's
-//      nor one it has taken in.  Thread 0 decides (bk_comp.hip.h):
-//   no unit (no seeds)              -> claimed, taken in;
-//   this unit's                     -> taken in (the unit walks its seeds in rank order: the other component stands where the
-//                                      serial run would have it); noted: the two are one component from now on;
-//   anything else                   -> the seed's component is given up, the pair noted for the repair pass.
-__device__ inline void bk_note_pair(uint32_t a, uint32_t b, uint32_t kind)
-{
-    const uint32_t at = atomicAdd(&C_.wk->n_pairs, 1u);
-    if (at < C_.wk->pairs_cap) { C_.pairs[3 * at] = a; C_.pairs[3 * at + 1] = b; C_.pairs[3 * at + 2] = kind; }
-    if (kind) atomicAdd(&C_.wk->n_conf, 1u);
-}
-__device__ inline void bk_meet(uint32_t root)
-{
-    BkAsmShared *S = S_;
-    if (!BK_CHK(root < C_.U, 1, root)) { S->status = BK_ST_CONFLICT; S->foreign = 0; S->foreign_root = BK_EMPTY32; return; }
-    uint32_t ci = __hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((ci & BK_CI_UNIT) == BK_CI_NOUNIT) { const uint32_t old = atomicCAS(&C_.cinfo[root], ci, C_.want); ci = old == ci ? C_.want : old; }
-    if ((ci & (0xFFFFu | BK_CI_ABORT)) == C_.want && S->acc_n < BK_ACC_MAX) {
-        bk_note_pair(S->ccomp, root, 0u);
-        C_.acc_root[S->acc_n] = root; __threadfence_block(); S->acc_n++;
-    } else {
-        bk_note_pair(S->ccomp, root, 1u);
-        if (S->acc_n < BK_ACC_MAX) { C_.acc_root[S->acc_n] = root | 0x80000000u; __threadfence_block(); S->acc_n++; S->dirty = 1; }      // met, not taken in: the iteration goes on without its k-mers
-        else S->status = BK_ST_CONFLICT;                                    // (no room to remember it: the iteration is left here, as in the first version)
-    }
-    S->foreign = 0; S->foreign_root = BK_EMPTY32;
-}
-
-BK_COLD void bk_build_myseeds(int fresh);
-// order MID replaces contig.kmers (set_kmers :548-550), FOR/REV extend it (:525-527, :543-545).
-// P1: m = L // 2 ; Q1: positions range(0, L-k).
-BK_COLD void bk_kmers_ordered(int s0, int L, int order)
-{
-    BK_ACC(S_->ctx);
-    BkAsmShared *S = S_;
-    const int k = C_.k, np = L - k;                      // number of positions
-    int *tmp = (int *)L_CAND;                           // rank per position (or -1)
-    const int m = L / 2;
-    if (np > 2 * C_.MAXCAND) { bk_fail(BK_ST_KLIST); return; }
-    if (np <= 0 && order != BK_ORD_MID) return;         // a one-base extension has no new k-mer (Q1: range(0, L-k) of a window of k bases): nothing to append, six barriers saved
-    if (S->status) return;                              // (uniform) a conflict is being unwound
-    // Split regions: a k-mer of a component this unit does not hold counts as a meeting WHATEVER its state says -- the other unit
-    // may be ahead of this one in seed order, and what it has removed by now may still have been there at this seed's turn in
-    // the serial order.  (Homopolymer k-mers are in no component: kroot = BK_EMPTY32.)  Bit 30 of tmp[x]: removed.
-    for (int x = BK_TID; x < np; x += BK_AT) {
-        BkKey key; uint32_t st = 0; int rk = bk_bytes_kmer(L_CSEQ + s0 + x, k, key) ? bk_lookup_state(key, st) : -1;
-        if (C_.own && rk >= 0) { const uint32_t root = C_.kroot[rk]; if (root != BK_EMPTY32 && root != S->ccomp && !bk_acc_has(root)) { S->foreign = 1; atomicMin(&S->foreign_root, root); } }
-        if (rk >= 0 && st == BK_K_REMOVED) rk = C_.own ? (rk | 0x40000000) : -1;                     // not in akmers.smers_set
-        tmp[x] = rk;
-    }
-    BK_SYNC();
-    if (C_.own) {
-        // The contig holds k-mers of components other than the seed's (a k-mer across the seam of two read pieces).  One new
-        // component per turn, smallest root first: same unit -> taken in; no unit (it has no seeds) -> claimed, taken in;
-        // another unit's -> the current component is given up (bk_comp.hip.h).  Rare: thread 0 decides, everyone re-checks.
-        // S->foreign steers the loop and bk_meet (thread 0) resets it: every wavefront reads it, THEN a barrier, then the reset
-        // (round 5: without that barrier a late wavefront read the reset word, skipped the loop and its barriers -- the wild
-        // indices and hangs of the split path under load).
-        bool more = S->foreign != 0;
-        while (more) {
-            BK_SYNC();
-            if (BK_TID == 0) bk_meet(S->foreign_root);
-            BK_SYNC();
-            if (S->status) return;
-            for (int x = BK_TID; x < np; x += BK_AT) { const int rk = tmp[x]; if (rk >= 0) { const uint32_t root = C_.kroot[rk & 0x3FFFFFFF]; if (root != BK_EMPTY32 && root != S->ccomp && !bk_acc_has(root)) { S->foreign = 1; atomicMin(&S->foreign_root, root); } } }
-            BK_SYNC();
-            more = S->foreign != 0;
-        }
-    }
-    if (C_.own) {
-        const bool dirty = S->dirty != 0;                    // (uniform) the iteration has met a component of another unit
-        for (int x = BK_TID; x < np; x += BK_AT) {
-            const int rk = tmp[x];
-            if (rk < 0) continue;
-            if (rk & 0x40000000) { tmp[x] = -1; continue; }
-            if (dirty) { const uint32_t root = C_.kroot[rk]; if (root != BK_EMPTY32 && !bk_acc_mine(root)) tmp[x] = -1; }
-        }
-        BK_SYNC();
-    }
-    const int chunk = (max(np, 0) + BK_AT - 1) / BK_AT, b = BK_TID * chunk, e = min(np, b + chunk);
-    uint32_t cnt = 0, T;
-    for (int x = b; x < e; x++) cnt += tmp[x] >= 0;
-    uint32_t pre = bk_scan256(cnt, S->scan, &T);
-    // pre_m = number of valid positions < m
-    if (order == BK_ORD_MID) {
-        if (BK_TID == 0) S->tmp0 = (int)T;              // default when m >= np
-        BK_SYNC();
-        if (m >= b && m < e) { uint32_t q = pre; for (int x = b; x < m; x++) q += tmp[x] >= 0; S->tmp0 = (int)q; }
-        BK_SYNC();
-    }
-    const int pre_m = S->tmp0;
-    const int base = (order == BK_ORD_MID) ? 0 : S->nk;
-    if (base + (int)T > (2 * C_.MAXC)) { bk_fail(BK_ST_KLIST); return; }
-    uint32_t q = pre;
-    for (int x = b; x < e; x++) {
-        int rk = tmp[x];
-        if (rk < 0) continue;
-        int idx; uint32_t rev;
-        if (order == BK_ORD_FOR) { idx = (int)q; rev = 1u; }                            // get_mer_reads :610-611: 'for' -> 'rev'
-        else if (order == BK_ORD_REV) { idx = (int)T - 1 - (int)q; rev = 0u; }
-        else { if (x >= m) { idx = (int)q - pre_m; rev = 1u; } else { idx = (int)T - 1 - (int)q; rev = 0u; } }   // :142 sorted by (x<m, |x-m|); :607-609
-        C_.klist[base + idx] = (uint32_t)rk | (rev << 31);
-        q++;
-    }
-    BK_SYNC();
-    if (BK_TID == 0) { S->nk = base + (int)T; if (order == BK_ORD_MID) { S->setup = 1; S->kscan = 0; } }
-    BK_SYNC();
-    BK_ACC(5);
-}
-
-// ---- find_reads (sv_assembly.py:111-122) from the posting list of k-mer `rank` -------------------------
-// key (pos, -len) / (-pos, -len); stable sort ties keep fq_recs order = unique index u.
-BK_COLD void bk_find_reads(int rank, bool rev, bool filter)
-{
-    BK_ACC(S_->ctx);
-    BkAsmShared *S = S_;
-    const uint32_t b = C_.poff[rank], e = C_.poff[rank + 1];
-    if (e - b <= 64u) {
-        // Short posting list (the rule for sequencing-error k-mers): one wavefront does everything in registers --
-        // first occurrence per read, filters, order -- with two global round trips and a single workgroup barrier.
-        if ((BK_TID >> 6) == 0) {
-            const int lane = BK_TID, np = (int)(e - b);
-            const bool have = lane < np;
-            const uint32_t en = have ? C_.post[b + lane] : 0u;
-            const uint32_t u = en >> 10; const int pos = (int)(en & 1023u);
-            uint32_t fl = 0; int bufst = 0; uint32_t len = 0;
-            if (have) { fl = C_.ufl[u]; bufst = C_.ubuf[u]; len = C_.ulen[u]; }
-            bool drop = false;                                                     // a smaller position of the same read exists
-            for (int j = 0; j < np; j++) {
-                const uint32_t oen = (uint32_t)__builtin_amdgcn_readlane((int)en, j);
-                drop = drop || ((oen >> 10) == u && (int)(oen & 1023u) < pos);
-            }
-            const bool valid = have && !drop && !(fl & BK_R_DELETED) && !(filter && bufst == S->serial);
-            const unsigned long long pk = rev ? (unsigned long long)(0xFFFF - pos) : (unsigned long long)pos;
-            const unsigned long long key = valid ? ((pk << 40) | ((0xFFFFull - len) << 24) | u) : ~0ull;
-            int idx = 0;                                                           // rank among the valid keys (unique: u is)
-            for (int j = 0; j < np; j++) {
-                const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)key, j);
-                idx += kj < key;
-            }
-            const unsigned long long vm = __ballot(valid);
-            if (valid) L_CANDU[idx] = u | ((uint32_t)pos << 22);
-            if (lane == 0) S->ncand = __popcll(vm);
-        }
-        BK_SYNC();
-        // every thread reads ncand BEFORE thread 0 may reset it (the extra barrier is only taken on the failing path; the
-        // condition is uniform, so the workgroup's barriers stay aligned -- a late wavefront must not see the reset value)
-        const int nc_ = S->ncand;
-        if (nc_ > C_.MAXCAND) { bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); }      // (bk_fail starts with a barrier: every thread has read ncand)
-        BK_ACC(4);
-        return;
-    }
-    if (BK_TID == 0) S->ncand = 0;
-    BK_SYNC();
-    // first occurrence of the k-mer in each read (re.search): min pos per read
-    for (uint32_t i = b + BK_TID; i < e; i += BK_AT) { uint32_t en = C_.post[i]; atomicMin(&C_.uminpos[en >> 10], (int)(en & 1023u)); }
-    BK_SYNC();
-    for (uint32_t i = b + BK_TID; i < e; i += BK_AT) {
-        uint32_t en = C_.post[i], u = en >> 10; int pos = (int)(en & 1023u);
-        if (C_.uminpos[u] != pos) continue;
-        if (C_.ufl[u] & BK_R_DELETED) continue;                                  // deleted from fq_recs (rb.clean :390)
-        if (filter && C_.ubuf[u] == S->serial) continue;                         // ids - self.buffer (:115-116)
-        int idx = atomicAdd(&S->ncand, 1);
-        if (idx < C_.MAXCAND) {
-            unsigned long long len = C_.ulen[u];
-            unsigned long long pk = rev ? (unsigned long long)(0xFFFF - pos) : (unsigned long long)pos;
-            L_CAND[idx] = (pk << 40) | ((0xFFFFull - len) << 24) | u;
-        }
-    }
-    BK_SYNC();
-    for (uint32_t i = b + BK_TID; i < e; i += BK_AT) C_.uminpos[C_.post[i] >> 10] = 0x7FFFFFFF;
-    const int n = S->ncand;
-    if (n > C_.MAXCAND) { bk_fail(BK_ST_CAND); if (BK_TID == 0) S->ncand = 0; BK_SYNC(); return; }      // (bk_fail starts with a barrier: every thread has read ncand)
-    int npad = 1; while (npad < n) npad <<= 1;
-    for (int i = n + BK_TID; i < npad; i += BK_AT) L_CAND[i] = ~0ull;
-    BK_SYNC();
-    for (int sz = 2; sz <= npad; sz <<= 1)
-        for (int st = sz >> 1; st > 0; st >>= 1) {
-            for (int i = BK_TID; i < npad / 2; i += BK_AT) {
-                int lo = (i / st) * (st * 2) + (i % st), hi = lo + st;
-                bool up = ((lo & sz) == 0);
-                unsigned long long a = L_CAND[lo], bb = L_CAND[hi];
-                if ((a > bb) == up) { L_CAND[lo] = bb; L_CAND[hi] = a; }
-            }
-            BK_SYNC();
-        }
-    for (int i = BK_TID; i < n; i += BK_AT) {             // u | (k-mer position in the read << 22)
-        const unsigned long long key = L_CAND[i]; const uint32_t pk = (uint32_t)(key >> 40) & 0xFFFFu;
-        L_CANDU[i] = (uint32_t)(key & 0x3FFFFFull) | ((rev ? 0xFFFFu - pk : pk) << 22);
-    }
-    BK_SYNC();
-    BK_ACC(4);
-}
-
-// first occurrence of k-mer `key` in seq[0..n) (str.find), executed by one wavefront: every lane rolls the k-mer at its
-// own position out of the LDS bytes and compares keys
-__device__ inline int bk_find_kmer_wave(const uint8_t *seq, int n, const BkKey &key, int k)
-{
-    const int lane = BK_TID & 63;
-    for (int b = 0; b + k <= n; b += 64) {
-        const int x = b + lane; bool ok = x + k <= n;
-        if (ok) { BkKey c; ok = bk_bytes_kmer(seq + x, k, c) && c.lo == key.lo && c.hi == key.hi; }
-        const unsigned long long m = __ballot(ok);
-        if (m) return b + __ffsll((long long)m) - 1;
-    }
-    return -1;
-}
-
-// ---- contig life cycle ------------------------------------------------------------------------------
-__device__ inline void bk_contig_new(int rank, int u, bool in_fifo)                  // contig.__init__ :417-426
-{
-    BK_ACC(S_->ctx);
-    BkAsmShared *S = S_;
-    bk_load_read(u);
-    const int len = S->rlen, nreads = S->rn, indel = S->rindel;
-    if (len > C_.MAXC) { bk_fail(BK_ST_CONTIG); return; }
-    const int base = C_.MAXC - len;
-    for (int t = BK_TID; t < len; t += BK_AT) L_CSEQ[base + t] = L_RSEQ[t];
-    int32_t *io = bk_cnt_io(0) + base, *ot = bk_cnt_ot(0) + base;
-    for (int t = BK_TID; t < len; t += BK_AT) { io[t] = indel ? nreads : 0; ot[t] = indel ? 0 : nreads; }      // :162-165
-    BK_SYNC();
-    if (BK_TID == 0) {
-        S->cbase = base; S->clen = len; S->nbase = base; S->nlen = len; S->cbuf = 0;
-        S->serial = ++S->serial_ctr; S->setup = 0; S->founder = u; S->founder_added = 0; S->in_fifo = in_fifo ? 1 : 0;
-        S->nk = 0; S->nr = 0; S->nalt = 0; S->kscan = 0;
-        C_.kstamp[3 * rank] = S->serial;                 // checked_kmers = [kmer_val]
-        C_.ubuf[u] = S->serial;                          // buffer = set([read.id])
-    }
-    BK_SYNC();
-    BK_ACC(9);
-}
-__device__ inline void bk_fifo_push(int rank, int u)                                 // buffer.add_contig :337-340 (thread 0)
-{
-    BkAsmShared *S = S_;
-    if (C_.ufound[u] >= 0 || (C_.ufl[u] & BK_R_USED)) return;
-    C_.pend[2 * S->ptail] = (uint32_t)rank; C_.pend[2 * S->ptail + 1] = (uint32_t)u;
-    C_.ufound[u] = S->ptail; S->ptail++; C_.ufl[u] |= BK_R_USED;
-}
-__device__ inline void bk_add_used_mer(int rank)                                     // thread 0
-{
-    if (C_.kstate[rank] == BK_K_LIVE) { C_.kstate[rank] = BK_K_USED; C_.usedl[S_->nused++] = (uint32_t)rank; }
-}
-
-// check_align's verdict on one read from its two overlap DPs (sv_assembly.py:459-503); tie: the k-mer position rule decides
-__device__ inline int bk_decide(const BkNwResult &v1, const BkNwResult &v2, int clen, int rl, int &ds, int &de, bool &tie)
-{
-    int dec = BK_DEC_NONE; ds = 0; de = 0; tie = false;
-    const int minlen = min(clen, rl);
-    const bool ok1 = (4 * v1.score >= minlen) && (200 * v1.score >= 179 * (clen - v1.j_start));
-    const bool ok2 = (4 * v2.score >= minlen) && (200 * v2.score >= 179 * (rl - v2.j_start));
-    if (!ok1 && !ok2) dec = BK_DEC_NONE;
-    else if (v1.score == v2.score && v1.j_start == 0 && v1.i_start == 0 && clen == rl) dec = BK_DEC_SAME;
-    else if (v1.score == v2.score) {
-        if (clen < rl || v1.j_start == 0) { dec = BK_DEC_SUPER; ds = v1.i_start; de = v1.i_end; }
-        else if (rl < clen || v2.j_start == 0) { dec = BK_DEC_SUB; ds = v2.i_start; de = v2.i_end; }
-        else tie = true;
-    } else if (v1.score > v2.score) {
-        if (v1.j_start == 0) { dec = BK_DEC_SUPER; ds = v1.i_start; de = v1.i_end; } else dec = BK_DEC_POST;
-    } else {
-        if (v2.j_start == 0) { dec = BK_DEC_SUB; ds = v2.i_start; de = v2.i_end; } else dec = BK_DEC_PRE;
-    }
-    return dec;
-}
-
-// ---- check_align (sv_assembly.py:449-504) + check_read (:552-566) -------------------------------------
-// Decision and state update for the read in look-ahead slot `sl`, whose two overlap DPs (v1 = nw(contig, read),
-// v2 = nw(read, contig)) were computed against the CURRENT contig.  `rank` = the k-mer that recruited the read.
-// Returns (uniform) whether the read matched.
-__device__ inline bool bk_retire(int rank, int sl, bool grow)
-{
-    BkAsmShared *S = S_;
-    const int k = C_.k;
-    const int u = S->slot[sl].u, rl = S->slot[sl].rl, nreads = S->slot[sl].rn, indel = S->slot[sl].rindel;
-    const uint8_t *rseq = L_RSEQ_S(sl);
-    const int clen = S->clen;
-    const uint8_t *cs = L_CSEQ + S->cbase;
-    const int wv = BK_TID >> 6;
-    const BkNwResult v1 = S->slot[sl].v1, v2 = S->slot[sl].v2;
-    // thread 0 asks now for the per-read words its bookkeeping at the end needs: nobody else writes them meanwhile, and the
-    // round trip hides behind the count updates instead of standing between two barriers
-    uint32_t pre_fl = 0, pre_kc = 0; int pre_ureads = 0, pre_found = -1;
-    if (BK_TID == 0) { pre_fl = C_.ufl[u]; pre_ureads = C_.ureads[u]; pre_kc = C_.kcnt[rank]; if (grow) pre_found = C_.ufound[u]; }
-    int ds = 0, de = 0;                             // uniform: computed identically by every thread
-    bool tie = false;
-    bool synced = false;                            // (uniform) a barrier has been passed since this function was entered
-    int dec = bk_decide(v1, v2, clen, rl, ds, de, tie);
-    if (tie) {
-        synced = true;
-        // k-mer position tie-break: x.replace('-','') of the aligned strings are the plain slices
-        if (wv == 0) {
-            BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank];
-            int i11 = bk_find_kmer_wave(cs + v1.j_start, clen - v1.j_start, key, k);
-            int i12 = bk_find_kmer_wave(rseq + v1.i_start, v1.i_end - v1.i_start, key, k);
-            int i21 = bk_find_kmer_wave(rseq + v2.j_start, rl - v2.j_start, key, k);
-            int i22 = bk_find_kmer_wave(cs + v2.i_start, v2.i_end - v2.i_start, key, k);
-            int d = BK_DEC_NONE;
-            if (i11 > -1 && i12 > -1) { if ((i21 == -1 && i22 == -1) || (abs(i21 - i22) > abs(i11 - i12))) d = BK_DEC_POST; }
-            else if (i21 > -1 && i22 > -1) { if ((i11 == -1 && i12 == -1) || (abs(i21 - i22) < abs(i11 - i12))) d = BK_DEC_PRE; }
-            if (BK_TID == 0) S->dec = d;
-        }
-        BK_SYNC();
-        dec = S->dec;
-        // contig_overlap_read / read_overlap_contig re-test the containment case (:508, :531)
-        if (dec == BK_DEC_POST && v1.j_start == 0) { dec = BK_DEC_SUPER; ds = v1.i_start; de = v1.i_end; }
-        if (dec == BK_DEC_PRE && v2.j_start == 0) { dec = BK_DEC_SUB; ds = v2.i_start; de = v2.i_end; }
-        BK_SYNC();
-    }
-    // ---- apply: one fused phase (disjoint index ranges, scalar state committed by thread 0, one barrier) -------
-    const bool match = dec != BK_DEC_NONE;
-    bool ext = false;                                   // contig was extended (POST / PRE): new k-mers in grow mode
-    if (dec == BK_DEC_SUPER) {                                                    // aseq.set_superseq :232-236 (rare: separate phases)
-        synced = true;
-        bk_counts_superseq(rl, nreads, indel, ds, de);
-        const int base = C_.MAXC - rl;
-        for (int t = BK_TID; t < rl; t += BK_AT) L_CSEQ[base + t] = rseq[t];
-        BK_SYNC();
-        if (BK_TID == 0) { S->cbase = base; S->clen = rl; S->pc = S->slot[sl].pos; }
-        BK_SYNC();
-        if (grow) bk_kmers_ordered(S->cbase, S->clen, BK_ORD_MID);              // set_kmers(skmers) :479/:515
-    } else if (dec != BK_DEC_NONE && dec != BK_DEC_SAME) {
-        const int cbase = S->cbase, nbase = S->nbase, nlen = S->nlen;
-        int32_t *io = bk_cnt_io(S->cbuf), *ot = bk_cnt_ot(S->cbuf);
-        int32_t *cv = (indel ? io : ot) + nbase;
-        int s0 = ds, s1 = de, pl = 0, at = 0; bool fail = false;
-        if (dec == BK_DEC_POST) {                                                 // :520-527, add_postseq :243-250
-            pl = max(rl - v1.i_end, 0); s0 = v1.j_start; s1 = clen; at = nbase + nlen;
-            fail = cbase + clen + pl > 2 * C_.MAXC || clen + pl > C_.MAXC || at + pl > 2 * C_.MAXC;
-            if (!fail) for (int t = BK_TID; t < pl; t += BK_AT) L_CSEQ[cbase + clen + t] = rseq[v1.i_end + t];
-        } else if (dec == BK_DEC_PRE) {                                           // :538-545, add_preseq :255-262
-            pl = v2.j_start; s0 = v2.i_start; s1 = v2.i_end; at = nbase - pl;
-            fail = cbase - pl < 0 || clen + pl > C_.MAXC || at < 0;
-            if (!fail) for (int t = BK_TID; t < pl; t += BK_AT) L_CSEQ[cbase - pl + t] = rseq[t];
-        }
-        if (fail) { bk_fail(BK_ST_CONTIG); synced = true; }
-        else {
-            for (int t = s0 + BK_TID; t < min(s1, nlen); t += BK_AT) cv[t] += nreads;          // set_counts :195-199 (old coordinates)
-            for (int t = BK_TID; t < pl; t += BK_AT) { io[at + t] = indel ? nreads : 0; ot[at + t] = indel ? 0 : nreads; }   // extend_counts :201-221
-            // Every wavefront has read the scalars above (cbase, nbase, clen, nlen) before thread 0 replaces them: without
-            // this barrier a wavefront that is late into this function (starved by co-resident workgroups) reads the
-            // NEW base and updates a range shifted by the prepended length.
-            BK_SYNC();
-            synced = true;
-            if (BK_TID == 0 && dec != BK_DEC_SUB) {
-                if (dec == BK_DEC_PRE) { S->cbase = cbase - pl; S->nbase = nbase - pl; S->pc += pl; }
-                S->clen = clen + pl; S->nlen = nlen + pl;
-            }
-            ext = dec != BK_DEC_SUB;
-        }
-    }
-    // check_read bookkeeping (:552-565).  It replaces words the CALLER's control flow reads right before this call, on every wavefront
-    // for itself (S->last_dec in bk_retire_checked, the acceptance counters in bk_expect_reject: which retire path is taken, whether the
-    // prediction held): a wavefront that is late into this call must have read them before thread 0 writes -- a read that changes
-    // nothing (dec NONE / SAME) passes no barrier on its way here, and a late wavefront then took another path than the others,
-    // with other barriers (found with a sleeping wavefront behind every barrier, -DBK_JITTER: wrong fixtures at any load; in the
-    // field: faults and hangs once several noisy workgroups share a CU).
-    if (!synced) BK_SYNC();
-    if (BK_TID == 0) {
-        S->last_dec = dec; S->hit = match ? 1 : 0;
-        if (match) S->n_acc++; else S->n_rej++;
-        if (S->n_acc + S->n_rej >= 64) { S->n_acc >>= 1; S->n_rej >>= 1; }
-        C_.ubuf[u] = S->serial;                                                    // self.buffer.add(read.id)
-        S->cells += 2ull * (unsigned long long)clen * (unsigned long long)rl; S->calls += 2;
-        if (match) {
-            C_.ufl[u] = (uint8_t)(pre_fl | BK_R_USED);
-            if (pre_ureads != S->serial) { C_.ureads[u] = S->serial; C_.readl[S->nr++] = (uint32_t)u; }
-            if (grow && pre_found >= 0 && BK_CHK((uint32_t)pre_found <= C_.U, 10, pre_found)) { C_.pend[2 * pre_found] = BK_EMPTY32; C_.ufound[u] = -1; }       // buff.remove_contig :638-639
-        } else if (pre_kc > 2 && !(pre_fl & BK_R_USED)) {
-            if (S->nalt < C_.MAXCAND) C_.altl[S->nalt++] = (uint32_t)u; else S->status = BK_ST_CAND;
-        } else C_.ufl[u] = (uint8_t)(pre_fl | BK_R_DELETED);                       // rb.delete -> rb.clean :390
-    }
-    BK_SYNC();
-    BK_ACC(3);
-    if (ext && grow && !S->status) {
-        const int k1 = k - 1;
-        if (dec == BK_DEC_POST) { const int from = max(clen - k1, 0); bk_kmers_ordered(S->cbase + from, (clen - from) + (S->clen - clen), BK_ORD_FOR); }
-        else bk_kmers_ordered(S->cbase, (S->clen - clen) + min(k1, clen), BK_ORD_REV);
-    }
-    return match;
-}
-
-// ---- the read loop of setup_contigs (:16-23) / grow (:634-639) with speculative look-ahead --------------------
-// The reference checks the candidate reads strictly one after the other: each accepted read changes the contig
-// the next one is aligned to.  The alignment of read q+1 only depends on the contig SEQUENCE after read q, and
-// that is predictable from where the recruiting k-mer sits in the read and in the contig (the read sticks out
-// `pos - pc` bases to the left, or its tail beyond the contig end).  So each round aligns up to BK_SPEC reads
-// at once -- slot s against the contig predicted after slots 0..s-1, two wavefronts per slot -- and then retires
-// them in order, for as long as the contig really became what was predicted (same kind of change, same
-// geometry => same bytes); the first misprediction discards the later slots, which are redone next round.
-// Results are therefore bit-identical to the serial loop; only the DP latency chain gets shorter.
-enum { BK_PK_SAME = 0, BK_PK_PRE = 1, BK_PK_POST = 2, BK_PK_STOP = 3 };
-// The overlap DPs of one look-ahead round.  Everything it needs is in LDS (slots, contig deque, staged reads); it is kept
-// OUT of line so that the dozens of DP variants it dispatches to (one function per column count) have ONE call site
-// whose live state is nothing: inlined into the state machine they made the allocator spill around every variant.
-__device__ __noinline__ void bk_dp_round()
-{
-    BkAsmShared *S = S_;
-    const int wv = BK_TID >> 6, nb = S->nb;
-    if (S->dual && nb > BK_WAVES) {                      // more reads than wavefronts (BK_PAIR builds): one score matrix per read, wavefront w takes slots 2w, 2w+1 (bk_nw_pair)
-        const int a = 2 * wv, b = 2 * wv + 1;
-        if (a < nb) {
-            BkPairArgs A, B;
-            A.contig = BK_O_CSEQ + S->slot[a].pb; A.clen = S->slot[a].plen; A.read = BK_O_RSEQ + a * (C_.MAXR + 16); A.n = S->slot[a].rl; A.res = (int)((uint8_t *)&S->slot[a].v1 - bk_lds);
-            if (b < nb) { B.contig = BK_O_CSEQ + S->slot[b].pb; B.clen = S->slot[b].plen; B.read = BK_O_RSEQ + b * (C_.MAXR + 16); B.n = S->slot[b].rl; B.res = (int)((uint8_t *)&S->slot[b].v1 - bk_lds); }
-            else { B.contig = 0; B.clen = 0; B.read = 0; B.n = 0; B.res = 0; }
-            if (S->fast) {
-                // the score sweep first: end cells and scores of both calls; the border cells follow without a traceback for overlaps
-                // without a mismatch or an indel (bk_nw.hip.h).  A read it cannot settle is swept again in full -- with its partner
-                const int nrd = b < nb ? 2 : 1;
-                bk_nw_score_pair(A, B);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                bool redo = S->slot[a].v1.j_start == BK_NW_NEEDS_DP || S->slot[a].v2.j_start == BK_NW_NEEDS_DP;
-                if (b < nb) redo = redo || S->slot[b].v1.j_start == BK_NW_NEEDS_DP || S->slot[b].v2.j_start == BK_NW_NEEDS_DP;
-                redo = __builtin_amdgcn_readfirstlane((int)redo) != 0;
-                if ((BK_TID & 63) == 0) { atomicAdd(&S->dp_n, nrd); if (redo) atomicAdd(&S->dp_redo, nrd); }
-                if (redo) bk_nw_pair(A, B);
-            } else bk_nw_pair(A, B);
-        }
-    } else if (S->dual) {                                // both DPs of slot wv on this wavefront
-        if (wv < nb) {
-            const int contig = BK_O_CSEQ + S->slot[wv].pb, clen = S->slot[wv].plen, rd = BK_O_RSEQ + wv * (C_.MAXR + 16), rl = S->slot[wv].rl, res = (int)((uint8_t *)&S->slot[wv].v1 - bk_lds);
-            if (S->fast) {
-                BkPairArgs A; A.contig = contig; A.clen = clen; A.read = rd; A.n = rl; A.res = res;
-                bk_nw_score_one(A);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                const bool redo = __builtin_amdgcn_readfirstlane((int)(S->slot[wv].v1.j_start == BK_NW_NEEDS_DP || S->slot[wv].v2.j_start == BK_NW_NEEDS_DP)) != 0;
-                if ((BK_TID & 63) == 0) { atomicAdd(&S->dp_n, 1); if (redo) atomicAdd(&S->dp_redo, 1); }
-                if (redo) bk_nw_dual(contig, clen, rd, rl, res);
-            } else bk_nw_dual(contig, clen, rd, rl, res);
-        }
-    } else {                                             // two wavefronts per slot, both with the contig on the tile columns
-        const int sl = wv >> 1;
-        if (sl < nb) {
-            const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
-            if (S->fast) {
-                // the score sweep of the whole matrix on ONE of the slot's two wavefronts (any contig length: column tiles); what it
-                // cannot settle is swept in full after the round's barrier (bk_dp_redo)
-                // (a tile pipeline over BOTH wavefronts of the slot -- alternate column tiles, the second ~128 steps behind on the edge
-                //  column in LDS -- was built and measured in round 5: bit-exact, and no faster where long contigs occur: configs[4]
-                //  6,367 -> 6,394 ms per batch, configs[3] 945 -> 953; not kept: profiles/r05/score_sweep_ab.txt)
-                if ((wv & 1) == 0) {
-                    bk_nw_score_long(BK_O_CSEQ + S->slot[sl].pb, cl, BK_O_RSEQ + sl * (C_.MAXR + 16), rl, (int)((uint8_t *)&S->slot[sl].v1 - bk_lds), L_BOUND_W(wv));
-                    if ((BK_TID & 63) == 0) atomicAdd(&S->dp_n, 1);
-                }
-            } else {
-                const uint8_t *cs = L_CSEQ + S->slot[sl].pb;
-                // waves w and w+4 land on the same SIMD: give it one direct (heavier) and one transposed sweep
-                if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
-                else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
-            }
-        }
-    }
-}
-// the slots of a two-wavefronts-per-slot round whose score sweep left a border cell open: both overlap DPs in full
-__device__ __noinline__ void bk_dp_redo()
-{
-    BkAsmShared *S = S_;
-    const int wv = BK_TID >> 6, sl = wv >> 1;
-    if (sl < S->nb && S->slot[sl].dec) {                 // (Slot::dec is free between the staging of a round and its retirement: here it says "sweep again")
-        const uint8_t *cs = L_CSEQ + S->slot[sl].pb; const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
-        if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
-        else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
-    }
-}
-// noisy reads: check_align has lately rejected three reads out of four (prediction then is "nothing changes", bk_predict)
-__device__ inline bool bk_expect_reject() { return S_->n_rej >= 24 && S_->n_rej >= 3 * S_->n_acc; }
-
-// Look-ahead across the k-mer visits of grow.  A visit usually recruits only a handful of reads (clean data) or a single
-// one (sequencing noise), far fewer than there are look-ahead slots.  The visits of a snapshot are known in advance
-// (nklist), and so is the candidate list of a LATER visit: every read a visit looks at ends up in the contig's buffer
-// (check_read :552 buffer.add, matched or not), so the list a later visit will see is its eligible reads now minus the
-// reads of the visits in between -- which are exactly the slots planned before it.  A round therefore goes on planning
-// into the following visits until the slots are full; their DPs run in the same round against the predicted contig and
-// their results wait in the slots.  When such a visit comes up, its real candidate list (the ordinary find_reads) is
-// compared with the planned one: equal -> the slots are retired in order under the usual prediction checks, no DP;
-// anything else -> the plan is dropped and the visit runs as before.  State only ever changes in bk_retire / finalize,
-// in the reference's order.
-//
-// One wavefront per following visit: its eligible reads (short posting lists only), ordered as find_reads orders them,
-// with the per-read fields a slot needs, and the position of its k-mer in the current contig.
-#define BK_LA_CH 16                                  // posting lists of up to 64 * BK_LA_CH entries are looked into
-#define BK_LA_CU(w) ((uint32_t *)L_CAND + (w) * 64)
-#define BK_LA_RL(w) ((int *)L_CAND + (BK_AT / 64 + (w)) * 64)
-#define BK_LA_RN(w) ((int *)L_CAND + (2 * (BK_AT / 64) + (w)) * 64)
-#define BK_LA_FL(w) ((int *)L_CAND + (3 * (BK_AT / 64) + (w)) * 64)
-BK_COLD void bk_lookahead_wave(int w, int vt, int T)
-{
-    BkAsmShared *S = S_;
-    const int lane = BK_TID & 63;
-    const int idx = vt + 1 + lane;
-    const uint32_t en = idx < T ? C_.nklist[idx] : 0x40000000u;
-    unsigned long long m = __ballot(!(en & 0x40000000u));                      // visits that may have candidates, in order
-    for (int i = 0; i < w; i++) m &= m - 1;
-    int cnt = -1, tt = -1, rank2 = 0, pc2 = -1;
-    if (m) {
-        const int bit = __ffsll((long long)m) - 1;
-        const uint32_t e2 = (uint32_t)__shfl((int)en, bit);
-        tt = vt + 1 + bit; rank2 = (int)(e2 & 0x3FFFFFFFu);
-        const bool rev = (e2 >> 31) != 0;
-        const uint32_t b = C_.poff[rank2], e = C_.poff[rank2 + 1];
-        if (e - b <= 64u * BK_LA_CH) {
-            // eligible entries of the posting list (a k-mer of a deep region sits in a few hundred reads, nearly all of them
-            // in the buffer already): BK_LA_CH entries per lane, loads issued together, compacted into the list
-            const int np = (int)(e - b);
-            uint32_t pe[BK_LA_CH]; uint32_t fl[BK_LA_CH]; int bs[BK_LA_CH];
-#pragma unroll
-            for (int c = 0; c < BK_LA_CH; c++) pe[c] = lane + 64 * c < np ? C_.post[b + lane + 64 * c] : 0u;
-#pragma unroll
-            for (int c = 0; c < BK_LA_CH; c++) { const bool have = lane + 64 * c < np; fl[c] = have ? C_.ufl[pe[c] >> 10] : 0u; bs[c] = have ? C_.ubuf[pe[c] >> 10] : 0; }
-            int nv = 0;
-#pragma unroll
-            for (int c = 0; c < BK_LA_CH; c++) {
-                const bool okc = lane + 64 * c < np && !(fl[c] & BK_R_DELETED) && bs[c] != S->serial;
-                const unsigned long long vm = __ballot(okc);
-                const int at = nv + __popcll(vm & ((1ull << lane) - 1ull));
-                if (okc && at < 64) { BK_LA_RL(w)[at] = (int)pe[c]; BK_LA_FL(w)[at] = (int)fl[c]; }      // staging: overwritten by the ordered list below
-                nv += __popcll(vm);
-            }
-            if (nv <= 64) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                const bool have = lane < nv;
-                const uint32_t mypost = have ? (uint32_t)BK_LA_RL(w)[lane] : 0u; const uint32_t myfl = have ? (uint32_t)BK_LA_FL(w)[lane] : 0u;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                const uint32_t u = mypost >> 10; const int pos = (int)(mypost & 1023u);
-                uint32_t len = 0; int rn = 0;
-                if (have) { len = C_.ulen[u]; rn = (int)C_.unr[u]; }
-                bool drop = false;                                                 // the k-mer twice in one read: first occurrence (re.search)
-                for (int j = 0; j < nv; j++) {
-                    const uint32_t oen = (uint32_t)__builtin_amdgcn_readlane((int)mypost, j);
-                    drop = drop || ((oen >> 10) == u && (int)(oen & 1023u) < pos);
-                }
-                const bool valid = have && !drop;
-                const unsigned long long pk = rev ? (unsigned long long)(0xFFFF - pos) : (unsigned long long)pos;
-                const unsigned long long key = valid ? ((pk << 40) | ((0xFFFFull - len) << 24) | u) : ~0ull;
-                int ord = 0;
-                for (int j = 0; j < nv; j++) {
-                    const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)key, j);
-                    ord += kj < key;
-                }
-                if (valid) { BK_LA_CU(w)[ord] = u | ((uint32_t)pos << 22); BK_LA_RL(w)[ord] = (int)len; BK_LA_RN(w)[ord] = rn; BK_LA_FL(w)[ord] = (int)myfl; }
-                cnt = __popcll(__ballot(valid));
-                BkKey kk; kk.hi = C_.khi[rank2]; kk.lo = C_.klo[rank2];
-                if (!bk_expect_reject()) pc2 = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, kk, C_.k);      // the geometry is not used while rejections are expected
-            }
-        }
-    }
-    if (lane == 0) { S->la_n[w] = cnt; S->la_t[w] = tt; S->la_rank[w] = rank2; S->la_pc[w] = pc2; }
-}
-
-// The same for the SEEDS that follow (setup_contigs :11-26).  With sequencing noise most DP rounds are the first round of a
-// seed: an error k-mer shared by two or three reads, one of them the founder.  The seeds to come are the next live k-mers in
-// (count, mer) order, their candidate lists are find_reads results without a buffer filter (only deleted reads are left out).
-// Wavefront w takes the (w+1)-th live k-mer after `rank`: list in find_reads order (entry 0 = founder) with the slot fields.
-BK_COLD void bk_seedahead_wave(int w, int rank)
-{
-    BkAsmShared *S = S_;
-    const int lane = BK_TID & 63;
-    // (the seeds that follow in THIS unit's list: S->head is where the running seed sits in it)
-    const int li = S->head + 1 + lane;
-    const int r = li < C_.n_my ? bk_seed_at(li) : -1;
-    const bool live = r >= 0 && C_.kstate[r] == BK_K_LIVE && C_.kcnt[r] >= 2;
-    unsigned long long m = __ballot(live);
-    for (int i = 0; i < w; i++) m &= m - 1;
-    int cnt = -1, rank2 = 0;
-    (void)rank;
-    if (m) {
-        rank2 = __shfl(r, __ffsll((long long)m) - 1);
-        const uint32_t b = C_.poff[rank2], e = C_.poff[rank2 + 1];
-        if (e - b <= 64u * BK_LA_CH) {
-            const int np = (int)(e - b);
-            uint32_t pe[BK_LA_CH]; uint32_t fl[BK_LA_CH];
-#pragma unroll
-            for (int c = 0; c < BK_LA_CH; c++) pe[c] = lane + 64 * c < np ? C_.post[b + lane + 64 * c] : 0u;
-#pragma unroll
-            for (int c = 0; c < BK_LA_CH; c++) fl[c] = lane + 64 * c < np ? C_.ufl[pe[c] >> 10] : 0u;
-            int nv = 0;
-#pragma unroll
-            for (int c = 0; c < BK_LA_CH; c++) {
-                const bool okc = lane + 64 * c < np && !(fl[c] & BK_R_DELETED);             // used_reads = set(): no buffer filter
-                const unsigned long long vm = __ballot(okc);
-                const int at = nv + __popcll(vm & ((1ull << lane) - 1ull));
-                if (okc && at < 64) { BK_LA_RL(w)[at] = (int)pe[c]; BK_LA_FL(w)[at] = (int)fl[c]; }
-                nv += __popcll(vm);
-            }
-            if (nv <= 64) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                const bool have = lane < nv;
-                const uint32_t mypost = have ? (uint32_t)BK_LA_RL(w)[lane] : 0u; const uint32_t myfl = have ? (uint32_t)BK_LA_FL(w)[lane] : 0u;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                const uint32_t u = mypost >> 10; const int pos = (int)(mypost & 1023u);
-                uint32_t len = 0; int rn = 0;
-                if (have) { len = C_.ulen[u]; rn = (int)C_.unr[u]; }
-                bool drop = false;
-                for (int j = 0; j < nv; j++) {
-                    const uint32_t oen = (uint32_t)__builtin_amdgcn_readlane((int)mypost, j);
-                    drop = drop || ((oen >> 10) == u && (int)(oen & 1023u) < pos);
-                }
-                const bool valid = have && !drop;
-                const unsigned long long key = valid ? (((unsigned long long)pos << 40) | ((0xFFFFull - len) << 24) | u) : ~0ull;
-                int ord = 0;
-                for (int j = 0; j < nv; j++) {
-                    const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)key, j);
-                    ord += kj < key;
-                }
-                if (valid) { BK_LA_CU(w)[ord] = u | ((uint32_t)pos << 22); BK_LA_RL(w)[ord] = (int)len; BK_LA_RN(w)[ord] = rn; BK_LA_FL(w)[ord] = (int)myfl; }
-                cnt = __popcll(__ballot(valid));
-            }
-        }
-    }
-    if (lane == 0) { S->la_n[w] = cnt; S->la_t[w] = -2 - rank2; S->la_rank[w] = rank2; S->la_pc[w] = 0; }
-}
-
-// one step of the prediction chain (thread 0): slot t is aligned against the contig [pb, pb+plen) in which its k-mer sits
-// at ppc; what the read is predicted to do to it.  Returns false when nothing can be predicted past this slot.
-__device__ inline bool bk_predict(BkAsmShared::Slot &t, int &pb, int &plen, int &ppc, int lo, int hi)
-{
-    const int pos = t.pos, rl = t.rl;
-    t.pb = pb; t.plen = plen;
-    // noisy reads: where check_align has lately rejected three reads out of four, the best guess for the next one is that
-    // it is rejected too and the contig stays as it is (a rejection after a predicted extension would void the later slots)
-    if (bk_expect_reject()) { t.kind = BK_PK_SAME; t.amt = 0; return true; }
-    const int left = pos - ppc, right = (rl - pos) - (plen - ppc);
-    if (ppc < 0 || (left > 0 && right > 0)) { t.kind = BK_PK_STOP; t.amt = 0; return false; }
-    if (left > 0) { t.kind = BK_PK_PRE; t.amt = left; if (pb - left < lo || plen + left > C_.MAXC) { t.kind = BK_PK_STOP; return false; } pb -= left; plen += left; ppc += left; }
-    else if (right > 0) { t.kind = BK_PK_POST; t.amt = right; if (pb + plen + right > hi || plen + right > C_.MAXC) { t.kind = BK_PK_STOP; return false; } plen += right; }
-    else { t.kind = BK_PK_SAME; t.amt = 0; }
-    return true;
-}
-
-// Run retire (BK_F_NO_RUN_RETIRE switches it off).  The slots of a round are retired together for as long as every one of
-// them does what was predicted: the decisions of slots sl .. s1-1 are taken at once (a lane each, against the contig length
-// each was aligned to), thread 0 walks the prediction chain over them -- a rejected, identical or contained read leaves the
-// sequence alone, an extension (contig_overlap_read :520-527, read_overlap_contig :538-545) must be the predicted kind and
-// length, which makes the bytes the predicted ones -- and the run is applied in ONE pass: the appended / prepended bases, the
-// count entries of the new bases (assigned, extend_counts :201-221), then one summed count update per base over the ranges
-// of all reads of the run in the coordinates each range was taken in (set_counts :195-199; old coordinates before a
-// prepend), one lane per read for the per-read words, appends in slot order.  Left to the one-read path (bk_retire): a read
-// that replaces the contig (superseq), a tie of the two scores (k-mer position rule), the first read of a seed planned
-// ahead, an extension that fails a bound, and in grow mode an extension by two or more bases (it adds contig k-mers, in
-// order, bk_kmers_ordered; an extension by one base adds none, Q1).  Four barriers per run instead of two to three per read.
-// The number retired is left in S->tmp0 (uniform after the function's last barrier).
-__device__ __forceinline__ void bk_retire_run(int sl, int s1, bool grow)
-{
-    BkAsmShared *S = S_;
-    const int nbt = s1 - sl;
-    const int cbase0 = S->cbase, clen0 = S->clen, nbase0 = S->nbase, nlen0 = S->nlen;      // read by every thread before thread 0 replaces them (two barriers on)
-    // wavefront 0, a lane per slot: the decision, whether the slot does what it may do here, whether the contig it was aligned
-    // against is what its predecessor leaves behind; the run = the slots before the first lane that says no.  The per-read
-    // words the bookkeeping at the end needs are asked for now (nobody writes them in between).
-    int my_u = 0, my_dec = BK_DEC_NONE, my_found = -1, my_ur = 0; uint32_t my_fl = 0, my_kc = 0; unsigned long long my_cells = 0;
-    if ((BK_TID >> 6) == 0) {
-        const int j = BK_TID;
-        const bool have = j < nbt;
-        bool ok = false; int dec = BK_DEC_NONE, pl = 0, a0 = 0, a1 = 0, cb_after = 0, cl_after = 0, pb = 0, plen = 0;
-        if (have) {
-            BkAsmShared::Slot &t = S->slot[sl + j];
-            my_u = t.u; my_fl = C_.ufl[my_u]; my_ur = C_.ureads[my_u]; my_kc = C_.kcnt[t.rank]; if (grow) my_found = C_.ufound[my_u];
-            pb = t.pb; plen = t.plen;
-            int ds, de; bool tie;
-            dec = bk_decide(t.v1, t.v2, plen, t.rl, ds, de, tie);
-            if (dec == BK_DEC_POST) { pl = max(t.rl - t.v1.i_end, 0); ds = t.v1.j_start; de = plen; }
-            else if (dec == BK_DEC_PRE) { pl = t.v2.j_start; ds = t.v2.i_start; de = t.v2.i_end; }
-            const int nb_ = nbase0 - (cbase0 - pb), nl_ = nlen0 + (plen - clen0);          // the count vectors move with the contig
-            ok = !t.first && !tie && dec != BK_DEC_SUPER && !(grow && pl >= 2);
-            if (dec == BK_DEC_POST) ok = ok && !(pb + plen + pl > 2 * C_.MAXC || plen + pl > C_.MAXC || nb_ + nl_ + pl > 2 * C_.MAXC);
-            else if (dec == BK_DEC_PRE) ok = ok && !(pb - pl < 0 || plen + pl > C_.MAXC || nb_ - pl < 0);
-            if (dec != BK_DEC_NONE && dec != BK_DEC_SAME) { a0 = nb_ + ds; a1 = max(nb_ + min(de, nl_), a0); }      // absolute span of the count update
-            cb_after = dec == BK_DEC_PRE ? pb - pl : pb; cl_after = (dec == BK_DEC_PRE || dec == BK_DEC_POST) ? plen + pl : plen;
-            my_dec = dec; my_cells = 2ull * (unsigned long long)plen * (unsigned long long)t.rl;
-            if (ok) { t.dec = dec; t.ds = a0; t.de = a1; t.hasn = pl; }      // hasn: only read when the slot is staged; from here on the length of the extension
-        }
-        // the contig this slot was aligned against = what the slot before it leaves (slot sl: the contig as it is)
-        int pcb = __shfl_up(cb_after, 1), pcl = __shfl_up(cl_after, 1), pdec = __shfl_up(dec, 1);
-        if (j == 0) { pcb = cbase0; pcl = clen0; pdec = S->last_dec; }
-        if (have) {
-            bool chain = pcb == pb && pcl == plen;
-            if (sl + j > 0) {
-                const int pk = S->slot[sl + j - 1].kind;
-                chain = chain && ((pk == BK_PK_PRE && pdec == BK_DEC_PRE) || (pk == BK_PK_POST && pdec == BK_DEC_POST) ||
-                                  (pk == BK_PK_SAME && (pdec == BK_DEC_NONE || pdec == BK_DEC_SAME || pdec == BK_DEC_SUB)));
-            }
-            ok = ok && chain;
-        }
-        const unsigned long long bad = ~__ballot(ok);
-        const int m = bad ? __ffsll((long long)bad) - 1 : 64;              // lanes >= nbt say no: m <= nbt
-        // span of all count updates of the run, geometry after its last slot
-        int lo = (j < m && a1 > a0) ? a0 : 0x7FFFFFFF, hi = (j < m && a1 > a0) ? a1 : 0;
-        for (int o = 1; o < 16; o <<= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }      // BK_SPEC <= 16 slots
-        if (j == 0) { S->tmp0 = m; S->tmp1 = hi > 0 ? lo : 0; S->tmp2 = hi; }
-        if (m > 0 && j == m - 1) { S->dstart = cb_after; S->dend = cl_after; }
-    }
-    BK_SYNC();
-    const int m = S->tmp0;
-    if (m == 0) return;
-    const int lo = S->tmp1, hi = S->tmp2, cbase1 = S->dstart, clen1 = S->dend;
-    int32_t *io = bk_cnt_io(S->cbuf), *ot = bk_cnt_ot(S->cbuf);
-    // new bases and their count entries: a wavefront per slot (the bases of all slots but the round's last were pre-written by the staging; the same bytes)
-    for (int j = BK_TID >> 6; j < m; j += BK_AT / 64) {
-        const BkAsmShared::Slot &q = S->slot[sl + j];
-        const int pl = q.hasn;
-        if ((q.dec != BK_DEC_POST && q.dec != BK_DEC_PRE) || pl == 0) continue;
-        const int nb_ = nbase0 - (cbase0 - q.pb), nl_ = nlen0 + (q.plen - clen0);
-        const uint8_t *rs = L_RSEQ_S(sl + j);
-        const int cat_io = q.rindel ? q.rn : 0, cat_ot = q.rindel ? 0 : q.rn;
-        if (q.dec == BK_DEC_POST) {
-            for (int t = BK_TID & 63; t < pl; t += 64) { L_CSEQ[q.pb + q.plen + t] = rs[q.rl - pl + t]; io[nb_ + nl_ + t] = cat_io; ot[nb_ + nl_ + t] = cat_ot; }
-        } else {
-            for (int t = BK_TID & 63; t < pl; t += 64) { L_CSEQ[q.pb - pl + t] = rs[t]; io[nb_ - pl + t] = cat_io; ot[nb_ - pl + t] = cat_ot; }
-        }
-    }
-    BK_SYNC();
-    for (int t = lo + BK_TID; t < hi; t += BK_AT) {
-        int a = 0, b = 0;
-        for (int j = 0; j < m; j++) {
-            const BkAsmShared::Slot &q = S->slot[sl + j];
-            if (t >= q.ds && t < q.de) { if (q.rindel) a += q.rn; else b += q.rn; }      // empty span for a read that changes no count
-        }
-        if (a) io[t] += a;
-        if (b) ot[t] += b;
-    }
-    if ((BK_TID >> 6) == 0) {
-        const int j = BK_TID;
-        const bool have = j < m;
-        const int u = my_u, dec = my_dec;
-        const bool match = have && dec != BK_DEC_NONE;
-        const bool to_list = match && my_ur != S->serial;
-        const bool to_alt = have && !match && my_kc > 2 && !(my_fl & BK_R_USED);
-        const unsigned long long lm = __ballot(to_list), am = __ballot(to_alt), mm = __ballot(match), below = (1ull << j) - 1ull;
-        if (have) {
-            C_.ubuf[u] = S->serial;
-            if (match) {
-                C_.ufl[u] = (uint8_t)(my_fl | BK_R_USED);
-                if (to_list) { C_.ureads[u] = S->serial; C_.readl[S->nr + __popcll(lm & below)] = (uint32_t)u; }
-                if (grow && my_found >= 0 && BK_CHK((uint32_t)my_found <= C_.U, 11, my_found)) { C_.pend[2 * my_found] = BK_EMPTY32; C_.ufound[u] = -1; }
-            } else if (to_alt) {
-                const int at = S->nalt + __popcll(am & below);
-                if (at < C_.MAXCAND) C_.altl[at] = (uint32_t)u; else S->status = BK_ST_CAND;
-            } else C_.ufl[u] = (uint8_t)(my_fl | BK_R_DELETED);
-        }
-        unsigned long long cells = have ? my_cells : 0ull;
-        for (int o = 1; o < 16; o <<= 1) cells += __shfl_xor(cells, o);
-        if (BK_TID == 0) {
-            S->nr += __popcll(lm); S->nalt = min(S->nalt + __popcll(am), C_.MAXCAND);
-            int na = S->n_acc, nr_ = S->n_rej;
-            for (int i = 0; i < m; i++) { if ((mm >> i) & 1ull) na++; else nr_++; if (na + nr_ >= 64) { na >>= 1; nr_ >>= 1; } }
-            S->n_acc = na; S->n_rej = nr_;
-            S->cells += cells; S->calls += 2 * m;
-            const bool lastm = ((mm >> (m - 1)) & 1ull) != 0;
-            S->last_dec = S->slot[sl + m - 1].dec; S->hit = lastm ? 1 : 0;
-            S->pc += cbase0 - cbase1;                                       // the recruiting k-mer moves with what was prepended
-            S->nbase = nbase0 - (cbase0 - cbase1); S->nlen = nlen0 + (clen1 - clen0); S->cbase = cbase1; S->clen = clen1;
-#ifdef BK_PHASE_STAMPS
-            S->acc[17] += m;
-#endif
-        }
-    }
-    BK_SYNC();
-}
-
-// retire slot sl if the contig is what the slot was aligned against; uniform result: 1 retired, 0 prediction failed
-__device__ __forceinline__ int bk_retire_checked(int sl, bool grow)
-{
-    BkAsmShared *S = S_;
-    if (S->slot[sl].first) {                        // first read of a seed planned ahead: the contig is its founder, nothing came before
-        if (S->cbase != S->slot[sl].pb || S->clen != S->slot[sl].plen) return 0;
-    } else if (sl > 0) {
-        const int pk = S->slot[sl - 1].kind, ld = S->last_dec;
-        const bool kind_ok = (pk == BK_PK_PRE && ld == BK_DEC_PRE) || (pk == BK_PK_POST && ld == BK_DEC_POST) ||
-                             (pk == BK_PK_SAME && (ld == BK_DEC_NONE || ld == BK_DEC_SAME || ld == BK_DEC_SUB));
-        if (!kind_ok || S->cbase != S->slot[sl].pb || S->clen != S->slot[sl].plen) return 0;
-    }
-    (void)bk_retire(S->slot[sl].rank, sl, grow);    // ends with a barrier; the FIFO entry of a matched read is dropped in its bookkeeping
-#ifdef BK_PHASE_STAMPS
-    if (BK_TID == 0) S->acc[17] += 1;
-#endif
-    return 1;
-}
-
-// the plan of one round (thread 0): prediction chain over this visit's slots, then over the following visits' lists.  Out of
-// line: its loops over slots and lists would otherwise sit in the register budget of the state machine's hot loop.
-BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int la_on)
-{
-    BkAsmShared *S = S_;
-    if (BK_TID != 0) return;
-    int pb = S->cbase, plen = S->clen, ppc = S->pc, nb = 0;
-    bool go = true;
-    // both DPs of a slot run on one wavefront while the (predicted) contig fits its columns; else two wavefronts per slot
-    for (int sl = 0; sl < nbmax && go; sl++) {
-        if (sl >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
-        nb = sl + 1;
-        go = bk_predict(S->slot[sl], pb, plen, ppc, 0, 2 * C_.MAXC);
-    }
-    const int ncur = nb;
-    int upto = vt;
-#ifdef BK_PHASE_STAMPS
-    if (la_on) S->acc[19] += 1ull;                                               // rounds with free slots
-    if (la_on && !(la && go && q + ncur == n)) S->acc[19] += 1ull << 16;          // ... not looked ahead (paused / STOP / round does not finish the visit)
-    else if (la_on && S->la_n[0] < 0) S->acc[19] += 1ull << 32;                  // ... next visit: none in the window or posting list too long
-    else if (la_on && S->la_n[0] == 0) S->acc[19] += 1ull << 48;                 // ... next visit has no eligible read
-#endif
-    if (la && vt >= 0 && go && q + ncur == n) {
-        for (int w = 0; w < BK_AT / 64 && go; w++) {
-            const int cn = S->la_n[w];
-            if (cn < 0) break;
-            // the visit's list once the reads planned before it are in the buffer
-            int keep = 0;
-            for (int i = 0; i < cn; i++) {
-                const int u = (int)(BK_LA_CU(w)[i] & 0x3FFFFFu); bool inflight = false;
-                for (int s2 = 0; s2 < nb; s2++) inflight = inflight || S->slot[s2].u == u;
-                keep += !inflight;
-                if (nb + keep > cap) break;                         // does not fit: no need to look at the rest of the list
-            }
-            if (nb + keep > cap) break;
-            const int pc2 = S->la_pc[w];
-            if (keep > 0 && pc2 < 0 && !bk_expect_reject()) break;
-            ppc = pc2 + (S->cbase - pb);                    // the predicted contig starts cbase - pb bases before the current one
-            const int nb0 = nb;
-            for (int i = 0; i < cn && go; i++) {
-                const uint32_t cu = BK_LA_CU(w)[i]; const int u = (int)(cu & 0x3FFFFFu); bool inflight = false;
-                for (int s2 = 0; s2 < nb0; s2++) inflight = inflight || S->slot[s2].u == u;
-                if (inflight) continue;
-                if (nb >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
-                BkAsmShared::Slot &t = S->slot[nb];
-                const int fl = BK_LA_FL(w)[i];
-                t.u = u; t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
-                t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
-                t.vt = S->la_t[w]; t.rank = S->la_rank[w]; t.fu = -1; t.first = 0;
-                nb++;
-                go = bk_predict(t, pb, plen, ppc, 0, 2 * C_.MAXC);
-            }
-            if (nb - nb0 != keep) { nb = nb0; break; }      // a visit is planned whole or not at all
-            upto = S->la_t[w];
-        }
-    }
-    int kind = 0;
-    if (la && vt < 0 && q + ncur == n) {
-        // the first round of the seeds that follow: a group per seed, aligned against its founder in a strip of its own
-        kind = 1;
-        int g = 0;
-        for (int w = 0; w < BK_AT / 64; w++) {
-            const int cn = S->la_n[w];
-            if (cn < 0) break;
-            if (cn < 2) continue;                                   // a seed with its founder only has no DP
-            if (nb + cn - 1 > cap) break;
-            const uint32_t fcu = BK_LA_CU(w)[0];
-            const int base = BK_SEEDBUF(g) + C_.MAXR + 16, lo = BK_SEEDBUF(g), hi = BK_SEEDBUF(g) + 3 * (C_.MAXR + 16);
-            int pb2 = base, plen2 = BK_LA_RL(w)[0], ppc2 = (int)(fcu >> 22);          // the contig IS the founder; the k-mer sits where it sits in that read
-            const int nb0 = nb; bool whole = true;
-            for (int i = 1; i < cn; i++) {
-                const uint32_t cu = BK_LA_CU(w)[i];
-                if (nb >= BK_SPEC_WIDE && plen2 > BK_NW_DUAL_COLS) { whole = false; break; }
-                BkAsmShared::Slot &t = S->slot[nb];
-                const int fl = BK_LA_FL(w)[i];
-                t.u = (int)(cu & 0x3FFFFFu); t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
-                t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
-                t.vt = S->la_t[w]; t.rank = S->la_rank[w]; t.fu = (int)(fcu & 0x3FFFFFu); t.first = (i == 1) ? 1 : 0;
-                nb++;
-                if (!bk_predict(t, pb2, plen2, ppc2, lo, hi) && i + 1 < cn) { whole = false; break; }
-            }
-            if (!whole) { nb = nb0; continue; }                     // a seed is planned whole or not at all
-            g++;
-        }
-    }
-    int mx = 0;
-    for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen);
-    if (kind == 1 && mx > BK_NW_TILE_COLS) { nb = ncur; mx = 0; for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen); }      // a multi-tile DP would use the scratch the strips sit in
-    // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
-    // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
-    S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
-    if (S->dp_n >= 64) { S->dp_tot += S->dp_n - (S->dp_n >> 1); S->dp_rtot += S->dp_redo - (S->dp_redo >> 1); S->dp_n >>= 1; S->dp_redo >>= 1; }
-    S->fast = !(C_.flags & BK_F_NO_SCORE_SWEEP) && 4 * S->dp_redo <= S->dp_n + 8;      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays)
-    int nc = ncur;
-    if (!S->dual && nb > BK_SPEC_WIDE) { nc = min(nc, BK_SPEC_WIDE); nb = nc; upto = vt; }      // two wavefronts per slot: this visit's reads only
-    S->nb = nb; S->ncur = nc;
-    S->plan_r = nc; S->plan_upto = upto; S->plan_ok = (nb > nc || upto > vt) ? 1 : 0; S->plan_kind = kind;
-    S->la_planned += nb - nc;
-    if (la_on && S->la_pause > 0) S->la_pause--;
-    if (S->la_planned >= 64) {                      // one window: did the slots planned for later visits get used?
-        if (4 * S->la_adopted < S->la_planned) { S->la_pause = S->la_backoff; S->la_backoff = min(2 * S->la_backoff, 4096); }
-        else S->la_backoff = 32;
-        S->la_planned = 0; S->la_adopted = 0;
-    }
-}
-
-// vt / T: index of this visit in the snapshot and the snapshot's length (grow); vt < 0: setup_contigs
-__device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bool grow, int vt, int T)
-{
-    BkAsmShared *S = S_;
-    const int wv = BK_TID >> 6;
-    int q = first;
-    // 0. a plan of an earlier round covers this visit: adopt its slots if it predicted exactly this candidate list
-    //    (uniform: every thread evaluates the same LDS words)
-    bool adopt = false;
-    int r0 = 0;
-    if (vt >= 0 && S->plan_ok && S->plan_kind == 0) {
-        r0 = S->plan_r;
-        adopt = vt <= S->plan_upto;
-        int g = 0;
-        if (adopt) { while (r0 + g < S->nb && S->slot[r0 + g].vt == vt) g++; adopt = g == n; }
-        for (int i = 0; adopt && i < n; i++) { const uint32_t cu = L_CANDU[i]; adopt = S->slot[r0 + i].u == (int)(cu & 0x3FFFFFu) && S->slot[r0 + i].pos == (int)(cu >> 22); }
-        if (!adopt || n == 0) {
-            BK_SYNC();
-            if (BK_TID == 0) { if (!adopt) S->plan_ok = 0; else if (r0 >= S->nb && vt >= S->plan_upto) S->plan_ok = 0; }
-            BK_SYNC();
-            adopt = false;
-        }
-    }
-    if (vt == -1 && S->plan_ok && S->plan_kind == 1) {
-        // a setup round planned the first round of this seed ahead: same founder, same candidates -> adopt
-        const int nbp = S->nb;
-        int r = S->plan_r;
-        while (r < nbp && -2 - S->slot[r].vt < rank) r++;          // seeds that never came up (their k-mer was used up meanwhile)
-        int g = 0; bool ad = false;
-        if (r < nbp && -2 - S->slot[r].vt == rank) {
-            while (r + g < nbp && S->slot[r + g].vt == S->slot[r].vt) g++;
-            ad = n >= 2 && g == n - 1 && S->slot[r].first && S->slot[r].fu == (int)(L_CANDU[0] & 0x3FFFFFu);
-            for (int i = 0; ad && i < g; i++) { const uint32_t cu = L_CANDU[1 + i]; ad = S->slot[r + i].u == (int)(cu & 0x3FFFFFu) && S->slot[r + i].pos == (int)(cu >> 22); }
-        }
-        BK_SYNC();
-        if (BK_TID == 0) {
-            if (ad) { const int delta = S->cbase - S->slot[r].pb; for (int i = 0; i < g; i++) S->slot[r + i].pb += delta; S->plan_r = r; }      // strip -> contig deque coordinates
-            else { S->plan_r = r + g; if (S->plan_r >= nbp) S->plan_ok = 0; }
-        }
-        BK_SYNC();
-        if (ad) { adopt = true; r0 = r; }
-    }
-    // one loop for both kinds of pass, so that the decision/apply step (bk_retire) is inlined once: a pass either retires
-    // the adopted slots of this visit or plans, aligns and retires a fresh round
-    while (adopt || q < n) {
-        int s0 = r0, s1 = r0 + (n - q);             // the adopted slots of this visit / seed ...
-        if (!adopt) {                               // ... or a fresh round:
-        if (S->status) return;
-        BK_ACC(S_->ctx);
-        // slots of a round: one per wavefront while both DPs of a slot fit one wavefront (contig <= BK_NW_DUAL_COLS), else half
-        const int cap = ((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) || S->clen > BK_NW_DUAL_COLS) ? BK_SPEC_WIDE : BK_SPEC;
-        const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
-        // look into the following visits when this one leaves slots free (needs the scratch for BK_AT/64 lists of 64 reads)
-        // (split regions, bk_comp.hip.h: until round 4 the look-ahead was off inside them -- with it the assembler faulted about once
-        //  in 25 runs of a 64-region noisy batch.  The causes were two missing barriers (bk_retire's bookkeeping, round 4; the
-        //  S->foreign loop of bk_kmers_ordered, round 5), not the plans; BK_F_SPLIT_NO_LOOKAHEAD is the round-4 setting.)
-        const bool la_on = n - q < cap && !(C_.flags & (vt >= 0 ? BK_F_NO_XVISIT : BK_F_NO_XSEED)) && 2 * C_.MAXCAND >= 4 * BK_AT && !(C_.split && (C_.flags & BK_F_SPLIT_NO_LOOKAHEAD));
-        const bool la = la_on && S->la_pause == 0;
-        // 1. stage the reads of this round (one lane per slot fetches the read's metadata), plan the predictions
-        BK_SYNC();
-        if (BK_TID < nbmax) {
-            const uint32_t cu = L_CANDU[q + BK_TID]; const int u = (int)(cu & 0x3FFFFFu);
-            const uint32_t ri = C_.urep[u];
-            BkAsmShared::Slot &t = S->slot[BK_TID];
-            t.u = u; t.pos = (int)(cu >> 22); t.rl = C_.rlen[ri]; t.rn = (int)C_.unr[u]; t.rindel = (C_.ufl[u] & BK_R_INDEL) ? 1 : 0;
-            t.hasn = (C_.n_nlist && (C_.ufl[u] & BK_R_HASN)) ? 1 : 0;
-            t.vt = vt; t.rank = rank; t.fu = -1; t.first = 0;
-        }
-        if (la) { if (vt >= 0) bk_lookahead_wave(wv, vt, T); else bk_seedahead_wave(wv, rank); }
-        BK_SYNC();
-        bk_plan_round(q, n, nbmax, cap, vt, la ? 1 : 0, la_on ? 1 : 0);
-        BK_SYNC();
-        const int nb = S->nb, ncur = S->ncur;
-#ifdef BK_PHASE_STAMPS
-        if (BK_TID == 0) { S->acc[16] += nb; S->acc[18] += 1; }
-#endif
-        {   // unpack the reads; pre-write the bytes slot sl is predicted to add.  One wavefront per slot: the global loads
-            // of all slots are in flight together (slot after slot they were nb dependent round trips per round)
-            const int ln = BK_TID & 63;
-            for (int sl = BK_TID >> 6; sl < nb; sl += BK_WAVES) {
-                const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
-                const uint32_t *w = C_.reads + (uint64_t)C_.urep[S->slot[sl].u] * C_.read_words;
-                for (int t = ln; t < rl; t += 64) rs[t] = (uint8_t)seq_base(w, t);
-                if (S->slot[sl].first) {                 // founder of a seed planned ahead: the contig its reads are aligned against
-                    const uint32_t fri = C_.urep[S->slot[sl].fu];
-                    const uint32_t *fw = C_.reads + (uint64_t)fri * C_.read_words;
-                    uint8_t *fs = L_CSEQ + S->slot[sl].pb; const int fl2 = S->slot[sl].plen;
-                    for (int t = ln; t < fl2; t += 64) fs[t] = (uint8_t)seq_base(fw, t);
-                    if (C_.n_nlist && (C_.ufl[S->slot[sl].fu] & BK_R_HASN)) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                        if (ln == 0) bk_patch_n(fri, fs, 0, fl2);
-                    }
-                }
-                if (sl + 1 < nb) {
-                    const int amt = S->slot[sl].amt, pb = S->slot[sl].pb, plen = S->slot[sl].plen;
-                    if (S->slot[sl].kind == BK_PK_PRE) for (int t = ln; t < amt; t += 64) L_CSEQ[pb - amt + t] = (uint8_t)seq_base(w, t);
-                    else if (S->slot[sl].kind == BK_PK_POST) for (int t = ln; t < amt; t += 64) L_CSEQ[pb + plen + t] = (uint8_t)seq_base(w, rl - amt + t);
-                }
-            }
-        }
-        BK_SYNC();
-        if (C_.n_nlist) {                                 // reads with N calls (rare): code 4 over the unpacked bytes and over the predicted contig bytes
-            bool any = false;
-            for (int sl = 0; sl < nb; sl++) any = any || S->slot[sl].hasn;
-            if (any) {
-                if (BK_TID < nb && S->slot[BK_TID].hasn) {
-                    const BkAsmShared::Slot &t = S->slot[BK_TID]; const uint32_t ri = C_.urep[t.u];
-                    bk_patch_n(ri, L_RSEQ_S(BK_TID), 0, t.rl);
-                    if (BK_TID + 1 < nb) {
-                        if (t.kind == BK_PK_PRE) bk_patch_n(ri, L_CSEQ + t.pb - t.amt, 0, t.amt);
-                        else if (t.kind == BK_PK_POST) bk_patch_n(ri, L_CSEQ + t.pb + t.plen, t.rl - t.amt, t.amt);
-                    }
-                }
-                BK_SYNC();
-            }
-        }
-        BK_ACC(1);
-        // 2. the overlap DPs (:451-452) of every slot of this round
-        bk_dp_round();
-        BK_SYNC();
-        if (!S->dual && S->fast) {                      // (uniform) two wavefronts per slot: did the score sweep leave a border cell open?
-            bool any = false;
-            for (int sl = 0; sl < nb; sl++) any = any || S->slot[sl].v1.j_start == BK_NW_NEEDS_DP || S->slot[sl].v2.j_start == BK_NW_NEEDS_DP;
-            if (any) {
-                BK_SYNC();                              // every wavefront has looked at the result words before they change
-                if (BK_TID < nb) {
-                    const int f = (S->slot[BK_TID].v1.j_start == BK_NW_NEEDS_DP || S->slot[BK_TID].v2.j_start == BK_NW_NEEDS_DP) ? 1 : 0;
-                    S->slot[BK_TID].dec = f;
-                    if (f) atomicAdd(&S->dp_redo, 1);
-                }
-                BK_SYNC();
-                bk_dp_redo();
-                BK_SYNC();
-            }
-        }
-        BK_ACC(2);
-        s0 = 0; s1 = ncur;
-        }
-        // 3. retire this visit's slots in order while the predictions hold; the slots of later visits wait for their turn
-        int sl = s0;
-        while (sl < s1) {
-            if (S->status) return;
-            // the reads that change nothing, together -- where there are runs of them: on clean data nearly every read
-            // extends the contig by a base and the attempt only costs its two barriers (same-box A/B on the headline:
-            // 1.82 ms with it always on, 1.70 ms without), so it waits until check_align has lately rejected most reads
-            if (!(C_.flags & BK_F_NO_RUN_RETIRE) && (s1 - sl >= 2 || bk_expect_reject())) {
-                bk_retire_run(sl, s1, grow);
-                const int m = S->tmp0;
-                sl += m; q += m;
-                if (sl >= s1 || S->status) break;
-            }
-            if (!bk_retire_checked(sl, grow)) break;        // the read that extends / replaces the contig (or fails the prediction)
-            sl++; q++;
-        }
-        if (adopt) {
-            BK_SYNC();
-            if (BK_TID == 0) {
-                S->la_adopted += sl - s0;
-                if (sl < s1) S->plan_ok = 0;
-                else { S->plan_r = s1; if (S->plan_r >= S->nb && vt >= S->plan_upto) S->plan_ok = 0; }
-            }
-            BK_SYNC();
-            adopt = false;
-        } else if (sl < s1 && S->plan_ok) { BK_SYNC(); if (BK_TID == 0) S->plan_ok = 0; BK_SYNC(); }      // a prediction failed: what was planned behind it is void
-    }
-}
-
-// ---- check_alt_reads (sv_assembly.py:568-582) + the adds of finalize (:590-592) -------------------------
-BK_COLD void bk_check_alt_reads()
-{
-    BK_ACC(S_->ctx);
-    BkAsmShared *S = S_;
-    const int k = C_.k;
-    const int nalt = S->nalt;
-    if (nalt == 0) return;
-    BK_SYNC();
-    if (BK_TID == 0) S->tmp2 = ++S->stamp_ctr;          // identifies mer_set of this call
-    BK_SYNC();
-    const int fin = S->tmp2;
-    int *tmp = (int *)L_CAND;
-    for (int a = 0; a < nalt; a++) {
-        const int u = (int)C_.altl[a];
-        bk_load_read(u);
-        const int len = S->rlen, np = len - k;
-        // x = get_read_kmers(read) - used_mers - mer_set   (set(self.kmers) holds tuples: removes nothing)
-        BkKey best; best.hi = ~0ull; best.lo = ~0ull; int bestrk = -1; int anyx = 0;
-        for (int x = BK_TID; x < np; x += BK_AT) {
-            BkKey key; uint32_t st = 0; int rk = bk_bytes_kmer(L_RSEQ + x, k, key) ? bk_lookup_state(key, st) : -1;
-            if (rk >= 0 && (st != BK_K_LIVE || C_.kstamp[3 * rk + 1] == fin)) rk = -1;
-            tmp[x] = rk;
-            if (rk >= 0) { anyx = 1; if (C_.kcnt[rk] > 1 && key_lt(key, best)) { best = key; bestrk = rk; } }   // sorted(x) (P2): smallest mer with count > 1
-        }
-        // reduce the minimum key over the block
-        for (int o = 32; o > 0; o >>= 1) {
-            unsigned long long oh = __shfl_xor(best.hi, o), ol = __shfl_xor(best.lo, o); int ork = __shfl_xor(bestrk, o);
-            BkKey ob; ob.hi = oh; ob.lo = ol;
-            if (ork >= 0 && (bestrk < 0 || key_lt(ob, best))) { best = ob; bestrk = ork; }
-        }
-        unsigned long long *red = (unsigned long long *)(tmp + 2 * C_.MAXCAND - 64);   // tail of the scratch: (hi, lo, rk) per wavefront (8 x 3 x 8 B <= 256 B)
-        BK_SYNC();
-        if ((BK_TID & 63) == 0) { int w = BK_TID >> 6; red[3 * w] = best.hi; red[3 * w + 1] = best.lo; red[3 * w + 2] = (unsigned long long)(long long)bestrk; }
-        BK_SYNC();
-        { best.hi = red[0]; best.lo = red[1]; bestrk = (int)(long long)red[2];
-          for (int w = 1; w < BK_AT / 64; w++) { BkKey ob; ob.hi = red[3 * w]; ob.lo = red[3 * w + 1]; int ork = (int)(long long)red[3 * w + 2];
-              if (ork >= 0 && (bestrk < 0 || key_lt(ob, best))) { best = ob; bestrk = ork; } } }
-        BK_SYNC();
-        (void)anyx;
-        if (bestrk >= 0) {
-            for (int x = BK_TID; x < np; x += BK_AT) if (tmp[x] >= 0) C_.kstamp[3 * tmp[x] + 1] = fin;       // mer_set = mer_set | x
-            if (BK_TID == 0) bk_fifo_push(bestrk, u);
-        }
-        BK_SYNC();
-    }
-    BK_ACC(6);
-}
-
-// ---- finalize (sv_assembly.py:584-599) ----------------------------------------------------------------
-__device__ inline void bk_finalize(bool setup)
-{
-    BK_ACC(S_->ctx);
-    BkAsmShared *S = S_;
-    if (setup) bk_kmers_ordered(S->cbase, S->clen, BK_ORD_MID);                 // set_kmers(akmers.smers_set)
-    bk_check_alt_reads();
-    BK_SYNC();
-    if (BK_TID == 0) {
-        if (!S->founder_added) {                                                  // batch_reads[0] = founder, aligned (:383)
-            S->founder_added = 1; int u = S->founder;
-            if (C_.ureads[u] != S->serial) { C_.ureads[u] = S->serial; C_.readl[S->nr++] = (uint32_t)u; }
-        }
-        S->nalt = 0;
-    }
-    BK_SYNC();
-    BK_ACC(10);
-}
-
-// ---- contig.grow (sv_assembly.py:616-649) --------------------------------------------------------------
-__device__ __forceinline__ void bk_grow()
-{
-    BK_ACC(S_->ctx); BK_CTX(15);
-    BkAsmShared *S = S_;
-    if (!S->setup) bk_kmers_ordered(S->cbase, S->clen, BK_ORD_MID);
-    for (;;) {
-        if (S->status) return;
-        // refresh_kmers :601-602 -> snapshot list
-        const int nk = S->nk, k0 = S->kscan;
-        uint32_t T;
-        // Every k-mer of a snapshot is in checked_kmers when its visits are over, and the list only grows at its end (a
-        // replacement, set_kmers, starts it anew): the next snapshot can only hold what was appended since.  With sequencing
-        // noise that is a handful of k-mers after every extension, a snapshot per round -- one wavefront takes them, the
-        // candidate-less ones marked in the same pass (below), one barrier instead of seven.
-        const bool small = nk - k0 <= 64;
-        if (small) {
-            if ((BK_TID >> 6) == 0) {
-                const int idx = k0 + BK_TID;
-                uint32_t en = idx < nk ? C_.klist[idx] : 0u;
-                const bool unchecked = idx < nk && C_.kstamp[3 * (en & 0x7FFFFFFFu)] != S->serial;
-                const unsigned long long bm = __ballot(unchecked);
-                if (unchecked) {
-                    const int rank = (int)(en & 0x3FFFFFFFu);
-                    const uint32_t pb = C_.poff[rank], pe = C_.poff[rank + 1];
-                    bool has = pe - pb > 16u;
-                    for (uint32_t i = pb; !has && i < pe; i++) { const uint32_t u = C_.post[i] >> 10; has = !(C_.ufl[u] & BK_R_DELETED) && C_.ubuf[u] != S->serial; }
-                    if (!has) { C_.kstamp[3 * rank] = S->serial; en |= 0x40000000u; }
-                    C_.nklist[__popcll(bm & ((1ull << BK_TID) - 1ull))] = en;
-                }
-                if (BK_TID == 0) {
-#ifdef BK_PHASE_STAMPS
-                    S->acc[20] += 1; S->acc[22] += (unsigned long long)(nk - k0);
-#endif
-                    S->tmp0 = __popcll(bm); S->kscan = nk;
-                    if (bm) {
-                        if (!S->founder_added) { S->founder_added = 1; const int fu = S->founder; if (C_.ureads[fu] != S->serial) { C_.ureads[fu] = S->serial; C_.readl[S->nr++] = (uint32_t)fu; } }
-                        if (S->plan_kind == 0) S->plan_ok = 0;
-                    }
-                }
-            }
-            BK_SYNC();
-            T = (uint32_t)S->tmp0;
-            BK_ACC(13);
-            if (T == 0) break;
-        } else {
-        const int chunk = (nk + BK_AT - 1) / BK_AT, b = BK_TID * chunk, e = min(nk, b + chunk);
-        uint32_t cnt = 0;
-        if (chunk == 1) {                                   // the usual case: an entry per thread, looked at once
-            uint32_t en = 0;
-            if (b < e) { en = C_.klist[b]; cnt = C_.kstamp[3 * (en & 0x7FFFFFFFu)] != S->serial; }
-            const uint32_t pre = bk_scan256(cnt, S->scan, &T);
-            if (cnt) C_.nklist[pre] = en;
-        } else {
-        for (int t = b; t < e; t++) cnt += C_.kstamp[3 * (C_.klist[t] & 0x7FFFFFFFu)] != S->serial;
-        uint32_t pre = bk_scan256(cnt, S->scan, &T);
-        for (int t = b; t < e; t++) { uint32_t en = C_.klist[t]; if (C_.kstamp[3 * (en & 0x7FFFFFFFu)] != S->serial) C_.nklist[pre++] = en; }
-        }
-#ifdef BK_PHASE_STAMPS
-        if (BK_TID == 0) { S->acc[21] += 1; S->acc[23] += (unsigned long long)nk; }
-#endif
-        if (BK_TID == 0) S->kscan = nk;
-        BK_SYNC();
-        BK_ACC(13);
-        if (T == 0) break;
-        // Visits without any candidate read.  Within one contig the candidate set of a k-mer only shrinks (reads get
-        // buffered or deleted, never the reverse), so a k-mer whose short posting list holds no eligible read now has
-        // none when its turn comes, and such a visit does nothing but mark the k-mer checked and, AT ITS TURN (the
-        // used set is read by check_alt_reads of the visits before it), used (get_mer_reads :604-614 returns []).
-        // With sequencing noise that is the majority of all visits: they are found here for the whole snapshot at once
-        // (bit 30 of the entry), and the loop below retires whole runs of them with one wavefront.
-        // The founder read joins the read list first, as the first finalize would do (:383).
-        if (BK_TID == 0 && !S->founder_added) {
-            S->founder_added = 1; const int fu = S->founder;
-            if (C_.ureads[fu] != S->serial) { C_.ureads[fu] = S->serial; C_.readl[S->nr++] = (uint32_t)fu; }
-        }
-        for (uint32_t t = BK_TID; t < T; t += BK_AT) {
-            const uint32_t en = C_.nklist[t]; int rank = (int)(en & 0x3FFFFFFFu);
-            if (!BK_CHK((uint32_t)rank < C_.M, 7, ((unsigned long long)t << 32) | en)) rank = 0;
-            const uint32_t pb = C_.poff[rank], pe = C_.poff[rank + 1];
-            bool has = pe - pb > 16u;                                             // long lists take the ordinary visit
-            for (uint32_t i = pb; !has && i < pe; i++) { const uint32_t u = C_.post[i] >> 10; has = !(C_.ufl[u] & BK_R_DELETED) && C_.ubuf[u] != S->serial; }
-            if (!has) { C_.kstamp[3 * rank] = S->serial; C_.nklist[t] = en | 0x40000000u; }       // checked_kmers is only read by the next snapshot
-        }
-        BK_SYNC();
-        if (BK_TID == 0 && S->plan_kind == 0) S->plan_ok = 0;                      // a plan of visits refers to one snapshot (and one contig)
-        BK_SYNC();
-        }
-        uint32_t t = 0, en_next = C_.nklist[0];
-        while (t < T) {
-            if (S->status) return;
-            const uint32_t en = en_next; int rank = (int)(en & 0x3FFFFFFFu); const bool rev = (en >> 31) != 0;
-            if (!BK_CHK((uint32_t)rank < C_.M, 6, ((unsigned long long)t << 32) | en)) { S->status = S->status ? S->status : BK_ST_UNSPLIT; BK_SYNC(); return; }
-            if (en & 0x40000000u) {
-                // a run of candidate-less visits, in order: used_mers.add(mer) for each k-mer not yet in it
-                if ((BK_TID >> 6) == 0) {
-                    const uint32_t idx = t + BK_TID;
-                    const uint32_t e2 = idx < T ? C_.nklist[idx] : 0u;
-                    const unsigned long long bm = __ballot((e2 & 0x40000000u) != 0);
-                    const int run = ~bm ? __ffsll((long long)~bm) - 1 : 64;                  // entries t .. t+run-1 are candidate-less
-                    const bool in_run = BK_TID < run;
-                    const int rk = (int)(e2 & 0x3FFFFFFFu);
-                    bool ap = in_run && C_.kstate[in_run ? rk : 0] == BK_K_LIVE;
-                    for (int j = 0; j < run; j++) { const int rj = __builtin_amdgcn_readlane(rk, j); if (j < BK_TID && rj == rk) ap = false; }   // listed twice: once
-                    const unsigned long long am = __ballot(ap);
-                    if (ap) { C_.kstate[rk] = BK_K_USED; C_.usedl[S->nused + __popcll(am & ((1ull << BK_TID) - 1ull))] = (uint32_t)rk; }
-                    if (BK_TID == 0) { S->nused += __popcll(am); S->tmp1 = run; }
-                }
-                BK_SYNC();
-                t += (uint32_t)S->tmp1;
-                if (t < T) en_next = C_.nklist[t];
-                BK_SYNC();
-                continue;
-            }
-            const int vt = (int)t;
-            t++;
-            if (t < T) en_next = C_.nklist[t];                                     // fetched a whole visit ahead of its use
-            bk_find_reads(rank, rev, true);                                    // get_mer_reads :604-614
-            if (BK_TID == 0) bk_add_used_mer(rank);
-            BK_SYNC();
-            // position of this k-mer in the contig (prediction seed); -1 disables the look-ahead
-            if ((BK_TID >> 6) == 0) {
-                int pc = -1;
-                // (a single candidate needs no prediction unless the round may go on into the following visits)
-                if (!bk_expect_reject() && (S->ncand >= 2 || (S->ncand == 1 && S->la_pause == 0 && !(C_.flags & BK_F_NO_XVISIT)))) { BkKey key; key.hi = C_.khi[rank]; key.lo = C_.klo[rank]; pc = bk_find_kmer_wave(L_CSEQ + S->cbase, S->clen, key, C_.k); }
-                if (BK_TID == 0) S->pc = pc;
-            }
-            BK_SYNC();
-            BK_ACC(14);
-            bk_run_candidates(rank, 0, S->ncand, true, vt, (int)T);
-            bk_finalize(false);
-            if (BK_TID == 0) C_.kstamp[3 * rank] = S->serial;                       // checked_kmers.append(mer): read by the next snapshot only
-        }
-        BK_SYNC();                                                                  // the stamps above are visible before the next snapshot reads them
-    }
-    BK_ACC(15); BK_CTX(0);
-}
-
-// ---- init_assembly keeps a contig iff support >= rc_thresh and len > read_len (sv_assembly.py:53-59);
-//      set_kmer_locs (:434-438) and the record the host reads back ------------------------------------------
-BK_COLD void bk_emit_contig()
-{
-    BK_ACC(S_->ctx);
-    BkAsmShared *S = S_;
-    const int total = bk_total_reads();
-    if (total < C_.rc_thresh || S->clen <= (int)C_.max_len) return;
-    const int k = C_.k, len = S->clen, nlen = S->nlen, nk = S->nk, nr = S->nr;
-    const uint32_t o_seq = (uint32_t)sizeof(BkContigRec), o_io = (uint32_t)bk_align_up(o_seq + len, 8), o_ot = o_io + 4u * nlen,
-                   o_kl = o_ot + 4u * nlen, o_km = (uint32_t)bk_align_up(o_kl + 4u * len, 8), o_rd = o_km + 16u * nk, size = (uint32_t)bk_align_up(o_rd + 4u * nr, 8);
-    BK_SYNC();
-    if (BK_TID == 0) {
-        uint64_t need = bk_align_up(size, 256);
-        uint64_t off = atomicAdd(C_.out_top, (unsigned long long)need);
-        if (off + need > C_.out_cap) { off = 0; S->status = BK_ST_OUT; }
-        S->scan[8] = (uint32_t)off; S->scan[9] = (uint32_t)(off >> 32);
-    }
-    BK_SYNC();
-    const uint64_t off = ((uint64_t)S->scan[9] << 32) | S->scan[8];
-    if (off == 0) return;                                 // offset 0 is reserved (out_top starts at 256)
-    uint8_t *rec = C_.out + off;
-    BkContigRec *h = (BkContigRec *)rec;
-    char *oseq = (char *)(rec + o_seq); int32_t *oio = (int32_t *)(rec + o_io), *oot = (int32_t *)(rec + o_ot), *okl = (int32_t *)(rec + o_kl);
-    uint64_t *okm = (uint64_t *)(rec + o_km); uint32_t *ord_ = (uint32_t *)(rec + o_rd);
-    const uint8_t *cs = L_CSEQ + S->cbase;
-    const int32_t *io = bk_cnt_io(S->cbuf) + S->nbase, *ot = bk_cnt_ot(S->cbuf) + S->nbase;
-    for (int t = BK_TID; t < len; t += BK_AT) { oseq[t] = "ACGTN"[cs[t]]; okl[t] = 0; }
-    for (int t = BK_TID; t < nlen; t += BK_AT) { oio[t] = io[t]; oot[t] = ot[t]; }
-    for (int t = BK_TID; t < nk; t += BK_AT) { uint32_t rk = C_.klist[t] & 0x7FFFFFFFu; if (!BK_CHK(rk < C_.M, 4, ((unsigned long long)t << 32) | C_.klist[t])) rk = 0; okm[2 * t] = C_.klo[rk]; okm[2 * t + 1] = C_.khi[rk]; }
-    for (int t = BK_TID; t < nr; t += BK_AT) ord_[t] = C_.urep[C_.readl[t]];
-    // first occurrence of every sample k-mer in the contig (str.find over all len-k+1 positions)
-    // (split regions: the stamps of other units' k-mers are left alone -- only the contig's own k-mers are read back below, and
-    // those all belong to components this unit holds)
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.own || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_mine(C_.kroot[rk])))) atomicMin(&C_.kstamp[3 * rk + 2], x); }
-    BK_SYNC();
-    for (int t = BK_TID; t < nk; t += BK_AT) {
-        if (!BK_CHK((C_.klist[t] & 0x7FFFFFFFu) < C_.M, 5, C_.klist[t])) continue;
-        int pos = C_.kstamp[3 * (C_.klist[t] & 0x7FFFFFFFu) + 2];
-        if (pos == 0x7FFFFFFF) continue;                 // find() == -1: the python slice [-1:k-1] is empty for len >= k
-        for (int q = pos; q < min(pos + k, len); q++) atomicAdd(&okl[q], 1);
-    }
-    BK_SYNC();
-    for (int x = BK_TID; x + k <= len; x += BK_AT) { BkKey key; int rk = bk_bytes_kmer(cs + x, k, key) ? bk_lookup(key) : -1; if (rk >= 0 && (!C_.own || (C_.kroot[rk] != BK_EMPTY32 && bk_acc_mine(C_.kroot[rk])))) C_.kstamp[3 * rk + 2] = 0x7FFFFFFF; }
-    if (BK_TID == 0) {
-        h->root = S->ccomp; h->pass = C_.want;
-        h->next = 0; h->hits_off = 0; h->seq_len = len; h->counts_len = nlen; h->n_kmers = nk; h->n_reads = nr; h->total_reads = total; h->n_hits = 0;
-        h->o_seq = o_seq; h->o_io = o_io; h->o_ot = o_ot; h->o_klocs = o_kl; h->o_kmers = o_km; h->o_reads = o_rd; h->n_sec = 0; h->size = size;
-        if (C_.split) {       // the units of a region emit side by side: (order key, record) pairs, ordered and linked by bk_link_kernel
-            const uint32_t at = atomicAdd(&C_.wk->n_cidx, 1u);
-            if (at < C_.wk->cidx_cap) { C_.cidx_key[at] = ((unsigned long long)(uint32_t)S->seed_rank << 20) | (unsigned long long)(uint32_t)min(S->emit_seq, 0xFFFFF); C_.cidx_key[C_.wk->cidx_cap + at] = off; }
-            S->emit_seq++;
-        } else {
-            if (C_.wk->o_first_contig == 0) C_.wk->o_first_contig = off; else ((BkContigRec *)(C_.out + C_.wk->o_last_contig))->next = off;
-            C_.wk->o_last_contig = off;
-        }
-        S->n_contigs++;
-        const unsigned long long ci = atomicAdd(C_.n_clist, 1ull);              // work list of the realign stage (one workgroup per contig)
-        if (ci < C_.clist_cap) C_.clist[ci] = off | ((unsigned long long)C_.region << 40);
-    }
-    BK_SYNC();
-    BK_ACC(7);
-}
-
-// ---- setup_contigs (sv_assembly.py:11-26) -----------------------------------------------------------------
-__device__ inline void bk_setup_contigs(int rank)
-{
-    BK_ACC(S_->ctx); BK_CTX(8);
-    BkAsmShared *S = S_;
-    bk_find_reads(rank, false, false);                                         // used_reads = set()
-    if (BK_TID == 0) bk_add_used_mer(rank);
-    BK_SYNC();
-    const int n = S->ncand;
-    if (n == 0 || S->status) return;
-    // the candidate list must survive the check_read calls below: candu is not touched by them
-    const int u0 = (int)(L_CANDU[0] & 0x3FFFFFu);
-    const bool in_fifo = C_.ufound[u0] < 0 && !(C_.ufl[u0] & BK_R_USED);            // buff.add_contig :337-340
-    BK_SYNC();
-    bk_contig_new(rank, u0, in_fifo);
-    if (BK_TID == 0 && in_fifo) C_.ufl[u0] |= BK_R_USED;
-    BK_SYNC();
-    if (BK_TID == 0) S->pc = (int)(L_CANDU[0] >> 22);      // the contig IS the first read: the k-mer sits where it sits in that read
-    BK_SYNC();
-    bk_run_candidates(rank, 1, n, false, -1, 0);
-    bk_finalize(true);
-    if (in_fifo) { bk_grow(); if (!S->status) bk_emit_contig(); }                // it is the FIFO head (:50-52)
-    BK_ACC(8); BK_CTX(0);
-}
-
-// The seed ranks of this unit's components, ascending: the seed scan and the look-ahead into the next seeds walk this list
-// (a sixteenth of the ranks; looking each rank's owner up costs two dependent loads, and the owner words must be read past
-// the caches once other units change them).  fresh: read the owner words with device-scope loads (after this unit lost a
-// component to unit 0; otherwise the words are as the labelling / the resolve kernel wrote them).  A wavefront per block of
-// ranks: count, prefix over the wavefronts, write in place.
-BK_COLD void bk_build_myseeds(int fresh)
-{
-    BkAsmShared *S = S_;
-    const int wv = BK_TID >> 6, lane = BK_TID & 63, M2 = (int)C_.M2;
-    const int B = (((M2 + BK_WAVES - 1) / BK_WAVES) + 63) / 64 * 64, lo = wv * B, hi = min(M2, lo + B);
-    auto mine = [&](int j) -> bool {
-        if (j >= hi || C_.kstate[j] == BK_K_REMOVED) return false;
-        const uint32_t root = C_.kroot[j];
-        if (root == BK_EMPTY32) return false;
-        const uint32_t ci = fresh ? __hip_atomic_load(&C_.cinfo[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : C_.cinfo[root];
-        return (ci & (0xFFFFu | BK_CI_ABORT)) == C_.want;
-    };
-    int cnt = 0;
-    for (int b = lo; b < hi; b += 64) cnt += __popcll(__ballot(mine(b + lane)));
-    BK_SYNC();
-    if (lane == 0) S->scan[wv] = (uint32_t)cnt;
-    BK_SYNC();
-    int base = 0, tot = 0;
-    for (int i = 0; i < BK_WAVES; i++) { const int t = (int)S->scan[i]; if (i < wv) base += t; tot += t; }
-    BK_SYNC();
-    int off = base;
-    const int end = base + cnt;
-    for (int b = lo; b < hi; b += 64) {
-        const bool m = mine(b + lane);
-        const unsigned long long bal = __ballot(m);
-        const int at = off + __popcll(bal & ((1ull << lane) - 1ull));
-        if (m && at < end) C_.myseeds[at] = b + lane;
-        off += __popcll(bal);
-    }
-    for (int i = min(off, end) + lane; i < end; i += 64) C_.myseeds[i] = -1;          // (owner words changed between the two sweeps: fewer than counted)
-    __threadfence_block();
-    BK_SYNC();
-    if (BK_TID == 0) { C_.n_my = tot; S->head = 0; }
-    BK_SYNC();
-}
-
-// unit 0, after the serial prefix (the seeds with a count >= BK_SPLIT_HI, run alone and in order): the connected components of what
-// is LEFT of the read / k-mer graph -- the k-mers that are still live -- dealt to the units (bk_comp.hip.h).  The read flags of
-// this moment are kept: a component that runs again starts from here.
-BK_COLD void bk_label_live()
-{
-    BkAsmShared *S = S_;
-    uint32_t *rroot = (uint32_t *)((uint8_t *)C_.cinfo - bk_align_up((uint64_t)C_.U * 4, 256));
-    uint32_t *kroot = const_cast<uint32_t *>(C_.kroot), *cinfo = C_.cinfo, *csz = C_.readl;      // readl: U + 1 words, free between two contigs
-    uint8_t *ufl0 = BK_UFL0;
-    const uint32_t U = C_.U, M = C_.M, M2 = C_.M2;
-    BK_SYNC();
-    if (BK_TID == 0) { const int now = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull); C_.wk->dbg_us[0] = (uint32_t)((now - S->t0) & 0x7FFFFFFF) / 100u; S->t0 = now; }
-    for (uint32_t u = BK_TID; u < U; u += BK_AT) { rroot[u] = u; csz[u] = 0; ufl0[u] = C_.ufl[u]; }
-    __threadfence(); BK_SYNC();
-    for (uint32_t j = BK_TID; j < M; j += BK_AT) {
-        if (C_.kstate[j] != BK_K_LIVE) continue;
-        const uint32_t b = C_.poff[j], e = C_.poff[j + 1];
-        uint32_t first = BK_EMPTY32, last = BK_EMPTY32;
-        for (uint32_t i = b; i < e; i++) {
-            const uint32_t v = C_.post[i] >> 10;
-            if (v == last) continue;                 // (deleted reads stay nodes: every live k-mer then has a component, and only one unit ever touches its state)
-            if (first == BK_EMPTY32) first = v; else bk_uf_union(rroot, first, v);
-            last = v;
-        }
-    }
-    __threadfence(); BK_SYNC();
-    for (uint32_t u = BK_TID; u < U; u += BK_AT) atomicMin(&rroot[u], bk_uf_find(rroot, u));
-    __threadfence(); BK_SYNC();
-    uint32_t seeds = 0;
-    for (uint32_t j = BK_TID; j < M; j += BK_AT) {
-        uint32_t r = BK_EMPTY32;
-        if (C_.kstate[j] == BK_K_LIVE && C_.poff[j + 1] > C_.poff[j]) r = bk_ld_agent(&rroot[C_.post[C_.poff[j]] >> 10]);
-        kroot[j] = r;
-        if (j < M2 && r != BK_EMPTY32 && C_.kcnt[j] >= 2) { atomicAdd(&csz[r], 1u); seeds++; }
-    }
-    uint32_t total;
-    (void)bk_scan256(seeds, S->scan, &total);
-    __threadfence(); BK_SYNC();
-    int big = 0;
-    for (uint32_t u = BK_TID; u < U; u += BK_AT) big = max(big, (int)bk_ld_agent(&csz[u]));
-    big = bk_max256(big, S->scan);
-    // one component with most of the seeds (the graph has percolated: 1 % noise and beyond): everything stays with unit 0
-    const bool deal = 10ull * (unsigned long long)big <= 7ull * total || (C_.flags & BK_F_SPLIT_ALWAYS);
-    for (uint32_t u = BK_TID; u < U; u += BK_AT) {
-        uint32_t ci = BK_CI_NOUNIT;
-        if (bk_ld_agent(&rroot[u]) == u && bk_ld_agent(&csz[u])) ci = (deal ? (uint32_t)(mix64(0x9E3779B97F4A7C15ull ^ u) % (uint32_t)C_.split) : 0u) | BK_CI_ACTIVE;
-        cinfo[u] = ci;
-    }
-    __threadfence(); BK_SYNC();
-    // Dealt by size, largest first to the unit with the least so far (a unit's time follows its seed k-mers; by a hash of the root
-    // the fullest unit had 1.8x the mean).  The components with seeds are listed and ordered in the candidate scratch (LDS);
-    // more of them than fit there keep the hash.
-    if (deal) {
-        unsigned long long *L = L_CAND;
-        if (BK_TID == 0) S->tmp0 = 0;
-        BK_SYNC();
-        for (uint32_t u = BK_TID; u < U; u += BK_AT) {
-            const uint32_t c = bk_ld_agent(&csz[u]);
-            if (bk_ld_agent(&rroot[u]) != u || !c) continue;
-            const int at = atomicAdd(&S->tmp0, 1);
-            if (at < (int)C_.MAXCAND) L[at] = ((unsigned long long)(0xFFFFFFFFu - c) << 32) | u;          // ascending key = size descending, then root ascending: deterministic
-        }
-        BK_SYNC();
-        const int n = S->tmp0;
-        if (n <= (int)C_.MAXCAND) {
-            int npad = 1; while (npad < n) npad <<= 1;
-            for (int i = n + BK_TID; i < npad; i += BK_AT) L[i] = ~0ull;
-            BK_SYNC();
-            for (int sz = 2; sz <= npad; sz <<= 1)
-                for (int st = sz >> 1; st > 0; st >>= 1) {
-                    for (int i = BK_TID; i < npad / 2; i += BK_AT) {
-                        const int lo = (i / st) * (st * 2) + (i % st), hi = lo + st;
-                        const bool up = ((lo & sz) == 0);
-                        const unsigned long long a = L[lo], bb = L[hi];
-                        if ((a > bb) == up) { L[lo] = bb; L[hi] = a; }
-                    }
-                    BK_SYNC();
-                }
-            if (BK_TID == 0) {
-                // (the units' loads in LDS -- the candidate list is free between two seeds.  NOT a local array: indexed at run time it
-                //  lives in scratch memory, and that made this out-of-line function fault at random, 3 runs in 20 of a 32-region
-                //  batch -- the second lesson of this kind after the out-of-line return values of round 2)
-                uint32_t *load = L_CANDU;
-                const int G_ = (int)C_.split;                                                      // units of this region (bk_sched_kernel: 2 .. BK_SPLIT_G)
-                for (int g = 0; g < G_; g++) load[g] = 0;
-                for (int i = 0; i < n; i++) {
-                    const uint32_t root = (uint32_t)L[i], c = 0xFFFFFFFFu - (uint32_t)(L[i] >> 32);
-                    int best = 0;
-                    for (int g = 1; g < G_; g++) if (load[g] < load[best]) best = g;
-                    load[best] += c + 4u;                                                             // (+ what an iteration costs whatever its size)
-                    cinfo[root] = (uint32_t)best | BK_CI_ACTIVE;
-                }
-            }
-            __threadfence(); BK_SYNC();
-        }
-    }
-    if (BK_TID == 0) {
-        C_.wk->serial_base = (uint32_t)S->serial_ctr; C_.wk->stamp_base = (uint32_t)S->stamp_ctr;
-        __threadfence();
-        __hip_atomic_store(&C_.wk->phase, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        C_.own = 1;
-        { const int now = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull); C_.wk->dbg_us[1] = (uint32_t)((now - S->t0) & 0x7FFFFFFF) / 100u; S->t0 = now; }
-    }
-    BK_SYNC();
-    bk_build_myseeds(0);
-    if (BK_TID == 0) { const int now = (int)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull); C_.wk->dbg_us[2] = (uint32_t)((now - S->t0) & 0x7FFFFFFF) / 100u; S->t0 = now; }
-}
+#include "bk_asm_kmers.hip.h"
+#include "bk_asm_apply.hip.h"
+#include "bk_asm_plan.hip.h"
+#include "bk_asm_round.hip.h"
+#include "bk_asm_grow.hip.h"
+#include "bk_asm_units.hip.h"
+#undef BK_SRC_ID
+#define BK_SRC_ID 5
 
 __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, const int unit)
 {

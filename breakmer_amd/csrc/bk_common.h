@@ -32,6 +32,9 @@
 //                     the run-time seed bk_jitter_seed: BK_JITTER_SEED in the environment of a -DBK_DIAG build) sleeps for a
 //                     few microseconds, so a wavefront that is "late after the barrier" happens at every site at any load.
 // The product build defines neither: BK_SYNC() is __syncthreads().
+// Source file ids of the barrier sites (the check build reports "file <id> line <n>"): 0 bk_common.h, 1 bk_kmer.hip.h, 2 bk_sched.hip.h,
+// 3 bk_nw.hip.h, 4 bk_comp.hip.h, 5 bk_asm.hip.h, 6 bk_sw.hip.h, 7 bk_asm_kmers, 8 bk_asm_apply, 9 bk_asm_plan, 10 bk_asm_round,
+// 11 bk_asm_grow, 12 bk_asm_units (.hip.h).
 #ifndef BK_SRC_ID
 #define BK_SRC_ID 0
 #endif

@@ -1150,7 +1150,7 @@ class runner(object):                                               # sv_process
                 owner[n] = rk
                 load[rk] += max(1, cost[n])
             mine = [n for n in names if owner[n] == self.rank]
-            self.assigned_cost = load[self.rank]
+            self.assigned_cost, self.assigned_targets, self.rank_loads = load[self.rank], list(mine), list(load)
             self.logger.info('rank %d of %d: %d of %d targets, estimated cost %d (all ranks: %s)' % (self.rank, self.world, len(mine), len(names), load[self.rank], load))
         else:
             mine = list(names)

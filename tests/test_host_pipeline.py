@@ -112,6 +112,22 @@ def _rank_main(rank, world, port, base, q, mode):
     import pathlib
     d = pathlib.Path(base) / ("rank%d" % rank)
     d.mkdir()
+    if mode in ("w8", "w8fail"):                          # 4,096 plain targets of mixed cost on eight ranks (configs[2]: 4,096 regions sharded region-per-GPU over 8)
+        cfg, data, script = _many_inputs(d)
+
+        class FailingScripted(ScriptedEngine):
+            def run(self, stages, sync=True):
+                raise RuntimeError("injected device failure")
+        cls = FailingScripted if (mode == "w8fail" and rank == 5) else ScriptedEngine
+        r = sp.runner(cfg, region_data=data, engine_factory=lambda prm: cls(script, []), rank=rank, world=world, collate=collate_results, status_exchange=exchange_status)
+        try:
+            rows = r.run()
+            import hashlib
+            q.put((rank, "ok", hashlib.sha256(repr(rows).encode()).hexdigest(), len(rows), (r.assigned_cost, hashlib.sha256("\n".join(r.assigned_targets).encode()).hexdigest(), len(r.assigned_targets), tuple(r.rank_loads))))
+        except Exception as ex:
+            q.put((rank, "raised", "%s: %s" % (type(ex).__name__, ex), None, getattr(r, "assigned_cost", None)))
+        td.destroy_process_group()
+        return
     if mode == "lane":                                   # plain targets with packed reads through a scripted engine: the batch lane on every rank
         cfg, data, script = _lane_inputs(d)
         r = sp.runner(cfg, region_data=data, engine_factory=lambda prm: ScriptedEngine(script, []), rank=rank, world=world, collate=collate_results, status_exchange=exchange_status)
@@ -154,17 +170,38 @@ def _lane_inputs(d):
     return cfg, data, script
 
 
-def _run_ranks(tmp_path, mode, tag):
+def _many_inputs(d, n=4096):
+    """4,096 plain targets (packed reads, no files) of a configs[3]-like cost mix -- sixteen base regions with 30 to 480 reads, cycled under
+    4,096 target names in a scrambled order -- and the script of a ScriptedEngine for them (rows per window)"""
+    from breakmer_amd import hip_backend as hb
+    regs = [synth.make_region(200 + i, sv_type=("del", "ins", "inv", "trl")[i % 4], depth=(3, 6, 12, 24, 48)[i % 5], W=500, L=50) for i in range(16)]
+    packs = [hb.pack_reads(r.reads, r.read_lens) for r in regs]
+    bed, genes, data, script = [], ["header"], {}, {}
+    for j, r in enumerate(regs):
+        script[r.window_str.encode()] = ([["T", "%s:%d" % (r.chrom, r.start + 7 * j), "D%d" % (10 + j), "0", "+", "0", "indel", "7", "30", "0", "40", "c%d" % j, "ACGT"]] * (j % 3), j % 3 + 1, None)
+    for t in range(n):
+        j = (t * 7 + t // 16) % 16
+        r, name = regs[j], "T%04d" % t
+        bed.append("\t".join([r.chrom, str(r.start + t), str(r.end + t), name, "exon"]))
+        genes.append("\t".join(["0", name, "chr" + r.chrom, "+", str(r.start + t), str(r.end + t)] + ["x"] * 6 + [name]))
+        data[name] = sp.RegionData(r.read_ids, None, None, None, r.window_str, [], r.disc_reads, read_codes=r.reads, read_lens=r.read_lens, read_packed=packs[j])
+    (d / "t.bed").write_text("\n".join(bed) + "\n")
+    (d / "g.txt").write_text("\n".join(genes) + "\n")
+    cfg = {"analysis_name": "many", "targets_bed_file": str(d / "t.bed"), "gene_annotation_file": str(d / "g.txt"), "kmer_size": "31", "keep_repeat_regions": True, "batch_regions": 256}
+    return cfg, data, script
+
+
+def _run_ranks(tmp_path, mode, tag, world=2):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() + hash(tag)) % 2000
     base = tmp_path / tag
     base.mkdir()
-    procs = [ctx.Process(target=_rank_main, args=(rk, 2, port, str(base), q, mode)) for rk in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(rk, world, port, str(base), q, mode)) for rk in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=180) for _ in procs]
+    got = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(60)
         assert not p.is_alive()
@@ -218,6 +255,36 @@ def test_two_rank_batch_lane_gloo(tmp_path):
     for rank, state, rows, summary, _cost in got:
         assert state == "ok" and rows == want and summary == sorted(one.summary.items()), rank
     assert sorted(g[4] for g in got) != [0, 0] and sum(g[4] for g in got) == sum(len(d_.read_ids) for d_ in data.values())
+
+
+def test_eight_ranks_4096_targets_gloo(tmp_path):
+    """configs[2]'s shape on CPU: 4,096 targets of mixed cost dealt over EIGHT ranks (gloo), batches of 256 through the batch lane.
+    Every rank computes the same assignment without communication (each reports the loads of all eight: identical tuples; the eight
+    target lists are disjoint and cover the 4,096); the load imbalance by cost is below 5 %; every rank ends with the rows of the
+    single-process run; and with one failed rank (rank 5's engine raises) ALL EIGHT raise, the healthy ones naming it, instead of
+    waiting in the collation.  No 8-GPU node was available to any round: on hardware this path is unmeasured."""
+    import hashlib
+    single = tmp_path / "single"
+    single.mkdir()
+    cfg, data, script = _many_inputs(single)
+    one = sp.runner(cfg, region_data=data, engine_factory=lambda prm: ScriptedEngine(script, []))
+    want = one.run()
+    assert len(want) == sum(len(script[d_.window.encode() if isinstance(d_.window, str) else d_.window][0]) for d_ in data.values()) and len(want) > 3000
+    got = _run_ranks(tmp_path, "w8", "w8", world=8)
+    assert [g[1] for g in got] == ["ok"] * 8, got
+    for rank, _state, digest, nrows, _info in got:
+        assert nrows == len(want) and digest == hashlib.sha256(repr(want).encode()).hexdigest(), rank
+    loads = {g[4][3] for g in got}
+    assert len(loads) == 1                                              # the same assignment on every rank
+    loads = list(loads)[0]
+    total = sum(len(d_.read_ids) for d_ in data.values())
+    assert sum(loads) == total and [g[4][0] for g in got] == list(loads)
+    assert max(loads) <= 1.05 * (total / 8.0), loads
+    assert sum(g[4][2] for g in got) == 4096 and len({g[4][1] for g in got}) == 8      # eight different lists that add up to all targets
+    got = _run_ranks(tmp_path, "w8fail", "w8fail", world=8)
+    assert [g[1] for g in got] == ["raised"] * 8, got
+    for rank, _state, text, _n, _c in got:
+        assert "injected device failure" in text and (rank == 5 or "rank 5" in text), (rank, text)
 
 
 def make_sam_inputs(tmp_path, rid=3, sv="del", size=120, n_pairs=400):

@@ -30,6 +30,45 @@ if st:
     for r in rows:
         if r["Name"].startswith("bk_"):
             print("stats", r["Name"], "calls", r["Calls"], "avg ms %.3f" % (float(r["AverageNs"]) / 1e6))
+    # average launch duration of every kernel of the library in THIS profile run: quoted by the bench line (roofline.kernel_ms_profiled), so that
+    # its roofline fraction can be recomputed from tracked files alone
+    kj = {r["Name"] + "_avg_ms": round(float(r["AverageNs"]) / 1e6, 4) for r in rows if r["Name"].startswith("bk_")}
+    kj.update({r["Name"] + "_calls": int(r["Calls"]) for r in rows if r["Name"].startswith("bk_")})
+    kj["kernel_ms_source"] = "profiles/%s/kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py --cpu-sample 0 --other-configs 0`, tools/profile_round.sh %s)" % (tag, tag)
+    json.dump(kj, open(os.path.join(root, "profiles", "kernel_ms.json"), "w"), indent=1)
+# ---- overlap of the batches in flight, from the kernel trace of the same run: per window of 100 assembler launches of the timed loop -- the span
+#      (first start .. last end), the summed durations per kernel, the time during which at least one kernel of the library ran (union-busy) and how
+#      many launches were resident on average.  This is what reconciles "2.2 ms per assembler launch" with "0.8 ms per step": launches overlap.
+tr = one("stats/**/*_kernel_trace.csv")
+if tr:
+    ev = []
+    for r in csv.DictReader(open(tr)):
+        if r["Kernel_Name"] in KERNELS:
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    ev.sort()
+    main = "bk_asm_kernel_w4" if sum(1 for e in ev if e[2] == "bk_asm_kernel_w4") >= sum(1 for e in ev if e[2] == "bk_asm_kernel") else "bk_asm_kernel"
+    idx = [i for i, e in enumerate(ev) if e[2] == main]
+    with open(os.path.join(dst, "overlap_summary.csv"), "w") as f:
+        f.write("window,first_launch,launches_of_%s,span_ms,span_ms_per_launch,union_busy_ms,busy_frac,sum_ms_%s,resident_launches_avg\n" % (main, ",sum_ms_".join(KERNELS)))
+        W = 100
+        for w0 in range(0, max(0, len(idx) - W + 1), W):
+            a, b = idx[w0], idx[w0 + W - 1]
+            t0, t1 = ev[a][0], max(e[1] for e in ev[a:b + 1])
+            win = [e for e in ev if e[0] >= t0 and e[0] <= ev[b][0]]
+            sums = {k: 0 for k in KERNELS}
+            for s_, e_, k in win:
+                sums[k] += e_ - s_
+            busy, cur_s, cur_e = 0, None, None
+            for s_, e_, _k in win:
+                if cur_e is None or s_ > cur_e:
+                    busy += (cur_e - cur_s) if cur_e is not None else 0
+                    cur_s, cur_e = s_, e_
+                else:
+                    cur_e = max(cur_e, e_)
+            busy += (cur_e - cur_s) if cur_e is not None else 0
+            span = t1 - t0
+            f.write("%d,%d,%d,%.3f,%.4f,%.3f,%.4f,%s,%.2f\n" % (w0 // W, w0, W, span / 1e6, span / 1e6 / W, busy / 1e6, busy / max(1, span), ",".join("%.3f" % (sums[k] / 1e6) for k in KERNELS), sum(sums.values()) / max(1, span)))
+            print("overlap window %d: span %.2f ms (%.3f per launch), union-busy %.2f ms, %.2f launches resident on average" % (w0 // W, span / 1e6, span / 1e6 / W, busy / 1e6, sum(sums.values()) / max(1, span)))
 tot = {}
 for cname, pat in (("FETCH_SIZE", "pmc_fetch/**/*_counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*_counter_collection.csv")):
     fn = one(pat)
