@@ -53,21 +53,23 @@ __device__ __noinline__ void bk_dp_round()
                 if (redo) bk_nw_dual(contig, clen, rd, rl, res);
             } else bk_nw_dual(contig, clen, rd, rl, res);
         }
+    } else if (S->fast) {
+        // A contig beyond the dual / pair kernels' columns, score sweep on: the sweep of the whole matrix (any contig length: registers up to
+        // 640 columns, column tiles beyond) takes ONE wavefront, so every wavefront has a slot of its own (round 6; bk_plan_round: until
+        // round 5 a slot had two wavefronts and the second one idled here).  What the sweep cannot settle is swept in full after the
+        // round's barrier, two wavefronts per read (bk_dp_redo).
+        // (a tile pipeline over two wavefronts of one slot -- alternate column tiles, the second ~128 steps behind on the edge column in
+        //  LDS -- was built and measured in round 5: bit-exact, and no faster where long contigs occur: configs[4] 6,367 -> 6,394 ms per
+        //  batch, configs[3] 945 -> 953; not kept: profiles/r05/score_sweep_ab.txt.  It shortened ONE read's sweep; this doubles the reads.)
+        if (wv < nb) {
+            bk_nw_score_long(BK_O_CSEQ + S->slot[wv].pb, S->slot[wv].plen, BK_O_RSEQ + wv * (C_.MAXR + 16), S->slot[wv].rl, (int)((uint8_t *)&S->slot[wv].v1 - bk_lds), L_BOUND_W(wv));
+            if ((BK_TID & 63) == 0) atomicAdd(&S->dp_n, 1);
+        }
     } else {                                             // two wavefronts per slot, both with the contig on the tile columns
         const int sl = wv >> 1;
         if (sl < nb) {
             const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
-            if (S->fast) {
-                // the score sweep of the whole matrix on ONE of the slot's two wavefronts (any contig length: column tiles); what it
-                // cannot settle is swept in full after the round's barrier (bk_dp_redo)
-                // (a tile pipeline over BOTH wavefronts of the slot -- alternate column tiles, the second ~128 steps behind on the edge
-                //  column in LDS -- was built and measured in round 5: bit-exact, and no faster where long contigs occur: configs[4]
-                //  6,367 -> 6,394 ms per batch, configs[3] 945 -> 953; not kept: profiles/r05/score_sweep_ab.txt)
-                if ((wv & 1) == 0) {
-                    bk_nw_score_long(BK_O_CSEQ + S->slot[sl].pb, cl, BK_O_RSEQ + sl * (C_.MAXR + 16), rl, (int)((uint8_t *)&S->slot[sl].v1 - bk_lds), L_BOUND_W(wv));
-                    if ((BK_TID & 63) == 0) atomicAdd(&S->dp_n, 1);
-                }
-            } else {
+            {
                 const uint8_t *cs = L_CSEQ + S->slot[sl].pb;
                 // waves w and w+4 land on the same SIMD: give it one direct (heavier) and one transposed sweep
                 if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
@@ -76,12 +78,15 @@ __device__ __noinline__ void bk_dp_round()
         }
     }
 }
-// the slots of a two-wavefronts-per-slot round whose score sweep left a border cell open: both overlap DPs in full
-__device__ __noinline__ void bk_dp_redo()
+// the slots of a long-contig round whose score sweep left a border cell open: both overlap DPs in full, two wavefronts per slot -- wavefront
+// pair p takes the (skip + p)-th flagged slot (the caller passes over the flagged slots BK_SPEC_WIDE at a time)
+__device__ __noinline__ void bk_dp_redo(int skip)
 {
     BkAsmShared *S = S_;
-    const int wv = BK_TID >> 6, sl = wv >> 1;
-    if (sl < S->nb && S->slot[sl].dec) {                 // (Slot::dec is free between the staging of a round and its retirement: here it says "sweep again")
+    const int wv = BK_TID >> 6;
+    int sl = -1, want = skip + (wv >> 1);
+    for (int s2 = 0; s2 < S->nb; s2++) if (S->slot[s2].dec && want-- == 0) { sl = s2; break; }      // (Slot::dec is free between the staging of a round and its retirement: here it says "sweep again")
+    if (sl >= 0) {
         const uint8_t *cs = L_CSEQ + S->slot[sl].pb; const int cl = S->slot[sl].plen, rl = S->slot[sl].rl;
         if ((((wv & 1) ^ (wv >> 2)) & 1) == 0) { BkNwResult r = bk_nw_suffix(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v1 = r; }
         else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }

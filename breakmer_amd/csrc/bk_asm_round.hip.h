@@ -161,9 +161,20 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     if (BK_TID != 0) return;
     int pb = S->cbase, plen = S->clen, ppc = S->pc, nb = 0;
     bool go = true;
-    // both DPs of a slot run on one wavefront while the (predicted) contig fits its columns; else two wavefronts per slot
+    // does this round run the score sweep first (bk_nw.hip.h)?  Decided before the slots are planned: it sets how many slots a round over a
+    // LONG contig may have (below)
+    if (S->dp_n >= 64) { S->dp_tot += S->dp_n - (S->dp_n >> 1); S->dp_rtot += S->dp_redo - (S->dp_redo >> 1); S->dp_n >>= 1; S->dp_redo >>= 1; }
+    S->fast = !(C_.flags & BK_F_NO_SCORE_SWEEP) && 4 * S->dp_redo <= S->dp_n + 8;      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays)
+    // Slots of a round whose (predicted) contig is longer than the dual / pair kernels take (BK_NW_DUAL_COLS).  The full overlap DPs of
+    // such a contig need TWO wavefronts per read (bk_nw_suffix + bk_nw_wave): half as many slots as wavefronts.  The score sweep
+    // (bk_nw_score_long: column tiles, any length) needs ONE -- until round 5 the second wavefront of each slot idled through it, so a
+    // round over a 650-column contig aligned 2 reads on the 4 wavefronts of the throughput build (configs[4]: 19,300 rounds of 2.5 reads
+    // per region, the chain that bounds it; configs[3]'s translocation contigs of 1,650 columns alike).  Round 6: a wavefront per slot
+    // while the sweep is on; the few reads it cannot settle are swept in full afterwards, BK_SPEC_WIDE at a time (bk_dp_redo).
+    const int widecap = S->fast ? BK_WAVES : BK_SPEC_WIDE;
+    // both DPs of a slot run on one wavefront while the (predicted) contig fits its columns; else a wavefront (score sweep) or two per slot
     for (int sl = 0; sl < nbmax && go; sl++) {
-        if (sl >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
+        if (sl >= widecap && plen > BK_NW_DUAL_COLS) { go = false; break; }
         nb = sl + 1;
         go = bk_predict(S->slot[sl], pb, plen, ppc, 0, 2 * C_.MAXC);
     }
@@ -196,7 +207,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
                 const uint32_t cu = BK_LA_CU(w)[i]; const int u = (int)(cu & 0x3FFFFFu); bool inflight = false;
                 for (int s2 = 0; s2 < nb0; s2++) inflight = inflight || S->slot[s2].u == u;
                 if (inflight) continue;
-                if (nb >= BK_SPEC_WIDE && plen > BK_NW_DUAL_COLS) { go = false; break; }
+                if (nb >= widecap && plen > BK_NW_DUAL_COLS) { go = false; break; }
                 BkAsmShared::Slot &t = S->slot[nb];
                 const int fl = BK_LA_FL(w)[i];
                 t.u = u; t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
@@ -225,7 +236,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
             const int nb0 = nb; bool whole = true;
             for (int i = 1; i < cn; i++) {
                 const uint32_t cu = BK_LA_CU(w)[i];
-                if (nb >= BK_SPEC_WIDE && plen2 > BK_NW_DUAL_COLS) { whole = false; break; }
+                if (nb >= widecap && plen2 > BK_NW_DUAL_COLS) { whole = false; break; }
                 BkAsmShared::Slot &t = S->slot[nb];
                 const int fl = BK_LA_FL(w)[i];
                 t.u = (int)(cu & 0x3FFFFFu); t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
@@ -244,10 +255,8 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
     // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
     S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
-    if (S->dp_n >= 64) { S->dp_tot += S->dp_n - (S->dp_n >> 1); S->dp_rtot += S->dp_redo - (S->dp_redo >> 1); S->dp_n >>= 1; S->dp_redo >>= 1; }
-    S->fast = !(C_.flags & BK_F_NO_SCORE_SWEEP) && 4 * S->dp_redo <= S->dp_n + 8;      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays)
     int nc = ncur;
-    if (!S->dual && nb > BK_SPEC_WIDE) { nc = min(nc, BK_SPEC_WIDE); nb = nc; upto = vt; }      // two wavefronts per slot: this visit's reads only
+    if (!S->dual && nb > widecap) { nc = min(nc, widecap); nb = nc; upto = vt; }      // a wavefront (score sweep) or two (full DPs) per slot: this visit's reads only
     S->nb = nb; S->ncur = nc;
     S->plan_r = nc; S->plan_upto = upto; S->plan_ok = (nb > nc || upto > vt) ? 1 : 0; S->plan_kind = kind;
     S->la_planned += nb - nc;
@@ -309,7 +318,10 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         if (S->status) return;
         BK_ACC(S_->ctx);
         // slots of a round: one per wavefront while both DPs of a slot fit one wavefront (contig <= BK_NW_DUAL_COLS), else half
-        const int cap = ((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) || S->clen > BK_NW_DUAL_COLS) ? BK_SPEC_WIDE : BK_SPEC;
+        // (a long contig: a slot per wavefront while the score sweep is on, bk_plan_round -- the same predicate on the same words, which
+        //  nobody writes between the last barrier and the plan; the plan's own verdict is what the round runs with)
+        const bool sweep_on = !(C_.flags & BK_F_NO_SCORE_SWEEP) && 4 * S->dp_redo <= S->dp_n + 8;
+        const int cap = (C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : S->clen > BK_NW_DUAL_COLS ? (sweep_on ? BK_WAVES : BK_SPEC_WIDE) : BK_SPEC;
         const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
         // look into the following visits when this one leaves slots free (needs the scratch for BK_AT/64 lists of 64 reads)
         // (split regions, bk_comp.hip.h: until round 4 the look-ahead was off inside them -- with it the assembler faulted about once
@@ -379,10 +391,10 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         // 2. the overlap DPs (:451-452) of every slot of this round
         bk_dp_round();
         BK_SYNC();
-        if (!S->dual && S->fast) {                      // (uniform) two wavefronts per slot: did the score sweep leave a border cell open?
-            bool any = false;
-            for (int sl = 0; sl < nb; sl++) any = any || S->slot[sl].v1.j_start == BK_NW_NEEDS_DP || S->slot[sl].v2.j_start == BK_NW_NEEDS_DP;
-            if (any) {
+        if (!S->dual && S->fast) {                      // (uniform) a wavefront per slot ran the score sweep: did it leave a border cell open?
+            int nflag = 0;
+            for (int sl = 0; sl < nb; sl++) nflag += (S->slot[sl].v1.j_start == BK_NW_NEEDS_DP || S->slot[sl].v2.j_start == BK_NW_NEEDS_DP) ? 1 : 0;
+            if (nflag) {
                 BK_SYNC();                              // every wavefront has looked at the result words before they change
                 if (BK_TID < nb) {
                     const int f = (S->slot[BK_TID].v1.j_start == BK_NW_NEEDS_DP || S->slot[BK_TID].v2.j_start == BK_NW_NEEDS_DP) ? 1 : 0;
@@ -390,8 +402,11 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
                     if (f) atomicAdd(&S->dp_redo, 1);
                 }
                 BK_SYNC();
-                bk_dp_redo();
-                BK_SYNC();
+                // the full overlap DPs of the flagged slots, two wavefronts each: BK_SPEC_WIDE slots per pass (nflag is uniform)
+                for (int done = 0; done < nflag; done += BK_SPEC_WIDE) {
+                    bk_dp_redo(done);
+                    BK_SYNC();
+                }
             }
         }
         BK_ACC(2);

@@ -32,3 +32,20 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle_bg():
+    """the CPU oracle's results for the full-size GPU tests, computed by a spawned pool in the background (tests/oracle_worker.py)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_worker import OracleBackground
+    bg = OracleBackground()
+    yield bg
+    bg.close()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_bg_autostart(request):
+    """the pool starts with the session when a selected test will ask for it, so that its work overlaps the GPU tests before it"""
+    if _gpu_present() and any("oracle_bg" in getattr(it, "fixturenames", ()) for it in request.session.items):
+        request.getfixturevalue("oracle_bg")
