@@ -225,7 +225,9 @@ def side_configs(a, hb, synth, opts, local):
     try:
         regs3 = [cfg3_region(synth, i) for i in range(a.cfg3_regions)]
         oc["configs[3]"] = time_other_config(hb, regs3, 31, opts, 2, local, flags=a.flags)
-        oc["configs[3]"]["workload"] = "mixed SV set (indel/inv/dup/trl + partner window), 1,000x 150 bp, k=31"
+        oc["configs[3]"]["workload"] = "mixed SV set (indel/inv/dup/trl + partner window), 1,000x 150 bp, k=31; value = ONE batch of %d regions at a time; in_flight = two batches of %d on two handles (the k-mer stage, the copy back and the call tail of one overlap the assembler of the other)" % (len(regs3), len(regs3) // 2)
+        if len(regs3) >= 512:
+            oc["configs[3]"]["in_flight"] = time_inflight(hb, regs3[:len(regs3) // 2], 31, opts, local, handles=2, steps=6, flags=a.flags, wg=0)
         del regs3
         regs4 = make_regions_parallel("cfg4", a.cfg4_regions)
         oc["configs[4]"] = time_other_config(hb, regs4, 41, opts, 1, local, flags=a.flags)
