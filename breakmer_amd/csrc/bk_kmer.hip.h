@@ -637,18 +637,33 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     BK_SYNC();
     BK_STAMP(11);
     const uint32_t tmask = tcap - 1;
-    for (uint32_t idx = tid; idx < T; idx += nt) {
-        uint32_t e = t_ent[idx], u = e >> 10, pos = e & 1023u;
-        BkKey key = seq_kmer_fast(reads + (uint64_t)urep[u] * RW, (int)RW, (int)pos, k);
-        uint32_t s = key_hash(key) & tmask;
-        for (;;) {
-            uint32_t cur = atomicCAS(&wslot[s], BK_EMPTY32, idx);
-            if (cur == BK_EMPTY32) break;
-            uint32_t e2 = t_ent[cur];
-            if (key_eq(seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k), key)) break;
-            s = (s + 1) & tmask;
+    // Four occurrences per thread at a time (round 6).  One occurrence is a chain of dependent accesses -- occurrence -> representative
+    // read -> its words -> slot (CAS) and, where the slot is taken, its claimant's occurrence -> read -> words --, and a noisy region has
+    // 10^5 (configs[4]: 4.4 M) of them on ONE workgroup: the first four links of four occurrences are in flight together, only the
+    // claimant checks of the ones that met a taken slot follow one after the other.
+    for (uint32_t idx0 = tid; idx0 < T; idx0 += 4 * (uint32_t)nt) {
+        uint32_t ee[4], ri[4], ss[4], cur[4], cn[4]; BkKey kk[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t idx = idx0 + (uint32_t)q * nt; ee[q] = idx < T ? t_ent[idx] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const bool on = idx0 + (uint32_t)q * nt < T; ri[q] = on ? urep[ee[q] >> 10] : 0u; cn[q] = on ? unr[ee[q] >> 10] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { kk[q] = seq_kmer_fast(reads + (uint64_t)ri[q] * RW, (int)RW, (int)(ee[q] & 1023u), k); ss[q] = key_hash(kk[q]) & tmask; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t idx = idx0 + (uint32_t)q * nt; cur[q] = idx < T ? atomicCAS(&wslot[ss[q]], BK_EMPTY32, idx) : BK_EMPTY32; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t idx = idx0 + (uint32_t)q * nt;
+            if (idx >= T) continue;
+            uint32_t s = ss[q], c = cur[q];
+            while (c != BK_EMPTY32) {
+                const uint32_t e2 = t_ent[c];
+                if (key_eq(seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k), kk[q])) break;
+                s = (s + 1) & tmask;
+                c = atomicCAS(&wslot[s], BK_EMPTY32, idx);
+            }
+            t_sl[idx] = s; atomicAdd(&wcnt[s], cn[q]);         // case[mer] counts every read (duplicates included)
         }
-        t_sl[idx] = s; atomicAdd(&wcnt[s], unr[u]);          // case[mer] counts every read (duplicates included)
     }
     BK_SYNC();
     // soft-clip set: keep only k-mers also present in case_sc (sv_processor.py:619-621)
@@ -675,14 +690,22 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     //      first, ordered by (count, mer) descending; the count-1 k-mers follow in table order: they are looked up and
     //      recruit reads like the others, but nothing depends on their order, so they are not sorted (with sequencing
     //      noise they are > 95 % of the set).
+    // Round 6: the table is walked by WAVEFRONTS -- wavefront w owns the slots [w R, (w + 1) R), lane l of it slot base + l of every
+    // block of 64 -- instead of a private chunk of consecutive slots per thread.  Same compaction order (ascending slot index inside
+    // each class), but a wavefront reads whole lines (a thread's chunk put the 64 lanes of every load on 64 different lines, each
+    // fetched sixteen times over: configs[4]'s 8 M slots took 68 of the stage's 163 ms; in LDS the same walk hit one bank 16- to 32-fold).
     uint32_t M = 0, M2 = 0;
-    const uint32_t chunk4 = (tcap + nt - 1) / nt, b4 = tid * chunk4, e4 = min(tcap, b4 + chunk4);
+    const uint32_t R4 = (((tcap + (uint32_t)nwv - 1) / (uint32_t)nwv) + 63u) / 64u * 64u, lo4 = min(tcap, (uint32_t)wv * R4), hi4 = min(tcap, lo4 + R4);
     uint32_t pre2, pre1;
     {
         uint32_t c2 = 0, c1 = 0, tot1 = 0;
-        for (uint32_t i = b4; i < e4; i++) if (tslot[i] < BK_EMPTY32 - 1) { if (tcnt[i] >= 2) c2++; else c1++; }
-        pre2 = bk_block_excl_scan(c2, scr, &M2);
-        pre1 = bk_block_excl_scan(c1, scr, &tot1);
+        for (uint32_t bs = lo4; bs < hi4; bs += 64) {
+            const uint32_t i = bs + (uint32_t)lane; const bool occ = i < hi4 && tslot[i] < BK_EMPTY32 - 1, two = occ && tcnt[i] >= 2;
+            c2 += (uint32_t)__popcll(__ballot(two)); c1 += (uint32_t)__popcll(__ballot(occ && !two));
+        }
+        pre2 = bk_block_excl_scan(lane == 0 ? c2 : 0u, scr, &M2);      // lane 0 of a wavefront: the sum over the wavefronts before it
+        pre1 = bk_block_excl_scan(lane == 0 ? c1 : 0u, scr, &tot1);
+        pre2 = (uint32_t)__shfl((int)pre2, 0); pre1 = (uint32_t)__shfl((int)pre1, 0);
         M = M2 + tot1;
     }
     uint32_t npad = 1; while (npad < M2) npad <<= 1;
@@ -704,10 +727,15 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     // permutation sort: perm in LDS when it fits, else in global memory
     uint32_t *perm = perm_in_lds ? perm_lds : (uint32_t *)(p.arena + o_perm);
     // keys and counts at the compaction index (count >= 2 first); ptmp: slot of the compaction index
-    for (uint32_t i = b4; i < e4; i++) if (tslot[i] < BK_EMPTY32 - 1) {
-        const uint32_t e2 = t_ent[tslot[i]]; const BkKey key = seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k);
-        const uint32_t j = tcnt[i] >= 2 ? pre2++ : M2 + pre1++;
-        klo[j] = key.lo; khi[j] = key.hi; kcnt[j] = tcnt[i]; ptmp[j] = i;
+    for (uint32_t bs = lo4; bs < hi4; bs += 64) {
+        const uint32_t i = bs + (uint32_t)lane; const bool occ = i < hi4 && tslot[i] < BK_EMPTY32 - 1; const uint32_t cn = occ ? tcnt[i] : 0u; const bool two = occ && cn >= 2;
+        const unsigned long long m2 = __ballot(two), m1 = __ballot(occ && !two), below = (1ull << lane) - 1ull;
+        if (occ) {
+            const uint32_t e2 = t_ent[tslot[i]]; const BkKey key = seq_kmer_fast(reads + (uint64_t)urep[e2 >> 10] * RW, (int)RW, (int)(e2 & 1023u), k);
+            const uint32_t j = two ? pre2 + (uint32_t)__popcll(m2 & below) : M2 + pre1 + (uint32_t)__popcll(m1 & below);
+            klo[j] = key.lo; khi[j] = key.hi; kcnt[j] = cn; ptmp[j] = i;
+        }
+        pre2 += (uint32_t)__popcll(m2); pre1 += (uint32_t)__popcll(m1);
     }
     BK_SYNC();
     bool sorted = false;
@@ -756,7 +784,16 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     // (LDS table: in the count words, which are free by now; else the start of the LDS, which holds nothing that is still needed)
     uint32_t *pcur = lds_tab ? tcnt : (M + 32u + 16u * 16u <= lds_words ? lds + 32 + 16 * 16 : ptmp);
     if (pcur != ptmp) { for (uint32_t j = tid; j < M; j += nt) pcur[j] = 0; BK_SYNC(); }
-    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = tslot[t_sl[idx]]; if (rk < BK_EMPTY32 - 1) atomicAdd(&pcur[rk], 1u); }
+    // (four occurrences per thread in flight, as in the table fill above: occurrence -> slot -> rank -> counter is a chain of dependent accesses)
+    for (uint32_t idx0 = tid; idx0 < T; idx0 += 4 * (uint32_t)nt) {
+        uint32_t sl[4], rk[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t idx = idx0 + (uint32_t)q * nt; sl[q] = idx < T ? t_sl[idx] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) rk[q] = idx0 + (uint32_t)q * nt < T ? tslot[sl[q]] : BK_EMPTY32;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (rk[q] < BK_EMPTY32 - 1) atomicAdd(&pcur[rk[q]], 1u);
+    }
     BK_SYNC();
     {
         const uint32_t chunk = (M + nt - 1) / nt, b = tid * chunk, e = min(M, b + chunk);
@@ -767,7 +804,17 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
         if (tid == 0) poff[M] = tot;
     }
     BK_SYNC();
-    for (uint32_t idx = tid; idx < T; idx += nt) { uint32_t rk = tslot[t_sl[idx]]; if (rk < BK_EMPTY32 - 1) post[atomicAdd(&pcur[rk], 1u)] = t_ent[idx]; }
+    for (uint32_t idx0 = tid; idx0 < T; idx0 += 4 * (uint32_t)nt) {
+        uint32_t sl[4], rk[4], en[4], at[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t idx = idx0 + (uint32_t)q * nt; sl[q] = idx < T ? t_sl[idx] : 0u; en[q] = idx < T ? t_ent[idx] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) rk[q] = idx0 + (uint32_t)q * nt < T ? tslot[sl[q]] : BK_EMPTY32;
+#pragma unroll
+        for (int q = 0; q < 4; q++) at[q] = rk[q] < BK_EMPTY32 - 1 ? atomicAdd(&pcur[rk[q]], 1u) : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (rk[q] < BK_EMPTY32 - 1) post[at[q]] = en[q];
+    }
     BK_SYNC();
     uint32_t out_tcap = tcap;
     if (lds_tab) {
