@@ -37,6 +37,12 @@
 #define BK_NW_G2 ((int)(((unsigned)-2) << 18) + (1 << 16))     // S[i][j-1] + gap, pointer 2
 #define BK_NW_G1 ((int)(((unsigned)-2) << 18))                 // S[i-1][j] + gap, pointer 1
 #define BK_NW_TILE_C 8
+#ifndef BK_NW_STILE_C
+#define BK_NW_STILE_C 13            // columns per lane of a column tile of the SCORE sweep (bk_nw_score_tile_c: 832 columns per tile).  A step costs ~24 + 3 C
+                                    // instructions and a tile n + 63 steps whatever its width: wide tiles pay the step's overhead and the skew's fill / drain
+                                    // fewer times (a 1,650-column translocation contig: 2 tiles of 13 instead of 4 of 8 columns per lane, 27 k instead of 41 k
+                                    // instructions per read; round 6)
+#endif
 // "closed" left border: a score no path can recover from (14-bit signed score field; rows <= 1024 cost at most -2048 more)
 #define BK_NW_CLOSED ((int)(((unsigned)-4096) << 18))
 #define LEFTB_OF(TR) ((TR) ? 0 : 0x8000)
@@ -565,14 +571,16 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
     // same one: S = V - 2 (i + j) exactly, taken where a score is read (the last column's running maximum, the last row at the end).
     // The row's symbol travels as the word 3 << 4 * code, a column keeps 4 * code: one bit-field extract yields 3 [match] or 0, and a
     // cell is v_bfe_u32, v_add3_u32, v_max3_i32 -- 3 instructions where the first version of the sweep had 6, and no condition code.
-    int H[C], cb[C], ms[C];
+    // (a mismatch on the diagonal adds -2 + 4 = 2.  The padding stands for the border column 0, V(i, 0) = 2 i: there a "diagonal" step of + 2 IS
+    //  the step down the border -- 2 (i - 1) + 2 = 2 i, what the left neighbour hands in anyway --, so the 2 is a literal of every column and the
+    //  per-column register of rounds 5 is gone)
+    int H[C], cb[C];
 #pragma unroll
     for (int x = 0; x < C; x++) {
         const int jj = hl * C + x - pad;                                            // 0-based column, < 0: padding (right-aligned columns: the last one is register C-1 of lane lm)
         const bool real = jj >= 0 && jj < mt && hl <= lm;
         H[x] = jj >= 0 ? 2 * (jj + 1) : 0;                                          // row 0: score 0 in matrix column jj + 1; the padding stands for column 0
         cb[x] = real ? 4 * (int)cols[jj] : 28;                                      // the column's symbol as a nibble position (28: no symbol sits there, matches nothing)
-        ms[x] = jj >= 0 ? 2 : 0;                                                    // mismatch on the diagonal: -2 + 4; inside the padding (all of it column 0) a "diagonal" step is a step down the border column
     }
     int dprev = 2 * max(hl * C - pad, 0), rb = 0, im1 = -hl;                        // V(0, column left of this lane's first)
     int voff = 2 * (1 - hl + mt);                                                   // 2 (i + m) of the row this lane is on: the last column's score is V - voff
@@ -593,9 +601,9 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
                 // to itself the compiler interleaves them and pays a register copy per column to put the new values back where the
                 // loop carries them
                 int dg[C];
-                dg[0] = dprev + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[0], 4u) + ms[0];
+                dg[0] = dprev + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[0], 4u) + 2;
 #pragma unroll
-                for (int x = 1; x < C; x++) dg[x] = H[x - 1] + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[x], 4u) + ms[x];
+                for (int x = 1; x < C; x++) dg[x] = H[x - 1] + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[x], 4u) + 2;
                 __builtin_amdgcn_sched_barrier(0);
                 int u_in = left;
 #pragma unroll
@@ -651,14 +659,16 @@ __device__ __noinline__ BkScoreCarry bk_nw_score_tile_c(const uint8_t *cols, con
     const int lane = threadIdx.x & 63;
     const int nl = (mt + C - 1) / C, lm = nl - 1, pad = nl * C - mt;
     // (cells hold V = S + 2 (i + column within the tile), as in bk_nw_score_c: 4 instructions per cell; the edge columns in LDS hold scores)
-    int H[C], cb[C], ms[C];
+    // (no per-column mismatch register either, as in bk_nw_score_c: padding only ever occurs in the FIRST tile (j0 = 0: bk_nw_score_long makes every
+    //  later tile a whole number of columns per lane), where it stands for the zero border and the literal 2 is exact; next to an edge column
+    //  with scores of its own a + 2 inside the padding could exceed the edge's value one row down)
+    int H[C], cb[C];
 #pragma unroll
     for (int x = 0; x < C; x++) {
         const int jj = lane * C + x - pad;
         const bool real = jj >= 0 && jj < mt && lane <= lm;
         H[x] = jj >= 0 ? 2 * (jj + 1) : 0;
         cb[x] = real ? 4 * (int)cols[j0 + jj] : 28;
-        ms[x] = jj >= 0 ? 2 : 0;
     }
     int dprev = 2 * max(lane * C - pad, 0), rb = 0, im1 = -lane;
     int voff = 2 * (1 - lane + mt);
@@ -680,9 +690,9 @@ __device__ __noinline__ BkScoreCarry bk_nw_score_tile_c(const uint8_t *cols, con
                 // to itself the compiler interleaves them and pays a register copy per column to put the new values back where the
                 // loop carries them
                 int dg[C];
-                dg[0] = dprev + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[0], 4u) + ms[0];
+                dg[0] = dprev + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[0], 4u) + 2;
 #pragma unroll
-                for (int x = 1; x < C; x++) dg[x] = H[x - 1] + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[x], 4u) + ms[x];
+                for (int x = 1; x < C; x++) dg[x] = H[x - 1] + (int)__builtin_amdgcn_ubfe((unsigned)rb, (unsigned)cb[x], 4u) + 2;
                 __builtin_amdgcn_sched_barrier(0);
                 int u_in = left;
 #pragma unroll
@@ -714,7 +724,7 @@ template <int C>
 __device__ inline BkScoreCarry bk_nw_score_tile_call(int c, const uint8_t *cols, const uint8_t *rows, int n, int j0, int mt, const int *bi, int *bo, int last, int s2, int i2)
 {
     if (c <= C) return bk_nw_score_tile_c<C>(cols, rows, n, j0, mt, bi, bo, last, s2, i2);
-    if constexpr (C < BK_NW_TILE_C) return bk_nw_score_tile_call<C + 1>(c, cols, rows, n, j0, mt, bi, bo, last, s2, i2);
+    if constexpr (C < BK_NW_STILE_C) return bk_nw_score_tile_call<C + 1>(c, cols, rows, n, j0, mt, bi, bo, last, s2, i2);
     BkScoreCarry z; z.s2 = s2; z.i2 = i2; z.best = 0; z.best_im1 = -1; return z;
 }
 // the epilogue of bk_nw_score_c as a function of the end cells (lane 0 writes the 8 result ints)
@@ -749,15 +759,19 @@ __device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int 
     res[4] = (n2 && !k2) ? BK_NW_NEEDS_DP : j2; res[5] = i2; res[6] = r2; res[7] = i2 == 0 ? 0 : s2;
 }
 // One read against a contig of any length, executed by the calling wavefront: up to 640 columns in registers (bk_nw_score_c), beyond
-// that in column tiles.  contig / read / res: offsets into the dynamic LDS block; bound: 2 * n ints of LDS scratch (tiles only).
+// that in column tiles of up to 64 x BK_NW_STILE_C columns.  contig / read / res: offsets into the dynamic LDS block; bound: 2 * n ints of
+// LDS scratch (used from the second tile on).
 __device__ inline void bk_nw_score_long(int contig, int clen, int read, int n, int res, int *bound, int force = 0)
 {
     if (clen <= 64 * BK_NW_DUAL_C) { BkPairArgs A; A.contig = contig; A.clen = clen; A.read = read; A.n = n; A.res = res; bk_nw_score_one(A, force); return; }
     const uint8_t *cols = bk_dyn_lds + contig, *rows = bk_dyn_lds + read;
     int *bi = bound, *bo = bound + n;
     BkScoreCarry c; c.s2 = 0; c.i2 = 0; c.best = 0; c.best_im1 = -1;
-    for (int j0 = 0; j0 < clen; j0 += BK_NW_TILE_COLS) {
-        const int mt = min(clen - j0, BK_NW_TILE_COLS);
+    // balanced tiles: as few as 64 x BK_NW_STILE_C columns allow; every tile but the FIRST is 64 lanes x a whole number of columns (no
+    // padding), the first one takes what is left (its padding stands for the zero border: bk_nw_score_tile_c)
+    const int nt_ = (clen + 64 * BK_NW_STILE_C - 1) / (64 * BK_NW_STILE_C), tw = 64 * (((clen + nt_ - 1) / nt_ + 63) / 64), w0 = clen - (nt_ - 1) * tw;
+    for (int j0 = 0; j0 < clen; j0 += (j0 == 0 ? w0 : tw)) {
+        const int mt = j0 == 0 ? w0 : tw;
         const bool last = j0 + mt >= clen;
         c = bk_nw_score_tile_call<1>((mt + 63) / 64, cols, rows, n, j0, mt, bi, bo, last ? 1 : 0, c.s2, c.i2);
         int *t = bi; bi = bo; bo = t;

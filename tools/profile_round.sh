@@ -21,7 +21,7 @@ python3 tools/summarize_profile.py "$out" "$tag"           # writes profiles/tra
 python3 bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"      # ... which the default bench line of the same session then quotes
 python3 tools/summarize_profile.py "$out" "$tag" > /dev/null
 # the summaries are written into profiles/ of THIS copy of the repo; only gpurun_out/ travels back from a gpurun box, so a copy goes there
-mkdir -p "$out/summaries" && cp -r profiles/$tag "$out/summaries/" 2>/dev/null; cp profiles/traffic.json profiles/valu.json "$out/summaries/" 2>/dev/null
+mkdir -p "$out/summaries" && cp -r profiles/$tag "$out/summaries/" 2>/dev/null; cp profiles/traffic.json profiles/valu.json profiles/kernel_ms.json "$out/summaries/" 2>/dev/null
 # raw per-dispatch counter CSVs are tens of MB: keep the small ones only
 find "$out" -name "*.csv" -size +4M -delete 2>/dev/null; find "$out" -name "*.db" -delete 2>/dev/null
 
