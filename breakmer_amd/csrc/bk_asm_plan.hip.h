@@ -62,7 +62,7 @@ __device__ __noinline__ void bk_dp_round()
         //  LDS -- was built and measured in round 5: bit-exact, and no faster where long contigs occur: configs[4] 6,367 -> 6,394 ms per
         //  batch, configs[3] 945 -> 953; not kept: profiles/r05/score_sweep_ab.txt.  It shortened ONE read's sweep; this doubles the reads.)
         if (wv < nb) {
-            bk_nw_score_long(BK_O_CSEQ + S->slot[wv].pb, S->slot[wv].plen, BK_O_RSEQ + wv * (C_.MAXR + 16), S->slot[wv].rl, (int)((uint8_t *)&S->slot[wv].v1 - bk_lds), L_BOUND_W(wv));
+            bk_nw_score_long(BK_O_CSEQ + S->slot[wv].pb, S->slot[wv].plen, BK_O_RSEQ + wv * (C_.MAXR + 16), S->slot[wv].rl, (int)((uint8_t *)&S->slot[wv].v1 - bk_lds), L_BOUND_W(wv), (C_.flags & BK_F_FORCE_REDO) ? 2 : 0);
             if ((BK_TID & 63) == 0) atomicAdd(&S->dp_n, 1);
         }
     } else {                                             // two wavefronts per slot, both with the contig on the tile columns

@@ -164,7 +164,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     // does this round run the score sweep first (bk_nw.hip.h)?  Decided before the slots are planned: it sets how many slots a round over a
     // LONG contig may have (below)
     if (S->dp_n >= 64) { S->dp_tot += S->dp_n - (S->dp_n >> 1); S->dp_rtot += S->dp_redo - (S->dp_redo >> 1); S->dp_n >>= 1; S->dp_redo >>= 1; }
-    S->fast = !(C_.flags & BK_F_NO_SCORE_SWEEP) && 4 * S->dp_redo <= S->dp_n + 8;      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays)
+    S->fast = !(C_.flags & BK_F_NO_SCORE_SWEEP) && (4 * S->dp_redo <= S->dp_n + 8 || (C_.flags & BK_F_FORCE_REDO));      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays; the diagnostic that flags every read keeps it on)
     // Slots of a round whose (predicted) contig is longer than the dual / pair kernels take (BK_NW_DUAL_COLS).  The full overlap DPs of
     // such a contig need TWO wavefronts per read (bk_nw_suffix + bk_nw_wave): half as many slots as wavefronts.  The score sweep
     // (bk_nw_score_long: column tiles, any length) needs ONE -- until round 5 the second wavefront of each slot idled through it, so a
@@ -320,7 +320,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         // slots of a round: one per wavefront while both DPs of a slot fit one wavefront (contig <= BK_NW_DUAL_COLS), else half
         // (a long contig: a slot per wavefront while the score sweep is on, bk_plan_round -- the same predicate on the same words, which
         //  nobody writes between the last barrier and the plan; the plan's own verdict is what the round runs with)
-        const bool sweep_on = !(C_.flags & BK_F_NO_SCORE_SWEEP) && 4 * S->dp_redo <= S->dp_n + 8;
+        const bool sweep_on = !(C_.flags & BK_F_NO_SCORE_SWEEP) && (4 * S->dp_redo <= S->dp_n + 8 || (C_.flags & BK_F_FORCE_REDO));
         const int cap = (C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : S->clen > BK_NW_DUAL_COLS ? (sweep_on ? BK_WAVES : BK_SPEC_WIDE) : BK_SPEC;
         const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
         // look into the following visits when this one leaves slots free (needs the scratch for BK_AT/64 lists of 64 reads)

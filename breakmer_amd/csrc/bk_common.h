@@ -277,6 +277,7 @@ enum {
     BK_F_NO_CALL_SHORTCUT = 2048,    // bk_call takes every contig through the full caller
     BK_F_HOST_REPAIR = 4096,         // split regions whose components met are repaired by host-driven passes (the fallback of the in-kernel repair, kept testable)
     BK_F_NO_SCORE_SWEEP = 8192,      // every overlap DP is the full sweep with origins (the round-4 DP rounds)
+    BK_F_FORCE_REDO = 32768,         // diagnostic: the score sweep of a long-contig round flags EVERY read, so that every slot goes through the full overlap DPs afterwards (bk_dp_redo, all its passes)
     BK_F_PREQUEUE_UNITS = 16384      // the units of a split region are queue entries of the launch and wait for unit 0 (the round-5 queue); default since round 6: unit 0 appends them once the graph is labelled
 };
 

@@ -757,6 +757,7 @@ __device__ inline void bk_nw_score_results(int *res, int mt, int n, int s1, int 
     else { n1 = o1 < 0; n2 = o2 < 0; }                                           // open: the border cell of the call(s) whose ok is not known
     res[0] = (n1 && !k1) ? BK_NW_NEEDS_DP : j1; res[1] = i1; res[2] = r1; res[3] = i1 == 0 ? 0 : s1;
     res[4] = (n2 && !k2) ? BK_NW_NEEDS_DP : j2; res[5] = i2; res[6] = r2; res[7] = i2 == 0 ? 0 : s2;
+    if (force == 2) { res[0] = BK_NW_NEEDS_DP; res[4] = BK_NW_NEEDS_DP; }        // diagnostic (BK_F_FORCE_REDO): the caller sweeps every read again in full
 }
 // One read against a contig of any length, executed by the calling wavefront: up to 640 columns in registers (bk_nw_score_c), beyond
 // that in column tiles of up to 64 x BK_NW_STILE_C columns.  contig / read / res: offsets into the dynamic LDS block; bound: 2 * n ints of

@@ -26,6 +26,7 @@ BK_ABI_VERSION = 5
 BK_E_ARG = -1
 # bk_config.flags (include/breakmer_hip.h: BK_CFG_*); production leaves 0
 BK_CFG_NO_SPLIT, BK_CFG_TEST_SPLIT_ALWAYS, BK_CFG_TEST_FULL_CALLER, BK_CFG_TEST_HOST_REPAIR, BK_CFG_TEST_PREQUEUE_UNITS = 128, 256, 2048, 4096, 16384
+BK_CFG_DIAG_FORCE_REDO = 32768      # diagnostic builds only
 BK_PSL_FLAT_HEAD = 18
 BK_W_REGIONS_FAILED = 1
 

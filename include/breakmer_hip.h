@@ -92,8 +92,9 @@ enum {
     BK_CFG_TEST_HOST_REPAIR = 4096,       /* test hook: repair passes of split regions driven by the host (the fallback when the unit queue is full) */
     BK_CFG_TEST_NO_SCORE_SWEEP = 8192,    /* test hook: every overlap DP is the full sweep with origins (the round-4 DP rounds) */
     BK_CFG_TEST_PREQUEUE_UNITS = 16384,   /* test hook: the units of a split region are queued at launch and wait for unit 0 (the round-5 queue) instead of being appended by it */
-    BK_CFG_DIAG_MASK = 1 | 2 | 4 | 512 | 1024,
-    BK_CFG_KNOWN_MASK = 32767
+    BK_CFG_DIAG_FORCE_REDO = 32768,       /* diagnostic: every read of a long-contig round is swept again in full after the score sweep (the redo passes, which real data takes for ~2 % of such reads) */
+    BK_CFG_DIAG_MASK = 1 | 2 | 4 | 512 | 1024 | 32768,
+    BK_CFG_KNOWN_MASK = 65535
 };
 
 /* One target region = what sv_processor.target hands to compare_kmers()/resolve_sv()

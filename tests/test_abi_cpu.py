@@ -187,7 +187,7 @@ def test_struct_layouts_of_the_header_equal_the_ctypes_mirrors(tmp_path):
     com = open(os.path.join(ROOT, "breakmer_amd", "csrc", "bk_common.h")).read()
     cfg_bits = {int(v) for v in re.findall(r"\bBK_CFG_(?:DIAG|TEST)?_?[A-Z0-9_]+\s*=\s*(\d+)\s*,", hdr)}
     f_bits = {int(v) for v in re.findall(r"\bBK_F_[A-Z0-9_]+\s*=\s*(\d+)", com)}
-    assert f_bits == cfg_bits and len(f_bits) == 15, (sorted(f_bits), sorted(cfg_bits))
+    assert f_bits == cfg_bits and len(f_bits) == 16, (sorted(f_bits), sorted(cfg_bits))
 
 
 def test_bk_create_checks_its_configuration_before_it_looks_for_a_device(lib):

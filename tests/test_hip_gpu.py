@@ -395,6 +395,18 @@ def test_barrier_discipline_of_every_kernel_gpu():
     assert out.count("ok    ") >= 3 * (2 + 4 + 4)
 
 
+def test_redo_passes_of_long_contig_rounds_gpu():
+    """Round 6: a look-ahead round over a contig beyond the dual / pair kernels' 320 columns has a slot per wavefront while the score sweep is on;
+    the reads the sweep cannot settle are swept again in full afterwards, two wavefronts per read, BK_SPEC_WIDE slots per pass (bk_dp_redo).  On
+    real data that is ~2 % of such reads -- hardly ever more than one pass.  With BK_CFG_DIAG_FORCE_REDO (accepted by diagnostic builds only: this
+    runs through the barrier-check + jitter build, in a child process) EVERY read of those rounds is flagged: all passes run, and the records must
+    still be the oracle's, on both workgroup sizes; the counter of reads swept again must show it."""
+    from breakmer_amd import build
+    assert os.path.isfile(build.lib_path("checkjit")), "libbreakmer_hip_checkjit.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` before the GPU suite"
+    out = _race_check(["--variant", "checkjit", "--seeds", "1", "redo"])
+    assert out.count("ok    ") == 4
+
+
 def test_batches_that_faulted_in_round_4_gpu():
     """The shape that faulted or hung until the barrier fixes (profiles/r04/split_fault/README.md; no test had it): several workgroups
     of small NOISY regions per CU.  720 and 1,024 regions at 1 % noise, four runs each on both workgroup sizes: every run gives the

@@ -10,6 +10,10 @@ what:
   shape:N[:R]   the batches that faulted in round 4 (profiles/r04/split_fault): N small regions at 1 % noise, R runs (default 6)
                 on both workgroup sizes -- records identical between runs, 8 sampled regions equal to the oracle
   noisy:N       N full-size regions (500x, 150 bp) at 0.5 % noise: split (default) against one unit per region, bit for bit
+  redo          regions with contigs beyond the dual / pair kernels' columns (a translocation, a 1,500-base insertion, 250-base reads at 3 % noise), with the
+                diagnostic flag that makes the score sweep of a long-contig round flag EVERY read (BK_CFG_DIAG_FORCE_REDO; a diagnostic build): every slot
+                of those rounds goes through the full overlap DPs, in as many passes of two wavefronts per read as the round has reads -- the path ~2 % of
+                such reads take on real data, a few per round at most -- against the oracle, both workgroup sizes, with and without the flag
   caps          regions that overflow a working cap of the assembler (4,700 candidate reads on one k-mer; a contig of 5,300 bases):
                 the give-up paths (bk_fail) and the re-run under larger caps, against the oracle -- the path on which the whole-suite
                 run through the check build found a missing barrier in round 5
@@ -146,6 +150,26 @@ def caps(tag):
         off.close()
 
 
+def redo(tag):
+    regions = [synth.make_region(7700, sv_type="trl", depth=120, W=2400), synth.make_region(7701, sv_type="ins", sv_size=1500, W=1500, depth=100),
+               synth.make_region(7702, sv_type="del", depth=150, W=2000, L=250, noise=0.03), synth.make_region(7703, sv_type="inv", depth=100, W=1800, noise=0.01)]
+    want = memo("redo", lambda: [bo.assemble_region(r.read_strs(), [r.window_str], 31, 2)[0] for r in regions])
+    assert max(len(c["seq"]) for w in want for c in w) > 700, "the check needs long contigs"
+    for wg in (256, 512):
+        base_redos = None
+        for flags in (0, 32768):
+            eng = engine(31, wg_threads=wg, flags=flags)
+            submit(eng, regions)
+            eng.run(hb.BK_STAGE_KMER | hb.BK_STAGE_ASSEMBLE)
+            wrong = sum(strip(eng.contigs(i)) != want[i] for i in range(len(regions)))
+            redos = eng.stat(31)
+            if flags == 0:
+                base_redos = redos
+            note(wrong == 0 and (flags == 0 or (redos > 4 * base_redos + 100 and redos > 1000)), "%s long-contig rounds, wg %d, flags %d: %d of %d regions differ from the oracle; reads swept again in full %d (of %d through the sweep)"
+                 % (tag, wg, flags, wrong, len(regions), redos, eng.stat(30)))
+            eng.close()
+
+
 def noisy(tag, n):
     regions = [synth.make_region(50000 + i, depth=500, L=150, sv_type=("del", "ins", "inv")[i % 3], noise=0.005) for i in range(n)]
     for wg in (256, 512):
@@ -190,6 +214,8 @@ def main():
                     noisy(tag, int(w.split(":")[1]))
                 elif w == "caps":
                     caps(tag)
+                elif w == "redo":
+                    redo(tag)
                 else:
                     raise SystemExit("unknown check " + w)
             except hb.BreakmerHipError as e:
