@@ -244,6 +244,19 @@ def side_configs(a, hb, synth, opts, local):
         oc["noise_0.5pct_256_regions"] = time_other_config(hb, regs256, a.kmer, opts, 2, local, flags=a.flags)
         oc["noise_0.5pct_256_regions"]["workload"] = "256 regions of the configs[1] shape with 0.5 % substitution noise per base; value = ONE batch at a time (a batch's latency: bound by the serial chain of its slowest region); in_flight = sustained rate with batches in flight"
         oc["noise_0.5pct_256_regions"]["in_flight"] = time_inflight(hb, regs256, a.kmer, opts, local, handles=a.noisy_inflight, steps=3 * a.noisy_inflight, flags=128 | a.flags, wg=256)
+        try:                                                  # the same through the retained driver surface: runner.run() with its launch queue eight deep
+            r_short = time_runner(synth, regs256, a.kmer, cycles=24, extra={"run_depth": a.noisy_inflight, "throughput_mode": "1"})
+            oc["noise_0.5pct_256_regions"]["runner_end_to_end"] = time_runner(synth, regs256, a.kmer, cycles=96, extra={"run_depth": a.noisy_inflight, "throughput_mode": "1"},
+                note="runner.run() wall time over 96 x 256 noisy targets (submit of 2-bit packed reads + GPU stages + native call tail + per-target Python), run_depth = %d launched batches in flight, throughput_mode (BK_CFG_NO_SPLIT, 256-thread workgroups), after one untimed warm-up run" % a.noisy_inflight)
+            r_long = oc["noise_0.5pct_256_regions"]["runner_end_to_end"]
+            # a run starts with ~10 fresh handles (device and pinned allocations, the first batch of each sizes its arenas): a fixed few seconds;
+            # the rate a long sample sees is the marginal one, from the difference of the two run lengths
+            r_long["short_run"] = {"value": r_short["value"], "regions": r_short["regions"], "seconds": r_short["seconds"]}
+            if r_long["seconds"] > r_short["seconds"]:
+                r_long["steady_state"] = {"value": round((r_long["regions"] - r_short["regions"]) / (r_long["seconds"] - r_short["seconds"]), 1), "unit": "regions/s",
+                                          "note": "(regions of the long run - regions of the short run) / (their wall times' difference): what every further batch of a sample costs; the fixed start-up is %.1f s" % max(0.0, r_short["seconds"] - r_short["regions"] * (r_long["seconds"] - r_short["seconds"]) / (r_long["regions"] - r_short["regions"]))}
+        except Exception as ex:
+            oc["noise_0.5pct_256_regions"]["runner_end_to_end"] = {"error": repr(ex)}
         oc["noise_0.5pct_256_regions"]["in_flight"]["note"] = "bk_config.flags = BK_CFG_NO_SPLIT, asm_wg_threads = 256: with the chip full of other batches one workgroup per region costs less than 16 units per region (same rows: rows_identical_across_batches compares every batch with a batch that ran alone)"
         del regs256
     except Exception as ex:                      # never lose what was measured to a later side measurement
@@ -310,7 +323,7 @@ def usable_cores():
     return n
 
 
-def time_runner(synth, regions, kmer, cycles=1):
+def time_runner(synth, regions, kmer, cycles=1, extra=None, note=None):
     """the retained driver surface end to end (breakmer_amd.sv_processor.runner.run: per-target objects, batches on two handles,
     submit = host 2-bit packing + H2D included, native call tail, rows in target order), code-matrix inputs, no output files.
     cycles > 1: the same regions again under further target names (more batches per run without more host memory)"""
@@ -329,8 +342,10 @@ def time_runner(synth, regions, kmer, cycles=1):
     def config(tag, nb):
         open(os.path.join(d, tag + ".bed"), "w").write("\n".join(bed[:nb]) + "\n")
         open(os.path.join(d, tag + ".txt"), "w").write("\n".join(genes[:nb + 1]) + "\n")
-        return {"analysis_name": tag, "targets_bed_file": os.path.join(d, tag + ".bed"), "gene_annotation_file": os.path.join(d, tag + ".txt"),
-                "kmer_size": str(kmer), "keep_repeat_regions": True, "batch_regions": 256}
+        c = {"analysis_name": tag, "targets_bed_file": os.path.join(d, tag + ".bed"), "gene_annotation_file": os.path.join(d, tag + ".txt"),
+             "kmer_size": str(kmer), "keep_repeat_regions": True, "batch_regions": 256}
+        c.update(extra or {})
+        return c
     if cycles > 1:                                      # untimed: creates the handles the process keeps between runs
         sp.runner(config("warmup", min(1536, len(bed))), region_data=data).run()
     cfg = config("bench", len(bed))
@@ -339,7 +354,7 @@ def time_runner(synth, regions, kmer, cycles=1):
     dt = time.perf_counter() - t0
     return {"value": round(len(data) / dt, 1), "unit": "regions/s", "regions": len(data), "rows": len(rows), "seconds": round(dt, 3),
             "batches": (len(data) + 255) // 256,
-            "note": "runner.run() wall time: submit of 2-bit packed reads (BK_SUBMIT_PACKED: row copies + H2D) + GPU stages + native call tail + per-target Python objects (no output files), "
+            "note": note or "runner.run() wall time: submit of 2-bit packed reads (BK_SUBMIT_PACKED: row copies + H2D) + GPU stages + native call tail + per-target Python objects (no output files), "
                     "after one untimed warm-up run of 6 batches (the process keeps its handles between runs); 2 x 256 distinct regions cycled under 16 sets of target names; "
                     "the timed `value` above excludes submit (inputs resident, SURVEY 8d)"}
 

@@ -71,15 +71,27 @@ static inline constexpr const char *bk_diag_env(const char *) { return nullptr; 
 
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
+    std::vector<void *> old;      // outgrown allocations, freed by release(): hipFree waits for EVERY stream of the device -- a handle whose arena grows
+                                  // (its first noisy batch) drained the kernels of every other handle in flight; the new block is allocated first and the
+                                  // old one kept until the handle is trimmed or destroyed (round 6).  When memory is short the old blocks go first.
     hipError_t ensure(size_t n) {
         if (n <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, n ? n : 256);
-        if (e == hipSuccess) bytes = n;
-        return e;
+        void *np = nullptr;
+        hipError_t e = hipMalloc(&np, n ? n : 256);
+        if (e != hipSuccess) {                      // not enough room beside what was outgrown: give that back (this waits for the device) and try again
+            (void)hipGetLastError();
+            for (void *o : old) (void)hipFree(o);
+            old.clear();
+            if (p) (void)hipFree(p);
+            p = nullptr; bytes = 0;
+            e = hipMalloc(&np, n ? n : 256);
+            if (e != hipSuccess) return e;
+        }
+        if (p) old.push_back(p);
+        p = np; bytes = n;
+        return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void release() { for (void *o : old) (void)hipFree(o); old.clear(); if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
 struct HostVec {            // pinned host mirror of the result arena (faster D2H than pageable memory)

@@ -225,7 +225,10 @@ BK_COLD void bk_emit_contig()
     if (BK_TID == 0) {
         uint64_t need = bk_align_up(size, 256);
         uint64_t off = atomicAdd(C_.out_top, (unsigned long long)need);
-        if (off + need > C_.out_cap) { off = 0; S->status = BK_ST_OUT; }
+        // The result arena is full: the region goes on WITHOUT writing records (offset 0 = none; its status says so at once) -- the bump pointer
+        // then ends at what the whole batch needs and the host grows the arena ONCE (round 6; until then a region stopped at its first
+        // record that did not fit, the demand was unknown, and a noisy batch on a fresh handle grew 8 -> 33 -> 134 -> 536 MB in three re-runs)
+        if (off + need > C_.out_cap) { off = 0; atomicCAS((int *)&C_.wk->status, BK_ST_OK, BK_ST_OUT); }
         S->scan[8] = (uint32_t)off; S->scan[9] = (uint32_t)(off >> 32);
     }
     BK_SYNC();

@@ -565,7 +565,15 @@ __device__ inline void bk_kmer_body(const BkParams &p, uint32_t ref_cap, uint32_
     //      the sample k-mer table.  One WAVEFRONT per listed read, one k-mer position per lane (plain probes):
     //      walking them one read per lane serialises the rare expensive events of 64 different reads.
     uint64_t a0 = bk_arena_alloc(p, (uint64_t)Tmax * 8 + 1024, scr + 20);
-    if (a0 == ~0ull) { if (tid == 0) wk->status = BK_ST_ARENA; return; }
+    if (a0 == ~0ull) {
+        // The arena is too small for this batch (a fresh handle sizes it for clean reads; the host grows it and runs the batch again).  The
+        // bump pointer is the host's only measure of the demand, and a region that stops here has asked for a seventh of what it needs:
+        // it adds an estimate of the rest -- sample k-mer table (<= 3 Tmax slots of 8 bytes), compact arrays and posting lists (~45 bytes per
+        // distinct k-mer <= Tmax), and for a region of the size that is split into units their scratch over two or three passes -- so that
+        // ONE growth step suffices (round 6; x4 at a time a noisy batch ran four times: 103 -> 495 -> 1,982 -> 7,931 MB).
+        if (tid == 0) { wk->status = BK_ST_ARENA; atomicAdd(p.arena_top, (unsigned long long)Tmax * 24ull + (Tmax > 65536u ? ((p.flags & BK_F_NO_SPLIT) ? (6ull << 20) : (40ull << 20)) : (1ull << 20))); }
+        return;
+    }
     const uint64_t o_ent = a0, o_tsl = bk_align_up(o_ent + (uint64_t)Tmax * 4, 256);
     uint32_t *t_ent = (uint32_t *)(p.arena + o_ent), *t_sl = (uint32_t *)(p.arena + o_tsl);
     if (tid == 0) scr[24] = 0;

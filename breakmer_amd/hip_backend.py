@@ -535,19 +535,21 @@ _POOL_MAX = 4                                   # the driver has up to four batc
 _POOL_KEEP_BYTES = 2 << 30
 
 
-def acquire_engine(kmer_size, rc_thresh=2, device=0):
-    key = (device, int(kmer_size), int(rc_thresh))
+def acquire_engine(kmer_size, rc_thresh=2, device=0, flags=0, wg_threads=0):
+    key = (device, int(kmer_size), int(rc_thresh), int(flags), int(wg_threads))
     for other in [k_ for k_ in _POOL if k_ != key]:
         for e in _POOL.pop(other):
             e.close()
     lst = _POOL.get(key)
     if lst:
         return lst.pop()
-    return Engine(kmer_size=kmer_size, rc_thresh=rc_thresh, device=device)
+    eng = Engine(kmer_size=kmer_size, rc_thresh=rc_thresh, device=device, flags=flags, wg_threads=wg_threads)
+    eng._pool_key = key
+    return eng
 
 
 def release_engine(eng):
-    key = (eng.device, eng.k, eng.rc_thresh)
+    key = getattr(eng, "_pool_key", (eng.device, eng.k, eng.rc_thresh, 0, 0))
     lst = _POOL.setdefault(key, [])
     if eng.h and len(lst) < _POOL_MAX:
         eng._inputs = None                      # nothing of the last batch is pending on a handle the driver gives back

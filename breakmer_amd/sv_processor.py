@@ -1126,7 +1126,9 @@ class runner(object):                                               # sv_process
         if self.engine_factory:
             return self.engine_factory(self.params)
         dev = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0                # one process per GPU
-        eng = hip_backend.acquire_engine(self.params.get_kmer_size(), self.params.get_sr_thresh('min'), dev)      # kept between runs of one process
+        tm = str(self.params.opts.get('throughput_mode', '')).lower() in ('1', 'true', 'yes')
+        eng = hip_backend.acquire_engine(self.params.get_kmer_size(), self.params.get_sr_thresh('min'), dev,      # kept between runs of one process
+                                         flags=hip_backend.BK_CFG_NO_SPLIT if tm else 0, wg_threads=256 if tm else 0)
         self._pooled.append(eng)
         return eng
 
@@ -1163,15 +1165,21 @@ class runner(object):                                               # sv_process
         # submits in flight before a batch's kernels are launched: with one, the launch of a batch of packed reads still waited ~1 ms for
         # the library's thread (row copies + H2D of 100 MB take longer than this thread needs for a batch); a handle per batch in flight
         depth = max(1, int(self.params.opts.get('submit_depth', 2)))
-        free, pending, running = [], [], []                         # handles; submitted batches; the launched batch
+        # launched batches in flight before the oldest is picked up.  1 (default): the batch launched one iteration earlier is picked up right
+        # after the next one is launched -- right for clean reads, whose batches take a millisecond.  Realistic (noisy) reads make a batch take
+        # a third of a second, bound by the serial chain of its slowest region: with `run_depth` 6-8 and `throughput_mode` (one
+        # workgroup per region on 256-thread workgroups: hip_backend.acquire_engine) the chip stays full -- 2,050 against 790 regions/s on the
+        # library's own loop (bench.py other_configs.noise_0.5pct_256_regions).  Rows are the same either way.
+        run_depth = max(1, int(self.params.opts.get('run_depth', 1)))
+        free, pending, running = [], [], []                         # handles; submitted batches; the launched batches, oldest first
 
         def advance():
             eng, live = pending.pop(0)
             again = self._launch_batch(eng, live)                    # the GPU starts on this batch ...
             if again is not None:                                     # (a lane batch that had to go the per-target way after all)
                 live = again
-            if running:                                               # ... while the one before it (long finished) is picked up
-                done = running.pop()
+            while len(running) >= run_depth:                          # ... while the oldest one before it (long finished) is picked up
+                done = running.pop(0)
                 self._finish_batch(done[0], done[1], order)
                 free.append(done[0])
             if live:
@@ -1212,8 +1220,8 @@ class runner(object):                                               # sv_process
                     advance()
             while pending:
                 advance()
-            if running:
-                done = running.pop()
+            while running:
+                done = running.pop(0)
                 self._finish_batch(done[0], done[1], order)
                 free.append(done[0])
             while self._retry:                                        # second pass (N4): targets with partner windows from the genome-wide search

@@ -257,6 +257,38 @@ def test_two_rank_batch_lane_gloo(tmp_path):
     assert sorted(g[4] for g in got) != [0, 0] and sum(g[4] for g in got) == sum(len(d_.read_ids) for d_ in data.values())
 
 
+def test_run_depth_keeps_rows_and_order(tmp_path):
+    """`run_depth` (launched batches in flight before the oldest is picked up: what a sample of noisy reads wants) changes when a
+    batch is picked up, not what comes out: rows, summary and the per-target files' order are those of the default depth -- through the batch
+    lane (scripted engine, batches of 2) and through the per-target way (oracle-backed engine, batches of 1 and 2)."""
+    for depth in (1, 2, 4):
+        d = tmp_path / ("lane%d" % depth)
+        d.mkdir()
+        cfg, data, script = _lane_inputs(d)
+        cfg["run_depth"] = depth
+        engines = []
+
+        def factory(prm, script=script, engines=engines):
+            e = ScriptedEngine(script, [])
+            engines.append(e)
+            return e
+        r = sp.runner(cfg, region_data=data, engine_factory=factory)
+        rows = r.run()
+        if depth == 1:
+            want, want_summary = rows, sorted(r.summary.items())
+        assert rows == want and sorted(r.summary.items()) == want_summary, depth
+        assert len(engines) <= depth + 3, (depth, len(engines))          # a handle per batch in flight (launched + submitted), reused afterwards
+    ref = None
+    for depth, bsz in ((1, 1), (3, 1), (2, 2)):
+        d = tmp_path / ("obj%d_%d" % (depth, bsz))
+        d.mkdir()
+        cfg, data = make_inputs(d, [(3, "del"), (5, "ins"), (7, "inv"), (9, "del"), (11, "del")])
+        cfg["run_depth"], cfg["batch_regions"] = depth, bsz
+        rows = sp.runner(cfg, region_data=data, engine_factory=lambda prm: FakeEngine(prm.get_kmer_size(), prm.get_sr_thresh('min'))).run()
+        ref = rows if ref is None else ref
+        assert rows == ref and len(rows) >= 4, (depth, bsz)
+
+
 def test_eight_ranks_4096_targets_gloo(tmp_path):
     """configs[2]'s shape on CPU: 4,096 targets of mixed cost dealt over EIGHT ranks (gloo), batches of 256 through the batch lane.
     Every rank computes the same assignment without communication (each reports the loads of all eight: identical tuples; the eight
