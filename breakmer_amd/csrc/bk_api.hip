@@ -646,8 +646,11 @@ static int sync_impl(bk_handle *h)
         HIPCHK(h, hipMemcpy(tops, h->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
         // (x4 while the arena is small, x1.5 beyond 4 GB or what was asked for + 25 %: a 256-region configs[4] batch needs ~90 GB
         // and must not jump from 42 to 166)
-        if (grow_arena) { h->arena_cap = std::max<uint64_t>(h->arena_cap < (4ull << 30) ? h->arena_cap * 4 : h->arena_cap + h->arena_cap / 2, tops[0] + tops[0] / 4); HIPCHK(h, h->d_arena.ensure(h->arena_cap)); }
-        if (grow_out) { h->out_cap = std::max<uint64_t>(h->out_cap * 4, tops[1] + tops[1] / 2); HIPCHK(h, h->d_out.ensure(h->out_cap)); }
+        // (round 6: the pointers end at -- an estimate of -- the batch's whole demand (bk_kmer.hip.h, bk_emit_contig), so the slack on top of them is
+        //  small at scale: a quarter, but at most 4 GB + 3 %; a 768-region configs[4] batch asks for ~210 GB of the 288, and a quarter on top of
+        //  that left no room for its records.  The result arena's demand is exact once a pass has run through: x4 only while it is not.)
+        if (grow_arena) { h->arena_cap = std::max<uint64_t>(h->arena_cap < (4ull << 30) ? h->arena_cap * 4 : h->arena_cap + h->arena_cap / 8, tops[0] + std::min<uint64_t>(tops[0] / 4, (4ull << 30) + tops[0] / 32)); HIPCHK(h, h->d_arena.ensure(h->arena_cap)); }
+        if (grow_out) { h->out_cap = std::max<uint64_t>(grow_arena ? h->out_cap * 4 : h->out_cap + h->out_cap / 8, tops[1] + std::min<uint64_t>(tops[1] / 4, (1ull << 30) + tops[1] / 16)); HIPCHK(h, h->d_out.ensure(h->out_cap)); }
         escalated = false; h->n_escalated = 0; h->n_repair_passes = 0; for (float &m : ms_first) m = 0;      // the whole batch again: regions that overflow a cap will be re-run again
         int rc = launch(h, h->ran_mask);
         if (rc != BK_OK) return rc;

@@ -583,18 +583,28 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
         cb[x] = real ? 4 * (int)cols[jj] : 28;                                      // the column's symbol as a nibble position (28: no symbol sits there, matches nothing)
     }
     int dprev = 2 * max(hl * C - pad, 0), rb = 0, im1 = -hl;                        // V(0, column left of this lane's first)
-    int voff = 2 * (1 - hl + mt);                                                   // 2 (i + m) of the row this lane is on: the last column's score is V - voff
-    int best = 0, best_im1 = -1;                                                    // the border cell (0, m): score 0 (olc.py:79-83)
+    // The end cell of the last column (olc.py:79-83: the LARGEST row among the maxima) as ONE word per lane: key = score << 11 | row, so that a plain
+    // signed maximum keeps the later row among equal scores (rows <= 1,024; a negative score makes a negative key, which never beats the border
+    // cell (0, m): score 0, row 0 = key 0).  The last column's score is V - 2 (row + m): key = (V << 11) + koff with koff = row - (2 (row + m) << 11),
+    // which moves by 1 - 4096 per step -- shift-add, max and the counter: 3 instructions per step where the compare-and-two-selects form of
+    // round 5 took 5 (round 6).
+    int koff = (1 - hl) - ((2 * (1 - hl + mt)) << 11);
+    int bkey = 0;
     const bool inl = hl <= lm && n > 0;
     const int steps = nmax + lm_max;
     for (int t0 = 0; t0 < steps; t0 += LPR) {
-        const int rblk = (t0 + hl < n) ? (int)rows[t0 + hl] : 0;
+        // The symbols of the next LPR rows, one per lane, already as the word the cells test (3 << 4 code).  They rotate TOWARDS the read's first
+        // lane by one lane per step (DPP wave_shl:1), so that lane always holds the word of the row that enters the pipeline now; the row
+        // words themselves move down the lanes by one (wave_shr:1) and the first lane takes the new one: three instructions per step -- two
+        // DPP moves and one select on a loop-invariant mask -- for one read or two (round 5: v_readlane, shift, move and select per read, nine
+        // for the pair).  A block ends after LPR steps, before what enters the rotation from the neighbouring half could reach a first lane.
+        int rrot = 3 << (4 * ((t0 + hl < n) ? (int)rows[t0 + hl] : 0));
         const int te = min(LPR, steps - t0);
         for (int tl = 0; tl < te; tl++) {
             const int recv = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);
             rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
-            if constexpr (LPR == 32) { const int ra = 3 << (4 * __builtin_amdgcn_readlane(rblk, tl)), rbb = 3 << (4 * __builtin_amdgcn_readlane(rblk, 32 + tl)); if (hl == 0) rb = half ? rbb : ra; }
-            else { const int ra = 3 << (4 * __builtin_amdgcn_readlane(rblk, tl)); if (hl == 0) rb = ra; }
+            rb = hl == 0 ? rrot : rb;
+            rrot = __builtin_amdgcn_update_dpp(rrot, rrot, 0x130, 0xf, 0xf, false);
             if (inl && (unsigned)im1 < (unsigned)n) {
                 const int left = hl == 0 ? 2 * im1 + 2 : recv;                      // border column (i, 0): score 0, V = 2 i
                 // the diagonal candidates of the whole row first (from the previous row's values), then the chain of max3 IN PLACE: left
@@ -609,14 +619,13 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
 #pragma unroll
                 for (int x = 0; x < C; x++) { H[x] = max(max(dg[x], u_in), H[x]); u_in = H[x]; }
                 dprev = left;
-                const int v = H[C - 1] - voff;                                     // lane lm: the last column's score (olc.py:81 '>=': last row wins)
-                const bool take = v >= best;
-                best = take ? v : best; best_im1 = take ? im1 : best_im1;
+                bkey = max(bkey, (H[C - 1] << 11) + koff);                          // lane lm: the last column's (score, row); '>=' of olc.py:81 = the later row wins
             }
-            im1++; voff += 2;
+            im1++; koff -= 4095;
         }
     }
-    const int s1 = __shfl(best, (half * LPR) + lm), i1 = __shfl(best_im1, (half * LPR) + lm) + 1;
+    const int bk1 = __shfl(bkey, (half * LPR) + lm);
+    const int s1 = bk1 >> 11, i1 = bk1 & 2047;
     // nw(read, contig): the last row, columns ascending ('>=' keeps the largest index), reduced over the read's lanes
     int s2 = 0, i2 = 0;
 #pragma unroll
@@ -676,14 +685,15 @@ __device__ __noinline__ BkScoreCarry bk_nw_score_tile_c(const uint8_t *cols, con
     const bool inl = lane <= lm;
     const int steps = n + lm;
     for (int t0 = 0; t0 < steps; t0 += 64) {
-        const int rblk = (t0 + lane < n) ? (int)rows[t0 + lane] : 0;
+        int rrot = 3 << (4 * ((t0 + lane < n) ? (int)rows[t0 + lane] : 0));          // the rows' symbol words rotate towards lane 0 (bk_nw_score_c)
         const int bblk = (j0 > 0 && t0 + lane < n) ? bound_in[t0 + lane] : 0;      // S[i][j0] for the rows lane 0 handles in this block (the border column: 0)
         const int te = min(64, steps - t0);
         for (int tl = 0; tl < te; tl++) {
             const int recv = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);
             rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
-            const int ra = 3 << (4 * __builtin_amdgcn_readlane(rblk, tl)), bi = __builtin_amdgcn_readlane(bblk, tl);
-            if (lane == 0) rb = ra;
+            const int bi = __builtin_amdgcn_readlane(bblk, tl);
+            rb = lane == 0 ? rrot : rb;
+            rrot = __builtin_amdgcn_update_dpp(rrot, rrot, 0x130, 0xf, 0xf, false);
             if (inl && (unsigned)im1 < (unsigned)n) {
                 const int left = lane == 0 ? bi + 2 * im1 + 2 : recv;               // lane 0 handles row t0 + tl at this step: its edge value is entry tl of the block
                 // the diagonal candidates of the whole row first (from the previous row's values), then the chain of max3 IN PLACE: left
