@@ -599,7 +599,7 @@ __device__ __noinline__ void bk_nw_score_c(BkPairArgs A_, BkPairArgs B_, int for
         // DPP moves and one select on a loop-invariant mask -- for one read or two (round 5: v_readlane, shift, move and select per read, nine
         // for the pair).  A block ends after LPR steps, before what enters the rotation from the neighbouring half could reach a first lane.
         int rrot = 3 << (4 * ((t0 + hl < n) ? (int)rows[t0 + hl] : 0));
-        const int te = min(LPR, steps - t0);
+        const int te = __builtin_amdgcn_readfirstlane(min(LPR, steps - t0));          // (uniform: the step counter stays in a scalar register)
         for (int tl = 0; tl < te; tl++) {
             const int recv = __builtin_amdgcn_mov_dpp(H[C - 1], 0x138, 0xf, 0xf, true);
             rb = __builtin_amdgcn_update_dpp(rb, rb, 0x138, 0xf, 0xf, false);
