@@ -70,6 +70,7 @@ struct BkAsmShared {
     // reads that had to be swept again, in a window that is halved at 64; fast = the plan of the current round uses it
     int dp_n, dp_redo, fast;
     int dp_tot, dp_rtot;             // the same counts over the whole region (reported: BkRegionWork.dp_sweeps / dp_redos)
+    int dp_off;                      // rounds planned since the sweep went off: after BK_SWEEP_RETRY of them the window starts afresh (bk_plan_round)
     // look-ahead across k-mer visits of grow (bk_run_candidates): slots [plan_r, nb) hold reads of LATER visits, already aligned
     // against the predicted contig; plan_upto = last visit (index into the snapshot) whose candidate list the plan knows
     int ncur, plan_r, plan_upto, plan_ok, hit;
@@ -418,7 +419,7 @@ __device__ __forceinline__ void bk_asm_region(const BkParams &p, const int r, co
         c.kcnt = (const uint32_t *)(p.arena + wk->o_kcnt); c.kstate = p.arena + wk->o_kstate; c.kstamp = (int32_t *)(p.arena + wk->o_kstamp);
         c.poff = (const uint32_t *)(p.arena + wk->o_poff); c.post = (const uint32_t *)(p.arena + wk->o_post);
         S->status = 0; S->serial_ctr = 0; S->stamp_ctr = 0; S->head = 0; S->nused = 0; S->phead = 0; S->ptail = 0; S->n_contigs = 0; S->cells = 0; S->calls = 0;
-        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32; S->n_rej = 0; S->n_acc = 0; S->dp_n = 0; S->dp_redo = 0; S->fast = 0; S->dp_tot = 0; S->dp_rtot = 0;
+        S->nalt = 0; S->nk = 0; S->nr = 0; S->ncand = 0; S->plan_ok = 0; S->plan_kind = 0; S->la_planned = 0; S->la_adopted = 0; S->la_pause = 0; S->la_backoff = 32; S->n_rej = 0; S->n_acc = 0; S->dp_n = 0; S->dp_redo = 0; S->fast = 0; S->dp_tot = 0; S->dp_rtot = 0; S->dp_off = 0;
 #ifdef BK_PHASE_STAMPS
         for (int i = 0; i < 24; i++) S->acc[i] = 0; S->ctx = 0;
         S->last = __builtin_amdgcn_s_memrealtime();

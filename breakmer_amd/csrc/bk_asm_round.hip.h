@@ -153,119 +153,191 @@ __device__ __forceinline__ int bk_retire_checked(int sl, bool grow)
     return 1;
 }
 
-// the plan of one round (thread 0): prediction chain over this visit's slots, then over the following visits' lists.  Out of
+// one step of the prediction chain on VALUES (bk_predict below is the same step on a slot in LDS): the read whose recruiting k-mer sits at pos of its rl
+// bases is aligned against the contig [pb, pb + plen) in which that k-mer sits at ppc; kind / amt = what it is predicted to do to it
+__device__ inline bool bk_predict_step(int pos, int rl, bool xrej, int maxc, int &pb, int &plen, int &ppc, int lo, int hi, int &kind, int &amt)
+{
+    amt = 0;
+    if (xrej) { kind = BK_PK_SAME; return true; }
+    const int left = pos - ppc, right = (rl - pos) - (plen - ppc);
+    if (ppc < 0 || (left > 0 && right > 0)) { kind = BK_PK_STOP; return false; }
+    if (left > 0) { kind = BK_PK_PRE; amt = left; if (pb - left < lo || plen + left > maxc) { kind = BK_PK_STOP; return false; } pb -= left; plen += left; ppc += left; }
+    else if (right > 0) { kind = BK_PK_POST; amt = right; if (pb + plen + right > hi || plen + right > maxc) { kind = BK_PK_STOP; return false; } plen += right; }
+    else kind = BK_PK_SAME;
+    return true;
+}
+
+// the plan of one round (the FIRST WAVEFRONT): prediction chain over this visit's slots, then over the following visits' lists.  Out of
 // line: its loops over slots and lists would otherwise sit in the register budget of the state machine's hot loop.
+// Until round 6 thread 0 ran it alone, word by word in LDS: every slot it wrote made the compiler re-read the region's state (the writes may
+// alias it), every list entry cost a dependent LDS round trip per slot already planned -- 5.2 us per round of the headline's 20 rounds per
+// region, 11 % of the assembler (profiles/r06/headline_plan_phases.txt).  Now slot s of the round lives in LANE s (read, k-mer position,
+// length), entry i of a look-ahead list in lane i: the chain itself stays serial, but on registers (v_readlane of the lane whose turn it
+// is, the contig geometry in scalars), "is this read already in a slot" is one compare per slot for the whole list at once, and every
+// lane writes the slot it ended up with.  The plan only decides what a round SPECULATES on; what it retires is checked against the contig
+// as it is then (bk_retire_checked), so the results cannot depend on it.
+#define BK_SWEEP_RETRY 16
 BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int la_on)
 {
     BkAsmShared *S = S_;
-    if (BK_TID != 0) return;
-    int pb = S->cbase, plen = S->clen, ppc = S->pc, nb = 0;
+    if (BK_TID >= 64) return;
+    const int lane = BK_TID;
+#define BK_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+    const int cbase = BK_UNI(S->cbase), maxc = BK_UNI(C_.MAXC), flags = BK_UNI(C_.flags);
+    const bool xrej = BK_UNI(bk_expect_reject()) != 0;
+    int pb = cbase, plen = BK_UNI(S->clen), ppc = BK_UNI(S->pc), nb = 0, mx = 0;
     bool go = true;
     // does this round run the score sweep first (bk_nw.hip.h)?  Decided before the slots are planned: it sets how many slots a round over a
     // LONG contig may have (below)
-    if (S->dp_n >= 64) { S->dp_tot += S->dp_n - (S->dp_n >> 1); S->dp_rtot += S->dp_redo - (S->dp_redo >> 1); S->dp_n >>= 1; S->dp_redo >>= 1; }
-    S->fast = !(C_.flags & BK_F_NO_SCORE_SWEEP) && (4 * S->dp_redo <= S->dp_n + 8 || (C_.flags & BK_F_FORCE_REDO));      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays; the diagnostic that flags every read keeps it on)
+    int dp_n = BK_UNI(S->dp_n), dp_redo = BK_UNI(S->dp_redo);
+    if (dp_n >= 64) {
+        if (lane == 0) { S->dp_tot += dp_n - (dp_n >> 1); S->dp_rtot += dp_redo - (dp_redo >> 1); S->dp_n = dp_n >> 1; S->dp_redo = dp_redo >> 1; }
+        dp_n >>= 1; dp_redo >>= 1;
+    }
+    // Off is not for good (round 6): while the sweep is off nothing feeds its window, so until now one bad stretch -- the reads of an indel
+    // against the first contigs of a region -- switched it off for the rest of the region (a noisy region with 27,000 reads swept 1,650 of
+    // them and ran full DPs, four times the instructions per cell, for the rest: profiles/r06/noisy_sweep_retry.txt).  After BK_SWEEP_RETRY
+    // rounds without it the window goes to the totals and starts afresh; a stretch that still needs the full DPs switches it off again
+    // within three to nine reads.
+    if (4 * dp_redo > dp_n + 8) {
+        int off = BK_UNI(S->dp_off) + 1;
+        if (off >= BK_SWEEP_RETRY) {
+            if (lane == 0) { S->dp_tot += dp_n; S->dp_rtot += dp_redo; S->dp_n = 0; S->dp_redo = 0; }
+            dp_n = 0; dp_redo = 0; off = 0;
+        }
+        if (lane == 0) S->dp_off = off;
+    }
+    const bool fast = !(flags & BK_F_NO_SCORE_SWEEP) && (4 * dp_redo <= dp_n + 8 || (flags & BK_F_FORCE_REDO));      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays; the diagnostic that flags every read keeps it on)
     // Slots of a round whose (predicted) contig is longer than the dual / pair kernels take (BK_NW_DUAL_COLS).  The full overlap DPs of
     // such a contig need TWO wavefronts per read (bk_nw_suffix + bk_nw_wave): half as many slots as wavefronts.  The score sweep
     // (bk_nw_score_long: column tiles, any length) needs ONE -- until round 5 the second wavefront of each slot idled through it, so a
     // round over a 650-column contig aligned 2 reads on the 4 wavefronts of the throughput build (configs[4]: 19,300 rounds of 2.5 reads
     // per region, the chain that bounds it; configs[3]'s translocation contigs of 1,650 columns alike).  Round 6: a wavefront per slot
     // while the sweep is on; the few reads it cannot settle are swept in full afterwards, BK_SPEC_WIDE at a time (bk_dp_redo).
-    const int widecap = S->fast ? BK_WAVES : BK_SPEC_WIDE;
+    const int widecap = fast ? BK_WAVES : BK_SPEC_WIDE;
+    // this visit's slots (staged by bk_run_candidates): lane s holds slot s
+    int my_u = -1, my_pos = 0, my_rl = 0;
+    if (lane < nbmax) { my_u = S->slot[lane].u; my_pos = S->slot[lane].pos; my_rl = S->slot[lane].rl; }
+    int t_pb = 0, t_plen = 0, t_kind = 0, t_amt = 0;
     // both DPs of a slot run on one wavefront while the (predicted) contig fits its columns; else a wavefront (score sweep) or two per slot
     for (int sl = 0; sl < nbmax && go; sl++) {
         if (sl >= widecap && plen > BK_NW_DUAL_COLS) { go = false; break; }
         nb = sl + 1;
-        go = bk_predict(S->slot[sl], pb, plen, ppc, 0, 2 * C_.MAXC);
+        const int pos = __builtin_amdgcn_readlane(my_pos, sl), rl = __builtin_amdgcn_readlane(my_rl, sl), pb0 = pb, plen0 = plen;
+        int kind, amt;
+        go = bk_predict_step(pos, rl, xrej, maxc, pb, plen, ppc, 0, 2 * maxc, kind, amt);
+        if (lane == sl) { t_pb = pb0; t_plen = plen0; t_kind = kind; t_amt = amt; }
+        mx = max(mx, plen0);
     }
-    const int ncur = nb;
+    if (lane < nb) { BkAsmShared::Slot &t = S->slot[lane]; t.pb = t_pb; t.plen = t_plen; t.kind = t_kind; t.amt = t_amt; }
+    const int ncur = nb, mxcur = mx;
     int upto = vt;
 #ifdef BK_PHASE_STAMPS
-    if (la_on) S->acc[19] += 1ull;                                               // rounds with free slots
-    if (la_on && !(la && go && q + ncur == n)) S->acc[19] += 1ull << 16;          // ... not looked ahead (paused / STOP / round does not finish the visit)
-    else if (la_on && S->la_n[0] < 0) S->acc[19] += 1ull << 32;                  // ... next visit: none in the window or posting list too long
-    else if (la_on && S->la_n[0] == 0) S->acc[19] += 1ull << 48;                 // ... next visit has no eligible read
+    if (lane == 0) {
+        if (la_on) S->acc[19] += 1ull;                                               // rounds with free slots
+        if (la_on && !(la && go && q + ncur == n)) S->acc[19] += 1ull << 16;          // ... not looked ahead (paused / STOP / round does not finish the visit)
+        else if (la_on && S->la_n[0] < 0) S->acc[19] += 1ull << 32;                  // ... next visit: none in the window or posting list too long
+        else if (la_on && S->la_n[0] == 0) S->acc[19] += 1ull << 48;                 // ... next visit has no eligible read
+    }
 #endif
     if (la && vt >= 0 && go && q + ncur == n) {
         for (int w = 0; w < BK_AT / 64 && go; w++) {
-            const int cn = S->la_n[w];
+            const int cn = BK_UNI(S->la_n[w]);
             if (cn < 0) break;
-            // the visit's list once the reads planned before it are in the buffer
-            int keep = 0;
-            for (int i = 0; i < cn; i++) {
-                const int u = (int)(BK_LA_CU(w)[i] & 0x3FFFFFu); bool inflight = false;
-                for (int s2 = 0; s2 < nb; s2++) inflight = inflight || S->slot[s2].u == u;
-                keep += !inflight;
-                if (nb + keep > cap) break;                         // does not fit: no need to look at the rest of the list
-            }
-            if (nb + keep > cap) break;
-            const int pc2 = S->la_pc[w];
-            if (keep > 0 && pc2 < 0 && !bk_expect_reject()) break;
-            ppc = pc2 + (S->cbase - pb);                    // the predicted contig starts cbase - pb bases before the current one
-            const int nb0 = nb;
-            for (int i = 0; i < cn && go; i++) {
-                const uint32_t cu = BK_LA_CU(w)[i]; const int u = (int)(cu & 0x3FFFFFu); bool inflight = false;
-                for (int s2 = 0; s2 < nb0; s2++) inflight = inflight || S->slot[s2].u == u;
-                if (inflight) continue;
+            // the visit's list once the reads planned before it are in the buffer: entry i in lane i
+            const uint32_t e_cu = lane < cn ? BK_LA_CU(w)[lane] : 0u;
+            const int e_u = (int)(e_cu & 0x3FFFFFu), e_pos = (int)(e_cu >> 22);
+            bool inflight = false;
+            for (int s2 = 0; s2 < nb; s2++) inflight = inflight || __builtin_amdgcn_readlane(my_u, s2) == e_u;
+            const unsigned long long km = __ballot(lane < cn && !inflight);
+            const int keep = __popcll(km);
+            if (nb + keep > cap) break;                             // does not fit
+            const int pc2 = BK_UNI(S->la_pc[w]);
+            if (keep > 0 && pc2 < 0 && !xrej) break;
+            ppc = pc2 + (cbase - pb);                       // the predicted contig starts cbase - pb bases before the current one
+            const int nb0 = nb, mx0 = mx, lt = BK_UNI(S->la_t[w]), lrank = BK_UNI(S->la_rank[w]);
+            int e_rl = 0, e_rn = 0, e_fl = 0;
+            if (lane < cn) { e_rl = BK_LA_RL(w)[lane]; e_rn = BK_LA_RN(w)[lane]; e_fl = BK_LA_FL(w)[lane]; }
+            int e_slot = -1;
+            unsigned long long rest = km;
+            while (rest && go) {
+                const int i = (int)__builtin_ctzll(rest);
+                rest &= rest - 1ull;
                 if (nb >= widecap && plen > BK_NW_DUAL_COLS) { go = false; break; }
-                BkAsmShared::Slot &t = S->slot[nb];
-                const int fl = BK_LA_FL(w)[i];
-                t.u = u; t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
-                t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
-                t.vt = S->la_t[w]; t.rank = S->la_rank[w]; t.fu = -1; t.first = 0;
+                const int pos = __builtin_amdgcn_readlane(e_pos, i), rl = __builtin_amdgcn_readlane(e_rl, i), u = __builtin_amdgcn_readlane(e_u, i), pb0 = pb, plen0 = plen;
+                int kind, amt;
+                go = bk_predict_step(pos, rl, xrej, maxc, pb, plen, ppc, 0, 2 * maxc, kind, amt);
+                if (lane == i) { e_slot = nb; t_pb = pb0; t_plen = plen0; t_kind = kind; t_amt = amt; }
+                if (lane == nb) my_u = u;
+                mx = max(mx, plen0);
                 nb++;
-                go = bk_predict(t, pb, plen, ppc, 0, 2 * C_.MAXC);
             }
-            if (nb - nb0 != keep) { nb = nb0; break; }      // a visit is planned whole or not at all
-            upto = S->la_t[w];
+            if (nb - nb0 != keep) { nb = nb0; mx = mx0; break; }      // a visit is planned whole or not at all
+            if (e_slot >= 0) {
+                BkAsmShared::Slot &t = S->slot[e_slot];
+                t.u = e_u; t.pos = e_pos; t.rl = e_rl; t.rn = e_rn; t.rindel = (e_fl & BK_R_INDEL) ? 1 : 0;
+                t.hasn = (C_.n_nlist && (e_fl & BK_R_HASN)) ? 1 : 0;
+                t.vt = lt; t.rank = lrank; t.fu = -1; t.first = 0;
+                t.pb = t_pb; t.plen = t_plen; t.kind = t_kind; t.amt = t_amt;
+            }
+            upto = lt;
         }
     }
     int kind = 0;
     if (la && vt < 0 && q + ncur == n) {
         // the first round of the seeds that follow: a group per seed, aligned against its founder in a strip of its own
+        // (lane 0, slot by slot in LDS as before: no "already in a slot" test here, and a seed's list is two or three reads)
         kind = 1;
-        int g = 0;
-        for (int w = 0; w < BK_AT / 64; w++) {
-            const int cn = S->la_n[w];
-            if (cn < 0) break;
-            if (cn < 2) continue;                                   // a seed with its founder only has no DP
-            if (nb + cn - 1 > cap) break;
-            const uint32_t fcu = BK_LA_CU(w)[0];
-            const int base = BK_SEEDBUF(g) + C_.MAXR + 16, lo = BK_SEEDBUF(g), hi = BK_SEEDBUF(g) + 3 * (C_.MAXR + 16);
-            int pb2 = base, plen2 = BK_LA_RL(w)[0], ppc2 = (int)(fcu >> 22);          // the contig IS the founder; the k-mer sits where it sits in that read
-            const int nb0 = nb; bool whole = true;
-            for (int i = 1; i < cn; i++) {
-                const uint32_t cu = BK_LA_CU(w)[i];
-                if (nb >= widecap && plen2 > BK_NW_DUAL_COLS) { whole = false; break; }
-                BkAsmShared::Slot &t = S->slot[nb];
-                const int fl = BK_LA_FL(w)[i];
-                t.u = (int)(cu & 0x3FFFFFu); t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
-                t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
-                t.vt = S->la_t[w]; t.rank = S->la_rank[w]; t.fu = (int)(fcu & 0x3FFFFFu); t.first = (i == 1) ? 1 : 0;
-                nb++;
-                if (!bk_predict(t, pb2, plen2, ppc2, lo, hi) && i + 1 < cn) { whole = false; break; }
+        int nbc = nb, mxc = mx;
+        if (lane == 0) {
+            int g = 0;
+            for (int w = 0; w < BK_AT / 64; w++) {
+                const int cn = S->la_n[w];
+                if (cn < 0) break;
+                if (cn < 2) continue;                                   // a seed with its founder only has no DP
+                if (nbc + cn - 1 > cap) break;
+                const uint32_t fcu = BK_LA_CU(w)[0];
+                const int base = BK_SEEDBUF(g) + C_.MAXR + 16, lo = BK_SEEDBUF(g), hi = BK_SEEDBUF(g) + 3 * (C_.MAXR + 16);
+                int pb2 = base, plen2 = BK_LA_RL(w)[0], ppc2 = (int)(fcu >> 22);          // the contig IS the founder; the k-mer sits where it sits in that read
+                const int nb0 = nbc, mx0 = mxc; bool whole = true;
+                for (int i = 1; i < cn; i++) {
+                    const uint32_t cu = BK_LA_CU(w)[i];
+                    if (nbc >= widecap && plen2 > BK_NW_DUAL_COLS) { whole = false; break; }
+                    BkAsmShared::Slot &t = S->slot[nbc];
+                    const int fl = BK_LA_FL(w)[i];
+                    t.u = (int)(cu & 0x3FFFFFu); t.pos = (int)(cu >> 22); t.rl = BK_LA_RL(w)[i]; t.rn = BK_LA_RN(w)[i]; t.rindel = (fl & BK_R_INDEL) ? 1 : 0;
+                    t.hasn = (C_.n_nlist && (fl & BK_R_HASN)) ? 1 : 0;
+                    t.vt = S->la_t[w]; t.rank = S->la_rank[w]; t.fu = (int)(fcu & 0x3FFFFFu); t.first = (i == 1) ? 1 : 0;
+                    nbc++;
+                    mxc = max(mxc, plen2);
+                    if (!bk_predict(t, pb2, plen2, ppc2, lo, hi) && i + 1 < cn) { whole = false; break; }
+                }
+                if (!whole) { nbc = nb0; mxc = mx0; continue; }             // a seed is planned whole or not at all
+                g++;
             }
-            if (!whole) { nb = nb0; continue; }                     // a seed is planned whole or not at all
-            g++;
         }
+        nb = BK_UNI(nbc); mx = BK_UNI(mxc);
     }
-    int mx = 0;
-    for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen);
-    if (kind == 1 && mx > BK_NW_TILE_COLS) { nb = ncur; mx = 0; for (int sl = 0; sl < nb; sl++) mx = max(mx, S->slot[sl].plen); }      // a multi-tile DP would use the scratch the strips sit in
+    if (kind == 1 && mx > BK_NW_TILE_COLS) { nb = ncur; mx = mxcur; }      // a multi-tile DP would use the scratch the strips sit in
     // both DPs of a slot on one wavefront when more than BK_SPEC_WIDE reads are in the round; with fewer, the idle
     // wavefronts take the second DP (two 64-lane sweeps finish sooner than one half-wave pair)
-    S->dual = mx <= BK_NW_DUAL_COLS && !(C_.flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (C_.flags & BK_F_DUAL_ALWAYS));
+    const bool dual = mx <= BK_NW_DUAL_COLS && !(flags & BK_F_NO_DUAL) && (nb > BK_SPEC_WIDE || (flags & BK_F_DUAL_ALWAYS));
     int nc = ncur;
-    if (!S->dual && nb > widecap) { nc = min(nc, widecap); nb = nc; upto = vt; }      // a wavefront (score sweep) or two (full DPs) per slot: this visit's reads only
-    S->nb = nb; S->ncur = nc;
-    S->plan_r = nc; S->plan_upto = upto; S->plan_ok = (nb > nc || upto > vt) ? 1 : 0; S->plan_kind = kind;
-    S->la_planned += nb - nc;
-    if (la_on && S->la_pause > 0) S->la_pause--;
-    if (S->la_planned >= 64) {                      // one window: did the slots planned for later visits get used?
-        if (4 * S->la_adopted < S->la_planned) { S->la_pause = S->la_backoff; S->la_backoff = min(2 * S->la_backoff, 4096); }
-        else S->la_backoff = 32;
-        S->la_planned = 0; S->la_adopted = 0;
+    if (!dual && nb > widecap) { nc = min(nc, widecap); nb = nc; upto = vt; }      // a wavefront (score sweep) or two (full DPs) per slot: this visit's reads only
+    if (lane == 0) {
+        S->fast = fast ? 1 : 0; S->dual = dual ? 1 : 0;
+        S->nb = nb; S->ncur = nc;
+        S->plan_r = nc; S->plan_upto = upto; S->plan_ok = (nb > nc || upto > vt) ? 1 : 0; S->plan_kind = kind;
+        int planned = S->la_planned + nb - nc, pause = S->la_pause;
+        if (la_on && pause > 0) pause--;
+        if (planned >= 64) {                        // one window: did the slots planned for later visits get used?
+            if (4 * S->la_adopted < planned) { pause = S->la_backoff; S->la_backoff = min(2 * S->la_backoff, 4096); }
+            else S->la_backoff = 32;
+            planned = 0; S->la_adopted = 0;
+        }
+        S->la_planned = planned; S->la_pause = pause;
     }
+#undef BK_UNI
 }
 
 // vt / T: index of this visit in the snapshot and the snapshot's length (grow); vt < 0: setup_contigs

@@ -16,5 +16,6 @@ tot = sum(acc[:16])
 for n, v in zip(names, acc):
     print("%-38s %10.1f us  %5.1f %%" % (n, v, 100 * v / tot))
 print("rounds %d slots %d retired %d" % (acc[18] * 100, acc[16] * 100, acc[17] * 100))
+print("score sweeps (reads) %d, of these swept again in full %d" % (eng.stat(30), eng.stat(31)))
 d = eng.stat(119)
 print("rounds with free slots %d; of these: not looked ahead %d, next visit unusable %d, next visit empty %d" % (d & 0xFFFF, (d >> 16) & 0xFFFF, (d >> 32) & 0xFFFF, (d >> 48) & 0xFFFF))
