@@ -92,6 +92,13 @@ __device__ __noinline__ void bk_dp_redo(int skip)
         else { BkNwResult r = bk_nw_wave<true>(cs, cl, L_RSEQ_S(sl), rl, L_BOUND_W(wv)); if ((BK_TID & 63) == 0) S->slot[sl].v2 = r; }
     }
 }
+// The score sweep (bk_nw.hip.h: 3 instructions per cell) runs first while at most HALF of the reads of its window had to be swept again in full (12 per
+// cell): a pair of reads is swept again when either is flagged, so at a read rate p the cost is 3 + 12 (1 - (1 - p)^2) against 12 -- it pays up
+// to p = 0.5; a wide round (a wavefront per slot, then passes of BK_SPEC_WIDE flagged slots on two wavefronts each) breaks even there too.
+// (a quarter until round 6, from the days of the 6-instruction cell.)  redo / n: S->dp_redo / S->dp_n, the window that is halved at 64.
+#ifndef BK_SWEEP_OFF
+#define BK_SWEEP_OFF(redo, n) (2 * (redo) > (n) + 8)
+#endif
 // noisy reads: check_align has lately rejected three reads out of four (prediction then is "nothing changes", bk_predict)
 __device__ inline bool bk_expect_reject() { return S_->n_rej >= 24 && S_->n_rej >= 3 * S_->n_acc; }
 

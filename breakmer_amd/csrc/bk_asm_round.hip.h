@@ -176,7 +176,7 @@ __device__ inline bool bk_predict_step(int pos, int rl, bool xrej, int maxc, int
 // is, the contig geometry in scalars), "is this read already in a slot" is one compare per slot for the whole list at once, and every
 // lane writes the slot it ended up with.  The plan only decides what a round SPECULATES on; what it retires is checked against the contig
 // as it is then (bk_retire_checked), so the results cannot depend on it.
-#define BK_SWEEP_RETRY 16
+#define BK_SWEEP_RETRY 8
 BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int la_on)
 {
     BkAsmShared *S = S_;
@@ -198,8 +198,8 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
     // against the first contigs of a region -- switched it off for the rest of the region (a noisy region with 27,000 reads swept 1,650 of
     // them and ran full DPs, four times the instructions per cell, for the rest: profiles/r06/noisy_sweep_retry.txt).  After BK_SWEEP_RETRY
     // rounds without it the window goes to the totals and starts afresh; a stretch that still needs the full DPs switches it off again
-    // within three to nine reads.
-    if (4 * dp_redo > dp_n + 8) {
+    // within five to seventeen reads.
+    if (BK_SWEEP_OFF(dp_redo, dp_n)) {
         int off = BK_UNI(S->dp_off) + 1;
         if (off >= BK_SWEEP_RETRY) {
             if (lane == 0) { S->dp_tot += dp_n; S->dp_rtot += dp_redo; S->dp_n = 0; S->dp_redo = 0; }
@@ -207,7 +207,7 @@ BK_COLD void bk_plan_round(int q, int n, int nbmax, int cap, int vt, int la, int
         }
         if (lane == 0) S->dp_off = off;
     }
-    const bool fast = !(flags & BK_F_NO_SCORE_SWEEP) && (4 * dp_redo <= dp_n + 8 || (flags & BK_F_FORCE_REDO));      // (a quarter of the reads swept twice: the score sweep costs half a full one, so it still pays; the diagnostic that flags every read keeps it on)
+    const bool fast = !(flags & BK_F_NO_SCORE_SWEEP) && (!BK_SWEEP_OFF(dp_redo, dp_n) || (flags & BK_F_FORCE_REDO));      // (the diagnostic that flags every read keeps it on)
     // Slots of a round whose (predicted) contig is longer than the dual / pair kernels take (BK_NW_DUAL_COLS).  The full overlap DPs of
     // such a contig need TWO wavefronts per read (bk_nw_suffix + bk_nw_wave): half as many slots as wavefronts.  The score sweep
     // (bk_nw_score_long: column tiles, any length) needs ONE -- until round 5 the second wavefront of each slot idled through it, so a
@@ -392,7 +392,7 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         // slots of a round: one per wavefront while both DPs of a slot fit one wavefront (contig <= BK_NW_DUAL_COLS), else half
         // (a long contig: a slot per wavefront while the score sweep is on, bk_plan_round -- the same predicate on the same words, which
         //  nobody writes between the last barrier and the plan; the plan's own verdict is what the round runs with)
-        const bool sweep_on = !(C_.flags & BK_F_NO_SCORE_SWEEP) && (4 * S->dp_redo <= S->dp_n + 8 || (C_.flags & BK_F_FORCE_REDO));
+        const bool sweep_on = !(C_.flags & BK_F_NO_SCORE_SWEEP) && (!BK_SWEEP_OFF(S->dp_redo, S->dp_n) || (C_.flags & BK_F_FORCE_REDO));
         const int cap = (C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : S->clen > BK_NW_DUAL_COLS ? (sweep_on ? BK_WAVES : BK_SPEC_WIDE) : BK_SPEC;
         const int nbmax = min((C_.flags & (BK_F_NO_DUAL | BK_F_SPEC4)) ? BK_SPEC_WIDE : BK_SPEC, n - q);
         // look into the following visits when this one leaves slots free (needs the scratch for BK_AT/64 lists of 64 reads)

@@ -24,3 +24,4 @@ for n, v in zip(names, acc):
 print("rounds %d slots %d retired %d" % (acc[18] * 100, acc[16] * 100, acc[17] * 100))
 d = eng.stat(119)
 print("rounds with free slots %d; of these: not looked ahead %d, next visit unusable %d, next visit empty %d" % (d & 0xFFFF, (d >> 16) & 0xFFFF, (d >> 32) & 0xFFFF, (d >> 48) & 0xFFFF))
+print("score sweeps (reads) %d, of these swept again in full %d" % (eng.stat(30), eng.stat(31)))
