@@ -414,8 +414,20 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
         if (la) { if (vt >= 0) bk_lookahead_wave(wv, vt, T); else bk_seedahead_wave(wv, rank); }
         BK_SYNC();
         bk_plan_round(q, n, nbmax, cap, vt, la ? 1 : 0, la_on ? 1 : 0);
+        // The reads of THIS visit's slots do not depend on the plan (staged above: slot s = candidate q + s): while the first wavefront plans, the
+        // others unpack them -- their global round trips used to start after the plan's barrier (round 6).  What the plan adds (slots of later
+        // visits / seeds, the bytes a slot is predicted to add to the contig) follows below as before.
+        if (BK_WAVES > 1 && wv > 0) {
+            const int ln = BK_TID & 63;
+            for (int sl = wv - 1; sl < nbmax; sl += BK_WAVES - 1) {
+                const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
+                const uint32_t *w = C_.reads + (uint64_t)C_.urep[S->slot[sl].u] * C_.read_words;
+                for (int t = ln; t < rl; t += 64) rs[t] = (uint8_t)seq_base(w, t);
+            }
+        }
         BK_SYNC();
         const int nb = S->nb, ncur = S->ncur;
+        const int nstaged = BK_WAVES > 1 ? min(nbmax, ncur) : 0;      // slots [0, nstaged) are unpacked already (slots from ncur on hold other reads)
 #ifdef BK_PHASE_STAMPS
         if (BK_TID == 0) { S->acc[16] += nb; S->acc[18] += 1; }
 #endif
@@ -424,6 +436,15 @@ __device__ __forceinline__ void bk_run_candidates(int rank, int first, int n, bo
             const int ln = BK_TID & 63;
             for (int sl = BK_TID >> 6; sl < nb; sl += BK_WAVES) {
                 const int rl = S->slot[sl].rl; uint8_t *rs = L_RSEQ_S(sl);
+                const bool staged = sl < nstaged;
+                if (staged) {                           // its bytes are in LDS (written before the barrier): the predicted contig bytes come from there
+                    if (sl + 1 < nb) {
+                        const int amt = S->slot[sl].amt, pb = S->slot[sl].pb, plen = S->slot[sl].plen;
+                        if (S->slot[sl].kind == BK_PK_PRE) for (int t = ln; t < amt; t += 64) L_CSEQ[pb - amt + t] = rs[t];
+                        else if (S->slot[sl].kind == BK_PK_POST) for (int t = ln; t < amt; t += 64) L_CSEQ[pb + plen + t] = rs[rl - amt + t];
+                    }
+                    continue;
+                }
                 const uint32_t *w = C_.reads + (uint64_t)C_.urep[S->slot[sl].u] * C_.read_words;
                 for (int t = ln; t < rl; t += 64) rs[t] = (uint8_t)seq_base(w, t);
                 if (S->slot[sl].first) {                 // founder of a seed planned ahead: the contig its reads are aligned against
