@@ -407,6 +407,24 @@ def test_redo_passes_of_long_contig_rounds_gpu():
     assert out.count("ok    ") == 4
 
 
+def test_score_sweep_comes_back_on_gpu(hb):
+    """Round 6: the score sweep switches itself off while more than half of the reads of its window have to be swept again in full -- and, until
+    this round, stayed off for the rest of the region, because nothing fed the window any more.  Region 50215 (0.5 % noise; the one whose serial
+    prefix bounds the 256-region noisy batch) hit such a stretch among its first reads and then ran 26,000 of its 27,400 slots through the full
+    DPs.  Now the window starts afresh after BK_SWEEP_RETRY rounds: nearly every read goes through the sweep, and the contigs are the oracle's."""
+    from oracle import bk_oracle as bo
+    r = synth.make_region(50215, sv_type="del", depth=500, W=3000, L=150, noise=0.005)
+    for wg in (512, 256):
+        eng = _run_regions(hb, [r], 31, stages=3, flags=128, wg_threads=wg)
+        assert eng.sync() == 0
+        reads_aligned, swept, again = eng.stat(1) // 2, eng.stat(30), eng.stat(31)
+        assert swept >= 0.9 * reads_aligned and again <= 0.1 * swept, (wg, reads_aligned, swept, again)
+        if wg == 512:
+            want, _ = bo.assemble_region(synth.BASES[r.reads], [r.window_str], 31, 2, find_index=True)
+            assert _strip(eng.contigs(0)) == want and len(want) > 1000
+        eng.close()
+
+
 def test_batches_that_faulted_in_round_4_gpu():
     """The shape that faulted or hung until the barrier fixes (profiles/r04/split_fault/README.md; no test had it): several workgroups
     of small NOISY regions per CU.  720 and 1,024 regions at 1 % noise, four runs each on both workgroup sizes: every run gives the
