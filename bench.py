@@ -46,7 +46,7 @@ def parse(argv=None):
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--cpu-sample", type=int, default=24, help="regions timed through the CPU oracle on ONE core (0 = skip the CPU baseline)")
-    ap.add_argument("--inflight", type=int, default=12, help="steps in flight (independent batches on separate HIP streams; 6 until round 6: with the shorter assembler the rate keeps rising to 12, profiles/r06/inflight_depth.txt)")
+    ap.add_argument("--inflight", type=int, default=0, help="steps in flight (independent batches on separate HIP streams); 0 = 12 for runs of 60 steps or more, 8 for shorter ones (a 20-step window cannot fill and drain a 12-deep pipeline: profiles/r06/inflight_depth.txt; 6 until round 6)")
     ap.add_argument("--max-candidates", type=int, default=0, help="diagnostic: device cap on one k-mer's candidate reads (0 = library default 2048); sizes the assembler's LDS and so its workgroups per CU")
     ap.add_argument("--max-contig", type=int, default=0, help="diagnostic: device cap on the contig length (0 = library default 4096); sizes the assembler's and the realigner's LDS")
     ap.add_argument("--wg", type=int, default=256, help="assembler workgroup size of the batches in flight (256: 4 per CU; 512: 2 per CU); the one-step-at-a-time pass always uses 512")
@@ -449,6 +449,8 @@ def main():
     ins = [hb.RegionInput(r.reads, r.window, read_lens=r.read_lens) for r in regions]
     engs = []
     submit_ms = []
+    if a.inflight <= 0:
+        a.inflight = 12 if a.steps >= 60 else 8
     for _ in range(max(1, a.inflight)):                # one handle (= one HIP stream + its own buffers) per step in flight
         e = hb.Engine(kmer_size=a.kmer, rc_thresh=2, device=local, flags=a.flags, wg_threads=a.wg, max_candidates=a.max_candidates, max_contig_len=a.max_contig)
         t0 = time.perf_counter()
